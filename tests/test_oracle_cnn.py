@@ -1,0 +1,82 @@
+"""InceptionV3 oracle vs the pins the reference's own tests hold (shapes, end-point
+names, parameter count) and vs an independent torch-CPU formulation.  CPU only."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import cnn_ref
+
+
+def test_param_count_and_conv_count():
+    log, macs, params = cnn_ref.describe(224)
+    assert len(log) == 94
+    # inception_v3_test.py:125-133 -> 21 802 784 model variables in inception_v3_base
+    assert sum(v.size for v in params.values()) == 21802784
+    # 2 836 MMAC @224, 5 711 MMAC @299
+    assert round(macs / 1e6) == 2836
+    assert round(cnn_ref.describe(299)[1] / 1e6) == 5711
+    # no BN gamma by default (inception_v3_test.py:321-328)
+    assert not any('gamma' in k for k in params)
+
+
+def test_endpoint_shapes_299():
+    """inception_v3_test.py:93-123 (batch 1 here)."""
+    net = cnn_ref._Net(None, np.random.default_rng(0), run=False)
+    pooled, ep = cnn_ref._run(net, np.zeros((1, 299, 299, 3), np.float32))
+    expected = {'Conv2d_1a_3x3': (149, 149, 32), 'Conv2d_2a_3x3': (147, 147, 32),
+                'Conv2d_2b_3x3': (147, 147, 64), 'MaxPool_3a_3x3': (73, 73, 64),
+                'Conv2d_3b_1x1': (73, 73, 80), 'Conv2d_4a_3x3': (71, 71, 192),
+                'MaxPool_5a_3x3': (35, 35, 192), 'Mixed_5b': (35, 35, 256),
+                'Mixed_5c': (35, 35, 288), 'Mixed_5d': (35, 35, 288), 'Mixed_6a': (17, 17, 768),
+                'Mixed_6b': (17, 17, 768), 'Mixed_6c': (17, 17, 768), 'Mixed_6d': (17, 17, 768),
+                'Mixed_6e': (17, 17, 768), 'Mixed_7a': (8, 8, 1280), 'Mixed_7b': (8, 8, 2048),
+                'Mixed_7c': (8, 8, 2048)}
+    for k, s in expected.items():
+        assert ep[k].shape[1:] == s, k
+    assert list(ep.keys())[:18] == list(expected.keys())          # inception_v3_test.py:75-91
+    assert pooled.shape == (1, 1, 1, 2048)                        # inception_v3_test.py:46-56
+
+
+def test_primitives_vs_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 13, 11, 8)).astype(np.float32)
+    xt = torch.tensor(x).permute(0, 3, 1, 2)
+    for (kh, kw), s, pad in [((3, 3), 2, 'VALID'), ((3, 3), 1, 'SAME'), ((1, 7), 1, 'SAME'),
+                             ((7, 1), 1, 'SAME'), ((5, 5), 1, 'SAME'), ((1, 1), 1, 'SAME'),
+                             ((7, 7), 2, 'SAME')]:
+        w = rng.standard_normal((kh, kw, 8, 6)).astype(np.float32)
+        y = cnn_ref.conv2d(x, w, s, pad)
+        wt = torch.tensor(w).permute(3, 2, 0, 1)
+        if pad == 'SAME':
+            _, pt, pb = cnn_ref.same_pad(13, kh, s)
+            _, pl, pr = cnn_ref.same_pad(11, kw, s)
+            xin = F.pad(xt, (pl, pr, pt, pb))
+        else:
+            xin = xt
+        yt = F.conv2d(xin, wt, stride=s).permute(0, 2, 3, 1).numpy()
+        np.testing.assert_allclose(y, yt, rtol=1e-4, atol=1e-4)
+    mp = cnn_ref.max_pool(x, 3, 2, 'VALID')
+    np.testing.assert_array_equal(mp, F.max_pool2d(xt, 3, 2).permute(0, 2, 3, 1).numpy())
+    ap = cnn_ref.avg_pool(x, 3, 1, 'SAME')
+    apt = F.avg_pool2d(xt, 3, 1, 1, count_include_pad=False).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(ap, apt, rtol=1e-5, atol=1e-6)
+    # asymmetric SAME padding of V1's 7x7 s2 conv at 224: 2 before, 3 after
+    assert cnn_ref.same_pad(224, 7, 2) == (112, 2, 3)
+
+
+def test_bf16_round():
+    x = np.array([1.0, 1.00390625, 1.005859375, -3.1415927, 0.0, 65504.0], np.float32)
+    r = cnn_ref.bf16_round(x)
+    t = torch.tensor(x).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(r, t)
+
+
+def test_forward_small_image_finite_and_deterministic():
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 139))
+    x = np.random.default_rng(1).uniform(-1, 1, (1, 139, 139, 3)).astype(np.float32)
+    im, fm = cnn_ref.encoder(params, x)
+    assert im.shape == (1, 2048) and fm.shape == (1, 9, 2048)     # 139 -> 3x3 map
+    assert np.isfinite(fm).all()
+    im2, fm2 = cnn_ref.encoder(params, x, act_dtype='bf16')
+    rel = np.abs(fm2 - fm).max() / np.abs(fm).max()
+    assert rel < 0.1
