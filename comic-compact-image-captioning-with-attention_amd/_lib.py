@@ -1,0 +1,128 @@
+"""ctypes binding of include/comic_hip.h (the drop-in boundary).
+
+Fails loudly when the HIP library is missing or a symbol is absent: the product has no
+CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libcomic_hip.so')
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
+    C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_char_p, C.c_uint64)
+
+
+class CnnOp(C.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'reserved')]
+
+
+class ConvWeight(C.Structure):
+    _fields_ = [('w', c_void_p), ('scale', c_void_p), ('shift', c_void_p)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [(n, c_int32) for n in ('B', 'M', 'D', 'H', 'Cv', 'method', 'prob', 'tied')]
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [(n, c_int32) for n in (
+        'D', 'E', 'A', 'V', 'C', 'Cg', 'H', 'M', 'Cv', 'fm_projection', 'method', 'prob', 'context_layer',
+        'init_method', 'start_id', 'end_id')] + [(n, c_float) for n in (
+            'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
+
+
+PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in PARAM_NAMES]
+
+
+P = c_void_p
+_SIGS = {
+    'comic_last_error': (c_char_p, []),
+    'comic_abi_version': (c_int, []),
+    'comic_device_count': (c_int, []),
+    'comic_pack_conv_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    'comic_fold_bn': (c_int, [P, P, P, c_float, P, P, c_int, P]),
+    'comic_cnn_forward': (c_int, [P, c_int, P, P, P, c_int, c_int, P]),
+    'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
+    'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                               c_float, P]),
+    'comic_embed_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'comic_embed_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),
+    'comic_dropout_mask': (c_int, [P, c_int64, c_float, c_uint64, c_uint64, P]),
+    'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
+    'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
+    'comic_attn_step_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_float, P, P, P, P]),
+    'comic_attn_step_bwd': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P, P]),
+    'comic_xent_fwd_bwd': (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    'comic_argmax_rows': (c_int, [P, P, c_int, c_int, P]),
+    'comic_beam_step': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'comic_gather_rows': (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    'comic_gather_tree': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'comic_adam_tf': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    'comic_colsum': (c_int, [P, P, c_int, c_int, c_float, P]),
+    'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
+    'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
+    'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),
+    'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
+                                         P, P, P, P, P, c_int64, P]),
+    'comic_decoder_greedy': (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, c_int64, P]),
+    'comic_decoder_beam': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int64, P]),
+    'comic_scorer_create': (c_void_p, [c_char_p, P, c_int64, c_double]),
+    'comic_scorer_destroy': (None, [c_void_p]),
+    'comic_scorer_score': (c_int, [c_void_p, P, c_int, P, P, P, P, c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+class ComicHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcomic_hip.so (built by __graft_entry__.build() / `make -C csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ComicHipError(
+            'HIP library not built: %s is missing (run `python -c "import __graft_entry__ as g; g.build()"`). '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ComicHipError('libcomic_hip.so does not export %s' % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.comic_abi_version() != 1:
+        raise ComicHipError('ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().comic_last_error()
+        raise ComicHipError('%s failed (rc=%d): %s' % (what or 'comic_hip call', rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

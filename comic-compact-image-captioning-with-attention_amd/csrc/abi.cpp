@@ -1,0 +1,230 @@
+// C-ABI plumbing (error reporting, version) and the host-side SCST reward scorer.
+//
+// The scorer restates, in C++ with float64 arithmetic in the reference's order of
+// operations, the pure-Python metrics that sit on the SCST training critical path:
+//   captionScorer.get_hypo_scores ... common/scst/scorers.py:43-171
+//   CiderScorer (CIDEr-D) ........... common/scst/cider_ruotianluo/pyciderevalcap/ciderD/ciderD_scorer.py:130-208
+//   BleuScorer ('closest') .......... common/coco_caption/pycocoevalcap/bleu/bleu_scorer.py:60-263
+// Hypotheses are scored independently, so they are spread over host threads.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/comic_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void comic_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* comic_last_error(void) { return g_err; }
+extern "C" int comic_abi_version(void) { return COMIC_ABI_VERSION; }
+extern "C" int comic_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------------------ scorer --
+namespace {
+
+typedef std::unordered_map<std::string, int> Counts;
+
+std::vector<std::string> split_ws(const char* s) {
+  std::vector<std::string> out;
+  const char* p = s;
+  while (*p) {
+    while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
+    if (!*p) break;
+    const char* q = p;
+    while (*q && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r' || *q == '\f' || *q == '\v')) ++q;
+    out.emplace_back(p, q - p);
+    p = q;
+  }
+  return out;
+}
+
+// n-gram counts per order; key = words joined by ' '
+void precook(const std::vector<std::string>& w, Counts cnt[4]) {
+  for (int k = 1; k <= 4; ++k) {
+    for (size_t i = 0; i + k <= w.size(); ++i) {
+      std::string key = w[i];
+      for (int j = 1; j < k; ++j) {
+        key.push_back(' ');
+        key += w[i + j];
+      }
+      ++cnt[k - 1][key];
+    }
+  }
+}
+
+struct TfIdf {
+  std::unordered_map<std::string, double> vec[4];
+  double norm[4];
+  int length;
+};
+
+}  // namespace
+
+struct comic_scorer {
+  std::unordered_map<std::string, double> df;
+  double log_ref_len;
+
+  void to_vec(const Counts cnt[4], TfIdf& t) const {
+    t.length = 0;
+    for (int k = 0; k < 4; ++k) {
+      double nrm = 0.0;
+      for (const auto& kv : cnt[k]) {
+        auto it = df.find(kv.first);
+        const double d = log(std::max(1.0, it == df.end() ? 0.0 : it->second));
+        const double v = (double)kv.second * (log_ref_len - d);
+        t.vec[k][kv.first] = v;
+        nrm += v * v;
+        if (k == 1) t.length += kv.second;  // reference quirk: "length" counts bigrams
+      }
+      t.norm[k] = sqrt(nrm);
+    }
+  }
+
+  double cider_one(const std::vector<std::string>& hyp, const std::vector<std::vector<std::string>>& refs) const {
+    Counts hc[4];
+    precook(hyp, hc);
+    TfIdf h;
+    to_vec(hc, h);
+    double score[4] = {0, 0, 0, 0};
+    for (const auto& r : refs) {
+      Counts rc[4];
+      precook(r, rc);
+      TfIdf rv;
+      to_vec(rc, rv);
+      const double delta = (double)(h.length - rv.length);
+      for (int k = 0; k < 4; ++k) {
+        double val = 0.0;
+        for (const auto& kv : h.vec[k]) {
+          auto it = rv.vec[k].find(kv.first);
+          const double rr = it == rv.vec[k].end() ? 0.0 : it->second;
+          val += std::min(kv.second, rr) * rr;
+        }
+        if (h.norm[k] != 0 && rv.norm[k] != 0) val /= (h.norm[k] * rv.norm[k]);
+        val *= pow(M_E, -(delta * delta) / (2 * 6.0 * 6.0));
+        score[k] += val;
+      }
+    }
+    double avg = (((score[0] + score[1]) + score[2]) + score[3]) / 4.0;
+    avg /= (double)refs.size();
+    avg *= 10.0;
+    return avg;
+  }
+
+  static void bleu_one(const std::vector<std::string>& hyp, const std::vector<std::vector<std::string>>& refs,
+                       double out[4]) {
+    const double small = 1e-9, tiny = 1e-15;
+    Counts maxc[4];
+    std::vector<int> reflens;
+    for (const auto& r : refs) {
+      Counts rc[4];
+      precook(r, rc);
+      reflens.push_back((int)r.size());
+      for (int k = 0; k < 4; ++k)
+        for (const auto& kv : rc[k]) {
+          int& m = maxc[k][kv.first];
+          m = std::max(m, kv.second);
+        }
+    }
+    const int testlen = (int)hyp.size();
+    // 'closest': min over (|l - testlen|, l)
+    int best_d = 1 << 30, reflen = 0;
+    for (int l : reflens) {
+      const int dd = abs(l - testlen);
+      if (dd < best_d || (dd == best_d && l < reflen)) {
+        best_d = dd;
+        reflen = l;
+      }
+    }
+    Counts hc[4];
+    precook(hyp, hc);
+    double bleu = 1.0;
+    for (int k = 0; k < 4; ++k) {
+      int correct = 0;
+      for (const auto& kv : hc[k]) {
+        auto it = maxc[k].find(kv.first);
+        correct += std::min(it == maxc[k].end() ? 0 : it->second, kv.second);
+      }
+      const int guess = std::max(0, testlen - (k + 1) + 1);
+      bleu *= ((double)correct + tiny) / ((double)guess + small);
+      out[k] = pow(bleu, 1.0 / (k + 1));
+    }
+    const double ratio = (testlen + tiny) / (reflen + small);
+    if (ratio < 1)
+      for (int k = 0; k < 4; ++k) out[k] *= exp(1 - 1 / ratio);
+  }
+};
+
+extern "C" comic_scorer* comic_scorer_create(const char* ngrams_host, const double* counts_host, int64_t n_entries,
+                                             double ref_len) {
+  if (!ngrams_host || !counts_host || ref_len <= 0) {
+    comic_set_error("scorer_create: bad arguments");
+    return nullptr;
+  }
+  comic_scorer* s = new comic_scorer();
+  s->log_ref_len = log(ref_len);
+  s->df.reserve((size_t)n_entries * 2);
+  const char* p = ngrams_host;
+  for (int64_t i = 0; i < n_entries; ++i) {
+    const size_t len = strlen(p);
+    s->df.emplace(std::string(p, len), counts_host[i]);
+    p += len + 1;
+  }
+  return s;
+}
+
+extern "C" void comic_scorer_destroy(comic_scorer* s) { delete s; }
+
+extern "C" int comic_scorer_score(const comic_scorer* s, const char* const* hypos_host, int n,
+                                  const char* const* refs_host, const int32_t* refs_per_host, double* out_cider_host,
+                                  double* out_bleu_host, int n_threads) {
+  if (!s || !hypos_host || !refs_host || !refs_per_host) {
+    comic_set_error("scorer_score: null argument");
+    return 2;
+  }
+  std::vector<int64_t> ref_off(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    if (refs_per_host[i] < 1) {
+      comic_set_error("scorer_score: hypothesis %d has no reference", i);
+      return 2;
+    }
+    ref_off[i + 1] = ref_off[i] + refs_per_host[i];
+  }
+  if (n_threads < 1) n_threads = 1;
+  n_threads = std::min(n_threads, std::max(1, n));
+  auto work = [&](int tid) {
+    for (int i = tid; i < n; i += n_threads) {
+      const std::vector<std::string> hyp = split_ws(hypos_host[i]);
+      std::vector<std::vector<std::string>> refs;
+      for (int64_t r = ref_off[i]; r < ref_off[i + 1]; ++r) refs.push_back(split_ws(refs_host[r]));
+      if (out_cider_host) out_cider_host[i] = s->cider_one(hyp, refs);
+      if (out_bleu_host) comic_scorer::bleu_one(hyp, refs, out_bleu_host + (size_t)i * 4);
+    }
+  };
+  if (n_threads == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+  }
+  return 0;
+}

@@ -1,0 +1,562 @@
+// CNN encoder kernels for gfx950: implicit-GEMM convolution on MFMA with a folded
+// BatchNorm + ReLU epilogue, the Cin=3 stem convolution, and the pooling kernels.
+//
+// Replaces the TF-1.9 op call-sites of slim.conv2d / slim.max_pool2d / slim.avg_pool2d in
+// common/nets/inception_v3.py:100-415 under inception_arg_scope
+// (common/nets/inception_utils.py:32-82): Conv2D (no bias) -> FusedBatchNorm(inference,
+// no gamma, eps 1e-3) -> Relu, NHWC.
+//
+// Implicit GEMM, "swapped" orientation so that the accumulator holds 4 consecutive output
+// channels of one pixel per lane (one 8-byte bf16 store):
+//     D[n][m] = sum_k  Wp[n][k] * im2col(X)[m][k]        n = cout, m = (b,ho,wo), k = (kh,kw,cin)
+// MFMA A-operand rows = weights, B-operand columns = pixels.  Both operands are staged in
+// LDS as [row][64 bytes of k] (+16 B row padding); a lane's fragment is one 16-byte chunk
+// (row = lane&15, chunk = lane>>4): 8 bf16 for v_mfma_f32_16x16x32_bf16, or 4 floats fed to
+// four v_mfma_f32_16x16x4_f32 (exact fp32 parity mode; both operands use the same
+// k-permutation so the sum over k is unchanged).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const void* x;
+  const void* w;
+  const float* scale;
+  const float* shift;
+  void* y;
+  int B, H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
+  int x_cs, x_co, y_cs, y_co;  // channel stride / offset of the src and dst pixel
+  int K, Kpad, M;
+  int relu, out_f32;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int EPC = 8;
+};
+
+constexpr int kRowBytes = 80;  // 64 B of k + 16 B pad (spreads ds_read_b128 over the banks)
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 4 * EPC;  // k elements per tile (64 bytes per row)
+  constexpr int A_PASSES = (BM + 63) / 64;
+  constexpr int B_PASSES = (BN + 63) / 64;
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  static_assert(WM * WN == 4, "4 waves");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * kRowBytes];
+  unsigned char* Xs = smem;                       // [2][BM][kRowBytes]
+  unsigned char* Ws = smem + 2 * BM * kRowBytes;  // [2][BN][kRowBytes]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bm0 = blockIdx.x * BM;
+  const int bn0 = blockIdx.y * BN;
+  const int cq = tid & 3;     // 16-byte chunk inside the 64-byte k row
+  const int lrow = tid >> 2;  // 0..63
+
+  const T* __restrict__ xg = (const T*)a.x;
+  const T* __restrict__ wg = (const T*)a.w;
+
+  // ---- per-thread im2col row state (one per pass) ------------------------------------
+  int xbase[A_PASSES], hi0[A_PASSES], wi0[A_PASSES];
+  bool mok[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int r = lrow + 64 * i;
+    const int m = bm0 + r;
+    mok[i] = (r < BM) && (m < a.M);
+    int mm = mok[i] ? m : 0;
+    const int wo = mm % a.Wo;
+    mm /= a.Wo;
+    const int ho = mm % a.Ho;
+    const int b = mm / a.Ho;
+    hi0[i] = ho * a.SH - a.PT;
+    wi0[i] = wo * a.SW - a.PL;
+    xbase[i] = ((b * a.H + hi0[i]) * a.W + wi0[i]) * a.x_cs + a.x_co;
+  }
+  // k state of this thread's chunk
+  int kc, kkw, kkh;
+  {
+    const int kk = cq * EPC;
+    kc = kk % a.Cin;
+    const int tap = kk / a.Cin;
+    kkw = tap % a.KW;
+    kkh = tap / a.KW;
+  }
+  // weight rows
+  const T* wrow[B_PASSES];
+  bool nok[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int r = lrow + 64 * i;
+    const int n = bn0 + r;
+    nok[i] = (r < BN) && (n < a.Cout);
+    wrow[i] = wg + (size_t)(nok[i] ? n : 0) * a.Kpad + cq * EPC;
+  }
+
+  const int nk = a.Kpad / BKE;
+  uint4 areg[A_PASSES], breg[B_PASSES];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tile = [&](int kt) {
+    const bool kvalid = kkh < a.KH;
+    const int koff = (kkh * a.W + kkw) * a.x_cs + kc;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int hi = hi0[i] + kkh, wi = wi0[i] + kkw;
+      const bool ok = mok[i] && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      areg[i] = ok ? *(const uint4*)(xg + (xbase[i] + koff)) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      breg[i] = nok[i] ? *(const uint4*)(wrow[i] + (size_t)kt * BKE) : zero4;
+    }
+    // advance k state by one tile
+    kc += BKE;
+    while (kc >= a.Cin) {
+      kc -= a.Cin;
+      if (++kkw == a.KW) {
+        kkw = 0;
+        ++kkh;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int r = lrow + 64 * i;
+      if (r < BM) *(uint4*)(Xs + (buf * BM + r) * kRowBytes + cq * 16) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int r = lrow + 64 * i;
+      if (r < BN) *(uint4*)(Ws + (buf * BN + r) * kRowBytes + cq * 16) = breg[i];
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int wbase = (wn * (BN / WN) + frow) * kRowBytes + fchunk * 16;
+  const int xbase_l = (wm * (BM / WM) + frow) * kRowBytes + fchunk * 16;
+  // n-tiles entirely beyond Cout are skipped (wave-uniform)
+  int tn_live = 0;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+    if (bn0 + wn * (BN / WN) + i * 16 < a.Cout) tn_live = i + 1;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    uint4 wf[TN], xf[TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      wf[i] = *(const uint4*)(Ws + buf * BN * kRowBytes + wbase + i * 16 * kRowBytes);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      xf[j] = *(const uint4*)(Xs + buf * BM * kRowBytes + xbase_l + j * 16 * kRowBytes);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      if (i < tn_live) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+          } else {
+            const f32x4_t wv = __builtin_bit_cast(f32x4_t, wf[i]);
+            const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], xv[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], xv[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], xv[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], xv[3], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: y = relu(acc * scale[n] + shift[n]) ----------------------------------
+  const int mcol = lane & 15, nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n0 = bn0 + wn * (BN / WN) + i * 16 + nq;
+    if (n0 >= a.Cout) continue;
+    const float4 sc = *(const float4*)(a.scale + n0);
+    const float4 sh = *(const float4*)(a.shift + n0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = bm0 + wm * (BM / WM) + j * 16 + mcol;
+      if (m >= a.M) continue;
+      float v0 = acc[i][j][0] * sc.x + sh.x;
+      float v1 = acc[i][j][1] * sc.y + sh.y;
+      float v2 = acc[i][j][2] * sc.z + sh.z;
+      float v3 = acc[i][j][3] * sc.w + sh.w;
+      if (a.relu) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        v2 = fmaxf(v2, 0.f);
+        v3 = fmaxf(v3, 0.f);
+      }
+      const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
+      if (sizeof(T) == 4 || a.out_f32) {
+        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+      } else {
+        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+  }
+}
+
+// ---- stem convolution: fp32 NHWC input with Cin <= 4 (images), direct form ------------
+// weights fp32 [K = KH*KW*Cin][Cout] staged in LDS; one output pixel per thread, 32 output
+// channels per pass.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  const float* __restrict__ wg = (const float*)a.w;
+  for (int i = threadIdx.x; i < a.K * a.Cout; i += blockDim.x) wsm[i] = wg[i];
+  __syncthreads();
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= a.M) return;
+  int mm = pix;
+  const int wo = mm % a.Wo;
+  mm /= a.Wo;
+  const int ho = mm % a.Ho;
+  const int b = mm / a.Ho;
+  const int hi0 = ho * a.SH - a.PT, wi0 = wo * a.SW - a.PL;
+  const float* __restrict__ xg = (const float*)a.x;
+  for (int co0 = 0; co0 < a.Cout; co0 += 32) {
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int kh = 0; kh < a.KH; ++kh) {
+      const int hi = hi0 + kh;
+      if ((unsigned)hi >= (unsigned)a.H) continue;
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int wi = wi0 + kw;
+        if ((unsigned)wi >= (unsigned)a.W) continue;
+        const float* xp = xg + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+          const float xv = xp[ci];
+          const float* wr = wsm + ((kh * a.KW + kw) * a.Cin + ci) * a.Cout + co0;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+        }
+      }
+    }
+    const size_t off = (size_t)pix * a.y_cs + a.y_co + co0;
+#pragma unroll
+    for (int j = 0; j < 32; j += 4) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = acc[j + q] * a.scale[co0 + j + q] + a.shift[co0 + j + q];
+        if (a.relu) v[q] = fmaxf(v[q], 0.f);
+      }
+      if (sizeof(T) == 4 || a.out_f32) {
+        *(float4*)((float*)a.y + off + j) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *(uint2*)((bf16_t*)a.y + off + j) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+  }
+}
+
+// ---- pooling ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load_vec(const T* p, float* v);
+template <>
+__device__ __forceinline__ void load_vec<float>(const float* p, float* v) {
+  const float4 t = *(const float4*)p;
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float* v) {
+  const uint4 t = *(const uint4*)p;
+  const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(u[i] << 16);
+    v[2 * i + 1] = __uint_as_float(u[i] & 0xFFFF0000u);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_vec(T* p, const float* v);
+template <>
+__device__ __forceinline__ void store_vec<float>(float* p, const float* v) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float* v) {
+  *(uint4*)p = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                          pack_bf16x2(v[6], v[7]));
+}
+
+// MODE 0: max-pool (VALID or padded with -inf)   MODE 1: avg-pool dividing by valid taps
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(ConvArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cvecs = a.Cin / EPC;
+  const long total = (long)a.M * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  int mm = (int)(idx / cvecs);
+  const int pix = mm;
+  const int wo = mm % a.Wo;
+  mm /= a.Wo;
+  const int ho = mm % a.Ho;
+  const int b = mm / a.Ho;
+  const T* __restrict__ xg = (const T*)a.x;
+  float acc[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) acc[j] = MODE == 0 ? -INFINITY : 0.f;
+  int cnt = 0;
+  for (int kh = 0; kh < a.KH; ++kh) {
+    const int hi = ho * a.SH - a.PT + kh;
+    if ((unsigned)hi >= (unsigned)a.H) continue;
+    for (int kw = 0; kw < a.KW; ++kw) {
+      const int wi = wo * a.SW - a.PL + kw;
+      if ((unsigned)wi >= (unsigned)a.W) continue;
+      float v[EPC];
+      load_vec<T>(xg + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + cv * EPC, v);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) acc[j] = MODE == 0 ? fmaxf(acc[j], v[j]) : acc[j] + v[j];
+      ++cnt;
+    }
+  }
+  if (MODE == 1) {
+    const float c = (float)cnt;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) acc[j] = acc[j] / c;
+  }
+  store_vec<T>((T*)a.y + (size_t)pix * a.y_cs + a.y_co + cv * EPC, acc);
+}
+
+// global KHxKW VALID average -> fp32 [B, Ho*Wo, C]; one thread per (pixel, channel vec)
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(ConvArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cvecs = a.Cin / EPC;
+  const long total = (long)a.M * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  int mm = (int)(idx / cvecs);
+  const int pix = mm;
+  const int wo = mm % a.Wo;
+  mm /= a.Wo;
+  const int ho = mm % a.Ho;
+  const int b = mm / a.Ho;
+  const T* __restrict__ xg = (const T*)a.x;
+  float acc[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+  for (int kh = 0; kh < a.KH; ++kh)
+    for (int kw = 0; kw < a.KW; ++kw) {
+      float v[EPC];
+      load_vec<T>(xg + ((size_t)(b * a.H + ho * a.SH + kh) * a.W + wo * a.SW + kw) * a.x_cs + a.x_co + cv * EPC, v);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) acc[j] += v[j];
+    }
+  const float inv = (float)(a.KH * a.KW);
+  float* yp = (float*)a.y + (size_t)pix * a.y_cs + a.y_co + cv * EPC;
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) yp[j] = acc[j] / inv;
+}
+
+// ---- weight packing / BN folding -----------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int K, int Kpad,
+                                         int cout) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)cout * Kpad) return;
+  const int k = (int)(idx % Kpad), n = (int)(idx / Kpad);
+  const float v = k < K ? w[(size_t)k * cout + n] : 0.f;
+  if (sizeof(T) == 4)
+    ((float*)out)[idx] = v;
+  else
+    ((bf16_t*)out)[idx] = f32_to_bf16(v);
+}
+
+__global__ void fold_bn_kernel(const float* beta, const float* mean, const float* var, float eps, float* scale,
+                               float* shift, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float s = 1.0f / sqrtf(var[i] + eps);
+  scale[i] = s;
+  shift[i] = beta[i] - mean[i] * s;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+void launch_igemm(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T>
+int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
+  // choose the largest tile that still gives >= ~2 workgroups per CU; small layers fall
+  // back to 64x64 (XCD note: grid.x = pixel tiles, so workgroups b, b+8 share an L2 and a
+  // neighbouring input window).
+  const int n64 = cdiv(a.Cout, 64);
+  const long blocks_128x128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
+  const long blocks_128x64 = (long)cdiv(a.M, 128) * n64;
+  if (a.Cout <= 32) {
+    launch_igemm<T, 128, 32, 4, 1>(a, st);
+  } else if (a.Cout % 128 == 0 && blocks_128x128 >= 512) {
+    launch_igemm<T, 128, 128, 2, 2>(a, st);
+  } else if (blocks_128x64 >= 512) {
+    launch_igemm<T, 128, 64, 2, 2>(a, st);
+  } else {
+    launch_igemm<T, 64, 64, 2, 2>(a, st);
+  }
+  return 0;
+}
+
+int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels, void* y, int y_channels,
+              const comic_conv_weight* wt, int batch) {
+  a.x = x;
+  a.y = y;
+  a.w = wt ? wt->w : nullptr;
+  a.scale = wt ? wt->scale : nullptr;
+  a.shift = wt ? wt->shift : nullptr;
+  a.B = batch;
+  a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout;
+  a.KH = op->KH; a.KW = op->KW; a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL;
+  a.Ho = op->Ho; a.Wo = op->Wo;
+  a.x_cs = x_channels; a.x_co = op->src_coff; a.y_cs = y_channels; a.y_co = op->dst_coff;
+  a.K = op->KH * op->KW * op->Cin;
+  a.Kpad = (a.K + 31) / 32 * 32;
+  a.M = batch * op->Ho * op->Wo;
+  a.relu = op->relu;
+  a.out_f32 = op->out_f32;
+  return 0;
+}
+
+template <typename T>
+int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const comic_conv_weight* wt, int batch,
+           hipStream_t st) {
+  constexpr int EPC = Elem<T>::EPC;
+  ConvArgs a;
+  fill_args(a, op, x, xc, y, yc, wt, batch);
+  COMIC_REQUIRE(x && y, "cnn op %d: null buffer", op->kind);
+  COMIC_REQUIRE((long)batch * op->H * op->W * xc < (1L << 31) && (long)a.M * yc < (1L << 31),
+                "cnn op: tensor exceeds 2^31 elements");
+  COMIC_REQUIRE(op->src_coff + op->Cin <= xc, "cnn op: source channel slice out of range");
+  switch (op->kind) {
+    case 0: {
+      COMIC_REQUIRE(wt && wt->w && wt->scale && wt->shift, "conv: missing weights");
+      COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0,
+                    "conv: Cin/offset/stride must be multiples of %d", EPC);
+      COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
+                    "conv: Cout must be a multiple of 16 (got %d)", op->Cout);
+      COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
+      dispatch_igemm<T>(a, st);
+      break;
+    }
+    case 1: {
+      COMIC_REQUIRE(wt && wt->w, "stem conv: missing weights");
+      COMIC_REQUIRE(op->Cin <= 4 && op->Cout % 32 == 0, "stem conv: needs Cin<=4, Cout%%32==0");
+      COMIC_REQUIRE(op->dst_coff % 4 == 0 && yc % 4 == 0, "stem conv: misaligned destination");
+      const size_t lds = (size_t)a.K * a.Cout * sizeof(float);
+      COMIC_REQUIRE(lds <= 64 * 1024, "stem conv: weights do not fit LDS");
+      hipLaunchKernelGGL((conv_stem_kernel<T>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a);
+      break;
+    }
+    case 2:
+    case 3: {
+      COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0 && op->dst_coff % EPC == 0 &&
+                        yc % EPC == 0,
+                    "pool: channel counts/offsets must be multiples of %d", EPC);
+      COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool: destination channel slice out of range");
+      const long total = (long)a.M * (op->Cin / EPC);
+      if (op->kind == 2)
+        hipLaunchKernelGGL((pool_kernel<T, 0>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((pool_kernel<T, 1>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      break;
+    }
+    case 4: {
+      COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0, "global pool: misaligned");
+      COMIC_REQUIRE((op->Ho - 1) * op->SH + op->KH <= op->H && (op->Wo - 1) * op->SW + op->KW <= op->W,
+                    "global pool: window exceeds input (VALID only)");
+      const long total = (long)a.M * (op->Cin / EPC);
+      hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      break;
+    }
+    default:
+      COMIC_REQUIRE(false, "unknown cnn op kind %d", op->kind);
+  }
+  COMIC_LAUNCH_CHECK("cnn op");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x_channels, void* y, int y_channels,
+                                    const comic_conv_weight* wt, int batch, int dtype, void* stream) {
+  COMIC_REQUIRE(op, "null op");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == COMIC_BF16) return run_op<bf16_t>(op, x, x_channels, y, y_channels, wt, batch, st);
+  if (dtype == COMIC_F32) return run_op<float>(op, x, x_channels, y, y_channels, wt, batch, st);
+  COMIC_REQUIRE(false, "unknown dtype %d", dtype);
+}
+
+extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,
+                                 const comic_conv_weight* weights, int batch, int dtype, void* stream) {
+  COMIC_REQUIRE(ops && buffers && buf_channels, "comic_cnn_forward: null table");
+  for (int i = 0; i < n_ops; ++i) {
+    const comic_cnn_op* op = ops + i;
+    const comic_conv_weight* wt = (op->kind <= 1) ? weights + op->weight : nullptr;
+    int rc = comic_conv2d_bn_relu(op, buffers[op->src], buf_channels[op->src], buffers[op->dst],
+                                  buf_channels[op->dst], wt, batch, dtype, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int comic_pack_conv_weights(const float* w_hwio, void* w_packed, int kh, int kw, int cin, int cout,
+                                       int dtype, void* stream) {
+  const int K = kh * kw * cin, Kpad = (K + 31) / 32 * 32;
+  const long total = (long)cout * Kpad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == COMIC_BF16)
+    hipLaunchKernelGGL((pack_conv_weights_kernel<bf16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st,
+                       w_hwio, (bf16_t*)w_packed, K, Kpad, cout);
+  else
+    hipLaunchKernelGGL((pack_conv_weights_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st,
+                       w_hwio, (float*)w_packed, K, Kpad, cout);
+  COMIC_LAUNCH_CHECK("pack_conv_weights");
+  return 0;
+}
+
+extern "C" int comic_fold_bn(const float* beta, const float* mean, const float* var, float eps, float* scale,
+                             float* shift, int c, void* stream) {
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, beta, mean, var, eps,
+                     scale, shift, c);
+  COMIC_LAUNCH_CHECK("fold_bn");
+  return 0;
+}

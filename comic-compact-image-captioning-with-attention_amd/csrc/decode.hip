@@ -1,0 +1,213 @@
+// Decoding kernels: row argmax (greedy), one fused beam-search step (log-softmax, finished
+// masking, top-k over beam*V, length/finished bookkeeping), parent gather, gather_tree.
+//
+// Restates tf.contrib.seq2seq [TF-1.9] as used by common/ops_rnn.py:49-180:
+//   GreedyEmbeddingHelper.sample = argmax (lowest index wins ties)
+//   _beam_search_step: log_softmax -> _mask_probs(finished rows: float32.min, 0 at EOS)
+//     -> total = log_probs[:, :, None] + step -> top_k(beam) over the flattened beam*V axis
+//     (lower flat index first among equal values) -> word = idx % V, parent = idx / V
+//   gather_tree: back-track parents from max_len-1, EOS-fill after the first EOS.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+struct ValIdx {
+  float v;
+  int i;
+};
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__device__ __forceinline__ ValIdx block_argmax(float v, int i, ValIdx* sh) {
+  const int tid = threadIdx.x;
+  sh[tid].v = v;
+  sh[tid].i = i;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s && better(sh[tid + s].v, sh[tid + s].i, sh[tid].v, sh[tid].i)) sh[tid] = sh[tid + s];
+    __syncthreads();
+  }
+  const ValIdx r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
+                                                          int V) {
+  __shared__ ValIdx sh[256];
+  const float* row = x + (size_t)blockIdx.x * V;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += 256) {
+    const float t = row[v];
+    if (better(t, v, bv, bi)) {
+      bv = t;
+      bi = v;
+    }
+  }
+  const ValIdx r = block_argmax(bv, bi, sh);
+  if (threadIdx.x == 0) idx[blockIdx.x] = r.i == 0x7fffffff ? 0 : r.i;
+}
+
+// One workgroup per batch entry.
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, float* __restrict__ log_probs,
+                                                        int32_t* __restrict__ finished, int64_t* __restrict__ lengths,
+                                                        int32_t* __restrict__ word_ids, int32_t* __restrict__ parent_ids,
+                                                        float* __restrict__ scores, int W, int V, int end_id) {
+  __shared__ ValIdx sh[256];
+  __shared__ float s_max[64], s_logsum[64], s_lp[64];
+  __shared__ int s_fin[64], s_sel[64];
+  __shared__ float s_selv[64];
+  __shared__ long long s_len[64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* lg = logits + (size_t)b * W * V;
+  for (int w = tid; w < W; w += 256) {
+    s_lp[w] = log_probs[b * W + w];
+    s_fin[w] = finished[b * W + w];
+    s_len[w] = lengths[b * W + w];
+  }
+  // log-softmax statistics per beam (one wave per beam)
+  for (int w = wave; w < W; w += 4) {
+    const float* row = lg + (size_t)w * V;
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, row[v]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(row[v] - mx);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s_max[w] = mx;
+      s_logsum[w] = logf(s);
+    }
+  }
+  __syncthreads();
+  const int total = W * V;
+  for (int r = 0; r < W; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int f = tid; f < total; f += 256) {
+      bool taken = false;
+      for (int q = 0; q < r; ++q) taken |= (s_sel[q] == f);
+      if (taken) continue;
+      const int w = f / V, v = f - w * V;
+      float step;
+      if (s_fin[w])
+        step = (v == end_id) ? 0.f : -FLT_MAX;  // dtype.min
+      else
+        step = (lg[f] - s_max[w]) - s_logsum[w];
+      const float tot = s_lp[w] + step;
+      if (better(tot, f, bv, bi)) {
+        bv = tot;
+        bi = f;
+      }
+    }
+    const ValIdx best = block_argmax(bv, bi, sh);
+    if (tid == 0) {
+      // all-(-inf) corner: fall back to the lowest untaken flat index (matches a stable sort)
+      int sel = best.i;
+      if (sel == 0x7fffffff) {
+        sel = 0;
+        bool again = true;
+        while (again) {
+          again = false;
+          for (int q = 0; q < r; ++q)
+            if (s_sel[q] == sel) {
+              ++sel;
+              again = true;
+            }
+        }
+      }
+      s_sel[r] = sel;
+      s_selv[r] = best.v;
+    }
+    __syncthreads();
+  }
+  if (tid < W) {
+    const int f = s_sel[tid];
+    const int parent = f / V, word = f - parent * V;
+    const int prev_fin = s_fin[parent];
+    word_ids[b * W + tid] = word;
+    parent_ids[b * W + tid] = parent;
+    scores[b * W + tid] = s_selv[tid];
+    log_probs[b * W + tid] = s_selv[tid];
+    finished[b * W + tid] = (prev_fin || word == end_id) ? 1 : 0;
+    lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ parent,
+                                   float* __restrict__ out, long total, int W, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  const int src = (r / W) * W + parent[r];
+  out[i] = in[(size_t)src * cols + c];
+}
+
+__global__ void gather_tree_kernel(const int32_t* __restrict__ step_ids, const int32_t* __restrict__ parent_ids,
+                                   const int32_t* __restrict__ max_len, int32_t* __restrict__ out, int T, int B, int W,
+                                   int end_id) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * W) return;
+  const int b = i / W, w = i % W;
+  for (int t = 0; t < T; ++t) out[((size_t)t * B + b) * W + w] = end_id;
+  const int L = min(T, max_len[b]);
+  if (L <= 0) return;
+  out[((size_t)(L - 1) * B + b) * W + w] = step_ids[((size_t)(L - 1) * B + b) * W + w];
+  int parent = parent_ids[((size_t)(L - 1) * B + b) * W + w];
+  for (int level = L - 2; level >= 0; --level) {
+    if (parent < 0 || parent >= W) return;  // invalid trajectory: leave EOS (reference raises)
+    out[((size_t)level * B + b) * W + w] = step_ids[((size_t)level * B + b) * W + parent];
+    parent = parent_ids[((size_t)level * B + b) * W + parent];
+  }
+  bool fin = false;
+  for (int t = 0; t < L; ++t) {
+    int32_t* p = out + ((size_t)t * B + b) * W + w;
+    if (fin)
+      *p = end_id;
+    else if (*p == end_id)
+      fin = true;
+  }
+}
+
+}  // namespace
+
+extern "C" int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, void* stream) {
+  COMIC_REQUIRE(x && idx && rows > 0 && V > 0, "argmax_rows: bad arguments");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, idx, V);
+  COMIC_LAUNCH_CHECK("argmax_rows");
+  return 0;
+}
+
+extern "C" int comic_beam_step(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths,
+                               int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int V, int end_id,
+                               void* stream) {
+  COMIC_REQUIRE(logits && log_probs && finished && lengths && word_ids && parent_ids && scores,
+                "beam_step: null pointer");
+  COMIC_REQUIRE(W >= 1 && W <= 64, "beam_step: beam width must be in [1,64] (got %d)", W);
+  COMIC_REQUIRE((long)W * V < (1L << 31) && W <= V, "beam_step: beam*V too large or beam > V");
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, log_probs, finished,
+                     lengths, word_ids, parent_ids, scores, W, V, end_id);
+  COMIC_LAUNCH_CHECK("beam_step");
+  return 0;
+}
+
+extern "C" int comic_gather_rows(const float* in, const int32_t* parent, float* out, int rows, int W, int cols,
+                                 void* stream) {
+  COMIC_REQUIRE(in != out, "gather_rows: in-place gather is not supported");
+  const long total = (long)rows * cols;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     parent, out, total, W, cols);
+  COMIC_LAUNCH_CHECK("gather_rows");
+  return 0;
+}
+
+extern "C" int comic_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* max_len,
+                                 int32_t* out, int T, int B, int W, int end_id, void* stream) {
+  hipLaunchKernelGGL(gather_tree_kernel, dim3(cdiv(B * W, 64)), dim3(64), 0, (hipStream_t)stream, step_ids,
+                     parent_ids, max_len, out, T, B, W, end_id);
+  COMIC_LAUNCH_CHECK("gather_tree");
+  return 0;
+}

@@ -1,0 +1,680 @@
+// Decoder step kernels for gfx950 (fp32): embeddings, dropout, fused LSTM gates,
+// fused per-step multi-head attention (score + softmax + dropout + context) forward and
+// backward, sequence cross-entropy, Adam, small reductions.
+//
+// Reference call-sites (see include/comic_hip.h for the per-function citations):
+//   common/ops_rnn.py:531-565, :611-632, :660-755   attention mechanisms + wrapper step
+//   common/ops.py:241-275                           layer_norm_activate (eps 1e-12)
+//   src/model_base.py:557-594, :606-648, :325-417   embeddings, LSTM cell + dropout, losses
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+constexpr float kLnEps = 1e-12f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------ embeddings --------
+__global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                 float* __restrict__ out, long total, int E, int V) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int r = (int)(i / E), e = (int)(i % E);
+  const int id = ids[r];
+  out[i] = (id >= 0 && id < V) ? table[(size_t)id * E + e] : 0.f;
+}
+
+// one block per vocabulary row: deterministic sum over the rows that reference it
+__global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dout,
+                                 float* __restrict__ dtable, int rows, int E) {
+  const int v = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r)
+      if (ids[r] == v) acc += dout[(size_t)r * E + e];
+    if (acc != 0.f) dtable[(size_t)v * E + e] += acc;
+  }
+}
+
+// ------------------------------------------------------------------ dropout -----------
+__global__ void dropout_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask, float keep,
+                                     float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = mask ? (x[i] / keep) * mask[i] : x[i];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float keep, uint64_t seed, uint64_t offset) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t r = splitmix64(splitmix64(seed) ^ (offset + (uint64_t)i));
+  const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // [0,1)
+  mask[i] = u < keep ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------ LSTM gates --------
+__global__ void lstm_gates_fwd_kernel(const float* __restrict__ g, const float* __restrict__ c_prev,
+                                      const float* __restrict__ h_prev, float* __restrict__ gates_act,
+                                      float* __restrict__ c_new, float* __restrict__ h_new, float* __restrict__ y,
+                                      const float* __restrict__ mask_out, float keep_out,
+                                      const int32_t* __restrict__ lens, int t, float* __restrict__ c_state,
+                                      float* __restrict__ h_state, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i % D;
+  const float* gr = g + (size_t)b * 4 * D;
+  const float si = sigmoidf_(gr[d]), tj = tanhf(gr[D + d]);
+  const float sf = sigmoidf_(gr[2 * D + d] + 1.0f), so = sigmoidf_(gr[3 * D + d]);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float c2 = cp * sf + si * tj;
+  const float tc = tanhf(c2);
+  const float h2 = tc * so;
+  if (gates_act) {
+    float* ga = gates_act + (size_t)b * 4 * D;
+    ga[d] = si; ga[D + d] = tj; ga[2 * D + d] = sf; ga[3 * D + d] = so;
+  }
+  if (c_new) c_new[i] = c2;
+  if (h_new) h_new[i] = h2;
+  if (y) y[i] = mask_out ? (h2 / keep_out) * mask_out[i] : h2;
+  const bool fin = lens && (t >= lens[b]);
+  if (c_state) c_state[i] = fin ? cp : c2;
+  if (h_state) h_state[i] = fin ? (h_prev ? h_prev[i] : 0.f) : h2;
+}
+
+__global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates_act, const float* __restrict__ c_prev,
+                                      const float* __restrict__ c_new, const float* __restrict__ dy,
+                                      const float* __restrict__ mask_out, float keep_out,
+                                      const int32_t* __restrict__ lens, int t, float* __restrict__ dc_state,
+                                      float* __restrict__ dh_state, float* __restrict__ dg, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, d = i % D;
+  const float live = (lens && t >= lens[b]) ? 0.f : 1.f;
+  const float* ga = gates_act + (size_t)b * 4 * D;
+  const float si = ga[d], tj = ga[D + d], sf = ga[2 * D + d], so = ga[3 * D + d];
+  const float tc = tanhf(c_new[i]);
+  const float dcs = dc_state[i], dhs = dh_state[i];
+  float dyv = dy ? dy[i] : 0.f;
+  if (mask_out) dyv = (dyv / keep_out) * mask_out[i];
+  const float dh2 = dhs * live + dyv;
+  float dc2 = dcs * live;
+  const float dso = dh2 * tc;
+  dc2 += dh2 * so * (1.f - tc * tc);
+  const float cp = c_prev ? c_prev[i] : 0.f;
+  const float dsf = dc2 * cp, dsi = dc2 * tj, dtj = dc2 * si;
+  float* dgr = dg + (size_t)b * 4 * D;
+  dgr[d] = dsi * si * (1.f - si);
+  dgr[D + d] = dtj * (1.f - tj * tj);
+  dgr[2 * D + d] = dsf * sf * (1.f - sf);
+  dgr[3 * D + d] = dso * so * (1.f - so);
+  dc_state[i] = dcs * (1.f - live) + dc2 * sf;
+  dh_state[i] = dhs * (1.f - live);
+}
+
+// ------------------------------------------------------------------ attention ---------
+// One workgroup (4 waves) per batch row.  A wave owns whole memory rows m (so the
+// LayerNorm statistics and the per-head partial sums are wave shuffles); lane l holds the
+// EPL = D/64 contiguous channels [l*EPL, (l+1)*EPL), all inside one head.
+struct AttnArgs {
+  comic_attn_desc d;
+  const float *keys, *values, *q, *ln_g, *ln_b, *v, *tau, *alpha_in, *mask_alpha, *dctx, *dmap;
+  float keep_alpha;
+  float *alpha, *alpha_d, *ctx, *dq, *dkeys, *dvalues, *pgrad;
+};
+
+template <int EPL>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float* v) {
+  if constexpr (EPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < EPL; i += 4) {
+      const float4 t = *(const float4*)(p + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) v[i] = p[i];
+  }
+}
+
+// sum over the `lph` consecutive lanes that share a head (lph is a power of two <= 64)
+__device__ __forceinline__ float head_sum(float v, int lph) {
+  for (int o = 1; o < lph; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// raw (unscaled) per-head scores of one memory row; returns this lane's head partial
+// already reduced over the head.  For add_LN also returns th = tanh(LN(z)), xh, rstd.
+template <int EPL>
+__device__ __forceinline__ float score_row(const AttnArgs& a, const float* kr, const float* qv, const float* gv,
+                                           const float* bv, const float* vv, int lph, float* th, float* xh,
+                                           float& rstd) {
+  const int D = a.d.D;
+  float part = 0.f;
+  if (a.d.method == 0) {
+    float z[EPL], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      z[i] = kr[i] + qv[i];
+      s += z[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const float c = z[i] - mean;
+      s2 += c * c;
+    }
+    const float var = wave_sum(s2) / (float)D;
+    rstd = 1.0f / sqrtf(var + kLnEps);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      // tf.nn.batch_normalization form: x*inv + (beta - mean*inv), inv = rstd*gamma
+      const float inv = rstd * gv[i];
+      const float zh = z[i] * inv + (bv[i] - mean * inv);
+      const float t = tanhf(zh);
+      if (th) th[i] = t;
+      if (xh) xh[i] = (z[i] - mean) * rstd;
+      part += t * vv[i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) part += kr[i] * qv[i];
+  }
+  return head_sum(part, lph);
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int B = a.d.B, M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
+  (void)B;
+  float* sc = sm;  // [H][M]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dh = D / H, lph = dh / EPL;
+  const int k0 = lane * EPL, head = k0 / dh;
+  float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
+  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
+  if (a.d.method == 0) {
+    load_row<EPL>(a.ln_g + k0, gv);
+    load_row<EPL>(a.ln_b + k0, bv);
+    load_row<EPL>(a.v + k0, vv);
+  }
+  const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
+  for (int m = wave; m < M; m += 4) {
+    float kr[EPL], rstd;
+    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
+    if ((lane % lph) == 0) sc[head * M + m] = raw / scale;
+  }
+  __syncthreads();
+  // probability fn per head (wave per head), then dropout; sc <- alpha_d
+  for (int h = wave; h < H; h += 4) {
+    float* row = sc + h * M;
+    const size_t go = ((size_t)b * H + h) * M;
+    if (a.d.prob == 0) {
+      float mx = -INFINITY;
+      for (int m = lane; m < M; m += 64) mx = fmaxf(mx, row[m]);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int m = lane; m < M; m += 64) s += expf(row[m] - mx);
+      s = wave_sum(s);
+      for (int m = lane; m < M; m += 64) {
+        const float al = expf(row[m] - mx) / s;
+        a.alpha[go + m] = al;
+        const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go + m] : al;
+        a.alpha_d[go + m] = ad;
+        row[m] = ad;
+      }
+    } else {
+      float s = 0.f;
+      for (int m = lane; m < M; m += 64) s += sigmoidf_(row[m]);
+      s = wave_sum(s);
+      for (int m = lane; m < M; m += 64) {
+        const float al = sigmoidf_(row[m]) / s;
+        a.alpha[go + m] = al;
+        const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go + m] : al;
+        a.alpha_d[go + m] = ad;
+        row[m] = ad;
+      }
+    }
+  }
+  __syncthreads();
+  // context: ctx[c] = sum_m alpha_d[head(c)][m] * values[m][c]   (coalesced over c)
+  const int dv = Cv / H;
+  for (int c = tid; c < Cv; c += 256) {
+    const float* al = sc + (c / dv) * M;
+    const float* vp = a.values + (size_t)b * M * Cv + c;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
+    a.ctx[(size_t)b * Cv + c] = acc;
+  }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
+  float* ss = sm;               // [H][M] scaled scores s
+  float* sd = ss + H * M;       // [H][M] d alpha_d, then d raw
+  float* red = sd + H * M;      // [4][D] cross-wave reduction
+  float* misc = red + 4 * D;    // [4] d tau partials
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dh = D / H, lph = dh / EPL;
+  const int k0 = lane * EPL, head = k0 / dh;
+  float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
+  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
+  if (a.d.method == 0) {
+    load_row<EPL>(a.ln_g + k0, gv);
+    load_row<EPL>(a.ln_b + k0, bv);
+    load_row<EPL>(a.v + k0, vv);
+  }
+  const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
+  // values-side lane mapping: EPLV contiguous channels per lane, all in one head
+  const int dv = Cv / H, eplv = Cv / 64, lphv = dv / eplv;
+  const int c0 = lane * eplv, headv = c0 / dv;
+  const float* dctx = a.dctx + (size_t)b * Cv;
+
+  // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
+  for (int m = wave; m < M; m += 4) {
+    float kr[EPL], rstd;
+    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
+    if ((lane % lph) == 0) ss[head * M + m] = raw / scale;
+    // alpha_d of this lane's value head
+    const size_t go = ((size_t)b * H + headv) * M + m;
+    const float al = a.alpha_in[go];
+    const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go] : al;
+    const float* vr = a.values + ((size_t)b * M + m) * Cv + c0;
+    float* dvr = a.dvalues + ((size_t)b * M + m) * Cv + c0;
+    float part = 0.f;
+    for (int i = 0; i < eplv; ++i) {
+      const float dc = dctx[c0 + i];
+      part = fmaf(dc, vr[i], part);
+      dvr[i] += ad * dc;
+    }
+    part = head_sum(part, lphv);
+    if ((lane % lphv) == 0) sd[headv * M + m] = part + (a.dmap ? a.dmap[(size_t)b * M + m] : 0.f);
+  }
+  __syncthreads();
+  // ---- phase B: through dropout and the probability fn; sd <- d raw -----------------------
+  float dtau = 0.f;
+  for (int h = wave; h < H; h += 4) {
+    const size_t go = ((size_t)b * H + h) * M;
+    float* srow = ss + h * M;
+    float* drow = sd + h * M;
+    if (a.d.prob == 0) {
+      float dot = 0.f;
+      for (int m = lane; m < M; m += 64) {
+        float da = drow[m];
+        if (a.mask_alpha) da = (da / a.keep_alpha) * a.mask_alpha[go + m];
+        drow[m] = da;
+        dot += a.alpha_in[go + m] * da;
+      }
+      dot = wave_sum(dot);
+      for (int m = lane; m < M; m += 64) {
+        const float ds = a.alpha_in[go + m] * (drow[m] - dot);
+        dtau -= ds * srow[m];
+        drow[m] = ds / scale;
+      }
+    } else {
+      float S = 0.f, dsum = 0.f;
+      for (int m = lane; m < M; m += 64) {
+        float da = drow[m];
+        if (a.mask_alpha) da = (da / a.keep_alpha) * a.mask_alpha[go + m];
+        drow[m] = da;
+        const float sg = sigmoidf_(srow[m]);
+        S += sg;
+        dsum += da * sg;
+      }
+      S = wave_sum(S);
+      dsum = wave_sum(dsum);
+      for (int m = lane; m < M; m += 64) {
+        const float sg = sigmoidf_(srow[m]);
+        const float dsg = drow[m] / S - dsum / (S * S);
+        const float ds = dsg * sg * (1.f - sg);
+        dtau -= ds * srow[m];
+        drow[m] = ds / scale;
+      }
+    }
+  }
+  dtau = wave_sum(dtau);
+  if (lane == 0) misc[wave] = dtau;
+  __syncthreads();
+  // ---- phase C: through tanh / LayerNorm (or the dot product) ------------------------------
+  float dq_acc[EPL], dv_acc[EPL], dg_acc[EPL], db_acc[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) dq_acc[i] = dv_acc[i] = dg_acc[i] = db_acc[i] = 0.f;
+  for (int m = wave; m < M; m += 4) {
+    float kr[EPL], th[EPL], xh[EPL], rstd = 0.f;
+    const float* kp = a.keys + ((size_t)b * M + m) * D + k0;
+    float* dkp = a.dkeys + ((size_t)b * M + m) * D + k0;
+    load_row<EPL>(kp, kr);
+    const float draw = sd[head * M + m];
+    if (a.d.method == 0) {
+      score_row<EPL>(a, kr, qv, gv, bv, vv, lph, th, xh, rstd);
+      float dxh[EPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        dv_acc[i] += draw * th[i];
+        const float dzh = draw * vv[i] * (1.f - th[i] * th[i]);
+        dg_acc[i] += dzh * xh[i];
+        db_acc[i] += dzh;
+        dxh[i] = dzh * gv[i];
+        s1 += dxh[i];
+        s2 += dxh[i] * xh[i];
+      }
+      const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
+        dkp[i] += dz;
+        dq_acc[i] += dz;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        dkp[i] += draw * qv[i];
+        dq_acc[i] += draw * kr[i];
+      }
+    }
+  }
+  // cross-wave reductions (4 waves), one array at a time through `red`
+  auto reduce_store = [&](const float* acc, float* dst, bool accumulate) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) red[wave * D + k0 + i] = acc[i];
+    __syncthreads();
+    for (int k = tid; k < D; k += 256) {
+      const float s = red[k] + red[D + k] + red[2 * D + k] + red[3 * D + k];
+      if (accumulate)
+        dst[k] += s;
+      else
+        dst[k] = s;
+    }
+  };
+  reduce_store(dq_acc, a.dq + (size_t)b * D, false);
+  if (a.d.method == 0 && a.pgrad) {
+    float* pg = a.pgrad + (size_t)b * (3 * D + 1);
+    reduce_store(dv_acc, pg, true);
+    reduce_store(dg_acc, pg + D, true);
+    reduce_store(db_acc, pg + 2 * D, true);
+    if (tid == 0) pg[3 * D] += (misc[0] + misc[1] + misc[2] + misc[3]) / a.tau[0];
+  }
+}
+
+// ------------------------------------------------------------------ cross-entropy -----
+__global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ targets_bt,
+                                                   const float* __restrict__ coef_bt,
+                                                   const float* __restrict__ wmask_bt,
+                                                   const int32_t* __restrict__ lens, float* __restrict__ loss_rows,
+                                                   float* __restrict__ dlogits, int32_t* __restrict__ ids_tb, int T,
+                                                   int B, int V) {  // T = stride of the [B,T] tables
+  __shared__ float smax[256];
+  __shared__ int sidx[256];
+  const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+  float* lg = logits + (size_t)row * V;
+  float* dl = dlogits ? dlogits + (size_t)row * V : nullptr;
+  if (lens && t >= lens[b]) {  // impute_finished: zero outputs
+    for (int v = tid; v < V; v += 256) {
+      lg[v] = 0.f;
+      if (dl) dl[v] = 0.f;
+    }
+    if (tid == 0) {
+      if (loss_rows) loss_rows[row] = 0.f;
+      if (ids_tb) ids_tb[row] = 0;
+    }
+    return;
+  }
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int v = tid; v < V; v += 256) {
+    const float x = lg[v];
+    if (x > mx) {
+      mx = x;
+      mi = v;
+    }
+  }
+  smax[tid] = mx;
+  sidx[tid] = mi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float o = smax[tid + s];
+      const int oi = sidx[tid + s];
+      if (o > smax[tid] || (o == smax[tid] && oi < sidx[tid])) {
+        smax[tid] = o;
+        sidx[tid] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  mx = smax[0];
+  const int amax = sidx[0];
+  __syncthreads();
+  float s = 0.f;
+  for (int v = tid; v < V; v += 256) s += expf(lg[v] - mx);
+  smax[tid] = s;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) smax[tid] += smax[tid + st];
+    __syncthreads();
+  }
+  const float sum = smax[0];
+  const int tgt = targets_bt[(size_t)b * T + t];
+  const float coef = coef_bt ? coef_bt[(size_t)b * T + t] : 0.f;
+  if (dl)
+    for (int v = tid; v < V; v += 256) dl[v] = (expf(lg[v] - mx) / sum - (v == tgt ? 1.f : 0.f)) * coef;
+  if (tid == 0) {
+    if (loss_rows) loss_rows[row] = (logf(sum) - (lg[tgt] - mx)) * (wmask_bt ? wmask_bt[(size_t)b * T + t] : 1.f);
+    if (ids_tb) ids_tb[row] = amax;
+  }
+}
+
+// ------------------------------------------------------------------ optimiser etc. ----
+__global__ void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                               float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps, float l2,
+                               float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float wi = w[i];
+  const float ge = g[i] * gscale + l2 * wi;
+  const float mi = m[i] + (ge - m[i]) * (1.f - b1);
+  const float vi = v[i] + (ge * ge - v[i]) * (1.f - b2);
+  m[i] = mi;
+  v[i] = vi;
+  w[i] = wi - (mi * lr_t) / (sqrtf(vi) + eps);
+}
+
+// out[j] = beta*out[j] + sum_i in[i*cols+j]; one thread per column (coalesced over j)
+__global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, float beta) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  float acc = 0.f;
+  for (int i = 0; i < rows; ++i) acc += in[(size_t)i * cols + j];
+  out[j] = (beta != 0.f ? beta * out[j] : 0.f) + acc;
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+int attn_check(const comic_attn_desc* d) {
+  COMIC_REQUIRE(d, "attn: null descriptor");
+  COMIC_REQUIRE(d->B > 0 && d->M > 0 && d->H > 0, "attn: bad shape");
+  COMIC_REQUIRE(d->D % 64 == 0 && d->D <= 1024, "attn: D must be a multiple of 64 and <= 1024 (got %d)", d->D);
+  COMIC_REQUIRE(d->D % d->H == 0 && (d->D / d->H) % (d->D / 64) == 0 && 64 % d->H == 0,
+                "attn: heads must divide 64 and D (D=%d H=%d)", d->D, d->H);
+  COMIC_REQUIRE(d->Cv % 64 == 0 && d->Cv % d->H == 0 && (d->Cv / d->H) % (d->Cv / 64) == 0,
+                "attn: value channels must be a multiple of 64 (Cv=%d H=%d)", d->Cv, d->H);
+  COMIC_REQUIRE(!d->tied || d->Cv == d->D, "attn: tied values need Cv == D");
+  COMIC_REQUIRE((size_t)d->H * d->M * 2 * 4 + 4 * d->D * 4 + 64 <= 60 * 1024, "attn: H*M too large for LDS");
+  return 0;
+}
+
+template <typename F>
+int attn_dispatch(int D, F&& f) {
+  switch (D / 64) {
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 2: f(std::integral_constant<int, 2>()); break;
+    case 4: f(std::integral_constant<int, 4>()); break;
+    case 8: f(std::integral_constant<int, 8>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    default:
+      comic_set_error("attn: unsupported D=%d (D/64 must be 1,2,4,8,16)", D);
+      return 2;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int comic_embed_fwd(const float* table, const int32_t* ids, float* out, int rows, int E, int V,
+                               void* stream) {
+  const long total = (long)rows * E;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, table,
+                     ids, out, total, E, V);
+  COMIC_LAUNCH_CHECK("embed_fwd");
+  return 0;
+}
+
+extern "C" int comic_embed_bwd(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V,
+                               void* stream) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(E < 256 ? ((E + 63) / 64) * 64 : 256), 0, (hipStream_t)stream,
+                     ids, dout, dtable, rows, E);
+  COMIC_LAUNCH_CHECK("embed_bwd");
+  return 0;
+}
+
+extern "C" int comic_dropout_apply(const float* x, const float* mask, float keep, float* y, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mask,
+                     keep, y, (long)n);
+  COMIC_LAUNCH_CHECK("dropout_apply");
+  return 0;
+}
+
+extern "C" int comic_dropout_mask(float* mask, int64_t n, float keep, uint64_t seed, uint64_t offset, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, mask,
+                     (long)n, keep, seed, offset);
+  COMIC_LAUNCH_CHECK("dropout_mask");
+  return 0;
+}
+
+extern "C" int comic_lstm_gates_fwd(const float* g, const float* c_prev, const float* h_prev, float* gates_act,
+                                    float* c_new, float* h_new, float* y, const float* mask_out, float keep_out,
+                                    const int32_t* lens, int t, float* c_state, float* h_state, int B, int D,
+                                    void* stream) {
+  COMIC_REQUIRE(g, "lstm_gates_fwd: null input");
+  hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, g, c_prev,
+                     h_prev, gates_act, c_new, h_new, y, mask_out, keep_out, lens, t, c_state, h_state, B, D);
+  COMIC_LAUNCH_CHECK("lstm_gates_fwd");
+  return 0;
+}
+
+extern "C" int comic_lstm_gates_bwd(const float* gates_act, const float* c_prev, const float* c_new, const float* dy,
+                                    const float* mask_out, float keep_out, const int32_t* lens, int t,
+                                    float* dc_state, float* dh_state, float* dg, int B, int D, void* stream) {
+  COMIC_REQUIRE(gates_act && c_new && dc_state && dh_state && dg, "lstm_gates_bwd: null pointer");
+  hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, gates_act,
+                     c_prev, c_new, dy, mask_out, keep_out, lens, t, dc_state, dh_state, dg, B, D);
+  COMIC_LAUNCH_CHECK("lstm_gates_bwd");
+  return 0;
+}
+
+extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
+                                   const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
+                                   void* stream) {
+  if (int rc = attn_check(d)) return rc;
+  COMIC_REQUIRE(keys && values && q && alpha && alpha_d && ctx, "attn_fwd: null pointer");
+  COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_fwd: add_LN needs ln_g/ln_b/v/tau");
+  AttnArgs a{};
+  a.d = *d;
+  a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
+  a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.alpha = alpha; a.alpha_d = alpha_d; a.ctx = ctx;
+  const size_t lds = (size_t)d->H * d->M * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = attn_dispatch(d->D, [&](auto epl) {
+    hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
+  });
+  if (rc) return rc;
+  COMIC_LAUNCH_CHECK("attn_fwd");
+  return 0;
+}
+
+extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
+                                   const float* alpha, const float* mask_alpha, float keep_alpha, const float* dctx,
+                                   const float* dmap, float* dq, float* dkeys, float* dvalues, float* pgrad,
+                                   void* stream) {
+  if (int rc = attn_check(d)) return rc;
+  COMIC_REQUIRE(keys && values && q && alpha && dctx && dq && dkeys && dvalues, "attn_bwd: null pointer");
+  COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_bwd: add_LN needs ln_g/ln_b/v/tau");
+  AttnArgs a{};
+  a.d = *d;
+  a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
+  a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
+  a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad;
+  const size_t lds = ((size_t)d->H * d->M * 2 + 4 * d->D + 16) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = attn_dispatch(d->D, [&](auto epl) {
+    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
+  });
+  if (rc) return rc;
+  COMIC_LAUNCH_CHECK("attn_bwd");
+  return 0;
+}
+
+// t_rows time steps of logits are processed; the [B, t_stride] tables are indexed b*t_stride + t
+int comic_xent_ex(float* logits, const int32_t* targets_bt, const float* coef_bt, const float* wmask_bt,
+                  const int32_t* lens, float* loss_rows, float* dlogits, int32_t* ids_tb, int t_rows, int t_stride,
+                  int B, int V, hipStream_t st) {
+  COMIC_REQUIRE(logits && targets_bt, "xent: null pointer");
+  COMIC_REQUIRE(t_rows > 0 && t_rows <= t_stride, "xent: bad time extent");
+  hipLaunchKernelGGL(xent_kernel, dim3(t_rows * B), dim3(256), 0, st, logits, targets_bt, coef_bt, wmask_bt, lens,
+                     loss_rows, dlogits, ids_tb, t_stride, B, V);
+  COMIC_LAUNCH_CHECK("xent");
+  return 0;
+}
+
+extern "C" int comic_xent_fwd_bwd(float* logits, const int32_t* targets_bt, const float* coef_bt,
+                                  const float* wmask_bt, const int32_t* lens, float* loss_rows, float* dlogits,
+                                  int32_t* ids_tb, int T, int B, int V, void* stream) {
+  return comic_xent_ex(logits, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, T, T, B, V,
+                       (hipStream_t)stream);
+}
+
+extern "C" int comic_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                             float beta2, float eps, float l2, float gscale, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
+                     (long)n, lr_t, beta1, beta2, eps, l2, gscale);
+  COMIC_LAUNCH_CHECK("adam_tf");
+  return 0;
+}
+
+extern "C" int comic_colsum(const float* in, float* out, int rows, int cols, float beta, void* stream) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols,
+                     beta);
+  COMIC_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+extern "C" int comic_axpy(float* y, const float* x, float a, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, a,
+                     (long)n);
+  COMIC_LAUNCH_CHECK("axpy");
+  return 0;
+}

@@ -1,0 +1,658 @@
+// Native executors for the attention-LSTM decoder: one teacher-forced forward+backward
+// (XE or SCST-weighted), greedy decode and beam search.  They issue the step kernels of
+// decoder.hip / gemm.hip / decode.hip on one HIP stream with no host synchronisation and no
+// allocation (caller-provided workspace), so a whole step can be captured in a hipGraph.
+//
+// Mirrors (not translates) the reference graph builders:
+//   ModelBase._decoder_rnn / _decoder_rnn_scst ...... src/model_base.py:109-269
+//   rnn_decoder_training / _search / _beam_search ... common/ops_rnn.py:49-243
+//   MultiHeadAttentionWrapperV3.call ................ common/ops_rnn.py:660-755
+//   _train_caption_model (losses) ................... src/model_base.py:325-405
+// Differences by design: the x-independent pieces are hoisted out of the time loop
+// (embedding lookup for all steps, output projection + cross-entropy as one batched GEMM,
+// all weight-gradient GEMMs batched over time), states are kept per step for the backward
+// pass instead of TF's TensorArray stack, and dropout masks are explicit inputs.
+#include <string.h>
+
+#include "common.h"
+
+// internal cross-file entry (decoder.hip)
+int comic_xent_ex(float* logits, const int32_t* targets_bt, const float* coef_bt, const float* wmask_bt,
+                  const int32_t* lens, float* loss_rows, float* dlogits, int32_t* ids_tb, int t_rows, int t_stride,
+                  int B, int V, hipStream_t st);
+
+namespace {
+
+#define RC(x)               \
+  do {                      \
+    int rc__ = (x);         \
+    if (rc__) return rc__;  \
+  } while (0)
+
+struct Bump {
+  char* base;
+  size_t off, cap;
+  bool ok;
+  Bump(void* p, size_t c) : base((char*)p), off(0), cap(c), ok(true) {}
+  template <typename T>
+  T* take(size_t n) {
+    const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    if (base && off + bytes > cap) ok = false;
+    T* r = base ? (T*)(base + off) : nullptr;
+    off += bytes;
+    return r;
+  }
+};
+
+// xh_row = [ drop(x) ; drop(att) ; h ]   (cell_input_fn concat + DropoutWrapper input dropout)
+__global__ void assemble_input_kernel(const float* __restrict__ x, const float* __restrict__ att,
+                                      const float* __restrict__ h, const float* __restrict__ mask, float keep,
+                                      float* __restrict__ xh, int B, int E, int A, int D) {
+  const int W = E + A + D;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * W) return;
+  const int b = i / W, c = i % W;
+  float v;
+  if (c < E + A) {
+    v = c < E ? x[(size_t)b * E + c] : att[(size_t)b * A + (c - E)];
+    if (mask) v = (v / keep) * mask[(size_t)b * (E + A) + c];
+  } else {
+    v = h ? h[(size_t)b * D + (c - E - A)] : 0.f;
+  }
+  xh[i] = v;
+}
+
+// dst = fin ? prev : cur      (impute_finished state select; lens NULL -> copy cur)
+__global__ void select_rows_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
+                                   const int32_t* __restrict__ lens, int t, float* __restrict__ dst, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C;
+  dst[i] = (lens && t >= lens[b]) ? prev[i] : cur[i];
+}
+
+// live = !(t >= lens[b]):  out_live = d*live ; d = d*(1-live)
+__global__ void split_live_kernel(float* __restrict__ d, float* __restrict__ out_live,
+                                  const int32_t* __restrict__ lens, int t, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C;
+  const bool fin = lens && t >= lens[b];
+  const float v = d[i];
+  out_live[i] = fin ? 0.f : v;
+  d[i] = fin ? v : 0.f;
+}
+
+// dxh [B, E+A+D] -> demb_t [B,E] = drop'(dxh[:, :E]); datt += drop'(dxh[:, E:E+A]); dh += dxh[:, E+A:]
+__global__ void input_bwd_kernel(const float* __restrict__ dxh, const float* __restrict__ mask, float keep,
+                                 float* __restrict__ demb, float* __restrict__ datt, float* __restrict__ dh, int B,
+                                 int E, int A, int D) {
+  const int W = E + A + D;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * W) return;
+  const int b = i / W, c = i % W;
+  float v = dxh[i];
+  if (c < E + A) {
+    if (mask) v = (v / keep) * mask[(size_t)b * (E + A) + c];
+    if (c < E) {
+      if (demb) demb[(size_t)b * E + c] = v;
+    } else {
+      datt[(size_t)b * A + (c - E)] += v;
+    }
+  } else {
+    dh[(size_t)b * D + (c - E - A)] += v;
+  }
+}
+
+// flat[b,t,m] = sum_h hist[t,b,h,m];  map_loss = mean((1-flat)^2)*scale;
+// dmap[t,b,m] = 2*(flat-1)/(B*Tp*M)*scale.   Single workgroup (deterministic).
+__global__ __launch_bounds__(1024) void maploss_kernel(const float* __restrict__ hist, float* __restrict__ dmap,
+                                                       float* __restrict__ map_loss, int Tp, int B, int H, int M,
+                                                       float scale) {
+  __shared__ float red[1024];
+  const long n = (long)Tp * B * M;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const int m = (int)(i % M);
+    const long tb = i / M;
+    const float* p = hist + (size_t)tb * H * M + m;
+    float f = 0.f;
+    for (int h = 0; h < H; ++h) f += p[(size_t)h * M];
+    const float d = 1.0f - f;
+    acc += d * d;
+    if (dmap) dmap[i] = 2.0f * (f - 1.0f) / (float)n * scale;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && map_loss) map_loss[0] = red[0] / (float)n * scale;
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// transpose int32 [B,T] -> [T,B] (first Tp rows)
+__global__ void transpose_ids_kernel(const int32_t* __restrict__ in_bt, int32_t* __restrict__ out_tb, int B, int T,
+                                     int Tp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Tp * B) return;
+  const int t = i / B, b = i % B;
+  out_tb[i] = in_bt[(size_t)b * T + t];
+}
+// tile_batch: out[b*W + w, :] = in[b, :]
+__global__ void tile_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long total, int W, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long r = i / cols;
+  out[i] = in[(size_t)(r / W) * cols + (i % cols)];
+}
+// greedy bookkeeping: first_eos[b] = min(first_eos[b], t) when ids[b] == end
+__global__ void eos_track_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ first_eos, int t, int end_id,
+                                 int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (ids[b] == end_id && first_eos[b] > t) first_eos[b] = t;
+}
+// beam bookkeeping: steps_executed = t+1 at the first step after which every beam is finished
+__global__ void all_finished_kernel(const int32_t* __restrict__ finished, int32_t* __restrict__ steps_executed, int t,
+                                    int n, int max_steps) {
+  __shared__ int any_live;
+  if (threadIdx.x == 0) any_live = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (!finished[i]) any_live = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && !any_live && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
+}
+
+__global__ void beam_init_kernel(float* __restrict__ log_probs, int32_t* __restrict__ finished,
+                                 int64_t* __restrict__ lengths, int R, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const bool first = (i % W) == 0;
+  log_probs[i] = first ? 0.f : -INFINITY;
+  finished[i] = first ? 0 : 1;
+  lengths[i] = 0;
+}
+
+inline int fill(float* p, float v, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p, v, n);
+  COMIC_LAUNCH_CHECK("fill");
+  return 0;
+}
+inline int gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                int ldc, int ta, int tb, float beta, hipStream_t st) {
+  return comic_gemm_f32(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, (void*)st);
+}
+
+int check_desc(const comic_decoder_desc* d) {
+  COMIC_REQUIRE(d, "decoder: null descriptor");
+  COMIC_REQUIRE(d->D > 0 && d->E > 0 && d->A > 0 && d->V > 1 && d->C > 0 && d->Cg > 0 && d->H > 0 && d->M > 0,
+                "decoder: bad dimensions");
+  const int cv = d->fm_projection == 0 ? d->C : d->D;
+  COMIC_REQUIRE(d->Cv == cv, "decoder: Cv must be %d for fm_projection %d", cv, d->fm_projection);
+  const int a = (d->fm_projection == 0 && !d->context_layer) ? d->C : d->D;
+  COMIC_REQUIRE(d->A == a, "decoder: attention size A must be %d", a);
+  return 0;
+}
+
+comic_attn_desc attn_desc(const comic_decoder_desc* d, int rows) {
+  comic_attn_desc a;
+  a.B = rows; a.M = d->M; a.D = d->D; a.H = d->H; a.Cv = d->Cv;
+  a.method = d->method; a.prob = d->prob; a.tied = d->fm_projection == 2;
+  return a;
+}
+
+// keys / values for `rows` feature maps (ops_rnn.py:440-477)
+int memory_projections(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm, int rows,
+                       float* keys, float* values_buf, const float** values, hipStream_t st) {
+  RC(gemm(fm, p->W_m, keys, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
+  if (d->fm_projection == 2) {
+    *values = keys;
+  } else if (d->fm_projection == 1) {
+    RC(gemm(fm, p->W_v, values_buf, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
+    *values = values_buf;
+  } else {
+    *values = fm;
+  }
+  return 0;
+}
+
+struct InitBufs {
+  float *x, *xh, *g, *gates, *c_new;
+};
+
+// _get_rnn_init (model_base.py:651-689) -> c0,h0 [rows,D]
+int rnn_init_fwd(const comic_decoder_desc* d, const comic_decoder_params* p, const float* im_embed, int rows,
+                 const float* mask_init, InitBufs& ib, float* c0, float* h0, hipStream_t st) {
+  const int D = d->D, EA = d->E + d->A;
+  if (d->init_method == 1) {
+    RC(gemm(im_embed, p->W_init, h0, nullptr, rows, D, d->Cg, d->Cg, D, D, 0, 0, 0.f, st));
+    RC(fill(c0, 0.f, (long)rows * D, st));
+    return 0;
+  }
+  RC(gemm(im_embed, p->W_init, ib.x, nullptr, rows, EA, d->Cg, d->Cg, EA, EA, 0, 0, 0.f, st));
+  RC(comic_dropout_apply(ib.x, mask_init, d->keep_in, ib.xh, (int64_t)rows * EA, (void*)st));
+  // zero initial state: only the first E+A rows of the LSTM kernel contribute
+  RC(gemm(ib.xh, p->K, ib.g, p->b, rows, 4 * D, EA, EA, 4 * D, 4 * D, 0, 0, 0.f, st));
+  RC(comic_lstm_gates_fwd(ib.g, nullptr, nullptr, ib.gates, ib.c_new, nullptr, nullptr, nullptr, 1.f, nullptr, 0, c0,
+                          h0, rows, D, (void*)st));
+  return 0;
+}
+
+// one wrapper step without dropout / imputing (inference)
+struct StepBufs {
+  float *xh, *g, *y, *q, *alpha, *ctx, *c2, *h2, *att2;
+};
+int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
+               const float* keys, const float* values, const float* x, const float* c, const float* h,
+               const float* att, StepBufs& sb, float* alpha_d_out, int rows, hipStream_t st) {
+  const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
+  hipLaunchKernelGGL(assemble_input_kernel, dim3(cdiv(rows * Wd, 256)), dim3(256), 0, st, x, att, h, nullptr, 1.f,
+                     sb.xh, rows, E, A, D);
+  COMIC_LAUNCH_CHECK("assemble_input");
+  RC(gemm(sb.xh, p->K, sb.g, p->b, rows, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
+  RC(comic_lstm_gates_fwd(sb.g, c, h, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0, sb.c2, sb.h2, rows,
+                          D, (void*)st));
+  RC(gemm(sb.y, p->W_q, sb.q, nullptr, rows, D, D, D, D, D, 0, 0, 0.f, st));
+  RC(comic_attn_step_fwd(&ad, keys, values, sb.q, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha,
+                         alpha_d_out, sb.ctx, (void*)st));
+  if (d->context_layer) {
+    RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, int B, int T) {
+  if (!d) return -1;
+  Bump w(nullptr, 0);
+  const long D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, Wd = E + A + D;
+  const long TB = (long)T * B;
+  w.take<float>(B * M * D); w.take<float>(B * M * D);              // keys, values
+  w.take<float>(B * (E + A)); w.take<float>(B * (E + A));          // init x, xh
+  w.take<float>(B * 4 * D); w.take<float>(B * 4 * D); w.take<float>(B * D);  // init g, gates, c_new
+  w.take<float>(TB * E); w.take<int32_t>(TB);                      // emb_all, ids_tb
+  w.take<float>(TB * Wd); w.take<float>(B * 4 * D);                // xh_all, g_tmp
+  w.take<float>(TB * 4 * D);                                       // gates_act
+  w.take<float>((TB + B) * D); w.take<float>((TB + B) * D);        // cs, hs
+  w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>(TB * D);  // c_new, y, q
+  w.take<float>(TB * H * M);                                       // alpha
+  w.take<float>(TB * Cv); w.take<float>(B * D); w.take<float>((TB + B) * A);  // ctx, att_new, att
+  w.take<float>(TB * V);                                           // dlogits
+  w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>(TB * 4 * D);    // dy_all, dq_all, dg_all
+  w.take<float>(B * Wd); w.take<float>(B * D); w.take<float>(B * D);          // dxh, dc, dh
+  w.take<float>(B * A); w.take<float>(B * A); w.take<float>(B * Cv);          // datt, datt_live, dctx
+  w.take<float>(TB * E); w.take<float>(B * M * D); w.take<float>(B * M * Cv); // demb, dkeys, dvalues
+  w.take<float>(B * (3 * D + 1)); w.take<float>(TB * M);                       // pgrad, dmap
+  w.take<float>(B * (E + A));                                                  // dx_init
+  return (int64_t)w.off;
+}
+
+extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_params* p,
+                                        const comic_decoder_params* gr, const float* fm, const float* im_embed,
+                                        const int32_t* inputs_bt, const int32_t* targets_bt, const float* wmask_bt,
+                                        const float* coef_bt, const int32_t* lens, int B, int T, int Tp,
+                                        const float* mask_init_in, const float* mask_in, const float* mask_out,
+                                        const float* mask_alpha, float* logits_tb, int32_t* ids_tb, float* attn_hist,
+                                        float* loss_rows, float* map_loss, float* dfm, float* dim_embed,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+  RC(check_desc(d));
+  COMIC_REQUIRE(p && gr && fm && im_embed && inputs_bt && targets_bt && wmask_bt && coef_bt && lens,
+                "train_step: null input");
+  COMIC_REQUIRE(logits_tb && ids_tb && attn_hist && loss_rows && map_loss && workspace, "train_step: null output");
+  COMIC_REQUIRE(B > 0 && T > 0 && Tp > 0 && Tp <= T, "train_step: bad B/T/Tp (%d %d %d)", B, T, Tp);
+  COMIC_REQUIRE(workspace_bytes >= comic_decoder_train_workspace(d, B, T), "train_step: workspace too small");
+  COMIC_REQUIRE(d->keep_in >= 1.f || (mask_in && (d->init_method == 1 || mask_init_in)),
+                "train_step: input dropout enabled but no mask given");
+  COMIC_REQUIRE(d->keep_out >= 1.f || mask_out, "train_step: output dropout enabled but no mask given");
+  COMIC_REQUIRE(d->keep_alpha >= 1.f || mask_alpha, "train_step: attention dropout enabled but no mask given");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, EA = E + A, Wd = E + A + D;
+  const long TB = (long)T * B;
+  const bool drop_in = d->keep_in < 1.f, drop_out = d->keep_out < 1.f, drop_al = d->keep_alpha < 1.f;
+  Bump w(workspace, (size_t)workspace_bytes);
+  float* keys = w.take<float>((long)B * M * D);
+  float* values_buf = w.take<float>((long)B * M * D);
+  InitBufs ib;
+  ib.x = w.take<float>((long)B * EA); ib.xh = w.take<float>((long)B * EA);
+  ib.g = w.take<float>((long)B * 4 * D); ib.gates = w.take<float>((long)B * 4 * D); ib.c_new = w.take<float>((long)B * D);
+  float* emb_all = w.take<float>(TB * E);
+  int32_t* in_tb = w.take<int32_t>(TB);
+  float* xh_all = w.take<float>(TB * Wd);
+  float* g_tmp = w.take<float>((long)B * 4 * D);
+  float* gates_all = w.take<float>(TB * 4 * D);
+  float* cs = w.take<float>((TB + B) * D);
+  float* hs = w.take<float>((TB + B) * D);
+  float* cnew_all = w.take<float>(TB * D);
+  float* y_all = w.take<float>(TB * D);
+  float* q_all = w.take<float>(TB * D);
+  float* alpha_all = w.take<float>(TB * H * M);
+  float* ctx_all = w.take<float>(TB * Cv);
+  float* att_new = w.take<float>((long)B * D);
+  float* att_all = w.take<float>((TB + B) * A);
+  float* dlogits = w.take<float>(TB * V);
+  float* dy_all = w.take<float>(TB * D);
+  float* dq_all = w.take<float>(TB * D);
+  float* dg_all = w.take<float>(TB * 4 * D);
+  float* dxh = w.take<float>((long)B * Wd);
+  float* dc = w.take<float>((long)B * D);
+  float* dh = w.take<float>((long)B * D);
+  float* datt = w.take<float>((long)B * A);
+  float* datt_live = w.take<float>((long)B * A);
+  float* dctx = w.take<float>((long)B * Cv);
+  float* demb = w.take<float>(TB * E);
+  float* dkeys = w.take<float>((long)B * M * D);
+  float* dvalues_buf = w.take<float>((long)B * M * Cv);
+  float* pgrad = w.take<float>((long)B * (3 * D + 1));
+  float* dmap = w.take<float>(TB * M);
+  float* dx_init = w.take<float>((long)B * EA);
+  COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
+
+  const comic_attn_desc ad = attn_desc(d, B);
+  const float* values = nullptr;
+  // ------------------------------------------------------------------ forward ------------
+  RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
+  RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, st));
+  RC(fill(att_all, 0.f, (long)B * A, st));
+  hipLaunchKernelGGL(transpose_ids_kernel, dim3(cdiv(Tp * B, 256)), dim3(256), 0, st, inputs_bt, in_tb, B, T, Tp);
+  COMIC_LAUNCH_CHECK("transpose_ids");
+  RC(comic_embed_fwd(p->emb, in_tb, emb_all, Tp * B, E, V, (void*)st));
+  for (int t = 0; t < Tp; ++t) {
+    float* xh_t = xh_all + (size_t)t * B * Wd;
+    const float* c_prev = cs + (size_t)t * B * D;
+    const float* h_prev = hs + (size_t)t * B * D;
+    const float* att_prev = att_all + (size_t)t * B * A;
+    hipLaunchKernelGGL(assemble_input_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st,
+                       emb_all + (size_t)t * B * E, att_prev, h_prev, drop_in ? mask_in + (size_t)t * B * EA : nullptr,
+                       d->keep_in, xh_t, B, E, A, D);
+    COMIC_LAUNCH_CHECK("assemble_input");
+    RC(gemm(xh_t, p->K, g_tmp, p->b, B, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
+    float* y_t = y_all + (size_t)t * B * D;
+    RC(comic_lstm_gates_fwd(g_tmp, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D, cnew_all + (size_t)t * B * D,
+                            nullptr, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t,
+                            cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D, (void*)st));
+    float* q_t = q_all + (size_t)t * B * D;
+    RC(gemm(y_t, p->W_q, q_t, nullptr, B, D, D, D, D, D, 0, 0, 0.f, st));
+    float* ctx_t = ctx_all + (size_t)t * B * Cv;
+    RC(comic_attn_step_fwd(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau,
+                           drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr, d->keep_alpha,
+                           alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, (void*)st));
+    const float* att_cur = ctx_t;
+    if (d->context_layer) {
+      RC(gemm(ctx_t, p->W_a, att_new, nullptr, B, D, Cv, Cv, D, D, 0, 0, 0.f, st));
+      att_cur = att_new;
+    }
+    hipLaunchKernelGGL(select_rows_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_prev, att_cur, lens, t,
+                       att_all + (size_t)(t + 1) * B * A, B, A);
+    COMIC_LAUNCH_CHECK("select_rows");
+  }
+  // output projection for all executed steps, loss, d logits
+  RC(gemm(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
+  RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
+  for (int t = Tp; t < T; ++t) {  // ops_rnn.py:235-241: pad by copying the last executed step
+    (void)hipMemcpyAsync(logits_tb + (size_t)t * B * V, logits_tb + (size_t)(Tp - 1) * B * V, sizeof(float) * B * V,
+                   hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(ids_tb + (size_t)t * B, ids_tb + (size_t)(Tp - 1) * B, sizeof(int32_t) * B,
+                   hipMemcpyDeviceToDevice, st);
+    RC(fill(loss_rows + (size_t)t * B, 0.f, B, st));
+  }
+  hipLaunchKernelGGL(maploss_kernel, dim3(1), dim3(1024), 0, st, attn_hist, dmap, map_loss, Tp, B, H, M,
+                     d->map_loss_scale);
+  COMIC_LAUNCH_CHECK("maploss");
+
+  // ------------------------------------------------------------------ backward -----------
+  const bool use_map = d->map_loss_scale > 0.f;
+  const bool sep_values = d->fm_projection != 2;
+  float* dvalues = sep_values ? dvalues_buf : dkeys;
+  RC(fill(dkeys, 0.f, (long)B * M * D, st));
+  if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
+  RC(fill(pgrad, 0.f, (long)B * (3 * D + 1), st));
+  RC(fill(dc, 0.f, (long)B * D, st));
+  RC(fill(dh, 0.f, (long)B * D, st));
+  RC(fill(datt, 0.f, (long)B * A, st));
+  // dy_all = dlogits * W_o^T ; dW_o, db_o
+  RC(gemm(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
+  RC(gemm(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
+  RC(comic_colsum(dlogits, gr->b_o, Tp * B, V, 0.f, (void*)st));
+  if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
+  for (int t = Tp - 1; t >= 0; --t) {
+    hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
+    COMIC_LAUNCH_CHECK("split_live");
+    const float* ctx_t = ctx_all + (size_t)t * B * Cv;
+    const float* dctx_t = datt_live;
+    if (d->context_layer) {
+      RC(gemm(ctx_t, datt_live, gr->W_a, nullptr, Cv, D, B, Cv, D, D, 1, 0, 1.f, st));
+      RC(gemm(datt_live, p->W_a, dctx, nullptr, B, Cv, D, D, D, Cv, 0, 1, 0.f, st));
+      dctx_t = dctx;
+    }
+    float* dq_t = dq_all + (size_t)t * B * D;
+    RC(comic_attn_step_bwd(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
+                           alpha_all + (size_t)t * B * H * M, drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr,
+                           d->keep_alpha, dctx_t, use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
+                           pgrad, (void*)st));
+    float* dy_t = dy_all + (size_t)t * B * D;
+    RC(gemm(dq_t, p->W_q, dy_t, nullptr, B, D, D, D, D, D, 0, 1, 1.f, st));
+    float* dg_t = dg_all + (size_t)t * B * 4 * D;
+    RC(comic_lstm_gates_bwd(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D, cnew_all + (size_t)t * B * D,
+                            dy_t, drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh,
+                            dg_t, B, D, (void*)st));
+    RC(gemm(dg_t, p->K, dxh, nullptr, B, Wd, 4 * D, 4 * D, 4 * D, Wd, 0, 1, 0.f, st));
+    hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, dxh,
+                       drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E, datt,
+                       dh, B, E, A, D);
+    COMIC_LAUNCH_CHECK("input_bwd");
+  }
+  // time-batched weight gradients
+  RC(gemm(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
+  RC(comic_colsum(dg_all, gr->b, Tp * B, 4 * D, 0.f, (void*)st));
+  RC(gemm(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, st));
+  RC(fill(gr->emb, 0.f, (long)V * E, st));
+  RC(comic_embed_bwd(in_tb, demb, gr->emb, Tp * B, E, V, (void*)st));
+  // rnn init
+  float* dx_im = nullptr;  // gradient w.r.t. (im_embed * W_init)
+  int n_init = 0;
+  if (d->init_method == 1) {
+    dx_im = dh;
+    n_init = D;
+  } else {
+    RC(comic_lstm_gates_bwd(ib.gates, nullptr, ib.c_new, nullptr, nullptr, 1.f, nullptr, 0, dc, dh, ib.g, B, D,
+                            (void*)st));
+    RC(gemm(ib.xh, ib.g, gr->K, nullptr, EA, 4 * D, B, EA, 4 * D, 4 * D, 1, 0, 1.f, st));
+    RC(comic_colsum(ib.g, gr->b, B, 4 * D, 1.f, (void*)st));
+    RC(gemm(ib.g, p->K, dx_init, nullptr, B, EA, 4 * D, 4 * D, 4 * D, EA, 0, 1, 0.f, st));
+    if (drop_in) RC(comic_dropout_apply(dx_init, mask_init_in, d->keep_in, dx_init, (int64_t)B * EA, (void*)st));
+    dx_im = dx_init;
+    n_init = EA;
+  }
+  RC(gemm(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
+  if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
+  // memory projections
+  RC(gemm(fm, dkeys, gr->W_m, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
+  if (dfm) RC(gemm(dkeys, p->W_m, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 0.f, st));
+  if (d->fm_projection == 1) {
+    RC(gemm(fm, dvalues_buf, gr->W_v, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
+    if (dfm) RC(gemm(dvalues_buf, p->W_v, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 1.f, st));
+  } else if (d->fm_projection == 0 && dfm) {
+    RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)st));
+  }
+  // attention parameters
+  if (d->method == 0) {
+    // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter.
+    // dg_all is free again here (its last reader, the dK GEMM, is ordered before on `st`).
+    float* tmp = dg_all;
+    RC(comic_colsum(pgrad, tmp, B, 3 * D + 1, 0.f, (void*)st));
+    (void)hipMemcpyAsync(gr->v, tmp, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(gr->ln_g, tmp + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(gr->ln_b, tmp + 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(gr->tau, tmp + 3 * D, sizeof(float), hipMemcpyDeviceToDevice, st);
+  }
+  COMIC_LAUNCH_CHECK("train_step");
+  return 0;
+}
+
+extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int max_steps) {
+  if (!d) return -1;
+  (void)max_steps;
+  Bump w(nullptr, 0);
+  const long D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, Wd = E + A + D, R = rows;
+  w.take<float>(R * M * d->C); w.take<float>(R * d->Cg);           // tiled fm, im_embed
+  w.take<float>(R * M * D); w.take<float>(R * M * D);              // keys, values
+  w.take<float>(R * (E + A)); w.take<float>(R * (E + A)); w.take<float>(R * 4 * D); w.take<float>(R * 4 * D);
+  w.take<float>(R * D);                                            // init bufs
+  w.take<float>(R * Wd); w.take<float>(R * 4 * D); w.take<float>(R * D); w.take<float>(R * D);  // xh,g,y,q
+  w.take<float>(R * H * M); w.take<float>(R * Cv);                 // alpha, ctx
+  for (int i = 0; i < 4; ++i) w.take<float>(R * D);                // c,h ping-pong
+  w.take<float>(R * D);                                            // att2 (context layer)
+  for (int i = 0; i < 2; ++i) w.take<float>(R * A);                // att ping-pong
+  w.take<float>(R * E); w.take<float>(R * V);                      // x, logits
+  w.take<int32_t>(R); w.take<float>(R); w.take<int32_t>(R);        // ids, log_probs, parents
+  w.take<float>(R * (2 * D + A));                                  // gather temp
+  return (int64_t)w.off;
+}
+
+namespace {
+struct InferBufs {
+  float *fm_t, *im_t, *keys, *values_buf;
+  InitBufs ib;
+  StepBufs sb;
+  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp;
+  int32_t *ids, *parents;
+  bool ok;
+};
+InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t bytes) {
+  Bump w(ws, (size_t)bytes);
+  const long D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, Wd = E + A + D, R = rows;
+  InferBufs b;
+  b.fm_t = w.take<float>(R * M * d->C); b.im_t = w.take<float>(R * d->Cg);
+  b.keys = w.take<float>(R * M * D); b.values_buf = w.take<float>(R * M * D);
+  b.ib.x = w.take<float>(R * (E + A)); b.ib.xh = w.take<float>(R * (E + A));
+  b.ib.g = w.take<float>(R * 4 * D); b.ib.gates = w.take<float>(R * 4 * D); b.ib.c_new = w.take<float>(R * D);
+  b.sb.xh = w.take<float>(R * Wd); b.sb.g = w.take<float>(R * 4 * D); b.sb.y = w.take<float>(R * D);
+  b.sb.q = w.take<float>(R * D); b.sb.alpha = w.take<float>(R * H * M); b.sb.ctx = w.take<float>(R * Cv);
+  b.c[0] = w.take<float>(R * D); b.c[1] = w.take<float>(R * D);
+  b.h[0] = w.take<float>(R * D); b.h[1] = w.take<float>(R * D);
+  b.sb.att2 = w.take<float>(R * D);
+  b.att[0] = w.take<float>(R * A); b.att[1] = w.take<float>(R * A);
+  b.x = w.take<float>(R * E); b.logits = w.take<float>(R * V);
+  b.ids = w.take<int32_t>(R); b.log_probs = w.take<float>(R); b.parents = w.take<int32_t>(R);
+  b.gtmp = w.take<float>(R * (2 * D + A));
+  b.ok = w.ok;
+  return b;
+}
+}  // namespace
+
+extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                                    const float* im_embed, int B, int max_steps, int32_t* ids_tb, float* logits_tb,
+                                    float* attn_hist, int32_t* first_eos, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+  RC(check_desc(d));
+  COMIC_REQUIRE(p && fm && im_embed && ids_tb && attn_hist && first_eos && workspace, "greedy: null pointer");
+  COMIC_REQUIRE(B > 0 && max_steps > 0, "greedy: bad shape");
+  COMIC_REQUIRE(workspace_bytes >= comic_decoder_infer_workspace(d, B, max_steps), "greedy: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  InferBufs ws = carve_infer(d, B, workspace, workspace_bytes);
+  COMIC_REQUIRE(ws.ok, "greedy: workspace overflow");
+  const int D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv;
+  const comic_attn_desc ad = attn_desc(d, B);
+  const float* values = nullptr;
+  RC(memory_projections(d, p, fm, B, ws.keys, ws.values_buf, &values, st));
+  RC(rnn_init_fwd(d, p, im_embed, B, nullptr, ws.ib, ws.c[0], ws.h[0], st));
+  RC(fill(ws.att[0], 0.f, (long)B * A, st));
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)B);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, first_eos, max_steps, (long)B);
+  COMIC_LAUNCH_CHECK("greedy init");
+  for (int t = 0; t < max_steps; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    RC(comic_embed_fwd(p->emb, ws.ids, ws.x, B, E, V, (void*)st));
+    ws.sb.c2 = ws.c[nxt];
+    ws.sb.h2 = ws.h[nxt];
+    float* att_next = ws.att[nxt];
+    StepBufs sb = ws.sb;
+    if (!d->context_layer) sb.ctx = att_next;  // context written straight into the next attention state
+    else sb.att2 = att_next;
+    RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
+                  attn_hist + (size_t)t * B * H * M, B, st));
+    float* lg = logits_tb ? logits_tb + (size_t)t * B * V : ws.logits;
+    RC(gemm(sb.y, p->W_o, lg, p->b_o, B, V, D, D, V, V, 0, 0, 0.f, st));
+    RC(comic_argmax_rows(lg, ws.ids, B, V, (void*)st));
+    (void)hipMemcpyAsync(ids_tb + (size_t)t * B, ws.ids, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(eos_track_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws.ids, first_eos, t, d->end_id, B);
+    COMIC_LAUNCH_CHECK("eos_track");
+  }
+  (void)Cv; (void)M;
+  return 0;
+}
+
+extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                                  const float* im_embed, int B, int W, int max_steps, int32_t* step_ids,
+                                  int32_t* parent_ids, float* scores, int64_t* lengths, int32_t* finished,
+                                  float* attn_hist, int32_t* steps_executed, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  RC(check_desc(d));
+  COMIC_REQUIRE(p && fm && im_embed && step_ids && parent_ids && scores && lengths && finished && attn_hist &&
+                    steps_executed && workspace,
+                "beam: null pointer");
+  COMIC_REQUIRE(B > 0 && W > 0 && W <= 64 && max_steps > 0, "beam: bad shape");
+  const int R = B * W;
+  COMIC_REQUIRE(workspace_bytes >= comic_decoder_infer_workspace(d, R, max_steps), "beam: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  InferBufs ws = carve_infer(d, R, workspace, workspace_bytes);
+  COMIC_REQUIRE(ws.ok, "beam: workspace overflow");
+  const int D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H;
+  // tile_batch BEFORE keys are computed (model_base.py:127-131)
+  {
+    const long n1 = (long)R * M * d->C, n2 = (long)R * d->Cg;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)cdiv64(n1, 256)), dim3(256), 0, st, fm, ws.fm_t, n1, W,
+                       M * d->C);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)cdiv64(n2, 256)), dim3(256), 0, st, im_embed, ws.im_t, n2, W,
+                       d->Cg);
+    COMIC_LAUNCH_CHECK("tile_rows");
+  }
+  const comic_attn_desc ad = attn_desc(d, R);
+  const float* values = nullptr;
+  RC(memory_projections(d, p, ws.fm_t, R, ws.keys, ws.values_buf, &values, st));
+  RC(rnn_init_fwd(d, p, ws.im_t, R, nullptr, ws.ib, ws.c[0], ws.h[0], st));
+  RC(fill(ws.att[0], 0.f, (long)R * A, st));
+  // initial beam state: log_probs [0,-inf,...], finished [0,1,...], lengths 0
+  hipLaunchKernelGGL(beam_init_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, ws.log_probs, finished, lengths, R, W);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)R);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps_executed, max_steps, 1L);
+  COMIC_LAUNCH_CHECK("beam init");
+  int cur = 0;
+  for (int t = 0; t < max_steps; ++t) {
+    RC(comic_embed_fwd(p->emb, ws.ids, ws.x, R, E, V, (void*)st));
+    StepBufs sb = ws.sb;
+    sb.c2 = ws.gtmp;
+    sb.h2 = ws.gtmp + (size_t)R * D;
+    float* att_new = ws.gtmp + (size_t)2 * R * D;
+    if (!d->context_layer) sb.ctx = att_new;
+    else sb.att2 = att_new;
+    RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
+                  attn_hist + (size_t)t * R * H * M, R, st));
+    RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
+    int32_t* word = step_ids + (size_t)t * R;
+    int32_t* parent = parent_ids + (size_t)t * R;
+    RC(comic_beam_step(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                       d->end_id, (void*)st));
+    const int nxt = cur ^ 1;
+    RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));
+    RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
+    RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));
+    (void)hipMemcpyAsync(ws.ids, word, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(all_finished_kernel, dim3(1), dim3(256), 0, st, finished, steps_executed, t, R, max_steps);
+    COMIC_LAUNCH_CHECK("all_finished");
+    cur = nxt;
+  }
+  return 0;
+}

@@ -1,0 +1,422 @@
+"""Host side of the attention-LSTM decoder: parameter storage, input processing and the
+calls into the native executors (`comic_decoder_train_step / _greedy / _beam`).
+
+Counterpart of the decoder half of `ModelBase` (reference src/model_base.py:109-314,
+:501-757) and of `common/ops_rnn.py`'s three dynamic-decode builders.  All arithmetic is in
+the HIP library; this module only prepares integer/mask tables on the host (the reference
+does the same work in `_process_inputs`, model_base.py:501-528) and post-processes ids.
+
+Parameters live in ONE flat fp32 device buffer (views per variable) so that the optimiser
+is a single fused kernel and the data-parallel gradient exchange is a single all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from .ops import number_to_base
+
+# TF variable names (scope Model/decoder/rnn_decoder/), SURVEY Appendix C
+TF_NAMES = {
+    'W_init': {'first_input': 'rnn_init_input/projection/weight', 'project_hidden': 'rnn_initial_state/weight'},
+    'K': 'rnn_init_input/basic_lstm_cell/kernel', 'b': 'rnn_init_input/basic_lstm_cell/bias',
+    'W_m': 'memory_layer/kernel', 'W_v': 'value_layer/kernel',
+    'W_q': 'multi_add_attention/query_layer/kernel', 'v': 'multi_add_attention/attention_v',
+    'ln_g': 'multi_add_attention/LN_tanh/gamma', 'ln_b': 'multi_add_attention/LN_tanh/beta',
+    'tau': 'softmax_temperature', 'W_a': 'a_layer/kernel',
+    'W_o': 'output_projection/kernel', 'b_o': 'output_projection/bias', 'emb': 'embedding_map',
+}
+
+
+@dataclass
+class DecoderSpec:
+    """Static decoder geometry derived from a reference `Config` (src/train.py:29-162)."""
+    D: int = 512
+    E: int = 256
+    V: int = 258
+    C: int = 2048
+    Cg: int = 2048
+    H: int = 8
+    M: int = 25
+    fm_projection: str | None = 'tied'
+    method: str = 'add_LN'
+    prob: str = 'softmax'
+    context_layer: bool = False
+    init_method: str = 'first_input'
+    token_type: str = 'radix'
+    start_id: int = 256
+    end_id: int = 257
+    dropout_rnn_in: float = 0.35
+    dropout_rnn_out: float = 0.35
+    attn_keep_prob: float = 0.9
+    map_loss_scale: float = 1.0
+    l2_decay: float = 1e-5
+
+    @property
+    def A(self):                     # model_base.py:611-615
+        return self.C if (self.fm_projection is None and not self.context_layer) else self.D
+
+    @property
+    def Cv(self):
+        return self.C if self.fm_projection is None else self.D
+
+    @classmethod
+    def from_config(cls, c, fm_shape, im_embed_size):
+        """c: reference-style Config (token_type, radix_base, rnn_size, ... itow/wtoi)."""
+        if c.rnn_name != 'LSTM':
+            raise NotImplementedError('only rnn_name=LSTM is on the MI355X hot path')
+        if c.attn_alignment_method not in ('add_LN', 'dot'):
+            raise ValueError('Invalid alignment method.')          # model_base.py:133-138
+        if c.attn_probability_fn not in ('softmax', 'sigmoid'):
+            raise ValueError('Invalid alignment method.')
+        if c.token_type == 'radix':
+            V, start, end = c.radix_base + 2, c.radix_base, c.radix_base + 1     # model_base.py:42-43,701-703
+        else:
+            V, start, end = len(c.itow), c.wtoi['<GO>'], c.wtoi['<EOS>']
+        return cls(D=c.rnn_size, E=c.rnn_word_size, V=V, C=fm_shape[-1], Cg=im_embed_size, H=c.attn_num_heads,
+                   M=fm_shape[-2], fm_projection=c.cnn_fm_projection, method=c.attn_alignment_method,
+                   prob=c.attn_probability_fn, context_layer=bool(c.attn_context_layer),
+                   init_method=c.rnn_init_method, token_type=c.token_type, start_id=start, end_id=end,
+                   dropout_rnn_in=getattr(c, 'dropout_rnn_in', 0.35), dropout_rnn_out=getattr(c, 'dropout_rnn_out', 0.35),
+                   attn_keep_prob=c.attn_keep_prob, map_loss_scale=getattr(c, 'rnn_map_loss_scale', 1.0),
+                   l2_decay=getattr(c, 'l2_decay', 1e-5))
+
+    def param_shapes(self):
+        D, E, A, V, C_, Cg = self.D, self.E, self.A, self.V, self.C, self.Cg
+        s = {}
+        s['W_init'] = (Cg, E + A) if self.init_method == 'first_input' else (Cg, D)
+        s['K'] = (E + A + D, 4 * D)
+        s['b'] = (4 * D,)
+        s['W_m'] = (C_, D)
+        if self.fm_projection == 'independent':
+            s['W_v'] = (C_, D)
+        s['W_q'] = (D, D)
+        if self.method == 'add_LN':
+            s['v'] = (D,); s['ln_g'] = (D,); s['ln_b'] = (D,); s['tau'] = ()
+        if self.context_layer:
+            s['W_a'] = (self.Cv, D)
+        s['W_o'] = (D, V)
+        s['b_o'] = (V,)
+        s['emb'] = (V, E)
+        return s
+
+    def desc(self, training):
+        d = L.DecoderDesc()
+        d.D, d.E, d.A, d.V, d.C, d.Cg, d.H, d.M, d.Cv = (self.D, self.E, self.A, self.V, self.C, self.Cg, self.H,
+                                                       self.M, self.Cv)
+        d.fm_projection = {None: 0, 'independent': 1, 'tied': 2}[self.fm_projection]
+        d.method = {'add_LN': 0, 'dot': 1}[self.method]
+        d.prob = {'softmax': 0, 'sigmoid': 1}[self.prob]
+        d.context_layer = int(self.context_layer)
+        d.init_method = {'first_input': 0, 'project_hidden': 1}[self.init_method]
+        d.start_id, d.end_id = self.start_id, self.end_id
+        d.keep_in = 1.0 - self.dropout_rnn_in if training else 1.0
+        d.keep_out = 1.0 - self.dropout_rnn_out if training else 1.0
+        d.keep_alpha = self.attn_keep_prob if training else 1.0
+        d.map_loss_scale = self.map_loss_scale
+        return d
+
+
+def xavier_uniform(rng, shape):
+    """slim.xavier_initializer() [TF-1.9] (model_base.py:823-831)."""
+    if len(shape) > 1:
+        fi, fo = shape[-2], shape[-1]
+    else:
+        fi = fo = shape[-1]
+    lim = math.sqrt(6.0 / (fi + fo))
+    return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+def init_params(spec: DecoderSpec, seed=0):
+    rng = np.random.default_rng(seed)
+    p = {}
+    for k, shp in spec.param_shapes().items():
+        if k in ('b', 'b_o', 'ln_b'):
+            p[k] = np.zeros(shp, np.float32)
+        elif k == 'ln_g':
+            p[k] = np.ones(shp, np.float32)
+        elif k == 'tau':
+            p[k] = np.array(5.0, np.float32)                       # ops_rnn.py:559
+        else:
+            p[k] = xavier_uniform(rng, shp)
+    return p
+
+
+class FlatParams:
+    """One flat fp32 device buffer with named views (+ identical layouts for grads/Adam slots)."""
+    ALIGN = 64      # floats: keeps every view 256-byte aligned (16-byte vector loads in the GEMM)
+
+    def __init__(self, shapes: dict, device='cuda:0'):
+        import torch
+        self.torch = torch
+        self.shapes = dict(shapes)
+        self.offsets = {}
+        off = 0
+        for k, shp in shapes.items():
+            self.offsets[k] = off
+            n = int(np.prod(shp)) if len(shp) else 1
+            off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        self.device = device
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def like(self):
+        o = FlatParams.__new__(FlatParams)
+        o.torch, o.shapes, o.offsets, o.numel, o.device = self.torch, self.shapes, self.offsets, self.numel, self.device
+        o.data = self.torch.zeros(self.numel, dtype=self.torch.float32, device=self.device)
+        return o
+
+    def view(self, k):
+        shp = self.shapes[k]
+        n = int(np.prod(shp)) if len(shp) else 1
+        return self.data[self.offsets[k]:self.offsets[k] + n].view(*shp) if len(shp) else \
+            self.data[self.offsets[k]:self.offsets[k] + 1]
+
+    def load(self, values: dict):
+        for k in self.shapes:
+            v = self.torch.from_numpy(np.ascontiguousarray(values[k], np.float32).reshape(-1))
+            self.view(k).reshape(-1).copy_(v)
+
+    def to_numpy(self):
+        return {k: self.view(k).detach().cpu().numpy().reshape(self.shapes[k]) for k in self.shapes}
+
+    def table(self):
+        t = L.DecoderParams()
+        base = self.data.data_ptr()
+        for k in L.PARAM_NAMES:
+            setattr(t, k, base + 4 * self.offsets[k] if k in self.offsets else None)
+        return t
+
+    def n_params(self):
+        return int(sum(int(np.prod(s)) if len(s) else 1 for s in self.shapes.values()))
+
+
+def process_inputs(captions, token_type):
+    """ModelBase._process_inputs (model_base.py:501-528) on the host.
+    -> inputs [B,T] int32, targets [B,T] int32, masks [B,T] fp32, lens [B] int32."""
+    sent = np.asarray(captions, np.int64)
+    masks = np.sign((sent[:, 1:] + 1).astype(np.float32))
+    lens = masks.sum(axis=1).astype(np.int32)
+    if token_type == 'word':
+        sent = np.maximum(sent, 0)
+        inputs = sent[:, :-1]
+    else:
+        inputs = sent[:, :-1]
+        sent = np.maximum(sent, 0)
+    targets = sent[:, 1:]
+    return (np.ascontiguousarray(inputs, np.int32), np.ascontiguousarray(targets, np.int32),
+            np.ascontiguousarray(masks, np.float32), lens)
+
+
+class Decoder:
+    """Device decoder: parameters, gradients and native step calls."""
+
+    def __init__(self, spec: DecoderSpec, params: dict | None = None, device='cuda:0', seed=0):
+        import torch
+        self.torch = torch
+        self.lib = L.load()
+        self.spec, self.device = spec, device
+        self.params = FlatParams(spec.param_shapes(), device)
+        self.params.load(params if params is not None else init_params(spec, seed))
+        self.grads = self.params.like()
+        self._ws = None
+        self._ws_bytes = 0
+        self._dropout_calls = 0
+
+    # ------------------------------------------------------------------ helpers --------
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws_bytes < nbytes:
+            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            self._ws_bytes = int(nbytes)
+        return self._ws
+
+    def _dev(self, a, dtype=None):
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device, non_blocking=False)
+
+    def make_masks(self, B, Tp, seed):
+        """Bernoulli keep masks generated on the device (counter-based; TF's RNG stream is
+        not reproducible, SURVEY §7 'Dropout parity')."""
+        torch, s = self.torch, self.spec
+        EA = s.E + s.A
+        out = {}
+        off = 0
+        for name, shape, keep in (('init_in', (B, EA), 1 - s.dropout_rnn_in), ('inp', (Tp, B, EA), 1 - s.dropout_rnn_in),
+                                  ('out', (Tp, B, s.D), 1 - s.dropout_rnn_out),
+                                  ('alpha', (Tp, B, s.H, s.M), s.attn_keep_prob)):
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            L.check(self.lib.comic_dropout_mask(t.data_ptr(), t.numel(), keep, int(seed), off, L.stream_ptr()),
+                    'dropout_mask')
+            off += t.numel()
+            out[name] = t
+        return out
+
+    # ------------------------------------------------------------------ training -------
+    def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
+                   want_input_grads=False):
+        """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
+        masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
+        device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
+        mean_b(xent_b * reward_b) (model_base.py:342-347).
+        Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device)."""
+        torch, s = self.torch, self.spec
+        inputs, targets, wmask, lens = process_inputs(captions, s.token_type)
+        B, T = inputs.shape
+        Tp = int(lens.max())
+        if rewards is None:
+            coef = wmask / np.float32(wmask.sum() + np.float32(1e-12))
+        else:
+            den = wmask.sum(axis=1, keepdims=True) + np.float32(1e-12)
+            coef = wmask / den * (np.asarray(rewards, np.float32)[:, None] / np.float32(B))
+        desc = s.desc(training)
+        if training and masks is None:
+            if seed is None:
+                self._dropout_calls += 1
+                seed = 0x9E3779B9 + self._dropout_calls
+            masks = self.make_masks(B, Tp, seed)
+        if masks is not None:
+            masks = {k: (v if torch.is_tensor(v) else self._dev(v, torch.float32)) for k, v in masks.items()}
+        else:
+            desc.keep_in = desc.keep_out = desc.keep_alpha = 1.0
+        fm = fm.contiguous(); im_embed = im_embed.contiguous()
+        assert fm.shape == (B, s.M, s.C) and im_embed.shape == (B, s.Cg), (fm.shape, im_embed.shape)
+        assert fm.dtype == torch.float32 and im_embed.dtype == torch.float32
+        d_in, d_tg = self._dev(inputs), self._dev(targets)
+        d_wm, d_cf, d_ln = self._dev(wmask), self._dev(coef.astype(np.float32)), self._dev(lens)
+        logits = torch.empty((T, B, s.V), dtype=torch.float32, device=self.device)
+        ids = torch.empty((T, B), dtype=torch.int32, device=self.device)
+        hist = torch.empty((Tp, B, s.H, s.M), dtype=torch.float32, device=self.device)
+        loss_rows = torch.empty(T * B, dtype=torch.float32, device=self.device)
+        map_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        dfm = torch.empty_like(fm) if want_input_grads else None
+        dim = torch.empty_like(im_embed) if want_input_grads else None
+        nbytes = self.lib.comic_decoder_train_workspace(C.byref(desc), B, T)
+        ws = self._workspace(nbytes)
+        ptab, gtab = self.params.table(), self.grads.table()
+        m = masks or {}
+        L.check(self.lib.comic_decoder_train_step(
+            C.byref(desc), C.byref(ptab), C.byref(gtab), fm.data_ptr(), im_embed.data_ptr(), d_in.data_ptr(),
+            d_tg.data_ptr(), d_wm.data_ptr(), d_cf.data_ptr(), d_ln.data_ptr(), B, T, Tp,
+            L.ptr(m.get('init_in')), L.ptr(m.get('inp')), L.ptr(m.get('out')), L.ptr(m.get('alpha')),
+            logits.data_ptr(), ids.data_ptr(), hist.data_ptr(), loss_rows.data_ptr(), map_loss.data_ptr(),
+            L.ptr(dfm), L.ptr(dim), ws.data_ptr(), nbytes, L.stream_ptr()), 'decoder_train_step')
+        # sequence_loss reduction (model_base.py:337-347): rows already carry xent*w
+        lr = loss_rows.view(T, B)
+        if rewards is None:
+            xe = lr.sum() / float(wmask.sum() + np.float32(1e-12))
+        else:
+            den_t = self._dev((wmask.sum(axis=1) + np.float32(1e-12)).astype(np.float32))
+            xe = ((lr.sum(dim=0) / den_t) * self._dev(np.asarray(rewards, np.float32))).mean()
+        return dict(loss=xe, map_loss=map_loss[0], logits=logits.permute(1, 0, 2), ids=ids.t(),
+                    attn_maps=hist.permute(1, 2, 0, 3), dfm=dfm, dim_embed=dim, Tp=Tp)
+
+    # ------------------------------------------------------------------ decoding -------
+    def max_iterations(self, infer_max_length, vocab_len):
+        """model_base.py:708-714."""
+        it = infer_max_length
+        if self.spec.token_type == 'radix':
+            it *= len(number_to_base(vocab_len, self.spec.start_id))    # start_id == radix_base
+        elif self.spec.token_type == 'char':
+            it *= 5
+        return it
+
+    def greedy(self, fm, im_embed, max_steps, want_logits=False):
+        """rnn_decoder_search(greedy) (ops_rnn.py:115-180).  -> ids [B,T_exec] (numpy int32),
+        attn_maps [B,H,T_exec,M] (device), logits [B,T_exec,V] or None."""
+        torch, s = self.torch, self.spec
+        B = fm.shape[0]
+        desc = s.desc(False)
+        ids = torch.empty((max_steps, B), dtype=torch.int32, device=self.device)
+        logits = torch.empty((max_steps, B, s.V), dtype=torch.float32, device=self.device) if want_logits else None
+        hist = torch.empty((max_steps, B, s.H, s.M), dtype=torch.float32, device=self.device)
+        first_eos = torch.empty(B, dtype=torch.int32, device=self.device)
+        nbytes = self.lib.comic_decoder_infer_workspace(C.byref(desc), B, max_steps)
+        ws = self._workspace(nbytes)
+        ptab = self.params.table()
+        L.check(self.lib.comic_decoder_greedy(C.byref(desc), C.byref(ptab), fm.contiguous().data_ptr(),
+                                              im_embed.contiguous().data_ptr(), B, max_steps, ids.data_ptr(),
+                                              L.ptr(logits), hist.data_ptr(), first_eos.data_ptr(), ws.data_ptr(),
+                                              nbytes, L.stream_ptr()), 'decoder_greedy')
+        fe = first_eos.cpu().numpy()
+        t_exec = int(min(max_steps, fe.max() + 1))       # loop ends when every row has emitted EOS
+        out_ids = ids[:t_exec].t().contiguous().cpu().numpy()
+        return out_ids, hist[:t_exec].permute(1, 2, 0, 3), (logits[:t_exec].permute(1, 0, 2) if want_logits else None)
+
+    def beam_search(self, fm, im_embed, beam, max_steps):
+        """rnn_decoder_beam_search (ops_rnn.py:49-112).  Returns predicted_ids [T,B,W] (after
+        gather_tree), scores [T,B,W], beam-sorted alignment history [T,B*W,H*M] (numpy) and the
+        raw step/parent ids."""
+        torch, s = self.torch, self.spec
+        B, W = fm.shape[0], beam
+        R = B * W
+        desc = s.desc(False)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        step_ids = torch.empty((max_steps, B, W), **i32)
+        parent_ids = torch.empty((max_steps, B, W), **i32)
+        scores = torch.empty((max_steps, B, W), dtype=torch.float32, device=self.device)
+        lengths = torch.empty((B, W), dtype=torch.int64, device=self.device)
+        finished = torch.empty((B, W), **i32)
+        hist = torch.empty((max_steps, R, s.H * s.M), dtype=torch.float32, device=self.device)
+        steps = torch.empty(1, **i32)
+        nbytes = self.lib.comic_decoder_infer_workspace(C.byref(desc), R, max_steps)
+        ws = self._workspace(nbytes)
+        ptab = self.params.table()
+        L.check(self.lib.comic_decoder_beam(C.byref(desc), C.byref(ptab), fm.contiguous().data_ptr(),
+                                            im_embed.contiguous().data_ptr(), B, W, max_steps, step_ids.data_ptr(),
+                                            parent_ids.data_ptr(), scores.data_ptr(), lengths.data_ptr(),
+                                            finished.data_ptr(), hist.data_ptr(), steps.data_ptr(), ws.data_ptr(),
+                                            nbytes, L.stream_ptr()), 'decoder_beam')
+        T = int(steps.item())
+        max_len = lengths.max(dim=1).values.to(torch.int32).contiguous()
+        pred = torch.empty((T, B, W), **i32)
+        L.check(self.lib.comic_gather_tree(step_ids[:T].contiguous().data_ptr(), parent_ids[:T].contiguous().data_ptr(),
+                                           max_len.data_ptr(), pred.data_ptr(), T, B, W, s.end_id, L.stream_ptr()),
+                'gather_tree')
+        par = parent_ids[:T].cpu().numpy()
+        ln = lengths.cpu().numpy()
+        hist_sorted = gather_tree_from_array(hist[:T].cpu().numpy(), par, ln, s.end_id)
+        return dict(predicted_ids=pred.cpu().numpy(), scores=scores[:T].cpu().numpy(), attn_hist=hist_sorted,
+                    step_ids=step_ids[:T].cpu().numpy(), parent_ids=par, lengths=ln)
+
+
+def _gather_tree_host(step_ids, parent_ids, max_len, end_token):
+    T, B, W = parent_ids.shape
+    beams = np.full((T, B, W), end_token, np.int32)
+    for b in range(B):
+        Lb = min(T, int(max_len[b]))
+        if Lb <= 0:
+            continue
+        for w in range(W):
+            beams[Lb - 1, b, w] = step_ids[Lb - 1, b, w]
+            parent = parent_ids[Lb - 1, b, w]
+            for level in range(Lb - 2, -1, -1):
+                beams[level, b, w] = step_ids[level, b, parent]
+                parent = parent_ids[level, b, parent]
+            fin = False
+            for t in range(Lb):
+                if fin:
+                    beams[t, b, w] = end_token
+                elif beams[t, b, w] == end_token:
+                    fin = True
+    return beams
+
+
+def gather_tree_from_array(t, parent_ids, sequence_length, _unused_end=None):
+    """Beam-sort a per-step state array [T, B*W, S] (BeamSearchDecoderMultiHead.
+    _maybe_sort_array_beams, ops_rnn.py:807-845 -> [TF-1.9] gather_tree_from_array).
+    Host post-processing of the alignment history (small, index-only)."""
+    T, B, W = parent_ids.shape
+    beam_ids = np.tile(np.arange(W, dtype=np.int32)[None, None, :], (T, B, 1))
+    mask = (np.arange(T)[None, None, :] < np.asarray(sequence_length)[:, :, None]).transpose(2, 0, 1)
+    masked = np.where(mask, beam_ids, W + 1).astype(np.int32)
+    max_len = np.asarray(sequence_length).max(axis=1)
+    sorted_ids = _gather_tree_host(masked, parent_ids, max_len, W + 1)
+    sorted_ids = np.where(mask, sorted_ids, beam_ids)
+    src = np.asarray(t).reshape(T, B, W, -1)
+    return src[np.arange(T)[:, None, None], np.arange(B)[None, :, None], sorted_ids].reshape(np.asarray(t).shape)

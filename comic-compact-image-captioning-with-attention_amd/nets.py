@@ -1,0 +1,305 @@
+"""CNN encoder plans (table-driven) and the device-side encoder object.
+
+Counterpart of `nets_factory.get_network_fn(cnn_name, num_classes=None, is_training=False)`
+(reference common/nets/nets_factory.py:116-159) + `ModelBase._encoder`
+(src/model_base.py:56-104) for the backbone on the hot path: InceptionV3
+(common/nets/inception_v3.py:100-415, head :520-532).  The network is described as a flat
+list of `comic_cnn_op` records over a buffer table; branch outputs are written straight
+into channel slices of the block's output buffer (tf.concat without a copy) and the whole
+plan is executed by one native call (`comic_cnn_forward`).
+
+Variable names follow the slim checkpoint (`InceptionV3/<scope>/weights`,
+`.../BatchNorm/{beta,moving_mean,moving_variance}`) so checkpoints map 1:1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+BN_EPS = 1e-3            # inception_utils.py:36
+
+# --- InceptionV3 topology as data ------------------------------------------------------
+# op forms: ('c', scope, cout, (kh,kw), stride, 'SAME'|'VALID') | ('avg',) | ('max',)
+#           | ('fork', [op, op])  -> two convs on the same input, outputs concatenated
+_STEM = [('c', 'Conv2d_1a_3x3', 32, (3, 3), 2, 'VALID'), ('c', 'Conv2d_2a_3x3', 32, (3, 3), 1, 'VALID'),
+         ('c', 'Conv2d_2b_3x3', 64, (3, 3), 1, 'SAME'), ('max', 'MaxPool_3a_3x3'),
+         ('c', 'Conv2d_3b_1x1', 80, (1, 1), 1, 'VALID'), ('c', 'Conv2d_4a_3x3', 192, (3, 3), 1, 'VALID'),
+         ('max', 'MaxPool_5a_3x3')]
+
+
+def _c(scope, cout, k, stride=1, pad='SAME'):
+    return ('c', scope, cout, k if isinstance(k, tuple) else (k, k), stride, pad)
+
+
+def _mixed5(pool_c, b1):
+    return [[_c('Conv2d_0a_1x1', 64, 1)],
+            [_c(b1[0], 48, 1), _c(b1[1], 64, 5)],
+            [_c('Conv2d_0a_1x1', 64, 1), _c('Conv2d_0b_3x3', 96, 3), _c('Conv2d_0c_3x3', 96, 3)],
+            [('avg',), _c('Conv2d_0b_1x1', pool_c, 1)]]
+
+
+def _mixed6(d):
+    return [[_c('Conv2d_0a_1x1', 192, 1)],
+            [_c('Conv2d_0a_1x1', d, 1), _c('Conv2d_0b_1x7', d, (1, 7)), _c('Conv2d_0c_7x1', 192, (7, 1))],
+            [_c('Conv2d_0a_1x1', d, 1), _c('Conv2d_0b_7x1', d, (7, 1)), _c('Conv2d_0c_1x7', d, (1, 7)),
+             _c('Conv2d_0d_7x1', d, (7, 1)), _c('Conv2d_0e_1x7', 192, (1, 7))],
+            [('avg',), _c('Conv2d_0b_1x1', 192, 1)]]
+
+
+def _mixed7(b1b):
+    return [[_c('Conv2d_0a_1x1', 320, 1)],
+            [_c('Conv2d_0a_1x1', 384, 1), ('fork', [_c('Conv2d_0b_1x3', 384, (1, 3)), _c(b1b, 384, (3, 1))])],
+            [_c('Conv2d_0a_1x1', 448, 1), _c('Conv2d_0b_3x3', 384, 3),
+             ('fork', [_c('Conv2d_0c_1x3', 384, (1, 3)), _c('Conv2d_0d_3x1', 384, (3, 1))])],
+            [('avg',), _c('Conv2d_0b_1x1', 192, 1)]]
+
+
+INCEPTION_V3_BLOCKS = [
+    ('Mixed_5b', _mixed5(32, ('Conv2d_0a_1x1', 'Conv2d_0b_5x5'))),
+    ('Mixed_5c', _mixed5(64, ('Conv2d_0b_1x1', 'Conv_1_0c_5x5'))),      # reference scope-name quirk
+    ('Mixed_5d', _mixed5(64, ('Conv2d_0a_1x1', 'Conv2d_0b_5x5'))),
+    ('Mixed_6a', [[_c('Conv2d_1a_1x1', 384, 3, 2, 'VALID')],
+                  [_c('Conv2d_0a_1x1', 64, 1), _c('Conv2d_0b_3x3', 96, 3), _c('Conv2d_1a_1x1', 96, 3, 2, 'VALID')],
+                  [('max',)]]),
+    ('Mixed_6b', _mixed6(128)), ('Mixed_6c', _mixed6(160)), ('Mixed_6d', _mixed6(160)), ('Mixed_6e', _mixed6(192)),
+    ('Mixed_7a', [[_c('Conv2d_0a_1x1', 192, 1), _c('Conv2d_1a_3x3', 320, 3, 2, 'VALID')],
+                  [_c('Conv2d_0a_1x1', 192, 1), _c('Conv2d_0b_1x7', 192, (1, 7)), _c('Conv2d_0c_7x1', 192, (7, 1)),
+                   _c('Conv2d_1a_3x3', 192, 3, 2, 'VALID')],
+                  [('max',)]]),
+    ('Mixed_7b', _mixed7('Conv2d_0b_3x1')), ('Mixed_7c', _mixed7('Conv2d_0c_3x1')),
+]
+
+
+def _out(size, k, s, pad):
+    if pad == 'SAME':
+        o = -(-size // s)
+        tot = max((o - 1) * s + k - size, 0)
+        return o, tot // 2
+    return (size - k) // s + 1, 0
+
+
+class CnnPlan:
+    """Flat op list + buffer table for one backbone at one input size."""
+
+    def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c'):
+        if name != 'inception_v3':
+            raise NotImplementedError('only inception_v3 is on the MI355X hot path (got %r)' % name)
+        self.name = name
+        self.ops = []            # dicts
+        self.buffers = []        # (H, W, C, f32)
+        self.weights = []        # (var_prefix, kh, kw, cin, cout, stem)
+        self.end_points = {}     # name -> buffer id
+        self.macs = 0
+        self._build_v3(image_size, final_endpoint)
+
+    # -- builder helpers ---------------------------------------------------------------
+    def _buf(self, H, W, Cc, f32=False):
+        self.buffers.append((H, W, Cc, f32))
+        return len(self.buffers) - 1
+
+    def _conv(self, src, scope, spec, dst=None, dst_coff=0, out_f32=False):
+        _, name, cout, (kh, kw), stride, pad = spec
+        H, W, Cin, _ = self.buffers[src]
+        Ho, pt = _out(H, kh, stride, pad)
+        Wo, pl = _out(W, kw, stride, pad)
+        if dst is None:
+            dst = self._buf(Ho, Wo, cout, out_f32)
+        stem = Cin <= 4
+        self.weights.append((scope + '/' + name, kh, kw, Cin, cout, stem))
+        self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
+                             Cin=Cin, Cout=cout, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
+                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32)))
+        self.macs += Ho * Wo * kh * kw * Cin * cout
+        return dst, (Ho, Wo, cout)
+
+    def _pool(self, src, kind, k, stride, pad, dst=None, dst_coff=0):
+        H, W, Cc, _ = self.buffers[src]
+        Ho, pt = _out(H, k, stride, pad)
+        Wo, pl = _out(W, k, stride, pad)
+        if dst is None:
+            dst = self._buf(Ho, Wo, Cc)
+        self.ops.append(dict(kind=kind, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc,
+                             KH=k, KW=k, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=-1, relu=0,
+                             out_f32=0))
+        return dst, (Ho, Wo, Cc)
+
+    @staticmethod
+    def _branch_out(branch, H, W, Cin):
+        """(Ho, Wo, C) produced by a branch."""
+        C_ = Cin
+        for op in branch:
+            if op[0] == 'c':
+                _, _, cout, (kh, kw), s, pad = op
+                H, W, C_ = _out(H, kh, s, pad)[0], _out(W, kw, s, pad)[0], cout
+            elif op[0] == 'max':
+                H, W = _out(H, 3, 2, 'VALID')[0], _out(W, 3, 2, 'VALID')[0]
+            elif op[0] == 'fork':
+                C_ = sum(o[2] for o in op[1])
+        return H, W, C_
+
+    def _build_v3(self, image_size, final_endpoint):
+        H, W = image_size
+        cur = self._buf(H, W, 3, True)          # fp32 images in [-1, 1]
+        self.input = cur
+        root = 'InceptionV3'
+        for op in _STEM:
+            if op[0] == 'c':
+                cur, _ = self._conv(cur, root, op)
+            else:
+                cur, _ = self._pool(cur, 2, 3, 2, 'VALID')
+            self.end_points[op[1]] = cur
+        for bname, branches in INCEPTION_V3_BLOCKS:
+            Hi, Wi, Ci, _ = self.buffers[cur]
+            outs = [self._branch_out(b, Hi, Wi, Ci) for b in branches]
+            Ho, Wo = outs[0][0], outs[0][1]
+            Ctot = sum(o[2] for o in outs)
+            last = bname == final_endpoint
+            blk = self._buf(Ho, Wo, Ctot, f32=last)   # the attention feature map is handed over in fp32
+            coff = 0
+            for bi, branch in enumerate(branches):
+                scope = '%s/%s/Branch_%d' % (root, bname, bi)
+                x = cur
+                for oi, op in enumerate(branch):
+                    final = oi == len(branch) - 1
+                    if op[0] == 'c':
+                        if final:
+                            self._conv(x, scope, op, blk, coff, out_f32=last)
+                        else:
+                            x, _ = self._conv(x, scope, op)
+                    elif op[0] == 'avg':
+                        x, _ = self._pool(x, 3, 3, 1, 'SAME')
+                    elif op[0] == 'max':
+                        assert final
+                        if last:
+                            raise NotImplementedError
+                        self._pool(x, 2, 3, 2, 'VALID', blk, coff)
+                    elif op[0] == 'fork':
+                        assert final
+                        o = coff
+                        for sub in op[1]:
+                            self._conv(x, scope, sub, blk, o, out_f32=last)
+                            o += sub[2]
+                coff += outs[bi][2]
+            cur = blk
+            self.end_points[bname] = cur
+            if last:
+                break
+        # head (inception_v3.py:520-532): kernel = min(8, H_f), VALID, num_classes=None
+        Hf, Wf, Cf, f32 = self.buffers[cur]
+        self.fm = cur
+        kh, kw = min(Hf, 8), min(Wf, 8)
+        Hp, Wp = Hf - kh + 1, Wf - kw + 1
+        pooled = self._buf(Hp, Wp, Cf, True)
+        self.ops.append(dict(kind=4, src=cur, dst=pooled, src_coff=0, dst_coff=0, H=Hf, W=Wf, Cin=Cf, Cout=Cf, KH=kh,
+                             KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1))
+        self.pooled = pooled
+        self.end_points['AvgPool_1a'] = pooled
+
+    # -- parameters -----------------------------------------------------------------------
+    def param_shapes(self):
+        out = {}
+        for prefix, kh, kw, cin, cout, _ in self.weights:
+            out[prefix + '/weights'] = (kh, kw, cin, cout)
+            for s in ('beta', 'moving_mean', 'moving_variance'):
+                out[prefix + '/BatchNorm/' + s] = (cout,)
+        return out
+
+    def init_params(self, seed=0):
+        """slim.variance_scaling_initializer() convs, BN beta 0 / mean 0 / var 1;
+        normally overwritten by the slim checkpoint (model_base.py:468-482)."""
+        rng = np.random.default_rng(seed)
+        p = {}
+        for prefix, kh, kw, cin, cout, _ in self.weights:
+            std = math.sqrt(1.3 * 2.0 / (kh * kw * cin))
+            w = np.clip(rng.standard_normal((kh, kw, cin, cout)), -2, 2).astype(np.float32) * np.float32(std)
+            p[prefix + '/weights'] = w
+            p[prefix + '/BatchNorm/beta'] = np.zeros(cout, np.float32)
+            p[prefix + '/BatchNorm/moving_mean'] = np.zeros(cout, np.float32)
+            p[prefix + '/BatchNorm/moving_variance'] = np.ones(cout, np.float32)
+        return p
+
+
+class CnnEncoder:
+    """Device-resident encoder: packed weights, folded BN, activation buffers, one native
+    forward call.  `dtype` 'bf16' (throughput path) or 'f32' (exact-fp32 MFMA, parity path)."""
+
+    def __init__(self, plan: CnnPlan, params: dict, batch: int, dtype='bf16', device='cuda:0'):
+        import torch
+        self.torch = torch
+        self.lib = L.load()
+        self.plan, self.batch, self.dtype, self.device = plan, batch, dtype, device
+        self.dcode = 1 if dtype == 'bf16' else 0
+        tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        st = L.stream_ptr()
+        self._keep = []
+        wt = (L.ConvWeight * len(plan.weights))()
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+            w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(device)
+            assert tuple(w.shape) == (kh, kw, cin, cout), prefix
+            beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
+                params[prefix + '/BatchNorm/' + s], np.float32)).to(device)
+                for s in ('beta', 'moving_mean', 'moving_variance'))
+            scale = torch.empty(cout, dtype=torch.float32, device=device)
+            shift = torch.empty(cout, dtype=torch.float32, device=device)
+            L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
+                                           scale.data_ptr(), shift.data_ptr(), cout, st), 'fold_bn')
+            if stem:
+                packed = w.reshape(kh * kw * cin, cout).contiguous()
+            else:
+                K = kh * kw * cin
+                kpad = (K + 31) // 32 * 32
+                packed = torch.empty(cout * kpad, dtype=tdt, device=device)
+                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), packed.data_ptr(), kh, kw, cin, cout,
+                                                         self.dcode, st), 'pack_conv_weights')
+            wt[i].w, wt[i].scale, wt[i].shift = packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
+            self._keep += [packed, scale, shift]
+        torch.cuda.synchronize()
+        self._wt = wt
+        self.bufs = []
+        for (H, W, Cc, f32) in plan.buffers:
+            self.bufs.append(torch.empty((batch, H, W, Cc), dtype=torch.float32 if f32 else tdt, device=device))
+        self._bufptr = (C.c_void_p * len(self.bufs))(*[b.data_ptr() for b in self.bufs])
+        self._bufch = (C.c_int32 * len(self.bufs))(*[b[2] for b in plan.buffers])
+        ops = (L.CnnOp * len(plan.ops))()
+        for i, o in enumerate(plan.ops):
+            for k, v in o.items():
+                setattr(ops[i], k, v)
+        self._ops = ops
+
+    def forward(self, images):
+        """images fp32 NHWC [B,H,W,3] in [-1,1] (device) -> (im_embed [B,C_g], fmaps [B,M,C]) fp32.
+        ModelBase._encoder, non-legacy (model_base.py:93-104)."""
+        inp = self.bufs[self.plan.input]
+        assert images.shape == inp.shape and images.dtype == inp.dtype, (images.shape, inp.shape)
+        inp.copy_(images)
+        L.check(self.lib.comic_cnn_forward(self._ops, len(self.plan.ops), self._bufptr, self._bufch, self._wt,
+                                           self.batch, self.dcode, L.stream_ptr()), 'cnn_forward')
+        fm = self.bufs[self.plan.fm]
+        pooled = self.bufs[self.plan.pooled]
+        B = self.batch
+        return pooled.reshape(B, -1), fm.reshape(B, fm.shape[1] * fm.shape[2], fm.shape[3])
+
+    def end_point(self, name):
+        return self.bufs[self.plan.end_points[name]]
+
+    @property
+    def flops_per_image(self):
+        return 2 * self.plan.macs
+
+
+def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
+    """Signature-compatible with nets_factory.get_network_fn for the supported backbone;
+    returns a builder of `CnnPlan` (the graph object of this framework)."""
+    if num_classes:
+        raise NotImplementedError('classification heads are outside the captioning hot path')
+    if is_training:
+        raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
+
+    def network_fn(image_size=(224, 224), final_endpoint='Mixed_7c'):
+        return CnnPlan(name, image_size, final_endpoint)
+    network_fn.default_image_size = 299
+    return network_fn

@@ -1,0 +1,101 @@
+"""Host helpers mirroring the reference's `common/ops.py` for the hot path.
+
+Only the pieces the captioning path calls are provided: `number_to_base`
+(common/ops.py:25-40) and the token/caption conversions that live next to it in the
+reference (`infer_fn.id_to_caption`, src/infer_fn.py:36-75; the radix table and
+`captions_to_batched_ids`, common/inputs/manager_image_caption.py:240-254, :477-509).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def number_to_base(n, base):
+    """Function to convert any base-10 integer to base-N (digits, most significant first)."""
+    if base < 2:
+        raise ValueError('Base cannot be less than 2.')
+    if n == 0:
+        return [0]
+    sign = 1
+    if n < 0:
+        sign, n = -1, -n
+    digits = []
+    while n:
+        n, r = divmod(n, base)
+        digits.append(sign * int(r))
+    digits.reverse()
+    return digits
+
+
+def base_n_to_dec(digits, base):
+    """Inverse of `number_to_base` (infer_fn._baseN_arr_to_dec)."""
+    value = 0
+    for d in digits:
+        value = value * base + int(d)
+    return value
+
+
+def id_to_caption(ids, config):
+    """ids [N,T] -> list of N strings.  Radix: keep ids in [0, base), drop one trailing id
+    when the count is not a multiple of the word length, decode base-N groups, skip word ids
+    >= vocab; word/char: drop negatives and <EOS>."""
+    ids = np.asarray(ids)
+    captions = []
+    if config.token_type == 'radix':
+        base = config.radix_base
+        vocab_size = len(config.itow)
+        word_len = len(number_to_base(vocab_size, base))
+        for row in ids:
+            keep = row[(row >= 0) & (row < base)].tolist()
+            if len(keep) % word_len:
+                keep.pop()
+            words = []
+            for j in range(0, len(keep), word_len):
+                wid = base_n_to_dec(keep[j:j + word_len], base)
+                if wid < vocab_size:
+                    words.append(config.itow[str(wid)])
+            captions.append(' '.join(words))
+        return captions
+    eos = config.wtoi['<EOS>']
+    joiner = ' ' if config.token_type == 'word' else ''
+    for row in ids:
+        captions.append(joiner.join(config.itow[str(int(w))] for w in row if w >= 0 and w != eos))
+    return captions
+
+
+def build_radix_wtoi(wtoi, radix_base):
+    """word -> zero-left-padded base-N digits; <GO> -> [base], <EOS> -> [base+1], <PAD> -> [-1]."""
+    assert wtoi['<PAD>'] == -1
+    max_word_len = len(number_to_base(len(wtoi), radix_base))
+    special = {'<GO>': [radix_base], '<EOS>': [radix_base + 1], '<PAD>': [-1]}
+    table = {}
+    for word, idx in wtoi.items():
+        if word in special:
+            table[word] = special[word]
+        else:
+            digits = number_to_base(idx, radix_base)
+            table[word] = [0] * (max_word_len - len(digits)) + digits
+    return table
+
+
+def captions_to_batched_ids(hypos, config, radix_wtoi=None):
+    """List of [string] hypotheses -> padded int matrix used as SCST targets."""
+    token_type = config.token_type
+    assert token_type in ('radix', 'word', 'char')
+    rows = []
+    for h in hypos:
+        if token_type == 'char':
+            r = [config.wtoi['<GO>']] + [config.wtoi[ch] for ch in h[0]] + [config.wtoi['<EOS>']]
+        else:
+            toks = ['<GO>'] + h[0].split() + ['<EOS>']
+            if token_type == 'radix':
+                r = [d for w in toks for d in radix_wtoi.get(w, radix_wtoi['<UNK>'])]
+            else:
+                r = [config.wtoi.get(w, config.wtoi['<UNK>']) for w in toks]
+        rows.append(r)
+    width = max(len(r) for r in rows)
+    assert width > 1
+    out = np.full((len(rows), width), config.wtoi['<PAD>'], np.int64)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return out

@@ -1,0 +1,53 @@
+"""Optimiser and learning-rate schedule of the reference, on the flat parameter buffer.
+
+`tf.train.AdamOptimizer` through `slim.learning.create_train_op` (reference
+src/model_base.py:387-401, :852-883) with the TF-1.9 ApplyAdam formula (eps outside the
+bias correction), L2 regularisation over every trainable variable
+(model_base.py:408-417, common/ops.py:184-190) folded into the update as grad += decay*w,
+and the cosine schedule of `_create_cosine_lr` (model_base.py:809-820).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+
+def cosine_lr(step, max_step, lr_start, lr_end):
+    s = np.float32(step / max_step)
+    s = np.float32(1.0) + np.cos(np.minimum(np.float32(1.0), s) * np.float32(math.pi), dtype=np.float32)
+    return float(np.float32(np.float32(lr_start - lr_end) * s / np.float32(2) + np.float32(lr_end)))
+
+
+def legacy_lr_reduce(lr, epoch, lr_end, every_n_epochs):
+    """train_fn._lr_reduce_check (src/train_fn.py:307-317)."""
+    if lr > lr_end and epoch % every_n_epochs == 0:
+        lr = max(lr / 2, lr_end)
+    return lr
+
+
+class AdamTF:
+    def __init__(self, params, beta1=0.9, beta2=0.999, epsilon=1e-2, l2_decay=1e-5):
+        self.lib = L.load()
+        self.params = params
+        self.m = params.like()
+        self.v = params.like()
+        self.beta1, self.beta2, self.eps, self.l2 = beta1, beta2, epsilon, l2_decay
+        self.t = 0                      # number of applied updates (== global_step)
+
+    def step(self, grads, lr, grad_scale=1.0):
+        self.t += 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
+        L.check(self.lib.comic_adam_tf(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
+                                       self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
+                                       self.eps, self.l2, grad_scale, L.stream_ptr()), 'adam_tf')
+
+    def state_dict(self):
+        return dict(t=self.t, m=self.m.data.clone(), v=self.v.data.clone())
+
+    def load_state_dict(self, sd):
+        self.t = int(sd['t'])
+        self.m.data.copy_(sd['m'])
+        self.v.data.copy_(sd['v'])

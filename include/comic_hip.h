@@ -1,0 +1,275 @@
+/*
+ * comic_hip.h -- C-ABI of the MI355X (gfx950) hot path of COMIC image captioning.
+ *
+ * The reference (jiahuei/COMIC-Compact-Image-Captioning-with-Attention) has NO FFI:
+ * its hot path is a Python operator API over the TensorFlow-1.9 runtime.  Each entry
+ * point below therefore replaces the TF op call-sites of one reference function and
+ * cites it (file:line relative to the reference root).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; comic_last_error()
+ *     returns a thread-local description.  No exceptions cross the boundary.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller
+ *     owns every buffer (the library never allocates, frees or retains pointers).
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and
+ *     safe to capture in a hipGraph (no allocation / synchronisation inside).
+ *   - activations NHWC; conv weights packed [Cout][Kpad] with K = (kh, kw, cin)
+ *     contiguous (see comic_pack_conv_weights); dense weights row-major [in][out]
+ *     (TensorFlow layout, so checkpoints map 1:1).
+ *   - dtype codes: COMIC_F32 = 0, COMIC_BF16 = 1.
+ */
+#ifndef COMIC_HIP_H_
+#define COMIC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMIC_F32 0
+#define COMIC_BF16 1
+#define COMIC_ABI_VERSION 1
+
+const char* comic_last_error(void);
+int comic_abi_version(void);
+/* number of HIP devices visible; does not create a context */
+int comic_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* CNN encoder  (common/nets/inception_v3.py:100-415, inception_utils.py:32-82) */
+/* ------------------------------------------------------------------------- */
+
+/* Repack TF HWIO conv weights [kh][kw][cin][cout] (fp32) to [cout][Kpad] in `dtype`,
+ * K = kh*kw*cin, Kpad = K rounded up to 32 elements, zero padded.
+ * Replaces nothing in the reference (layout prep done once at checkpoint load). */
+int comic_pack_conv_weights(const float* w_hwio, void* w_packed, int kh, int kw, int cin, int cout,
+                            int dtype, void* stream);
+
+/* Fold BatchNorm(inference, no gamma, eps) into per-channel scale/shift:
+ * scale = rsqrt(var+eps), shift = beta - mean*scale   (inception_utils.py:56-66). */
+int comic_fold_bn(const float* beta, const float* mean, const float* var, float eps, float* scale,
+                  float* shift, int c, void* stream);
+
+/* One op of a CNN forward plan. */
+typedef struct comic_cnn_op {
+  int32_t kind;      /* 0 conv(implicit GEMM, MFMA)  1 stem conv (cin<=4, fp32 input)
+                        2 max-pool  3 avg-pool 3x3 s1 SAME (count excludes padding)
+                        4 global avg-pool KHxKW VALID -> fp32 */
+  int32_t src, dst;  /* indices into the buffer table */
+  int32_t src_coff, dst_coff; /* channel offsets inside src/dst (concat without a copy) */
+  int32_t H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
+  int32_t weight;    /* index into the weight table (conv ops) */
+  int32_t relu;
+  int32_t out_f32;   /* store fp32 even when the plan dtype is bf16 */
+  int32_t reserved;
+} comic_cnn_op;
+
+typedef struct comic_conv_weight {
+  const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */
+  const float* scale;  /* [Cout] */
+  const float* shift;  /* [Cout] */
+} comic_conv_weight;
+
+/* Run a whole forward plan on `stream`.  buffers[i] has buf_channels[i] channels per
+ * pixel.  Replaces nets_factory.get_network_fn(...)(images) (nets/nets_factory.py:116-159;
+ * src/model_base.py:72-77) for the ops listed above. */
+int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                      const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
+                      int dtype, void* stream);
+
+/* Single conv + folded BN + ReLU (slim.conv2d under inception_arg_scope). */
+int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x_channels, void* y,
+                         int y_channels, const comic_conv_weight* wt, int batch, int dtype,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Dense algebra for the decoder (tf MatMul call-sites: common/ops.py:200-238,   */
+/* ops_rnn.py:440-447,545; model_base.py:541-543,618-621)                       */
+/* ------------------------------------------------------------------------- */
+/* C[M,N] = alpha * op(A) * op(B) + beta * C + bias[N]      (fp32, exact-f32 MFMA)
+ *   trans_a = 0: A is [M,K] (lda);  1: A is [K,M] (lda)
+ *   trans_b = 0: B is [K,N] (ldb);  1: B is [N,K] (ldb)
+ * bias may be NULL. */
+int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                   int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
+                   void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Decoder step kernels                                                       */
+/* ------------------------------------------------------------------------- */
+/* out[r,:] = ids[r] >= 0 ? table[ids[r],:] : 0        (model_base.py:523-526,587-593) */
+int comic_embed_fwd(const float* table, const int32_t* ids, float* out, int rows, int E, int V,
+                    void* stream);
+/* dtable[v,:] += sum_{r: ids[r]==v} dout[r,:]   (deterministic, no atomics) */
+int comic_embed_bwd(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V,
+                    void* stream);
+
+/* y = (x / keep) * mask  (tf.nn.dropout, TF-1.9 form); mask NULL -> copy */
+int comic_dropout_apply(const float* x, const float* mask, float keep, float* y, int64_t n,
+                        void* stream);
+/* Bernoulli(keep) 0/1 masks from a counter-based generator (stateless, seed+offset). */
+int comic_dropout_mask(float* mask, int64_t n, float keep, uint64_t seed, uint64_t offset,
+                       void* stream);
+
+/* BasicLSTMCell gate math (model_base.py:618-621; gate order i,j,f,o; forget_bias 1).
+ *  g [B,4D] pre-activations (bias included).  Writes activated gates [B,4D] (for bwd),
+ *  c_new/h_new [B,D], y = dropout(h_new) [B,D].  A row is FINISHED when lens != NULL and
+ *  t >= lens[b] (TrainingHelper rule); finished rows keep their state (impute_finished,
+ *  ops_rnn.py:222-228): c_state = fin ? c_prev : c_new, h_state likewise.  c_prev/h_prev
+ *  NULL mean zero state.  Any output pointer may be NULL. */
+int comic_lstm_gates_fwd(const float* g, const float* c_prev, const float* h_prev, float* gates_act,
+                         float* c_new, float* h_new, float* y, const float* mask_out, float keep_out,
+                         const int32_t* lens, int t, float* c_state, float* h_state, int B, int D,
+                         void* stream);
+/* Backward of the above.  dc_state/dh_state are the gradients w.r.t. the carried state
+ * (in/out: on return they hold the pass-through part for finished rows plus dc_prev; the
+ * caller adds dh_prev from dg * K^T); dy is the gradient w.r.t. y (may be NULL).
+ * dg [B,4D] is the gradient w.r.t. the pre-activations. */
+int comic_lstm_gates_bwd(const float* gates_act, const float* c_prev, const float* c_new,
+                         const float* dy, const float* mask_out, float keep_out, const int32_t* lens,
+                         int t, float* dc_state, float* dh_state, float* dg, int B, int D, void* stream);
+
+/* Attention descriptor shared by fwd/bwd. */
+typedef struct comic_attn_desc {
+  int32_t B, M, D, H, Cv;  /* keys [B,M,D]; values [B,M,Cv]; H heads */
+  int32_t method;          /* 0 add_LN (ops_rnn.py:531-565)   1 dot (ops_rnn.py:611-632) */
+  int32_t prob;            /* 0 softmax   1 sigmoid-normalised (model_base.py:599-603) */
+  int32_t tied;            /* values alias keys (cnn_fm_projection == 'tied') */
+} comic_attn_desc;
+
+/* Fused per-step attention: score (LN-tanh-v | dot) -> per-head softmax over M ->
+ * dropout(alpha) -> context.  MultiHeadAddLN.__call__ + MultiHeadAttentionWrapperV3.call
+ * (ops_rnn.py:543-563, :692-716).  alpha [B,H,M] (pre-dropout, kept for backward),
+ * alpha_d [B,H,M] (post-dropout = alignment history entry), ctx [B,Cv]. */
+int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, const float* values,
+                        const float* q, const float* ln_g, const float* ln_b, const float* v,
+                        const float* tau, const float* mask_alpha, float keep_alpha, float* alpha,
+                        float* alpha_d, float* ctx, void* stream);
+/* Backward: given dctx [B,Cv] and the map-loss term dmap [B,M] (added to every head's
+ * d alpha_d; may be NULL) produces dq [B,D]; ACCUMULATES into dkeys [B,M,D] and dvalues
+ * [B,M,Cv] (same buffer when tied) and into the per-row parameter partials
+ * pgrad [B, 3*D+1] = (d v | d ln_g | d ln_b | d tau). */
+int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values,
+                        const float* q, const float* ln_g, const float* ln_b, const float* v,
+                        const float* tau, const float* alpha, const float* mask_alpha,
+                        float keep_alpha, const float* dctx, const float* dmap, float* dq,
+                        float* dkeys, float* dvalues, float* pgrad, void* stream);
+
+/* sequence_loss forward+backward over time-major logits [T,B,V] (model_base.py:337-347):
+ * rows with t >= lens[b] are zeroed (impute_finished), loss_rows[t*B+b] = xent*w,
+ * dlogits = (softmax - onehot) * coef[b*T+t]; ids = argmax (lowest index wins). */
+int comic_xent_fwd_bwd(float* logits, const int32_t* targets_bt, const float* coef_bt,
+                       const float* wmask_bt, const int32_t* lens, float* loss_rows, float* dlogits,
+                       int32_t* ids_tb, int T, int B, int V, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Decoding (ops_rnn.py:49-180; tf.contrib.seq2seq BeamSearchDecoder, gather_tree) */
+/* ------------------------------------------------------------------------- */
+int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, void* stream);
+/* One _beam_search_step: logits [B,W,V]; in/out log_probs [B,W], finished [B,W] (int32),
+ * lengths [B,W] (int64); out word/parent/scores [B,W].  Ties: lower flat index first. */
+int comic_beam_step(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths,
+                    int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int V,
+                    int end_id, void* stream);
+/* out[r,:] = in[(r/W)*W + parent[r], :]   (state re-ordering by parent beam) */
+int comic_gather_rows(const float* in, const int32_t* parent, float* out, int rows, int W, int cols,
+                      void* stream);
+/* beam_search_ops.gather_tree: step_ids/parent_ids/out [T,B,W]; max_len [B]. */
+int comic_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* max_len,
+                      int32_t* out, int T, int B, int W, int end_id, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Optimiser (model_base.py:852-883; tf.train.AdamOptimizer ApplyAdam, TF-1.9)  */
+/* ------------------------------------------------------------------------- */
+/* g_eff = g*gscale + l2*w; m += (g_eff-m)(1-b1); v += (g_eff^2-v)(1-b2);
+ * w -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int comic_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                  float beta2, float eps, float l2, float gscale, void* stream);
+/* out[j] = sum_i in[i*cols + j]  (deterministic column sums; parameter-partial reduce) */
+int comic_colsum(const float* in, float* out, int rows, int cols, float beta, void* stream);
+int comic_axpy(float* y, const float* x, float a, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Native decoder executors                                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct comic_decoder_desc {
+  int32_t D, E, A, V, C, Cg, H, M;     /* rnn, word, attention, softmax, fm ch, im_embed, heads, map */
+  int32_t Cv;                          /* value channels (D, or C when projection is none) */
+  int32_t fm_projection;               /* 0 none, 1 independent, 2 tied */
+  int32_t method, prob;                /* as comic_attn_desc */
+  int32_t context_layer;               /* attn_context_layer */
+  int32_t init_method;                 /* 0 first_input, 1 project_hidden */
+  int32_t start_id, end_id;
+  float keep_in, keep_out, keep_alpha; /* 1.0 disables the dropout */
+  float map_loss_scale;
+} comic_decoder_desc;
+
+/* Parameter (or gradient) table; every pointer is a view into one flat fp32 buffer. */
+typedef struct comic_decoder_params {
+  float *W_init, *K, *b, *W_m, *W_v, *W_q, *v, *ln_g, *ln_b, *tau, *W_a, *W_o, *b_o, *emb;
+} comic_decoder_params;
+
+/* Workspace size in bytes for a training step at (B, T, M) / a decode at rows=B*W. */
+int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, int B, int T);
+int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int max_steps);
+
+/* One teacher-forced forward + backward (CaptionModel train graph: src/model.py:44-59;
+ * rnn_decoder_training ops_rnn.py:183-243; losses model_base.py:325-405).
+ *   fm [B,M,C], im_embed [B,Cg] fp32; inputs_bt/targets_bt [B,T] int32; wmask/coef [B,T];
+ *   lens [B] int32 (device) and Tp = max(lens) (host);
+ *   masks (may be NULL when the keeps are 1): init_in [B,E+A], in [Tp,B,E+A],
+ *   out [Tp,B,D], alpha [Tp,B,H,M].
+ * Outputs: logits [T,B,V] (time-major), ids [T,B], attn history [Tp,B,H,M], loss_rows [T*B],
+ *   map_loss (1 float), grads (no L2), dfm [B,M,C] / dim_embed [B,Cg] (may be NULL). */
+int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_params* p,
+                             const comic_decoder_params* grads, const float* fm,
+                             const float* im_embed, const int32_t* inputs_bt,
+                             const int32_t* targets_bt, const float* wmask_bt, const float* coef_bt,
+                             const int32_t* lens, int B, int T, int Tp, const float* mask_init_in,
+                             const float* mask_in, const float* mask_out, const float* mask_alpha,
+                             float* logits_tb, int32_t* ids_tb, float* attn_hist, float* loss_rows,
+                             float* map_loss, float* dfm, float* dim_embed, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* Greedy decode (rnn_decoder_search, ops_rnn.py:115-180): runs `max_steps` steps on the
+ * device without host sync; ids [max_steps,B], attn [max_steps,B,H,M]; finished-at step per
+ * row in first_eos [B] (max_steps when no EOS).  The host trims to the executed length. */
+int comic_decoder_greedy(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                         const float* im_embed, int B, int max_steps, int32_t* ids_tb,
+                         float* logits_tb, float* attn_hist, int32_t* first_eos, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/* Beam search (rnn_decoder_beam_search, ops_rnn.py:49-112).  fm/im_embed are UN-tiled
+ * [B,...]; tiling by W happens inside (model_base.py:127-131).  Outputs, all [max_steps,B,W]:
+ * step_ids, parent_ids, scores; final lengths [B,W] (int64), finished [B,W];
+ * attn_hist [max_steps, B*W, H*M] (un-sorted; sort on host with gather_tree_from_array).
+ * The loop always issues max_steps steps (no host sync); steps_executed (device int32)
+ * receives the step count after which every beam was finished, i.e. the length the
+ * reference's dynamic_decode would have produced; later steps are identity and ignored. */
+int comic_decoder_beam(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                       const float* im_embed, int B, int W, int max_steps, int32_t* step_ids,
+                       int32_t* parent_ids, float* scores, int64_t* lengths, int32_t* finished,
+                       float* attn_hist, int32_t* steps_executed, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* SCST reward scorer (host, multi-threaded)  common/scst/scorers.py:43-171      */
+/* ------------------------------------------------------------------------- */
+typedef struct comic_scorer comic_scorer;
+/* df entries: `ngrams_host` = n_entries NUL-terminated strings (words joined by ' '),
+ * concatenated; counts_host[n_entries]; ref_len = number of images in the df corpus. */
+comic_scorer* comic_scorer_create(const char* ngrams_host, const double* counts_host,
+                                  int64_t n_entries, double ref_len);
+void comic_scorer_destroy(comic_scorer* s);
+/* hypos: n strings; refs: for hypothesis i, refs_per[i] strings, concatenated in order.
+ * out_cider[n]; out_bleu[n*4] (BLEU-1..4 per sentence, 'closest' reflen). */
+int comic_scorer_score(const comic_scorer* s, const char* const* hypos_host, int n,
+                       const char* const* refs_host, const int32_t* refs_per_host,
+                       double* out_cider_host, double* out_bleu_host, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMIC_HIP_H_ */

@@ -1,0 +1,46 @@
+"""Helpers for the -m gpu parity tests (HIP path vs the CPU oracle)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import comic_amd._lib as L
+
+DEV = 'cuda:0'
+# Parity bar (BASELINE.json north_star): fp32 results within 1e-3 relative of the oracle,
+# measured as max|a-b| / max|b| per tensor; integer / index outputs bit-exact.
+F32_RTOL = 1e-3
+
+
+def lib():
+    return L.load()
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    denom = np.abs(ref).max() + 1e-30
+    return float(np.abs(got - ref).max() / denom)
+
+
+def assert_close(got, ref, tol=F32_RTOL, name=''):
+    e = rel_err(got, ref)
+    assert np.isfinite(np.asarray(got, np.float64)).all(), '%s: non-finite values' % name
+    assert e <= tol, '%s: rel err %.3e > %.1e (max|ref| %.3e)' % (name, e, tol, np.abs(ref).max())
+    return e
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def sync():
+    torch.cuda.synchronize()

@@ -1,0 +1,417 @@
+"""Op-level parity: every HIP kernel behind the C-ABI vs the CPU oracle on the same seeded
+inputs.  Tolerances: fp32 1e-3 relative (max-norm), bf16 storage 2e-2 vs a bf16-emulating
+oracle (inputs/weights rounded to bf16, fp32 accumulate), indices bit-exact."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import comic_amd._lib as L
+from oracle import beam_ref, cnn_ref, decoder_ref as dr
+from tests.gpu_util import DEV, F32_RTOL, assert_close, dev, lib, rel_err, stream, sync
+
+
+# ------------------------------------------------------------------------ GEMM -----------
+@pytest.mark.parametrize('M,N,K,ta,tb', [
+    (64, 2048, 1280, 0, 0), (64, 512, 512, 0, 0), (64, 258, 512, 0, 0), (37, 258, 130, 0, 0),
+    (64, 1280, 2048, 0, 1), (64, 512, 258, 0, 1), (1856, 512, 258, 0, 1),
+    (1280, 2048, 1856, 1, 0), (512, 258, 1856, 1, 0), (2048, 768, 64, 1, 0), (33, 70, 19, 1, 1),
+    (1600, 512, 2048, 0, 0), (2048, 512, 1600, 1, 0)])
+def test_gemm_f32(M, N, K, ta, tb):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    dA, dB, dC, db = dev(A), dev(B), dev(C0), dev(bias)
+    L.check(lib().comic_gemm_f32(dA.data_ptr(), dB.data_ptr(), dC.data_ptr(), db.data_ptr(), M, N, K,
+                                 A.shape[1], B.shape[1], N, ta, tb, 0.5, 2.0, stream()))
+    sync()
+    assert_close(dC.cpu().numpy(), 0.5 * ref + 2.0 * C0 + bias, 1e-5, 'gemm')
+    # plain product, strided C (ldc > N)
+    big = torch.zeros((M, N + 8), dtype=torch.float32, device=DEV)
+    L.check(lib().comic_gemm_f32(dA.data_ptr(), dB.data_ptr(), big.data_ptr(), None, M, N, K, A.shape[1],
+                                 B.shape[1], N + 8, ta, tb, 1.0, 0.0, stream()))
+    sync()
+    assert_close(big[:, :N].cpu().numpy(), ref, 1e-5, 'gemm strided')
+    assert float(big[:, N:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------ conv / pool -----
+def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, dst_coff=0, relu=1, out_f32=0):
+    B, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    Ho, pt, _ = cnn_ref.out_size(H, kh, stride, padding)
+    Wo, pl, _ = cnn_ref.out_size(W, kw, stride, padding)
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    code = 1 if dtype == 'bf16' else 0
+    stem = Cin <= 4
+    xd = dev(x) if stem else dev(x).to(tdt)
+    wd = dev(w)
+    scale = torch.empty(Cout, device=DEV); shift = torch.empty(Cout, device=DEV)
+    L.check(lib().comic_fold_bn(dev(beta).data_ptr(), dev(mean).data_ptr(), dev(var).data_ptr(), 1e-3,
+                                scale.data_ptr(), shift.data_ptr(), Cout, stream()))
+    if stem:
+        packed = wd.reshape(-1, Cout).contiguous()
+    else:
+        K = kh * kw * Cin
+        packed = torch.empty(Cout * ((K + 31) // 32 * 32), dtype=tdt, device=DEV)
+        L.check(lib().comic_pack_conv_weights(wd.data_ptr(), packed.data_ptr(), kh, kw, Cin, Cout, code, stream()))
+    yc = dst_channels or Cout
+    ydt = torch.float32 if out_f32 else tdt
+    y = torch.full((B, Ho, Wo, yc), -7.0, dtype=ydt, device=DEV)
+    op = L.CnnOp(kind=1 if stem else 0, src=0, dst=1, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cin, Cout=Cout,
+                 KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=relu, out_f32=out_f32)
+    wt = L.ConvWeight(packed.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    L.check(lib().comic_conv2d_bn_relu(C.byref(op), xd.data_ptr(), Cin, y.data_ptr(), yc, C.byref(wt), B, code,
+                                       stream()), 'conv')
+    sync()
+    return y.float().cpu().numpy()
+
+
+def _ref_conv(x, w, beta, mean, var, stride, padding, dtype, relu=1, round_out=True):
+    q = cnn_ref.bf16_round if dtype == 'bf16' else (lambda a: a)
+    y = cnn_ref.conv2d(q(x), q(w), stride, padding)
+    y = cnn_ref.batch_norm_inference(y, beta, mean, var)
+    if relu:
+        y = np.maximum(y, 0)
+    return q(y) if round_out else y
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, (kh,kw), stride, padding
+    (2, 17, 15, 32, 32, (3, 3), 1, 'VALID'), (2, 17, 15, 32, 64, (3, 3), 1, 'SAME'),
+    (2, 21, 21, 64, 80, (1, 1), 1, 'VALID'), (1, 19, 19, 80, 192, (3, 3), 1, 'VALID'),
+    (2, 25, 25, 48, 64, (5, 5), 1, 'SAME'), (3, 25, 25, 288, 384, (3, 3), 2, 'VALID'),
+    (2, 12, 12, 128, 128, (1, 7), 1, 'SAME'), (2, 12, 12, 160, 192, (7, 1), 1, 'SAME'),
+    (2, 5, 5, 448, 384, (3, 3), 1, 'SAME'), (2, 5, 5, 384, 384, (1, 3), 1, 'SAME'),
+    (2, 5, 5, 2048, 320, (1, 1), 1, 'SAME'), (70, 12, 12, 768, 192, (1, 1), 1, 'SAME'),
+    (9, 25, 25, 192, 48, (1, 1), 1, 'SAME'), (1, 1, 1, 32, 16, (1, 1), 1, 'SAME')]
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_bn_relu(case, dtype):
+    B, H, W, Cin, Cout, k, s, pad = case
+    rng = np.random.default_rng(B * 1000 + H * 7 + Cin + Cout + k[0])
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k[0], k[1], Cin, Cout)) / math.sqrt(k[0] * k[1] * Cin)).astype(np.float32)
+    beta = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    mean = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    if dtype == 'bf16':
+        x = cnn_ref.bf16_round(x)
+    ref = _ref_conv(x, w, beta, mean, var, s, pad, dtype)
+    got = _run_conv(x, w, beta, mean, var, s, pad, dtype)
+    # bf16: one output ulp (2^-8) on top of accumulation-order noise
+    assert_close(got, ref, 1e-4 if dtype == 'f32' else 1e-2, 'conv %s' % (case,))
+    # concat slice: write at a channel offset of a wider buffer, neighbours untouched
+    got2 = _run_conv(x, w, beta, mean, var, s, pad, dtype, dst_channels=Cout + 48, dst_coff=16)
+    np.testing.assert_array_equal(got2[..., 16:16 + Cout], got)
+    assert (got2[..., :16] == -7).all() and (got2[..., 16 + Cout:] == -7).all()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_stem_conv(dtype):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (2, 37, 41, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 32)) / 5).astype(np.float32)
+    beta = 0.1 * rng.standard_normal(32).astype(np.float32)
+    mean = 0.1 * rng.standard_normal(32).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    # the stem reads fp32 images and fp32 weights in both modes; only the store is bf16
+    ref = cnn_ref.batch_norm_inference(cnn_ref.conv2d(x, w, 2, 'VALID'), beta, mean, var)
+    ref = np.maximum(ref, 0)
+    got = _run_conv(x, w, beta, mean, var, 2, 'VALID', dtype)
+    assert_close(got, cnn_ref.bf16_round(ref) if dtype == 'bf16' else ref, 1e-4 if dtype == 'f32' else 5e-3, 'stem')
+
+
+def _run_pool(x, kind, k, s, pad, dtype, dst_channels=None, dst_coff=0):
+    B, H, W, Cc = x.shape
+    kh, kw = (k, k) if isinstance(k, int) else k
+    Ho, pt, _ = cnn_ref.out_size(H, kh, s, pad)
+    Wo, pl, _ = cnn_ref.out_size(W, kw, s, pad)
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    xd = dev(x).to(tdt)
+    yc = dst_channels or Cc
+    y = torch.full((B, Ho, Wo, yc), -7.0, dtype=torch.float32 if kind == 4 else tdt, device=DEV)
+    op = L.CnnOp(kind=kind, src=0, dst=1, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc, KH=kh, KW=kw,
+                 SH=s, SW=s, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=-1, relu=0, out_f32=int(kind == 4))
+    L.check(lib().comic_conv2d_bn_relu(C.byref(op), xd.data_ptr(), Cc, y.data_ptr(), yc, None, B,
+                                       1 if dtype == 'bf16' else 0, stream()), 'pool')
+    sync()
+    return y.float().cpu().numpy()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_pools(dtype):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 13, 11, 64)).astype(np.float32)
+    if dtype == 'bf16':
+        x = cnn_ref.bf16_round(x)
+    q = cnn_ref.bf16_round if dtype == 'bf16' else (lambda a: a)
+    np.testing.assert_array_equal(_run_pool(x, 2, 3, 2, 'VALID', dtype), cnn_ref.max_pool(x, 3, 2, 'VALID'))
+    got = _run_pool(x, 3, 3, 1, 'SAME', dtype)
+    assert_close(got, q(cnn_ref.avg_pool(x, 3, 1, 'SAME')), 1e-6 if dtype == 'f32' else 5e-3, 'avgpool')
+    got = _run_pool(x, 2, 3, 2, 'VALID', dtype, dst_channels=160, dst_coff=96)
+    np.testing.assert_array_equal(got[..., 96:], cnn_ref.max_pool(x, 3, 2, 'VALID'))
+    x5 = x[:, :5, :5, :]
+    got = _run_pool(x5, 4, 5, 1, 'VALID', dtype)
+    assert_close(got, cnn_ref.avg_pool(x5, 5, 1, 'VALID'), 1e-5, 'global avgpool')
+    got = _run_pool(x[:, :9, :9, :], 4, 8, 1, 'VALID', dtype)        # 9x9 map, 8x8 window -> 2x2
+    assert_close(got, cnn_ref.avg_pool(x[:, :9, :9, :], 8, 1, 'VALID'), 1e-5, 'global avgpool 8x8')
+
+
+# ------------------------------------------------------------------------ decoder kernels --
+def test_embed_fwd_bwd():
+    rng = np.random.default_rng(2)
+    V, E, rows = 258, 256, 150
+    table = rng.standard_normal((V, E)).astype(np.float32)
+    ids = rng.integers(-1, V, rows).astype(np.int32)
+    out = torch.empty((rows, E), device=DEV)
+    L.check(lib().comic_embed_fwd(dev(table).data_ptr(), dev(ids).data_ptr(), out.data_ptr(), rows, E, V, stream()))
+    np.testing.assert_array_equal(out.cpu().numpy(), dr.embed(table, ids))
+    dout = rng.standard_normal((rows, E)).astype(np.float32)
+    dt = torch.zeros((V, E), device=DEV)
+    L.check(lib().comic_embed_bwd(dev(ids).data_ptr(), dev(dout).data_ptr(), dt.data_ptr(), rows, E, V, stream()))
+    ref = np.zeros((V, E), np.float64)
+    np.add.at(ref, ids[ids >= 0], dout[ids >= 0])
+    assert_close(dt.cpu().numpy(), ref, 1e-6, 'embed_bwd')
+
+
+def test_dropout_mask_and_apply():
+    n = 1 << 20
+    m = torch.empty(n, device=DEV)
+    L.check(lib().comic_dropout_mask(m.data_ptr(), n, 0.65, 1234, 0, stream()))
+    m2 = torch.empty(n, device=DEV)
+    L.check(lib().comic_dropout_mask(m2.data_ptr(), n, 0.65, 1234, 0, stream()))
+    m3 = torch.empty(n, device=DEV)
+    L.check(lib().comic_dropout_mask(m3.data_ptr(), n, 0.65, 1235, 0, stream()))
+    mm = m.cpu().numpy()
+    assert set(np.unique(mm)) <= {0.0, 1.0}
+    assert abs(mm.mean() - 0.65) < 3e-3
+    assert torch.equal(m, m2) and not torch.equal(m, m3)
+    x = torch.randn(n, device=DEV)
+    y = torch.empty_like(x)
+    L.check(lib().comic_dropout_apply(x.data_ptr(), m.data_ptr(), 0.65, y.data_ptr(), n, stream()))
+    np.testing.assert_array_equal(y.cpu().numpy(), (x.cpu().numpy() / np.float32(0.65)) * mm)
+
+
+def test_lstm_gates_fwd_bwd():
+    rng = np.random.default_rng(3)
+    B, D = 6, 128
+    g = rng.standard_normal((B, 4 * D)).astype(np.float32)
+    c = rng.standard_normal((B, D)).astype(np.float32)
+    h = rng.standard_normal((B, D)).astype(np.float32)
+    mask = (rng.random((B, D)) < 0.65).astype(np.float32)
+    lens = np.array([3, 1, 5, 2, 9, 2], np.int32)
+    t = 2
+    fin = t >= lens
+    i, j, f, o = g[:, :D], g[:, D:2 * D], g[:, 2 * D:3 * D], g[:, 3 * D:]
+    si, tj, sf, so = dr.sigmoid(i), np.tanh(j), dr.sigmoid(f + 1), dr.sigmoid(o)
+    c2 = c * sf + si * tj
+    tc = np.tanh(c2)
+    h2 = tc * so
+    y = h2 / np.float32(0.65) * mask
+    outs = {k: torch.empty((B, D), device=DEV) for k in ('c_new', 'h_new', 'y', 'cs', 'hs')}
+    ga = torch.empty((B, 4 * D), device=DEV)
+    L.check(lib().comic_lstm_gates_fwd(dev(g).data_ptr(), dev(c).data_ptr(), dev(h).data_ptr(), ga.data_ptr(),
+                                       outs['c_new'].data_ptr(), outs['h_new'].data_ptr(), outs['y'].data_ptr(),
+                                       dev(mask).data_ptr(), 0.65, dev(lens).data_ptr(), t, outs['cs'].data_ptr(),
+                                       outs['hs'].data_ptr(), B, D, stream()))
+    assert_close(outs['c_new'].cpu().numpy(), c2, 1e-5, 'c_new')
+    assert_close(outs['y'].cpu().numpy(), y, 1e-5, 'y')
+    assert_close(outs['cs'].cpu().numpy(), np.where(fin[:, None], c, c2), 1e-5, 'c_state')
+    assert_close(outs['hs'].cpu().numpy(), np.where(fin[:, None], h, h2), 1e-5, 'h_state')
+    assert_close(ga.cpu().numpy(), np.concatenate([si, tj, sf, so], 1), 1e-5, 'gates')
+    # backward vs the oracle's cell backward
+    dc = rng.standard_normal((B, D)).astype(np.float32)
+    dh = rng.standard_normal((B, D)).astype(np.float32)
+    dy = rng.standard_normal((B, D)).astype(np.float32)
+    live = (~fin)[:, None].astype(np.float32)
+    dh2 = dh * live + dy / np.float32(0.65) * mask
+    dg_ref, dcp_ref = dr._lstm_backward(None, (si, tj, sf, so, tc), c, dc * live, dh2, D)
+    d_dc, d_dh = dev(dc), dev(dh)
+    dg = torch.empty((B, 4 * D), device=DEV)
+    L.check(lib().comic_lstm_gates_bwd(ga.data_ptr(), dev(c).data_ptr(), outs['c_new'].data_ptr(), dev(dy).data_ptr(),
+                                       dev(mask).data_ptr(), 0.65, dev(lens).data_ptr(), t, d_dc.data_ptr(),
+                                       d_dh.data_ptr(), dg.data_ptr(), B, D, stream()))
+    assert_close(dg.cpu().numpy(), dg_ref, 1e-5, 'dg')
+    assert_close(d_dc.cpu().numpy(), dc * (1 - live) + dcp_ref, 1e-5, 'dc')
+    assert_close(d_dh.cpu().numpy(), dh * (1 - live), 1e-6, 'dh')
+
+
+ATTN_CASES = [
+    # B, M, D, H, Cv, method, prob, tied
+    (5, 25, 512, 8, 512, 'add_LN', 'softmax', True),
+    (3, 64, 512, 8, 512, 'add_LN', 'softmax', False),
+    (3, 196, 512, 8, 512, 'add_LN', 'sigmoid', True),
+    (4, 25, 512, 1, 2048, 'add_LN', 'softmax', False),
+    (4, 9, 128, 4, 128, 'dot', 'softmax', True),
+    (2, 70, 64, 2, 192, 'dot', 'sigmoid', False),
+    (3, 25, 1024, 16, 1024, 'add_LN', 'softmax', True)]
+
+
+@pytest.mark.parametrize('case', ATTN_CASES)
+@pytest.mark.parametrize('use_mask', [False, True])
+def test_attn_step_fwd_bwd(case, use_mask):
+    B, M, D, H, Cv, method, prob, tied = case
+    rng = np.random.default_rng(B * M + D)
+    cfg = dr.DecoderConfig(rnn_size=D, attn_num_heads=H, attn_alignment_method=method, attn_probability_fn=prob,
+                           cnn_fm_projection='tied' if tied else 'independent')
+    keys = rng.standard_normal((B, M, D)).astype(np.float32)
+    values = keys if tied else rng.standard_normal((B, M, Cv)).astype(np.float32)
+    q = rng.standard_normal((B, D)).astype(np.float32)
+    p = dict(ln_g=(1 + 0.1 * rng.standard_normal(D)).astype(np.float32),
+             ln_b=(0.1 * rng.standard_normal(D)).astype(np.float32),
+             v=(rng.standard_normal(D) / math.sqrt(D / H) * 3).astype(np.float32), tau=np.array(2.5, np.float32))
+    keep = 0.9
+    mask = (rng.random((B, H, M)) < keep).astype(np.float32) if use_mask else None
+    alpha_ref, ac = dr.attention_scores(p, cfg, keys, q)
+    alpha_d_ref = dr.dropout(alpha_ref, mask, keep)
+    ctx_ref = dr.context(cfg, alpha_d_ref, values)
+    d = L.AttnDesc(B=B, M=M, D=D, H=H, Cv=Cv, method=0 if method == 'add_LN' else 1,
+                   prob=0 if prob == 'softmax' else 1, tied=int(tied))
+    dk = dev(keys)
+    dvv = dk if tied else dev(values)
+    dq_in = dev(q)
+    dp = {k: dev(v.reshape(-1)) for k, v in p.items()}
+    alpha = torch.empty((B, H, M), device=DEV); alpha_d = torch.empty((B, H, M), device=DEV)
+    ctx = torch.empty((B, Cv), device=DEV)
+    dmask = dev(mask) if use_mask else None
+    L.check(lib().comic_attn_step_fwd(C.byref(d), dk.data_ptr(), dvv.data_ptr(), dq_in.data_ptr(),
+                                      dp['ln_g'].data_ptr(), dp['ln_b'].data_ptr(), dp['v'].data_ptr(),
+                                      dp['tau'].data_ptr(), L.ptr(dmask), keep, alpha.data_ptr(), alpha_d.data_ptr(),
+                                      ctx.data_ptr(), stream()), 'attn_fwd')
+    sync()
+    assert_close(alpha.cpu().numpy(), alpha_ref, 1e-4, 'alpha')
+    assert_close(alpha_d.cpu().numpy(), alpha_d_ref, 1e-4, 'alpha_d')
+    assert_close(ctx.cpu().numpy(), ctx_ref, 1e-4, 'ctx')
+    # ---- backward vs the oracle's analytic backward ----
+    dctx = rng.standard_normal((B, Cv)).astype(np.float32)
+    dmap = (0.01 * rng.standard_normal((B, M))).astype(np.float32)
+    vs = values.reshape(B, M, H, Cv // H)
+    dalpha_d = np.einsum('bhd,bmhd->bhm', dctx.reshape(B, H, Cv // H), vs) + dmap[:, None, :]
+    dvalues_ref = np.einsum('bhm,bhd->bmhd', alpha_d_ref, dctx.reshape(B, H, Cv // H)).reshape(B, M, Cv)
+    dalpha = dalpha_d / np.float32(keep) * mask if use_mask else dalpha_d
+    grads = {k: np.zeros_like(v) for k, v in p.items()}
+    dk_ref, dq_ref = dr._attention_backward(p, cfg, keys, q, ac, alpha_ref, dalpha, grads)
+    dq = torch.empty((B, D), device=DEV)
+    dkeys = torch.zeros((B, M, D), device=DEV)
+    dvalues = dkeys if tied else torch.zeros((B, M, Cv), device=DEV)
+    pgrad = torch.zeros((B, 3 * D + 1), device=DEV)
+    L.check(lib().comic_attn_step_bwd(C.byref(d), dk.data_ptr(), dvv.data_ptr(), dq_in.data_ptr(),
+                                      dp['ln_g'].data_ptr(), dp['ln_b'].data_ptr(), dp['v'].data_ptr(),
+                                      dp['tau'].data_ptr(), alpha.data_ptr(), L.ptr(dmask), keep,
+                                      dev(dctx).data_ptr(), dev(dmap).data_ptr(), dq.data_ptr(), dkeys.data_ptr(),
+                                      dvalues.data_ptr(), pgrad.data_ptr(), stream()), 'attn_bwd')
+    sync()
+    assert_close(dq.cpu().numpy(), dq_ref, F32_RTOL, 'dq')
+    if tied:
+        assert_close(dkeys.cpu().numpy(), dk_ref + dvalues_ref, F32_RTOL, 'dkeys(tied)')
+    else:
+        assert_close(dkeys.cpu().numpy(), dk_ref, F32_RTOL, 'dkeys')
+        assert_close(dvalues.cpu().numpy(), dvalues_ref, F32_RTOL, 'dvalues')
+    if method == 'add_LN':
+        pg = pgrad.cpu().numpy().sum(0)
+        assert_close(pg[:D], grads['v'], F32_RTOL, 'dv')
+        assert_close(pg[D:2 * D], grads['ln_g'], F32_RTOL, 'dln_g')
+        assert_close(pg[2 * D:3 * D], grads['ln_b'], F32_RTOL, 'dln_b')
+        assert abs(pg[3 * D] - grads['tau']) <= F32_RTOL * max(1e-3, abs(float(grads['tau']))) + 1e-6, 'dtau'
+
+
+@pytest.mark.parametrize('V', [258, 25599])
+def test_xent_fwd_bwd(V):
+    rng = np.random.default_rng(V)
+    T, B = 7, 5
+    logits = (3 * rng.standard_normal((T, B, V))).astype(np.float32)
+    lens = np.array([7, 3, 5, 1, 6], np.int32)
+    targets = rng.integers(0, V, (B, T)).astype(np.int32)
+    wmask = (np.arange(T)[None, :] < lens[:, None]).astype(np.float32)
+    coef = (wmask / wmask.sum()).astype(np.float32)
+    dl = dev(logits)
+    loss_rows = torch.empty(T * B, device=DEV); dlog = torch.empty((T, B, V), device=DEV)
+    ids = torch.empty((T, B), dtype=torch.int32, device=DEV)
+    L.check(lib().comic_xent_fwd_bwd(dl.data_ptr(), dev(targets).data_ptr(), dev(coef).data_ptr(),
+                                     dev(wmask).data_ptr(), dev(lens).data_ptr(), loss_rows.data_ptr(),
+                                     dlog.data_ptr(), ids.data_ptr(), T, B, V, stream()))
+    live = (np.arange(T)[:, None] < lens[None, :])
+    lg = logits * live[..., None]
+    lsm = dr.log_softmax(lg.astype(np.float64), -1)
+    xent = -np.take_along_axis(lsm, targets.T[..., None], 2)[..., 0] * wmask.T
+    np.testing.assert_array_equal(dl.cpu().numpy(), lg)                      # finished rows zeroed
+    assert_close(loss_rows.cpu().numpy().reshape(T, B), xent, 1e-5, 'xent rows')
+    oh = np.zeros_like(lsm); np.put_along_axis(oh, targets.T[..., None], 1.0, 2)
+    assert_close(dlog.cpu().numpy(), (np.exp(lsm) - oh) * coef.T[..., None], 1e-5, 'dlogits')
+    np.testing.assert_array_equal(ids.cpu().numpy(), lg.argmax(-1))
+
+
+def test_argmax_ties_lowest_index():
+    x = np.zeros((3, 300), np.float32)
+    x[0, [7, 100, 299]] = 5; x[1, :] = -1; x[2, 299] = 1
+    idx = torch.empty(3, dtype=torch.int32, device=DEV)
+    L.check(lib().comic_argmax_rows(dev(x).data_ptr(), idx.data_ptr(), 3, 300, stream()))
+    assert idx.cpu().tolist() == [7, 0, 299]
+
+
+def test_beam_step_vs_oracle_step():
+    rng = np.random.default_rng(5)
+    B, W, V, end = 4, 3, 258, 257
+    logits = (2 * rng.standard_normal((B, W, V))).astype(np.float32)
+    logits[0, 0, 5] = logits[0, 0, 9] = 40.0            # exact tie -> lower flat index first
+    lp = np.array([[0, -1.5, -2.0]] * B, np.float32); lp[1] = [0, -np.inf, -np.inf]
+    fin = np.zeros((B, W), np.int32); fin[2, 1] = 1; fin[3] = 1
+    lens = rng.integers(0, 5, (B, W)).astype(np.int64)
+    step = dr.log_softmax(logits, -1)
+    row = np.full(V, np.finfo(np.float32).min, np.float32); row[end] = 0
+    step = np.where(fin[:, :, None].astype(bool), row[None, None, :], step)
+    total = (lp[:, :, None] + step).reshape(B, W * V)
+    order = np.argsort(-total, axis=1, kind='stable')[:, :W]
+    d_lp, d_fin, d_len = dev(lp), dev(fin), dev(lens)
+    word = torch.empty((B, W), dtype=torch.int32, device=DEV); par = torch.empty_like(word)
+    sc = torch.empty((B, W), device=DEV)
+    L.check(lib().comic_beam_step(dev(logits).data_ptr(), d_lp.data_ptr(), d_fin.data_ptr(), d_len.data_ptr(),
+                                  word.data_ptr(), par.data_ptr(), sc.data_ptr(), B, W, V, end, stream()))
+    np.testing.assert_array_equal(word.cpu().numpy(), order % V)
+    np.testing.assert_array_equal(par.cpu().numpy(), order // V)
+    ref_sc = np.take_along_axis(total, order, 1)
+    assert_close(sc.cpu().numpy(), ref_sc, 1e-6, 'beam scores')
+    bidx = np.arange(B)[:, None]
+    pf = fin[bidx, order // V].astype(bool)
+    np.testing.assert_array_equal(d_fin.cpu().numpy().astype(bool), pf | (order % V == end))
+    np.testing.assert_array_equal(d_len.cpu().numpy(), lens[bidx, order // V] + (~pf))
+    assert word.cpu().numpy()[0, 0] == 5 and word.cpu().numpy()[0, 1] == 9
+
+
+def test_gather_tree_matches_oracle():
+    rng = np.random.default_rng(6)
+    T, B, W, end = 9, 5, 4, 17
+    step = rng.integers(0, 18, (T, B, W)).astype(np.int32)
+    par = rng.integers(0, W, (T, B, W)).astype(np.int32)
+    ml = np.array([9, 4, 0, 12, 1], np.int32)
+    out = torch.empty((T, B, W), dtype=torch.int32, device=DEV)
+    L.check(lib().comic_gather_tree(dev(step).data_ptr(), dev(par).data_ptr(), dev(ml).data_ptr(), out.data_ptr(),
+                                    T, B, W, end, stream()))
+    np.testing.assert_array_equal(out.cpu().numpy(), beam_ref.gather_tree(step, par, ml, end))
+
+
+def test_adam_tf_matches_oracle():
+    rng = np.random.default_rng(7)
+    n = 100003
+    w = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    m = (0.1 * rng.standard_normal(n)).astype(np.float32); v = (0.1 * rng.random(n)).astype(np.float32)
+    dw, dg, dm, dv = dev(w), dev(g), dev(m), dev(v)
+    t, lr, l2 = 3, 1e-2, 1e-5
+    lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    L.check(lib().comic_adam_tf(dw.data_ptr(), dg.data_ptr(), dm.data_ptr(), dv.data_ptr(), n, lr_t, 0.9, 0.999,
+                                1e-2, l2, 1.0, stream()))
+    g_eff = g + np.float32(l2) * w
+    dr.adam_tf_update(w, g_eff, m, v, t, lr, eps=1e-2)
+    assert_close(dw.cpu().numpy(), w, 1e-6, 'adam w')
+    assert_close(dm.cpu().numpy(), m, 1e-6, 'adam m')
+    assert_close(dv.cpu().numpy(), v, 1e-6, 'adam v')
