@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of decoder-mode XE training (BASELINE.json configs[1]):
+COMIC-256 (radix-256 tokens, 8 heads, tied projection) on InceptionV3 (frozen, bf16 conv
+MFMA path), batch 64 per GPU, synthetic 224x224x3 inputs resident in HBM.
+
+One "step" = InceptionV3 forward + keys projection + teacher-forced decoder forward and
+backward + (N>1: RCCL all-reduce of the 22.8 MB flat gradient) + fused TF-Adam update.
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 64
+IMG = 224
+FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
+PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
+
+
+def synth_captions(rng, B):
+    """N ~ U{8..14} words, ids ~ U{0..9999}, radix-256 -> [256, d1 d0 ..., 257], PAD -1."""
+    rows = []
+    for _ in range(B):
+        n = int(rng.integers(8, 15))
+        ids = rng.integers(0, 10000, n)
+        r = [256]
+        for w in ids:
+            r += [int(w) // 256, int(w) % 256]
+        r.append(257)
+        rows.append(r)
+    L = max(len(r) for r in rows)
+    out = np.full((B, L), -1, np.int64)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (numpy restatement of the reference graph: 'port') timed on this host's
+    cores for the same step at the reference's CPU-runnable size (configs[0]: batch 2)."""
+    from oracle import cnn_ref, decoder_ref as dr
+    rng = np.random.default_rng(0)
+    B = 2
+    params = cnn_ref.init_params(0, IMG)
+    cfg = dr.DecoderConfig()
+    p = dr.init_params(cfg, 0)
+    x = rng.uniform(-1, 1, (B, IMG, IMG, 3)).astype(np.float32)
+    caps = synth_captions(rng, B)
+    n, t0 = 0, time.time()
+    while True:
+        im, fm = cnn_ref.encoder(params, x)
+        masks = dr.make_dropout_masks(cfg, B, caps.shape[1] - 1, fm.shape[1], n)
+        out = dr.train_forward(p, cfg, fm, im, caps, masks)
+        grads, _, _ = dr.train_backward(p, cfg, out)
+        for k in p:
+            p[k] = p[k] - np.float32(1e-3) * grads[k]
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 8:
+            break
+    dt = time.time() - t0
+    return dict(value=round(n * B / dt, 3), unit='images/sec', cores=os.cpu_count(), kind='port',
+                sample='%d decoder-mode XE steps at batch %d (InceptionV3 fwd + decoder fwd/bwd + SGD update), '
+                       'numpy/OpenBLAS oracle on all host cores' % (n, B))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = 'cuda:%d' % local_rank
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device(device))
+
+    from comic_amd import decoder as cdec, nets, trainer
+    dp = trainer.DataParallel(dist if world > 1 else None)
+    plan = nets.CnnPlan('inception_v3', (IMG, IMG))
+    cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
+    spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
+    tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1)
+    # identical initial parameters on every rank (C2: broadcast)
+    if world > 1:
+        dist.broadcast(tr.decoder.params.data, 0)
+    rng = np.random.default_rng(48964896 + rank)                # train.py:203 seed
+    images = torch.from_numpy(rng.uniform(-1, 1, (BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+    cap_sets = [synth_captions(rng, BATCH) for _ in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.xe_step(images, cap_sets[i % 4])
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # HIP events on the launch stream bracket the CNN forward (the conv implicit-GEMM kernels)
+        ev[i][0].record()
+        im_embed, fm = tr.encoder.forward(images)
+        ev[i][1].record()
+        cap = cap_sets[i % 4]
+        denom = None
+        if world > 1:
+            denom = dp.global_tokens(float((cap[:, 1:] >= 0).sum()), device) / world + 1e-12
+        res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom)
+        scale = dp.average_(tr.decoder.grads.data)
+        tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    loss = float(res['loss'])
+    assert np.isfinite(loss), 'non-finite loss'
+
+    if rank == 0:
+        n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1))
+        achieved = FLOP_PER_IMAGE_CNN * BATCH / (cnn_ms * 1e-3)
+        out = {
+            'metric': 'images/sec (decoder-mode XE training, COMIC-256, InceptionV3 frozen)',
+            'value': round(BATCH * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'MS-COCO decoder-mode XE, COMIC-256 (radix-256, 8 heads, tied), InceptionV3 '
+                                   'frozen, batch 64/GPU, 224x224x3 (BASELINE configs[1])',
+                       'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'image_size': IMG,
+                       'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<bf16> (%d conv launches per step, whole '
+                                                    'InceptionV3 forward timed with HIP events)' % n_conv,
+                         'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
+                         'cnn_forward_ms': round(cnn_ms, 4)},
+            'final_loss': round(loss, 5),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

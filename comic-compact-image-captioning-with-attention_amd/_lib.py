@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
 class CnnOp(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
-        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'reserved')]
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32')]
 
 
 class ConvWeight(C.Structure):

@@ -520,9 +520,14 @@ extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x
                                     const comic_conv_weight* wt, int batch, int dtype, void* stream) {
   COMIC_REQUIRE(op, "null op");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == COMIC_BF16 && op->src_f32) {
+    COMIC_REQUIRE(op->kind == 4, "src_f32 is only supported by the global average pool");
+    return run_op<float>(op, x, x_channels, y, y_channels, wt, batch, st);
+  }
   if (dtype == COMIC_BF16) return run_op<bf16_t>(op, x, x_channels, y, y_channels, wt, batch, st);
   if (dtype == COMIC_F32) return run_op<float>(op, x, x_channels, y, y_channels, wt, batch, st);
   COMIC_REQUIRE(false, "unknown dtype %d", dtype);
+  return 2;
 }
 
 extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,

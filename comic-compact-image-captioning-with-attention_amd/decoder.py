@@ -259,18 +259,21 @@ class Decoder:
 
     # ------------------------------------------------------------------ training -------
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
-                   want_input_grads=False):
+                   want_input_grads=False, xe_denom=None):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
         mean_b(xent_b * reward_b) (model_base.py:342-347).
+        xe_denom: override of the XE normaliser sum(w)+1e-12 (data parallel: global token count / world size,
+        so that the rank-mean of the gradients equals the single-process gradient of the global batch).
         Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device)."""
         torch, s = self.torch, self.spec
         inputs, targets, wmask, lens = process_inputs(captions, s.token_type)
         B, T = inputs.shape
         Tp = int(lens.max())
         if rewards is None:
-            coef = wmask / np.float32(wmask.sum() + np.float32(1e-12))
+            den_xe = np.float32(xe_denom) if xe_denom is not None else np.float32(wmask.sum() + np.float32(1e-12))
+            coef = wmask / den_xe
         else:
             den = wmask.sum(axis=1, keepdims=True) + np.float32(1e-12)
             coef = wmask / den * (np.asarray(rewards, np.float32)[:, None] / np.float32(B))
@@ -309,7 +312,7 @@ class Decoder:
         # sequence_loss reduction (model_base.py:337-347): rows already carry xent*w
         lr = loss_rows.view(T, B)
         if rewards is None:
-            xe = lr.sum() / float(wmask.sum() + np.float32(1e-12))
+            xe = lr.sum() / float(den_xe)
         else:
             den_t = self._dev((wmask.sum(axis=1) + np.float32(1e-12)).astype(np.float32))
             xe = ((lr.sum(dim=0) / den_t) * self._dev(np.asarray(rewards, np.float32))).mean()

@@ -195,7 +195,8 @@ class CnnPlan:
         Hp, Wp = Hf - kh + 1, Wf - kw + 1
         pooled = self._buf(Hp, Wp, Cf, True)
         self.ops.append(dict(kind=4, src=cur, dst=pooled, src_coff=0, dst_coff=0, H=Hf, W=Wf, Cin=Cf, Cout=Cf, KH=kh,
-                             KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1))
+                             KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1,
+                             src_f32=int(f32)))
         self.pooled = pooled
         self.end_points['AvgPool_1a'] = pooled
 

@@ -63,7 +63,8 @@ typedef struct comic_cnn_op {
   int32_t weight;    /* index into the weight table (conv ops) */
   int32_t relu;
   int32_t out_f32;   /* store fp32 even when the plan dtype is bf16 */
-  int32_t reserved;
+  int32_t src_f32;   /* the source buffer holds fp32 although the plan dtype is bf16
+                        (global avg-pool over the fp32 attention feature map) */
 } comic_cnn_op;
 
 typedef struct comic_conv_weight {

@@ -23,3 +23,11 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_parked_tensors(request):
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from tests import gpu_util
+        gpu_util.release()

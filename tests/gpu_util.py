@@ -44,3 +44,20 @@ def stream():
 
 def sync():
     torch.cuda.synchronize()
+
+
+# Host arrays handed to an asynchronous kernel by raw pointer must stay alive until the
+# kernel has run: a temporary `dev(x).data_ptr()` frees its block right away and the next
+# temporary re-uses the same address.  P() parks the tensor until the test ends.
+_KEEP = []
+
+
+def P(a, dtype=None):
+    t = dev(a, dtype)
+    _KEEP.append(t)
+    return t.data_ptr()
+
+
+def release():
+    sync()
+    _KEEP.clear()
