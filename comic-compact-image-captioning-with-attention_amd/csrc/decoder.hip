@@ -16,6 +16,17 @@ constexpr float kLnEps = 1e-12f;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// tanh for the attention score (called B*M*D times per step): odd polynomial below 0.25
+// (next term < 2e-9), 1 - 2/(1+e^{2|x|}) on v_exp_f32 above; |error| < 3e-7 absolute.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float p = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.053968254f + x2 * 0.021869488f))));
+  const float e = __expf(2.0f * ax);
+  const float t = 1.0f - __fdividef(2.0f, e + 1.0f);
+  return ax < 0.25f ? p : copysignf(t, x);
+}
+
 // ------------------------------------------------------------------ embeddings --------
 __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                  float* __restrict__ out, long total, int E, int V) {
@@ -27,14 +38,43 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t*
 }
 
 // one block per vocabulary row: deterministic sum over the rows that reference it
-__global__ void embed_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dout,
-                                 float* __restrict__ dtable, int rows, int E) {
-  const int v = blockIdx.x;
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids,
+                                                        const float* __restrict__ dout,
+                                                        float* __restrict__ dtable, int rows, int E) {
+  // ordered (ascending row) compaction of the rows that hold this vocabulary id, then a
+  // sequential sum over that list: deterministic, and the id scan is parallel
+  __shared__ int list[2048];
+  __shared__ int wcnt[4];
+  __shared__ int total;
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  for (int base = 0; base < rows; base += 256) {
+    const int r = base + tid;
+    const bool hit = r < rows && ids[r] == v;
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = total;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    if (hit) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (pos < 2048) list[pos] = r;
+    }
+    __syncthreads();
+    if (tid == 0) total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int n = min(total, 2048);
+  if (n == 0) return;
+  for (int e = tid; e < E; e += 256) {
     float acc = 0.f;
-    for (int r = 0; r < rows; ++r)
-      if (ids[r] == v) acc += dout[(size_t)r * E + e];
-    if (acc != 0.f) dtable[(size_t)v * E + e] += acc;
+    for (int i = 0; i < n; ++i) acc += dout[(size_t)list[i] * E + e];
+    // rows beyond the LDS list (a token repeated > 2048 times in one batch): direct scan
+    if (total > 2048)
+      for (int r = list[2047] + 1; r < rows; ++r)
+        if (ids[r] == v) acc += dout[(size_t)r * E + e];
+    dtable[(size_t)v * E + e] += acc;
   }
 }
 
@@ -66,7 +106,8 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ g, const float* 
                                       float* __restrict__ c_new, float* __restrict__ h_new, float* __restrict__ y,
                                       const float* __restrict__ mask_out, float keep_out,
                                       const int32_t* __restrict__ lens, int t, float* __restrict__ c_state,
-                                      float* __restrict__ h_state, int B, int D) {
+                                      float* __restrict__ h_state, int B, int D, float* __restrict__ xh_next,
+                                      int xh_ld) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   const int b = i / D, d = i % D;
@@ -86,7 +127,9 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ g, const float* 
   if (y) y[i] = mask_out ? (h2 / keep_out) * mask_out[i] : h2;
   const bool fin = lens && (t >= lens[b]);
   if (c_state) c_state[i] = fin ? cp : c2;
-  if (h_state) h_state[i] = fin ? (h_prev ? h_prev[i] : 0.f) : h2;
+  const float hs = fin ? (h_prev ? h_prev[i] : 0.f) : h2;
+  if (h_state) h_state[i] = hs;
+  if (xh_next) xh_next[(size_t)b * xh_ld + d] = hs;  // recurrent part of the next step's GEMM operand
 }
 
 __global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates_act, const float* __restrict__ c_prev,
@@ -128,6 +171,16 @@ struct AttnArgs {
   const float *keys, *values, *q, *ln_g, *ln_b, *v, *tau, *alpha_in, *mask_alpha, *dctx, *dmap;
   float keep_alpha;
   float *alpha, *alpha_d, *ctx, *dq, *dkeys, *dvalues, *pgrad;
+  // optional fusion of the wrapper's state plumbing (executor only; all NULL in the public op)
+  const int32_t* lens;      // finished rule t >= lens[b]
+  int t;
+  const float* att_prev;    // [B,Cv] previous attention state (forward select)
+  float* att_next;          // [B,Cv] att_next = fin ? att_prev : ctx
+  float* xh_next;           // next step's LSTM input row: xh_next[b*xh_ld + c] = drop(att_next[c])
+  int xh_ld;
+  const float* mask_next;   // [B, mask_ld] input-dropout mask of the next step (offset applied by caller)
+  int mask_ld;
+  float keep_in;
 };
 
 template <int EPL>
@@ -179,7 +232,7 @@ __device__ __forceinline__ float score_row(const AttnArgs& a, const float* kr, c
       // tf.nn.batch_normalization form: x*inv + (beta - mean*inv), inv = rstd*gamma
       const float inv = rstd * gv[i];
       const float zh = z[i] * inv + (bv[i] - mean * inv);
-      const float t = tanhf(zh);
+      const float t = fast_tanh(zh);
       if (th) th[i] = t;
       if (xh) xh[i] = (z[i] - mean) * rstd;
       part += t * vv[i];
@@ -255,6 +308,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     float acc = 0.f;
     for (int m = 0; m < M; ++m) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
     a.ctx[(size_t)b * Cv + c] = acc;
+    if (a.att_next) {  // impute_finished select + next step's (dropped) LSTM input
+      const bool fin = a.lens && a.t >= a.lens[b];
+      const float av = fin ? a.att_prev[(size_t)b * Cv + c] : acc;
+      a.att_next[(size_t)b * Cv + c] = av;
+      if (a.xh_next) {
+        float xv = av;
+        if (a.mask_next) xv = (xv / a.keep_in) * a.mask_next[(size_t)b * a.mask_ld + c];
+        a.xh_next[(size_t)b * a.xh_ld + c] = xv;
+      }
+    }
   }
 }
 
@@ -281,6 +344,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int dv = Cv / H, eplv = Cv / 64, lphv = dv / eplv;
   const int c0 = lane * eplv, headv = c0 / dv;
   const float* dctx = a.dctx + (size_t)b * Cv;
+  // state-gradient form: only live rows pass d(att state) into the context (finished rows
+  // kept their previous state)
+  const float live = (a.lens && a.t >= a.lens[b]) ? 0.f : 1.f;
 
   // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
   for (int m = wave; m < M; m += 4) {
@@ -296,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     float* dvr = a.dvalues + ((size_t)b * M + m) * Cv + c0;
     float part = 0.f;
     for (int i = 0; i < eplv; ++i) {
-      const float dc = dctx[c0 + i];
+      const float dc = dctx[c0 + i] * live;
       part = fmaf(dc, vr[i], part);
       dvr[i] += ad * dc;
     }
@@ -497,9 +563,17 @@ __global__ void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ 
 __global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, float beta) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
-  float acc = 0.f;
-  for (int i = 0; i < rows; ++i) acc += in[(size_t)i * cols + j];
-  out[j] = (beta != 0.f ? beta * out[j] : 0.f) + acc;
+  // fixed summation tree (4 interleaved partial sums) -> deterministic, 4 loads in flight
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  for (; i + 3 < rows; i += 4) {
+    a0 += in[(size_t)i * cols + j];
+    a1 += in[(size_t)(i + 1) * cols + j];
+    a2 += in[(size_t)(i + 2) * cols + j];
+    a3 += in[(size_t)(i + 3) * cols + j];
+  }
+  for (; i < rows; ++i) a0 += in[(size_t)i * cols + j];
+  out[j] = (beta != 0.f ? beta * out[j] : 0.f) + ((a0 + a1) + (a2 + a3));
 }
 
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
@@ -549,8 +623,7 @@ extern "C" int comic_embed_fwd(const float* table, const int32_t* ids, float* ou
 
 extern "C" int comic_embed_bwd(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V,
                                void* stream) {
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(E < 256 ? ((E + 63) / 64) * 64 : 256), 0, (hipStream_t)stream,
-                     ids, dout, dtable, rows, E);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, rows, E);
   COMIC_LAUNCH_CHECK("embed_bwd");
   return 0;
 }
@@ -577,7 +650,18 @@ extern "C" int comic_lstm_gates_fwd(const float* g, const float* c_prev, const f
                                     void* stream) {
   COMIC_REQUIRE(g, "lstm_gates_fwd: null input");
   hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, g, c_prev,
-                     h_prev, gates_act, c_new, h_new, y, mask_out, keep_out, lens, t, c_state, h_state, B, D);
+                     h_prev, gates_act, c_new, h_new, y, mask_out, keep_out, lens, t, c_state, h_state, B, D,
+                     (float*)nullptr, 0);
+  COMIC_LAUNCH_CHECK("lstm_gates_fwd");
+  return 0;
+}
+
+// executor-internal: also scatters the carried h into the next step's [x;att;h] operand row
+int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
+                            float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
+                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, g, c_prev, h_prev, gates_act,
+                     c_new, (float*)nullptr, y, mask_out, keep_out, lens, t, c_state, h_state, B, D, xh_next, xh_ld);
   COMIC_LAUNCH_CHECK("lstm_gates_fwd");
   return 0;
 }
@@ -592,10 +676,12 @@ extern "C" int comic_lstm_gates_bwd(const float* gates_act, const float* c_prev,
   return 0;
 }
 
-extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
-                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
-                                   const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
-                                   void* stream) {
+// executor-internal forms (fused state plumbing); the public ops pass no extras
+int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                      const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
+                      float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
+                      const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
+                      int mask_ld, float keep_in, hipStream_t st) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && alpha_d && ctx, "attn_fwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_fwd: add_LN needs ln_g/ln_b/v/tau");
@@ -603,8 +689,9 @@ extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, 
   a.d = *d;
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.alpha = alpha; a.alpha_d = alpha_d; a.ctx = ctx;
+  a.lens = lens; a.t = t; a.att_prev = att_prev; a.att_next = att_next; a.xh_next = xh_next; a.xh_ld = xh_ld;
+  a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in;
   const size_t lds = (size_t)d->H * d->M * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
   });
@@ -613,11 +700,10 @@ extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, 
   return 0;
 }
 
-extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
-                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
-                                   const float* alpha, const float* mask_alpha, float keep_alpha, const float* dctx,
-                                   const float* dmap, float* dq, float* dkeys, float* dvalues, float* pgrad,
-                                   void* stream) {
+int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                      const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
+                      const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
+                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && dctx && dq && dkeys && dvalues, "attn_bwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_bwd: add_LN needs ln_g/ln_b/v/tau");
@@ -625,15 +711,31 @@ extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, 
   a.d = *d;
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
-  a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad;
+  a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad; a.lens = lens; a.t = t;
   const size_t lds = ((size_t)d->H * d->M * 2 + 4 * d->D + 16) * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_bwd");
   return 0;
+}
+
+extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
+                                   const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
+                                   void* stream) {
+  return comic_attn_fwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, mask_alpha, keep_alpha, alpha, alpha_d, ctx, nullptr,
+                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                                   const float* ln_g, const float* ln_b, const float* v, const float* tau,
+                                   const float* alpha, const float* mask_alpha, float keep_alpha, const float* dctx,
+                                   const float* dmap, float* dq, float* dkeys, float* dvalues, float* pgrad,
+                                   void* stream) {
+  return comic_attn_bwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, alpha, mask_alpha, keep_alpha, dctx, dmap, dq,
+                           dkeys, dvalues, pgrad, nullptr, 0, (hipStream_t)stream);
 }
 
 // t_rows time steps of logits are processed; the [B, t_stride] tables are indexed b*t_stride + t
@@ -665,7 +767,7 @@ extern "C" int comic_adam_tf(float* w, const float* g, float* m, float* v, int64
 }
 
 extern "C" int comic_colsum(const float* in, float* out, int rows, int cols, float beta, void* stream) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols,
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, in, out, rows, cols,
                      beta);
   COMIC_LAUNCH_CHECK("colsum");
   return 0;

@@ -16,10 +16,26 @@
 
 #include "common.h"
 
-// internal cross-file entry (decoder.hip)
+// internal cross-file entries (gemm.hip, decoder.hip)
+int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                      int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws, int64_t ws_bytes,
+                      hipStream_t st);
 int comic_xent_ex(float* logits, const int32_t* targets_bt, const float* coef_bt, const float* wmask_bt,
                   const int32_t* lens, float* loss_rows, float* dlogits, int32_t* ids_tb, int t_rows, int t_stride,
                   int B, int V, hipStream_t st);
+
+int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                      const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
+                      float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
+                      const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
+                      int mask_ld, float keep_in, hipStream_t st);
+int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
+                      const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
+                      const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
+                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st);
+int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
+                            float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
+                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, hipStream_t st);
 
 namespace {
 
@@ -62,6 +78,38 @@ __global__ void assemble_input_kernel(const float* __restrict__ x, const float* 
   xh[i] = v;
 }
 
+// xh_all[t][b][0:E] = drop(emb[ids[t,b]]) for every step at once (embedding lookup hoisted out
+// of the time loop; the attention / recurrent parts of the row are filled by the step kernels)
+__global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids_tb,
+                                   const float* __restrict__ mask, float keep, float* __restrict__ xh, long rows,
+                                   int E, int V, int EA, int Wd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * E) return;
+  const long r = i / E;
+  const int e = (int)(i % E);
+  const int id = ids_tb[r];
+  float v = (id >= 0 && id < V) ? table[(size_t)id * E + e] : 0.f;
+  if (mask) v = (v / keep) * mask[(size_t)r * EA + e];
+  xh[(size_t)r * Wd + e] = v;
+}
+
+// context-layer path only: att_next = fin ? att_prev : att_cur ; xh_next[:, E:E+A] = drop(att_next)
+__global__ void select_att_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
+                                  const int32_t* __restrict__ lens, int t, float* __restrict__ dst,
+                                  float* __restrict__ xh_next, int xh_ld, const float* __restrict__ mask_next,
+                                  int mask_ld, float keep, int B, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, c = i % A;
+  const float v = (lens && t >= lens[b]) ? prev[i] : cur[i];
+  dst[i] = v;
+  if (xh_next) {
+    float x = v;
+    if (mask_next) x = (x / keep) * mask_next[(size_t)b * mask_ld + c];
+    xh_next[(size_t)b * xh_ld + c] = x;
+  }
+}
+
 // dst = fin ? prev : cur      (impute_finished state select; lens NULL -> copy cur)
 __global__ void select_rows_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
                                    const int32_t* __restrict__ lens, int t, float* __restrict__ dst, int B, int C) {
@@ -84,9 +132,11 @@ __global__ void split_live_kernel(float* __restrict__ d, float* __restrict__ out
 }
 
 // dxh [B, E+A+D] -> demb_t [B,E] = drop'(dxh[:, :E]); datt += drop'(dxh[:, E:E+A]); dh += dxh[:, E+A:]
+// `carry`: datt holds d(att state after this step); only FINISHED rows carry it through to the
+// state before the step (live rows' share went into the context inside attn_bwd).
 __global__ void input_bwd_kernel(const float* __restrict__ dxh, const float* __restrict__ mask, float keep,
-                                 float* __restrict__ demb, float* __restrict__ datt, float* __restrict__ dh, int B,
-                                 int E, int A, int D) {
+                                 float* __restrict__ demb, float* __restrict__ datt, float* __restrict__ dh,
+                                 const int32_t* __restrict__ lens, int t, int carry, int B, int E, int A, int D) {
   const int W = E + A + D;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * W) return;
@@ -97,7 +147,9 @@ __global__ void input_bwd_kernel(const float* __restrict__ dxh, const float* __r
     if (c < E) {
       if (demb) demb[(size_t)b * E + c] = v;
     } else {
-      datt[(size_t)b * A + (c - E)] += v;
+      float* p = datt + (size_t)b * A + (c - E);
+      const bool fin = lens && t >= lens[b];
+      *p = ((carry && !fin) ? 0.f : *p) + v;
     }
   } else {
     dh[(size_t)b * D + (c - E - A)] += v;
@@ -106,6 +158,46 @@ __global__ void input_bwd_kernel(const float* __restrict__ dxh, const float* __r
 
 // flat[b,t,m] = sum_h hist[t,b,h,m];  map_loss = mean((1-flat)^2)*scale;
 // dmap[t,b,m] = 2*(flat-1)/(B*Tp*M)*scale.   Single workgroup (deterministic).
+// two stages (fixed partition -> deterministic): per-workgroup partial sums, then one workgroup
+__global__ __launch_bounds__(256) void maploss_part_kernel(const float* __restrict__ hist, float* __restrict__ dmap,
+                                                           float* __restrict__ partial, int Tp, int B, int H, int M,
+                                                           float scale) {
+  __shared__ float red[256];
+  const long n = (long)Tp * B * M;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (i < n) {
+    const int m = (int)(i % M);
+    const long tb = i / M;
+    const float* p = hist + (size_t)tb * H * M + m;
+    float f = 0.f;
+    for (int h = 0; h < H; ++h) f += p[(size_t)h * M];
+    const float d = 1.0f - f;
+    acc = d * d;
+    if (dmap) dmap[i] = 2.0f * (f - 1.0f) / (float)n * scale;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void maploss_final_kernel(const float* __restrict__ partial, int nparts, long n,
+                                                            float scale, float* __restrict__ map_loss) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) map_loss[0] = red[0] / (float)n * scale;
+}
+
 __global__ __launch_bounds__(1024) void maploss_kernel(const float* __restrict__ hist, float* __restrict__ dmap,
                                                        float* __restrict__ map_loss, int Tp, int B, int H, int M,
                                                        float scale) {
@@ -189,9 +281,14 @@ inline int fill(float* p, float v, long n, hipStream_t st) {
   COMIC_LAUNCH_CHECK("fill");
   return 0;
 }
+// split-K scratch of the running executor call (carved from the caller's workspace)
+constexpr int64_t kSplitKBytes = 8ll << 20;
+thread_local void* g_splitk_ws = nullptr;
+
 inline int gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int ta, int tb, float beta, hipStream_t st) {
-  return comic_gemm_f32(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, (void*)st);
+  return comic_gemm_f32_ws(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, g_splitk_ws,
+                           g_splitk_ws ? kSplitKBytes : 0, st);
 }
 
 int check_desc(const comic_decoder_desc* d) {
@@ -296,6 +393,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(TB * E); w.take<float>(B * M * D); w.take<float>(B * M * Cv); // demb, dkeys, dvalues
   w.take<float>(B * (3 * D + 1)); w.take<float>(TB * M);                       // pgrad, dmap
   w.take<float>(B * (E + A));                                                  // dx_init
+  w.take<char>(kSplitKBytes);                                                  // split-K partials
   return (int64_t)w.off;
 }
 
@@ -357,6 +455,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* pgrad = w.take<float>((long)B * (3 * D + 1));
   float* dmap = w.take<float>(TB * M);
   float* dx_init = w.take<float>((long)B * EA);
+  g_splitk_ws = w.take<char>(kSplitKBytes);
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
 
   const comic_attn_desc ad = attn_desc(d, B);
@@ -367,49 +466,72 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(fill(att_all, 0.f, (long)B * A, st));
   hipLaunchKernelGGL(transpose_ids_kernel, dim3(cdiv(Tp * B, 256)), dim3(256), 0, st, inputs_bt, in_tb, B, T, Tp);
   COMIC_LAUNCH_CHECK("transpose_ids");
-  RC(comic_embed_fwd(p->emb, in_tb, emb_all, Tp * B, E, V, (void*)st));
+  // x part of every step's [x ; att ; h] operand row: embedding lookup + input dropout, hoisted
+  {
+    const long n = (long)Tp * B * E;
+    hipLaunchKernelGGL(embed_to_xh_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, in_tb,
+                       drop_in ? mask_in : nullptr, d->keep_in, xh_all, (long)Tp * B, E, V, EA, Wd);
+    COMIC_LAUNCH_CHECK("embed_to_xh");
+  }
+  // step 0 operand: att = 0 (dropout of 0 is 0), h = h0
+  hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_all, att_all,
+                     (const int32_t*)nullptr, 0, att_all, xh_all + E, Wd, (const float*)nullptr, 0, 1.f, B, A);
+  hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, hs, hs, (const int32_t*)nullptr, 0,
+                     hs, xh_all + EA, Wd, (const float*)nullptr, 0, 1.f, B, D);
+  COMIC_LAUNCH_CHECK("step0 operand");
   for (int t = 0; t < Tp; ++t) {
     float* xh_t = xh_all + (size_t)t * B * Wd;
+    float* xh_n = (t + 1 < Tp) ? xh_all + (size_t)(t + 1) * B * Wd : nullptr;
     const float* c_prev = cs + (size_t)t * B * D;
     const float* h_prev = hs + (size_t)t * B * D;
     const float* att_prev = att_all + (size_t)t * B * A;
-    hipLaunchKernelGGL(assemble_input_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st,
-                       emb_all + (size_t)t * B * E, att_prev, h_prev, drop_in ? mask_in + (size_t)t * B * EA : nullptr,
-                       d->keep_in, xh_t, B, E, A, D);
-    COMIC_LAUNCH_CHECK("assemble_input");
+    float* att_next = att_all + (size_t)(t + 1) * B * A;
+    const float* mask_n = (drop_in && xh_n) ? mask_in + (size_t)(t + 1) * B * EA + E : nullptr;
     RC(gemm(xh_t, p->K, g_tmp, p->b, B, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
     float* y_t = y_all + (size_t)t * B * D;
-    RC(comic_lstm_gates_fwd(g_tmp, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D, cnew_all + (size_t)t * B * D,
-                            nullptr, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t,
-                            cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D, (void*)st));
+    RC(comic_lstm_gates_fwd_ex(g_tmp, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
+                               cnew_all + (size_t)t * B * D, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
+                               d->keep_out, lens, t, cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D,
+                               xh_n ? xh_n + EA : nullptr, Wd, st));
     float* q_t = q_all + (size_t)t * B * D;
     RC(gemm(y_t, p->W_q, q_t, nullptr, B, D, D, D, D, D, 0, 0, 0.f, st));
     float* ctx_t = ctx_all + (size_t)t * B * Cv;
-    RC(comic_attn_step_fwd(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau,
-                           drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr, d->keep_alpha,
-                           alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, (void*)st));
-    const float* att_cur = ctx_t;
-    if (d->context_layer) {
+    const float* mal = drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr;
+    if (!d->context_layer) {
+      RC(comic_attn_fwd_ex(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
+                           alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, lens, t,
+                           att_prev, att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, st));
+    } else {
+      RC(comic_attn_fwd_ex(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
+                           alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, nullptr, 0,
+                           nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, st));
       RC(gemm(ctx_t, p->W_a, att_new, nullptr, B, D, Cv, Cv, D, D, 0, 0, 0.f, st));
-      att_cur = att_new;
+      hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_prev, att_new, lens, t,
+                         att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, B, A);
+      COMIC_LAUNCH_CHECK("select_att");
     }
-    hipLaunchKernelGGL(select_rows_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_prev, att_cur, lens, t,
-                       att_all + (size_t)(t + 1) * B * A, B, A);
-    COMIC_LAUNCH_CHECK("select_rows");
   }
   // output projection for all executed steps, loss, d logits
   RC(gemm(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
   RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
   for (int t = Tp; t < T; ++t) {  // ops_rnn.py:235-241: pad by copying the last executed step
     (void)hipMemcpyAsync(logits_tb + (size_t)t * B * V, logits_tb + (size_t)(Tp - 1) * B * V, sizeof(float) * B * V,
-                   hipMemcpyDeviceToDevice, st);
+                         hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(ids_tb + (size_t)t * B, ids_tb + (size_t)(Tp - 1) * B, sizeof(int32_t) * B,
-                   hipMemcpyDeviceToDevice, st);
+                         hipMemcpyDeviceToDevice, st);
     RC(fill(loss_rows + (size_t)t * B, 0.f, B, st));
   }
-  hipLaunchKernelGGL(maploss_kernel, dim3(1), dim3(1024), 0, st, attn_hist, dmap, map_loss, Tp, B, H, M,
-                     d->map_loss_scale);
-  COMIC_LAUNCH_CHECK("maploss");
+  {
+    const long n = (long)Tp * B * M;
+    const int nparts = (int)cdiv64(n, 256);
+    float* partial = dxh;  // free until the backward loop; needs nparts floats
+    COMIC_REQUIRE(nparts <= B * Wd, "train_step: map-loss scratch too small");
+    hipLaunchKernelGGL(maploss_part_kernel, dim3(nparts), dim3(256), 0, st, attn_hist, dmap, partial, Tp, B, H, M,
+                       d->map_loss_scale);
+    hipLaunchKernelGGL(maploss_final_kernel, dim3(1), dim3(256), 0, st, partial, nparts, n, d->map_loss_scale,
+                       map_loss);
+    COMIC_LAUNCH_CHECK("maploss");
+  }
 
   // ------------------------------------------------------------------ backward -----------
   const bool use_map = d->map_loss_scale > 0.f;
@@ -427,20 +549,26 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(comic_colsum(dlogits, gr->b_o, Tp * B, V, 0.f, (void*)st));
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
   for (int t = Tp - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
-    COMIC_LAUNCH_CHECK("split_live");
     const float* ctx_t = ctx_all + (size_t)t * B * Cv;
-    const float* dctx_t = datt_live;
-    if (d->context_layer) {
+    float* dq_t = dq_all + (size_t)t * B * D;
+    const float* mal = drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr;
+    int carry;
+    if (!d->context_layer) {
+      // attn_bwd masks d(att state) by "live" itself; input_bwd keeps the finished rows' share
+      RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
+                           alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, datt,
+                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues, pgrad, lens, t, st));
+      carry = 1;
+    } else {
+      hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
+      COMIC_LAUNCH_CHECK("split_live");
       RC(gemm(ctx_t, datt_live, gr->W_a, nullptr, Cv, D, B, Cv, D, D, 1, 0, 1.f, st));
       RC(gemm(datt_live, p->W_a, dctx, nullptr, B, Cv, D, D, D, Cv, 0, 1, 0.f, st));
-      dctx_t = dctx;
+      RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
+                           alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, dctx,
+                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues, pgrad, nullptr, 0, st));
+      carry = 0;
     }
-    float* dq_t = dq_all + (size_t)t * B * D;
-    RC(comic_attn_step_bwd(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
-                           alpha_all + (size_t)t * B * H * M, drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr,
-                           d->keep_alpha, dctx_t, use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
-                           pgrad, (void*)st));
     float* dy_t = dy_all + (size_t)t * B * D;
     RC(gemm(dq_t, p->W_q, dy_t, nullptr, B, D, D, D, D, D, 0, 1, 1.f, st));
     float* dg_t = dg_all + (size_t)t * B * 4 * D;
@@ -450,7 +578,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     RC(gemm(dg_t, p->K, dxh, nullptr, B, Wd, 4 * D, 4 * D, 4 * D, Wd, 0, 1, 0.f, st));
     hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, dxh,
                        drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E, datt,
-                       dh, B, E, A, D);
+                       dh, lens, t, carry, B, E, A, D);
     COMIC_LAUNCH_CHECK("input_bwd");
   }
   // time-batched weight gradients
@@ -518,6 +646,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>(R * E); w.take<float>(R * V);                      // x, logits
   w.take<int32_t>(R); w.take<float>(R); w.take<int32_t>(R);        // ids, log_probs, parents
   w.take<float>(R * (2 * D + A));                                  // gather temp
+  w.take<char>(kSplitKBytes);                                      // split-K partials
   return (int64_t)w.off;
 }
 
@@ -547,6 +676,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.x = w.take<float>(R * E); b.logits = w.take<float>(R * V);
   b.ids = w.take<int32_t>(R); b.log_probs = w.take<float>(R); b.parents = w.take<int32_t>(R);
   b.gtmp = w.take<float>(R * (2 * D + A));
+  g_splitk_ws = w.take<char>(kSplitKBytes);
   b.ok = w.ok;
   return b;
 }

@@ -11,6 +11,8 @@
 //   k-contiguous  [rows][16 k]  (+pad): fragment = one 16-byte read, element s used at step s
 //   row-contiguous [16 k][rows] (+pad): fragment = four ds_read_b32 at k = 4*(lane>>4)+s
 // Both forms give lane-group g the physical k = 4g+s at MFMA step s, so the k-sums agree.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -171,6 +173,195 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 64 per row block): the decoder's per-step products at batch 64 are
+// weight-streaming problems (0.34 GFLOP over a 10.5 MB LSTM kernel), so the tiled kernel
+// above (64 workgroups, one 6 KB tile in flight each) is latency-bound.  Here every wave
+// streams its own operands straight into MFMA fragments (no LDS staging, no barriers in
+// the k loop, next k-block prefetched in registers), the k range is split over the 4 waves
+// of a workgroup (reduced through LDS in a fixed order -> deterministic) and, when the
+// caller provides a workspace, additionally over gridDim.y workgroups (partials + a
+// reduce/epilogue kernel) so that ~all 1024 SIMDs take part.
+//
+// A is [M,K] k-contiguous.  B_KC=false: B is [K,N] (n-contiguous): a lane's float4 along n
+// feeds FOUR column-strided 16-wide tiles (tile j = columns n0+4c+j), so the 4 results a
+// lane holds for one row are 4 consecutive columns (float4 store).  B_KC=true: B is [N,K]
+// (k-contiguous): a lane's float4 along k is the 4 MFMA k-steps of tile j = columns
+// n0+16j+c.
+struct SkinnyArgs {
+  const float* A;
+  const float* B;
+  float* C;          // output (S == 1) or partial buffer [S][M][N] (S > 1)
+  const float* bias;
+  int M, N, K, lda, ldb, ldc;
+  float alpha, beta;
+  int kb_per_slice;  // k16-blocks per gridDim.y slice
+  int direct;        // 1: write alpha*acc + bias + beta*C to C ; 0: write raw partial
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float* __restrict__ base, long off, int nvalid, bool vec) {
+  if (nvalid >= 4 && vec) return *(const float4*)(base + off);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (nvalid > 0) r.x = base[off];
+  if (nvalid > 1) r.y = base[off + 1];
+  if (nvalid > 2) r.z = base[off + 2];
+  if (nvalid > 3) r.w = base[off + 3];
+  return r;
+}
+
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
+  constexpr int MT = 4;
+  __shared__ __attribute__((aligned(16))) float red[3 * 64 * 16 * MT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.z * 64;
+  const int KB = (a.K + 15) >> 4;
+  const int kb_begin = blockIdx.y * a.kb_per_slice;
+  const int kb_end = min(KB, kb_begin + a.kb_per_slice);
+  const bool a_vec = (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
+  const bool b_vec = (a.ldb % 4 == 0) && (((uintptr_t)a.B & 15) == 0);
+
+  f32x4_t acc[4][MT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto load_block = [&](int kb, float4* xa, float4* wb) {
+    const int k = kb * 16 + 4 * g;
+    const int kv = a.K - k;  // valid k elements from k on (may be <= 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + 16 * i + r;
+      xa[i] = (m < a.M && kv > 0) ? ld4_guard(a.A, (long)m * a.lda + k, kv, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + r;
+        wb[j] = (n < a.N && kv > 0) ? ld4_guard(a.B, (long)n * a.ldb + k, kv, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int n = n0 + 4 * r;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        wb[s] = (k + s < a.K && n < a.N) ? ld4_guard(a.B, (long)(k + s) * a.ldb + n, a.N - n, b_vec)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto mfma_block = [&](const float4* xa, const float4* wb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float w;
+        if (B_KC) {
+          w = s == 0 ? wb[j].x : s == 1 ? wb[j].y : s == 2 ? wb[j].z : wb[j].w;
+        } else {
+          w = j == 0 ? wb[s].x : j == 1 ? wb[s].y : j == 2 ? wb[s].z : wb[s].w;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float x = s == 0 ? xa[i].x : s == 1 ? xa[i].y : s == 2 ? xa[i].z : xa[i].w;
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, acc[j][i], 0, 0, 0);
+        }
+      }
+  };
+
+  // this wave's k-blocks: kb_begin + wave, +4, ...   (register double buffering)
+  float4 xa0[MT], wb0[4], xa1[MT], wb1[4];
+  int kb = kb_begin + wave;
+  if (kb < kb_end) load_block(kb, xa0, wb0);
+  while (kb < kb_end) {
+    const int kb1 = kb + 4;
+    if (kb1 < kb_end) load_block(kb1, xa1, wb1);
+    mfma_block(xa0, wb0);
+    if (kb1 >= kb_end) break;
+    const int kb2 = kb1 + 4;
+    if (kb2 < kb_end) load_block(kb2, xa0, wb0);
+    mfma_block(xa1, wb1);
+    kb = kb2;
+  }
+
+  // fixed-order reduction over the 4 waves: waves 1..3 park their tiles, wave 0 adds them
+  if (wave > 0) {
+    float* dst = red + (size_t)(wave - 1) * 64 * 16 * MT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) *(float4*)(dst + ((j * MT + i) * 64 + lane) * 4) = *(float4*)&acc[j][i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float* src = red + (size_t)w * 64 * 16 * MT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float4 t = *(const float4*)(src + ((j * MT + i) * 64 + lane) * 4);
+        acc[j][i][0] += t.x; acc[j][i][1] += t.y; acc[j][i][2] += t.z; acc[j][i][3] += t.w;
+      }
+  }
+  // store: lane holds, for output row m = m0+16i+r, tile-column index cidx = 4g+q
+  float* Cout = a.direct ? a.C : a.C + (size_t)blockIdx.y * a.M * a.ldc;
+  const bool c_vec = (a.ldc % 4 == 0) && (((uintptr_t)Cout & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + 16 * i + r;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      // four consecutive columns: NN -> cidx = 4g+u over tiles j=0..3 ; NT -> tile j=u, q=0..3
+      int n;
+      float v[4];
+      if (B_KC) {
+        n = n0 + 16 * u + 4 * g;
+        v[0] = acc[u][i][0]; v[1] = acc[u][i][1]; v[2] = acc[u][i][2]; v[3] = acc[u][i][3];
+      } else {
+        n = n0 + 4 * (4 * g + u);
+        v[0] = acc[0][i][u]; v[1] = acc[1][i][u]; v[2] = acc[2][i][u]; v[3] = acc[3][i][u];
+      }
+      if (n >= a.N) continue;
+      const int nv = min(4, a.N - n);
+      float* cp = Cout + (size_t)m * a.ldc + n;
+      if (a.direct) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] *= a.alpha;
+          if (a.bias && q < nv) v[q] += a.bias[n + q];
+          if (a.beta != 0.f && q < nv) v[q] += a.beta * cp[q];
+        }
+      }
+      if (nv == 4 && c_vec) {
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int q = 0; q < nv; ++q) cp[q] = v[q];
+      }
+    }
+  }
+}
+
+// C = alpha * sum_s P[s] + bias + beta*C
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ C, const float* __restrict__ bias,
+                                     int M, int N, int ldc, int S, float alpha, float beta) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += P[(size_t)k * M * N + i];
+  s *= alpha;
+  if (bias) s += bias[n];
+  float* cp = C + (size_t)m * ldc + n;
+  if (beta != 0.f) s += beta * *cp;
+  *cp = s;
+}
+
 template <int BN>
 void launch(const GemmArgs& a, int ta, int tb, hipStream_t st) {
   dim3 grid(cdiv(a.M, 64), cdiv(a.N, BN));
@@ -187,14 +378,37 @@ void launch(const GemmArgs& a, int ta, int tb, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                              int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
-                              void* stream) {
+int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                      int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws, int64_t ws_bytes,
+                      hipStream_t st) {
   COMIC_REQUIRE(A && B && C, "gemm: null pointer");
   COMIC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape %d %d %d", M, N, K);
   COMIC_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm: leading dimension too small");
+  if (!trans_a && M <= 512) {
+    // skinny path
+    const int KB = (K + 15) / 16, NB = cdiv(N, 64), MB = cdiv(M, 64);
+    int S = 1;
+    if (ws) {
+      S = std::max(1, std::min(std::min(256 / std::max(1, NB * MB), KB / 8), 32));
+      while (S > 1 && (int64_t)S * M * N * 4 > ws_bytes) --S;
+    }
+    SkinnyArgs a{A, B, S > 1 ? (float*)ws : C, bias, M, N, K, lda, ldb, S > 1 ? N : ldc, alpha, beta, cdiv(KB, S),
+                 S > 1 ? 0 : 1};
+    S = cdiv(KB, a.kb_per_slice);
+    dim3 grid(NB, S, MB);
+    if (trans_b)
+      hipLaunchKernelGGL((gemm_skinny_kernel<true>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((gemm_skinny_kernel<false>), grid, dim3(256), 0, st, a);
+    if (a.direct == 0) {
+      const long total = (long)M * N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const float*)ws,
+                         C, bias, M, N, ldc, S, alpha, beta);
+    }
+    COMIC_LAUNCH_CHECK("gemm_skinny");
+    return 0;
+  }
   GemmArgs a{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta};
-  hipStream_t st = (hipStream_t)stream;
   const long blocks64 = (long)cdiv(M, 64) * cdiv(N, 64);
   if (blocks64 >= 192)
     launch<64>(a, trans_a, trans_b, st);
@@ -202,4 +416,11 @@ extern "C" int comic_gemm_f32(const float* A, const float* B, float* C, const fl
     launch<32>(a, trans_a, trans_b, st);
   COMIC_LAUNCH_CHECK("gemm_f32");
   return 0;
+}
+
+extern "C" int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                              int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
+                              void* stream) {
+  return comic_gemm_f32_ws(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, beta, nullptr, 0,
+                           (hipStream_t)stream);
 }
