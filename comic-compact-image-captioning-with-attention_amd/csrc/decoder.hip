@@ -107,13 +107,20 @@ __global__ void lstm_gates_fwd_kernel(const float* __restrict__ g, const float* 
                                       const float* __restrict__ mask_out, float keep_out,
                                       const int32_t* __restrict__ lens, int t, float* __restrict__ c_state,
                                       float* __restrict__ h_state, int B, int D, float* __restrict__ xh_next,
-                                      int xh_ld) {
+                                      int xh_ld, int S, const float* __restrict__ bias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   const int b = i / D, d = i % D;
   const float* gr = g + (size_t)b * 4 * D;
-  const float si = sigmoidf_(gr[d]), tj = tanhf(gr[D + d]);
-  const float sf = sigmoidf_(gr[2 * D + d] + 1.0f), so = sigmoidf_(gr[3 * D + d]);
+  // S > 0: g is [S][B][4D] split-K partials of the pre-activations (bias not yet added)
+  float gi = gr[d], gj = gr[D + d], gf = gr[2 * D + d], go = gr[3 * D + d];
+  for (int s = 1; s < S; ++s) {
+    const float* gs = gr + (size_t)s * B * 4 * D;
+    gi += gs[d]; gj += gs[D + d]; gf += gs[2 * D + d]; go += gs[3 * D + d];
+  }
+  if (bias) { gi += bias[d]; gj += bias[D + d]; gf += bias[2 * D + d]; go += bias[3 * D + d]; }
+  const float si = sigmoidf_(gi), tj = tanhf(gj);
+  const float sf = sigmoidf_(gf + 1.0f), so = sigmoidf_(go);
   const float cp = c_prev ? c_prev[i] : 0.f;
   const float c2 = cp * sf + si * tj;
   const float tc = tanhf(c2);
@@ -136,7 +143,8 @@ __global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates_act, const
                                       const float* __restrict__ c_new, const float* __restrict__ dy,
                                       const float* __restrict__ mask_out, float keep_out,
                                       const int32_t* __restrict__ lens, int t, float* __restrict__ dc_state,
-                                      float* __restrict__ dh_state, float* __restrict__ dg, int B, int D) {
+                                      float* __restrict__ dh_state, float* __restrict__ dg, int B, int D,
+                                      const float* __restrict__ dy_part, int S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   const int b = i / D, d = i % D;
@@ -146,6 +154,7 @@ __global__ void lstm_gates_bwd_kernel(const float* __restrict__ gates_act, const
   const float tc = tanhf(c_new[i]);
   const float dcs = dc_state[i], dhs = dh_state[i];
   float dyv = dy ? dy[i] : 0.f;
+  for (int s = 0; s < S; ++s) dyv += dy_part[(size_t)s * B * D + i];  // + split-K partials of dq * W_q^T
   if (mask_out) dyv = (dyv / keep_out) * mask_out[i];
   const float dh2 = dhs * live + dyv;
   float dc2 = dcs * live;
@@ -181,6 +190,8 @@ struct AttnArgs {
   const float* mask_next;   // [B, mask_ld] input-dropout mask of the next step (offset applied by caller)
   int mask_ld;
   float keep_in;
+  int q_parts;              // > 1: q is [q_parts][B][D] split-K partials; the reduced row goes to q_out
+  float* q_out;
 };
 
 template <int EPL>
@@ -244,8 +255,11 @@ __device__ __forceinline__ float score_row(const AttnArgs& a, const float* kr, c
   return head_sum(part, lph);
 }
 
+constexpr int kAttnWaves = 16;   // waves per workgroup: each wave owns <= 2 memory rows at M=25
+constexpr int kAttnThreads = kAttnWaves * 64;
+
 template <int EPL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int B = a.d.B, M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
   (void)B;
@@ -255,13 +269,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int k0 = lane * EPL, head = k0 / dh;
   float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
   load_row<EPL>(a.q + (size_t)b * D + k0, qv);
+  for (int s = 1; s < a.q_parts; ++s) {
+    float qs[EPL];
+    load_row<EPL>(a.q + ((size_t)s * a.d.B + b) * D + k0, qs);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) qv[i] += qs[i];
+  }
+  if (a.q_out && wave == 0) {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) a.q_out[(size_t)b * D + k0 + i] = qv[i];
+  }
   if (a.d.method == 0) {
     load_row<EPL>(a.ln_g + k0, gv);
     load_row<EPL>(a.ln_b + k0, bv);
     load_row<EPL>(a.v + k0, vv);
   }
   const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
-  for (int m = wave; m < M; m += 4) {
+  for (int m = wave; m < M; m += kAttnWaves) {
     float kr[EPL], rstd;
     load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
   __syncthreads();
   // probability fn per head (wave per head), then dropout; sc <- alpha_d
-  for (int h = wave; h < H; h += 4) {
+  for (int h = wave; h < H; h += kAttnWaves) {
     float* row = sc + h * M;
     const size_t go = ((size_t)b * H + h) * M;
     if (a.d.prob == 0) {
@@ -302,7 +326,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __syncthreads();
   // context: ctx[c] = sum_m alpha_d[head(c)][m] * values[m][c]   (coalesced over c)
   const int dv = Cv / H;
-  for (int c = tid; c < Cv; c += 256) {
+  for (int c = tid; c < Cv; c += kAttnThreads) {
     const float* al = sc + (c / dv) * M;
     const float* vp = a.values + (size_t)b * M * Cv + c;
     float acc = 0.f;
@@ -322,13 +346,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 template <int EPL>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
   float* ss = sm;               // [H][M] scaled scores s
   float* sd = ss + H * M;       // [H][M] d alpha_d, then d raw
-  float* red = sd + H * M;      // [4][D] cross-wave reduction
-  float* misc = red + 4 * D;    // [4] d tau partials
+  float* red = sd + H * M;               // [kAttnWaves][D] cross-wave reduction
+  float* misc = red + kAttnWaves * 512;  // [kAttnWaves] d tau partials
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dh = D / H, lph = dh / EPL;
   const int k0 = lane * EPL, head = k0 / dh;
@@ -349,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const float live = (a.lens && a.t >= a.lens[b]) ? 0.f : 1.f;
 
   // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
-  for (int m = wave; m < M; m += 4) {
+  for (int m = wave; m < M; m += kAttnWaves) {
     float kr[EPL], rstd;
     load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   __syncthreads();
   // ---- phase B: through dropout and the probability fn; sd <- d raw -----------------------
   float dtau = 0.f;
-  for (int h = wave; h < H; h += 4) {
+  for (int h = wave; h < H; h += kAttnWaves) {
     const size_t go = ((size_t)b * H + h) * M;
     float* srow = ss + h * M;
     float* drow = sd + h * M;
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   float dq_acc[EPL], dv_acc[EPL], dg_acc[EPL], db_acc[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) dq_acc[i] = dv_acc[i] = dg_acc[i] = db_acc[i] = 0.f;
-  for (int m = wave; m < M; m += 4) {
+  for (int m = wave; m < M; m += kAttnWaves) {
     float kr[EPL], th[EPL], xh[EPL], rstd = 0.f;
     const float* kp = a.keys + ((size_t)b * M + m) * D + k0;
     float* dkp = a.dkeys + ((size_t)b * M + m) * D + k0;
@@ -453,17 +477,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   // cross-wave reductions (4 waves), one array at a time through `red`
+  // cross-wave reductions, one array at a time through `red` ([kAttnWaves][<=512] floats,
+  // processed in 512-channel chunks so the LDS footprint is independent of D)
   auto reduce_store = [&](const float* acc, float* dst, bool accumulate) {
-    __syncthreads();
+    for (int cb = 0; cb < D; cb += 512) {
+      const int cw = min(512, D - cb);
+      __syncthreads();
+      if (k0 >= cb && k0 < cb + cw) {
 #pragma unroll
-    for (int i = 0; i < EPL; ++i) red[wave * D + k0 + i] = acc[i];
-    __syncthreads();
-    for (int k = tid; k < D; k += 256) {
-      const float s = red[k] + red[D + k] + red[2 * D + k] + red[3 * D + k];
-      if (accumulate)
-        dst[k] += s;
-      else
-        dst[k] = s;
+        for (int i = 0; i < EPL; ++i) red[wave * 512 + (k0 - cb) + i] = acc[i];
+      }
+      __syncthreads();
+      for (int k = tid; k < cw; k += kAttnThreads) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kAttnWaves; ++w) s += red[w * 512 + k];
+        if (accumulate)
+          dst[cb + k] += s;
+        else
+          dst[cb + k] = s;
+      }
     }
   };
   reduce_store(dq_acc, a.dq + (size_t)b * D, false);
@@ -472,7 +505,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     reduce_store(dv_acc, pg, true);
     reduce_store(dg_acc, pg + D, true);
     reduce_store(db_acc, pg + 2 * D, true);
-    if (tid == 0) pg[3 * D] += (misc[0] + misc[1] + misc[2] + misc[3]) / a.tau[0];
+    if (tid == 0) {
+      float dt = 0.f;
+      for (int w = 0; w < kAttnWaves; ++w) dt += misc[w];
+      pg[3 * D] += dt / a.tau[0];
+    }
   }
 }
 
@@ -590,7 +627,7 @@ int attn_check(const comic_attn_desc* d) {
   COMIC_REQUIRE(d->Cv % 64 == 0 && d->Cv % d->H == 0 && (d->Cv / d->H) % (d->Cv / 64) == 0,
                 "attn: value channels must be a multiple of 64 (Cv=%d H=%d)", d->Cv, d->H);
   COMIC_REQUIRE(!d->tied || d->Cv == d->D, "attn: tied values need Cv == D");
-  COMIC_REQUIRE((size_t)d->H * d->M * 2 * 4 + 4 * d->D * 4 + 64 <= 60 * 1024, "attn: H*M too large for LDS");
+  COMIC_REQUIRE((size_t)d->H * d->M * 2 * 4 + (size_t)kAttnWaves * 512 * 4 + 256 <= 64 * 1024, "attn: H*M too large for LDS");
   return 0;
 }
 
@@ -651,7 +688,7 @@ extern "C" int comic_lstm_gates_fwd(const float* g, const float* c_prev, const f
   COMIC_REQUIRE(g, "lstm_gates_fwd: null input");
   hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, g, c_prev,
                      h_prev, gates_act, c_new, h_new, y, mask_out, keep_out, lens, t, c_state, h_state, B, D,
-                     (float*)nullptr, 0);
+                     (float*)nullptr, 0, 1, (const float*)nullptr);
   COMIC_LAUNCH_CHECK("lstm_gates_fwd");
   return 0;
 }
@@ -659,9 +696,11 @@ extern "C" int comic_lstm_gates_fwd(const float* g, const float* c_prev, const f
 // executor-internal: also scatters the carried h into the next step's [x;att;h] operand row
 int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
                             float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
-                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, hipStream_t st) {
+                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
+                            const float* bias, hipStream_t st) {
   hipLaunchKernelGGL(lstm_gates_fwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, g, c_prev, h_prev, gates_act,
-                     c_new, (float*)nullptr, y, mask_out, keep_out, lens, t, c_state, h_state, B, D, xh_next, xh_ld);
+                     c_new, (float*)nullptr, y, mask_out, keep_out, lens, t, c_state, h_state, B, D, xh_next, xh_ld,
+                     S, bias);
   COMIC_LAUNCH_CHECK("lstm_gates_fwd");
   return 0;
 }
@@ -671,7 +710,17 @@ extern "C" int comic_lstm_gates_bwd(const float* gates_act, const float* c_prev,
                                     float* dc_state, float* dh_state, float* dg, int B, int D, void* stream) {
   COMIC_REQUIRE(gates_act && c_new && dc_state && dh_state && dg, "lstm_gates_bwd: null pointer");
   hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, (hipStream_t)stream, gates_act,
-                     c_prev, c_new, dy, mask_out, keep_out, lens, t, dc_state, dh_state, dg, B, D);
+                     c_prev, c_new, dy, mask_out, keep_out, lens, t, dc_state, dh_state, dg, B, D,
+                     (const float*)nullptr, 0);
+  COMIC_LAUNCH_CHECK("lstm_gates_bwd");
+  return 0;
+}
+
+int comic_lstm_gates_bwd_ex(const float* gates_act, const float* c_prev, const float* c_new, const float* dy,
+                            const float* dy_part, int S, const float* mask_out, float keep_out, const int32_t* lens,
+                            int t, float* dc_state, float* dh_state, float* dg, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, gates_act, c_prev, c_new, dy,
+                     mask_out, keep_out, lens, t, dc_state, dh_state, dg, B, D, dy_part, S);
   COMIC_LAUNCH_CHECK("lstm_gates_bwd");
   return 0;
 }
@@ -681,7 +730,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, hipStream_t st) {
+                      int mask_ld, float keep_in, int q_parts, float* q_out, hipStream_t st) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && alpha_d && ctx, "attn_fwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_fwd: add_LN needs ln_g/ln_b/v/tau");
@@ -690,10 +739,10 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.alpha = alpha; a.alpha_d = alpha_d; a.ctx = ctx;
   a.lens = lens; a.t = t; a.att_prev = att_prev; a.att_next = att_next; a.xh_next = xh_next; a.xh_ld = xh_ld;
-  a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in;
+  a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in; a.q_parts = q_parts; a.q_out = q_out;
   const size_t lds = (size_t)d->H * d->M * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
-    hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_fwd");
@@ -712,9 +761,9 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
   a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad; a.lens = lens; a.t = t;
-  const size_t lds = ((size_t)d->H * d->M * 2 + 4 * d->D + 16) * sizeof(float);
+  const size_t lds = ((size_t)d->H * d->M * 2 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
-    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_bwd");
@@ -726,7 +775,7 @@ extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, 
                                    const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
                                    void* stream) {
   return comic_attn_fwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, mask_alpha, keep_alpha, alpha, alpha_d, ctx, nullptr,
-                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, (hipStream_t)stream);
+                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, 1, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,

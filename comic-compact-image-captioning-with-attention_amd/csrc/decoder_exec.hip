@@ -28,14 +28,20 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, hipStream_t st);
+                      int mask_ld, float keep_in, int q_parts, float* q_out, hipStream_t st);
+int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int trans_b,
+                           void* ws, int64_t ws_bytes, int* S_out, hipStream_t st);
+int comic_lstm_gates_bwd_ex(const float* gates_act, const float* c_prev, const float* c_new, const float* dy,
+                            const float* dy_part, int S, const float* mask_out, float keep_out, const int32_t* lens,
+                            int t, float* dc_state, float* dh_state, float* dg, int B, int D, hipStream_t st);
 int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
                       const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
                       float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st);
 int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
                             float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
-                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, hipStream_t st);
+                            float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
+                            const float* bias, hipStream_t st);
 
 namespace {
 
@@ -136,12 +142,14 @@ __global__ void split_live_kernel(float* __restrict__ d, float* __restrict__ out
 // state before the step (live rows' share went into the context inside attn_bwd).
 __global__ void input_bwd_kernel(const float* __restrict__ dxh, const float* __restrict__ mask, float keep,
                                  float* __restrict__ demb, float* __restrict__ datt, float* __restrict__ dh,
-                                 const int32_t* __restrict__ lens, int t, int carry, int B, int E, int A, int D) {
+                                 const int32_t* __restrict__ lens, int t, int carry, int B, int E, int A, int D,
+                                 int S) {
   const int W = E + A + D;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * W) return;
   const int b = i / W, c = i % W;
   float v = dxh[i];
+  for (int s = 1; s < S; ++s) v += dxh[(size_t)s * B * W + i];  // split-K partials of dg * K^T
   if (c < E + A) {
     if (mask) v = (v / keep) * mask[(size_t)b * (E + A) + c];
     if (c < E) {
@@ -487,24 +495,26 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     const float* att_prev = att_all + (size_t)t * B * A;
     float* att_next = att_all + (size_t)(t + 1) * B * A;
     const float* mask_n = (drop_in && xh_n) ? mask_in + (size_t)(t + 1) * B * EA + E : nullptr;
-    RC(gemm(xh_t, p->K, g_tmp, p->b, B, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
+    int S1 = 1, S2 = 1;
+    float* part = (float*)g_splitk_ws;
+    RC(comic_gemm_f32_partial(xh_t, p->K, B, 4 * D, Wd, Wd, 4 * D, 0, part, kSplitKBytes, &S1, st));
     float* y_t = y_all + (size_t)t * B * D;
-    RC(comic_lstm_gates_fwd_ex(g_tmp, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
+    RC(comic_lstm_gates_fwd_ex(part, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
                                cnew_all + (size_t)t * B * D, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
                                d->keep_out, lens, t, cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D,
-                               xh_n ? xh_n + EA : nullptr, Wd, st));
+                               xh_n ? xh_n + EA : nullptr, Wd, S1, p->b, st));
     float* q_t = q_all + (size_t)t * B * D;
-    RC(gemm(y_t, p->W_q, q_t, nullptr, B, D, D, D, D, D, 0, 0, 0.f, st));
+    RC(comic_gemm_f32_partial(y_t, p->W_q, B, D, D, D, D, 0, part, kSplitKBytes, &S2, st));
     float* ctx_t = ctx_all + (size_t)t * B * Cv;
     const float* mal = drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr;
     if (!d->context_layer) {
-      RC(comic_attn_fwd_ex(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
+      RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
                            alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, lens, t,
-                           att_prev, att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, st));
+                           att_prev, att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, S2, q_t, st));
     } else {
-      RC(comic_attn_fwd_ex(&ad, keys, values, q_t, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
+      RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
                            alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, nullptr, 0,
-                           nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, st));
+                           nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S2, q_t, st));
       RC(gemm(ctx_t, p->W_a, att_new, nullptr, B, D, Cv, Cv, D, D, 0, 0, 0.f, st));
       hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_prev, att_new, lens, t,
                          att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, B, A);
@@ -570,15 +580,18 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       carry = 0;
     }
     float* dy_t = dy_all + (size_t)t * B * D;
-    RC(gemm(dq_t, p->W_q, dy_t, nullptr, B, D, D, D, D, D, 0, 1, 1.f, st));
+    float* part = (float*)g_splitk_ws;
+    int S3 = 1, S4 = 1;
+    RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
     float* dg_t = dg_all + (size_t)t * B * 4 * D;
-    RC(comic_lstm_gates_bwd(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D, cnew_all + (size_t)t * B * D,
-                            dy_t, drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh,
-                            dg_t, B, D, (void*)st));
-    RC(gemm(dg_t, p->K, dxh, nullptr, B, Wd, 4 * D, 4 * D, 4 * D, Wd, 0, 1, 0.f, st));
-    hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, dxh,
+    RC(comic_lstm_gates_bwd_ex(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
+                               cnew_all + (size_t)t * B * D, dy_t, part, S3,
+                               drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh, dg_t,
+                               B, D, st));
+    RC(comic_gemm_f32_partial(dg_t, p->K, B, Wd, 4 * D, 4 * D, 4 * D, 1, part, kSplitKBytes, &S4, st));
+    hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, part,
                        drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E, datt,
-                       dh, lens, t, carry, B, E, A, D);
+                       dh, lens, t, carry, B, E, A, D, S4);
     COMIC_LAUNCH_CHECK("input_bwd");
   }
   // time-batched weight gradients

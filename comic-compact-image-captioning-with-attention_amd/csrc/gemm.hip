@@ -378,13 +378,35 @@ void launch(const GemmArgs& a, int ta, int tb, hipStream_t st) {
 
 }  // namespace
 
+// Skinny product left as split-K partials: ws receives [S][M][N] (ld = N) raw partial sums and
+// *S_out their count; the consumer kernel adds them up (saves a reduce launch per GEMM).
+int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int trans_b,
+                           void* ws, int64_t ws_bytes, int* S_out, hipStream_t st) {
+  COMIC_REQUIRE(A && B && ws && S_out, "gemm_partial: null pointer");
+  COMIC_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldb >= (trans_b ? K : N), "gemm_partial: bad shape");
+  const int KB = (K + 15) / 16, NB = cdiv(N, 64), MB = cdiv(M, 64);
+  int S = std::max(1, std::min(std::min(256 / std::max(1, NB * MB), KB / 8), 32));
+  while (S > 1 && (int64_t)S * M * N * 4 > ws_bytes) --S;
+  COMIC_REQUIRE((int64_t)S * M * N * 4 <= ws_bytes, "gemm_partial: workspace too small");
+  SkinnyArgs a{A, B, (float*)ws, nullptr, M, N, K, lda, ldb, N, 1.f, 0.f, cdiv(KB, S), 0};
+  S = cdiv(KB, a.kb_per_slice);
+  dim3 grid(NB, S, MB);
+  if (trans_b)
+    hipLaunchKernelGGL((gemm_skinny_kernel<true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<false>), grid, dim3(256), 0, st, a);
+  COMIC_LAUNCH_CHECK("gemm_skinny(partial)");
+  *S_out = S;
+  return 0;
+}
+
 int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                       int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws, int64_t ws_bytes,
                       hipStream_t st) {
   COMIC_REQUIRE(A && B && C, "gemm: null pointer");
   COMIC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape %d %d %d", M, N, K);
   COMIC_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm: leading dimension too small");
-  if (!trans_a && M <= 512) {
+  if (!trans_a && M <= 2048) {
     // skinny path
     const int KB = (K + 15) / 16, NB = cdiv(N, 64), MB = cdiv(M, 64);
     int S = 1;
