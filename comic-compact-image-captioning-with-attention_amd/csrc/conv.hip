@@ -14,6 +14,8 @@
 // (row = lane&15, chunk = lane>>4): 8 bf16 for v_mfma_f32_16x16x32_bf16, or 4 floats fed to
 // four v_mfma_f32_16x16x4_f32 (exact fp32 parity mode; both operands use the same
 // k-permutation so the sum over k is unchanged).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -410,6 +412,256 @@ __global__ void fold_bn_kernel(const float* beta, const float* mean, const float
   shift[i] = beta[i] - mean[i] * s;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 throughput path: LDS-DMA pipelined implicit GEMM.
+//
+// Same math and orientation as conv_igemm_kernel, but the operand tiles go global -> LDS with
+// `global_load_lds_dwordx4` (no VGPR staging) into a ring of NSTAGE stages of [rows][128 B of
+// k] (BK = 64 bf16), so two whole k-tiles stay in flight behind the one being multiplied.
+// One raw s_barrier per k-tile; DMA completion is tracked with counted `s_waitcnt vmcnt(N)`;
+// fragment reads are inline-asm ds_read_b128 (hipcc would otherwise drain vmcnt(0) in front of
+// every LDS read that may alias an in-flight DMA -- cdna_hip_programming.md §5).
+//
+// LDS image: 128-byte rows, 16-byte slot = chunk ^ ((row >> 1) & 7).  The DMA writes LDS
+// linearly (wave base + lane*16), so the swizzle is applied to the per-lane SOURCE chunk; the
+// ds_read_b128 lane groups of the 16x16x32 operand fetch then hit 16 distinct slots.
+// Padding / out-of-range rows read from a 16-byte zero page.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read128(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                   (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
+  constexpr int NSTAGE = 3;
+  constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE_BYTES = ROWS * 128;
+  constexpr int IPW_A = BM / 32;                // 8-row DMA instructions per wave per stage (A)
+  constexpr int IPW_B = BN / 32;
+  constexpr int LPT = IPW_A + IPW_B;            // DMA instructions per wave per stage
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
+  const bf16_t* __restrict__ wg = (const bf16_t*)a.w;
+  const int slot = lane & 7, rsub = lane >> 3;
+
+  // ---- im2col state of the rows this lane feeds ------------------------------------------
+  int xbase[IPW_A], hi0[IPW_A], wi0[IPW_A];
+  bool mok[IPW_A];
+#pragma unroll
+  for (int i = 0; i < IPW_A; ++i) {
+    const int r = (wave * IPW_A + i) * 8 + rsub;
+    const int m = bm0 + r;
+    mok[i] = m < a.M;
+    int mm = mok[i] ? m : 0;
+    const int wo = mm % a.Wo;
+    mm /= a.Wo;
+    const int ho = mm % a.Ho;
+    const int b = mm / a.Ho;
+    hi0[i] = ho * a.SH - a.PT;
+    wi0[i] = wo * a.SW - a.PL;
+    xbase[i] = ((b * a.H + hi0[i]) * a.W + wi0[i]) * a.x_cs + a.x_co;
+  }
+  // the source chunk of a lane alternates between two values with the parity of the 8-row group
+  // (swizzle term (row>>1)&7 = 4*(group&1) + (rsub>>1)); keep one k-state per parity
+  int kc[2], kkw[2], kkh[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int chunk = slot ^ ((4 * par + (rsub >> 1)) & 7);
+    const int kk = chunk * 8;
+    kc[par] = kk % a.Cin;
+    const int tap = kk / a.Cin;
+    kkw[par] = tap % a.KW;
+    kkh[par] = tap / a.KW;
+  }
+  const bf16_t* wsrc[IPW_B];
+  bool nok[IPW_B];
+#pragma unroll
+  for (int i = 0; i < IPW_B; ++i) {
+    const int gb = wave * IPW_B + i;
+    const int n = bn0 + gb * 8 + rsub;
+    nok[i] = n < a.Cout;
+    const int chunk = slot ^ ((4 * (gb & 1) + (rsub >> 1)) & 7);
+    wsrc[i] = wg + (size_t)(nok[i] ? n : 0) * a.Kpad + chunk * 8;
+  }
+  const int nk = a.Kpad / BKE;
+
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sbase = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < IPW_A; ++i) {
+      const int ga = wave * IPW_A + i;
+      const int par = ga & 1;
+      const int hi = hi0[i] + kkh[par], wi = wi0[i] + kkw[par];
+      const bool ok = mok[i] && kkh[par] < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      const void* src = ok ? (const void*)(xg + (xbase[i] + (kkh[par] * a.W + kkw[par]) * a.x_cs + kc[par]))
+                           : (const void*)g_zero_page;
+      dma16(src, sbase + ga * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < IPW_B; ++i) {
+      const int gb = wave * IPW_B + i;
+      const void* src = nok[i] ? (const void*)(wsrc[i] + (size_t)kt * BKE) : (const void*)g_zero_page;
+      dma16(src, sbase + BM * 128 + gb * 1024);
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      kc[par] += BKE;
+      while (kc[par] >= a.Cin) {
+        kc[par] -= a.Cin;
+        if (++kkw[par] == a.KW) {
+          kkw[par] = 0;
+          ++kkh[par];
+        }
+      }
+    }
+  };
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: lane (r, g) reads row r of a 16-row tile, k-chunk ks*4+g, at slot chunk^((r>>1)&7)
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t sw = (fr >> 1) & 7;
+  const uint32_t x_off0 = (wm * (BM / WM) + fr) * 128 + (((0 + fg) ^ sw) & 7) * 16;
+  const uint32_t x_off1 = (wm * (BM / WM) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
+  const uint32_t w_off0 = (BM + wn * (BN / WN) + fr) * 128 + (((0 + fg) ^ sw) & 7) * 16;
+  const uint32_t w_off1 = (BM + wn * (BN / WN) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
+  int tn_live = 0;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+    if (bn0 + wn * (BN / WN) + i * 16 < a.Cout) tn_live = i + 1;
+
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt % NSTAGE;
+    if (kt + 1 < nk)
+      wait_vmcnt<LPT>();   // tile kt landed (this wave's share); tile kt+1 may still be in flight
+    else
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; stage (kt+2)%3 is free again
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
+    const uint32_t sb = lds0 + stage * STAGE_BYTES;
+    u32x4_t xf0[TM], xf1[TM], wf0[TN], wf1[TN];
+    static_for<0, TN>([&](auto i) {
+      wf0[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off0);
+      wf1[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off1);
+    });
+    static_for<0, TM>([&](auto j) {
+      xf0[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off0);
+      xf1[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off1);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      if (i < tn_live) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf0[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf1[j]), acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: y = relu(acc * scale[n] + shift[n]) ----------------------------------
+  const int mcol = lane & 15, nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n0 = bn0 + wn * (BN / WN) + i * 16 + nq;
+    if (n0 >= a.Cout) continue;
+    const float4 sc = *(const float4*)(a.scale + n0);
+    const float4 sh = *(const float4*)(a.shift + n0);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = bm0 + wm * (BM / WM) + j * 16 + mcol;
+      if (m >= a.M) continue;
+      float v0 = acc[i][j][0] * sc.x + sh.x;
+      float v1 = acc[i][j][1] * sc.y + sh.y;
+      float v2 = acc[i][j][2] * sc.z + sh.z;
+      float v3 = acc[i][j][3] * sc.w + sh.w;
+      if (a.relu) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        v2 = fmaxf(v2, 0.f);
+        v3 = fmaxf(v3, 0.f);
+      }
+      const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
+      if (a.out_f32) {
+        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+      } else {
+        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_dma(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds = 3 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, a);
+  return 0;
+}
+
+int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
+  const long b128x128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
+  const long b128x64 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 64);
+  const long b64x64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
+  if (a.Cout <= 32) return launch_dma<128, 32, 4, 1>(a, st);
+  if (a.Cout % 128 == 0 && b128x128 >= 512) return launch_dma<128, 128, 2, 2>(a, st);
+  if (b128x64 >= 512) return launch_dma<128, 64, 2, 2>(a, st);
+  if (b64x64 >= 384) return launch_dma<64, 64, 2, 2>(a, st);
+  return launch_dma<32, 64, 1, 4>(a, st);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 void launch_igemm(const ConvArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
@@ -449,7 +701,7 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.Ho = op->Ho; a.Wo = op->Wo;
   a.x_cs = x_channels; a.x_co = op->src_coff; a.y_cs = y_channels; a.y_co = op->dst_coff;
   a.K = op->KH * op->KW * op->Cin;
-  a.Kpad = (a.K + 31) / 32 * 32;
+  a.Kpad = (a.K + 63) / 64 * 64;
   a.M = batch * op->Ho * op->Wo;
   a.relu = op->relu;
   a.out_f32 = op->out_f32;
@@ -474,7 +726,12 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
                     "conv: Cout must be a multiple of 16 (got %d)", op->Cout);
       COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
-      dispatch_igemm<T>(a, st);
+      if constexpr (sizeof(T) == 2) {
+        COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "conv: activation tensor too large");
+        if (int rc = dispatch_igemm_dma(a, st)) return rc;
+      } else {
+        dispatch_igemm<T>(a, st);
+      }
       break;
     }
     case 1: {
@@ -545,7 +802,7 @@ extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const
 
 extern "C" int comic_pack_conv_weights(const float* w_hwio, void* w_packed, int kh, int kw, int cin, int cout,
                                        int dtype, void* stream) {
-  const int K = kh * kw * cin, Kpad = (K + 31) / 32 * 32;
+  const int K = kh * kw * cin, Kpad = (K + 63) / 64 * 64;
   const long total = (long)cout * Kpad;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == COMIC_BF16)

@@ -252,7 +252,7 @@ class CnnEncoder:
                 packed = w.reshape(kh * kw * cin, cout).contiguous()
             else:
                 K = kh * kw * cin
-                kpad = (K + 31) // 32 * 32
+                kpad = (K + 63) // 64 * 64
                 packed = torch.empty(cout * kpad, dtype=tdt, device=device)
                 L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), packed.data_ptr(), kh, kw, cin, cout,
                                                          self.dcode, st), 'pack_conv_weights')

@@ -42,7 +42,7 @@ int comic_device_count(void);
 /* ------------------------------------------------------------------------- */
 
 /* Repack TF HWIO conv weights [kh][kw][cin][cout] (fp32) to [cout][Kpad] in `dtype`,
- * K = kh*kw*cin, Kpad = K rounded up to 32 elements, zero padded.
+ * K = kh*kw*cin, Kpad = K rounded up to 64 elements, zero padded.
  * Replaces nothing in the reference (layout prep done once at checkpoint load). */
 int comic_pack_conv_weights(const float* w_hwio, void* w_packed, int kh, int kw, int cin, int cout,
                             int dtype, void* stream);

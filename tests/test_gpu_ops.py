@@ -60,7 +60,7 @@ def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, 
         packed = wd.reshape(-1, Cout).contiguous()
     else:
         K = kh * kw * Cin
-        packed = torch.empty(Cout * ((K + 31) // 32 * 32), dtype=tdt, device=DEV)
+        packed = torch.empty(Cout * ((K + 63) // 64 * 64), dtype=tdt, device=DEV)
         L.check(lib().comic_pack_conv_weights(wd.data_ptr(), packed.data_ptr(), kh, kw, Cin, Cout, code, stream()))
     yc = dst_channels or Cout
     ydt = torch.float32 if out_f32 else tdt
