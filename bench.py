@@ -22,13 +22,15 @@ BATCH = 64
 IMG = 224
 FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
 PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
+GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
+GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '1') == '1'   # hipGraph replay of the decoder step
 
 
 def synth_captions(rng, B):
     """N ~ U{8..14} words, ids ~ U{0..9999}, radix-256 -> [256, d1 d0 ..., 257], PAD -1."""
     rows = []
-    for _ in range(B):
-        n = int(rng.integers(8, 15))
+    for b in range(B):
+        n = 14 if b == 0 else int(rng.integers(8, 15))   # row 0 pins the bucket length (one graph shape)
         ids = rng.integers(0, 10000, n)
         r = [256]
         for w in ids:
@@ -93,10 +95,10 @@ def main():
 
     from comic_amd import decoder as cdec, nets, trainer
     dp = trainer.DataParallel(dist if world > 1 else None)
-    plan = nets.CnnPlan('inception_v3', (IMG, IMG))
+    plan = nets.CnnPlan('inception_v3', (IMG, IMG), branch_streams=os.environ.get('COMIC_CNN_LANES', '0') == '1')
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
-    tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1)
+    tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan)
     # identical initial parameters on every rank (C2: broadcast)
     if world > 1:
         dist.broadcast(tr.decoder.params.data, 0)
@@ -109,21 +111,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tr.use_graph = GRAPH_CNN and GRAPH_DEC
     for i in range(args.warmup):
-        tr.xe_step(images, cap_sets[i % 4])
+        im_embed, fm = tr.encoder.forward(images, use_graph=GRAPH_CNN)
+        tr.decoder.train_step(fm, im_embed, cap_sets[i % 4], training=True, use_graph=GRAPH_DEC)
+        tr.opt.step(tr.decoder.grads, tr.lr())
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         # HIP events on the launch stream bracket the CNN forward (the conv implicit-GEMM kernels)
         ev[i][0].record()
-        im_embed, fm = tr.encoder.forward(images)
+        im_embed, fm = tr.encoder.forward(images, use_graph=GRAPH_CNN)
         ev[i][1].record()
         cap = cap_sets[i % 4]
         denom = None
         if world > 1:
             denom = dp.global_tokens(float((cap[:, 1:] >= 0).sum()), device) / world + 1e-12
-        res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom)
+        res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC)
         scale = dp.average_(tr.decoder.grads.data)
         tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
     barrier()

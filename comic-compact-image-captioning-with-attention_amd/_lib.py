@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
 class CnnOp(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
-        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32')]
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane')]
 
 
 class ConvWeight(C.Structure):
@@ -55,6 +55,7 @@ _SIGS = {
     'comic_embed_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),
     'comic_dropout_mask': (c_int, [P, c_int64, c_float, c_uint64, c_uint64, P]),
+    'comic_dropout_mask_dev': (c_int, [P, c_int64, c_float, P, c_uint64, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
     'comic_attn_step_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_float, P, P, P, P]),

@@ -787,14 +787,67 @@ extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x
   return 2;
 }
 
+namespace {
+// Branch lanes: three internal non-blocking streams + fork/join events per device, created on
+// first use and kept for the life of the process (the only objects this library owns).
+struct Lanes {
+  hipStream_t s[3];
+  hipEvent_t fork_ev, join_ev[3];
+  bool ok = false;
+};
+Lanes* get_lanes() {
+  static Lanes lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Lanes& l = lanes[dev];
+  if (!l.ok) {
+    for (int i = 0; i < 3; ++i) {
+      if (hipStreamCreateWithFlags(&l.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&l.join_ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    if (hipEventCreateWithFlags(&l.fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    l.ok = true;
+  }
+  return &l;
+}
+}  // namespace
+
 extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,
                                  const comic_conv_weight* weights, int batch, int dtype, void* stream) {
   COMIC_REQUIRE(ops && buffers && buf_channels, "comic_cnn_forward: null table");
+  hipStream_t main_st = (hipStream_t)stream;
+  Lanes* lanes = nullptr;
+  bool used[3] = {false, false, false};
   for (int i = 0; i < n_ops; ++i) {
     const comic_cnn_op* op = ops + i;
+    if (op->kind == 5) {  // fork
+      if (!lanes) lanes = get_lanes();
+      COMIC_REQUIRE(lanes, "comic_cnn_forward: cannot create branch streams");
+      COMIC_REQUIRE(hipEventRecord(lanes->fork_ev, main_st) == hipSuccess, "fork: event record failed");
+      for (int l = 0; l < 3; ++l) {
+        COMIC_REQUIRE(hipStreamWaitEvent(lanes->s[l], lanes->fork_ev, 0) == hipSuccess, "fork: wait failed");
+        used[l] = false;
+      }
+      continue;
+    }
+    if (op->kind == 6) {  // join
+      COMIC_REQUIRE(lanes, "join without fork");
+      for (int l = 0; l < 3; ++l) {
+        if (!used[l]) continue;
+        COMIC_REQUIRE(hipEventRecord(lanes->join_ev[l], lanes->s[l]) == hipSuccess, "join: event record failed");
+        COMIC_REQUIRE(hipStreamWaitEvent(main_st, lanes->join_ev[l], 0) == hipSuccess, "join: wait failed");
+      }
+      continue;
+    }
+    hipStream_t st = main_st;
+    if (op->lane > 0) {
+      COMIC_REQUIRE(lanes && op->lane <= 3, "branch lane %d outside a fork/join region", op->lane);
+      st = lanes->s[op->lane - 1];
+      used[op->lane - 1] = true;
+    }
     const comic_conv_weight* wt = (op->kind <= 1) ? weights + op->weight : nullptr;
     int rc = comic_conv2d_bn_relu(op, buffers[op->src], buf_channels[op->src], buffers[op->dst],
-                                  buf_channels[op->dst], wt, batch, dtype, stream);
+                                  buf_channels[op->dst], wt, batch, dtype, (void*)st);
     if (rc) return rc;
   }
   return 0;

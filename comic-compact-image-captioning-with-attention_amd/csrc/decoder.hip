@@ -92,9 +92,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float keep, uint64_t seed, uint64_t offset) {
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float keep, uint64_t seed,
+                                    const uint64_t* __restrict__ seed_dev, uint64_t offset) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (seed_dev) seed = seed_dev[0];  // graph replay: the seed lives in device memory
   const uint64_t r = splitmix64(splitmix64(seed) ^ (offset + (uint64_t)i));
   const float u = (float)(r >> 40) * (1.0f / 16777216.0f);  // [0,1)
   mask[i] = u < keep ? 1.f : 0.f;
@@ -676,8 +678,18 @@ extern "C" int comic_dropout_apply(const float* x, const float* mask, float keep
 extern "C" int comic_dropout_mask(float* mask, int64_t n, float keep, uint64_t seed, uint64_t offset, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, mask,
-                     (long)n, keep, seed, offset);
+                     (long)n, keep, seed, (const uint64_t*)nullptr, offset);
   COMIC_LAUNCH_CHECK("dropout_mask");
+  return 0;
+}
+
+extern "C" int comic_dropout_mask_dev(float* mask, int64_t n, float keep, const uint64_t* seed_dev, uint64_t offset,
+                                      void* stream) {
+  if (n == 0) return 0;
+  COMIC_REQUIRE(seed_dev, "dropout_mask_dev: null seed");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, mask,
+                     (long)n, keep, (uint64_t)0, seed_dev, offset);
+  COMIC_LAUNCH_CHECK("dropout_mask_dev");
   return 0;
 }
 

@@ -226,6 +226,7 @@ class Decoder:
         self._ws = None
         self._ws_bytes = 0
         self._dropout_calls = 0
+        self._ctx = {}
 
     # ------------------------------------------------------------------ helpers --------
     def _workspace(self, nbytes):
@@ -258,66 +259,131 @@ class Decoder:
         return out
 
     # ------------------------------------------------------------------ training -------
+    def _train_ctx(self, B, T, Tp, training, gen_masks, want_input_grads):
+        """Persistent device buffers (+ hipGraph) of one training-step shape."""
+        key = (B, T, Tp, bool(training), bool(gen_masks), bool(want_input_grads))
+        ctx = self._ctx.get(key)
+        if ctx is not None:
+            return ctx
+        torch, s, dev = self.torch, self.spec, self.device
+        from types import SimpleNamespace
+        ctx = SimpleNamespace(key=key, calls=0, graph=None)
+        f32 = dict(dtype=torch.float32, device=dev)
+        ctx.i32 = torch.zeros(2 * B * T + B, dtype=torch.int32, device=dev)      # inputs | targets | lens
+        ctx.f32 = torch.zeros(3 * B * T, **f32)                                   # wmask | coef | row scale
+        ctx.i32_host = torch.zeros(2 * B * T + B, dtype=torch.int32).pin_memory()
+        ctx.f32_host = torch.zeros(3 * B * T, dtype=torch.float32).pin_memory()
+        ctx.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        ctx.fm = torch.empty((B, s.M, s.C), **f32)
+        ctx.im = torch.empty((B, s.Cg), **f32)
+        EA = s.E + s.A
+        ctx.masks = None
+        if training:
+            ctx.masks = dict(init_in=torch.empty((B, EA), **f32), inp=torch.empty((Tp, B, EA), **f32),
+                             out=torch.empty((Tp, B, s.D), **f32), alpha=torch.empty((Tp, B, s.H, s.M), **f32))
+        ctx.logits = torch.empty((T, B, s.V), **f32)
+        ctx.ids = torch.empty((T, B), dtype=torch.int32, device=dev)
+        ctx.hist = torch.empty((Tp, B, s.H, s.M), **f32)
+        ctx.loss_rows = torch.empty(T * B, **f32)
+        ctx.map_loss = torch.zeros(1, **f32)
+        ctx.loss = torch.zeros(1, **f32)
+        ctx.dfm = torch.empty((B, s.M, s.C), **f32) if want_input_grads else None
+        ctx.dim = torch.empty((B, s.Cg), **f32) if want_input_grads else None
+        ctx.desc = s.desc(training)
+        ctx.nbytes = self.lib.comic_decoder_train_workspace(C.byref(ctx.desc), B, T)
+        ctx.ws = torch.empty(int(ctx.nbytes), dtype=torch.uint8, device=dev)
+        self._ctx[key] = ctx
+        return ctx
+
+    def _train_device(self, ctx):
+        """Device-only part of a training step (no host sync, no host memcpy): capturable."""
+        torch, s = self.torch, self.spec
+        B, T, Tp, training, gen_masks, _ = ctx.key
+        st = L.stream_ptr()
+        m = ctx.masks or {}
+        if training and gen_masks:
+            off = 0
+            for name, keep in (('init_in', 1 - s.dropout_rnn_in), ('inp', 1 - s.dropout_rnn_in),
+                               ('out', 1 - s.dropout_rnn_out), ('alpha', s.attn_keep_prob)):
+                t = m[name]
+                L.check(self.lib.comic_dropout_mask_dev(t.data_ptr(), t.numel(), keep, ctx.seed.data_ptr(), off, st),
+                        'dropout_mask')
+                off += t.numel()
+        BT = B * T
+        i32, f32 = ctx.i32, ctx.f32
+        ptab, gtab = self.params.table(), self.grads.table()
+        L.check(self.lib.comic_decoder_train_step(
+            C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm.data_ptr(), ctx.im.data_ptr(),
+            i32.data_ptr(), i32.data_ptr() + 4 * BT, f32.data_ptr(), f32.data_ptr() + 4 * BT,
+            i32.data_ptr() + 8 * BT, B, T, Tp,
+            L.ptr(m.get('init_in')), L.ptr(m.get('inp')), L.ptr(m.get('out')), L.ptr(m.get('alpha')),
+            ctx.logits.data_ptr(), ctx.ids.data_ptr(), ctx.hist.data_ptr(), ctx.loss_rows.data_ptr(),
+            ctx.map_loss.data_ptr(), L.ptr(ctx.dfm), L.ptr(ctx.dim), ctx.ws.data_ptr(), ctx.nbytes, st),
+            'decoder_train_step')
+        # sequence_loss reduction (model_base.py:337-347): rows carry xent*w; rs = 1/denominator (* reward/B)
+        rs_tb = f32[2 * BT:3 * BT].view(B, T).t()
+        ctx.loss.copy_((ctx.loss_rows.view(T, B) * rs_tb).sum().reshape(1))
+
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
-                   want_input_grads=False, xe_denom=None):
+                   want_input_grads=False, xe_denom=None, use_graph=False):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
         mean_b(xent_b * reward_b) (model_base.py:342-347).
         xe_denom: override of the XE normaliser sum(w)+1e-12 (data parallel: global token count / world size,
         so that the rank-mean of the gradients equals the single-process gradient of the global batch).
-        Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device)."""
+        use_graph: replay the step from a hipGraph captured per (B, T, T') shape (the second call with
+        a shape captures it) -- removes the ~450 host launches of a step from the critical path.
+        Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device views
+        of persistent buffers: valid until the next call with the same shape)."""
         torch, s = self.torch, self.spec
         inputs, targets, wmask, lens = process_inputs(captions, s.token_type)
         B, T = inputs.shape
         Tp = int(lens.max())
         if rewards is None:
             den_xe = np.float32(xe_denom) if xe_denom is not None else np.float32(wmask.sum() + np.float32(1e-12))
+            rs = np.full((B, T), np.float32(1.0) / den_xe, np.float32)
             coef = wmask / den_xe
         else:
             den = wmask.sum(axis=1, keepdims=True) + np.float32(1e-12)
-            coef = wmask / den * (np.asarray(rewards, np.float32)[:, None] / np.float32(B))
-        desc = s.desc(training)
-        if training and masks is None:
+            rb = (np.asarray(rewards, np.float32)[:, None] / np.float32(B))
+            rs = np.broadcast_to(rb / den, (B, T)).astype(np.float32)
+            coef = wmask / den * rb
+        gen_masks = bool(training and masks is None)
+        use_masks = bool(training or masks is not None)
+        ctx = self._train_ctx(B, T, Tp, use_masks, gen_masks, want_input_grads)
+        BT = B * T
+        ih, fh = ctx.i32_host.numpy(), ctx.f32_host.numpy()
+        ih[:BT] = inputs.reshape(-1); ih[BT:2 * BT] = targets.reshape(-1); ih[2 * BT:] = lens
+        fh[:BT] = wmask.reshape(-1); fh[BT:2 * BT] = coef.reshape(-1); fh[2 * BT:] = rs.reshape(-1)
+        ctx.i32.copy_(ctx.i32_host, non_blocking=True)
+        ctx.f32.copy_(ctx.f32_host, non_blocking=True)
+        if gen_masks:
             if seed is None:
                 self._dropout_calls += 1
                 seed = 0x9E3779B9 + self._dropout_calls
-            masks = self.make_masks(B, Tp, seed)
-        if masks is not None:
-            masks = {k: (v if torch.is_tensor(v) else self._dev(v, torch.float32)) for k, v in masks.items()}
-        else:
-            desc.keep_in = desc.keep_out = desc.keep_alpha = 1.0
-        fm = fm.contiguous(); im_embed = im_embed.contiguous()
+            ctx.seed_host[0] = int(seed)
+            ctx.seed.copy_(ctx.seed_host, non_blocking=True)
+        elif masks is not None:
+            for k, v in masks.items():
+                ctx.masks[k].copy_(v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, np.float32)))
         assert fm.shape == (B, s.M, s.C) and im_embed.shape == (B, s.Cg), (fm.shape, im_embed.shape)
         assert fm.dtype == torch.float32 and im_embed.dtype == torch.float32
-        d_in, d_tg = self._dev(inputs), self._dev(targets)
-        d_wm, d_cf, d_ln = self._dev(wmask), self._dev(coef.astype(np.float32)), self._dev(lens)
-        logits = torch.empty((T, B, s.V), dtype=torch.float32, device=self.device)
-        ids = torch.empty((T, B), dtype=torch.int32, device=self.device)
-        hist = torch.empty((Tp, B, s.H, s.M), dtype=torch.float32, device=self.device)
-        loss_rows = torch.empty(T * B, dtype=torch.float32, device=self.device)
-        map_loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        dfm = torch.empty_like(fm) if want_input_grads else None
-        dim = torch.empty_like(im_embed) if want_input_grads else None
-        nbytes = self.lib.comic_decoder_train_workspace(C.byref(desc), B, T)
-        ws = self._workspace(nbytes)
-        ptab, gtab = self.params.table(), self.grads.table()
-        m = masks or {}
-        L.check(self.lib.comic_decoder_train_step(
-            C.byref(desc), C.byref(ptab), C.byref(gtab), fm.data_ptr(), im_embed.data_ptr(), d_in.data_ptr(),
-            d_tg.data_ptr(), d_wm.data_ptr(), d_cf.data_ptr(), d_ln.data_ptr(), B, T, Tp,
-            L.ptr(m.get('init_in')), L.ptr(m.get('inp')), L.ptr(m.get('out')), L.ptr(m.get('alpha')),
-            logits.data_ptr(), ids.data_ptr(), hist.data_ptr(), loss_rows.data_ptr(), map_loss.data_ptr(),
-            L.ptr(dfm), L.ptr(dim), ws.data_ptr(), nbytes, L.stream_ptr()), 'decoder_train_step')
-        # sequence_loss reduction (model_base.py:337-347): rows already carry xent*w
-        lr = loss_rows.view(T, B)
-        if rewards is None:
-            xe = lr.sum() / float(den_xe)
+        ctx.fm.copy_(fm)
+        ctx.im.copy_(im_embed)
+        if use_graph and ctx.graph is None and ctx.calls >= 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._train_device(ctx)
+            ctx.graph = g
+        if use_graph and ctx.graph is not None:
+            ctx.graph.replay()
         else:
-            den_t = self._dev((wmask.sum(axis=1) + np.float32(1e-12)).astype(np.float32))
-            xe = ((lr.sum(dim=0) / den_t) * self._dev(np.asarray(rewards, np.float32))).mean()
-        return dict(loss=xe, map_loss=map_loss[0], logits=logits.permute(1, 0, 2), ids=ids.t(),
-                    attn_maps=hist.permute(1, 2, 0, 3), dfm=dfm, dim_embed=dim, Tp=Tp)
+            self._train_device(ctx)
+        ctx.calls += 1
+        return dict(loss=ctx.loss[0], map_loss=ctx.map_loss[0], logits=ctx.logits.permute(1, 0, 2), ids=ctx.ids.t(),
+                    attn_maps=ctx.hist.permute(1, 2, 0, 3), dfm=ctx.dfm, dim_embed=ctx.dim, Tp=Tp)
 
     # ------------------------------------------------------------------ decoding -------
     def max_iterations(self, infer_max_length, vocab_len):

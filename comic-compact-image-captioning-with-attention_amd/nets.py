@@ -85,7 +85,7 @@ def _out(size, k, s, pad):
 class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
-    def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c'):
+    def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False):
         if name != 'inception_v3':
             raise NotImplementedError('only inception_v3 is on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -94,6 +94,8 @@ class CnnPlan:
         self.weights = []        # (var_prefix, kh, kw, cin, cout, stem)
         self.end_points = {}     # name -> buffer id
         self.macs = 0
+        self._lane = 0
+        self.branch_streams = branch_streams
         self._build_v3(image_size, final_endpoint)
 
     # -- builder helpers ---------------------------------------------------------------
@@ -112,7 +114,7 @@ class CnnPlan:
         self.weights.append((scope + '/' + name, kh, kw, Cin, cout, stem))
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
                              Cin=Cin, Cout=cout, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
-                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32)))
+                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32), lane=self._lane))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
 
@@ -124,8 +126,15 @@ class CnnPlan:
             dst = self._buf(Ho, Wo, Cc)
         self.ops.append(dict(kind=kind, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc,
                              KH=k, KW=k, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=-1, relu=0,
-                             out_f32=0))
+                             out_f32=0, lane=self._lane))
         return dst, (Ho, Wo, Cc)
+
+    @staticmethod
+    def _sync_op(kind):
+        z = dict.fromkeys(('src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW', 'PT',
+                           'PL', 'Ho', 'Wo', 'relu', 'out_f32'), 0)
+        z.update(kind=kind, weight=-1, lane=0)
+        return z
 
     @staticmethod
     def _branch_out(branch, H, W, Cin):
@@ -160,8 +169,10 @@ class CnnPlan:
             last = bname == final_endpoint
             blk = self._buf(Ho, Wo, Ctot, f32=last)   # the attention feature map is handed over in fp32
             coff = 0
+            self.ops.append(self._sync_op(5))          # fork: the branches are independent
             for bi, branch in enumerate(branches):
                 scope = '%s/%s/Branch_%d' % (root, bname, bi)
+                self._lane = bi if self.branch_streams else 0   # branch 0 stays on the caller's stream
                 x = cur
                 for oi, op in enumerate(branch):
                     final = oi == len(branch) - 1
@@ -184,6 +195,8 @@ class CnnPlan:
                             self._conv(x, scope, sub, blk, o, out_f32=last)
                             o += sub[2]
                 coff += outs[bi][2]
+            self._lane = 0
+            self.ops.append(self._sync_op(6))          # join
             cur = blk
             self.end_points[bname] = cur
             if last:
@@ -196,7 +209,7 @@ class CnnPlan:
         pooled = self._buf(Hp, Wp, Cf, True)
         self.ops.append(dict(kind=4, src=cur, dst=pooled, src_coff=0, dst_coff=0, H=Hf, W=Wf, Cin=Cf, Cout=Cf, KH=kh,
                              KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1,
-                             src_f32=int(f32)))
+                             src_f32=int(f32), lane=0))
         self.pooled = pooled
         self.end_points['AvgPool_1a'] = pooled
 
@@ -270,15 +283,32 @@ class CnnEncoder:
             for k, v in o.items():
                 setattr(ops[i], k, v)
         self._ops = ops
+        self._graph = None
+        self._calls = 0
 
-    def forward(self, images):
-        """images fp32 NHWC [B,H,W,3] in [-1,1] (device) -> (im_embed [B,C_g], fmaps [B,M,C]) fp32.
-        ModelBase._encoder, non-legacy (model_base.py:93-104)."""
-        inp = self.bufs[self.plan.input]
-        assert images.shape == inp.shape and images.dtype == inp.dtype, (images.shape, inp.shape)
-        inp.copy_(images)
+    def _run(self):
         L.check(self.lib.comic_cnn_forward(self._ops, len(self.plan.ops), self._bufptr, self._bufch, self._wt,
                                            self.batch, self.dcode, L.stream_ptr()), 'cnn_forward')
+
+    def forward(self, images, use_graph=False):
+        """images fp32 NHWC [B,H,W,3] in [-1,1] (device) -> (im_embed [B,C_g], fmaps [B,M,C]) fp32.
+        ModelBase._encoder, non-legacy (model_base.py:93-104).  use_graph: the ~130 launches of
+        the plan (incl. the fork/join of the branch streams) are replayed from a hipGraph that
+        is captured on the second call."""
+        inp = self.bufs[self.plan.input]
+        assert images.shape == inp.shape and images.dtype == inp.dtype, (images.shape, inp.shape)
+        if images.data_ptr() != inp.data_ptr():
+            inp.copy_(images)
+        if use_graph and self._graph is None and self._calls >= 1:
+            g = self.torch.cuda.CUDAGraph()
+            with self.torch.cuda.graph(g):
+                self._run()
+            self._graph = g
+        if use_graph and self._graph is not None:
+            self._graph.replay()
+        else:
+            self._run()
+        self._calls += 1
         fm = self.bufs[self.plan.fm]
         pooled = self.bufs[self.plan.pooled]
         B = self.batch

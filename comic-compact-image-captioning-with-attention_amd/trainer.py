@@ -46,8 +46,9 @@ class DataParallel:
 
 class CaptionTrainer:
     def __init__(self, cnn_params, dec_spec, dec_params=None, batch=64, image_size=(224, 224), cnn_dtype='bf16',
-                 device='cuda:0', lr_start=1e-2, lr_end=1e-5, max_step=100000, adam_epsilon=1e-2, dp=None, seed=0):
-        self.plan = nets.CnnPlan('inception_v3', image_size)
+                 device='cuda:0', lr_start=1e-2, lr_end=1e-5, max_step=100000, adam_epsilon=1e-2, dp=None, seed=0,
+                 plan=None):
+        self.plan = plan or nets.CnnPlan('inception_v3', image_size)
         self.encoder = nets.CnnEncoder(self.plan, cnn_params, batch, cnn_dtype, device)
         self.decoder = cdec.Decoder(dec_spec, dec_params, device, seed)
         self.opt = optim.AdamTF(self.decoder.params, epsilon=adam_epsilon, l2_decay=dec_spec.l2_decay)
@@ -55,6 +56,7 @@ class CaptionTrainer:
         self.lr_start, self.lr_end, self.max_step = lr_start, lr_end, max_step
         self.device = device
         self.batch = batch
+        self.use_graph = True       # hipGraph replay of the CNN plan and of the decoder step
 
     @property
     def global_step(self):
@@ -65,21 +67,23 @@ class CaptionTrainer:
 
     def xe_step(self, images, captions, masks=None, training=True):
         """images [B,H,W,3] fp32 device tensor, captions [B,L] int (PAD -1) -> dict(loss, map_loss)."""
-        im_embed, fm = self.encoder.forward(images)
+        im_embed, fm = self.encoder.forward(images, use_graph=self.use_graph)
         cap = np.asarray(captions)
         local_tokens = float((cap[:, 1:] >= 0).sum())
         denom = None
         if self.dp.world > 1:
             denom = self.dp.global_tokens(local_tokens, self.device) / self.dp.world + 1e-12
-        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom)
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+                                      use_graph=self.use_graph)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res
 
     def scst_step(self, images_tiled, hypo_ids, rewards, masks=None, training=True):
         """train_fn_scst's train run (train_fn.py:251-256): images already tiled by the beam size."""
-        im_embed, fm = self.encoder.forward(images_tiled)
-        res = self.decoder.train_step(fm, im_embed, hypo_ids, masks=masks, rewards=rewards, training=training)
+        im_embed, fm = self.encoder.forward(images_tiled, use_graph=self.use_graph)
+        res = self.decoder.train_step(fm, im_embed, hypo_ids, masks=masks, rewards=rewards, training=training,
+                                      use_graph=self.use_graph)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res

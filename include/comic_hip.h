@@ -56,7 +56,9 @@ int comic_fold_bn(const float* beta, const float* mean, const float* var, float 
 typedef struct comic_cnn_op {
   int32_t kind;      /* 0 conv(implicit GEMM, MFMA)  1 stem conv (cin<=4, fp32 input)
                         2 max-pool  3 avg-pool 3x3 s1 SAME (count excludes padding)
-                        4 global avg-pool KHxKW VALID -> fp32 */
+                        4 global avg-pool KHxKW VALID -> fp32
+                        5 fork: the branch lanes 1..3 start after everything issued so far
+                        6 join: the main lane waits for every branch lane */
   int32_t src, dst;  /* indices into the buffer table */
   int32_t src_coff, dst_coff; /* channel offsets inside src/dst (concat without a copy) */
   int32_t H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
@@ -65,6 +67,8 @@ typedef struct comic_cnn_op {
   int32_t out_f32;   /* store fp32 even when the plan dtype is bf16 */
   int32_t src_f32;   /* the source buffer holds fp32 although the plan dtype is bf16
                         (global avg-pool over the fp32 attention feature map) */
+  int32_t lane;      /* 0 = caller's stream; 1..3 = internal branch streams (independent
+                        Inception branches run concurrently between a fork and a join) */
 } comic_cnn_op;
 
 typedef struct comic_conv_weight {
@@ -113,6 +117,9 @@ int comic_dropout_apply(const float* x, const float* mask, float keep, float* y,
 /* Bernoulli(keep) 0/1 masks from a counter-based generator (stateless, seed+offset). */
 int comic_dropout_mask(float* mask, int64_t n, float keep, uint64_t seed, uint64_t offset,
                        void* stream);
+/* same generator, seed read from device memory at run time (hipGraph replays draw new masks) */
+int comic_dropout_mask_dev(float* mask, int64_t n, float keep, const uint64_t* seed_dev,
+                           uint64_t offset, void* stream);
 
 /* BasicLSTMCell gate math (model_base.py:618-621; gate order i,j,f,o; forget_bias 1).
  *  g [B,4D] pre-activations (bias included).  Writes activated gates [B,4D] (for bwd),
