@@ -1,0 +1,251 @@
+"""`CaptionModel` / `CaptionModel_SCST` with the reference's constructor signatures and the
+attributes its drivers use (src/model.py:21-141, src/model_base.py).
+
+The reference objects are TF graph builders whose tensors are fetched with `sess.run`; here
+the same names are METHODS/attributes over the native executors:
+
+  reference                               this framework
+  --------------------------------------  ----------------------------------------------
+  sess.run(m.dec_log_ppl)  (train mode)    m.run_train_step(batch) -> dec_log_ppl (one update)
+  sess.run(m.dec_log_ppl)  (eval mode)     m.run_eval_step(batch)  -> dec_log_ppl
+  sess.run(m.infer_output)                 m.infer(images) -> [dec_preds, attention_maps]
+  m.global_step / m.lr / m.update_lr       same names (Python ints / floats)
+  m.restore_model(sess, saver, lr)         m.restore_model(lr)
+  m_sample.dec_preds_beam / _greedy        m.sample(images) -> (beam ids (W,B,T), greedy ids (B,T))
+  sess.run(m.train_scst, feed)             m.run_train_scst(imgs, captions, rewards)
+Models built with reuse=True share encoder/decoder/optimiser objects with the first model
+(AUTO_REUSE variable sharing, model.py:40-42).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import checkpoint as ckpt
+from . import decoder as cdec
+from . import nets, optim
+from .trainer import DataParallel
+
+_SHARED = {}          # variable store of the current "graph" (tf.variable_scope('Model', AUTO_REUSE))
+
+
+def reset_default_graph():
+    _SHARED.clear()
+
+
+class ModelBase(object):
+    """Shared construction / restore / decode logic (src/model_base.py)."""
+
+    def __init__(self, config):
+        self._config = c = config
+        assert c.token_type in ['radix', 'word', 'char']
+        self._softmax_size = c.radix_base + 2 if c.token_type == 'radix' else len(c.itow)
+
+    # ---- graph assembly --------------------------------------------------------------
+    def _build(self, batch_size, device, dp=None):
+        c = self._config
+        import torch
+        self.torch, self.device = torch, device
+        share = _SHARED if self.reuse or _SHARED else _SHARED
+        if 'plan' not in share:
+            plan = nets.get_network_fn(c.cnn_name, num_classes=None, is_training=False)(
+                tuple(c.cnn_input_size), c.cnn_fm_attention)
+            share['plan'] = plan
+            share['cnn_params'] = plan.init_params(seed=c.rand_seed % (2 ** 31))
+            fm = plan.buffers[plan.fm]
+            spec = cdec.DecoderSpec.from_config(c, (fm[0] * fm[1], fm[2]), plan.buffers[plan.pooled][2])
+            share['spec'] = spec
+            share['decoder'] = cdec.Decoder(spec, None, device, seed=c.rand_seed % (2 ** 31))
+            share['encoders'] = {}
+        self.plan, self.spec, self.decoder = share['plan'], share['spec'], share['decoder']
+        self._share = share
+        self._encoder_for(batch_size)
+        self.dp = dp or DataParallel(None)
+
+    def _encoder_for(self, batch_size):
+        encs = self._share['encoders']
+        if batch_size not in encs:
+            dtype = getattr(self._config, 'cnn_dtype', 'bf16')
+            encs[batch_size] = nets.CnnEncoder(self.plan, self._share['cnn_params'], batch_size, dtype, self.device)
+        return encs[batch_size]
+
+    def _encode(self, images):
+        images = np.asarray(images, np.float32) if not self.torch.is_tensor(images) else images
+        enc = self._encoder_for(int(images.shape[0]))
+        if not self.torch.is_tensor(images):
+            images = self.torch.from_numpy(np.ascontiguousarray(images)).to(self.device)
+        return enc.forward(images, use_graph=True)
+
+    def is_training(self):
+        return self.mode == 'train'
+
+    # ---- optimiser / LR (model_base.py:775-883) -----------------------------------------
+    def _create_optimiser(self):
+        c, share = self._config, self._share
+        if 'opt' not in share:
+            if c.optimiser != 'adam':
+                raise NotImplementedError('only optimiser=adam is on the MI355X hot path')
+            share['opt'] = optim.AdamTF(self.decoder.params, epsilon=c.adam_epsilon, l2_decay=getattr(c, 'l2_decay', 1e-5))
+            share['legacy_lr'] = c.lr_start
+        self.opt = share['opt']
+
+    @property
+    def global_step(self):
+        return self._share['opt'].t if 'opt' in self._share else 0
+
+    @property
+    def lr(self):
+        c = self._config
+        if getattr(c, 'legacy', False):
+            return self._share['legacy_lr']
+        return optim.cosine_lr(self.global_step, c.max_step, c.lr_start, c.lr_end)
+
+    def update_lr(self, lr_value):
+        self._share['legacy_lr'] = lr_value
+
+    # ---- restore (model_base.py:422-490) ------------------------------------------------
+    def restore_model(self, lr=None):
+        c = self._config
+        if not c.checkpoint_path:
+            print('INFO: Training entire model from scratch.')
+            return (self.lr if lr is None else lr) if self.is_training() else None
+        path = c.checkpoint_path
+        if os.path.isdir(path):
+            path = ckpt.latest_checkpoint(path, 'model') or ckpt.latest_checkpoint(path, 'model_compact')
+        elif not os.path.isfile(path) and os.path.isfile(path + '.npz'):
+            path = path + '.npz'
+        if path is None or not os.path.isfile(path):
+            raise ValueError('checkpoint not found: %s' % c.checkpoint_path)
+        cnn_names = list(self.plan.param_shapes())
+        cnn, dec, extra = ckpt.restore(path, cnn_names, self.spec, getattr(c, 'resume_training', False),
+                                       getattr(c, 'checkpoint_exclude_scopes', ''))
+        if cnn:
+            self._share['cnn_params'].update(cnn)
+            self._share['encoders'].clear()          # repack weights on next use
+        if dec is not None:
+            cur = self.decoder.params.to_numpy()
+            cur.update(dec)
+            self.decoder.params.load(cur)
+            print('INFO: Restored `Model` from checkpoint: {}'.format(path))
+        else:
+            print('INFO: Restored CNN model from checkpoint {}'.format(path))
+        if extra and 'opt' in self._share:
+            o = self._share['opt']
+            o.t = int(extra.get('global_step', 0))
+            if 'optimise/caption/adam_m' in extra:
+                o.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_m']))
+                o.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v']))
+            print('INFO: Resume training from checkpoint: {}'.format(path))
+        if not self.is_training():
+            return None
+        if lr is not None and getattr(c, 'legacy', False):
+            self.update_lr(lr)
+        return self.lr
+
+    def save(self, save_path, compact=True, max_to_keep=None):
+        extra = {}
+        if not compact and 'opt' in self._share:
+            o = self._share['opt']
+            extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(), 'optimise/caption/adam_v': o.v.data.cpu().numpy()}
+        return ckpt.save(save_path, self.global_step, self._share['cnn_params'], self.spec,
+                         self.decoder.params.to_numpy(), extra, max_to_keep)
+
+    # ---- decode (model_base.py:692-757, :272-314) ----------------------------------------
+    def _decode(self, images, beam_size, max_length, top_beam=True):
+        c = self._config
+        im_embed, fm = self._encode(images)
+        iters = self.decoder.max_iterations(max_length, len(c.wtoi))
+        if beam_size > 1:
+            r = self.decoder.beam_search(fm, im_embed, beam_size, iters)
+            pred = r['predicted_ids']                                  # (T, B, W)
+            T = pred.shape[0]
+            hist = r['attn_hist'].reshape(T, -1, beam_size, self.spec.H, self.spec.M)[:, :, 0]
+            attn = hist.transpose(1, 2, 0, 3)                          # (B, H, T, M) of beam 0
+            if top_beam:
+                return pred[:, :, 0].T.copy(), attn
+            return pred.transpose(2, 1, 0).copy(), attn               # (W, B, T)
+        ids, amap, _ = self.decoder.greedy(fm, im_embed, iters)
+        return ids, amap.cpu().numpy()
+
+
+class CaptionModel(ModelBase):
+    def __init__(self, config, mode, batch_ops=None, reuse=False, name=None, device='cuda:0', dp=None):
+        assert mode in ['train', 'eval', 'infer']
+        print('INFO: Building graph for: {}'.format(name))
+        super(CaptionModel, self).__init__(config)
+        self.mode, self.batch_ops, self.reuse, self.name = mode, batch_ops, reuse, name
+        c = self._config
+        bs = {'train': getattr(c, 'batch_size_train', 32), 'eval': getattr(c, 'batch_size_eval', 61),
+              'infer': getattr(c, 'batch_size_infer', 25)}[mode]
+        self._batch_size = bs
+        self._build(bs, device, dp)
+        if self.is_training():
+            self._create_optimiser()
+        self.dec_log_ppl = None
+        print('INFO: Model `{}` initialisation complete.'.format(mode))
+
+    def run_train_step(self, batch=None):
+        """== sess.run(m_train.dec_log_ppl): one XE update (train_fn.py:120-121)."""
+        images, captions = batch if batch is not None else next(self.batch_ops)
+        im_embed, fm = self._encode(images)
+        cap = np.asarray(captions)
+        denom = None
+        if self.dp.world > 1:
+            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
+        lr = self.lr
+        res = self.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=True)
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        self.dec_log_ppl = res['loss']
+        self.last = res
+        return res['loss']
+
+    def run_eval_step(self, batch=None):
+        """== sess.run(m_valid.dec_log_ppl) (train_fn.py:328-330): loss only, dropout off.
+        The fused step also produces gradients; they are simply not applied."""
+        images, captions = batch if batch is not None else next(self.batch_ops)
+        im_embed, fm = self._encode(images)
+        res = self.decoder.train_step(fm, im_embed, np.asarray(captions), training=False, use_graph=True)
+        return res['loss']
+
+    def infer(self, batch=None):
+        """== sess.run(m_infer.infer_output) -> [dec_preds (B,T), attention_maps (B,H,T,M)]."""
+        c = self._config
+        images = batch[0] if isinstance(batch, (tuple, list)) else (batch if batch is not None else next(self.batch_ops)[0])
+        ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+        self.infer_output = [ids, attn]
+        return self.infer_output
+
+
+class CaptionModel_SCST(ModelBase):
+    def __init__(self, config, scst_mode, reuse=False, device='cuda:0', dp=None):
+        assert scst_mode in ['train', 'sample']
+        print('INFO: Building graph for: {}'.format(scst_mode))
+        super(CaptionModel_SCST, self).__init__(config)
+        self.mode = scst_mode if scst_mode == 'train' else 'infer'
+        self.reuse, self.name = reuse, scst_mode
+        c = self._config
+        bs = c.batch_size_train * (c.scst_beam_size if self.is_training() else 1)
+        self._batch_size = bs
+        self._build(bs, device, dp)
+        if self.is_training():
+            self._create_optimiser()
+        print('INFO: Model `{}` initialisation complete.'.format(scst_mode))
+
+    def sample(self, imgs):
+        """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
+        infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
+        c = self._config
+        greedy, _ = self._decode(imgs, 1, 20)
+        beam, _ = self._decode(imgs, c.scst_beam_size, 20, top_beam=False)
+        return beam, greedy
+
+    def run_train_scst(self, imgs, captions, rewards):
+        im_embed, fm = self._encode(imgs)
+        lr = self.lr
+        res = self.decoder.train_step(fm, im_embed, np.asarray(captions), rewards=np.asarray(rewards, np.float32),
+                                      training=True, use_graph=True)
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        return res['loss']

@@ -1,0 +1,59 @@
+"""End-to-end CLI test on the GPU: train.py (decoder-mode XE) -> infer.py (beam 3) ->
+train.py --train_mode scst on a tiny dataset in the reference's file formats."""
+import glob
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(module_path, argv):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cli_' + os.path.basename(module_path)[:-3], module_path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(argv)
+
+
+def test_train_infer_scst_cli(tmp_path):
+    from tests import tiny_dataset
+    from comic_amd import configuration as conf
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=16, n_valid=4, n_test=4)
+    logs = str(tmp_path / 'experiments')
+    common = ['--dataset_dir', ds, '--log_root', logs, '--cnn_name', 'inception_v3', '--cnn_fm_attention', 'Mixed_7c',
+              '--cnn_input_size', '139,139', '--batch_size_eval', '4', '--rnn_size', '128', '--rnn_word_size', '64']
+    _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'decoder', '--batch_size_train', '8',
+                                                          '--max_epoch', '2'])
+    run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01')
+    assert not glob.glob(os.path.join(logs, 'mscoco', 'error__*')), open(glob.glob(os.path.join(logs, 'mscoco', 'error__*'))[0]).read()
+    c = conf.load_config(os.path.join(run_dir, 'config.pkl'))
+    assert c.token_type == 'radix' and c.cnn_fm_projection == 'tied' and c.rand_seed == 48964896
+    ckpts = sorted(glob.glob(os.path.join(run_dir, 'model_compact-*.npz')))
+    assert ckpts, os.listdir(run_dir)
+    assert os.path.isfile(os.path.join(run_dir, 'model_size.txt'))
+    # ---- inference ----
+    _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--get_metric_score', ''])
+    out_dir = os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0')
+    caps = glob.glob(os.path.join(out_dir, 'captions___*.json'))
+    assert caps
+    data = json.load(open(caps[0]))
+    assert len(data) == 4 and all(set(d) == {'image_id', 'caption'} for d in data)
+    assert os.path.isfile(os.path.join(out_dir, 'infer_speed.txt'))
+    # ---- SCST (the reference chains decoder -> cnn_finetune -> scst; the fine-tune stage is
+    # not built yet, so its run directory is a copy of the decoder run) ----
+    shutil.copytree(run_dir, run_dir.replace('_run_01', '_cnnFT_run_01'))
+    _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'scst', '--max_epoch', '2',
+                                                          '--scst_beam_size', '3'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    scst_dirs = glob.glob(os.path.join(logs, 'mscoco', '*_cnnFT_SCST_beam_3_*'))
+    assert scst_dirs and glob.glob(os.path.join(scst_dirs[0], 'model_compact-*.npz'))
