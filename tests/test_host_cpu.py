@@ -1,0 +1,244 @@
+"""CPU-side tests of the PRODUCT's host logic (no GPU compute): C-ABI exports, golden
+vectors for the token helpers and the C++ reward scorer, config.pkl compatibility, input
+managers, CLI run-directory naming, checkpoint restore logic, schedules."""
+import json
+import os
+import pickle
+import re
+import types
+
+import numpy as np
+import pytest
+
+import comic_amd._lib as L
+from comic_amd import checkpoint as ckpt, configuration as conf, decoder as cdec, nets, ops, optim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+# ------------------------------------------------------------------ C-ABI ---------------
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    header = open(os.path.join(ROOT, 'include', 'comic_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(comic_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libcomic_hip.so does not export %s' % name
+    assert set(L.EXPORTED_SYMBOLS) == declared, set(L.EXPORTED_SYMBOLS) ^ declared
+    assert lib.comic_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(L.CnnOp) == 22 * 4
+    assert C.sizeof(L.AttnDesc) == 8 * 4
+    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4
+    assert C.sizeof(L.DecoderParams) == 14 * 8
+    assert C.sizeof(L.ConvWeight) == 3 * 8
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/libcomic_hip.so')
+    with pytest.raises(L.ComicHipError, match='no CPU fallback'):
+        L.load()
+
+
+# ------------------------------------------------------------------ token helpers -------
+def test_product_text_helpers_match_reference_goldens(golden_dir):
+    g = _golden(golden_dir, 'text_golden.json')
+    for n, b, exp in g['number_to_base']:
+        assert ops.number_to_base(n, b) == exp
+    for case in g['id_to_caption']:
+        cfg = types.SimpleNamespace(token_type=case['token_type'], radix_base=case['radix_base'], itow=case['itow'],
+                                    wtoi=case['wtoi'])
+        assert ops.id_to_caption(np.array(case['ids']), cfg) == case['captions']
+    for case in g['captions_to_batched_ids']:
+        cfg = types.SimpleNamespace(token_type=case['token_type'], wtoi=g['wtoi'])
+        table = ops.build_radix_wtoi(g['wtoi'], case['radix_base']) if case['token_type'] == 'radix' else None
+        if table:
+            assert table == case['radix_wtoi']
+        assert ops.captions_to_batched_ids(case['hypos'], cfg, table).tolist() == case['ids']
+
+
+def test_cpp_scorer_matches_reference_goldens(golden_dir):
+    """The C++ scorer behind the C-ABI (host code, runs without a GPU) vs outputs captured
+    from the reference's captionScorer."""
+    from comic_amd.scst.scorers import captionScorer
+    g = _golden(golden_dir, 'scorer_golden.json')
+    df = dict(document_frequency={tuple(k.split(' ')): v for k, v in g['document_frequency'].items()},
+              ref_len=g['ref_len'])
+    for case in g['cases']:
+        sc = captionScorer(df, case['weights'], n_threads=4)
+        hyp, s_s, s_g = sc.get_hypo_scores(case['refs'], case['sample'], case['greedy'])
+        assert hyp == case['sample']
+        np.testing.assert_allclose(s_s, case['sc_sample'], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(s_g, case['sc_greedy'], rtol=1e-12, atol=1e-12)
+    sc = captionScorer(df, g['cases'][0]['weights'])
+    c0 = g['cases'][0]
+    n = len(c0['refs'])
+    cider, bleu = sc._score([h[0] for h in c0['sample']], [c0['refs'][i % n] for i in range(len(c0['sample']))])
+    np.testing.assert_allclose(cider, g['ciderD']['scores'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(bleu.T, np.array(g['bleu']['scores']), rtol=1e-12, atol=1e-300)
+    # best_hypo_only branch (scorers.py:136-158)
+    final, best, greedy = sc.get_hypo_scores(c0['refs'], c0['sample'], c0['greedy'], best_hypo_only=True)
+    assert len(final) == n and best.shape == (n,) and greedy.shape == (n,)
+
+
+def test_scorer_reads_reference_pickle(tmp_path, golden_dir):
+    from comic_amd.scst.scorers import captionScorer
+    g = _golden(golden_dir, 'scorer_golden.json')
+    df = {tuple(k.split(' ')): v for k, v in g['document_frequency'].items()}
+    p = tmp_path / 'scst-words.p'
+    with open(p, 'wb') as f:
+        pickle.dump({'document_frequency': df, 'ref_len': g['ref_len']}, f, 2)      # prepro_ngrams.py:149-151
+    sc = captionScorer(str(p), dict(ciderD=1.0, bleu=[0, 0, 0, 2]))
+    c0 = g['cases'][0]
+    _, s_s, _ = sc.get_hypo_scores(c0['refs'], c0['sample'], c0['greedy'])
+    np.testing.assert_allclose(s_s, c0['sc_sample'], rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ config --------------
+def test_config_pickle_roundtrip_and_py2_layout(tmp_path):
+    c = conf.Config(log_path=str(tmp_path), token_type='radix', radix_base=256, cnn_input_size=[224, 224],
+                    cnn_fm_projection=None, scst_weight_bleu=[0.0, 0.0, 0.0, 2.0], rand_seed=48964896)
+    c.save_config_to_file()
+    raw = open(tmp_path / 'config.pkl', 'rb').read()
+    assert raw[:2] == b'\x80\x02'                                   # protocol 2 (configuration.py:34-35)
+    d = pickle.loads(raw)
+    assert isinstance(d, dict) and d['radix_base'] == 256            # a plain dict, not the object
+    c2 = conf.load_config(str(tmp_path / 'config.pkl'))
+    assert c2.__dict__ == c.__dict__
+    txt = [f for f in os.listdir(tmp_path) if f.startswith('config___')]
+    assert txt and b'\r\n' in open(tmp_path / txt[0], 'rb').read()
+    with pytest.raises(SystemExit):
+        c.overwrite_safety_check(False)
+
+
+def test_cli_run_dir_naming_and_mode_overrides(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('train_cli', os.path.join(ROOT, 'src', 'train.py'))
+    train = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(train)
+    args = train.create_parser().parse_args(['--log_root', str(tmp_path), '--cnn_fm_projection', 'none', '--run', '2'])
+    kw, fn, overwrite = train.build_kwargs(args)
+    assert os.path.basename(kw['log_path']) == 'radix_b256_add_LN_softmax_h8_non_lstm_run_02'   # train.py:214-230
+    assert kw['cnn_fm_projection'] is None and kw['rand_seed'] == 88888888 and fn == 'train_fn'
+    assert kw['dropout_rnn_in'] == 0.35 and kw['l2_decay'] == 1e-5 and kw['max_saves'] == 12     # train.py:281-300
+    assert kw['cnn_input_size'] == [224, 224] and not overwrite
+    # scst mode overrides (train.py:253-270)
+    base = os.path.join(str(tmp_path), 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_cnnFT_run_01')
+    os.makedirs(base)
+    args = train.create_parser().parse_args(['--log_root', str(tmp_path), '--train_mode', 'scst'])
+    kw, fn, _ = train.build_kwargs(args)
+    assert fn == 'train_fn_scst' and kw['batch_size_train'] == 10 and kw['lr_start'] == 1e-3 and kw['max_epoch'] == 10
+    assert kw['scst_weight_bleu'] == [0.0, 0.0, 0.0, 2.0] and kw['checkpoint_path'] == base
+    assert os.path.basename(kw['log_path']) == \
+        'radix_b256_add_LN_softmax_h8_tie_lstm_cnnFT_SCST_beam_7_CrD_1.0_B1_0.0_B4_2.0_run_01'
+    # `type=bool` quirk: any non-empty string is True (train.py:45)
+    assert train.create_parser().parse_args(['--legacy', 'False']).legacy is True
+
+
+# ------------------------------------------------------------------ inputs --------------
+def test_input_managers_on_tiny_dataset(tmp_path):
+    from tests import tiny_dataset
+    from comic_amd import inputs
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=2, n_test=2)
+    c = conf.Config(dataset_dir=ds, dataset_file_pattern='mscoco_{}_w5_s20_include_restval', cnn_name='inception_v3',
+                    cnn_input_size=[224, 224], cnn_input_augment=True, batch_size_train=4, batch_size_eval=2,
+                    max_epoch=3, rand_seed=1, token_type='radix', radix_base=256)
+    man = inputs.InputManager_Radix(c)
+    assert c.split_sizes == {'train': 40, 'valid': 2} and c.max_step == int(40 / 4 * 3)    # :132,:141
+    assert man.buckets == [11, 13, 15]                      # 23-word vocab -> 1 radix digit per word
+    ims, caps = next(man.batch_train)
+    assert ims.shape == (4, 224, 224, 3) and ims.dtype == np.float32 and -1.0 <= ims.min() and ims.max() <= 1.0
+    assert caps.dtype == np.int32 and (caps[:, 0] == 256).all()
+    assert all(257 in row for row in caps.tolist()) and caps.min() >= -1
+    ims_e, _ = next(man.batch_eval)
+    assert ims_e.shape == (2, 224, 224, 3)
+    c2 = conf.Config(**{**c.__dict__, 'batch_size_train': 2, 'scst_beam_size': 3})
+    scst = inputs.InputManager_SCST(c2)
+    imgs, refs = next(scst.batch_train)
+    assert imgs.shape[0] == 2 and len(refs) == 2 and all(len(r) == 5 and '<GO>' not in r[0] for r in refs)
+    ids = scst.captions_to_batched_ids([['a man'], ['dog notaword cat']])
+    assert ids.tolist() == [[256, 0, 1, 257, -1], [256, 2, c.wtoi['<UNK>'], 3, 257]]
+
+
+def test_tf1_bilinear_resize_matches_definition():
+    from comic_amd.inputs import resize_bilinear_tf1
+    img = np.arange(2 * 3 * 1, dtype=np.float32).reshape(2, 3, 1)
+    out = resize_bilinear_tf1(img, 4, 6)
+    # src = dst * in/out, no half-pixel offset: even indices reproduce the source pixels
+    np.testing.assert_allclose(out[::2, ::2, 0], img[..., 0])
+    np.testing.assert_allclose(out[0, 1, 0], 0.5)
+    np.testing.assert_allclose(out[3, 5, 0], img[1, 2, 0])      # clamped at the border
+
+
+# ------------------------------------------------------------------ plan / spec ---------
+def test_cnn_plan_known_answers():
+    plan = nets.CnnPlan('inception_v3', (224, 224))
+    assert sum(1 for o in plan.ops if o['kind'] in (0, 1)) == 94
+    shapes = plan.param_shapes()
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 21802784       # inception_v3_test.py:125-133
+    assert plan.macs == 2835873120
+    assert plan.buffers[plan.fm][:3] == (5, 5, 2048) and plan.buffers[plan.pooled][:3] == (1, 1, 2048)
+    p299 = nets.CnnPlan('inception_v3', (299, 299))
+    assert p299.buffers[p299.fm][:3] == (8, 8, 2048)
+    assert p299.buffers[p299.end_points['Mixed_6e']][:3] == (17, 17, 768)  # inception_v3_test.py:93-123
+    with pytest.raises(NotImplementedError):
+        nets.CnnPlan('vgg_16')
+
+
+def test_decoder_spec_from_config_and_errors():
+    c = types.SimpleNamespace(rnn_name='LSTM', attn_alignment_method='add_LN', attn_probability_fn='softmax',
+                              token_type='radix', radix_base=256, rnn_size=512, rnn_word_size=256, attn_num_heads=8,
+                              cnn_fm_projection='tied', attn_context_layer=False, rnn_init_method='first_input',
+                              attn_keep_prob=0.9)
+    s = cdec.DecoderSpec.from_config(c, (25, 2048), 2048)
+    assert (s.V, s.start_id, s.end_id, s.A, s.Cv) == (258, 256, 257, 512, 512)
+    assert sum(int(np.prod(v)) if v else 1 for v in s.param_shapes().values()) == 5707011
+    c.attn_alignment_method = 'add'                 # accepted by the CLI, rejected by the model (model_base.py:133-138)
+    with pytest.raises(ValueError):
+        cdec.DecoderSpec.from_config(c, (25, 2048), 2048)
+    c.attn_alignment_method = 'add_LN'
+    c.cnn_fm_projection, c.token_type = None, 'word'
+    c.itow = {str(i): 'w%d' % i for i in range(-1, 99)}
+    c.wtoi = {'<GO>': 97, '<EOS>': 98}
+    s = cdec.DecoderSpec.from_config(c, (25, 2048), 2048)
+    assert (s.V, s.A, s.Cv) == (100, 2048, 2048)    # softmax_size counts <PAD> (model_base.py:44-45)
+
+
+def test_checkpoint_restore_three_way_logic(tmp_path):
+    spec = cdec.DecoderSpec(D=64, E=32, C=64, Cg=64, M=4)
+    plan_names = ['InceptionV3/Conv2d_1a_3x3/weights']
+    cnn = {plan_names[0]: np.ones((3, 3, 3, 32), np.float32)}
+    dec = cdec.init_params(spec, 0)
+    path = ckpt.save(str(tmp_path / 'model'), 7, cnn, spec, dec, {'optimise/caption/adam_m': np.zeros(3)})
+    assert path.endswith('model-7.npz') and ckpt.latest_checkpoint(str(tmp_path)) == path
+    names = ckpt.decoder_var_names(spec)
+    assert names['W_init'] == 'Model/decoder/rnn_decoder/rnn_init_input/projection/weight'
+    assert names['K'].endswith('basic_lstm_cell/kernel') and names['emb'].endswith('embedding_map')
+    c2, d2, extra = ckpt.restore(path, plan_names, spec, resume_training=True)
+    assert set(d2) == set(dec) and 'global_step' in extra and int(extra['global_step']) == 7
+    _, _, extra = ckpt.restore(path, plan_names, spec, resume_training=False)
+    assert extra == {}
+    # slim-style checkpoint (no Model/ prefix, no decoder): CNN only (model_base.py:468-482)
+    np.savez(tmp_path / 'slim.npz', **{plan_names[0]: 2 * cnn[plan_names[0]]})
+    c3, d3, _ = ckpt.restore(str(tmp_path / 'slim.npz'), plan_names, spec)
+    assert d3 is None and c3[plan_names[0]].max() == 2
+
+
+def test_schedules():
+    assert np.isclose(optim.cosine_lr(0, 100, 1e-2, 1e-5), 1e-2)
+    assert np.isclose(optim.cosine_lr(100, 100, 1e-2, 1e-5), 1e-5)
+    assert np.isclose(optim.cosine_lr(50, 100, 1e-2, 1e-5), (1e-2 - 1e-5) / 2 + 1e-5)
+    lr = 1e-3
+    for epoch in range(1, 13):
+        lr = optim.legacy_lr_reduce(lr, epoch, 2e-4, 4)
+    assert np.isclose(lr, 2e-4)                       # 1e-3 -> 5e-4 -> 2.5e-4 -> clamp 2e-4
