@@ -454,9 +454,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
-  constexpr int NSTAGE = 3;
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
   constexpr int STAGE_BYTES = ROWS * 128;
@@ -566,16 +565,23 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   for (int i = 0; i < TN; ++i)
     if (bn0 + wn * (BN / WN) + i * 16 < a.Cout) tn_live = i + 1;
 
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  // NSTAGE-1 tiles are in flight before the loop; at the top of iteration kt the tiles
+  // kt .. min(kt+NSTAGE-2, nk-1) have been issued and tile kt must have landed.
+  constexpr int AHEAD = NSTAGE - 1;
+#pragma unroll
+  for (int p = 0; p < AHEAD; ++p)
+    if (p < nk) issue(p, p);
   for (int kt = 0; kt < nk; ++kt) {
     const int stage = kt % NSTAGE;
-    if (kt + 1 < nk)
-      wait_vmcnt<LPT>();   // tile kt landed (this wave's share); tile kt+1 may still be in flight
+    const int pending = min(AHEAD - 1, nk - 1 - kt);   // tiles allowed to stay in flight
+    if (pending >= 2)
+      wait_vmcnt<2 * LPT>();
+    else if (pending == 1)
+      wait_vmcnt<LPT>();
     else
       wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; stage (kt+2)%3 is free again
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % NSTAGE);
+    __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; the stage read in kt-1 is free
+    if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
     const uint32_t sb = lds0 + stage * STAGE_BYTES;
     u32x4_t xf0[TM], xf1[TM], wf0[TN], wf1[TN];
     static_for<0, TN>([&](auto i) {
@@ -634,12 +640,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
-  constexpr int lds = 3 * (BM + BN) * 128;
+  static_assert(NSTAGE == 3 || NSTAGE == 4, "pipeline depth");
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN>,
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
       return 1;
@@ -647,8 +655,30 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), lds, st, a);
   return 0;
+}
+
+// explicit tile selection (comic_cnn_op.tile, filled by the host-side autotuner)
+constexpr int kNumConvTiles = 12;
+int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
+  switch (tile) {
+    case 1: return launch_dma<128, 128, 2, 2, 3>(a, st);
+    case 2: return launch_dma<128, 64, 2, 2, 3>(a, st);
+    case 3: return launch_dma<64, 64, 2, 2, 3>(a, st);
+    case 4: return launch_dma<32, 64, 1, 4, 3>(a, st);
+    case 5: return launch_dma<128, 32, 4, 1, 3>(a, st);
+    case 6: return launch_dma<64, 128, 2, 2, 3>(a, st);
+    case 7: return launch_dma<256, 64, 4, 1, 3>(a, st);
+    case 8: return launch_dma<128, 64, 2, 2, 4>(a, st);
+    case 9: return launch_dma<64, 64, 2, 2, 4>(a, st);
+    case 10: return launch_dma<32, 64, 1, 4, 4>(a, st);
+    case 11: return launch_dma<64, 128, 2, 2, 4>(a, st);
+    case 12: return launch_dma<128, 32, 4, 1, 4>(a, st);
+    default:
+      comic_set_error("conv: unknown tile id %d", tile);
+      return 2;
+  }
 }
 
 int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
@@ -728,7 +758,11 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
       if constexpr (sizeof(T) == 2) {
         COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "conv: activation tensor too large");
-        if (int rc = dispatch_igemm_dma(a, st)) return rc;
+        if (op->tile > 0) {
+          if (int rc = launch_dma_tile(op->tile, a, st)) return rc;
+        } else if (int rc = dispatch_igemm_dma(a, st)) {
+          return rc;
+        }
       } else {
         dispatch_igemm<T>(a, st);
       }

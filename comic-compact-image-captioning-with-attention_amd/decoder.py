@@ -326,7 +326,7 @@ class Decoder:
         ctx.loss.copy_((ctx.loss_rows.view(T, B) * rs_tb).sum().reshape(1))
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
-                   want_input_grads=False, xe_denom=None, use_graph=False):
+                   want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
@@ -372,6 +372,8 @@ class Decoder:
         assert fm.dtype == torch.float32 and im_embed.dtype == torch.float32
         ctx.fm.copy_(fm)
         ctx.im.copy_(im_embed)
+        if on_inputs_consumed is not None:      # the encoder buffers may be overwritten from here on
+            on_inputs_consumed()
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):

@@ -314,6 +314,50 @@ class CnnEncoder:
         B = self.batch
         return pooled.reshape(B, -1), fm.reshape(B, fm.shape[1] * fm.shape[2], fm.shape[3])
 
+    def autotune(self, reps=5, verbose=False):
+        """Pick the fastest tile / pipeline-depth variant of the LDS-DMA conv kernel for every
+        conv of the plan at this batch size (times each variant with HIP events on the real
+        buffers; ~0.3 s).  Results are bit-identical across variants for a given op only up to
+        the fp32 summation order inside a k-tile, i.e. identical: the k order does not depend
+        on the tile shape."""
+        if self.dcode != 1:
+            return {}
+        torch = self.torch
+        st = L.stream_ptr()
+        chosen = {}
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i, o in enumerate(self.plan.ops):
+            if o['kind'] != 0:
+                continue
+            op = self._ops[i]
+            src, dst = self.bufs[o['src']], self.bufs[o['dst']]
+            wt = self._wt[o['weight']]
+            best = (None, 0)
+            for tile in range(0, L.CONV_TILES + 1):
+                op.tile = tile
+
+                def run():
+                    L.check(self.lib.comic_conv2d_bn_relu(C.byref(op), src.data_ptr(), src.shape[3], dst.data_ptr(),
+                                                          dst.shape[3], C.byref(wt), self.batch, self.dcode, st),
+                            'conv (autotune)')
+                run(); run()
+                ev0.record()
+                for _ in range(reps):
+                    run()
+                ev1.record()
+                ev1.synchronize()
+                t = ev0.elapsed_time(ev1) / reps
+                if best[0] is None or t < best[0]:
+                    best = (t, tile)
+            op.tile = best[1]
+            chosen[i] = best
+            if verbose:
+                print('autotune op %3d %3dx%-3d Cin%4d Cout%4d %dx%d -> tile %2d  %.1f us' % (
+                    i, o['Ho'], o['Wo'], o['Cin'], o['Cout'], o['KH'], o['KW'], best[1], best[0] * 1e3))
+        self._graph = None        # a captured graph holds the old variants
+        self._calls = 0
+        return chosen
+
     def end_point(self, name):
         return self.bufs[self.plan.end_points[name]]
 

@@ -57,6 +57,14 @@ class CaptionTrainer:
         self.device = device
         self.batch = batch
         self.use_graph = True       # hipGraph replay of the CNN plan and of the decoder step
+        # decoder-mode pipelining: the CNN is frozen, so the encoder forward of the NEXT batch
+        # does not depend on this step's update and runs on a second stream under the decoder
+        import torch
+        self._torch = torch
+        self._side = torch.cuda.Stream(device=device)
+        self._ev_cnn = torch.cuda.Event()
+        self._ev_used = torch.cuda.Event()
+        self._pending = None
 
     @property
     def global_step(self):
@@ -75,6 +83,40 @@ class CaptionTrainer:
             denom = self.dp.global_tokens(local_tokens, self.device) / self.dp.world + 1e-12
         res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
                                       use_graph=self.use_graph)
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
+        return res
+
+    def submit_images(self, images):
+        """Start the encoder forward of a future step on the side stream (frozen-CNN modes)."""
+        torch = self._torch
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main) if self._pending is None else self._side.wait_event(self._ev_used)
+        with torch.cuda.stream(self._side):
+            self._pending = self.encoder.forward(images, use_graph=self.use_graph)
+            self._ev_cnn.record(self._side)
+
+    def xe_step_pending(self, captions, next_images=None, masks=None, training=True):
+        """XE step on the batch submitted earlier; `next_images` (if given) are submitted as soon
+        as the decoder has taken its copy of the encoder outputs, overlapping with this step."""
+        assert self._pending is not None, 'submit_images() first'
+        torch = self._torch
+        main = torch.cuda.current_stream()
+        main.wait_event(self._ev_cnn)
+        im_embed, fm = self._pending
+        cap = np.asarray(captions)
+        denom = None
+        if self.dp.world > 1:
+            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
+
+        def consumed():
+            self._ev_used.record(main)
+            if next_images is not None:
+                self.submit_images(next_images)
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+                                      use_graph=self.use_graph, on_inputs_consumed=consumed)
+        if next_images is None:
+            self._pending = None
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res

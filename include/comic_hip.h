@@ -31,6 +31,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
+#define COMIC_CONV_TILES 12
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -69,6 +70,8 @@ typedef struct comic_cnn_op {
                         (global avg-pool over the fp32 attention feature map) */
   int32_t lane;      /* 0 = caller's stream; 1..3 = internal branch streams (independent
                         Inception branches run concurrently between a fork and a join) */
+  int32_t tile;      /* conv: 0 = built-in heuristic, 1..COMIC_CONV_TILES = explicit tile /
+                        pipeline-depth variant (chosen by the host-side autotuner) */
 } comic_cnn_op;
 
 typedef struct comic_conv_weight {
