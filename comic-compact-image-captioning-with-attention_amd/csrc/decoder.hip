@@ -6,6 +6,7 @@
 //   common/ops_rnn.py:531-565, :611-632, :660-755   attention mechanisms + wrapper step
 //   common/ops.py:241-275                           layer_norm_activate (eps 1e-12)
 //   src/model_base.py:557-594, :606-648, :325-417   embeddings, LSTM cell + dropout, losses
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -210,6 +211,17 @@ __device__ __forceinline__ void load_row(const float* __restrict__ p, float* v) 
   }
 }
 
+template <int EPL>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float* v) {
+  if constexpr (EPL % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < EPL; i += 4) *(float4*)(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) p[i] = v[i];
+  }
+}
+
 // sum over the `lph` consecutive lanes that share a head (lph is a power of two <= 64)
 __device__ __forceinline__ float head_sum(float v, int lph) {
   for (int o = 1; o < lph; o <<= 1) v += __shfl_xor(v, o, 64);
@@ -353,7 +365,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   const int M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
   float* ss = sm;               // [H][M] scaled scores s
   float* sd = ss + H * M;       // [H][M] d alpha_d, then d raw
-  float* red = sd + H * M;               // [kAttnWaves][D] cross-wave reduction
+  float* sa = sd + H * M;                // [H][M] alpha_d (tied values)
+  float* red = sa + H * M;               // [kAttnWaves][512] cross-wave reduction
   float* misc = red + kAttnWaves * 512;  // [kAttnWaves] d tau partials
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dh = D / H, lph = dh / EPL;
@@ -375,22 +388,38 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   const float live = (a.lens && a.t >= a.lens[b]) ? 0.f : 1.f;
 
   // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
+  // tied values: the value row IS the key row (one load), and the alpha_d * dctx term of
+  // d keys is folded into phase C's single read-modify-write (alpha_d parked in LDS)
+  const bool tied = a.d.tied != 0;
+  float dcl[EPL];   // this lane's slice of d ctx (tied layout: c0 == k0, eplv == EPL)
+  if (tied) {
+    load_row<EPL>(dctx + k0, dcl);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) dcl[i] *= live;
+  }
   for (int m = wave; m < M; m += kAttnWaves) {
     float kr[EPL], rstd;
     load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    const size_t go = ((size_t)b * H + headv) * M + m;
+    const float al = a.alpha_in[go];
+    const float mk = a.mask_alpha ? a.mask_alpha[go] : 1.f;
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
     if ((lane % lph) == 0) ss[head * M + m] = raw / scale;
     // alpha_d of this lane's value head
-    const size_t go = ((size_t)b * H + headv) * M + m;
-    const float al = a.alpha_in[go];
-    const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go] : al;
-    const float* vr = a.values + ((size_t)b * M + m) * Cv + c0;
-    float* dvr = a.dvalues + ((size_t)b * M + m) * Cv + c0;
+    const float ad = a.mask_alpha ? (al / a.keep_alpha) * mk : al;
     float part = 0.f;
-    for (int i = 0; i < eplv; ++i) {
-      const float dc = dctx[c0 + i] * live;
-      part = fmaf(dc, vr[i], part);
-      dvr[i] += ad * dc;
+    if (tied) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) part = fmaf(dcl[i], kr[i], part);
+      if ((lane % lphv) == 0) sa[headv * M + m] = ad;
+    } else {
+      const float* vr = a.values + ((size_t)b * M + m) * Cv + c0;
+      float* dvr = a.dvalues + ((size_t)b * M + m) * Cv + c0;
+      for (int i = 0; i < eplv; ++i) {
+        const float dc = dctx[c0 + i] * live;
+        part = fmaf(dc, vr[i], part);
+        dvr[i] += ad * dc;
+      }
     }
     part = head_sum(part, lphv);
     if ((lane % lphv) == 0) sd[headv * M + m] = part + (a.dmap ? a.dmap[(size_t)b * M + m] : 0.f);
@@ -464,16 +493,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
         s2 += dxh[i] * xh[i];
       }
       const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+      const float adm = tied ? sa[head * M + m] : 0.f;
+      float dko[EPL];
+      load_row<EPL>(dkp, dko);
 #pragma unroll
       for (int i = 0; i < EPL; ++i) {
         const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
-        dkp[i] += dz;
+        dko[i] += dz + (tied ? adm * dcl[i] : 0.f);
         dq_acc[i] += dz;
       }
+      store_row<EPL>(dkp, dko);
     } else {
+      const float adm = tied ? sa[head * M + m] : 0.f;
 #pragma unroll
       for (int i = 0; i < EPL; ++i) {
-        dkp[i] += draw * qv[i];
+        dkp[i] += draw * qv[i] + (tied ? adm * dcl[i] : 0.f);
         dq_acc[i] += draw * kr[i];
       }
     }
@@ -615,6 +649,22 @@ __global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ 
   out[j] = (beta != 0.f ? beta * out[j] : 0.f) + ((a0 + a1) + (a2 + a3));
 }
 
+// two-stage column sum for tall inputs: stage 1 sums row chunks into partial[R][cols]
+__global__ void colsum_part_kernel(const float* __restrict__ in, float* __restrict__ partial, int rows, int cols,
+                                   int rows_per_chunk) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cols) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float a0 = 0.f, a1 = 0.f;
+  int i = r0;
+  for (; i + 1 < r1; i += 2) {
+    a0 += in[(size_t)i * cols + j];
+    a1 += in[(size_t)(i + 1) * cols + j];
+  }
+  if (i < r1) a0 += in[(size_t)i * cols + j];
+  partial[(size_t)blockIdx.y * cols + j] = a0 + a1;
+}
+
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] += a * x[i];
@@ -629,7 +679,7 @@ int attn_check(const comic_attn_desc* d) {
   COMIC_REQUIRE(d->Cv % 64 == 0 && d->Cv % d->H == 0 && (d->Cv / d->H) % (d->Cv / 64) == 0,
                 "attn: value channels must be a multiple of 64 (Cv=%d H=%d)", d->Cv, d->H);
   COMIC_REQUIRE(!d->tied || d->Cv == d->D, "attn: tied values need Cv == D");
-  COMIC_REQUIRE((size_t)d->H * d->M * 2 * 4 + (size_t)kAttnWaves * 512 * 4 + 256 <= 64 * 1024, "attn: H*M too large for LDS");
+  COMIC_REQUIRE((size_t)d->H * d->M * 3 * 4 + (size_t)kAttnWaves * 512 * 4 + 256 <= 64 * 1024, "attn: H*M too large for LDS");
   return 0;
 }
 
@@ -773,7 +823,7 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
   a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad; a.lens = lens; a.t = t;
-  const size_t lds = ((size_t)d->H * d->M * 2 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
+  const size_t lds = ((size_t)d->H * d->M * 3 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
   });
@@ -831,6 +881,17 @@ extern "C" int comic_colsum(const float* in, float* out, int rows, int cols, flo
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, (hipStream_t)stream, in, out, rows, cols,
                      beta);
   COMIC_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+// executor-internal: `ws` holds at least 64*cols floats
+int comic_colsum_ws(const float* in, float* out, int rows, int cols, float beta, float* ws, hipStream_t st) {
+  if (!ws || rows < 256) return comic_colsum(in, out, rows, cols, beta, (void*)st);
+  const int R = std::min(64, (rows + 31) / 32);
+  const int rpc = (rows + R - 1) / R;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(cols, 64), R), dim3(64), 0, st, in, ws, rows, cols, rpc);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(64), 0, st, (const float*)ws, out, R, cols, beta);
+  COMIC_LAUNCH_CHECK("colsum_ws");
   return 0;
 }
 

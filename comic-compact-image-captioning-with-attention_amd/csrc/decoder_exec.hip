@@ -29,6 +29,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
                       int mask_ld, float keep_in, int q_parts, float* q_out, hipStream_t st);
+int comic_colsum_ws(const float* in, float* out, int rows, int cols, float beta, float* ws, hipStream_t st);
 int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int trans_b,
                            void* ws, int64_t ws_bytes, int* S_out, hipStream_t st);
 int comic_lstm_gates_bwd_ex(const float* gates_act, const float* c_prev, const float* c_new, const float* dy,
@@ -556,7 +557,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // dy_all = dlogits * W_o^T ; dW_o, db_o
   RC(gemm(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
   RC(gemm(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
-  RC(comic_colsum(dlogits, gr->b_o, Tp * B, V, 0.f, (void*)st));
+  RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
   for (int t = Tp - 1; t >= 0; --t) {
     const float* ctx_t = ctx_all + (size_t)t * B * Cv;
@@ -596,7 +597,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   }
   // time-batched weight gradients
   RC(gemm(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
-  RC(comic_colsum(dg_all, gr->b, Tp * B, 4 * D, 0.f, (void*)st));
+  RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
   RC(gemm(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, st));
   RC(fill(gr->emb, 0.f, (long)V * E, st));
   RC(comic_embed_bwd(in_tb, demb, gr->emb, Tp * B, E, V, (void*)st));
