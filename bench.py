@@ -23,7 +23,7 @@ IMG = 224
 FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
 PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
 GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
-GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '1') == '1'   # hipGraph replay of the decoder step
+GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '0') == '1'   # hipGraph replay of the decoder step (eager measured faster)
 
 
 def synth_captions(rng, B):
@@ -41,6 +41,86 @@ def synth_captions(rng, B):
     out = np.full((B, L), -1, np.int64)
     for i, r in enumerate(rows):
         out[i, :len(r)] = r
+    return out
+
+
+def extras(device, enc, cnn_params, plan):
+    """Secondary figures of BASELINE.json's metric line (not `value`): beam-3 captions/sec on the
+    InstaPIC-style word baseline (configs[4]: word tokens, V=25 599, 1 head, no projection, batch 50)
+    and SCST images/sec (configs[3]: greedy + beam-7 rollouts, C++ CIDEr-D/BLEU reward, reward-weighted
+    step, batch 32).  Synthetic inputs; single GPU."""
+    import torch
+    from comic_amd import decoder as cdec, nets, optim
+    from comic_amd.ops import id_to_caption, captions_to_batched_ids, build_radix_wtoi
+    from comic_amd.scst.scorers import captionScorer
+    from comic_amd.scst import prepro_ngrams
+    import types
+    out = {}
+    rng = np.random.default_rng(7)
+    # ---- beam-3 inference, word baseline --------------------------------------------------
+    B = 50
+    enc50 = nets.CnnEncoder(plan, cnn_params, B, 'bf16', device)
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (B, IMG, IMG, 3)).astype(np.float32)).to(device)
+    V = 25599
+    spec = cdec.DecoderSpec(V=V, H=1, fm_projection=None, token_type='word', start_id=V - 2, end_id=V - 1)
+    dec = cdec.Decoder(spec, None, device, seed=3)
+    max_steps = 30
+    for _ in range(2):
+        im, fm = enc50.forward(imgs, use_graph=True)
+        r = dec.beam_search(fm, im, 3, max_steps)
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        im, fm = enc50.forward(imgs, use_graph=True)
+        r = dec.beam_search(fm, im, 3, max_steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    out['beam3_captions_per_sec'] = round(B / dt, 1)
+    out['beam3_config'] = 'word tokens V=25599, 1 head, fm_projection none, batch 50, max 30 steps, %d steps executed' % r['predicted_ids'].shape[0]
+    del dec, enc50
+    # ---- SCST step, COMIC-256 -------------------------------------------------------------
+    Bs, W = 32, 7
+    words = ['w%d' % i for i in range(10000)]
+    wtoi = {'<PAD>': -1}
+    for i, w in enumerate(words):
+        wtoi[w] = i
+    for tok in ('<UNK>', '<GO>', '<EOS>'):
+        wtoi[tok] = len(wtoi) - 1
+    cfg = types.SimpleNamespace(token_type='radix', radix_base=256, wtoi=wtoi, itow={str(v): k for k, v in wtoi.items()})
+    table = build_radix_wtoi(wtoi, 256)
+    refs = [[' '.join(rng.choice(words[:200], int(rng.integers(8, 15)))) for _ in range(5)] for _ in range(Bs)]
+    df = prepro_ngrams.build(['i%d,<GO> %s <EOS>' % (i, r) for i, rl in enumerate(refs) for r in rl])
+    scorer = captionScorer(df, dict(ciderD=1.0, bleu=[0, 0, 0, 2]))
+    spec = cdec.DecoderSpec()
+    dec = cdec.Decoder(spec, None, device, seed=4)
+    dec.params.view('b_o')[257] = 2.0
+    opt = optim.AdamTF(dec.params)
+    enc_s = nets.CnnEncoder(plan, cnn_params, Bs, 'bf16', device)
+    enc_t = nets.CnnEncoder(plan, cnn_params, Bs * W, 'bf16', device)
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (Bs, IMG, IMG, 3)).astype(np.float32)).to(device)
+    iters = 40                                   # infer_max_length 20 x 2 radix digits
+
+    def scst_step():
+        im, fm = enc_s.forward(imgs, use_graph=True)
+        greedy, _, _ = dec.greedy(fm, im, iters)
+        beam = dec.beam_search(fm, im, W, iters)['predicted_ids'].transpose(2, 1, 0)     # (W,B,T)
+        cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
+        cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
+        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
+        ids = captions_to_batched_ids(hypos, cfg, table)
+        im, fm = enc_t.forward(imgs.repeat(W, 1, 1, 1), use_graph=True)
+        res = dec.train_step(fm, im, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True)
+        opt.step(dec.grads, 1e-3)
+        return res
+    for _ in range(2):
+        scst_step()
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        scst_step()
+    torch.cuda.synchronize()
+    out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
+    out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-image step'
     return out
 
 
@@ -78,6 +158,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
     args = ap.parse_args()
 
     import torch
@@ -195,6 +276,15 @@ def main():
                                  'next batch runs concurrently with the decoder step (frozen CNN)' if overlap else ''},
             'final_loss': round(loss, 5),
         }
+        tfile = os.path.join(ROOT, 'profiles', 'r01_cnn_hbm_traffic.json')
+        if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
+            out['roofline']['traffic'] = json.load(open(tfile))['per_forward']['conv_only_bytes_corrected']
+            out['roofline']['traffic_source'] = 'profiles/r01_cnn_hbm_traffic.json (bytes per InceptionV3 forward at batch 64, conv kernels)'
+        if not args.no_extras and world == 1:
+            try:
+                out['extras'] = extras(device, tr.encoder, cnn_params, plan)
+            except Exception as e:          # secondary figures must never break the headline line
+                out['extras'] = {'error': repr(e)}
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         else:

@@ -440,6 +440,13 @@ int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bia
   return 0;
 }
 
+extern "C" int comic_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                     int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  return comic_gemm_f32_ws(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, beta, workspace,
+                           workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                               int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
                               void* stream) {

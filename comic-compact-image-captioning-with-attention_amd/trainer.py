@@ -56,7 +56,8 @@ class CaptionTrainer:
         self.lr_start, self.lr_end, self.max_step = lr_start, lr_end, max_step
         self.device = device
         self.batch = batch
-        self.use_graph = True       # hipGraph replay of the CNN plan and of the decoder step
+        self.use_graph = True       # hipGraph replay of the CNN plan
+        self.use_graph_decoder = False   # eager decoder launches measured faster next to the side stream
         # decoder-mode pipelining: the CNN is frozen, so the encoder forward of the NEXT batch
         # does not depend on this step's update and runs on a second stream under the decoder
         import torch
@@ -82,7 +83,7 @@ class CaptionTrainer:
         if self.dp.world > 1:
             denom = self.dp.global_tokens(local_tokens, self.device) / self.dp.world + 1e-12
         res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
-                                      use_graph=self.use_graph)
+                                      use_graph=self.use_graph_decoder)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res
@@ -114,7 +115,7 @@ class CaptionTrainer:
             if next_images is not None:
                 self.submit_images(next_images)
         res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
-                                      use_graph=self.use_graph, on_inputs_consumed=consumed)
+                                      use_graph=self.use_graph_decoder, on_inputs_consumed=consumed)
         if next_images is None:
             self._pending = None
         scale = self.dp.average_(self.decoder.grads.data)
@@ -125,7 +126,7 @@ class CaptionTrainer:
         """train_fn_scst's train run (train_fn.py:251-256): images already tiled by the beam size."""
         im_embed, fm = self.encoder.forward(images_tiled, use_graph=self.use_graph)
         res = self.decoder.train_step(fm, im_embed, hypo_ids, masks=masks, rewards=rewards, training=training,
-                                      use_graph=self.use_graph)
+                                      use_graph=self.use_graph_decoder)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res

@@ -104,6 +104,12 @@ int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, 
                    int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
                    void* stream);
 
+/* Same product; a caller-provided workspace lets skinny problems (M <= 2048, no trans_a)
+ * split K over extra workgroups (deterministic slab reduction). */
+int comic_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N,
+                          int K, int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha,
+                          float beta, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Decoder step kernels                                                       */
 /* ------------------------------------------------------------------------- */

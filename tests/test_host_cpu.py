@@ -242,3 +242,17 @@ def test_schedules():
     for epoch in range(1, 13):
         lr = optim.legacy_lr_reduce(lr, epoch, 2e-4, 4)
     assert np.isclose(lr, 2e-4)                       # 1e-3 -> 5e-4 -> 2.5e-4 -> clamp 2e-4
+
+
+def test_prepro_ngrams_matches_reference_df(golden_dir):
+    """Product df builder vs the document_frequency captured from the reference's
+    prepro_ngrams.compute_doc_freq (refs keep ' <EOS>')."""
+    from comic_amd.scst import prepro_ngrams
+    g = _golden(golden_dir, 'scorer_golden.json')
+    lines = []
+    for i, refs in enumerate(g['corpus_refs']):
+        for r in refs:
+            lines.append('img%d.jpg,<GO> %s <EOS>' % (i, r))
+    out = prepro_ngrams.build(lines)
+    assert out['ref_len'] == g['ref_len']
+    assert {' '.join(k): v for k, v in out['document_frequency'].items()} == g['document_frequency']
