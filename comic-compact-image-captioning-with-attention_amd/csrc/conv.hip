@@ -30,6 +30,7 @@ struct ConvArgs {
   int x_cs, x_co, y_cs, y_co;  // channel stride / offset of the src and dst pixel
   int K, Kpad, M;
   int relu, out_f32;
+  const void* zero;  // 16 zero bytes in device memory (source of padding / out-of-range DMA lanes)
 };
 
 template <typename T>
@@ -454,7 +455,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+// ALIGNED (Cin % 64 == 0): a whole k-tile lies inside one filter tap, so the tap walk (kh, kw, c0)
+// is wave-uniform scalar state and the per-lane part of a source address is a constant.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
@@ -468,11 +471,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS DMA bases become SGPR math
   const int wm = wave / WN, wn = wave % WN;
   const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
   const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
   const bf16_t* __restrict__ wg = (const bf16_t*)a.w;
+  const bf16_t* zp = (const bf16_t*)a.zero;
   const int slot = lane & 7, rsub = lane >> 3;
 
   // ---- im2col state of the rows this lane feeds ------------------------------------------
@@ -495,10 +500,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   // the source chunk of a lane alternates between two values with the parity of the 8-row group
   // (swizzle term (row>>1)&7 = 4*(group&1) + (rsub>>1)); keep one k-state per parity
   int kc[2], kkw[2], kkh[2];
+  int chunk8[2];          // ALIGNED: element offset of this lane's chunk inside the k-tile, per parity
+  int s_kh = 0, s_kw = 0, s_c0 = 0;   // ALIGNED: wave-uniform tap walk
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
     const int chunk = slot ^ ((4 * par + (rsub >> 1)) & 7);
     const int kk = chunk * 8;
+    chunk8[par] = kk;
     kc[par] = kk % a.Cin;
     const int tap = kk / a.Cin;
     kkw[par] = tap % a.KW;
@@ -518,30 +526,56 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
 
   auto issue = [&](int kt, int stage) {
     unsigned char* sbase = smem + stage * STAGE_BYTES;
+    if constexpr (ALIGNED) {
+      const bool kvalid = s_kh < a.KH;
+      const int koff = (s_kh * a.W + s_kw) * a.x_cs + s_c0;   // scalar
 #pragma unroll
-    for (int i = 0; i < IPW_A; ++i) {
-      const int ga = wave * IPW_A + i;
-      const int par = ga & 1;
-      const int hi = hi0[i] + kkh[par], wi = wi0[i] + kkw[par];
-      const bool ok = mok[i] && kkh[par] < a.KH && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      const void* src = ok ? (const void*)(xg + (xbase[i] + (kkh[par] * a.W + kkw[par]) * a.x_cs + kc[par]))
-                           : (const void*)g_zero_page;
-      dma16(src, sbase + ga * 1024);
+      for (int i = 0; i < IPW_A; ++i) {
+        const int ga = wave * IPW_A + i;
+        const int hi = hi0[i] + s_kh, wi = wi0[i] + s_kw;
+        const bool ok = mok[i] & kvalid & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+        const bf16_t* src = xg + (xbase[i] + koff + chunk8[ga & 1]);
+        src = ok ? src : zp;
+        dma16(src, sbase + ga * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IPW_A; ++i) {
+        const int ga = wave * IPW_A + i;
+        const int par = ga & 1;
+        const int hi = hi0[i] + kkh[par], wi = wi0[i] + kkw[par];
+        const bool ok = mok[i] & (kkh[par] < a.KH) & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+        const bf16_t* src = xg + (xbase[i] + (kkh[par] * a.W + kkw[par]) * a.x_cs + kc[par]);
+        src = ok ? src : zp;
+        dma16(src, sbase + ga * 1024);
+      }
     }
 #pragma unroll
     for (int i = 0; i < IPW_B; ++i) {
       const int gb = wave * IPW_B + i;
-      const void* src = nok[i] ? (const void*)(wsrc[i] + (size_t)kt * BKE) : (const void*)g_zero_page;
+      const bf16_t* src = wsrc[i] + (size_t)kt * BKE;
+      src = nok[i] ? src : zp;
       dma16(src, sbase + BM * 128 + gb * 1024);
     }
+    if constexpr (ALIGNED) {
+      s_c0 += BKE;
+      if (s_c0 >= a.Cin) {
+        s_c0 = 0;
+        if (++s_kw == a.KW) {
+          s_kw = 0;
+          ++s_kh;
+        }
+      }
+    } else {
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      kc[par] += BKE;
-      while (kc[par] >= a.Cin) {
-        kc[par] -= a.Cin;
-        if (++kkw[par] == a.KW) {
-          kkw[par] = 0;
-          ++kkh[par];
+      for (int par = 0; par < 2; ++par) {
+        kc[par] += BKE;
+        while (kc[par] >= a.Cin) {
+          kc[par] -= a.Cin;
+          if (++kkw[par] == a.KW) {
+            kkw[par] = 0;
+            ++kkh[par];
+          }
         }
       }
     }
@@ -560,10 +594,6 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   const uint32_t x_off1 = (wm * (BM / WM) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
   const uint32_t w_off0 = (BM + wn * (BN / WN) + fr) * 128 + (((0 + fg) ^ sw) & 7) * 16;
   const uint32_t w_off1 = (BM + wn * (BN / WN) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
-  int tn_live = 0;
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-    if (bn0 + wn * (BN / WN) + i * 16 < a.Cout) tn_live = i + 1;
 
   // NSTAGE-1 tiles are in flight before the loop; at the top of iteration kt the tiles
   // kt .. min(kt+NSTAGE-2, nk-1) have been issued and tile kt must have landed.
@@ -594,16 +624,15 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    // n-tiles beyond Cout multiply zero-filled weight rows (no branch: keeps the accumulators in place)
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      if (i < tn_live) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]),
-                                                              __builtin_bit_cast(bf16x8_t, xf0[j]), acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]),
-                                                              __builtin_bit_cast(bf16x8_t, xf1[j]), acc[i][j], 0, 0, 0);
-        }
+      for (int j = 0; j < TM; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]),
+                                                            __builtin_bit_cast(bf16x8_t, xf0[j]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]),
+                                                            __builtin_bit_cast(bf16x8_t, xf1[j]), acc[i][j], 0, 0, 0);
       }
     }
   }
@@ -647,7 +676,9 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE>,
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
       return 1;
@@ -655,7 +686,10 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
-  hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), lds, st, a);
+  if (a.Cin % 64 == 0)
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, st, a);
   return 0;
 }
 
@@ -690,6 +724,17 @@ int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
   if (b128x64 >= 512) return launch_dma<128, 64, 2, 2>(a, st);
   if (b64x64 >= 384) return launch_dma<64, 64, 2, 2>(a, st);
   return launch_dma<32, 64, 1, 4>(a, st);
+}
+
+const void* zero_page_address() {
+  static const void* p[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!p[dev]) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_zero_page)) == hipSuccess) p[dev] = q;
+  }
+  return p[dev];
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -735,6 +780,7 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.M = batch * op->Ho * op->Wo;
   a.relu = op->relu;
   a.out_f32 = op->out_f32;
+  a.zero = zero_page_address();
   return 0;
 }
 
@@ -757,6 +803,7 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "conv: Cout must be a multiple of 16 (got %d)", op->Cout);
       COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
       if constexpr (sizeof(T) == 2) {
+        COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
         COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "conv: activation tensor too large");
         if (op->tile > 0) {
           if (int rc = launch_dma_tile(op->tile, a, st)) return rc;
