@@ -176,7 +176,8 @@ def main():
 
     from comic_amd import decoder as cdec, nets, trainer
     dp = trainer.DataParallel(dist if world > 1 else None)
-    plan = nets.CnnPlan('inception_v3', (IMG, IMG), branch_streams=os.environ.get('COMIC_CNN_LANES', '0') == '1')
+    plan = nets.CnnPlan('inception_v3', (IMG, IMG), branch_streams=os.environ.get('COMIC_CNN_LANES', '0') == '1',
+                        group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1')
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
     tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan)

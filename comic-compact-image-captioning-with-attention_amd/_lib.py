@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
 class CnnOp(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
-        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile')]
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group')]
 
 
 class ConvWeight(C.Structure):
@@ -49,6 +49,9 @@ _SIGS = {
     'comic_pack_conv_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'comic_fold_bn': (c_int, [P, P, P, c_float, P, P, c_int, P]),
     'comic_cnn_forward': (c_int, [P, c_int, P, P, P, c_int, c_int, P]),
+    'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
+    'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
+    'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),
     'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
     'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_float, P]),

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -31,6 +32,8 @@ struct ConvArgs {
   int K, Kpad, M;
   int relu, out_f32;
   const void* zero;  // 16 zero bytes in device memory (source of padding / out-of-range DMA lanes)
+  int blk0, tiles_m; // grouped launch: first flat workgroup id of this problem, its pixel-tile count
+  int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index)
 };
 
 template <typename T>
@@ -458,7 +461,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ALIGNED (Cin % 64 == 0): a whole k-tile lies inside one filter tap, so the tap walk (kh, kw, c0)
 // is wave-uniform scalar state and the per-lane part of a source address is a constant.
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int block_m, const int block_n) {
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
   constexpr int STAGE_BYTES = ROWS * 128;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS DMA bases become SGPR math
   const int wm = wave / WN, wn = wave % WN;
-  const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+  const int bm0 = block_m * BM, bn0 = block_n * BN;
   const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
   const bf16_t* __restrict__ wg = (const bf16_t*)a.w;
   const bf16_t* zp = (const bf16_t*)a.zero;
@@ -669,6 +672,86 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
   }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i % 8), each with a private
+// L2.  xcd_tile_index turns the hardware id into a logical tile index such that every XCD owns one
+// CONTIGUOUS range of logical tiles; with the out-channel tile as the fastest logical dimension,
+// all out-channel tiles of a pixel tile (and its halo neighbours) run on the same XCD, so an
+// activation row is pulled from the memory side into exactly one L2 instead of up to 8.
+// The grid is padded to a multiple of 8; ids past `total` exit.
+__device__ __forceinline__ int xcd_tile_index(int total) {
+  const int per = gridDim.x >> 3;
+  const int l = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return l < total ? l : -1;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
+  const int tiles_n = (a.Cout + BN - 1) / BN;
+  int bm, bn;
+  if (a.remap) {
+    const int l = xcd_tile_index(a.tiles_m * tiles_n);
+    if (l < 0) return;
+    bn = l % tiles_n;
+    bm = l / tiles_n;
+  } else {
+    if ((int)blockIdx.x >= a.tiles_m * tiles_n) return;
+    bm = blockIdx.x % a.tiles_m;
+    bn = blockIdx.x / a.tiles_m;
+  }
+  conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, ALIGNED>(a, bm, bn);
+}
+
+// Grouped launch: blockIdx.z selects one of several independent convolutions (the same-depth
+// ops of the parallel Inception branches) whose argument records live in device memory.  One
+// launch then carries 2-4x the workgroups of a single 12x12 / 5x5 layer, which is what those
+// layers lack to fill 256 CUs at batch 64.
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_dma_grouped_kernel(const ConvArgs* __restrict__ args, int n, int total) {
+  int bid = blockIdx.x;
+  const int remap = args[0].remap;
+  if (remap) {
+    bid = xcd_tile_index(total);
+    if (bid < 0) return;
+  } else if (bid >= total) {
+    return;
+  }
+  int p = 0;
+  for (int i = 1; i < n; ++i)
+    if (bid >= args[i].blk0) p = i;
+  const ConvArgs a = args[p];
+  const int local = bid - a.blk0;
+  int bm, bn;
+  if (remap) {
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    bn = local % tiles_n;
+    bm = local / tiles_n;
+  } else {
+    bm = local % a.tiles_m;
+    bn = local / a.tiles_m;
+  }
+  if (a.Cin % 64 == 0)
+    conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, true>(a, bm, bn);
+  else
+    conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, false>(a, bm, bn);
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
+  constexpr int lds = NSTAGE * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_grouped_kernel<BM, BN, WM, WN, NSTAGE>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_dma_grouped_kernel<BM, BN, WM, WN, NSTAGE>), dim3((total_blocks + 7) / 8 * 8),
+                     dim3(256), lds, st, args_dev, n, total_blocks);
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
   static_assert(NSTAGE == 3 || NSTAGE == 4, "pipeline depth");
@@ -685,11 +768,18 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN));
+  ConvArgs b = a;
+  b.tiles_m = cdiv(a.M, BM);
+  const long total = (long)b.tiles_m * cdiv(a.Cout, BN);
+  if (total >= (1L << 31) - 8) {
+    comic_set_error("conv: too many tiles");
+    return 1;
+  }
+  dim3 grid((unsigned)((total + 7) / 8 * 8));
   if (a.Cin % 64 == 0)
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, st, b);
   else
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, st, b);
   return 0;
 }
 
@@ -713,6 +803,48 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
   }
+}
+
+// (BM, BN) of the explicit tile ids above
+constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 128, 64, 32, 64, 128};
+constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
+
+int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
+  switch (tile) {
+    case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
+    case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
+    case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
+    case 4: return launch_dma_grouped<32, 64, 1, 4, 3>(args_dev, n, total_blocks, st);
+    case 5: return launch_dma_grouped<128, 32, 4, 1, 3>(args_dev, n, total_blocks, st);
+    case 6: return launch_dma_grouped<64, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
+    case 7: return launch_dma_grouped<256, 64, 4, 1, 3>(args_dev, n, total_blocks, st);
+    case 8: return launch_dma_grouped<128, 64, 2, 2, 4>(args_dev, n, total_blocks, st);
+    case 9: return launch_dma_grouped<64, 64, 2, 2, 4>(args_dev, n, total_blocks, st);
+    case 10: return launch_dma_grouped<32, 64, 1, 4, 4>(args_dev, n, total_blocks, st);
+    case 11: return launch_dma_grouped<64, 128, 2, 2, 4>(args_dev, n, total_blocks, st);
+    case 12: return launch_dma_grouped<128, 32, 4, 1, 4>(args_dev, n, total_blocks, st);
+    default:
+      comic_set_error("conv: unknown tile id %d", tile);
+      return 2;
+  }
+}
+
+// Tile of a group: the explicit id of its first member, else the same fill rule as the
+// single-conv heuristic applied to the group's total tile count.
+int group_tile(const comic_cnn_op* ops, int n, int batch) {
+  if (ops[0].tile > 0 && ops[0].tile <= kNumConvTiles) return ops[0].tile;
+  bool all128 = true;
+  for (int i = 0; i < n; ++i) all128 = all128 && ops[i].Cout % 128 == 0;
+  auto blocks = [&](int t) {
+    long b = 0;
+    for (int i = 0; i < n; ++i)
+      b += (long)cdiv(batch * ops[i].Ho * ops[i].Wo, kTileBM[t]) * cdiv(ops[i].Cout, kTileBN[t]);
+    return b;
+  };
+  if (all128 && blocks(1) >= 512) return 1;
+  if (blocks(2) >= 512) return 2;
+  if (blocks(3) >= 384) return 3;
+  return 4;
 }
 
 int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
@@ -763,6 +895,15 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+int xcd_remap_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("COMIC_XCD_MAP");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels, void* y, int y_channels,
               const comic_conv_weight* wt, int batch) {
   a.x = x;
@@ -781,6 +922,9 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.relu = op->relu;
   a.out_f32 = op->out_f32;
   a.zero = zero_page_address();
+  a.blk0 = 0;
+  a.tiles_m = 0;
+  a.remap = xcd_remap_enabled();
   return 0;
 }
 
@@ -852,7 +996,66 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
   return 0;
 }
 
+int validate_grouped_conv(const comic_cnn_op* op, int xc, int yc, const comic_conv_weight* wt, int batch) {
+  COMIC_REQUIRE(op->kind == 0, "grouped launch: op kind %d is not a conv", op->kind);
+  COMIC_REQUIRE(wt && wt->w && wt->scale && wt->shift, "conv: missing weights");
+  COMIC_REQUIRE(op->Cin % 8 == 0 && op->src_coff % 8 == 0 && xc % 8 == 0, "conv: Cin/offset/stride must be multiples of 8");
+  COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0, "conv: Cout must be a multiple of 16 (got %d)",
+                op->Cout);
+  COMIC_REQUIRE(op->src_coff + op->Cin <= xc, "conv: source channel slice out of range");
+  COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
+  COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31) && (long)batch * op->Ho * op->Wo * yc < (1L << 31),
+                "conv: activation tensor too large");
+  return 0;
+}
+
+// length of the group run starting at ops[i] (1 when ungrouped)
+int group_run(const comic_cnn_op* ops, int n_ops, int i) {
+  if (ops[i].group <= 0) return 1;
+  int j = i + 1;
+  while (j < n_ops && ops[j].group == ops[i].group) ++j;
+  return j - i;
+}
+
 }  // namespace
+
+extern "C" long comic_cnn_group_args_bytes(const comic_cnn_op* ops, int n_ops) {
+  long n = 0;
+  for (int i = 0; i < n_ops; ++i) n += ops[i].group > 0;
+  return n * (long)sizeof(ConvArgs);
+}
+
+extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                                          const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
+                                          void* host_out) {
+  COMIC_REQUIRE(ops && buffers && buf_channels && weights && host_out, "comic_cnn_build_group_args: null argument");
+  ConvArgs* out = (ConvArgs*)host_out;
+  for (int i = 0; i < n_ops;) {
+    const int n = group_run(ops, n_ops, i);
+    if (ops[i].group <= 0) {
+      ++i;
+      continue;
+    }
+    const int tile = group_tile(ops + i, n, batch);
+    int blk = 0;
+    for (int j = 0; j < n; ++j) {
+      const comic_cnn_op* op = ops + i + j;
+      const comic_conv_weight* wt = weights + op->weight;
+      if (int rc = validate_grouped_conv(op, buf_channels[op->src], buf_channels[op->dst], wt, batch)) return rc;
+      COMIC_REQUIRE(buffers[op->src] && buffers[op->dst], "grouped conv: null buffer");
+      ConvArgs& a = out[j];
+      fill_args(a, op, buffers[op->src], buf_channels[op->src], buffers[op->dst], buf_channels[op->dst], wt, batch);
+      COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
+      a.blk0 = blk;
+      a.remap = 0;   // members differ in K: contiguous per-XCD ranges would put the heavy ones on few XCDs
+      a.tiles_m = cdiv(a.M, kTileBM[tile]);
+      blk += a.tiles_m * cdiv(a.Cout, kTileBN[tile]);
+    }
+    out += n;
+    i += n;
+  }
+  return 0;
+}
 
 extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x_channels, void* y, int y_channels,
                                     const comic_conv_weight* wt, int batch, int dtype, void* stream) {
@@ -893,9 +1096,11 @@ Lanes* get_lanes() {
 }
 }  // namespace
 
-extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,
-                                 const comic_conv_weight* weights, int batch, int dtype, void* stream) {
+static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,
+                            const comic_conv_weight* weights, int batch, int dtype, const void* group_args_dev,
+                            void* stream) {
   COMIC_REQUIRE(ops && buffers && buf_channels, "comic_cnn_forward: null table");
+  const ConvArgs* gargs = (const ConvArgs*)group_args_dev;
   hipStream_t main_st = (hipStream_t)stream;
   Lanes* lanes = nullptr;
   bool used[3] = {false, false, false};
@@ -920,6 +1125,21 @@ extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const
       }
       continue;
     }
+    if (gargs && op->group > 0) {
+      COMIC_REQUIRE(dtype == COMIC_BF16 && op->kind == 0 && op->lane == 0,
+                    "grouped launch needs a bf16 plan and conv ops on the caller's stream");
+      const int n = group_run(ops, n_ops, i);
+      const int tile = group_tile(op, n, batch);
+      long blocks = 0;
+      for (int j = 0; j < n; ++j)
+        blocks += (long)cdiv(batch * op[j].Ho * op[j].Wo, kTileBM[tile]) * cdiv(op[j].Cout, kTileBN[tile]);
+      COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
+      if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, main_st)) return rc;
+      COMIC_LAUNCH_CHECK("grouped conv");
+      gargs += n;
+      i += n - 1;
+      continue;
+    }
     hipStream_t st = main_st;
     if (op->lane > 0) {
       COMIC_REQUIRE(lanes && op->lane <= 3, "branch lane %d outside a fork/join region", op->lane);
@@ -932,6 +1152,19 @@ extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers, const int32_t* buf_channels,
+                                 const comic_conv_weight* weights, int batch, int dtype, void* stream) {
+  return cnn_forward_impl(ops, n_ops, buffers, buf_channels, weights, batch, dtype, nullptr, stream);
+}
+
+extern "C" int comic_cnn_forward_grouped(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                                         const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
+                                         int dtype, const void* group_args_dev, void* stream) {
+  COMIC_REQUIRE(group_args_dev || comic_cnn_group_args_bytes(ops, n_ops) == 0,
+                "comic_cnn_forward_grouped: plan has grouped ops but no argument records");
+  return cnn_forward_impl(ops, n_ops, buffers, buf_channels, weights, batch, dtype, group_args_dev, stream);
 }
 
 extern "C" int comic_pack_conv_weights(const float* w_hwio, void* w_packed, int kh, int kw, int cin, int cout,

@@ -85,7 +85,8 @@ def _out(size, k, s, pad):
 class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
-    def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False):
+    def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
+                 group_branches=True):
         if name != 'inception_v3':
             raise NotImplementedError('only inception_v3 is on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -96,6 +97,10 @@ class CnnPlan:
         self.macs = 0
         self._lane = 0
         self.branch_streams = branch_streams
+        # same-depth convs of the parallel branches share one launch (comic_cnn_forward_grouped)
+        self.group_branches = group_branches and not branch_streams
+        self._depth = 0
+        self._next_group = 1
         self._build_v3(image_size, final_endpoint)
 
     # -- builder helpers ---------------------------------------------------------------
@@ -114,7 +119,8 @@ class CnnPlan:
         self.weights.append((scope + '/' + name, kh, kw, Cin, cout, stem))
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
                              Cin=Cin, Cout=cout, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
-                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32), lane=self._lane))
+                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32), lane=self._lane,
+                             depth=self._depth))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
 
@@ -126,8 +132,25 @@ class CnnPlan:
             dst = self._buf(Ho, Wo, Cc)
         self.ops.append(dict(kind=kind, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc,
                              KH=k, KW=k, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=-1, relu=0,
-                             out_f32=0, lane=self._lane))
+                             out_f32=0, lane=self._lane, depth=self._depth))
         return dst, (Ho, Wo, Cc)
+
+    def _schedule_by_depth(self, first_op):
+        """Reorder one Inception block's ops depth-major (an op at depth d of a branch depends
+        only on the depth d-1 op of the same branch), pools first, and give the >=2 convs of
+        one depth a common group id, heaviest reduction first so the long workgroups start
+        early."""
+        block = self.ops[first_op:]
+        del self.ops[first_op:]
+        for d in sorted({o['depth'] for o in block}):
+            level = [o for o in block if o['depth'] == d]
+            self.ops += [o for o in level if o['kind'] != 0]
+            convs = sorted((o for o in level if o['kind'] == 0), key=lambda o: -(o['KH'] * o['KW'] * o['Cin']))
+            if len(convs) >= 2:
+                for o in convs:
+                    o['group'] = self._next_group
+                self._next_group += 1
+            self.ops += convs
 
     @staticmethod
     def _sync_op(kind):
@@ -169,13 +192,16 @@ class CnnPlan:
             last = bname == final_endpoint
             blk = self._buf(Ho, Wo, Ctot, f32=last)   # the attention feature map is handed over in fp32
             coff = 0
-            self.ops.append(self._sync_op(5))          # fork: the branches are independent
+            if self.branch_streams:
+                self.ops.append(self._sync_op(5))      # fork: the branches are independent
+            first_op = len(self.ops)
             for bi, branch in enumerate(branches):
                 scope = '%s/%s/Branch_%d' % (root, bname, bi)
                 self._lane = bi if self.branch_streams else 0   # branch 0 stays on the caller's stream
                 x = cur
                 for oi, op in enumerate(branch):
                     final = oi == len(branch) - 1
+                    self._depth = oi
                     if op[0] == 'c':
                         if final:
                             self._conv(x, scope, op, blk, coff, out_f32=last)
@@ -196,7 +222,11 @@ class CnnPlan:
                             o += sub[2]
                 coff += outs[bi][2]
             self._lane = 0
-            self.ops.append(self._sync_op(6))          # join
+            self._depth = 0
+            if self.group_branches:
+                self._schedule_by_depth(first_op)
+            if self.branch_streams:
+                self.ops.append(self._sync_op(6))      # join
             cur = blk
             self.end_points[bname] = cur
             if last:
@@ -281,12 +311,40 @@ class CnnEncoder:
         ops = (L.CnnOp * len(plan.ops))()
         for i, o in enumerate(plan.ops):
             for k, v in o.items():
-                setattr(ops[i], k, v)
+                if k != 'depth':
+                    setattr(ops[i], k, v)
+            if self.dcode != 1:
+                ops[i].group = 0               # the fp32 parity path launches every conv on its own
         self._ops = ops
+        self._group_args = None
+        self._build_group_args()
         self._graph = None
         self._calls = 0
 
+    def _build_group_args(self):
+        """(Re)build the device-resident argument records of the grouped launches; they embed
+        buffer addresses and the tile-dependent workgroup ranges, so this follows any change
+        of `tile` ids."""
+        torch = self.torch
+        n = self.lib.comic_cnn_group_args_bytes(self._ops, len(self.plan.ops))
+        if n == 0:
+            self._group_args = None
+            return
+        host = np.zeros(n, np.uint8)
+        L.check(self.lib.comic_cnn_build_group_args(self._ops, len(self.plan.ops), self._bufptr, self._bufch,
+                                                    self._wt, self.batch, host.ctypes.data), 'cnn_build_group_args')
+        if self._group_args is None or self._group_args.numel() != n:
+            self._group_args = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._group_args.copy_(torch.from_numpy(host))
+        torch.cuda.synchronize()
+
     def _run(self):
+        if self._group_args is not None:
+            L.check(self.lib.comic_cnn_forward_grouped(self._ops, len(self.plan.ops), self._bufptr, self._bufch,
+                                                       self._wt, self.batch, self.dcode,
+                                                       self._group_args.data_ptr(), L.stream_ptr()),
+                    'cnn_forward_grouped')
+            return
         L.check(self.lib.comic_cnn_forward(self._ops, len(self.plan.ops), self._bufptr, self._bufch, self._wt,
                                            self.batch, self.dcode, L.stream_ptr()), 'cnn_forward')
 
@@ -326,20 +384,46 @@ class CnnEncoder:
         st = L.stream_ptr()
         chosen = {}
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i, o in enumerate(self.plan.ops):
+        n_ops = len(self.plan.ops)
+        grouped = self._group_args is not None
+        rec_bytes = 0
+        if grouped:
+            n_rec = sum(1 for j in range(n_ops) if self._ops[j].group > 0)
+            rec_bytes = self.lib.comic_cnn_group_args_bytes(self._ops, n_ops) // n_rec
+        rec = 0
+        i = 0
+        while i < n_ops:
+            o = self.plan.ops[i]
             if o['kind'] != 0:
+                i += 1
                 continue
             op = self._ops[i]
-            src, dst = self.bufs[o['src']], self.bufs[o['dst']]
-            wt = self._wt[o['weight']]
-            best = (None, 0)
-            for tile in range(0, L.CONV_TILES + 1):
-                op.tile = tile
+            n = 1
+            if grouped and op.group > 0:
+                while i + n < n_ops and self._ops[i + n].group == op.group:
+                    n += 1
+                first = C.byref(self._ops, i * C.sizeof(L.CnnOp))
+                rec_off = rec * rec_bytes
+
+                def run():
+                    L.check(self.lib.comic_cnn_forward_grouped(first, n, self._bufptr, self._bufch, self._wt,
+                                                               self.batch, self.dcode,
+                                                               self._group_args.data_ptr() + rec_off, st),
+                            'grouped conv (autotune)')
+                rec += n
+            else:
+                src, dst = self.bufs[o['src']], self.bufs[o['dst']]
+                wt = self._wt[o['weight']]
 
                 def run():
                     L.check(self.lib.comic_conv2d_bn_relu(C.byref(op), src.data_ptr(), src.shape[3], dst.data_ptr(),
                                                           dst.shape[3], C.byref(wt), self.batch, self.dcode, st),
                             'conv (autotune)')
+            best = (None, 0)
+            for tile in range(0, L.CONV_TILES + 1):
+                op.tile = tile
+                if n > 1:
+                    self._build_group_args()
                 run(); run()
                 ev0.record()
                 for _ in range(reps):
@@ -352,8 +436,11 @@ class CnnEncoder:
             op.tile = best[1]
             chosen[i] = best
             if verbose:
-                print('autotune op %3d %3dx%-3d Cin%4d Cout%4d %dx%d -> tile %2d  %.1f us' % (
-                    i, o['Ho'], o['Wo'], o['Cin'], o['Cout'], o['KH'], o['KW'], best[1], best[0] * 1e3))
+                print('autotune op %3d x%d %3dx%-3d Cin%4d Cout%4d %dx%d -> tile %2d  %.1f us' % (
+                    i, n, o['Ho'], o['Wo'], o['Cin'], o['Cout'], o['KH'], o['KW'], best[1], best[0] * 1e3))
+            i += n
+        if grouped:
+            self._build_group_args()
         self._graph = None        # a captured graph holds the old variants
         self._calls = 0
         return chosen

@@ -72,6 +72,10 @@ typedef struct comic_cnn_op {
                         Inception branches run concurrently between a fork and a join) */
   int32_t tile;      /* conv: 0 = built-in heuristic, 1..COMIC_CONV_TILES = explicit tile /
                         pipeline-depth variant (chosen by the host-side autotuner) */
+  int32_t group;     /* conv, bf16 plans: 0 = own launch; ops that are ADJACENT in the table and
+                        share a non-zero id are mutually independent (the same-depth convs of
+                        the parallel Inception branches) and comic_cnn_forward_grouped runs
+                        them as one launch */
 } comic_cnn_op;
 
 typedef struct comic_conv_weight {
@@ -86,6 +90,23 @@ typedef struct comic_conv_weight {
 int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
                       int dtype, void* stream);
+
+/* Grouped execution of the same plan (bf16 plans): every run of ops with the same non-zero
+ * `group` becomes ONE launch whose workgroups are spread over all member convolutions (a
+ * 12x12 or 5x5 Inception stage has too few tiles per conv to fill 256 CUs at batch 64).
+ * The per-conv argument records are built once on the host and kept in device memory:
+ *   n = comic_cnn_group_args_bytes(ops, n_ops)            bytes of records the plan needs
+ *   comic_cnn_build_group_args(..., host_out)             fills `n` bytes (validates the ops)
+ *   <caller copies host_out to device memory: group_args_dev>
+ *   comic_cnn_forward_grouped(..., group_args_dev, stream)
+ * Results are bit-identical to comic_cnn_forward (same kernels body, same k order). */
+long comic_cnn_group_args_bytes(const comic_cnn_op* ops, int n_ops);
+int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                               const int32_t* buf_channels, const comic_conv_weight* weights,
+                               int batch, void* host_out);
+int comic_cnn_forward_grouped(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                              const int32_t* buf_channels, const comic_conv_weight* weights,
+                              int batch, int dtype, const void* group_args_dev, void* stream);
 
 /* Single conv + folded BN + ReLU (slim.conv2d under inception_arg_scope). */
 int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x_channels, void* y,

@@ -62,6 +62,28 @@ def test_cnn_batch_independence_full_batch():
     assert torch.isfinite(fm1).all()
 
 
+def test_grouped_branch_launch_is_bit_identical():
+    """comic_cnn_forward_grouped (one launch per depth of an Inception block) against the
+    op-by-op executor: every end point bit-identical, at a ragged batch (tile tails) and
+    with autotuned tiles."""
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=2)
+    x = np.random.default_rng(7).uniform(-1, 1, (5, 224, 224, 3)).astype(np.float32)
+    single = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224), group_branches=False), params, 5, 'bf16', DEV)
+    grouped = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224), group_branches=True), params, 5, 'bf16', DEV)
+    assert grouped._group_args is not None and single._group_args is None
+    im0, fm0 = (t.clone() for t in single.forward(dev(x)))
+    for tuned in (False, True):
+        if tuned:
+            grouped.autotune(reps=2)
+        im1, fm1 = grouped.forward(dev(x))
+        for name in single.plan.end_points:
+            assert torch.equal(single.end_point(name), grouped.end_point(name)), name
+        assert torch.equal(fm0, fm1) and torch.equal(im0, im1)
+        im2, fm2 = grouped.forward(dev(x), use_graph=True)      # second call captures, third replays
+        im2, fm2 = grouped.forward(dev(x), use_graph=True)
+        assert torch.equal(fm0, fm2) and torch.equal(im0, im2)
+
+
 # ----------------------------------------------------------------------------- decoder ----
 def _spec_and_cfg(**kw):
     base = dict(D=128, E=64, V=258, C=192, Cg=192, H=8, M=25)
