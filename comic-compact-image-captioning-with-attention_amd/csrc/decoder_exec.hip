@@ -12,6 +12,7 @@
 // (embedding lookup for all steps, output projection + cross-entropy as one batched GEMM,
 // all weight-gradient GEMMs batched over time), states are kept per step for the backward
 // pass instead of TF's TensorArray stack, and dropout masks are explicit inputs.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -44,7 +45,34 @@ int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
                             const float* bias, hipStream_t st);
 
+// decoder_fused.hip
+int comic_fused_step_supported(int D, int Wd);
+long comic_lstm_panel_floats(int D, int Wd, int mode);
+int comic_pack_lstm_panels(const float* K, float* fwd_panel, float* bwd_panel, int D, int Wd, hipStream_t st);
+int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const float* bias, const float* c_prev,
+                          const float* h_prev, float* gates_act, float* c_new, float* y, const float* mask_out,
+                          float keep_out, const int32_t* lens, int t, float* c_state, float* h_state, float* xh_next,
+                          int xh_ld, int B, int D, int Wd, hipStream_t st);
+int comic_pack_wq_panel(const float* Wq, float* panel, int D, hipStream_t st);
+int comic_lstm_grad_fused(const float* dq, const float* wq_panel, const float* gates_act, const float* c_prev,
+                          const float* c_new, const float* dy, const float* mask_out, float keep_out,
+                          const int32_t* lens, int t, float* dc_state, float* dh_state, float* dg, int B, int D,
+                          hipStream_t st);
+int comic_input_grad_fused(const float* dg, const float* K, const float* mask, float keep, float* demb, float* datt,
+                           float* dh, const int32_t* lens, int t, int carry, int B, int E, int A, int D,
+                           hipStream_t st);
+
 namespace {
+
+// COMIC_FUSED_STEP=0 keeps the split-K GEMM + element-wise kernel chain (A/B switch for profiling)
+bool fused_step_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("COMIC_FUSED_STEP");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
 
 #define RC(x)               \
   do {                      \
@@ -403,6 +431,9 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(B * (3 * D + 1)); w.take<float>(TB * M);                       // pgrad, dmap
   w.take<float>(B * (E + A));                                                  // dx_init
   w.take<char>(kSplitKBytes);                                                  // split-K partials
+  w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
+  w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
+  w.take<float>(D * D);                                                        // W_q panel
   return (int64_t)w.off;
 }
 
@@ -465,10 +496,17 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dmap = w.take<float>(TB * M);
   float* dx_init = w.take<float>((long)B * EA);
   g_splitk_ws = w.take<char>(kSplitKBytes);
+  float* kpanel_f = w.take<float>(comic_lstm_panel_floats(D, Wd, 0));
+  float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
+  float* wq_panel = w.take<float>((long)D * D);
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
 
   const comic_attn_desc ad = attn_desc(d, B);
   const float* values = nullptr;
+  const bool fused = fused_step_enabled() && comic_fused_step_supported(D, Wd);
+  const bool fused_q = fused && D % 16 == 0;
+  if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, kpanel_b, D, Wd, st));
+  if (fused_q) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
   // ------------------------------------------------------------------ forward ------------
   RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
   RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, st));
@@ -498,12 +536,20 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     const float* mask_n = (drop_in && xh_n) ? mask_in + (size_t)(t + 1) * B * EA + E : nullptr;
     int S1 = 1, S2 = 1;
     float* part = (float*)g_splitk_ws;
-    RC(comic_gemm_f32_partial(xh_t, p->K, B, 4 * D, Wd, Wd, 4 * D, 0, part, kSplitKBytes, &S1, st));
     float* y_t = y_all + (size_t)t * B * D;
-    RC(comic_lstm_gates_fwd_ex(part, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
+    if (fused) {
+      RC(comic_lstm_step_fused(xh_t, Wd, kpanel_f, p->b, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
                                cnew_all + (size_t)t * B * D, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
-                               d->keep_out, lens, t, cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D,
-                               xh_n ? xh_n + EA : nullptr, Wd, S1, p->b, st));
+                               d->keep_out, lens, t, cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D,
+                               xh_n ? xh_n + EA : nullptr, Wd, B, D, Wd, st));
+    } else {
+      RC(comic_gemm_f32_partial(xh_t, p->K, B, 4 * D, Wd, Wd, 4 * D, 0, part, kSplitKBytes, &S1, st));
+      RC(comic_lstm_gates_fwd_ex(part, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
+                                 cnew_all + (size_t)t * B * D, y_t,
+                                 drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t,
+                                 cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D,
+                                 xh_n ? xh_n + EA : nullptr, Wd, S1, p->b, st));
+    }
     float* q_t = q_all + (size_t)t * B * D;
     RC(comic_gemm_f32_partial(y_t, p->W_q, B, D, D, D, D, 0, part, kSplitKBytes, &S2, st));
     float* ctx_t = ctx_all + (size_t)t * B * Cv;
@@ -583,17 +629,28 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     float* dy_t = dy_all + (size_t)t * B * D;
     float* part = (float*)g_splitk_ws;
     int S3 = 1, S4 = 1;
-    RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
     float* dg_t = dg_all + (size_t)t * B * 4 * D;
-    RC(comic_lstm_gates_bwd_ex(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
-                               cnew_all + (size_t)t * B * D, dy_t, part, S3,
-                               drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh, dg_t,
-                               B, D, st));
-    RC(comic_gemm_f32_partial(dg_t, p->K, B, Wd, 4 * D, 4 * D, 4 * D, 1, part, kSplitKBytes, &S4, st));
-    hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, part,
-                       drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E, datt,
-                       dh, lens, t, carry, B, E, A, D, S4);
-    COMIC_LAUNCH_CHECK("input_bwd");
+    if (fused_q) {
+      RC(comic_lstm_grad_fused(dq_t, wq_panel, gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
+                               cnew_all + (size_t)t * B * D, dy_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
+                               d->keep_out, lens, t, dc, dh, dg_t, B, D, st));
+    } else {
+      RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
+      RC(comic_lstm_gates_bwd_ex(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
+                                 cnew_all + (size_t)t * B * D, dy_t, part, S3,
+                                 drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh,
+                                 dg_t, B, D, st));
+    }
+    if (fused) {
+      RC(comic_input_grad_fused(dg_t, kpanel_b, drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in,
+                                demb + (size_t)t * B * E, datt, dh, lens, t, carry, B, E, A, D, st));
+    } else {
+      RC(comic_gemm_f32_partial(dg_t, p->K, B, Wd, 4 * D, 4 * D, 4 * D, 1, part, kSplitKBytes, &S4, st));
+      hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, part,
+                         drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E,
+                         datt, dh, lens, t, carry, B, E, A, D, S4);
+      COMIC_LAUNCH_CHECK("input_bwd");
+    }
   }
   // time-batched weight gradients
   RC(gemm(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
