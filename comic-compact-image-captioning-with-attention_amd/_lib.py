@@ -41,6 +41,10 @@ class DecoderParams(C.Structure):
     _fields_ = [(n, c_void_p) for n in PARAM_NAMES]
 
 
+class ConvGrad(C.Structure):         # struct comic_conv_grad
+    _fields_ = [('w_master', c_void_p), ('dw', c_void_p), ('dbeta', c_void_p), ('w_bwd', c_void_p)]
+
+
 P = c_void_p
 _SIGS = {
     'comic_last_error': (c_char_p, []),
@@ -52,6 +56,9 @@ _SIGS = {
     'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
     'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
     'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),
+    'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int]),
+    'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, P, c_int64, P]),
+    'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
     'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
     'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_float, P]),

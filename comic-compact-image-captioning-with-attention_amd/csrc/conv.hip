@@ -34,6 +34,7 @@ struct ConvArgs {
   const void* zero;  // 16 zero bytes in device memory (source of padding / out-of-range DMA lanes)
   int blk0, tiles_m; // grouped launch: first flat workgroup id of this problem, its pixel-tile count
   int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index)
+  int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
 };
 
 template <typename T>
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int i = 0; i < TN; ++i) {
     const int n0 = bn0 + wn * (BN / WN) + i * 16 + nq;
     if (n0 >= a.Cout) continue;
-    const float4 sc = *(const float4*)(a.scale + n0);
-    const float4 sh = *(const float4*)(a.shift + n0);
+    const float4 sc = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = bm0 + wm * (BM / WM) + j * 16 + mcol;
@@ -227,9 +228,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
       const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
       if (sizeof(T) == 4 || a.out_f32) {
-        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+        float4* yp = (float4*)((float*)a.y + off);
+        if (a.accum) {
+          const float4 o = *yp;
+          v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+        }
+        *yp = make_float4(v0, v1, v2, v3);
       } else {
-        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        uint2* yp = (uint2*)((bf16_t*)a.y + off);
+        if (a.accum) {
+          const uint2 o = *yp;
+          v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xFFFF0000u);
+          v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xFFFF0000u);
+        }
+        *yp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     }
   }
@@ -646,8 +658,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   for (int i = 0; i < TN; ++i) {
     const int n0 = bn0 + wn * (BN / WN) + i * 16 + nq;
     if (n0 >= a.Cout) continue;
-    const float4 sc = *(const float4*)(a.scale + n0);
-    const float4 sh = *(const float4*)(a.shift + n0);
+    const float4 sc = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = bm0 + wm * (BM / WM) + j * 16 + mcol;
@@ -664,9 +676,20 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
       }
       const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
       if (a.out_f32) {
-        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+        float4* yp = (float4*)((float*)a.y + off);
+        if (a.accum) {
+          const float4 o = *yp;
+          v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+        }
+        *yp = make_float4(v0, v1, v2, v3);
       } else {
-        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        uint2* yp = (uint2*)((bf16_t*)a.y + off);
+        if (a.accum) {
+          const uint2 o = *yp;
+          v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xFFFF0000u);
+          v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xFFFF0000u);
+        }
+        *yp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     }
   }
@@ -924,23 +947,25 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.zero = zero_page_address();
   a.blk0 = 0;
   a.tiles_m = 0;
+  a.accum = 0;
   a.remap = xcd_remap_enabled();
   return 0;
 }
 
 template <typename T>
 int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const comic_conv_weight* wt, int batch,
-           hipStream_t st) {
+           hipStream_t st, int accum = 0) {
   constexpr int EPC = Elem<T>::EPC;
   ConvArgs a;
   fill_args(a, op, x, xc, y, yc, wt, batch);
+  a.accum = accum;
   COMIC_REQUIRE(x && y, "cnn op %d: null buffer", op->kind);
   COMIC_REQUIRE((long)batch * op->H * op->W * xc < (1L << 31) && (long)a.M * yc < (1L << 31),
                 "cnn op: tensor exceeds 2^31 elements");
   COMIC_REQUIRE(op->src_coff + op->Cin <= xc, "cnn op: source channel slice out of range");
   switch (op->kind) {
     case 0: {
-      COMIC_REQUIRE(wt && wt->w && wt->scale && wt->shift, "conv: missing weights");
+      COMIC_REQUIRE(wt && wt->w && (accum || (wt->scale && wt->shift)), "conv: missing weights");
       COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0,
                     "conv: Cin/offset/stride must be multiples of %d", EPC);
       COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
@@ -1187,5 +1212,544 @@ extern "C" int comic_fold_bn(const float* beta, const float* mean, const float* 
   hipLaunchKernelGGL(fold_bn_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, beta, mean, var, eps,
                      scale, shift, c);
   COMIC_LAUNCH_CHECK("fold_bn");
+  return 0;
+}
+
+
+// =================================================================================================
+// Backward of the plan (train_mode cnn_finetune, src/train.py:241-249): freeze_scopes == '' puts the
+// conv weights and BN betas into the trainable set (src/model_base.py:834-849) while the graph stays
+// in BN-inference mode (model_base.py:76), so per conv
+//     z = conv(x, w) * scale + (beta - mean * scale),  y = relu(z)
+//     dz = 1[y > 0] * dy ;  d beta = sum_pixels dz ;  d conv = dz * scale
+//     d w = x^T (*) d conv (backward-weight) ;  d x += w^T (*) d conv (backward-data)
+// Backward-data runs the FORWARD kernels on `d conv` with the flipped / transposed filter
+// (stride-2 convs: `d conv` is written zero-dilated), accumulating into the gradient buffer.
+// Backward-weight is an implicit GEMM whose reduction runs over output pixels; operand tiles are
+// transposed on their way into LDS so the MFMA fragments are the same 16-byte row reads as in the
+// forward kernel; pixel ranges are split over workgroups and combined with fp32 atomics.
+// =================================================================================================
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void load_chunk_f(const void* base, size_t elem_off, bool f32, float* v) {
+  constexpr int EPC = Elem<T>::EPC;
+  if (sizeof(T) == 4 || f32) {
+    const float* p = (const float*)base + elem_off;
+#pragma unroll
+    for (int i = 0; i < EPC; i += 4) {
+      const float4 t = *(const float4*)(p + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else {
+    load_vec<T>((const T*)base + elem_off, v);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_chunk_f(void* base, size_t elem_off, bool f32, const float* v) {
+  constexpr int EPC = Elem<T>::EPC;
+  if (sizeof(T) == 4 || f32) {
+    float* p = (float*)base + elem_off;
+#pragma unroll
+    for (int i = 0; i < EPC; i += 4) *(float4*)(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else {
+    store_vec<T>((T*)base + elem_off, v);
+  }
+}
+
+struct ActGradArgs {
+  const void* y;    // forward output (post-ReLU), channel slice [yco, yco + C) of rows of ycs channels
+  const void* dy;   // its gradient, same geometry
+  int ycs, yco, yf32;
+  const float* scale;
+  void* dz;         // [B][Hd][Wd][C] plan dtype; output pixel (ho, wo) lands at (ho*dil, wo*dil)
+  int B, Ho, Wo, C, Hd, Wd, dil;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_grad_kernel(ActGradArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cvecs = a.C / EPC;
+  const long total = (long)a.B * a.Ho * a.Wo * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  long p = idx / cvecs;
+  const int wo = (int)(p % a.Wo);
+  const long q = p / a.Wo;
+  const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
+  float yv[EPC], gv[EPC];
+  const size_t src = (size_t)p * a.ycs + a.yco + cv * EPC;
+  load_chunk_f<T>(a.y, src, a.yf32 != 0, yv);
+  load_chunk_f<T>(a.dy, src, a.yf32 != 0, gv);
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) gv[i] = yv[i] > 0.f ? gv[i] * a.scale[cv * EPC + i] : 0.f;
+  const size_t dst = (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.C + cv * EPC;
+  store_chunk_f<T>(a.dz, dst, false, gv);
+}
+
+// column sums of dz [rows][C] (plan dtype) -> partial[R][C] fp32, then d beta[c] = sum / scale[c]
+template <typename T>
+__global__ void dz_colsum_part_kernel(const T* __restrict__ dz, float* __restrict__ part, long rows, int C,
+                                      long rows_per_chunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    if (sizeof(T) == 4)
+      s += ((const float*)dz)[(size_t)r * C + c];
+    else
+      s += bf16_to_f32(((const bf16_t*)dz)[(size_t)r * C + c]);
+  }
+  part[(size_t)blockIdx.y * C + c] = s;
+}
+__global__ void dbeta_final_kernel(const float* __restrict__ part, const float* __restrict__ scale,
+                                   float* __restrict__ dbeta, int R, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += part[(size_t)r * C + c];
+  dbeta[c] += s / scale[c];
+}
+
+// master [Cout][Kpad] (k = (kh*KW + kw)*Cin + ci) -> backward-data filter [Cin][Kpad2],
+// k2 = ((KH-1-kh)*KW + (KW-1-kw))*Cout + co
+template <typename T>
+__global__ void pack_bwd_weights_kernel(const float* __restrict__ master, T* __restrict__ out, int KH, int KW, int Cin,
+                                        int Cout, int Kpad, int Kpad2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cin * Kpad2) return;
+  const int k2 = (int)(idx % Kpad2), ci = (int)(idx / Kpad2);
+  float v = 0.f;
+  if (k2 < KH * KW * Cout) {
+    const int tap2 = k2 / Cout, co = k2 % Cout;
+    const int kh = KH - 1 - tap2 / KW, kw = KW - 1 - tap2 % KW;
+    v = master[(size_t)co * Kpad + (kh * KW + kw) * Cin + ci];
+  }
+  if (sizeof(T) == 4)
+    ((float*)out)[idx] = v;
+  else
+    ((bf16_t*)out)[idx] = f32_to_bf16(v);
+}
+
+struct WgradArgs {
+  const void* dz;   // [B][Hd][Wd][Cout] plan dtype
+  int Hd, Wd, dil;
+  const void* x;    // forward input (plan dtype; STEM: fp32 image)
+  int x_cs, x_co;
+  float* dw;        // [Cout][Kpad] fp32 (STEM: [K][Cout]), accumulated with atomics
+  int B, H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo, K, Kpad;
+  long P, p_per_split;
+};
+
+// grid (Kpad/64, ceil(Cout/64), splits): D[co][kk] += sum_{p in slice} dz[p][co] * xcol[p][kk]
+template <typename T, bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int BKE = 4 * EPC;          // pixels per k-step (64 bytes of k per LDS row)
+  constexpr int CPP = 64 / EPC;         // 16-byte chunks per pixel in a 64-channel tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 64 * kRowBytes];
+  unsigned char* Zs = smem;                        // [2][64 co][kRowBytes]
+  unsigned char* Xs = smem + 2 * 64 * kRowBytes;   // [2][64 kk][kRowBytes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kk0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const long p_begin = (long)blockIdx.z * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
+  const int px_l = tid / CPP, cg = tid % CPP;
+  // this thread's fixed channel chunk of each tile
+  const int co_c = co0 + cg * EPC;
+  const bool co_ok = co_c < a.Cout;           // Cout % EPC == 0
+  const int kk_c = kk0 + cg * EPC;
+  int kh = 0, kw = 0, ci = 0;
+  bool kk_ok = kk_c < a.K;
+  if (!STEM) {
+    if (kk_ok) {
+      const int tap = kk_c / a.Cin;
+      ci = kk_c % a.Cin;
+      kh = tap / a.KW;
+      kw = tap % a.KW;
+    }
+  }
+  const int hw = a.Ho * a.Wo;
+  uint4 zreg, xreg;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto load_tile = [&](long pbase) {
+    const long p = pbase + px_l;
+    zreg = xreg = zero4;
+    if (p >= p_end) return;
+    const int b = (int)(p / hw);
+    const int rem = (int)(p - (long)b * hw);
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    if (co_ok)
+      zreg = *(const uint4*)((const T*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.Cout + co_c);
+    if (STEM) {
+      float v[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int kk = kk_c + e;
+        v[e] = 0.f;
+        if (kk < a.K) {
+          const int tap = kk / a.Cin, c = kk - tap * a.Cin;
+          const int hi = ho * a.SH - a.PT + tap / a.KW, wi = wo * a.SW - a.PL + tap % a.KW;
+          if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+            v[e] = ((const float*)a.x)[((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + c];
+        }
+      }
+      if (sizeof(T) == 4) {
+        xreg = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+      } else {
+        xreg = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4 % EPC], v[5 % EPC]),
+                          pack_bf16x2(v[6 % EPC], v[7 % EPC]));
+      }
+    } else if (kk_ok) {
+      const int hi = ho * a.SH - a.PT + kh, wi = wo * a.SW - a.PL + kw;
+      if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+        xreg = *(const uint4*)((const T*)a.x + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + ci);
+    }
+  };
+  // transposed store: element e of the chunk goes to row (cg*EPC + e), k position px_l
+  auto store_tile = [&](int buf) {
+    unsigned char* zb = Zs + buf * 64 * kRowBytes;
+    unsigned char* xb = Xs + buf * 64 * kRowBytes;
+    if (sizeof(T) == 4) {
+      const uint32_t zu[4] = {zreg.x, zreg.y, zreg.z, zreg.w}, xu[4] = {xreg.x, xreg.y, xreg.z, xreg.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *(uint32_t*)(zb + (cg * 4 + e) * kRowBytes + px_l * 4) = zu[e];
+        *(uint32_t*)(xb + (cg * 4 + e) * kRowBytes + px_l * 4) = xu[e];
+      }
+    } else {
+      const uint32_t zu[4] = {zreg.x, zreg.y, zreg.z, zreg.w}, xu[4] = {xreg.x, xreg.y, xreg.z, xreg.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint16_t zv = (uint16_t)(e & 1 ? zu[e >> 1] >> 16 : zu[e >> 1] & 0xFFFFu);
+        const uint16_t xv = (uint16_t)(e & 1 ? xu[e >> 1] >> 16 : xu[e >> 1] & 0xFFFFu);
+        *(uint16_t*)(zb + (cg * 8 + e) * kRowBytes + px_l * 2) = zv;
+        *(uint16_t*)(xb + (cg * 8 + e) * kRowBytes + px_l * 2) = xv;
+      }
+    }
+  };
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fchunk = lane >> 4;
+  const int zoff = (wn * 32 + frow) * kRowBytes + fchunk * 16;
+  const int xoff = (wm * 32 + frow) * kRowBytes + fchunk * 16;
+
+  if (p_begin < p_end) {
+    load_tile(p_begin);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (long pb = p_begin; pb < p_end; pb += BKE, buf ^= 1) {
+      const bool more = pb + BKE < p_end;
+      if (more) load_tile(pb + BKE);
+      uint4 zf[2], xf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) zf[i] = *(const uint4*)(Zs + buf * 64 * kRowBytes + zoff + i * 16 * kRowBytes);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xf[j] = *(const uint4*)(Xs + buf * 64 * kRowBytes + xoff + j * 16 * kRowBytes);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf[i]),
+                                                                __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+          } else {
+            const f32x4_t zv = __builtin_bit_cast(f32x4_t, zf[i]);
+            const f32x4_t xv = __builtin_bit_cast(f32x4_t, xf[j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[0], xv[0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[1], xv[1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[2], xv[2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[3], xv[3], acc[i][j], 0, 0, 0);
+          }
+        }
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // D[co][kk]: lane holds co = .. + 4*(lane>>4) + reg, kk = .. + (lane & 15)
+  const int kcol = lane & 15, cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kk = kk0 + wm * 32 + j * 16 + kcol;
+      if (kk >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wn * 32 + i * 16 + cq + r;
+        if (co >= a.Cout) continue;
+        float* dst = STEM ? a.dw + (size_t)kk * a.Cout + co : a.dw + (size_t)co * a.Kpad + kk;
+        atomicAdd(dst, acc[i][j][r]);
+      }
+    }
+}
+
+struct PoolGradArgs {
+  const void* x;    // forward input of the pool (max only)
+  const void* dy;   // gradient of the pool output, slice [yco, yco + C) of ycs
+  void* dx;         // gradient of the pool input, slice [xco, xco + C) of xcs  (accumulated)
+  int xcs, xco, ycs, yco, dy_f32, dx_f32;
+  int B, H, W, C, KH, KW, SH, SW, PT, PL, Ho, Wo;
+};
+
+// MODE 0 max (first maximum in window scan order), 1 avg over valid taps, 2 plain mean over the
+// KHxKW VALID window (the head's global pool).  Gather form: one thread per input pixel x chunk.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cvecs = a.C / EPC;
+  const long total = (long)a.B * a.H * a.W * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  const long p = idx / cvecs;
+  const int wi = (int)(p % a.W);
+  const long q = p / a.W;
+  const int hi = (int)(q % a.H), b = (int)(q / a.H);
+  float g[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) g[j] = 0.f;
+  // windows (ho, wo) that contain (hi, wi): ho*SH - PT <= hi < ho*SH - PT + KH
+  const int ho_lo = max(0, (hi + a.PT - a.KH + a.SH) / a.SH), ho_hi = min(a.Ho - 1, (hi + a.PT) / a.SH);
+  const int wo_lo = max(0, (wi + a.PL - a.KW + a.SW) / a.SW), wo_hi = min(a.Wo - 1, (wi + a.PL) / a.SW);
+  for (int ho = ho_lo; ho <= ho_hi; ++ho)
+    for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+      float dyv[EPC];
+      load_chunk_f<T>(a.dy, ((size_t)(b * a.Ho + ho) * a.Wo + wo) * a.ycs + a.yco + cv * EPC, a.dy_f32 != 0, dyv);
+      if (MODE == 0) {
+        float best[EPC];
+        int arg[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { best[j] = -INFINITY; arg[j] = -1; }
+        for (int kh = 0; kh < a.KH; ++kh) {
+          const int h2 = ho * a.SH - a.PT + kh;
+          if ((unsigned)h2 >= (unsigned)a.H) continue;
+          for (int kw = 0; kw < a.KW; ++kw) {
+            const int w2 = wo * a.SW - a.PL + kw;
+            if ((unsigned)w2 >= (unsigned)a.W) continue;
+            float v[EPC];
+            load_vec<T>((const T*)a.x + ((size_t)(b * a.H + h2) * a.W + w2) * a.xcs + a.xco + cv * EPC, v);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j)
+              if (v[j] > best[j]) { best[j] = v[j]; arg[j] = h2 * a.W + w2; }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < EPC; ++j)
+          if (arg[j] == hi * a.W + wi) g[j] += dyv[j];
+      } else if (MODE == 1) {
+        const int h0 = max(0, ho * a.SH - a.PT), h1 = min(a.H, ho * a.SH - a.PT + a.KH);
+        const int w0 = max(0, wo * a.SW - a.PL), w1 = min(a.W, wo * a.SW - a.PL + a.KW);
+        const float inv = 1.0f / (float)((h1 - h0) * (w1 - w0));
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) g[j] += dyv[j] * inv;
+      } else {
+        const float inv = 1.0f / (float)(a.KH * a.KW);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) g[j] += dyv[j] * inv;
+      }
+    }
+  const size_t off = (size_t)p * a.xcs + a.xco + cv * EPC;
+  float old[EPC];
+  load_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) old[j] += g[j];
+  store_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
+}
+
+template <typename T>
+int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
+                  const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
+                  int64_t scratch_bytes, hipStream_t st) {
+  constexpr int EPC = Elem<T>::EPC;
+  const bool stem = op->kind == 1;
+  COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
+  COMIC_REQUIRE(op->Cout % EPC == 0 && op->dst_coff % EPC == 0 && yc % EPC == 0, "conv backward: misaligned output slice");
+  COMIC_REQUIRE(op->SH == op->SW && (op->SH == 1 || op->SH == 2), "conv backward: stride must be 1 or 2");
+  const int K = op->KH * op->KW * op->Cin, Kpad = (K + 63) / 64 * 64;
+  const int dil = op->SH;
+  // zero-dilated d conv geometry: H + KH - 1 - 2*PT' with PT' = KH - 1 - PT  (see the section header)
+  const int Hd = dil == 1 ? op->Ho : op->H - op->KH + 1 + 2 * op->PT;
+  const int Wd = dil == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
+  COMIC_REQUIRE(Hd >= (op->Ho - 1) * dil + 1 && Wd >= (op->Wo - 1) * dil + 1, "conv backward: dilated geometry");
+  const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
+  const int R = 128;
+  const size_t part_bytes = (size_t)R * op->Cout * sizeof(float);
+  COMIC_REQUIRE((int64_t)(dz_bytes + part_bytes) <= scratch_bytes, "conv backward: scratch too small (%zu needed)",
+                dz_bytes + part_bytes);
+  T* dz = (T*)scratch;
+  float* part = (float*)((char*)scratch + dz_bytes);
+  if (dil > 1) {
+    COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward: memset failed");
+  }
+  {
+    ActGradArgs a{y, gy, yc, op->dst_coff, op->out_f32, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
+    const long total = (long)batch * op->Ho * op->Wo * (op->Cout / EPC);
+    hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+  }
+  {
+    const long rows = (long)batch * Hd * Wd;
+    const long rpc = cdiv64(rows, R);
+    const int Ract = (int)cdiv64(rows, rpc);
+    hipLaunchKernelGGL((dz_colsum_part_kernel<T>), dim3(cdiv(op->Cout, 64), Ract), dim3(64), 0, st, (const T*)dz, part,
+                       rows, op->Cout, rpc);
+    hipLaunchKernelGGL(dbeta_final_kernel, dim3(cdiv(op->Cout, 64)), dim3(64), 0, st, (const float*)part, wt->scale,
+                       gr->dbeta, Ract, op->Cout);
+  }
+  {
+    WgradArgs a{};
+    a.dz = dz; a.Hd = Hd; a.Wd = Wd; a.dil = dil; a.x = x; a.x_cs = xc; a.x_co = op->src_coff; a.dw = gr->dw;
+    a.B = batch; a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout; a.KH = op->KH; a.KW = op->KW;
+    a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL; a.Ho = op->Ho; a.Wo = op->Wo; a.K = K; a.Kpad = Kpad;
+    a.P = (long)batch * op->Ho * op->Wo;
+    constexpr int BKE = 4 * EPC;
+    const int tiles = cdiv(K, 64) * cdiv(op->Cout, 64);
+    long S = std::max<long>(1, std::min<long>(2048 / tiles, cdiv64(a.P, (long)BKE * 8)));
+    a.p_per_split = cdiv64(cdiv64(a.P, S), BKE) * BKE;
+    S = cdiv64(a.P, a.p_per_split);
+    dim3 grid(cdiv(K, 64), cdiv(op->Cout, 64), (unsigned)S);
+    if (stem) {
+      COMIC_REQUIRE(op->Cin <= 4, "stem conv backward: needs Cin <= 4");
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, true>), grid, dim3(256), 0, st, a);
+    } else {
+      COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0, "conv backward: misaligned input slice");
+      hipLaunchKernelGGL((conv_wgrad_kernel<T, false>), grid, dim3(256), 0, st, a);
+    }
+  }
+  COMIC_LAUNCH_CHECK("conv backward (weights)");
+  if (stem || !gx) return 0;
+  // backward-data: forward conv of dz with the flipped / transposed filter, accumulated into gx
+  COMIC_REQUIRE(gr->w_bwd, "conv backward: missing backward-data filter buffer");
+  const int K2 = op->KH * op->KW * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
+  {
+    const long n = (long)op->Cin * Kpad2;
+    hipLaunchKernelGGL((pack_bwd_weights_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, gr->w_master,
+                       (T*)gr->w_bwd, op->KH, op->KW, op->Cin, op->Cout, Kpad, Kpad2);
+  }
+  comic_cnn_op t = *op;
+  t.kind = 0;
+  t.H = Hd; t.W = Wd; t.Cin = op->Cout; t.Cout = op->Cin; t.SH = t.SW = 1;
+  t.PT = op->KH - 1 - op->PT; t.PL = op->KW - 1 - op->PL;
+  t.Ho = op->H; t.Wo = op->W;
+  t.src_coff = 0; t.dst_coff = op->src_coff; t.relu = 0; t.out_f32 = 0; t.tile = 0; t.group = 0; t.lane = 0;
+  comic_conv_weight w2{gr->w_bwd, nullptr, nullptr};
+  return run_op<T>(&t, dz, op->Cout, gx, xc, &w2, batch, st, /*accum=*/1);
+}
+
+template <typename T>
+int pool_backward(const comic_cnn_op* op, const void* x, int xc, const void* gy, int yc, void* gx, int batch,
+                  hipStream_t st) {
+  constexpr int EPC = Elem<T>::EPC;
+  COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && op->dst_coff % EPC == 0 && xc % EPC == 0 &&
+                    yc % EPC == 0, "pool backward: misaligned channel slices");
+  PoolGradArgs a{x, gy, gx, xc, op->src_coff, yc, op->dst_coff, op->kind == 4 ? 1 : 0,
+                 (op->kind == 4 && op->src_f32) ? 1 : 0,
+                 batch, op->H, op->W, op->Cin, op->KH, op->KW, op->SH, op->SW, op->PT, op->PL, op->Ho, op->Wo};
+  const long total = (long)batch * op->H * op->W * (op->Cin / EPC);
+  dim3 grid((unsigned)cdiv64(total, 256));
+  if (op->kind == 2)
+    hipLaunchKernelGGL((pool_grad_kernel<T, 0>), grid, dim3(256), 0, st, a);
+  else if (op->kind == 3)
+    hipLaunchKernelGGL((pool_grad_kernel<T, 1>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((pool_grad_kernel<T, 2>), grid, dim3(256), 0, st, a);
+  COMIC_LAUNCH_CHECK("pool backward");
+  return 0;
+}
+
+template <typename T>
+int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
+                      const int32_t* buf_channels, const comic_conv_weight* weights, const comic_conv_grad* grads,
+                      int batch, void* scratch, int64_t scratch_bytes, hipStream_t st) {
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const comic_cnn_op* op = ops + i;
+    if (op->kind == 5 || op->kind == 6) continue;
+    void* gy = grad_buffers[op->dst];
+    COMIC_REQUIRE(gy, "cnn_backward: op %d has no output gradient buffer", i);
+    void* gx = grad_buffers[op->src];
+    const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
+    if (op->kind <= 1) {
+      if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
+                                    grads + op->weight, batch, scratch, scratch_bytes, st))
+        return rc;
+    } else if (op->kind <= 4) {
+      if (!gx) continue;
+      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st)) return rc;
+    } else {
+      COMIC_REQUIRE(false, "cnn_backward: unknown op kind %d", op->kind);
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype) {
+  if (!ops) return -1;
+  const size_t es = dtype == COMIC_BF16 ? 2 : 4;
+  size_t best = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const comic_cnn_op* op = ops + i;
+    if (op->kind > 1) continue;
+    const int Hd = op->SH == 1 ? op->Ho : op->H - op->KH + 1 + 2 * op->PT;
+    const int Wd = op->SW == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
+    const size_t dz = ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
+    best = std::max(best, dz + (size_t)128 * op->Cout * sizeof(float));
+  }
+  return (int64_t)best;
+}
+
+extern "C" int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
+                                  const int32_t* buf_channels, const comic_conv_weight* weights,
+                                  const comic_conv_grad* grads, int batch, int dtype, void* scratch,
+                                  int64_t scratch_bytes, void* stream) {
+  COMIC_REQUIRE(ops && buffers && grad_buffers && buf_channels && weights && grads && scratch,
+                "comic_cnn_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == COMIC_BF16)
+    return cnn_backward_impl<bf16_t>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
+                                     scratch_bytes, st);
+  if (dtype == COMIC_F32)
+    return cnn_backward_impl<float>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
+                                    scratch_bytes, st);
+  COMIC_REQUIRE(false, "unknown dtype %d", dtype);
+  return 2;
+}
+
+// fp32 master -> plan-dtype copy of a flat parameter block (the packed layouts are identical)
+namespace {
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = f32_to_bf16(in[i]);
+}
+__global__ void refold_bn_kernel(const float* __restrict__ beta, const float* __restrict__ mean,
+                                 const float* __restrict__ scale, float* __restrict__ shift, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) shift[i] = beta[i] - mean[i] * scale[i];
+}
+}  // namespace
+
+extern "C" int comic_cnn_refresh_weights(const float* master, void* plan_copy, int64_t n, const float* beta,
+                                         const float* mean, const float* scale, float* shift, int64_t channels,
+                                         void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (plan_copy && n > 0) {
+    COMIC_REQUIRE(master, "cnn_refresh_weights: null master");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, master, (bf16_t*)plan_copy,
+                       (long)n);
+  }
+  if (channels > 0) {
+    COMIC_REQUIRE(beta && mean && scale && shift, "cnn_refresh_weights: null BN arrays");
+    hipLaunchKernelGGL(refold_bn_kernel, dim3((unsigned)cdiv64(channels, 256)), dim3(256), 0, st, beta, mean, scale,
+                       shift, (long)channels);
+  }
+  COMIC_LAUNCH_CHECK("cnn_refresh_weights");
   return 0;
 }

@@ -12,6 +12,8 @@
 //                              d h state   (backward of the cell_input_fn concat, ops_rnn.py:696-701)
 // Both use v_mfma_f32_16x16x4_f32 (exact fp32 products) with operands loaded straight from
 // global memory into registers: every operand element is used by exactly one wave.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -73,85 +75,110 @@ struct LstmStepArgs {
   int B, D, Wd;
 };
 
-// grid (D/4, ceil(B/16)): a workgroup owns 4 hidden units (16 gate columns) of 16 batch rows.
+// grid (D/4, ceil(B/(16*MT))): a workgroup owns 4 hidden units (16 gate columns) of 16*MT batch rows.
+template <int MT>
 __global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_kernel(LstmStepArgs a) {
-  __shared__ float4 red[kFusedWaves - 1][64];
+  __shared__ float4 red[kFusedWaves - 1][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int u0 = blockIdx.x * 4, m0 = blockIdx.y * 16;
+  const int u0 = blockIdx.x * 4, m0 = blockIdx.y * 16 * MT;
   const int D = a.D, N4 = 4 * D, Wd = a.Wd;
-  const int m = m0 + r;
-  const bool mok = m < a.B;
-  const float* xrow = a.xh + (size_t)(mok ? m : 0) * a.ld_xh;
+  const float* xrow[MT];
+  bool mok[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int m = m0 + 16 * j + r;
+    mok[j] = m < a.B;
+    xrow[j] = a.xh + (size_t)(mok[j] ? m : 0) * a.ld_xh;
+  }
   const int KB = (Wd + 15) >> 4;
   // panel rows of this unit tile: row r = gate (r & 3) of unit u0 + (r >> 2); lane reads k = 4*kq..+3
   const float* wpanel = a.K + ((size_t)blockIdx.x * KB * 16 + r) * 16 + 4 * kq;
-  // wave 0 runs the epilogue for (row m0 + r, unit u0 + kq): fetch its inputs before the product
-  float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f, e_hp = 0.f, e_mask = 1.f;
-  bool e_fin = false;
-  const bool e_ok = wave == 0 && mok && u0 + kq < D;
-  if (e_ok) {
-    const int d = u0 + kq;
-    const size_t i = (size_t)m * D + d;
+  // wave 0 runs the epilogue for (row m0 + 16j + r, unit u0 + kq): fetch its inputs before the product
+  float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_cp[MT], e_hp[MT], e_mask[MT];
+  bool e_fin[MT];
+  const int d = u0 + kq;
+  const bool e_wave = wave == 0 && d < D;
+  if (e_wave) {
     if (a.bias) {
       e_b[0] = a.bias[d]; e_b[1] = a.bias[D + d]; e_b[2] = a.bias[2 * D + d]; e_b[3] = a.bias[3 * D + d];
     }
-    if (a.c_prev) e_cp = a.c_prev[i];
-    if (a.h_prev) e_hp = a.h_prev[i];
-    if (a.mask_out) e_mask = a.mask_out[i];
-    e_fin = a.lens && (a.t >= a.lens[m]);
-  }
-  f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // a wave takes PAIRS of adjacent k16-blocks: its two activation loads per row share a 128-B line
-  for (int kp0 = wave; 2 * kp0 < KB; kp0 += kFusedWaves * (kChunk / 2)) {
-    float4 xa[kChunk], wb[kChunk];
 #pragma unroll
-    for (int i = 0; i < kChunk; ++i) {
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + 16 * j + r;
+      const size_t i = (size_t)(mok[j] ? m : 0) * D + d;
+      e_cp[j] = a.c_prev ? a.c_prev[i] : 0.f;
+      e_hp[j] = a.h_prev ? a.h_prev[i] : 0.f;
+      e_mask[j] = a.mask_out ? a.mask_out[i] : 1.f;
+      e_fin[j] = a.lens && mok[j] && (a.t >= a.lens[m]);
+    }
+  }
+  f32x4_t acc[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int CH = MT >= 4 ? 4 : kChunk;   // k16-blocks in flight per wave (register budget)
+  // a wave takes PAIRS of adjacent k16-blocks: its two activation loads per row share a 128-B line
+  for (int kp0 = wave; 2 * kp0 < KB; kp0 += kFusedWaves * (CH / 2)) {
+    float4 xa[CH][MT], wb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
       const int kb = 2 * (kp0 + kFusedWaves * (i >> 1)) + (i & 1);
       const int k = kb * 16 + 4 * kq;
-      xa[i] = wb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kb < KB) {
-        wb[i] = *(const float4*)(wpanel + (size_t)kb * 256);
-        if (mok && k < Wd) xa[i] = *(const float4*)(xrow + k);   // Wd % 4 == 0 (checked by the host)
+      wb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb < KB) wb[i] = *(const float4*)(wpanel + (size_t)kb * 256);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        xa[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb < KB && mok[j] && k < Wd) xa[i][j] = *(const float4*)(xrow[j] + k);   // Wd % 4 == 0 (host check)
       }
     }
 #pragma unroll
-    for (int i = 0; i < kChunk; ++i) {
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].x, xa[i].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].y, xa[i].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].z, xa[i].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].w, xa[i].w, acc, 0, 0, 0);
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].x, xa[i][j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].y, xa[i][j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].z, xa[i][j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i].w, xa[i][j].w, acc[j], 0, 0, 0);
     }
   }
   // D[n][m]: lane (m = lane & 15, kq) holds the 4 gates (n = 4*kq + g) of unit u0 + kq of row m
-  if (wave > 0) red[wave - 1][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  __syncthreads();
-  if (wave != 0) return;
+  if (wave > 0) {
 #pragma unroll
-  for (int w = 0; w < kFusedWaves - 1; ++w) {
-    const float4 p = red[w][lane];
-    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+    for (int j = 0; j < MT; ++j) red[wave - 1][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }
-  const int b = m0 + r, d = u0 + kq;
-  if (!e_ok) return;
-  const size_t i = (size_t)b * D + d;
-  const float gi = acc[0] + e_b[0], gj = acc[1] + e_b[1], gf = acc[2] + e_b[2], go = acc[3] + e_b[3];
-  const float si = sigmoid_(gi), tj = tanhf(gj);
-  const float sf = sigmoid_(gf + 1.0f), so = sigmoid_(go);   // forget_bias = 1
-  const float cp = e_cp;
-  const float c2 = cp * sf + si * tj;
-  const float h2 = tanhf(c2) * so;
-  if (a.gates_act) {
-    float* ga = a.gates_act + (size_t)b * N4;
-    ga[d] = si; ga[D + d] = tj; ga[2 * D + d] = sf; ga[3 * D + d] = so;
+  __syncthreads();
+  if (!e_wave) return;
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+#pragma unroll
+    for (int w = 0; w < kFusedWaves - 1; ++w) {
+      const float4 p = red[w][j][lane];
+      acc[j][0] += p.x; acc[j][1] += p.y; acc[j][2] += p.z; acc[j][3] += p.w;
+    }
+    const int b = m0 + 16 * j + r;
+    if (b >= a.B) continue;
+    const size_t i = (size_t)b * D + d;
+    const float gi = acc[j][0] + e_b[0], gj = acc[j][1] + e_b[1], gf = acc[j][2] + e_b[2], go = acc[j][3] + e_b[3];
+    const float si = sigmoid_(gi), tj = tanhf(gj);
+    const float sf = sigmoid_(gf + 1.0f), so = sigmoid_(go);   // forget_bias = 1
+    const float cp = e_cp[j];
+    const float c2 = cp * sf + si * tj;
+    const float h2 = tanhf(c2) * so;
+    if (a.gates_act) {
+      float* ga = a.gates_act + (size_t)b * N4;
+      ga[d] = si; ga[D + d] = tj; ga[2 * D + d] = sf; ga[3 * D + d] = so;
+    }
+    if (a.c_new) a.c_new[i] = c2;
+    if (a.y) a.y[i] = a.mask_out ? (h2 / a.keep_out) * e_mask[j] : h2;
+    const bool fin = e_fin[j];
+    if (a.c_state) a.c_state[i] = fin ? cp : c2;
+    const float hs = fin ? e_hp[j] : h2;
+    if (a.h_state) a.h_state[i] = hs;
+    if (a.xh_next) a.xh_next[(size_t)b * a.xh_ld + d] = hs;
   }
-  if (a.c_new) a.c_new[i] = c2;
-  if (a.y) a.y[i] = a.mask_out ? (h2 / a.keep_out) * e_mask : h2;
-  const bool fin = e_fin;
-  if (a.c_state) a.c_state[i] = fin ? cp : c2;
-  const float hs = fin ? e_hp : h2;
-  if (a.h_state) a.h_state[i] = hs;
-  if (a.xh_next) a.xh_next[(size_t)b * a.xh_ld + d] = hs;
 }
 
 struct InputGradArgs {
@@ -401,7 +428,17 @@ int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const floa
                 "lstm_step_fused: D, Wd and the operand stride must be multiples of 4 (16-byte rows)");
   LstmStepArgs a{xh, ld_xh, K, bias, c_prev, h_prev, gates_act, c_new, y, mask_out, keep_out, lens, t,
                  c_state, h_state, xh_next, xh_ld, B, D, Wd};
-  hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(D / 4, cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  static int mt = -1;
+  if (mt < 0) {
+    const char* e = getenv("COMIC_LSTM_MT");
+    mt = e ? atoi(e) : 1;
+  }
+  if (mt == 4)
+    hipLaunchKernelGGL(lstm_step_fused_kernel<4>, dim3(D / 4, cdiv(B, 64)), dim3(kFusedThreads), 0, st, a);
+  else if (mt == 2)
+    hipLaunchKernelGGL(lstm_step_fused_kernel<2>, dim3(D / 4, cdiv(B, 32)), dim3(kFusedThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL(lstm_step_fused_kernel<1>, dim3(D / 4, cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
   COMIC_LAUNCH_CHECK("lstm_step_fused");
   return 0;
 }

@@ -86,8 +86,8 @@ class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
-                 group_branches=True):
-        if name != 'inception_v3':
+                 group_branches=True, layers=None):
+        if name not in ('inception_v3', 'chain'):
             raise NotImplementedError('only inception_v3 is on the MI355X hot path (got %r)' % name)
         self.name = name
         self.ops = []            # dicts
@@ -101,7 +101,10 @@ class CnnPlan:
         self.group_branches = group_branches and not branch_streams
         self._depth = 0
         self._next_group = 1
-        self._build_v3(image_size, final_endpoint)
+        if name == 'chain':
+            self._build_chain(image_size, layers)
+        else:
+            self._build_v3(image_size, final_endpoint)
 
     # -- builder helpers ---------------------------------------------------------------
     def _buf(self, H, W, Cc, f32=False):
@@ -173,6 +176,39 @@ class CnnPlan:
                 C_ = sum(o[2] for o in op[1])
         return H, W, C_
 
+    def _build_chain(self, image_size, layers):
+        """A plain sequence of the same op forms as the InceptionV3 table (('c', scope, cout, (kh, kw),
+        stride, pad) | ('max',) | ('avg',)) under scope 'Chain', ending like the real network: the last
+        conv writes the fp32 feature map, followed by the head's global average pool.  Used to
+        exercise every forward / backward kernel on shallow stacks."""
+        H, W = image_size
+        cur = self._buf(H, W, 3, True)
+        self.input = cur
+        assert layers and layers[-1][0] == 'c'
+        for li, op in enumerate(layers):
+            last = li == len(layers) - 1
+            if op[0] == 'c':
+                cur, _ = self._conv(cur, 'Chain', op, out_f32=last)
+                self.end_points[op[1]] = cur
+            elif op[0] == 'max':
+                cur, _ = self._pool(cur, 2, 3, 2, 'VALID')
+            else:
+                cur, _ = self._pool(cur, 3, 3, 1, 'SAME')
+        self._finish_head(cur)
+
+    def _finish_head(self, cur):
+        # head (inception_v3.py:520-532): kernel = min(8, H_f), VALID, num_classes=None
+        Hf, Wf, Cf, f32 = self.buffers[cur]
+        self.fm = cur
+        kh, kw = min(Hf, 8), min(Wf, 8)
+        Hp, Wp = Hf - kh + 1, Wf - kw + 1
+        pooled = self._buf(Hp, Wp, Cf, True)
+        self.ops.append(dict(kind=4, src=cur, dst=pooled, src_coff=0, dst_coff=0, H=Hf, W=Wf, Cin=Cf, Cout=Cf, KH=kh,
+                             KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1,
+                             src_f32=int(f32), lane=0))
+        self.pooled = pooled
+        self.end_points['AvgPool_1a'] = pooled
+
     def _build_v3(self, image_size, final_endpoint):
         H, W = image_size
         cur = self._buf(H, W, 3, True)          # fp32 images in [-1, 1]
@@ -231,17 +267,7 @@ class CnnPlan:
             self.end_points[bname] = cur
             if last:
                 break
-        # head (inception_v3.py:520-532): kernel = min(8, H_f), VALID, num_classes=None
-        Hf, Wf, Cf, f32 = self.buffers[cur]
-        self.fm = cur
-        kh, kw = min(Hf, 8), min(Wf, 8)
-        Hp, Wp = Hf - kh + 1, Wf - kw + 1
-        pooled = self._buf(Hp, Wp, Cf, True)
-        self.ops.append(dict(kind=4, src=cur, dst=pooled, src_coff=0, dst_coff=0, H=Hf, W=Wf, Cin=Cf, Cout=Cf, KH=kh,
-                             KW=kw, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=-1, relu=0, out_f32=1,
-                             src_f32=int(f32), lane=0))
-        self.pooled = pooled
-        self.end_points['AvgPool_1a'] = pooled
+        self._finish_head(cur)
 
     # -- parameters -----------------------------------------------------------------------
     def param_shapes(self):
@@ -273,13 +299,28 @@ class CnnEncoder:
 
     def __init__(self, plan: CnnPlan, params: dict, batch: int, dtype='bf16', device='cuda:0'):
         import torch
+        from .decoder import FlatParams
         self.torch = torch
         self.lib = L.load()
         self.plan, self.batch, self.dtype, self.device = plan, batch, dtype, device
         self.dcode = 1 if dtype == 'bf16' else 0
         tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self._tdt = tdt
         st = L.stream_ptr()
-        self._keep = []
+        # fp32 masters in the packed kernel layout ([Cout][Kpad]; stem [K][Cout]) in ONE flat buffer, BN
+        # vectors in a second one: the forward reads a plan-dtype copy of the first (the fp32 plan reads
+        # the masters themselves), cnn_finetune trains both (comic_cnn_backward + AdamTF on the flats)
+        wshapes, bshapes = {}, {}
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+            K = kh * kw * cin
+            wshapes['w%d' % i] = (K * cout,) if stem else (cout * ((K + 63) // 64 * 64),)
+            bshapes['b%d' % i] = (cout,)
+        self.w_master = FlatParams(wshapes, device)
+        self.beta = FlatParams(bshapes, device)
+        self.mean, self.scale, self.shift = self.beta.like(), self.beta.like(), self.beta.like()
+        self.scale.data.fill_(1.0)
+        self.w_plan = self.w_master.data if self.dcode == 0 else torch.zeros(self.w_master.numel, dtype=tdt,
+                                                                              device=device)
         wt = (L.ConvWeight * len(plan.weights))()
         for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
             w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(device)
@@ -287,20 +328,25 @@ class CnnEncoder:
             beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
                 params[prefix + '/BatchNorm/' + s], np.float32)).to(device)
                 for s in ('beta', 'moving_mean', 'moving_variance'))
-            scale = torch.empty(cout, dtype=torch.float32, device=device)
-            shift = torch.empty(cout, dtype=torch.float32, device=device)
+            bk = 'b%d' % i
+            self.beta.view(bk).copy_(beta)
+            self.mean.view(bk).copy_(mean)
             L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
-                                           scale.data_ptr(), shift.data_ptr(), cout, st), 'fold_bn')
+                                           self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
+                    'fold_bn')
+            master = self.w_master.view('w%d' % i)
             if stem:
-                packed = w.reshape(kh * kw * cin, cout).contiguous()
+                master.copy_(w.reshape(-1))
             else:
-                K = kh * kw * cin
-                kpad = (K + 63) // 64 * 64
-                packed = torch.empty(cout * kpad, dtype=tdt, device=device)
-                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), packed.data_ptr(), kh, kw, cin, cout,
-                                                         self.dcode, st), 'pack_conv_weights')
-            wt[i].w, wt[i].scale, wt[i].shift = packed.data_ptr(), scale.data_ptr(), shift.data_ptr()
-            self._keep += [packed, scale, shift]
+                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
+                        'pack_conv_weights')
+            esz = 4 if (stem or self.dcode == 0) else 2
+            wbase = self.w_master.data.data_ptr() if (stem or self.dcode == 0) else self.w_plan.data_ptr()
+            wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
+            wt[i].scale = self.scale.view(bk).data_ptr()
+            wt[i].shift = self.shift.view(bk).data_ptr()
+        self._train = None
+        self.refresh_weights()
         torch.cuda.synchronize()
         self._wt = wt
         self.bufs = []
@@ -320,6 +366,86 @@ class CnnEncoder:
         self._build_group_args()
         self._graph = None
         self._calls = 0
+
+    def refresh_weights(self):
+        """Re-derive what the forward reads from the fp32 masters: the plan-dtype weight copy and
+        shift = beta - mean*scale (after loading a checkpoint or an optimiser step)."""
+        plan_copy = self.w_plan.data_ptr() if self.dcode == 1 else None
+        L.check(self.lib.comic_cnn_refresh_weights(self.w_master.data.data_ptr(), plan_copy, self.w_master.numel,
+                                                   self.beta.data.data_ptr(), self.mean.data.data_ptr(),
+                                                   self.scale.data.data_ptr(), self.shift.data.data_ptr(),
+                                                   self.beta.numel, L.stream_ptr()), 'cnn_refresh_weights')
+
+    def export_params(self):
+        """Trainable CNN variables back in the slim checkpoint layout: {name: HWIO weights / beta}."""
+        out = {}
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            K = kh * kw * cin
+            m = self.w_master.view('w%d' % i)
+            w = m.view(K, cout) if stem else m.view(cout, -1)[:, :K].t()
+            out[prefix + '/weights'] = w.reshape(kh, kw, cin, cout).contiguous().cpu().numpy()
+            out[prefix + '/BatchNorm/beta'] = self.beta.view('b%d' % i).cpu().numpy().copy()
+        return out
+
+    # -- cnn_finetune ------------------------------------------------------------------------------
+    def enable_training(self):
+        """Allocate what comic_cnn_backward needs: a gradient buffer per activation buffer (one
+        flat allocation, zeroed per step), fp32 weight / beta gradients with the masters' layout,
+        the backward-data filter scratch and the d-conv scratch."""
+        if self._train is not None:
+            return self._train
+        torch, plan = self.torch, self.plan
+        t = type('CnnTrainState', (), {})()
+        t.dw, t.dbeta = self.w_master.like(), self.beta.like()
+        sizes, total = [], 0
+        for bi, (H, W, Cc, f32) in enumerate(plan.buffers):
+            nbytes = 0 if bi == plan.input else self.batch * H * W * Cc * (4 if (f32 or self.dcode == 0) else 2)
+            sizes.append((total, nbytes))
+            total += (nbytes + 255) // 256 * 256
+        t.gflat = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        t.gbufs = []
+        for bi, (H, W, Cc, f32) in enumerate(plan.buffers):
+            off, nbytes = sizes[bi]
+            if nbytes == 0:
+                t.gbufs.append(None)
+                continue
+            dt = torch.float32 if (f32 or self.dcode == 0) else self._tdt
+            t.gbufs.append(t.gflat[off:off + nbytes].view(dt).view(self.batch, H, W, Cc))
+        t.gptr = (C.c_void_p * len(t.gbufs))(*[g.data_ptr() if g is not None else None for g in t.gbufs])
+        esz = 4 if self.dcode == 0 else 2
+        wb_off, n = [], 0
+        for (prefix, kh, kw, cin, cout, stem) in plan.weights:
+            wb_off.append(n)
+            if not stem:
+                n += (cin * ((kh * kw * cout + 63) // 64 * 64) * esz + 255) // 256 * 256
+        t.w_bwd = torch.zeros(max(n, 256), dtype=torch.uint8, device=self.device)
+        t.grads = (L.ConvGrad * len(plan.weights))()
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+            t.grads[i].w_master = self.w_master.view('w%d' % i).data_ptr()
+            t.grads[i].dw = t.dw.view('w%d' % i).data_ptr()
+            t.grads[i].dbeta = t.dbeta.view('b%d' % i).data_ptr()
+            t.grads[i].w_bwd = None if stem else t.w_bwd.data_ptr() + wb_off[i]
+        t.scratch_bytes = int(self.lib.comic_cnn_backward_scratch_bytes(self._ops, len(plan.ops), self.batch,
+                                                                         self.dcode))
+        t.scratch = torch.empty(t.scratch_bytes, dtype=torch.uint8, device=self.device)
+        self._train = t
+        return t
+
+    def backward(self, d_fm, d_im_embed):
+        """d_fm [B, M, C] / d_im_embed [B, C_g] fp32 (the gradients of `forward`'s two outputs; either
+        may be None) -> fills the weight / beta gradients of `enable_training()`'s state."""
+        t = self.enable_training()
+        t.gflat.zero_()
+        t.dw.data.zero_()
+        t.dbeta.data.zero_()
+        if d_fm is not None:
+            t.gbufs[self.plan.fm].view(-1).copy_(d_fm.reshape(-1))
+        if d_im_embed is not None:
+            t.gbufs[self.plan.pooled].view(-1).copy_(d_im_embed.reshape(-1))
+        L.check(self.lib.comic_cnn_backward(self._ops, len(self.plan.ops), self._bufptr, t.gptr, self._bufch, self._wt,
+                                            t.grads, self.batch, self.dcode, t.scratch.data_ptr(), t.scratch_bytes,
+                                            L.stream_ptr()), 'cnn_backward')
+        return t
 
     def _build_group_args(self):
         """(Re)build the device-resident argument records of the grouped launches; they embed

@@ -108,6 +108,35 @@ int comic_cnn_forward_grouped(const comic_cnn_op* ops, int n_ops, void* const* b
                               const int32_t* buf_channels, const comic_conv_weight* weights,
                               int batch, int dtype, const void* group_args_dev, void* stream);
 
+/* ---- cnn_finetune: backward of the plan (train.py:241-249; model_base.py:76,834-849) ------
+ * The CNN variables (conv weights, BN beta) become trainable; BN stays in inference mode, so a
+ * conv contributes d beta = sum(1[y>0] dy), d w (backward-weight) and d x (backward-data).
+ * grad_buffers[i] mirrors buffers[i] (same shape and element type; NULL where no gradient is
+ * wanted, e.g. the image).  They are ACCUMULATED into: zero them, seed the gradients of the
+ * plan outputs (feature map, pooled vector), then call.  Per conv weight record `grads[w]`:
+ *   w_master  fp32 packed [Cout][Kpad] (stem: [K][Cout]) -- the trainable copy
+ *   dw        fp32, same layout, accumulated (atomics: summation order over pixel slices is
+ *             not fixed; zero it per step)
+ *   dbeta     fp32 [Cout], accumulated
+ *   w_bwd     plan-dtype scratch of Cin * roundup64(KH*KW*Cout) elements for the flipped /
+ *             transposed filter of the backward-data pass (NULL for the stem conv)
+ * comic_cnn_refresh_weights re-derives the plan-dtype weight copy (flat bf16 conversion of all
+ * masters) and shift = beta - mean*scale after an optimiser step. */
+typedef struct comic_conv_grad {
+  const float* w_master;
+  float* dw;
+  float* dbeta;
+  void* w_bwd;
+} comic_conv_grad;
+int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype);
+int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
+                       void* const* grad_buffers, const int32_t* buf_channels,
+                       const comic_conv_weight* weights, const comic_conv_grad* grads, int batch,
+                       int dtype, void* scratch, int64_t scratch_bytes, void* stream);
+int comic_cnn_refresh_weights(const float* master, void* plan_copy, int64_t n, const float* beta,
+                              const float* mean, const float* scale, float* shift,
+                              int64_t channels, void* stream);
+
 /* Single conv + folded BN + ReLU (slim.conv2d under inception_arg_scope). */
 int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x_channels, void* y,
                          int y_channels, const comic_conv_weight* wt, int batch, int dtype,

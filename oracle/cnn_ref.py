@@ -122,10 +122,73 @@ def avg_pool(x, k=3, stride=1, padding='SAME'):
 
 
 # --------------------------------------------------------------------------- #
+# backward primitives (cnn_finetune: the CNN variables join the trainable set when
+# freeze_scopes == '' -- src/train.py:241-249, src/model_base.py:834-849; the graph is still
+# built with is_training=False, model_base.py:76, so BN contributes d beta only)
+# --------------------------------------------------------------------------- #
+def conv2d_bwd(x, w, dy, stride=1, padding='VALID'):
+    """-> (dx, dw) of y = conv2d(x, w)."""
+    B, H, W, C = x.shape
+    kh, kw, ci, co = w.shape
+    Ho, pt, pb = out_size(H, kh, stride, padding)
+    Wo, pl, pr = out_size(W, kw, stride, padding)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0))) if (pt or pb or pl or pr) else x
+    cols = np.empty((B, Ho, Wo, kh, kw, C), np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, :, i, j, :] = xp[:, i:i + (Ho - 1) * stride + 1:stride,
+                                        j:j + (Wo - 1) * stride + 1:stride, :]
+    dy2 = np.ascontiguousarray(dy, np.float32).reshape(B * Ho * Wo, co)
+    dw = (cols.reshape(B * Ho * Wo, kh * kw * C).T @ dy2).reshape(kh, kw, ci, co)
+    dcols = (dy2 @ w.reshape(kh * kw * C, co).T).reshape(B, Ho, Wo, kh, kw, C)
+    dxp = np.zeros_like(xp)
+    for i in range(kh):
+        for j in range(kw):
+            dxp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :] += dcols[:, :, :, i, j, :]
+    return dxp[:, pt:pt + H, pl:pl + W, :], dw
+
+
+def max_pool_bwd(x, dy, k=3, stride=2, padding='VALID'):
+    """MaxPoolGrad: the gradient of a window goes to its FIRST maximum in window scan order
+    (kh-major) -- TF's CPU kernel (argmax from the forward pass).  Ties other than between
+    ReLU zeros (whose gradient the producing conv masks anyway) do not occur in practice."""
+    assert padding == 'VALID'
+    B, H, W, C = x.shape
+    Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
+    win = np.stack([x[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+                    for i in range(k) for j in range(k)], axis=0)          # [k*k, B, Ho, Wo, C]
+    arg = np.argmax(win, axis=0)                                          # first maximum
+    dx = np.zeros_like(x)
+    for t in range(k * k):
+        i, j = divmod(t, k)
+        dx[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :] += np.where(arg == t, dy, 0)
+    return dx
+
+
+def avg_pool_bwd(x_shape, dy, k=3, stride=1, padding='SAME'):
+    B, H, W, C = x_shape
+    kh, kw = (k, k) if isinstance(k, int) else k
+    Ho, pt, pb = out_size(H, kh, stride, padding)
+    Wo, pl, pr = out_size(W, kw, stride, padding)
+    ones = np.pad(np.ones((1, H, W, 1), np.float32), ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+    cnt = np.zeros((1, Ho, Wo, 1), np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            cnt += ones[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+    g = np.asarray(dy, np.float32) / cnt
+    dxp = np.zeros((B, H + pt + pb, W + pl + pr, C), np.float32)
+    for i in range(kh):
+        for j in range(kw):
+            dxp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :] += g
+    return dxp[:, pt:pt + H, pl:pl + W, :]
+
+
+# --------------------------------------------------------------------------- #
 # network builder: used both to create parameters and to run the forward pass
 # --------------------------------------------------------------------------- #
 class _Net:
-    def __init__(self, params=None, rng=None, act_dtype='f32', run=True):
+    def __init__(self, params=None, rng=None, act_dtype='f32', run=True, tape=False):
+        self.tape = [] if tape else None     # reverse-mode records: (kind, inputs, output, ctx)
         self.params = params if params is not None else OrderedDict()
         self.create = params is None
         self.rng = rng
@@ -164,6 +227,8 @@ class _Net:
             y = conv2d(_q(x, self.act_dtype), _q(w, self.act_dtype), stride, padding)
             y = batch_norm_inference(y, self.params[bn], self.params[mn], self.params[vn])
             y = _q(np.maximum(y, 0), self.act_dtype)
+            if self.tape is not None:
+                self.tape.append(('conv', [x], y, (wn, bn, vn, stride, padding)))
         else:
             y = np.zeros((B, Ho, Wo, cout), np.float32)
         self.scope.pop()
@@ -174,7 +239,55 @@ class _Net:
             B, H, W, C = x.shape
             return np.zeros((B, out_size(H, k, stride, padding)[0],
                              out_size(W, k, stride, padding)[0], C), np.float32)
-        return max_pool(x, k, stride, padding)
+        y = max_pool(x, k, stride, padding)
+        if self.tape is not None:
+            self.tape.append(('max', [x], y, (k, stride, padding)))
+        return y
+
+    def concat(self, xs):
+        y = np.concatenate(xs, axis=3)
+        if self.tape is not None:
+            self.tape.append(('cat', list(xs), y, None))
+        return y
+
+    def backward(self, seeds):
+        """seeds: list of (array produced by this net, gradient).  -> {variable name: gradient}
+        for every conv weight and BN beta (fp32 arithmetic on the taped activations)."""
+        g = {}
+        keep = []
+
+        def add(arr, val):
+            k = id(arr)
+            if k in g:
+                g[k] = g[k] + val
+            else:
+                g[k] = np.asarray(val, np.float32)
+                keep.append(arr)
+        for arr, val in seeds:
+            add(arr, val)
+        out = {}
+        for kind, ins, y, ctx in reversed(self.tape):
+            dy = g.pop(id(y), None)
+            if dy is None:
+                continue
+            if kind == 'conv':
+                wn, bn, vn, stride, padding = ctx
+                dz = np.where(y > 0, dy, 0).astype(np.float32)
+                out[bn] = out.get(bn, 0) + dz.sum(axis=(0, 1, 2))
+                dz = dz * (np.float32(1.0) / np.sqrt(self.params[vn] + np.float32(BN_EPS)))
+                dx, dw = conv2d_bwd(_q(ins[0], self.act_dtype), _q(self.params[wn], self.act_dtype), dz, stride, padding)
+                out[wn] = out.get(wn, 0) + dw
+                add(ins[0], dx)
+            elif kind == 'max':
+                add(ins[0], max_pool_bwd(ins[0], dy, *ctx))
+            elif kind == 'avg':
+                add(ins[0], avg_pool_bwd(ins[0].shape, dy, *ctx))
+            elif kind == 'cat':
+                o = 0
+                for x in ins:
+                    add(x, dy[..., o:o + x.shape[3]])
+                    o += x.shape[3]
+        return out
 
     def avg_pool(self, x, k=3, stride=1, padding='SAME'):
         if not self.run:
@@ -182,12 +295,15 @@ class _Net:
             kh, kw = (k, k) if isinstance(k, int) else k
             return np.zeros((B, out_size(H, kh, stride, padding)[0],
                              out_size(W, kw, stride, padding)[0], C), np.float32)
-        return _q(avg_pool(x, k, stride, padding), self.act_dtype)
+        y = _q(avg_pool(x, k, stride, padding), self.act_dtype)
+        if self.tape is not None:
+            self.tape.append(('avg', [x], y, (k, stride, padding)))
+        return y
 
 
 def _inception_v3_base(net: _Net, x, end_points):
     """common/nets/inception_v3.py:100-415."""
-    cat = lambda xs: np.concatenate(xs, axis=3)
+    cat = net.concat
     net.scope.append('InceptionV3')
     # stem, stride 1 / VALID defaults (inception_v3.py:100-137)
     x = net.conv(x, 32, 3, 2, 'VALID', 'Conv2d_1a_3x3'); end_points['Conv2d_1a_3x3'] = x
@@ -312,6 +428,22 @@ def inception_v3(params, images, act_dtype='f32'):
     num_classes=None, is_training=False) (nets/nets_factory.py:116-159)."""
     net = _Net(params, None, act_dtype=act_dtype, run=True)
     return _run(net, images)
+
+
+def inception_v3_grads(params, images, d_net, d_fm, fm_name='Mixed_7c', act_dtype='f32'):
+    """Gradients of the CNN variables given d(net [B,1,1,C]) and d(end_points[fm_name]) (the
+    two tensors ModelBase._encoder hands to the decoder, model_base.py:93-104).
+    -> (grads {name: array}, net, end_points)."""
+    # act_dtype='bf16': the taped forward emulates the product's bf16 storage (so the ReLU masks and
+    # pool arg-maxima are those of a bf16 forward); the reverse pass itself stays fp32
+    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+    net, ep = _run(n, images)
+    seeds = []
+    if d_net is not None:
+        seeds.append((net, np.asarray(d_net, np.float32).reshape(net.shape)))
+    if d_fm is not None:
+        seeds.append((ep[fm_name], np.asarray(d_fm, np.float32).reshape(ep[fm_name].shape)))
+    return n.backward(seeds), net, ep
 
 
 def describe(image_size=224):

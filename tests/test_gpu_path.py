@@ -84,6 +84,122 @@ def test_grouped_branch_launch_is_bit_identical():
         assert torch.equal(fm0, fm2) and torch.equal(im0, im2)
 
 
+def _cnn_grads_device(enc, t):
+    """{variable name: gradient} in the slim layout from the packed fp32 gradient buffers."""
+    out = {}
+    for i, (prefix, kh, kw, cin, cout, stem) in enumerate(enc.plan.weights):
+        K = kh * kw * cin
+        g = t.dw.view('w%d' % i)
+        w = g.view(K, cout) if stem else g.view(cout, -1)[:, :K].t()
+        out[prefix + '/weights'] = w.reshape(kh, kw, cin, cout).cpu().numpy()
+        out[prefix + '/BatchNorm/beta'] = t.dbeta.view('b%d' % i).cpu().numpy()
+    return out
+
+
+def _seeds(rng, B, M, C):
+    """Gradients of (net, feature map) with a non-zero mean: with zero-mean seeds a variable's
+    gradient is a sqrt(N)-sized random sum, and the handful of ReLU masks / pool arg-maxima that
+    differ between two forward passes dominates its relative error."""
+    return ((1 + 0.5 * rng.standard_normal((B, C))).astype(np.float32),
+            ((1 + 0.5 * rng.standard_normal((B, M, C))) / M).astype(np.float32))
+
+
+def test_inception_v3_backward_224_f32():
+    """cnn_finetune: d(conv weights), d(BN beta) of all 94 convs from seeded gradients of the two
+    encoder outputs, against the oracle's reverse pass.  fp32 plan; the tolerance (max-norm per
+    variable) is 2e-3 rather than 1e-3 because ReLU masks of near-zero activations differ between
+    the two forward passes in the 109x109 / 54x54 stem layers (median error over the 188
+    variables is ~1e-6, asserted below)."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 25, 2048)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), params, B, 'f32', DEV)
+    enc.forward(dev(x))
+    t = enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    got = _cnn_grads_device(enc, t)
+    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm)
+    assert set(got) == set(want) and len(want) == 188
+    errs = sorted((rel_err(got[k], want[k]), k) for k in want)
+    assert errs[-1][0] < 2e-3, errs[-1]
+    assert errs[len(errs) // 2][0] < 1e-5, errs[len(errs) // 2]
+    # the trainable copies export back to the checkpoint layout unchanged
+    ex = enc.export_params()
+    for k in ('InceptionV3/Conv2d_1a_3x3/weights', 'InceptionV3/Mixed_6b/Branch_2/Conv2d_0c_1x7/weights',
+              'InceptionV3/Mixed_7a/Branch_0/Conv2d_1a_3x3/BatchNorm/beta'):
+        np.testing.assert_array_equal(ex[k], params[k])
+
+
+_CHAIN = [('c', 'c1', 32, (3, 3), 2, 'VALID'), ('c', 'c2', 64, (3, 3), 1, 'SAME'), ('max',),
+          ('c', 'c3', 96, (1, 7), 1, 'SAME'), ('avg',), ('c', 'c4', 64, (3, 3), 2, 'VALID'),
+          ('c', 'c5', 48, (5, 5), 1, 'SAME')]
+
+
+def _chain_oracle(params, x, d_net, d_fm, act_dtype):
+    n = cnn_ref._Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+    n.scope.append('Chain')
+    h = np.asarray(x, np.float32)
+    for op in _CHAIN:
+        if op[0] == 'c':
+            h = n.conv(h, op[2], op[3], op[4], op[5], op[1])
+        elif op[0] == 'max':
+            h = n.max_pool(h, 3, 2, 'VALID')
+        else:
+            h = n.avg_pool(h, 3, 1, 'SAME')
+    pooled = n.avg_pool(h, (h.shape[1], h.shape[2]), 1, 'VALID')
+    g = n.backward([(pooled, d_net.reshape(pooled.shape)), (h, d_fm.reshape(h.shape))])
+    return h, pooled, g
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 4e-2)])
+@pytest.mark.parametrize('B,size', [(3, 63), (2, 70)])
+def test_cnn_backward_chain(dtype, tol, B, size):
+    """Every backward kernel on a shallow stack (stem conv, 3x3 SAME, max pool, 1x7, avg pool,
+    stride-2 VALID with odd and even input sizes, 5x5 into the fp32 feature map, head pool), both
+    plan dtypes, ragged batch: d weights / d beta against the oracle's reverse pass over a
+    forward that emulates the plan's storage type."""
+    rng = np.random.default_rng(5 + B)
+    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN)
+    params = cnn_ref.randomize_bn(plan.init_params(seed=3), seed=4)
+    x = rng.uniform(-1, 1, (B, size, size, 3)).astype(np.float32)
+    Hf, Wf, Cf, _ = plan.buffers[plan.fm]
+    d_net, d_fm = _seeds(rng, B, Hf * Wf, Cf)
+    enc = nets.CnnEncoder(plan, params, B, dtype, DEV)
+    im, fm = enc.forward(dev(x))
+    t = enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    h, pooled, want = _chain_oracle(params, x, d_net, d_fm, dtype)
+    assert_close(fm.cpu().numpy().reshape(h.shape), h, tol, 'chain fm ' + dtype)
+    assert_close(im.cpu().numpy(), pooled.reshape(B, -1), tol, 'chain pooled ' + dtype)
+    got = _cnn_grads_device(enc, t)
+    assert set(got) == set(want)
+    for k in sorted(want):
+        assert_close(got[k], want[k], tol, '%s %s' % (k, dtype))
+
+
+def test_inception_v3_backward_224_bf16_sanity():
+    """Whole-network bf16 backward against the fp32-arithmetic oracle over a bf16-emulating
+    forward.  After ~45 bf16 layers the two forwards differ by up to 3e-2 (forward test), so a few
+    per cent of the ReLU masks differ; the per-kernel bf16 bound is test_cnn_backward_chain's."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 25, 2048)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), params, B, 'bf16', DEV)
+    enc.forward(dev(x))
+    t = enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    got = _cnn_grads_device(enc, t)
+    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm, act_dtype='bf16')
+    errs = sorted((rel_err(got[k], want[k]), k) for k in want)
+    assert errs[-1][0] < 0.2, errs[-1]
+    assert errs[len(errs) // 2][0] < 6e-2, errs[len(errs) // 2]
+    assert all(np.isfinite(v).all() for v in got.values())
+
+
 # ----------------------------------------------------------------------------- decoder ----
 def _spec_and_cfg(**kw):
     base = dict(D=128, E=64, V=258, C=192, Cg=192, H=8, M=25)
