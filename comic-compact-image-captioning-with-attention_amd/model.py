@@ -64,11 +64,21 @@ class ModelBase(object):
         self.dp = dp or DataParallel(None)
 
     def _encoder_for(self, batch_size):
+        """One encoder (activation buffers, hipGraph) per batch size over ONE set of CNN variables,
+        like the reference's reuse=True train / eval / infer graphs (train_fn.py:60-66)."""
         encs = self._share['encoders']
         if batch_size not in encs:
             dtype = getattr(self._config, 'cnn_dtype', 'bf16')
-            encs[batch_size] = nets.CnnEncoder(self.plan, self._share['cnn_params'], batch_size, dtype, self.device)
+            first = next(iter(encs.values()), None)
+            encs[batch_size] = nets.CnnEncoder(self.plan, self._share['cnn_params'], batch_size, dtype, self.device,
+                                               weights_from=first)
         return encs[batch_size]
+
+    @property
+    def cnn_trainable(self):
+        """train_mode cnn_finetune sets freeze_scopes = '' (train.py:241-249), which puts the CNN
+        variables into `_get_trainable_vars` (model_base.py:834-849)."""
+        return self.is_training() and not getattr(self._config, 'freeze_scopes', 'Model/encoder/cnn')
 
     def _encode(self, images):
         images = np.asarray(images, np.float32) if not self.torch.is_tensor(images) else images
@@ -80,6 +90,19 @@ class ModelBase(object):
     def is_training(self):
         return self.mode == 'train'
 
+    def _cnn_update(self, res, lr):
+        """cnn_finetune: encoder backward from the decoder's input gradients, rank-mean of the CNN
+        gradients, TF-Adam on the fp32 masters, refresh of what the forward reads."""
+        enc = self._encoder_for(self._batch_size)
+        t = enc.backward(res['dfm'], res['dim_embed'])
+        ow, ob, mult = self._share['opt_cnn']
+        s1 = self.dp.average_(t.dw.data)
+        self.dp.average_(t.dbeta.data)
+        ow.t = ob.t = self.opt.t            # one global step for every variable
+        ow.step(t.dw, lr, grad_scale=s1 * mult)
+        ob.step(t.dbeta, lr, grad_scale=s1 * mult)
+        enc.refresh_weights()
+
     # ---- optimiser / LR (model_base.py:775-883) -----------------------------------------
     def _create_optimiser(self):
         c, share = self._config, self._share
@@ -89,6 +112,13 @@ class ModelBase(object):
             share['opt'] = optim.AdamTF(self.decoder.params, epsilon=c.adam_epsilon, l2_decay=getattr(c, 'l2_decay', 1e-5))
             share['legacy_lr'] = c.lr_start
         self.opt = share['opt']
+        if self.cnn_trainable and 'opt_cnn' not in share:
+            # gradient_multipliers scale the whole CNN gradient, L2 term included (model_base.py:388-401)
+            enc = self._encoder_for(self._batch_size)
+            mult = float(getattr(c, 'cnn_grad_multiplier', 1.0))
+            l2 = getattr(c, 'l2_decay', 1e-5) * mult
+            share['opt_cnn'] = (optim.AdamTF(enc.w_master, epsilon=c.adam_epsilon, l2_decay=l2),
+                                optim.AdamTF(enc.beta, epsilon=c.adam_epsilon, l2_decay=l2), mult)
 
     @property
     def global_step(self):
@@ -136,6 +166,12 @@ class ModelBase(object):
             if 'optimise/caption/adam_m' in extra:
                 o.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_m']))
                 o.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v']))
+            if 'optimise/caption/cnn_w_adam_m' in extra and 'opt_cnn' in self._share:
+                ow, ob, _ = self._share['opt_cnn']
+                ow.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_m']))
+                ow.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_v']))
+                ob.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_b_adam_m']))
+                ob.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_b_adam_v']))
             print('INFO: Resume training from checkpoint: {}'.format(path))
         if not self.is_training():
             return None
@@ -148,6 +184,14 @@ class ModelBase(object):
         if not compact and 'opt' in self._share:
             o = self._share['opt']
             extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(), 'optimise/caption/adam_v': o.v.data.cpu().numpy()}
+        if 'opt_cnn' in self._share:      # fine-tuned CNN variables back into the checkpoint layout
+            self._share['cnn_params'].update(next(iter(self._share['encoders'].values())).export_params())
+            if not compact:
+                ow, ob, _ = self._share['opt_cnn']
+                extra.update({'optimise/caption/cnn_w_adam_m': ow.m.data.cpu().numpy(),
+                              'optimise/caption/cnn_w_adam_v': ow.v.data.cpu().numpy(),
+                              'optimise/caption/cnn_b_adam_m': ob.m.data.cpu().numpy(),
+                              'optimise/caption/cnn_b_adam_v': ob.v.data.cpu().numpy()})
         return ckpt.save(save_path, self.global_step, self._share['cnn_params'], self.spec,
                          self.decoder.params.to_numpy(), extra, max_to_keep)
 
@@ -194,7 +238,11 @@ class CaptionModel(ModelBase):
         if self.dp.world > 1:
             denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
         lr = self.lr
-        res = self.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=True)
+        ft = self.cnn_trainable
+        res = self.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=not ft,
+                                      want_input_grads=ft)
+        if ft:
+            self._cnn_update(res, lr)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, lr, grad_scale=scale)
         self.dec_log_ppl = res['loss']

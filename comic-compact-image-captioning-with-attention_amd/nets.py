@@ -297,7 +297,7 @@ class CnnEncoder:
     """Device-resident encoder: packed weights, folded BN, activation buffers, one native
     forward call.  `dtype` 'bf16' (throughput path) or 'f32' (exact-fp32 MFMA, parity path)."""
 
-    def __init__(self, plan: CnnPlan, params: dict, batch: int, dtype='bf16', device='cuda:0'):
+    def __init__(self, plan: CnnPlan, params: dict, batch: int, dtype='bf16', device='cuda:0', weights_from=None):
         import torch
         from .decoder import FlatParams
         self.torch = torch
@@ -310,43 +310,52 @@ class CnnEncoder:
         # fp32 masters in the packed kernel layout ([Cout][Kpad]; stem [K][Cout]) in ONE flat buffer, BN
         # vectors in a second one: the forward reads a plan-dtype copy of the first (the fp32 plan reads
         # the masters themselves), cnn_finetune trains both (comic_cnn_backward + AdamTF on the flats)
-        wshapes, bshapes = {}, {}
-        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-            K = kh * kw * cin
-            wshapes['w%d' % i] = (K * cout,) if stem else (cout * ((K + 63) // 64 * 64),)
-            bshapes['b%d' % i] = (cout,)
-        self.w_master = FlatParams(wshapes, device)
-        self.beta = FlatParams(bshapes, device)
-        self.mean, self.scale, self.shift = self.beta.like(), self.beta.like(), self.beta.like()
-        self.scale.data.fill_(1.0)
-        self.w_plan = self.w_master.data if self.dcode == 0 else torch.zeros(self.w_master.numel, dtype=tdt,
-                                                                              device=device)
-        wt = (L.ConvWeight * len(plan.weights))()
-        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-            w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(device)
-            assert tuple(w.shape) == (kh, kw, cin, cout), prefix
-            beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
-                params[prefix + '/BatchNorm/' + s], np.float32)).to(device)
-                for s in ('beta', 'moving_mean', 'moving_variance'))
-            bk = 'b%d' % i
-            self.beta.view(bk).copy_(beta)
-            self.mean.view(bk).copy_(mean)
-            L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
-                                           self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
-                    'fold_bn')
-            master = self.w_master.view('w%d' % i)
-            if stem:
-                master.copy_(w.reshape(-1))
-            else:
-                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
-                        'pack_conv_weights')
-            esz = 4 if (stem or self.dcode == 0) else 2
-            wbase = self.w_master.data.data_ptr() if (stem or self.dcode == 0) else self.w_plan.data_ptr()
-            wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
-            wt[i].scale = self.scale.view(bk).data_ptr()
-            wt[i].shift = self.shift.view(bk).data_ptr()
+        if weights_from is not None:
+            # a second encoder (other batch size) over the SAME variables, like the reference's
+            # reuse=True graphs (train_fn.py:60-66): alias the flat buffers and the weight table
+            o = weights_from
+            assert o.plan.weights == plan.weights and o.dtype == dtype
+            self.w_master, self.beta, self.mean, self.scale, self.shift = o.w_master, o.beta, o.mean, o.scale, o.shift
+            self.w_plan, wt = o.w_plan, o._wt
+        else:
+            wshapes, bshapes = {}, {}
+            for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+                K = kh * kw * cin
+                wshapes['w%d' % i] = (K * cout,) if stem else (cout * ((K + 63) // 64 * 64),)
+                bshapes['b%d' % i] = (cout,)
+            self.w_master = FlatParams(wshapes, device)
+            self.beta = FlatParams(bshapes, device)
+            self.mean, self.scale, self.shift = self.beta.like(), self.beta.like(), self.beta.like()
+            self.scale.data.fill_(1.0)
+            self.w_plan = self.w_master.data if self.dcode == 0 else torch.zeros(self.w_master.numel, dtype=tdt,
+                                                                                  device=device)
+            wt = (L.ConvWeight * len(plan.weights))()
+            for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+                w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(device)
+                assert tuple(w.shape) == (kh, kw, cin, cout), prefix
+                beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
+                    params[prefix + '/BatchNorm/' + s], np.float32)).to(device)
+                    for s in ('beta', 'moving_mean', 'moving_variance'))
+                bk = 'b%d' % i
+                self.beta.view(bk).copy_(beta)
+                self.mean.view(bk).copy_(mean)
+                L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
+                                               self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
+                        'fold_bn')
+                master = self.w_master.view('w%d' % i)
+                if stem:
+                    master.copy_(w.reshape(-1))
+                else:
+                    L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
+                            'pack_conv_weights')
+                esz = 4 if (stem or self.dcode == 0) else 2
+                wbase = self.w_master.data.data_ptr() if (stem or self.dcode == 0) else self.w_plan.data_ptr()
+                wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
+                wt[i].scale = self.scale.view(bk).data_ptr()
+                wt[i].shift = self.shift.view(bk).data_ptr()
         self._train = None
-        self.refresh_weights()
+        if weights_from is None:
+            self.refresh_weights()
         torch.cuda.synchronize()
         self._wt = wt
         self.bufs = []

@@ -88,6 +88,38 @@ class CaptionTrainer:
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res
 
+    def enable_cnn_finetune(self, cnn_grad_multiplier=1.0):
+        """train_mode cnn_finetune (train.py:241-249): the CNN variables join the trainable set."""
+        mult = float(cnn_grad_multiplier)
+        l2 = self.opt.l2 * mult
+        self.opt_cnn = (optim.AdamTF(self.encoder.w_master, epsilon=self.opt.eps, l2_decay=l2),
+                        optim.AdamTF(self.encoder.beta, epsilon=self.opt.eps, l2_decay=l2), mult)
+        self.encoder.enable_training()
+
+    def finetune_step(self, images, captions, masks=None, training=True):
+        """One cnn_finetune update: CNN forward -> decoder forward/backward (with input gradients)
+        -> CNN backward -> [all-reduce] -> TF-Adam on decoder and CNN variables -> weight refresh."""
+        assert getattr(self, 'opt_cnn', None), 'enable_cnn_finetune() first'
+        im_embed, fm = self.encoder.forward(images, use_graph=self.use_graph)
+        cap = np.asarray(captions)
+        denom = None
+        if self.dp.world > 1:
+            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+                                      use_graph=False, want_input_grads=True)
+        t = self.encoder.backward(res['dfm'], res['dim_embed'])
+        lr = self.lr()
+        ow, ob, mult = self.opt_cnn
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.dp.average_(t.dw.data)
+        self.dp.average_(t.dbeta.data)
+        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        ow.t = ob.t = self.opt.t - 1
+        ow.step(t.dw, lr, grad_scale=scale * mult)
+        ob.step(t.dbeta, lr, grad_scale=scale * mult)
+        self.encoder.refresh_weights()
+        return res
+
     def submit_images(self, images):
         """Start the encoder forward of a future step on the side stream (frozen-CNN modes)."""
         torch = self._torch

@@ -138,8 +138,6 @@ def build_kwargs(args):
 def main(argv=None):
     args = create_parser().parse_args(argv)
     kwargs, train_fn_name, overwrite = build_kwargs(args)
-    if kwargs['train_mode'] == 'cnn_finetune':
-        raise NotImplementedError('cnn_finetune needs the conv backward kernels (SURVEY §8f, next round)')
     import torch
     import torch.distributed as dist
     from comic_amd import train_fn as train

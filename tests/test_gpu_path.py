@@ -281,6 +281,62 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
 
 
+def test_cnn_finetune_step_end_to_end():
+    """train_mode cnn_finetune on a shallow stack: CNN forward -> decoder XE step -> CNN backward
+    -> TF-Adam on decoder AND CNN variables, against the oracle chain (cnn_ref reverse pass fed by
+    decoder_ref's input gradients, then adam_tf_update); two steps, so the second one runs on the
+    refreshed weights.  fp32 plan."""
+    from comic_amd import trainer
+    B, size, Lc = 3, 63, 9
+    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN)
+    cnn_p = cnn_ref.randomize_bn(plan.init_params(seed=3), seed=4)
+    Hf, Wf, Cf, _ = plan.buffers[plan.fm]
+    spec, cfg = _spec_and_cfg(C=Cf, Cg=Cf, M=Hf * Wf, l2_decay=0.0)
+    cfg.l2_decay = 0.0
+    p = _rand_params(cfg, 3)
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1, 1, (B, size, size, 3)).astype(np.float32)
+    _, _, caps = _batch(spec, B, Lc, 7)
+    lr, eps = 1e-2, 1e-2
+    tr = trainer.CaptionTrainer(cnn_p, spec, p, B, (size, size), 'f32', DEV, lr_start=lr, lr_end=lr, max_step=10,
+                                adam_epsilon=eps, plan=plan)
+    tr.use_graph = False
+    tr.enable_cnn_finetune()
+    # oracle state
+    names = sorted(k for k in cnn_p if k.endswith('weights') or k.endswith('beta'))
+    ow = {k: cnn_p[k].copy() for k in cnn_p}
+    om = {k: np.zeros_like(cnn_p[k]) for k in names}
+    ov = {k: np.zeros_like(cnn_p[k]) for k in names}
+    dm = {k: np.zeros_like(v) for k, v in p.items()}
+    dv = {k: np.zeros_like(v) for k, v in p.items()}
+    dp_ = {k: v.copy() for k, v in p.items()}
+    for step in (1, 2):
+        res = tr.finetune_step(dev(x), caps, training=False)
+        sync()
+        n = cnn_ref._Net(ow, None, act_dtype='f32', run=True, tape=True)
+        n.scope.append('Chain')
+        h = x
+        for op in _CHAIN:
+            h = n.conv(h, op[2], op[3], op[4], op[5], op[1]) if op[0] == 'c' else (
+                n.max_pool(h, 3, 2, 'VALID') if op[0] == 'max' else n.avg_pool(h, 3, 1, 'SAME'))
+        pooled = n.avg_pool(h, (h.shape[1], h.shape[2]), 1, 'VALID')
+        out = dr.train_forward(dp_, cfg, h.reshape(B, Hf * Wf, Cf), pooled.reshape(B, Cf), caps, None, None)
+        grads, dfm, dim = dr.train_backward(dp_, cfg, out)
+        assert abs(float(res['loss']) - float(out['xe'])) <= 2e-3 * abs(float(out['xe'])) + 1e-6, step
+        g = n.backward([(pooled, dim.reshape(pooled.shape)), (h, dfm.reshape(h.shape))])
+        for k in names:
+            dr.adam_tf_update(ow[k], np.asarray(g[k], np.float32), om[k], ov[k], step, lr, eps=eps)
+        for k in grads:
+            dr.adam_tf_update(dp_[k], grads[k], dm[k], dv[k], step, lr, eps=eps)
+    got = tr.encoder.export_params()
+    for k in names:
+        # compare the UPDATE (w - w0): the variables themselves barely move in two steps
+        assert_close(got[k] - cnn_p[k], ow[k] - cnn_p[k], 5e-3, 'finetune update ' + k)
+    gd = tr.decoder.params.to_numpy()
+    for k in ('K', 'W_q', 'W_m', 'W_o'):
+        assert_close(gd[k] - p[k], dp_[k] - p[k], 5e-3, 'decoder update ' + k)
+
+
 def test_known_answer_param_count_on_device():
     """README.md:222 '4.3 M' -> 4 297 987 (SURVEY §8 a-P); InceptionV3 variant 5 707 011."""
     s1 = cdec.DecoderSpec(C=832, Cg=1024, M=196)
