@@ -1266,51 +1266,58 @@ struct ActGradArgs {
   int B, Ho, Wo, C, Hd, Wd, dil;
 };
 
+// grid (pixel chunks, ceil(C/64)); 256 threads = (64/EPC channel chunks) x (pixel lanes).  Besides dz
+// the workgroup reduces its share of d beta[c] = sum_pixels 1[y>0] dy (unscaled) in LDS and adds
+// it to the fp32 accumulator with one atomic per channel.
 template <typename T>
-__global__ __launch_bounds__(256) void act_grad_kernel(ActGradArgs a) {
+__global__ __launch_bounds__(256) void act_grad_kernel(ActGradArgs a, float* __restrict__ dbeta, long px_per_block) {
   constexpr int EPC = Elem<T>::EPC;
-  const int cvecs = a.C / EPC;
-  const long total = (long)a.B * a.Ho * a.Wo * cvecs;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int cv = (int)(idx % cvecs);
-  long p = idx / cvecs;
-  const int wo = (int)(p % a.Wo);
-  const long q = p / a.Wo;
-  const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
-  float yv[EPC], gv[EPC];
-  const size_t src = (size_t)p * a.ycs + a.yco + cv * EPC;
-  load_chunk_f<T>(a.y, src, a.yf32 != 0, yv);
-  load_chunk_f<T>(a.dy, src, a.yf32 != 0, gv);
+  constexpr int CPB = 64 / EPC;        // channel chunks per workgroup
+  constexpr int PL = 256 / CPB;        // pixel lanes
+  __shared__ float red[PL][64 + 1];
+  const int tid = threadIdx.x;
+  const int cc = tid % CPB, pl = tid / CPB;
+  const int c0 = blockIdx.y * 64 + cc * EPC;
+  const bool cok = c0 < a.C;           // C % EPC == 0
+  const long P = (long)a.B * a.Ho * a.Wo;
+  const long p0 = (long)blockIdx.x * px_per_block, p1 = min(P, p0 + px_per_block);
+  float sc[EPC], sum[EPC];
 #pragma unroll
-  for (int i = 0; i < EPC; ++i) gv[i] = yv[i] > 0.f ? gv[i] * a.scale[cv * EPC + i] : 0.f;
-  const size_t dst = (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.C + cv * EPC;
-  store_chunk_f<T>(a.dz, dst, false, gv);
-}
-
-// column sums of dz [rows][C] (plan dtype) -> partial[R][C] fp32, then d beta[c] = sum / scale[c]
-template <typename T>
-__global__ void dz_colsum_part_kernel(const T* __restrict__ dz, float* __restrict__ part, long rows, int C,
-                                      long rows_per_chunk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    if (sizeof(T) == 4)
-      s += ((const float*)dz)[(size_t)r * C + c];
-    else
-      s += bf16_to_f32(((const bf16_t*)dz)[(size_t)r * C + c]);
+  for (int i = 0; i < EPC; ++i) {
+    sc[i] = cok ? a.scale[c0 + i] : 0.f;
+    sum[i] = 0.f;
   }
-  part[(size_t)blockIdx.y * C + c] = s;
-}
-__global__ void dbeta_final_kernel(const float* __restrict__ part, const float* __restrict__ scale,
-                                   float* __restrict__ dbeta, int R, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += part[(size_t)r * C + c];
-  dbeta[c] += s / scale[c];
+  if (cok) {
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const int wo = (int)(p % a.Wo);
+      const long q = p / a.Wo;
+      const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
+      float yv[EPC], gv[EPC];
+      const size_t src = (size_t)p * a.ycs + a.yco + c0;
+      load_chunk_f<T>(a.y, src, a.yf32 != 0, yv);
+      load_chunk_f<T>(a.dy, src, a.yf32 != 0, gv);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) {
+        const float g = yv[i] > 0.f ? gv[i] : 0.f;
+        sum[i] += g;
+        gv[i] = g * sc[i];
+      }
+      const size_t dst = (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.C + c0;
+      store_chunk_f<T>(a.dz, dst, false, gv);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) red[pl][cc * EPC + i] = sum[i];
+  __syncthreads();
+  if (tid < 64) {
+    const int c = blockIdx.y * 64 + tid;
+    if (c < a.C) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < PL; ++r) s += red[r][tid];
+      atomicAdd(dbeta + c, s);
+    }
+  }
 }
 
 // master [Cout][Kpad] (k = (kh*KW + kw)*Cin + ci) -> backward-data filter [Cin][Kpad2],
@@ -1580,28 +1587,17 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   const int Wd = dil == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
   COMIC_REQUIRE(Hd >= (op->Ho - 1) * dil + 1 && Wd >= (op->Wo - 1) * dil + 1, "conv backward: dilated geometry");
   const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
-  const int R = 128;
-  const size_t part_bytes = (size_t)R * op->Cout * sizeof(float);
-  COMIC_REQUIRE((int64_t)(dz_bytes + part_bytes) <= scratch_bytes, "conv backward: scratch too small (%zu needed)",
-                dz_bytes + part_bytes);
+  COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward: scratch too small (%zu needed)", dz_bytes);
   T* dz = (T*)scratch;
-  float* part = (float*)((char*)scratch + dz_bytes);
   if (dil > 1) {
     COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward: memset failed");
   }
   {
     ActGradArgs a{y, gy, yc, op->dst_coff, op->out_f32, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
-    const long total = (long)batch * op->Ho * op->Wo * (op->Cout / EPC);
-    hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
-  }
-  {
-    const long rows = (long)batch * Hd * Wd;
-    const long rpc = cdiv64(rows, R);
-    const int Ract = (int)cdiv64(rows, rpc);
-    hipLaunchKernelGGL((dz_colsum_part_kernel<T>), dim3(cdiv(op->Cout, 64), Ract), dim3(64), 0, st, (const T*)dz, part,
-                       rows, op->Cout, rpc);
-    hipLaunchKernelGGL(dbeta_final_kernel, dim3(cdiv(op->Cout, 64)), dim3(64), 0, st, (const float*)part, wt->scale,
-                       gr->dbeta, Ract, op->Cout);
+    const long P = (long)batch * op->Ho * op->Wo;
+    const long ppb = std::max<long>(64, cdiv64(P, 512));
+    hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(P, ppb), cdiv(op->Cout, 64)), dim3(256), 0, st, a,
+                       gr->dbeta, ppb);
   }
   {
     WgradArgs a{};
@@ -1701,7 +1697,7 @@ extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int
     const int Hd = op->SH == 1 ? op->Ho : op->H - op->KH + 1 + 2 * op->PT;
     const int Wd = op->SW == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
     const size_t dz = ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
-    best = std::max(best, dz + (size_t)128 * op->Cout * sizeof(float));
+    best = std::max(best, dz);
   }
   return (int64_t)best;
 }

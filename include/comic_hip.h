@@ -117,7 +117,7 @@ int comic_cnn_forward_grouped(const comic_cnn_op* ops, int n_ops, void* const* b
  *   w_master  fp32 packed [Cout][Kpad] (stem: [K][Cout]) -- the trainable copy
  *   dw        fp32, same layout, accumulated (atomics: summation order over pixel slices is
  *             not fixed; zero it per step)
- *   dbeta     fp32 [Cout], accumulated
+ *   dbeta     fp32 [Cout], accumulated (atomics)
  *   w_bwd     plan-dtype scratch of Cin * roundup64(KH*KW*Cout) elements for the flipped /
  *             transposed filter of the backward-data pass (NULL for the stem conv)
  * comic_cnn_refresh_weights re-derives the plan-dtype weight copy (flat bf16 conversion of all
