@@ -152,7 +152,8 @@ class ModelBase(object):
                                        getattr(c, 'checkpoint_exclude_scopes', ''))
         if cnn:
             self._share['cnn_params'].update(cnn)
-            self._share['encoders'].clear()          # repack weights on next use
+            for enc in list(self._share['encoders'].values())[:1]:
+                enc.load_params(self._share['cnn_params'])      # in place: shared by every encoder / optimiser
         if dec is not None:
             cur = self.decoder.params.to_numpy()
             cur.update(dec)

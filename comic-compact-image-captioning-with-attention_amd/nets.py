@@ -331,31 +331,14 @@ class CnnEncoder:
                                                                                   device=device)
             wt = (L.ConvWeight * len(plan.weights))()
             for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-                w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(device)
-                assert tuple(w.shape) == (kh, kw, cin, cout), prefix
-                beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
-                    params[prefix + '/BatchNorm/' + s], np.float32)).to(device)
-                    for s in ('beta', 'moving_mean', 'moving_variance'))
                 bk = 'b%d' % i
-                self.beta.view(bk).copy_(beta)
-                self.mean.view(bk).copy_(mean)
-                L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
-                                               self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
-                        'fold_bn')
-                master = self.w_master.view('w%d' % i)
-                if stem:
-                    master.copy_(w.reshape(-1))
-                else:
-                    L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
-                            'pack_conv_weights')
                 esz = 4 if (stem or self.dcode == 0) else 2
                 wbase = self.w_master.data.data_ptr() if (stem or self.dcode == 0) else self.w_plan.data_ptr()
                 wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
                 wt[i].scale = self.scale.view(bk).data_ptr()
                 wt[i].shift = self.shift.view(bk).data_ptr()
+            self.load_params(params)
         self._train = None
-        if weights_from is None:
-            self.refresh_weights()
         torch.cuda.synchronize()
         self._wt = wt
         self.bufs = []
@@ -375,6 +358,31 @@ class CnnEncoder:
         self._build_group_args()
         self._graph = None
         self._calls = 0
+
+    def load_params(self, params):
+        """(Re)load every CNN variable from {slim name: array} into the flat masters IN PLACE (all
+        encoders that share them, and any optimiser bound to them, see the new values)."""
+        torch, st = self.torch, L.stream_ptr()
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(self.device)
+            assert tuple(w.shape) == (kh, kw, cin, cout), prefix
+            beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
+                params[prefix + '/BatchNorm/' + s], np.float32)).to(self.device)
+                for s in ('beta', 'moving_mean', 'moving_variance'))
+            bk = 'b%d' % i
+            self.beta.view(bk).copy_(beta)
+            self.mean.view(bk).copy_(mean)
+            L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
+                                           self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
+                    'fold_bn')
+            master = self.w_master.view('w%d' % i)
+            if stem:
+                master.copy_(w.reshape(-1))
+            else:
+                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
+                        'pack_conv_weights')
+        self.refresh_weights()
+        torch.cuda.synchronize()
 
     def refresh_weights(self):
         """Re-derive what the forward reads from the fp32 masters: the plan-dtype weight copy and

@@ -1,5 +1,7 @@
 """End-to-end CLI test on the GPU: train.py (decoder-mode XE) -> infer.py (beam 3) ->
-train.py --train_mode scst on a tiny dataset in the reference's file formats."""
+train.py --train_mode cnn_finetune -> train.py --train_mode scst, chained through the run
+directories exactly as the reference does (train.py:232-269), on a tiny dataset in the
+reference's file formats."""
 import glob
 import json
 import os
@@ -48,9 +50,21 @@ def test_train_infer_scst_cli(tmp_path):
     data = json.load(open(caps[0]))
     assert len(data) == 4 and all(set(d) == {'image_id', 'caption'} for d in data)
     assert os.path.isfile(os.path.join(out_dir, 'infer_speed.txt'))
-    # ---- SCST (the reference chains decoder -> cnn_finetune -> scst; the fine-tune stage is
-    # not built yet, so its run directory is a copy of the decoder run) ----
-    shutil.copytree(run_dir, run_dir.replace('_run_01', '_cnnFT_run_01'))
+    # ---- CNN fine-tune: restores the decoder run, trains CNN + decoder, saves both ----
+    _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '8',
+                                                          '--max_epoch', '1'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    ft_dir = run_dir.replace('_run_01', '_cnnFT_run_01')
+    ft_ckpts = sorted(glob.glob(os.path.join(ft_dir, 'model_compact-*.npz')))
+    assert ft_ckpts, os.listdir(ft_dir)
+    a, b = np.load(ckpts[-1]), np.load(ft_ckpts[-1])
+    k = 'InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights'
+    k = [n for n in a.files if n.endswith(k)][0]
+    assert a[k].shape == b[k].shape and not np.array_equal(a[k], b[k]), 'CNN variables were not trained'
+    km = [n for n in a.files if n.endswith('Mixed_7c/Branch_0/Conv2d_0a_1x1/BatchNorm/moving_mean')][0]
+    np.testing.assert_array_equal(a[km], b[km])         # BN statistics stay frozen (model_base.py:76)
+    # ---- SCST on top of the fine-tuned run ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'scst', '--max_epoch', '2',
                                                           '--scst_beam_size', '3'])
     errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
