@@ -121,6 +121,25 @@ def extras(device, enc, cnn_params, plan):
     torch.cuda.synchronize()
     out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
     out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-image step'
+    del enc_s, enc_t, dec, opt
+    torch.cuda.empty_cache()
+    # ---- cnn_finetune step (configs[2]: CNN + decoder trainable, batch 32) ---------------------
+    from comic_amd import trainer
+    Bf = 32
+    tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16', device, seed=5, plan=plan)
+    tr.enable_cnn_finetune()
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (Bf, IMG, IMG, 3)).astype(np.float32)).to(device)
+    caps = synth_captions(rng, Bf)
+    for _ in range(3):
+        tr.finetune_step(imgs, caps)
+    torch.cuda.synchronize()
+    n, t0 = 10, time.perf_counter()
+    for _ in range(n):
+        res = tr.finetune_step(imgs, caps)
+    torch.cuda.synchronize()
+    out['cnn_finetune_images_per_sec'] = round(Bf * n / (time.perf_counter() - t0), 1)
+    out['cnn_finetune_config'] = ('COMIC-256 + InceptionV3 trainable (94 conv weights + BN betas, bf16 activations / '
+                                  'fp32 masters), batch 32, 224x224; loss %.4f' % float(res['loss']))
     return out
 
 

@@ -1498,6 +1498,139 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// bf16 fast path of the backward-weight product: operand tiles stay pixel-major in LDS (16-byte
+// stores, no scalar transposition) and the MFMA fragments are gathered with the CDNA4 transposing
+// read ds_read_b64_tr_b16 (4 pixel rows x 16 channels per 16-lane group, delivered channel-major).
+// k index <-> pixel mapping of a 32-pixel step: k = 8g + e  <->  pixel 4*(g + 4*(e >> 2)) + (e & 3), the
+// same for both operands, so that the two 16-lane groups of a 32-lane half touch 8 consecutive pixel
+// rows; with a row stride of 32*odd bytes those are 64 distinct banks (conflict-free).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+template <int BM, int BN>   // BM output channels x BN filter taps*channels per workgroup
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs a) {
+  constexpr int ZS = BM * 2 + 32, XS = BN * 2 + 32;       // LDS row strides in bytes (32 * odd)
+  constexpr int ZCH = BM / 64, XCH = BN / 64;             // 16-byte chunks per thread per step
+  constexpr int TM = BM / 32, TN = BN / 32;               // 16x16 tiles per wave (2 x 2 waves)
+  static_assert((ZS / 32) % 2 == 1 && (XS / 32) % 2 == 1, "bank-conflict-free row strides");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 32 * (ZS + XS)];
+  unsigned char* Zs = smem;                    // [2][32 px][ZS]
+  unsigned char* Xs = smem + 2 * 32 * ZS;      // [2][32 px][XS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kk0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
+  const long p_begin = (long)blockIdx.z * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
+  const int px_l = tid >> 3, cg = tid & 7;     // pixel of the step, 8-channel chunk inside 64 channels
+  // fixed channel chunks of this thread
+  int co_c[ZCH];
+  bool co_ok[ZCH];
+#pragma unroll
+  for (int i = 0; i < ZCH; ++i) {
+    co_c[i] = co0 + i * 64 + cg * 8;
+    co_ok[i] = co_c[i] < a.Cout;
+  }
+  int kh[XCH], kw[XCH], ci[XCH];
+  bool kk_ok[XCH];
+#pragma unroll
+  for (int i = 0; i < XCH; ++i) {
+    const int kk = kk0 + i * 64 + cg * 8;
+    kk_ok[i] = kk < a.K;
+    const int tap = kk_ok[i] ? kk / a.Cin : 0;
+    ci[i] = kk_ok[i] ? kk % a.Cin : 0;
+    kh[i] = tap / a.KW;
+    kw[i] = tap % a.KW;
+  }
+  const int hw = a.Ho * a.Wo;
+  uint4 zreg[ZCH], xreg[XCH];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  auto load_tile = [&](long pbase) {
+    const long p = pbase + px_l;
+#pragma unroll
+    for (int i = 0; i < ZCH; ++i) zreg[i] = zero4;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) xreg[i] = zero4;
+    if (p >= p_end) return;
+    const int b = (int)(p / hw);
+    const int rem = (int)(p - (long)b * hw);
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    const bf16_t* zp = (const bf16_t*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.Cout;
+#pragma unroll
+    for (int i = 0; i < ZCH; ++i)
+      if (co_ok[i]) zreg[i] = *(const uint4*)(zp + co_c[i]);
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int hi = ho * a.SH - a.PT + kh[i], wi = wo * a.SW - a.PL + kw[i];
+      if (kk_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+        xreg[i] = *(const uint4*)((const bf16_t*)a.x + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + ci[i]);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < ZCH; ++i) *(uint4*)(Zs + (buf * 32 + px_l) * ZS + (i * 64 + cg * 8) * 2) = zreg[i];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) *(uint4*)(Xs + (buf * 32 + px_l) * XS + (i * 64 + cg * 8) * 2) = xreg[i];
+  };
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // transposing-read lane addressing: 16-lane group g, lane j = 4q + p supplies row q, columns 4p..4p+3
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const uint32_t zs0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)Zs);
+  const uint32_t xs0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)Xs);
+  const uint32_t zlane = (4 * g + q) * ZS + (wn * (BM / 2) + 4 * pp) * 2;   // + 16*ZS for the second half
+  const uint32_t xlane = (4 * g + q) * XS + (wm * (BN / 2) + 4 * pp) * 2;
+  auto tr_read = [&](uint32_t addr) -> s16x4_t {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)addr);
+  };
+
+  if (p_begin < p_end) {
+    load_tile(p_begin);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (long pb = p_begin; pb < p_end; pb += 32, buf ^= 1) {
+      const bool more = pb + 32 < p_end;
+      if (more) load_tile(pb + 32);
+      const uint32_t zb = zs0 + buf * 32 * ZS + zlane, xb = xs0 + buf * 32 * XS + xlane;
+      s16x8_t zf[TM], xf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4_t lo = tr_read(zb + i * 32), hi = tr_read(zb + i * 32 + 16 * ZS);
+        zf[i] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const s16x4_t lo = tr_read(xb + j * 32), hi = tr_read(xb + j * 32 + 16 * XS);
+        xf[j] = (s16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, zf[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  const int kcol = lane & 15, cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int kk = kk0 + wm * (BN / 2) + j * 16 + kcol;
+      if (kk >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wn * (BM / 2) + i * 16 + cq + r;
+        if (co >= a.Cout) continue;
+        atomicAdd(a.dw + (size_t)co * a.Kpad + kk, acc[i][j][r]);
+      }
+    }
+}
+
 struct PoolGradArgs {
   const void* x;    // forward input of the pool (max only)
   const void* dy;   // gradient of the pool output, slice [yco, yco + C) of ycs
@@ -1616,7 +1749,25 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
       hipLaunchKernelGGL((conv_wgrad_kernel<T, true>), grid, dim3(256), 0, st, a);
     } else {
       COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0, "conv backward: misaligned input slice");
-      hipLaunchKernelGGL((conv_wgrad_kernel<T, false>), grid, dim3(256), 0, st, a);
+      if constexpr (sizeof(T) == 2) {
+        const bool big_m = op->Cout % 128 == 0, big_n = Kpad % 128 == 0 && K >= 256;
+        const int bm = big_m ? 128 : 64, bn = big_n ? 128 : 64;
+        const int tiles2 = cdiv(K, bn) * cdiv(op->Cout, bm);
+        long S2 = std::max<long>(1, std::min<long>(1536 / tiles2, cdiv64(a.P, 32L * 8)));
+        a.p_per_split = cdiv64(cdiv64(a.P, S2), 32) * 32;
+        S2 = cdiv64(a.P, a.p_per_split);
+        dim3 g2(cdiv(K, bn), cdiv(op->Cout, bm), (unsigned)S2);
+        if (big_m && big_n)
+          hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), g2, dim3(256), 0, st, a);
+        else if (big_m)
+          hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), g2, dim3(256), 0, st, a);
+        else if (big_n)
+          hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), g2, dim3(256), 0, st, a);
+        else
+          hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), g2, dim3(256), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<T, false>), grid, dim3(256), 0, st, a);
+      }
     }
   }
   COMIC_LAUNCH_CHECK("conv backward (weights)");
