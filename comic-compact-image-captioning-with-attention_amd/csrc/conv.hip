@@ -1704,6 +1704,17 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
   store_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
 }
 
+// workgroups per backward-weight launch that the pixel split aims for (every split adds one fp32
+// atomic pass over the filter; tunable for experiments with COMIC_WGRAD_BLOCKS)
+int wgrad_blocks_target() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("COMIC_WGRAD_BLOCKS");
+    v = e ? std::max(1, atoi(e)) : 1024;
+  }
+  return v;
+}
+
 template <typename T>
 int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
                   const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
@@ -1753,7 +1764,7 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
         const bool big_m = op->Cout % 128 == 0, big_n = Kpad % 128 == 0 && K >= 256;
         const int bm = big_m ? 128 : 64, bn = big_n ? 128 : 64;
         const int tiles2 = cdiv(K, bn) * cdiv(op->Cout, bm);
-        long S2 = std::max<long>(1, std::min<long>(1536 / tiles2, cdiv64(a.P, 32L * 8)));
+        long S2 = std::max<long>(1, std::min<long>(wgrad_blocks_target() / tiles2, cdiv64(a.P, 32L * 8)));
         a.p_per_split = cdiv64(cdiv64(a.P, S2), 32) * 32;
         S2 = cdiv64(a.P, a.p_per_split);
         dim3 g2(cdiv(K, bn), cdiv(op->Cout, bm), (unsigned)S2);
