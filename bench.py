@@ -277,6 +277,7 @@ def main():
 
     if rank == 0:
         n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1))
+        n_launch = sum(1 for o in plan.ops if o['kind'] in (0, 1) and not o.get('group')) + len({o['group'] for o in plan.ops if o.get('group')})
         achieved = FLOP_PER_IMAGE_CNN * BATCH / (cnn_ms * 1e-3)
         out = {
             'metric': 'images/sec (decoder-mode XE training, COMIC-256, InceptionV3 frozen)',
@@ -287,8 +288,8 @@ def main():
                                    'frozen, batch 64/GPU, 224x224x3 (BASELINE configs[1])',
                        'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'image_size': IMG,
                        'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<bf16> (%d conv launches per step, whole '
-                                                    'InceptionV3 forward timed with HIP events)' % n_conv,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma(_grouped)_kernel<bf16> (%d convs in %d launches per '
+                                                    'step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
                          'cnn_forward_ms': round(cnn_ms, 4), 'cnn_forward_ms_not_overlapped': round(cnn_iso_ms, 4),
