@@ -59,6 +59,7 @@ _SIGS = {
     'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int]),
     'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, P, c_int64, P]),
     'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
+    'comic_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),
     'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
     'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_float, P]),

@@ -4,9 +4,15 @@ The reference saves TensorFlow V2 checkpoints `model_compact-N` (variables under
 and `model-N` (everything, incl. global_step and the Adam slots) with two Savers
 (src/train_fn.py:67-70,131-132) and restores them with the three-way logic of
 `ModelBase.restore_model` (src/model_base.py:422-490).  This module keeps the file NAMES,
-the variable NAMES and the restore logic; the container is `.npz`
-(one array per TF variable name).  Reading/writing the TF tensor-bundle container itself is
-the next row of SURVEY §8f (no real checkpoint is available offline to verify against).
+the variable NAMES and the restore logic.  Two containers:
+  * `.npz`  (default for saving: one array per TF variable name)
+  * the TF checkpoint-V2 tensor bundle `<prefix>.index` + `<prefix>.data-00000-of-00001`
+    (`tf_bundle.py`; `save(..., fmt='tf')`, restored transparently), so slim CNN checkpoints and
+    the reference's own `model_compact-N` / `model-N` files load unchanged.  The bundle code is
+    written from the published formats and pinned by round trips only (no TensorFlow here).
+In the bundle the Adam slots use tf.train.AdamOptimizer's names under the train-op scope
+(`optimise/caption/<variable>/Adam`, `/Adam_1`, `optimise/caption/beta{1,2}_power`,
+model_base.py:387-401); the `.npz` container keeps them as flat arrays.
 """
 from __future__ import annotations
 
@@ -15,6 +21,7 @@ import re
 
 import numpy as np
 
+from . import tf_bundle
 from .decoder import TF_NAMES
 
 DEC_SCOPE = 'Model/decoder/rnn_decoder/'
@@ -33,8 +40,8 @@ def decoder_var_names(spec):
     return out
 
 
-def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None, max_to_keep=None):
-    """Write `<path_prefix>-<global_step>.npz`; returns the path."""
+def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None, max_to_keep=None, fmt='npz'):
+    """Write `<path_prefix>-<global_step>.npz` (or the TF bundle pair for fmt='tf'); returns the path."""
     arrays = {}
     for k, v in cnn_params.items():
         arrays[CNN_SCOPE + k] = np.asarray(v)
@@ -43,6 +50,19 @@ def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None,
         arrays[names[k]] = np.asarray(v)
     for k, v in (extra or {}).items():
         arrays[k] = np.asarray(v)
+    if fmt == 'tf':
+        arrays['global_step'] = np.asarray(global_step, np.int64)      # tf.train.get_or_create_global_step
+        prefix = '%s-%d' % (path_prefix, int(global_step))
+        tf_bundle.write_bundle(prefix, arrays)
+        d, base = os.path.split(prefix)
+        kept = tf_bundle.update_checkpoint_state(d or '.', base)
+        if max_to_keep:
+            mine = [p for p in kept if p.rsplit('-', 1)[0] == os.path.basename(path_prefix)]
+            for p in mine[:-max_to_keep]:
+                for f in (p + '.index', tf_bundle.data_path(p)):
+                    if os.path.isfile(os.path.join(d or '.', f)):
+                        os.remove(os.path.join(d or '.', f))
+        return prefix
     arrays['global_step'] = np.asarray(global_step, np.int32)
     path = '%s-%d.npz' % (path_prefix, int(global_step))
     os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
@@ -57,19 +77,58 @@ def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None,
 
 
 def latest_checkpoint(directory, prefix='model'):
-    """tf.train.latest_checkpoint counterpart for `<prefix>-N.npz` files."""
-    pat = re.compile(r'^%s-(\d+)\.npz$' % re.escape(prefix))
-    best = None
-    for f in os.listdir(directory):
-        m = pat.match(f)
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), os.path.join(directory, f))
-    return best[1] if best else None
+    """tf.train.latest_checkpoint counterpart: the newest `<prefix>-N.npz`, else the newest TF
+    bundle `<prefix>-N.index` (returned as its prefix path)."""
+    for ext in (r'\.npz', r'\.index'):
+        pat = re.compile(r'^%s-(\d+)%s$' % (re.escape(prefix), ext))
+        best = None
+        for f in os.listdir(directory):
+            m = pat.match(f)
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), os.path.join(directory, f))
+        if best:
+            return best[1] if best[1].endswith('.npz') else best[1][:-len('.index')]
+    return None
+
+
+def is_tf_bundle(path):
+    return os.path.isfile(path + '.index') or path.endswith('.index') or path.endswith('.ckpt')
 
 
 def load(path):
+    """{variable name: array} from an `.npz` file or a TF tensor bundle (prefix, `.index` path or
+    a slim `*.ckpt` file in the older single-file naming that still is a bundle prefix)."""
+    if path.endswith('.index'):
+        path = path[:-len('.index')]
+    if os.path.isfile(path + '.index'):
+        return tf_bundle.read_bundle(path)
     with np.load(path, allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+ADAM_SCOPE = 'optimise/caption/'
+
+
+def adam_to_tf(dec_spec, m, v, t, beta1=0.9, beta2=0.999):
+    """Flat-buffer Adam state -> tf.train.AdamOptimizer's variables ({name: array}; m, v keyed like
+    the decoder parameters).  After t applied updates TF holds beta^(t+1) in the power accumulators."""
+    names = decoder_var_names(dec_spec)
+    out = {}
+    for k, n in names.items():
+        out[ADAM_SCOPE + n + '/Adam'] = np.asarray(m[k], np.float32)
+        out[ADAM_SCOPE + n + '/Adam_1'] = np.asarray(v[k], np.float32)
+    out[ADAM_SCOPE + 'beta1_power'] = np.asarray(beta1 ** (t + 1), np.float32)
+    out[ADAM_SCOPE + 'beta2_power'] = np.asarray(beta2 ** (t + 1), np.float32)
+    return out
+
+
+def adam_from_tf(dec_spec, arrays):
+    """Inverse of adam_to_tf: -> (m, v) dicts keyed like the decoder parameters, or None."""
+    names = decoder_var_names(dec_spec)
+    if not all(ADAM_SCOPE + n + '/Adam' in arrays and ADAM_SCOPE + n + '/Adam_1' in arrays for n in names.values()):
+        return None
+    return ({k: arrays[ADAM_SCOPE + n + '/Adam'] for k, n in names.items()},
+            {k: arrays[ADAM_SCOPE + n + '/Adam_1'] for k, n in names.items()})
 
 
 def restore(path, cnn_param_names, dec_spec, resume_training=False, exclude_scopes=None):

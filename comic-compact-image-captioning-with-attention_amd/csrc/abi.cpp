@@ -228,3 +228,36 @@ extern "C" int comic_scorer_score(const comic_scorer* s, const char* const* hypo
   }
   return 0;
 }
+
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78): the checksum of TensorFlow's table blocks
+// and tensor-bundle entries (checkpoint container, comic_amd/tf_bundle.py).  Host code; slicing
+// by 8 over a table built on first use.
+extern "C" uint32_t comic_crc32c(const void* data, size_t n, uint32_t crc) {
+  static uint32_t table[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+    ready = true;
+  }
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = crc ^ 0xFFFFFFFFu;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}

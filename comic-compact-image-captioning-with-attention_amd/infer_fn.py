@@ -89,7 +89,8 @@ def evaluate_model(config, curr_ckpt_path, scores_combined, valid_ppl_dict=None,
     ckpt_num = int(P_CKPT.findall(ckpt_file)[0])
     coco_json = pjoin(c.infer_save_path, 'captions___{}.json'.format(ckpt_num))
     if c.run_inference:
-        if not (os.path.isfile(curr_ckpt_path) or os.path.isfile(curr_ckpt_path + '.npz')):
+        if not (os.path.isfile(curr_ckpt_path) or os.path.isfile(curr_ckpt_path + '.npz')
+                or os.path.isfile(curr_ckpt_path + '.index')):
             print('WARNING: `{}` not found. Checkpoint skipped.'.format(ckpt_file))
             return None
         if os.path.isfile(coco_json):

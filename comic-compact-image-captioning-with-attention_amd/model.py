@@ -145,7 +145,7 @@ class ModelBase(object):
             path = ckpt.latest_checkpoint(path, 'model') or ckpt.latest_checkpoint(path, 'model_compact')
         elif not os.path.isfile(path) and os.path.isfile(path + '.npz'):
             path = path + '.npz'
-        if path is None or not os.path.isfile(path):
+        if path is None or not (os.path.isfile(path) or os.path.isfile(path + '.index')):
             raise ValueError('checkpoint not found: %s' % c.checkpoint_path)
         cnn_names = list(self.plan.param_shapes())
         cnn, dec, extra = ckpt.restore(path, cnn_names, self.spec, getattr(c, 'resume_training', False),
@@ -167,6 +167,11 @@ class ModelBase(object):
             if 'optimise/caption/adam_m' in extra:
                 o.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_m']))
                 o.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v']))
+            else:
+                slots = ckpt.adam_from_tf(self.spec, extra)        # TF bundle: per-variable Adam / Adam_1
+                if slots:
+                    o.m.load(slots[0])
+                    o.v.load(slots[1])
             if 'optimise/caption/cnn_w_adam_m' in extra and 'opt_cnn' in self._share:
                 ow, ob, _ = self._share['opt_cnn']
                 ow.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_m']))
@@ -182,9 +187,14 @@ class ModelBase(object):
 
     def save(self, save_path, compact=True, max_to_keep=None):
         extra = {}
+        fmt = getattr(self._config, 'checkpoint_format', 'npz')
         if not compact and 'opt' in self._share:
             o = self._share['opt']
-            extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(), 'optimise/caption/adam_v': o.v.data.cpu().numpy()}
+            if fmt == 'tf':
+                extra = ckpt.adam_to_tf(self.spec, o.m.to_numpy(), o.v.to_numpy(), o.t, o.beta1, o.beta2)
+            else:
+                extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(),
+                         'optimise/caption/adam_v': o.v.data.cpu().numpy()}
         if 'opt_cnn' in self._share:      # fine-tuned CNN variables back into the checkpoint layout
             self._share['cnn_params'].update(next(iter(self._share['encoders'].values())).export_params())
             if not compact:
@@ -194,7 +204,7 @@ class ModelBase(object):
                               'optimise/caption/cnn_b_adam_m': ob.m.data.cpu().numpy(),
                               'optimise/caption/cnn_b_adam_v': ob.v.data.cpu().numpy()})
         return ckpt.save(save_path, self.global_step, self._share['cnn_params'], self.spec,
-                         self.decoder.params.to_numpy(), extra, max_to_keep)
+                         self.decoder.params.to_numpy(), extra, max_to_keep, fmt=fmt)
 
     # ---- decode (model_base.py:692-757, :272-314) ----------------------------------------
     def _decode(self, images, beam_size, max_length, top_beam=True):

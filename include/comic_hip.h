@@ -22,6 +22,7 @@
 #ifndef COMIC_HIP_H_
 #define COMIC_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -335,6 +336,10 @@ void comic_scorer_destroy(comic_scorer* s);
 int comic_scorer_score(const comic_scorer* s, const char* const* hypos_host, int n,
                        const char* const* refs_host, const int32_t* refs_per_host,
                        double* out_cider_host, double* out_bleu_host, int n_threads);
+
+/* CRC-32C of a host buffer, continuing from `crc` (0 to start): checksum of the TF checkpoint-V2
+ * container the reference's tf.train.Saver reads and writes (train_fn.py:67-70,131-132). */
+uint32_t comic_crc32c(const void* data_host, size_t n, uint32_t crc);
 
 #ifdef __cplusplus
 }

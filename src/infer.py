@@ -43,7 +43,10 @@ def main(argv=None):
         args.infer_checkpoints_dir = pjoin(BASE_DIR, 'experiments', args.infer_checkpoints_dir)
     if args.infer_checkpoints == 'all':
         files = sorted(os.listdir(args.infer_checkpoints_dir), key=natural_keys)
-        files = [f[len(ckpt_prefix):-len('.npz')] for f in files if f.startswith(ckpt_prefix) and f.endswith('.npz')]
+        # `.npz` containers and TF tensor bundles (`model_compact-N.index`, like the reference's own)
+        files = [f[len(ckpt_prefix):].rsplit('.', 1)[0] for f in files
+                 if f.startswith(ckpt_prefix) and (f.endswith('.npz') or f.endswith('.index'))]
+        files = sorted(set(files), key=natural_keys)
         if len(files) > 20:
             files = files[-12:]
         args.infer_checkpoints = files
@@ -68,8 +71,9 @@ def main(argv=None):
     torch.cuda.set_device(int(str(c.gpu).split(',')[0]))
     scores_combined = {}
     for ckpt_num in c.infer_checkpoints:
-        infer.evaluate_model(config=c, curr_ckpt_path=pjoin(c.infer_checkpoints_dir, ckpt_prefix + ckpt_num + '.npz'),
-                             scores_combined=scores_combined)
+        path = pjoin(c.infer_checkpoints_dir, ckpt_prefix + ckpt_num)
+        path = path + '.npz' if os.path.isfile(path + '.npz') else path       # else: TF bundle prefix
+        infer.evaluate_model(config=c, curr_ckpt_path=path, scores_combined=scores_combined)
         print('\n')
 
 

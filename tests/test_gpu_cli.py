@@ -52,19 +52,22 @@ def test_train_infer_scst_cli(tmp_path):
     assert os.path.isfile(os.path.join(out_dir, 'infer_speed.txt'))
     # ---- CNN fine-tune: restores the decoder run, trains CNN + decoder, saves both ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '8',
-                                                          '--max_epoch', '1'])
+                                                          '--max_epoch', '1', '--checkpoint_format', 'tf'])
     errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
     assert not errs, open(errs[0]).read()
     ft_dir = run_dir.replace('_run_01', '_cnnFT_run_01')
-    ft_ckpts = sorted(glob.glob(os.path.join(ft_dir, 'model_compact-*.npz')))
-    assert ft_ckpts, os.listdir(ft_dir)
-    a, b = np.load(ckpts[-1]), np.load(ft_ckpts[-1])
-    k = 'InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights'
-    k = [n for n in a.files if n.endswith(k)][0]
+    # saved as TF checkpoint-V2 tensor bundles (the reference's own container)
+    from comic_amd import tf_bundle
+    ft_ckpts = sorted(glob.glob(os.path.join(ft_dir, 'model_compact-*.index')))
+    assert ft_ckpts and os.path.isfile(os.path.join(ft_dir, 'checkpoint')), os.listdir(ft_dir)
+    a, b = np.load(ckpts[-1]), tf_bundle.read_bundle(ft_ckpts[-1][:-len('.index')])
+    k = 'Model/encoder/cnn/InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights'
     assert a[k].shape == b[k].shape and not np.array_equal(a[k], b[k]), 'CNN variables were not trained'
-    km = [n for n in a.files if n.endswith('Mixed_7c/Branch_0/Conv2d_0a_1x1/BatchNorm/moving_mean')][0]
+    km = 'Model/encoder/cnn/InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/BatchNorm/moving_mean'
     np.testing.assert_array_equal(a[km], b[km])         # BN statistics stay frozen (model_base.py:76)
-    # ---- SCST on top of the fine-tuned run ----
+    full = tf_bundle.list_variables(sorted(glob.glob(os.path.join(ft_dir, 'model-*.index')))[-1][:-len('.index')])
+    assert 'optimise/caption/beta1_power' in full and 'global_step' in full
+    # ---- SCST on top of the fine-tuned run (restores the TF bundle) ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'scst', '--max_epoch', '2',
                                                           '--scst_beam_size', '3'])
     errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))

@@ -256,3 +256,126 @@ def test_prepro_ngrams_matches_reference_df(golden_dir):
     out = prepro_ngrams.build(lines)
     assert out['ref_len'] == g['ref_len']
     assert {' '.join(k): v for k, v in out['document_frequency'].items()} == g['document_frequency']
+
+
+# ----------------------------------------------------------------------------- TF checkpoint-V2 --
+def test_tf_bundle_crc_and_snappy_known_answers():
+    from comic_amd import tf_bundle as tb
+    assert tb.crc32c(b'123456789') == 0xE3069283          # CRC-32C check value (RFC 3720 B.4 family)
+    assert tb.crc32c(bytes(32)) == 0x8A9136AA              # RFC 3720 B.4: 32 bytes of zeros
+    assert tb.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43     # RFC 3720 B.4: 32 bytes of ones
+    assert tb.crc32c(bytes(range(32))) == 0x46DD794E       # RFC 3720 B.4: incrementing
+    native = tb._load_native_crc()
+    tb._native_crc = False                                 # pure-Python path agrees with the C one
+    try:
+        assert tb.crc32c(b'123456789') == 0xE3069283 and tb.crc32c(bytes(range(32))) == 0x46DD794E
+    finally:
+        tb._native_crc = native
+    assert tb.unmask_crc(tb.mask_crc(0xE3069283)) == 0xE3069283 and tb.mask_crc(0) == 0xA282EAD8
+    # snappy block format: literal 'abcd', 1-byte-offset copy (len 4, off 4), 2-byte-offset copy
+    # (len 5, off 8), long literal with an explicit length byte
+    long_lit = bytes(range(70))
+    stream = bytes([4 + 4 + 5 + 70]) + bytes([3 << 2]) + b'abcd' + bytes([(0 << 2) | 1, 4]) + \
+        bytes([((5 - 1) << 2) | 2, 8, 0]) + bytes([60 << 2, 69]) + long_lit
+    assert tb.snappy_uncompress(stream) == b'abcdabcd' + b'abcda' + long_lit
+    # overlapping copy (run-length): 'x' then copy len 7 off 1
+    assert tb.snappy_uncompress(bytes([8, 0, ord('x'), ((7 - 4) << 2) | 1, 1])) == b'x' * 8
+
+
+def test_tf_bundle_round_trip_and_table_structure(tmp_path, monkeypatch):
+    from comic_amd import tf_bundle as tb
+    rng = np.random.default_rng(0)
+    t = {'Model/decoder/rnn_decoder/basic_lstm_cell/kernel': rng.standard_normal((37, 20)).astype(np.float32),
+         'global_step': np.asarray(123, np.int64), 'x/ids': np.arange(5, dtype=np.int32),
+         'empty': np.zeros((0, 3), np.float32)}
+    for i in range(300):                                   # > 16 entries: restart points + prefix sharing
+        t['InceptionV3/Mixed_%03d/weights' % i] = rng.standard_normal((3, 4)).astype(np.float32)
+    monkeypatch.setattr(tb, 'BLOCK_SIZE', 2048)            # several data blocks + a real index block
+    prefix = str(tmp_path / 'model_compact-123')
+    tb.write_bundle(prefix, t)
+    assert sorted(os.listdir(tmp_path)) == ['model_compact-123.data-00000-of-00001', 'model_compact-123.index']
+    r = tb.read_bundle(prefix)
+    assert set(r) == set(t)
+    for k in t:
+        assert r[k].dtype == t[k].dtype and r[k].shape == t[k].shape and np.array_equal(r[k], t[k]), k
+    lv = tb.list_variables(prefix)
+    assert lv['global_step'] == (np.dtype(np.int64), ()) and lv['empty'][1] == (0, 3)
+    # table structure: footer magic, sorted keys, header entry first, >1 data block
+    raw = open(prefix + '.index', 'rb').read()
+    assert int.from_bytes(raw[-8:], 'little') == tb.TABLE_MAGIC and len(raw) > 48
+    items = tb._read_table(prefix + '.index')
+    keys = [k for k, _ in items]
+    assert keys[0] == b'' and keys == sorted(keys)
+    _, _, pos = tb._decode_handle(raw[-48:], 0)
+    ioff, isize, _ = tb._decode_handle(raw[-48:], pos)
+    assert len(tb._parse_block(tb._read_block(raw, ioff, isize))) > 3
+    # a flipped payload byte is caught by the entry checksum, a flipped index byte by the block checksum
+    data = bytearray(open(tb.data_path(prefix), 'rb').read())
+    data[10] ^= 1
+    open(tb.data_path(prefix), 'wb').write(bytes(data))
+    with pytest.raises(ValueError, match='checksum'):
+        tb.read_bundle(prefix)
+    idx = bytearray(raw)
+    idx[5] ^= 1
+    open(prefix + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ValueError, match='checksum'):
+        tb.list_variables(prefix)
+
+
+def test_tf_bundle_reads_snappy_compressed_blocks(tmp_path):
+    """TF's TableBuilder compresses blocks with snappy by default; build such a file by hand: one
+    data block stored as a snappy stream of literals."""
+    import struct
+    from comic_amd import tf_bundle as tb
+    arr = np.arange(6, dtype=np.float32).reshape(2, 3)
+    blk = tb._BlockBuilder()
+    blk.add(b'', tb._encode_header())
+    blk.add(b'v', tb._encode_entry(1, arr.shape, 0, arr.nbytes, tb.mask_crc(tb.crc32c(arr.tobytes()))))
+    contents = blk.finish()
+    assert len(contents) < 60
+    comp = bytes([len(contents)]) + bytes([(len(contents) - 1) << 2]) + contents      # one literal
+    prefix = str(tmp_path / 'm-1')
+    with open(prefix + '.index', 'wb') as f:
+        f.write(comp + b'\x01' + struct.pack('<I', tb.mask_crc(tb.crc32c(comp + b'\x01'))))
+        h = bytearray()
+        tb._put_varint(h, 0)
+        tb._put_varint(h, len(comp))
+        index = tb._BlockBuilder()
+        index.add(b'v', bytes(h))
+        meta = tb._emit_block(f, tb._BlockBuilder().finish())
+        ih = tb._emit_block(f, index.finish())
+        footer = meta + ih
+        f.write(footer + b'\x00' * (40 - len(footer)) + struct.pack('<Q', tb.TABLE_MAGIC))
+    open(tb.data_path(prefix), 'wb').write(arr.tobytes())
+    out = tb.read_bundle(prefix)
+    assert list(out) == ['v'] and np.array_equal(out['v'], arr)
+
+
+def test_checkpoint_tf_container_three_way_restore(tmp_path):
+    """checkpoint.save(fmt='tf') -> restore(): whole model, Adam slots under TF names, slim-style
+    CNN-only bundle (names without the Model/encoder/cnn/ prefix), latest_checkpoint."""
+    from comic_amd import checkpoint as ckpt, decoder as cdec, tf_bundle as tb
+    spec = cdec.DecoderSpec(D=16, E=8, V=20, C=12, Cg=12, H=2, M=4)
+    rng = np.random.default_rng(1)
+    dec = {k: rng.standard_normal(v).astype(np.float32) for k, v in spec.param_shapes().items()}
+    cnn = {'InceptionV3/Conv2d_1a_3x3/weights': rng.standard_normal((3, 3, 3, 4)).astype(np.float32),
+           'InceptionV3/Conv2d_1a_3x3/BatchNorm/beta': rng.standard_normal(4).astype(np.float32)}
+    m = {k: rng.standard_normal(v.shape).astype(np.float32) for k, v in dec.items()}
+    v = {k: rng.random(v.shape).astype(np.float32) for k, v in dec.items()}
+    extra = ckpt.adam_to_tf(spec, m, v, t=7)
+    p = ckpt.save(str(tmp_path / 'model'), 7, cnn, spec, dec, extra, fmt='tf')
+    assert p.endswith('model-7') and os.path.isfile(p + '.index')
+    names = tb.list_variables(p)
+    assert 'optimise/caption/beta1_power' in names and 'global_step' in names
+    assert any(n.endswith('basic_lstm_cell/kernel/Adam_1') for n in names)
+    assert ckpt.latest_checkpoint(str(tmp_path), 'model') == p and tb.latest_checkpoint(str(tmp_path)) == p
+    c2, d2, ex = ckpt.restore(p, list(cnn), spec, resume_training=True)
+    assert all(np.array_equal(c2[k], cnn[k]) for k in cnn) and all(np.array_equal(d2[k], dec[k]) for k in dec)
+    assert int(ex['global_step']) == 7
+    m2, v2 = ckpt.adam_from_tf(spec, ex)
+    assert all(np.array_equal(m2[k], m[k]) and np.array_equal(v2[k], v[k]) for k in dec)
+    np.testing.assert_allclose(ex['optimise/caption/beta2_power'], 0.999 ** 8, rtol=1e-6)
+    slim = str(tmp_path / 'inception_v3.ckpt')             # slim checkpoint: bare variable names
+    tb.write_bundle(slim, cnn)
+    c3, d3, _ = ckpt.restore(slim, list(cnn), spec)
+    assert d3 is None and all(np.array_equal(c3[k], cnn[k]) for k in cnn)
