@@ -195,6 +195,7 @@ struct AttnArgs {
   float keep_in;
   int q_parts;              // > 1: q is [q_parts][B][D] split-K partials; the reduced row goes to q_out
   float* q_out;
+  int pgrad_overwrite;      // backward: 1 = store this step's parameter-gradient row instead of adding to it
 };
 
 template <int EPL>
@@ -538,13 +539,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   reduce_store(dq_acc, a.dq + (size_t)b * D, false);
   if (a.d.method == 0 && a.pgrad) {
     float* pg = a.pgrad + (size_t)b * (3 * D + 1);
-    reduce_store(dv_acc, pg, true);
-    reduce_store(dg_acc, pg + D, true);
-    reduce_store(db_acc, pg + 2 * D, true);
+    const bool add = a.pgrad_overwrite == 0;   // executor: one row per (step, batch row), summed once at the end
+    reduce_store(dv_acc, pg, add);
+    reduce_store(dg_acc, pg + D, add);
+    reduce_store(db_acc, pg + 2 * D, add);
     if (tid == 0) {
       float dt = 0.f;
       for (int w = 0; w < kAttnWaves; ++w) dt += misc[w];
-      pg[3 * D] += dt / a.tau[0];
+      pg[3 * D] = (add ? pg[3 * D] : 0.f) + dt / a.tau[0];
     }
   }
 }
@@ -814,7 +816,8 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
 int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
                       const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
-                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st) {
+                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st,
+                      int pgrad_overwrite) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && dctx && dq && dkeys && dvalues, "attn_bwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_bwd: add_LN needs ln_g/ln_b/v/tau");
@@ -823,6 +826,7 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.keys = keys; a.values = values; a.q = q; a.ln_g = ln_g; a.ln_b = ln_b; a.v = v; a.tau = tau;
   a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
   a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad; a.lens = lens; a.t = t;
+  a.pgrad_overwrite = pgrad_overwrite;
   const size_t lds = ((size_t)d->H * d->M * 3 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
@@ -846,7 +850,7 @@ extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, 
                                    const float* dmap, float* dq, float* dkeys, float* dvalues, float* pgrad,
                                    void* stream) {
   return comic_attn_bwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, alpha, mask_alpha, keep_alpha, dctx, dmap, dq,
-                           dkeys, dvalues, pgrad, nullptr, 0, (hipStream_t)stream);
+                           dkeys, dvalues, pgrad, nullptr, 0, (hipStream_t)stream, 0);
 }
 
 // t_rows time steps of logits are processed; the [B, t_stride] tables are indexed b*t_stride + t

@@ -39,7 +39,8 @@ int comic_lstm_gates_bwd_ex(const float* gates_act, const float* c_prev, const f
 int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
                       const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
-                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st);
+                      float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st,
+                      int pgrad_overwrite);
 int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
                             float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
@@ -428,7 +429,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(B * Wd); w.take<float>(B * D); w.take<float>(B * D);          // dxh, dc, dh
   w.take<float>(B * A); w.take<float>(B * A); w.take<float>(B * Cv);          // datt, datt_live, dctx
   w.take<float>(TB * E); w.take<float>(B * M * D); w.take<float>(B * M * Cv); // demb, dkeys, dvalues
-  w.take<float>(B * (3 * D + 1)); w.take<float>(TB * M);                       // pgrad, dmap
+  w.take<float>(TB * (3 * D + 1)); w.take<float>(TB * M);                      // pgrad rows, dmap
   w.take<float>(B * (E + A));                                                  // dx_init
   w.take<char>(kSplitKBytes);                                                  // split-K partials
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
@@ -492,7 +493,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* demb = w.take<float>(TB * E);
   float* dkeys = w.take<float>((long)B * M * D);
   float* dvalues_buf = w.take<float>((long)B * M * Cv);
-  float* pgrad = w.take<float>((long)B * (3 * D + 1));
+  float* pgrad = w.take<float>(TB * (3 * D + 1));   // one attention-parameter gradient row per (step, batch row)
   float* dmap = w.take<float>(TB * M);
   float* dx_init = w.take<float>((long)B * EA);
   g_splitk_ws = w.take<char>(kSplitKBytes);
@@ -596,7 +597,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dvalues = sep_values ? dvalues_buf : dkeys;
   RC(fill(dkeys, 0.f, (long)B * M * D, st));
   if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
-  RC(fill(pgrad, 0.f, (long)B * (3 * D + 1), st));
   RC(fill(dc, 0.f, (long)B * D, st));
   RC(fill(dh, 0.f, (long)B * D, st));
   RC(fill(datt, 0.f, (long)B * A, st));
@@ -614,7 +614,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       // attn_bwd masks d(att state) by "live" itself; input_bwd keeps the finished rows' share
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, datt,
-                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues, pgrad, lens, t, st));
+                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
+                           pgrad + (size_t)t * B * (3 * D + 1), lens, t, st, 1));
       carry = 1;
     } else {
       hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
@@ -623,7 +624,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(gemm(datt_live, p->W_a, dctx, nullptr, B, Cv, D, D, D, Cv, 0, 1, 0.f, st));
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, dctx,
-                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues, pgrad, nullptr, 0, st));
+                           use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
+                           pgrad + (size_t)t * B * (3 * D + 1), nullptr, 0, st, 1));
       carry = 0;
     }
     float* dy_t = dy_all + (size_t)t * B * D;
@@ -690,7 +692,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter.
     // dg_all is free again here (its last reader, the dK GEMM, is ordered before on `st`).
     float* tmp = dg_all;
-    RC(comic_colsum(pgrad, tmp, B, 3 * D + 1, 0.f, (void*)st));
+    RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
     (void)hipMemcpyAsync(gr->v, tmp, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(gr->ln_g, tmp + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(gr->ln_b, tmp + 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
