@@ -9,6 +9,8 @@
 //   gather_tree: back-track parents from max_len-1, EOS-fill after the first EOS.
 #include <float.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -136,6 +138,163 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
   }
 }
 
+// ---- large vocabularies: the step split over `chunks` workgroups per batch entry ------------------
+// (word tokens: V = 25 599, beam 3 -> 76 797 candidates per entry; one workgroup per entry leaves
+// the GPU empty and scans them 2 + W times).  Same arithmetic and the same total order
+// (value descending, flat index ascending) as beam_step_kernel:
+//   beam_stats_kernel ..... per (entry, beam, chunk): max and sum exp(x - max) of the chunk
+//   beam_chunk_topk_kernel  per (entry, chunk): log-softmax constants from the partials, then the
+//                           chunk's own top-W candidates (W rounds over a cache-resident slice)
+//   beam_merge_kernel ..... per entry: top-W of the chunks' candidates + bookkeeping
+// The global top-W under a total order is the top-W of the union of the per-chunk top-W lists.
+__global__ __launch_bounds__(256) void beam_stats_kernel(const float* __restrict__ logits, float* __restrict__ pmax,
+                                                         float* __restrict__ psum, int W, int V, int chunks) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, w = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (V + chunks - 1) / chunks, v0 = c * per, v1 = min(V, v0 + per);
+  const float* row = logits + ((size_t)b * W + w) * V;
+  float mx = -INFINITY;
+  for (int v = v0 + tid; v < v1; v += 256) mx = fmaxf(mx, row[v]);
+  mx = wave_max(mx);
+  if (lane == 0) sh[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int v = v0 + tid; v < v1; v += 256) s += expf(row[v] - mx);
+  s = wave_sum(s);
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const size_t o = ((size_t)b * W + w) * chunks + c;
+    pmax[o] = mx;
+    psum[o] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void beam_chunk_topk_kernel(const float* __restrict__ logits,
+                                                              const float* __restrict__ log_probs,
+                                                              const int32_t* __restrict__ finished,
+                                                              const float* __restrict__ pmax,
+                                                              const float* __restrict__ psum, float* __restrict__ cand_v,
+                                                              int32_t* __restrict__ cand_i, int W, int V, int chunks,
+                                                              int end_id) {
+  __shared__ ValIdx sh[256];
+  __shared__ float s_max[64], s_logsum[64], s_lp[64];
+  __shared__ int s_fin[64], s_sel[64];
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* lg = logits + (size_t)b * W * V;
+  for (int w = tid; w < W; w += 256) {
+    const float* pm = pmax + ((size_t)b * W + w) * chunks;
+    const float* ps = psum + ((size_t)b * W + w) * chunks;
+    float mx = -INFINITY;
+    for (int k = 0; k < chunks; ++k) mx = fmaxf(mx, pm[k]);
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += ps[k] * expf(pm[k] - mx);
+    s_max[w] = mx;
+    s_logsum[w] = logf(s);
+    s_lp[w] = log_probs[b * W + w];
+    s_fin[w] = finished[b * W + w];
+  }
+  __syncthreads();
+  const int per = (V + chunks - 1) / chunks, v0 = c * per, v1 = min(V, v0 + per), nv = max(0, v1 - v0);
+  const int total = W * nv;
+  for (int r = 0; r < W; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < total; j += 256) {
+      const int w = j / nv, v = v0 + (j - w * nv);
+      const int f = w * V + v;
+      bool taken = false;
+      for (int q = 0; q < r; ++q) taken |= (s_sel[q] == f);
+      if (taken) continue;
+      float step;
+      if (s_fin[w])
+        step = (v == end_id) ? 0.f : -FLT_MAX;  // dtype.min
+      else
+        step = (lg[f] - s_max[w]) - s_logsum[w];
+      const float tot = s_lp[w] + step;
+      if (better(tot, f, bv, bi)) {
+        bv = tot;
+        bi = f;
+      }
+    }
+    const ValIdx best = block_argmax(bv, bi, sh);
+    if (tid == 0) {
+      s_sel[r] = best.i;                        // 0x7fffffff when the chunk has fewer than r+1 candidates
+      const size_t o = ((size_t)b * chunks + c) * W + r;
+      cand_v[o] = best.v;
+      cand_i[o] = best.i;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ cand_v, const int32_t* __restrict__ cand_i,
+                                                         float* __restrict__ log_probs, int32_t* __restrict__ finished,
+                                                         int64_t* __restrict__ lengths, int32_t* __restrict__ word_ids,
+                                                         int32_t* __restrict__ parent_ids, float* __restrict__ scores,
+                                                         int W, int V, int chunks, int end_id) {
+  __shared__ ValIdx sh[256];
+  __shared__ int s_fin[64], s_sel[64];
+  __shared__ float s_selv[64];
+  __shared__ long long s_len[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int w = tid; w < W; w += 256) {
+    s_fin[w] = finished[b * W + w];
+    s_len[w] = lengths[b * W + w];
+  }
+  __syncthreads();
+  const int n = chunks * W;
+  const float* cv = cand_v + (size_t)b * n;
+  const int32_t* ci = cand_i + (size_t)b * n;
+  for (int r = 0; r < W; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < n; j += 256) {
+      const int f = ci[j];
+      if (f == 0x7fffffff) continue;
+      bool taken = false;
+      for (int q = 0; q < r; ++q) taken |= (s_sel[q] == f);
+      if (taken) continue;
+      if (better(cv[j], f, bv, bi)) {
+        bv = cv[j];
+        bi = f;
+      }
+    }
+    const ValIdx best = block_argmax(bv, bi, sh);
+    if (tid == 0) {
+      int sel = best.i;
+      if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
+        sel = 0;
+        bool again = true;
+        while (again) {
+          again = false;
+          for (int q = 0; q < r; ++q)
+            if (s_sel[q] == sel) {
+              ++sel;
+              again = true;
+            }
+        }
+      }
+      s_sel[r] = sel;
+      s_selv[r] = best.v;
+    }
+    __syncthreads();
+  }
+  if (tid < W) {
+    const int f = s_sel[tid];
+    const int parent = f / V, word = f - parent * V;
+    const int prev_fin = s_fin[parent];
+    word_ids[b * W + tid] = word;
+    parent_ids[b * W + tid] = parent;
+    scores[b * W + tid] = s_selv[tid];
+    log_probs[b * W + tid] = s_selv[tid];
+    finished[b * W + tid] = (prev_fin || word == end_id) ? 1 : 0;
+    lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
+  }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ parent,
                                    float* __restrict__ out, long total, int W, int cols) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +349,32 @@ extern "C" int comic_beam_step(const float* logits, float* log_probs, int32_t* f
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, log_probs, finished,
                      lengths, word_ids, parent_ids, scores, W, V, end_id);
   COMIC_LAUNCH_CHECK("beam_step");
+  return 0;
+}
+
+// executor-internal: with a workspace and a large vocabulary the step is split over several
+// workgroups per entry (needs 2*B*W*chunks floats + B*chunks*W (float + int32))
+int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                       int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
+                       hipStream_t st) {
+  int chunks = std::max(1, std::min(32, 1024 / std::max(1, B)));
+  chunks = std::min(chunks, std::max(1, V / 1024));
+  const int64_t need = ((int64_t)2 * B * W * chunks + (int64_t)2 * B * chunks * W) * 4 + 1024;
+  if (!ws || ws_bytes < need || chunks < 2 || (long)W * V < 8192)
+    return comic_beam_step(logits, log_probs, finished, lengths, word_ids, parent_ids, scores, B, W, V, end_id,
+                           (void*)st);
+  COMIC_REQUIRE(W >= 1 && W <= 64 && (long)W * V < (1L << 31) && W <= V, "beam_step: bad beam width");
+  float* pmax = (float*)ws;
+  float* psum = pmax + (size_t)B * W * chunks;
+  float* cand_v = psum + (size_t)B * W * chunks;
+  int32_t* cand_i = (int32_t*)(cand_v + (size_t)B * chunks * W);
+  hipLaunchKernelGGL(beam_stats_kernel, dim3(chunks, W, B), dim3(256), 0, st, logits, pmax, psum, W, V, chunks);
+  hipLaunchKernelGGL(beam_chunk_topk_kernel, dim3(chunks, B), dim3(256), 0, st, logits, (const float*)log_probs,
+                     (const int32_t*)finished, (const float*)pmax, (const float*)psum, cand_v, cand_i, W, V, chunks,
+                     end_id);
+  hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, st, (const float*)cand_v, (const int32_t*)cand_i,
+                     log_probs, finished, lengths, word_ids, parent_ids, scores, W, V, chunks, end_id);
+  COMIC_LAUNCH_CHECK("beam_step (split)");
   return 0;
 }
 

@@ -46,6 +46,10 @@ int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
                             const float* bias, hipStream_t st);
 
+// decode.hip
+int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                       int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
+                       hipStream_t st);
 // decoder_fused.hip
 int comic_fused_step_supported(int D, int Wd);
 long comic_lstm_panel_floats(int D, int Wd, int mode);
@@ -846,8 +850,8 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
     RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
     int32_t* word = step_ids + (size_t)t * R;
     int32_t* parent = parent_ids + (size_t)t * R;
-    RC(comic_beam_step(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
-                       d->end_id, (void*)st));
+    RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                          d->end_id, g_splitk_ws, kSplitKBytes, st));
     const int nxt = cur ^ 1;
     RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));
     RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
