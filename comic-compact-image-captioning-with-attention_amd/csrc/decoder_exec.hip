@@ -133,6 +133,30 @@ __global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_
   xh[(size_t)r * Wd + e] = v;
 }
 
+// inference step operand: xh[r] = [ emb[ids[r]] ; att[src(r)] ; h[src(r)] ], c_in[r] = c[src(r)] with
+// src(r) = the beam-search parent of row r in the previous step (identity for greedy / step 0): the
+// embedding lookup, the three state gathers and the concat of one step in a single pass.
+__global__ void infer_prep_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                  const int32_t* __restrict__ parent, int W, const float* __restrict__ att,
+                                  const float* __restrict__ h, const float* __restrict__ c, float* __restrict__ xh,
+                                  float* __restrict__ c_in, int R, int E, int A, int D, int V) {
+  const int Wd = E + A + D, cols = Wd + D;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * cols) return;
+  const int r = (int)(i / cols), k = (int)(i % cols);
+  const int src = parent ? (r / W) * W + parent[r] : r;
+  if (k < E) {
+    const int id = ids[r];
+    xh[(size_t)r * Wd + k] = (id >= 0 && id < V) ? table[(size_t)id * E + k] : 0.f;
+  } else if (k < E + A) {
+    xh[(size_t)r * Wd + k] = att[(size_t)src * A + (k - E)];
+  } else if (k < Wd) {
+    xh[(size_t)r * Wd + k] = h[(size_t)src * D + (k - E - A)];
+  } else {
+    c_in[(size_t)r * D + (k - Wd)] = c[(size_t)src * D + (k - Wd)];
+  }
+}
+
 // context-layer path only: att_next = fin ? att_prev : att_cur ; xh_next[:, E:E+A] = drop(att_next)
 __global__ void select_att_kernel(const float* __restrict__ prev, const float* __restrict__ cur,
                                   const int32_t* __restrict__ lens, int t, float* __restrict__ dst,
@@ -405,6 +429,33 @@ int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const
   RC(gemm(sb.y, p->W_q, sb.q, nullptr, rows, D, D, D, D, D, 0, 0, 0.f, st));
   RC(comic_attn_step_fwd(&ad, keys, values, sb.q, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha,
                          alpha_d_out, sb.ctx, (void*)st));
+  if (d->context_layer) {
+    RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
+  }
+  return 0;
+}
+
+// The same wrapper step on the fused kernels: operand prep (embedding + parent gather + concat),
+// LSTM product + gates, query product left as split-K partials for the attention kernel.
+// Reads the previous step's raw outputs (c_src, h_src, att_src) through `parent`.
+int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
+                     const float* keys, const float* values, const float* kpanel, const int32_t* ids,
+                     const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
+                     StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st) {
+  const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
+  {
+    const long n = (long)rows * (Wd + D);
+    hipLaunchKernelGGL(infer_prep_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, ids, parent, W,
+                       att_src, h_src, c_src, sb.xh, c_in, rows, E, A, D, d->V);
+    COMIC_LAUNCH_CHECK("infer_prep");
+  }
+  RC(comic_lstm_step_fused(sb.xh, Wd, kpanel, p->b, c_in, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0,
+                           sb.c2, sb.h2, nullptr, 0, rows, D, Wd, st));
+  int S = 1;
+  float* part = (float*)g_splitk_ws;
+  RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
+  RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha, alpha_d_out,
+                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, st));
   if (d->context_layer) {
     RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
   }
@@ -724,6 +775,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<int32_t>(R); w.take<float>(R); w.take<int32_t>(R);        // ids, log_probs, parents
   w.take<float>(R * (2 * D + A));                                  // gather temp
   w.take<char>(kSplitKBytes);                                      // split-K partials
+  w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
   return (int64_t)w.off;
 }
 
@@ -732,7 +784,7 @@ struct InferBufs {
   float *fm_t, *im_t, *keys, *values_buf;
   InitBufs ib;
   StepBufs sb;
-  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp;
+  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel;
   int32_t *ids, *parents;
   bool ok;
 };
@@ -754,6 +806,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.ids = w.take<int32_t>(R); b.log_probs = w.take<float>(R); b.parents = w.take<int32_t>(R);
   b.gtmp = w.take<float>(R * (2 * D + A));
   g_splitk_ws = w.take<char>(kSplitKBytes);
+  b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
   b.ok = w.ok;
   return b;
 }
@@ -779,22 +832,32 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)B);
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, first_eos, max_steps, (long)B);
   COMIC_LAUNCH_CHECK("greedy init");
+  const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
+  if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   for (int t = 0; t < max_steps; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    RC(comic_embed_fwd(p->emb, ws.ids, ws.x, B, E, V, (void*)st));
     ws.sb.c2 = ws.c[nxt];
     ws.sb.h2 = ws.h[nxt];
     float* att_next = ws.att[nxt];
     StepBufs sb = ws.sb;
     if (!d->context_layer) sb.ctx = att_next;  // context written straight into the next attention state
     else sb.att2 = att_next;
-    RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
-                  attn_hist + (size_t)t * B * H * M, B, st));
+    // the ids of step t-1 are read where argmax wrote them (ids_tb), no copy
+    const int32_t* ids_in = t == 0 ? ws.ids : ids_tb + (size_t)(t - 1) * B;
+    if (fused) {
+      RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, nullptr, 1, ws.c[cur], ws.h[cur], ws.att[cur],
+                          sb, ws.gtmp, attn_hist + (size_t)t * B * H * M, B, st));
+    } else {
+      RC(comic_embed_fwd(p->emb, ids_in, ws.x, B, E, V, (void*)st));
+      RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
+                    attn_hist + (size_t)t * B * H * M, B, st));
+    }
     float* lg = logits_tb ? logits_tb + (size_t)t * B * V : ws.logits;
     RC(gemm(sb.y, p->W_o, lg, p->b_o, B, V, D, D, V, V, 0, 0, 0.f, st));
-    RC(comic_argmax_rows(lg, ws.ids, B, V, (void*)st));
-    (void)hipMemcpyAsync(ids_tb + (size_t)t * B, ws.ids, sizeof(int32_t) * B, hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(eos_track_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws.ids, first_eos, t, d->end_id, B);
+    int32_t* ids_out = ids_tb + (size_t)t * B;
+    RC(comic_argmax_rows(lg, ids_out, B, V, (void*)st));
+    hipLaunchKernelGGL(eos_track_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, (const int32_t*)ids_out, first_eos, t,
+                       d->end_id, B);
     COMIC_LAUNCH_CHECK("eos_track");
   }
   (void)Cv; (void)M;
@@ -836,27 +899,47 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)R);
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps_executed, max_steps, 1L);
   COMIC_LAUNCH_CHECK("beam init");
+  const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
+  if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   int cur = 0;
   for (int t = 0; t < max_steps; ++t) {
-    RC(comic_embed_fwd(p->emb, ws.ids, ws.x, R, E, V, (void*)st));
-    StepBufs sb = ws.sb;
-    sb.c2 = ws.gtmp;
-    sb.h2 = ws.gtmp + (size_t)R * D;
-    float* att_new = ws.gtmp + (size_t)2 * R * D;
-    if (!d->context_layer) sb.ctx = att_new;
-    else sb.att2 = att_new;
-    RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
-                  attn_hist + (size_t)t * R * H * M, R, st));
-    RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
     int32_t* word = step_ids + (size_t)t * R;
     int32_t* parent = parent_ids + (size_t)t * R;
-    RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
-                          d->end_id, g_splitk_ws, kSplitKBytes, st));
     const int nxt = cur ^ 1;
-    RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));
-    RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
-    RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));
-    (void)hipMemcpyAsync(ws.ids, word, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, st);
+    if (fused) {
+      // raw step outputs ping-pong in c/h/att[]; the NEXT step's operand prep gathers them through the
+      // parents chosen here (no gather / copy / embedding kernels in between)
+      StepBufs sb = ws.sb;
+      sb.c2 = ws.c[nxt];
+      sb.h2 = ws.h[nxt];
+      if (!d->context_layer) sb.ctx = ws.att[nxt];
+      else sb.att2 = ws.att[nxt];
+      const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
+      const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
+      RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
+                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st));
+      RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
+      RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                            d->end_id, g_splitk_ws, kSplitKBytes, st));
+    } else {
+      if (t > 0) (void)hipMemcpyAsync(ws.ids, step_ids + (size_t)(t - 1) * R, sizeof(int32_t) * R,
+                                      hipMemcpyDeviceToDevice, st);
+      RC(comic_embed_fwd(p->emb, ws.ids, ws.x, R, E, V, (void*)st));
+      StepBufs sb = ws.sb;
+      sb.c2 = ws.gtmp;
+      sb.h2 = ws.gtmp + (size_t)R * D;
+      float* att_new = ws.gtmp + (size_t)2 * R * D;
+      if (!d->context_layer) sb.ctx = att_new;
+      else sb.att2 = att_new;
+      RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
+                    attn_hist + (size_t)t * R * H * M, R, st));
+      RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
+      RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                            d->end_id, g_splitk_ws, kSplitKBytes, st));
+      RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));
+      RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
+      RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));
+    }
     hipLaunchKernelGGL(all_finished_kernel, dim3(1), dim3(256), 0, st, finished, steps_executed, t, R, max_steps);
     COMIC_LAUNCH_CHECK("all_finished");
     cur = nxt;
