@@ -67,12 +67,12 @@ def extras(device, enc, cnn_params, plan):
     max_steps = 30
     for _ in range(2):
         im, fm = enc50.forward(imgs, use_graph=True)
-        r = dec.beam_search(fm, im, 3, max_steps)
+        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
     torch.cuda.synchronize()
     n, t0 = 5, time.perf_counter()
     for _ in range(n):
         im, fm = enc50.forward(imgs, use_graph=True)
-        r = dec.beam_search(fm, im, 3, max_steps)
+        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     out['beam3_captions_per_sec'] = round(B / dt, 1)
@@ -103,7 +103,7 @@ def extras(device, enc, cnn_params, plan):
     def scst_step():
         im, fm = enc_s.forward(imgs, use_graph=True)
         greedy, _, _ = dec.greedy(fm, im, iters)
-        beam = dec.beam_search(fm, im, W, iters)['predicted_ids'].transpose(2, 1, 0)     # (W,B,T)
+        beam = dec.beam_search(fm, im, W, iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
         cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
         cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)

@@ -181,6 +181,97 @@ __global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_kernel(LstmStep
   }
 }
 
+// Wider variant: a workgroup owns NT adjacent unit tiles (4*NT hidden units) of 16 batch rows, so an
+// activation fragment feeds NT weight fragments and there are NT times fewer workgroups; after the
+// cross-wave combine, wave j runs the epilogue of unit tile j.
+template <int NT>
+__global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_wide_kernel(LstmStepArgs a) {
+  static_assert(NT >= 2 && NT <= kFusedWaves, "unit tiles per workgroup");
+  __shared__ float4 red[kFusedWaves][NT][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int t0 = blockIdx.x * NT, m0 = blockIdx.y * 16;
+  const int D = a.D, N4 = 4 * D, Wd = a.Wd;
+  const int n_tiles = D / 4;
+  const int m = m0 + r;
+  const bool mok = m < a.B;
+  const float* xrow = a.xh + (size_t)(mok ? m : 0) * a.ld_xh;
+  const int KB = (Wd + 15) >> 4;
+  const float* wpanel = a.K + ((size_t)t0 * KB * 16 + r) * 16 + 4 * kq;   // tile j: + j*KB*256 floats
+  // epilogue operands of wave j < NT: (row m0 + r, unit 4*(t0 + j) + kq)
+  const int et = t0 + wave;
+  const int d = 4 * et + kq;
+  const bool e_wave = wave < NT && et < n_tiles && d < D;
+  float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f, e_hp = 0.f, e_mask = 1.f;
+  bool e_fin = false;
+  if (e_wave) {
+    if (a.bias) {
+      e_b[0] = a.bias[d]; e_b[1] = a.bias[D + d]; e_b[2] = a.bias[2 * D + d]; e_b[3] = a.bias[3 * D + d];
+    }
+    const size_t i = (size_t)(mok ? m : 0) * D + d;
+    e_cp = a.c_prev ? a.c_prev[i] : 0.f;
+    e_hp = a.h_prev ? a.h_prev[i] : 0.f;
+    e_mask = a.mask_out ? a.mask_out[i] : 1.f;
+    e_fin = a.lens && mok && (a.t >= a.lens[m]);
+  }
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int CH = 4;
+  for (int kp0 = wave; 2 * kp0 < KB; kp0 += kFusedWaves * (CH / 2)) {
+    float4 xa[CH], wb[CH][NT];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int kb = 2 * (kp0 + kFusedWaves * (i >> 1)) + (i & 1);
+      const int k = kb * 16 + 4 * kq;
+      xa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb < KB && mok && k < Wd) xa[i] = *(const float4*)(xrow + k);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        wb[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb < KB && t0 + j < n_tiles) wb[i][j] = *(const float4*)(wpanel + ((size_t)j * KB + kb) * 256);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][j].x, xa[i].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][j].y, xa[i].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][j].z, xa[i].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][j].w, xa[i].w, acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) red[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  __syncthreads();
+  if (!e_wave) return;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < kFusedWaves; ++w) {      // fixed order: deterministic
+    const float4 p = red[w][wave][lane];
+    g[0] += p.x; g[1] += p.y; g[2] += p.z; g[3] += p.w;
+  }
+  if (!mok) return;
+  const size_t i = (size_t)m * D + d;
+  const float si = sigmoid_(g[0] + e_b[0]), tj = tanhf(g[1] + e_b[1]);
+  const float sf = sigmoid_(g[2] + e_b[2] + 1.0f), so = sigmoid_(g[3] + e_b[3]);   // forget_bias = 1
+  const float c2 = e_cp * sf + si * tj;
+  const float h2 = tanhf(c2) * so;
+  if (a.gates_act) {
+    float* ga = a.gates_act + (size_t)m * N4;
+    ga[d] = si; ga[D + d] = tj; ga[2 * D + d] = sf; ga[3 * D + d] = so;
+  }
+  if (a.c_new) a.c_new[i] = c2;
+  if (a.y) a.y[i] = a.mask_out ? (h2 / a.keep_out) * e_mask : h2;
+  if (a.c_state) a.c_state[i] = e_fin ? e_cp : c2;
+  const float hs = e_fin ? e_hp : h2;
+  if (a.h_state) a.h_state[i] = hs;
+  if (a.xh_next) a.xh_next[(size_t)m * a.xh_ld + d] = hs;
+}
+
 struct InputGradArgs {
   const float* dg;   // [B][4D]
   const float* K;    // backward panel of the [Wd][4D] LSTM kernel
@@ -436,7 +527,16 @@ int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const floa
     mt_env = e ? atoi(e) : 0;
   }
   const int mt = mt_env > 0 ? mt_env : 1;
-  if (mt == 4)
+  static int nt_env = -1;
+  if (nt_env < 0) {
+    const char* e = getenv("COMIC_LSTM_NT");
+    nt_env = e ? atoi(e) : 0;
+  }
+  if (nt_env == 4) {
+    hipLaunchKernelGGL(lstm_step_fused_wide_kernel<4>, dim3(cdiv(D / 4, 4), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  } else if (nt_env == 2) {
+    hipLaunchKernelGGL(lstm_step_fused_wide_kernel<2>, dim3(cdiv(D / 4, 2), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  } else if (mt == 4)
     hipLaunchKernelGGL(lstm_step_fused_kernel<4>, dim3(D / 4, cdiv(B, 64)), dim3(kFusedThreads), 0, st, a);
   else if (mt == 2)
     hipLaunchKernelGGL(lstm_step_fused_kernel<2>, dim3(D / 4, cdiv(B, 32)), dim3(kFusedThreads), 0, st, a);

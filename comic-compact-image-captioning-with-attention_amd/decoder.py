@@ -397,63 +397,106 @@ class Decoder:
             it *= 5
         return it
 
-    def greedy(self, fm, im_embed, max_steps, want_logits=False):
+    def _infer_ctx(self, kind, B, W, max_steps, want_logits, fm, im_embed):
+        """Persistent buffers (+ a hipGraph of the whole decode loop, captured on the second call
+        with the same shape) of greedy / beam decoding: the executors run all `max_steps` steps on
+        the device without host synchronisation, so one graph launch replaces ~8 kernel launches
+        per step of host work."""
+        torch, s = self.torch, self.spec
+        key = (kind, B, W, max_steps, bool(want_logits))
+        ctxs = self.__dict__.setdefault('_infer_ctxs', {})
+        ctx = ctxs.get(key)
+        if ctx is None:
+            ctx = type('InferCtx', (), {})()
+            R = B * W
+            i32 = dict(dtype=torch.int32, device=self.device)
+            f32 = dict(dtype=torch.float32, device=self.device)
+            ctx.fm = torch.empty((B, s.M, s.C), **f32)
+            ctx.im = torch.empty((B, s.Cg), **f32)
+            ctx.hist = torch.empty((max_steps, R, s.H * s.M), **f32)
+            if kind == 'greedy':
+                ctx.ids = torch.empty((max_steps, B), **i32)
+                ctx.logits = torch.empty((max_steps, B, s.V), **f32) if want_logits else None
+                ctx.first_eos = torch.empty(B, **i32)
+            else:
+                ctx.step_ids = torch.empty((max_steps, B, W), **i32)
+                ctx.parent_ids = torch.empty((max_steps, B, W), **i32)
+                ctx.scores = torch.empty((max_steps, B, W), **f32)
+                ctx.lengths = torch.empty((B, W), dtype=torch.int64, device=self.device)
+                ctx.finished = torch.empty((B, W), **i32)
+                ctx.steps = torch.empty(1, **i32)
+            ctx.desc = s.desc(False)
+            ctx.nbytes = int(self.lib.comic_decoder_infer_workspace(C.byref(ctx.desc), R, max_steps))
+            ctx.ws = torch.empty(ctx.nbytes, dtype=torch.uint8, device=self.device)   # own workspace: graph-stable
+            ctx.ptab = self.params.table()
+            ctx.graph, ctx.calls = None, 0
+            ctxs[key] = ctx
+        ctx.fm.copy_(fm.reshape(ctx.fm.shape))
+        ctx.im.copy_(im_embed.reshape(ctx.im.shape))
+        return ctx
+
+    def _run_infer(self, ctx, launch, use_graph):
+        torch = self.torch
+        if use_graph and ctx.graph is None and ctx.calls >= 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch()
+            ctx.graph = g
+        if use_graph and ctx.graph is not None:
+            ctx.graph.replay()
+        else:
+            launch()
+        ctx.calls += 1
+
+    def greedy(self, fm, im_embed, max_steps, want_logits=False, use_graph=True):
         """rnn_decoder_search(greedy) (ops_rnn.py:115-180).  -> ids [B,T_exec] (numpy int32),
         attn_maps [B,H,T_exec,M] (device), logits [B,T_exec,V] or None."""
-        torch, s = self.torch, self.spec
+        s = self.spec
         B = fm.shape[0]
-        desc = s.desc(False)
-        ids = torch.empty((max_steps, B), dtype=torch.int32, device=self.device)
-        logits = torch.empty((max_steps, B, s.V), dtype=torch.float32, device=self.device) if want_logits else None
-        hist = torch.empty((max_steps, B, s.H, s.M), dtype=torch.float32, device=self.device)
-        first_eos = torch.empty(B, dtype=torch.int32, device=self.device)
-        nbytes = self.lib.comic_decoder_infer_workspace(C.byref(desc), B, max_steps)
-        ws = self._workspace(nbytes)
-        ptab = self.params.table()
-        L.check(self.lib.comic_decoder_greedy(C.byref(desc), C.byref(ptab), fm.contiguous().data_ptr(),
-                                              im_embed.contiguous().data_ptr(), B, max_steps, ids.data_ptr(),
-                                              L.ptr(logits), hist.data_ptr(), first_eos.data_ptr(), ws.data_ptr(),
-                                              nbytes, L.stream_ptr()), 'decoder_greedy')
-        fe = first_eos.cpu().numpy()
-        t_exec = int(min(max_steps, fe.max() + 1))       # loop ends when every row has emitted EOS
-        out_ids = ids[:t_exec].t().contiguous().cpu().numpy()
-        return out_ids, hist[:t_exec].permute(1, 2, 0, 3), (logits[:t_exec].permute(1, 0, 2) if want_logits else None)
+        ctx = self._infer_ctx('greedy', B, 1, max_steps, want_logits, fm, im_embed)
 
-    def beam_search(self, fm, im_embed, beam, max_steps):
+        def launch():
+            L.check(self.lib.comic_decoder_greedy(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(),
+                                                  ctx.im.data_ptr(), B, max_steps, ctx.ids.data_ptr(),
+                                                  L.ptr(ctx.logits), ctx.hist.data_ptr(), ctx.first_eos.data_ptr(),
+                                                  ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()), 'decoder_greedy')
+        self._run_infer(ctx, launch, use_graph)
+        fe = ctx.first_eos.cpu().numpy()
+        t_exec = int(min(max_steps, fe.max() + 1))       # loop ends when every row has emitted EOS
+        out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
+        hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
+        return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
+
+    def beam_search(self, fm, im_embed, beam, max_steps, want_attention=True, use_graph=True):
         """rnn_decoder_beam_search (ops_rnn.py:49-112).  Returns predicted_ids [T,B,W] (after
-        gather_tree), scores [T,B,W], beam-sorted alignment history [T,B*W,H*M] (numpy) and the
-        raw step/parent ids."""
+        gather_tree), scores [T,B,W], the raw step/parent ids and, unless want_attention=False, the
+        beam-sorted alignment history [T,B*W,H*M] (numpy; BeamSearchDecoderMultiHead,
+        ops_rnn.py:807-845 -- host post-processing that only visualisation needs)."""
         torch, s = self.torch, self.spec
         B, W = fm.shape[0], beam
-        R = B * W
-        desc = s.desc(False)
-        i32 = dict(dtype=torch.int32, device=self.device)
-        step_ids = torch.empty((max_steps, B, W), **i32)
-        parent_ids = torch.empty((max_steps, B, W), **i32)
-        scores = torch.empty((max_steps, B, W), dtype=torch.float32, device=self.device)
-        lengths = torch.empty((B, W), dtype=torch.int64, device=self.device)
-        finished = torch.empty((B, W), **i32)
-        hist = torch.empty((max_steps, R, s.H * s.M), dtype=torch.float32, device=self.device)
-        steps = torch.empty(1, **i32)
-        nbytes = self.lib.comic_decoder_infer_workspace(C.byref(desc), R, max_steps)
-        ws = self._workspace(nbytes)
-        ptab = self.params.table()
-        L.check(self.lib.comic_decoder_beam(C.byref(desc), C.byref(ptab), fm.contiguous().data_ptr(),
-                                            im_embed.contiguous().data_ptr(), B, W, max_steps, step_ids.data_ptr(),
-                                            parent_ids.data_ptr(), scores.data_ptr(), lengths.data_ptr(),
-                                            finished.data_ptr(), hist.data_ptr(), steps.data_ptr(), ws.data_ptr(),
-                                            nbytes, L.stream_ptr()), 'decoder_beam')
-        T = int(steps.item())
-        max_len = lengths.max(dim=1).values.to(torch.int32).contiguous()
-        pred = torch.empty((T, B, W), **i32)
-        L.check(self.lib.comic_gather_tree(step_ids[:T].contiguous().data_ptr(), parent_ids[:T].contiguous().data_ptr(),
+        ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed)
+
+        def launch():
+            L.check(self.lib.comic_decoder_beam(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(),
+                                                ctx.im.data_ptr(), B, W, max_steps, ctx.step_ids.data_ptr(),
+                                                ctx.parent_ids.data_ptr(), ctx.scores.data_ptr(),
+                                                ctx.lengths.data_ptr(), ctx.finished.data_ptr(), ctx.hist.data_ptr(),
+                                                ctx.steps.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()),
+                    'decoder_beam')
+        self._run_infer(ctx, launch, use_graph)
+        T = int(ctx.steps.item())
+        max_len = ctx.lengths.max(dim=1).values.to(torch.int32).contiguous()
+        pred = torch.empty((T, B, W), dtype=torch.int32, device=self.device)
+        L.check(self.lib.comic_gather_tree(ctx.step_ids[:T].data_ptr(), ctx.parent_ids[:T].data_ptr(),
                                            max_len.data_ptr(), pred.data_ptr(), T, B, W, s.end_id, L.stream_ptr()),
                 'gather_tree')
-        par = parent_ids[:T].cpu().numpy()
-        ln = lengths.cpu().numpy()
-        hist_sorted = gather_tree_from_array(hist[:T].cpu().numpy(), par, ln, s.end_id)
-        return dict(predicted_ids=pred.cpu().numpy(), scores=scores[:T].cpu().numpy(), attn_hist=hist_sorted,
-                    step_ids=step_ids[:T].cpu().numpy(), parent_ids=par, lengths=ln)
+        par = ctx.parent_ids[:T].cpu().numpy()
+        ln = ctx.lengths.cpu().numpy()
+        out = dict(predicted_ids=pred.cpu().numpy(), scores=ctx.scores[:T].cpu().numpy(),
+                   step_ids=ctx.step_ids[:T].cpu().numpy(), parent_ids=par, lengths=ln)
+        if want_attention:
+            out['attn_hist'] = gather_tree_from_array(ctx.hist[:T].cpu().numpy(), par, ln, s.end_id)
+        return out
 
 
 def _gather_tree_host(step_ids, parent_ids, max_len, end_token):

@@ -207,16 +207,18 @@ class ModelBase(object):
                          self.decoder.params.to_numpy(), extra, max_to_keep, fmt=fmt)
 
     # ---- decode (model_base.py:692-757, :272-314) ----------------------------------------
-    def _decode(self, images, beam_size, max_length, top_beam=True):
+    def _decode(self, images, beam_size, max_length, top_beam=True, want_attention=True):
         c = self._config
         im_embed, fm = self._encode(images)
         iters = self.decoder.max_iterations(max_length, len(c.wtoi))
         if beam_size > 1:
-            r = self.decoder.beam_search(fm, im_embed, beam_size, iters)
+            r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention)
             pred = r['predicted_ids']                                  # (T, B, W)
             T = pred.shape[0]
-            hist = r['attn_hist'].reshape(T, -1, beam_size, self.spec.H, self.spec.M)[:, :, 0]
-            attn = hist.transpose(1, 2, 0, 3)                          # (B, H, T, M) of beam 0
+            attn = None
+            if want_attention:
+                hist = r['attn_hist'].reshape(T, -1, beam_size, self.spec.H, self.spec.M)[:, :, 0]
+                attn = hist.transpose(1, 2, 0, 3)                      # (B, H, T, M) of beam 0
             if top_beam:
                 return pred[:, :, 0].T.copy(), attn
             return pred.transpose(2, 1, 0).copy(), attn               # (W, B, T)
@@ -296,8 +298,8 @@ class CaptionModel_SCST(ModelBase):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
         infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
         c = self._config
-        greedy, _ = self._decode(imgs, 1, 20)
-        beam, _ = self._decode(imgs, c.scst_beam_size, 20, top_beam=False)
+        greedy, _ = self._decode(imgs, 1, 20, want_attention=False)
+        beam, _ = self._decode(imgs, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
 
     def run_train_scst(self, imgs, captions, rewards):
