@@ -530,7 +530,7 @@ int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const floa
   static int nt_env = -1;
   if (nt_env < 0) {
     const char* e = getenv("COMIC_LSTM_NT");
-    nt_env = e ? atoi(e) : 0;
+    nt_env = e ? atoi(e) : 2;   // 2 adjacent unit tiles per workgroup measured fastest (training and beam search)
   }
   if (nt_env == 4) {
     hipLaunchKernelGGL(lstm_step_fused_wide_kernel<4>, dim3(cdiv(D / 4, 4), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
