@@ -96,7 +96,6 @@ def extras(device, enc, cnn_params, plan):
     dec.params.view('b_o')[257] = 2.0
     opt = optim.AdamTF(dec.params)
     enc_s = nets.CnnEncoder(plan, cnn_params, Bs, 'bf16', device)
-    enc_t = nets.CnnEncoder(plan, cnn_params, Bs * W, 'bf16', device)
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bs, IMG, IMG, 3)).astype(np.float32)).to(device)
     iters = 40                                   # infer_max_length 20 x 2 radix digits
 
@@ -108,7 +107,7 @@ def extras(device, enc, cnn_params, plan):
         cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         ids = captions_to_batched_ids(hypos, cfg, table)
-        im, fm = enc_t.forward(imgs.repeat(W, 1, 1, 1), use_graph=True)
+        im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)     # = encoder(imgs tiled W times): frozen CNN, run once
         res = dec.train_step(fm, im, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True)
         opt.step(dec.grads, 1e-3)
         return res
@@ -120,8 +119,8 @@ def extras(device, enc, cnn_params, plan):
         scst_step()
     torch.cuda.synchronize()
     out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
-    out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-image step'
-    del enc_s, enc_t, dec, opt
+    out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-hypothesis step (encoder once, features tiled)'
+    del enc_s, dec, opt
     torch.cuda.empty_cache()
     # ---- cnn_finetune step (configs[2]: CNN + decoder trainable, batch 32) ---------------------
     from comic_amd import trainer

@@ -287,7 +287,7 @@ class CaptionModel_SCST(ModelBase):
         self.mode = scst_mode if scst_mode == 'train' else 'infer'
         self.reuse, self.name = reuse, scst_mode
         c = self._config
-        bs = c.batch_size_train * (c.scst_beam_size if self.is_training() else 1)
+        bs = c.batch_size_train            # the encoder sees the untiled batch in both SCST graphs (run_train_scst tiles its outputs)
         self._batch_size = bs
         self._build(bs, device, dp)
         if self.is_training():
@@ -302,8 +302,13 @@ class CaptionModel_SCST(ModelBase):
         beam, _ = self._decode(imgs, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
 
-    def run_train_scst(self, imgs, captions, rewards):
+    def run_train_scst(self, imgs, captions, rewards, tile=1):
+        """One reward-weighted update on `tile` hypotheses per image.  imgs: the batch tiled `tile`
+        times (tile=1, the reference's feed) or the untiled batch with tile=beam: the frozen encoder
+        then runs once and (im_embed, fm) are tiled -- same values, 1/tile of the CNN work."""
         im_embed, fm = self._encode(imgs)
+        if tile > 1:
+            im_embed, fm = im_embed.repeat(tile, 1), fm.repeat(tile, 1, 1)
         lr = self.lr
         res = self.decoder.train_step(fm, im_embed, np.asarray(captions), rewards=np.asarray(rewards, np.float32),
                                       training=True, use_graph=True)

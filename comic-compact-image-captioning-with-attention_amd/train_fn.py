@@ -135,8 +135,9 @@ def train_fn_scst(config, idx_ngram=False, device='cuda:0', dp=None):
         greedy_high_sc = max(greedy_high_sc, np.amax(sc_greedy))
         hypos_idx = inputs_man.captions_to_batched_ids(hypos)
         assert hypos_idx.shape[0] == sc_sample.shape[0]
-        imgs = np.concatenate([imgs] * c.scst_beam_size)
-        ppl = m_train.run_train_scst(imgs, hypos_idx, rewards)
+        # the reference feeds the images tiled by the beam size (train_fn.py:251-253); the CNN is frozen
+        # and deterministic, so the encoder runs once and its two outputs are tiled instead
+        ppl = m_train.run_train_scst(imgs, hypos_idx, rewards, tile=c.scst_beam_size)
         global_step = m_train.global_step
         if (step + 1) % (n_steps_log * 5) == 0:
             t = time.time() - start_epoch

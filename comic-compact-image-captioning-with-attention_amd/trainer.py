@@ -154,9 +154,12 @@ class CaptionTrainer:
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res
 
-    def scst_step(self, images_tiled, hypo_ids, rewards, masks=None, training=True):
-        """train_fn_scst's train run (train_fn.py:251-256): images already tiled by the beam size."""
-        im_embed, fm = self.encoder.forward(images_tiled, use_graph=self.use_graph)
+    def scst_step(self, images, hypo_ids, rewards, masks=None, training=True, tile=1):
+        """train_fn_scst's train run (train_fn.py:251-256).  images: tiled by the beam size (tile=1) or
+        the untiled batch with tile=beam (encoder once, outputs tiled: identical values)."""
+        im_embed, fm = self.encoder.forward(images, use_graph=self.use_graph)
+        if tile > 1:
+            im_embed, fm = im_embed.repeat(tile, 1), fm.repeat(tile, 1, 1)
         res = self.decoder.train_step(fm, im_embed, hypo_ids, masks=masks, rewards=rewards, training=training,
                                       use_graph=self.use_graph_decoder)
         scale = self.dp.average_(self.decoder.grads.data)
