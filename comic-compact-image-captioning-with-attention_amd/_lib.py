@@ -63,6 +63,8 @@ _SIGS = {
     'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
     'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_float, P]),
+    'comic_gemm_f32_split3': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_float, P, c_int64, P]),
     'comic_gemm_f32_splitk': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, P, c_int64, P]),
     'comic_embed_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -38,8 +38,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// two floats -> packed bf16 pair with the gfx950 conversion instruction (v_cvt_pk_bf16_f32, RNE:
+// bit-identical to f32_to_bf16 for finite inputs)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -46,6 +46,10 @@ int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
                             const float* bias, hipStream_t st);
 
+// gemm.hip
+int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                           int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws,
+                           int64_t ws_bytes, hipStream_t st);
 // decode.hip
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
@@ -348,13 +352,29 @@ inline int fill(float* p, float v, long n, hipStream_t st) {
   return 0;
 }
 // split-K scratch of the running executor call (carved from the caller's workspace)
-constexpr int64_t kSplitKBytes = 8ll << 20;
+constexpr int64_t kSplitKBytes = 32ll << 20;
 thread_local void* g_splitk_ws = nullptr;
 
 inline int gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int ta, int tb, float beta, hipStream_t st) {
   return comic_gemm_f32_ws(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, g_splitk_ws,
                            g_splitk_ws ? kSplitKBytes : 0, st);
+}
+
+// The time-batched products (hundreds of rows: keys, logits, d logits * W_o^T, every weight gradient) go
+// to the bf16 matrix cores with hi/lo-split operands (comic_gemm_f32_split3, product error ~2^-15); the
+// per-step products keep exact fp32 MFMAs.  COMIC_SPLIT3=0 selects the exact kernels everywhere.
+inline int gemm_big(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                    int ldc, int ta, int tb, float beta, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("COMIC_SPLIT3");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!on || (long)M * N < 64 * 256 || K < 64)
+    return gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, beta, st);
+  return comic_gemm_bf16x3_impl(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, g_splitk_ws,
+                                g_splitk_ws ? kSplitKBytes : 0, st);
 }
 
 int check_desc(const comic_decoder_desc* d) {
@@ -378,11 +398,11 @@ comic_attn_desc attn_desc(const comic_decoder_desc* d, int rows) {
 // keys / values for `rows` feature maps (ops_rnn.py:440-477)
 int memory_projections(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm, int rows,
                        float* keys, float* values_buf, const float** values, hipStream_t st) {
-  RC(gemm(fm, p->W_m, keys, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
+  RC(gemm_big(fm, p->W_m, keys, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
   if (d->fm_projection == 2) {
     *values = keys;
   } else if (d->fm_projection == 1) {
-    RC(gemm(fm, p->W_v, values_buf, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
+    RC(gemm_big(fm, p->W_v, values_buf, nullptr, rows * d->M, d->D, d->C, d->C, d->D, d->D, 0, 0, 0.f, st));
     *values = values_buf;
   } else {
     *values = fm;
@@ -625,7 +645,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     }
   }
   // output projection for all executed steps, loss, d logits
-  RC(gemm(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
+  RC(gemm_big(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
   RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
   for (int t = Tp; t < T; ++t) {  // ops_rnn.py:235-241: pad by copying the last executed step
     (void)hipMemcpyAsync(logits_tb + (size_t)t * B * V, logits_tb + (size_t)(Tp - 1) * B * V, sizeof(float) * B * V,
@@ -656,8 +676,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(fill(dh, 0.f, (long)B * D, st));
   RC(fill(datt, 0.f, (long)B * A, st));
   // dy_all = dlogits * W_o^T ; dW_o, db_o
-  RC(gemm(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
-  RC(gemm(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
+  RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
+  RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
   RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
   for (int t = Tp - 1; t >= 0; --t) {
@@ -710,9 +730,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     }
   }
   // time-batched weight gradients
-  RC(gemm(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
+  RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
   RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
-  RC(gemm(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, st));
+  RC(gemm_big(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, st));
   RC(fill(gr->emb, 0.f, (long)V * E, st));
   RC(comic_embed_bwd(in_tb, demb, gr->emb, Tp * B, E, V, (void*)st));
   // rnn init
@@ -731,14 +751,14 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     dx_im = dx_init;
     n_init = EA;
   }
-  RC(gemm(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
+  RC(gemm_big(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
   if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
   // memory projections
-  RC(gemm(fm, dkeys, gr->W_m, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
-  if (dfm) RC(gemm(dkeys, p->W_m, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 0.f, st));
+  RC(gemm_big(fm, dkeys, gr->W_m, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
+  if (dfm) RC(gemm_big(dkeys, p->W_m, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 0.f, st));
   if (d->fm_projection == 1) {
-    RC(gemm(fm, dvalues_buf, gr->W_v, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
-    if (dfm) RC(gemm(dvalues_buf, p->W_v, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 1.f, st));
+    RC(gemm_big(fm, dvalues_buf, gr->W_v, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
+    if (dfm) RC(gemm_big(dvalues_buf, p->W_v, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 1.f, st));
   } else if (d->fm_projection == 0 && dfm) {
     RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)st));
   }
@@ -918,7 +938,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
       RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
                           sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st));
-      RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
+      RC(gemm_big(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
       RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
                             d->end_id, g_splitk_ws, kSplitKBytes, st));
     } else {
@@ -933,7 +953,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       else sb.att2 = att_new;
       RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
                     attn_hist + (size_t)t * R * H * M, R, st));
-      RC(gemm(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
+      RC(gemm_big(sb.y, p->W_o, ws.logits, p->b_o, R, V, D, D, V, V, 0, 0, 0.f, st));
       RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
                             d->end_id, g_splitk_ws, kSplitKBytes, st));
       RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));

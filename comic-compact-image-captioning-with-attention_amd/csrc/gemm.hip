@@ -24,6 +24,8 @@ struct GemmArgs {
   const float* bias;
   int M, N, K, lda, ldb, ldc;
   float alpha, beta;
+  int k_per_slice = 0;   // bf16x3 kernel: > 0 = blockIdx.z owns k in [z*k_per_slice, ...) and writes a raw
+  float* slab = nullptr; //   partial tile to slab[z][M][N] (combined by splitk_reduce_kernel)
 };
 
 constexpr int BK = 16;
@@ -173,6 +175,224 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores: every operand element x is split on the fly into
+// hi = bf16(x), lo = bf16(x - hi) and the product is accumulated as hi*hi + hi*lo + lo*hi in fp32
+// (the dropped lo*lo term and the 16 kept mantissa bits bound the relative error of a product by
+// ~2^-15; measured 2e-6 on the decoder's shapes).  v_mfma_f32_16x16x32_bf16 does 16 384 FLOP in 16
+// cycles against 2 048 in 32 for the f32-input MFMA, so three of them are ~5x faster than the exact
+// path.  Used by the decoder executors for the time-batched products (keys, logits, every weight
+// gradient); the per-step products and the public comic_gemm_f32 keep exact fp32 products.
+// Tiles: BM x 128 x 32, operands converted while they are staged into k-contiguous LDS rows of
+// 32 bf16 (+16 B pad: ds_read_b128 fragments, conflict-free), register-prefetched double buffer.
+// (a, b) -> packed hi pair, packed lo pair
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
+
+// LDS images of a ROWS x 32 operand tile (bf16, one for hi and one for lo):
+//   k-contiguous operand  -> [ROWS][32 k] rows of 64 B + 16 B pad, read with ds_read_b128; the 8-byte
+//                            chunk holding physical k = 4c..4c+3 sits at chunk position 2*(c&3) + (c>>2)
+//   row-contiguous operand -> [32 k][ROWS] rows of 2*ROWS + 32 B, read with ds_read_b64_tr_b16
+// Both give lane group g the physical k {4g..4g+3, 16+4g..16+4g+3} as its 8 MFMA k-values (the
+// conflict-free transposing-read order, see conv_wgrad_tr_kernel).
+template <int ROWS, bool KC>
+struct X3Tile {
+  static constexpr int ROWB = 80;
+  static constexpr int KSTR = 2 * ROWS + 32;
+  static constexpr int BYTES = KC ? ROWS * ROWB : 32 * KSTR;
+};
+
+// chunk q of a ROWS x 32 fp32 tile.  k-contiguous operand: row = q / 8, k = (q % 8) * 4;
+// row-contiguous operand: k = q / (ROWS/4), rows (q % (ROWS/4)) * 4 .. +3
+template <int ROWS, bool KC, int NCH>
+__device__ __forceinline__ void x3_load_tile(const float* __restrict__ g, int ld, int row0, int rows_total, int k0, int K,
+                                             int tid, bool vec, float4 (&out)[NCH]) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int q = tid + 256 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int row = row0 + (q >> 3), k = k0 + (q & 7) * 4;
+      if (row < rows_total && k < K) v = load4(g + (size_t)row * ld + k, K - k, vec);
+    } else {
+      constexpr int CPR = ROWS / 4;
+      const int k = k0 + q / CPR, row = row0 + (q % CPR) * 4;
+      if (k < K && row < rows_total) v = load4(g + (size_t)k * ld + row, rows_total - row, vec);
+    }
+    out[i] = v;
+  }
+}
+template <int ROWS, bool KC, int NCH>
+__device__ __forceinline__ void x3_store_tile(unsigned char* hi_base, unsigned char* lo_base, int tid,
+                                              const float4 (&in)[NCH]) {
+  using T = X3Tile<ROWS, KC>;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int q = tid + 256 * i;
+    uint32_t h0, l0, h1, l1;
+    split_bf16x2(in[i].x, in[i].y, h0, l0);
+    split_bf16x2(in[i].z, in[i].w, h1, l1);
+    int off;
+    if (KC) {
+      const int row = q >> 3, c = q & 7;
+      off = row * T::ROWB + (2 * (c & 3) + (c >> 2)) * 8;
+    } else {
+      constexpr int CPR = ROWS / 4;
+      const int kk = q / CPR, row = (q % CPR) * 4;
+      off = kk * T::KSTR + row * 2;
+    }
+    *(uint2*)(hi_base + off) = make_uint2(h0, h1);
+    *(uint2*)(lo_base + off) = make_uint2(l0, l1);
+  }
+}
+typedef __attribute__((ext_vector_type(4))) short x3_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short x3_s16x8_t;
+// 16x32 MFMA fragment of the 16 operand rows starting at `row16`
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8_t x3_frag(const unsigned char* base, int row16, int lane) {
+  using T = X3Tile<ROWS, KC>;
+  if (KC) {
+    const uint4 v = *(const uint4*)(base + (row16 + (lane & 15)) * T::ROWB + (lane >> 4) * 16);
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned char* p = base + (4 * g + q) * T::KSTR + (row16 + 4 * pp) * 2;
+    const uint32_t a0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p);
+    const x3_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)a0);
+    const x3_s16x4_t hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)(a0 + 16 * T::KSTR));
+    const x3_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <int BM, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
+  constexpr int BN = 128, BKx = 32;
+  constexpr int TM = BM / 32, TN = BN / 32;               // 16x16 tiles per wave (2 x 2 waves)
+  constexpr int ACH = BM * BKx / 4 / 256, BCH = BN * BKx / 4 / 256;   // float4 chunks per thread
+  constexpr int ABYTES = X3Tile<BM, A_KC>::BYTES, BBYTES = X3Tile<BN, B_KC>::BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ah = smem;                              // [2] tile images each
+  unsigned char* Al = Ah + 2 * ABYTES;
+  unsigned char* Bh = Al + 2 * ABYTES;
+  unsigned char* Bl = Bh + 2 * BBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bool a_vec = (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
+  const bool b_vec = (a.ldb % 4 == 0) && (((uintptr_t)a.B & 15) == 0);
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  float4 ar[ACH], br[BCH];
+  const int kbeg = a.k_per_slice > 0 ? blockIdx.z * a.k_per_slice : 0;
+  const int kend = a.k_per_slice > 0 ? min(a.K, kbeg + a.k_per_slice) : a.K;
+  const int nk = (kend - kbeg + BKx - 1) / BKx;
+  x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg, kend, tid, a_vec, ar);
+  x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg, kend, tid, b_vec, br);
+  x3_store_tile<BM, A_KC, ACH>(Ah, Al, tid, ar);
+  x3_store_tile<BN, B_KC, BCH>(Bh, Bl, tid, br);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BKx, kend, tid, a_vec, ar);
+      x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + (kt + 1) * BKx, kend, tid, b_vec, br);
+    }
+    bf16x8_t bh[TN], bl[TN], ah[TM], al[TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      bh[i] = x3_frag<BN, B_KC>(Bh + buf * BBYTES, wn * (BN / 2) + i * 16, lane);
+      bl[i] = x3_frag<BN, B_KC>(Bl + buf * BBYTES, wn * (BN / 2) + i * 16, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      ah[j] = x3_frag<BM, A_KC>(Ah + buf * ABYTES, wm * (BM / 2) + j * 16, lane);
+      al[j] = x3_frag<BM, A_KC>(Al + buf * ABYTES, wm * (BM / 2) + j * 16, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < nk) {
+      x3_store_tile<BM, A_KC, ACH>(Ah + (buf ^ 1) * ABYTES, Al + (buf ^ 1) * ABYTES, tid, ar);
+      x3_store_tile<BN, B_KC, BCH>(Bh + (buf ^ 1) * BBYTES, Bl + (buf ^ 1) * BBYTES, tid, br);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15)
+  const bool to_slab = a.k_per_slice > 0;
+  float* Cbase = to_slab ? a.slab + (size_t)blockIdx.z * a.M * a.N : a.C;
+  const int ldc = to_slab ? a.N : a.ldc;
+  const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)Cbase & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * (BN / 2) + i * 16 + (lane >> 4) * 4;
+    if (n >= a.N) continue;
+    const int nv = min(4, a.N - n);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * (BM / 2) + j * 16 + (lane & 15);
+      if (m >= a.M) continue;
+      float* cp = Cbase + (size_t)m * ldc + n;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (!to_slab) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] *= a.alpha;
+          if (a.bias && q < nv) v[q] += a.bias[n + q];
+          if (a.beta != 0.f && q < nv) v[q] += a.beta * cp[q];
+        }
+      }
+      if (nv == 4 && c_vec) {
+        *(float4*)cp = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < nv) cp[q] = v[q];
+      }
+    }
+  }
+}
+
+template <int BM>
+int launch_x3(const GemmArgs& a, int ta, int tb, hipStream_t st) {
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, 128), a.k_per_slice > 0 ? cdiv(a.K, a.k_per_slice) : 1);
+  const bool a_kc = (ta == 0), b_kc = (tb == 1);
+#define COMIC_X3(AK, BK_)                                                                                              \
+  do {                                                                                                                 \
+    constexpr int lds = 4 * (X3Tile<BM, AK>::BYTES + X3Tile<128, BK_>::BYTES);                                         \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, AK, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              lds) != hipSuccess) {                                                                    \
+        comic_set_error("gemm_bf16x3: cannot reserve %d bytes of LDS", lds);                                           \
+        return 1;                                                                                                      \
+      }                                                                                                                \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, AK, BK_>), grid, dim3(256), lds, st, a);                                \
+  } while (0)
+  if (a_kc && b_kc) COMIC_X3(true, true);
+  else if (a_kc && !b_kc) COMIC_X3(true, false);
+  else if (!a_kc && b_kc) COMIC_X3(false, true);
+  else COMIC_X3(false, false);
+#undef COMIC_X3
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------
 // Skinny GEMM (M <= 64 per row block): the decoder's per-step products at batch 64 are
@@ -438,6 +658,49 @@ int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bia
     launch<32>(a, trans_a, trans_b, st);
   COMIC_LAUNCH_CHECK("gemm_f32");
   return 0;
+}
+
+// C = alpha * op(A) * op(B) + beta * C + bias with 3-term bf16-split products (see gemm_bf16x3_kernel).
+// With a workspace the k range is split over gridDim.z workgroups when there are too few output tiles to
+// fill the chip (weight gradients: K = T*B rows, small M x N); the raw partial slabs are combined in a
+// fixed order (deterministic).
+int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                           int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws,
+                           int64_t ws_bytes, hipStream_t st) {
+  COMIC_REQUIRE(A && B && C, "gemm_bf16x3: null pointer");
+  COMIC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape %d %d %d", M, N, K);
+  COMIC_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm_bf16x3: leading dimension too small");
+  GemmArgs a{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta};
+  const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128);
+  const bool big = blocks128 >= 200;
+  const long tiles = big ? blocks128 : (long)cdiv(M, 64) * cdiv(N, 128);
+  int S = 1;
+  if (ws && tiles < 512) {
+    S = (int)std::min<long>(std::min<long>(16, 768 / tiles), K / 128);
+    while (S > 1 && (int64_t)S * M * N * 4 > ws_bytes) --S;
+    S = std::max(S, 1);
+  }
+  if (S > 1) {
+    a.k_per_slice = cdiv(cdiv(K, S), 32) * 32;
+    a.slab = (float*)ws;
+    S = cdiv(K, a.k_per_slice);
+  }
+  int rc = big ? launch_x3<128>(a, trans_a, trans_b, st) : launch_x3<64>(a, trans_a, trans_b, st);
+  if (rc) return rc;
+  if (S > 1) {
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, (const float*)ws, C,
+                       bias, M, N, ldc, S, alpha, beta);
+  }
+  COMIC_LAUNCH_CHECK("gemm_bf16x3");
+  return 0;
+}
+
+extern "C" int comic_gemm_f32_split3(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                                     int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  return comic_gemm_bf16x3_impl(A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, beta, workspace,
+                                workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int comic_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,

@@ -155,6 +155,16 @@ int comic_gemm_f32(const float* A, const float* B, float* C, const float* bias, 
                    int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta,
                    void* stream);
 
+/* Same contract on the bf16 matrix cores: each fp32 operand element is split into hi + lo bf16 and a
+ * product is accumulated as hi*hi + hi*lo + lo*hi in fp32 (relative error of a product <= ~2^-15,
+ * ~5x the MFMA rate of the exact path).  With a workspace, shapes with few output tiles split K over
+ * workgroups (partial slabs, fixed-order combine).  The decoder executors use it for the time-batched
+ * products (keys, logits, weight gradients). */
+int comic_gemm_f32_split3(const float* A, const float* B, float* C, const float* bias, int M, int N,
+                          int K, int lda, int ldb, int ldc, int trans_a, int trans_b, float alpha,
+                          float beta, void* workspace /* may be NULL: no split-K */,
+                          int64_t workspace_bytes, void* stream);
+
 /* Same product; a caller-provided workspace lets skinny problems (M <= 2048, no trans_a)
  * split K over extra workgroups (deterministic slab reduction). */
 int comic_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N,
