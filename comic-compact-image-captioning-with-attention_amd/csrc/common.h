@@ -47,14 +47,39 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// Wave-wide reductions on the DPP data path (VALU-latency lane exchanges) instead of __shfl_xor
+// (ds_bpermute: an LDS round trip per step): 4 row rotations give every lane its 16-lane row total,
+// row_bcast:15 / row_bcast:31 fold the four rows into lane 63, v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0x121>(0.f, v);         // row_ror:1
+  v += dpp_move<0x122>(0.f, v);         // row_ror:2
+  v += dpp_move<0x124>(0.f, v);         // row_ror:4
+  v += dpp_move<0x128>(0.f, v);         // row_ror:8
+  v += dpp_move<0x142, 0xA>(0.f, v);    // row_bcast:15 into rows 1, 3
+  v += dpp_move<0x143, 0xC>(0.f, v);    // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, dpp_move<0x121>(v, v));
+  v = fmaxf(v, dpp_move<0x122>(v, v));
+  v = fmaxf(v, dpp_move<0x124>(v, v));
+  v = fmaxf(v, dpp_move<0x128>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over aligned groups of `n` consecutive lanes (n = 2, 4, 8 or 16): quad permutes, then the
+// half-row and row mirrors pair each lane with one from the other half of its group
+__device__ __forceinline__ float group_sum_dpp(float v, int n) {
+  v += dpp_move<0xB1>(0.f, v);                    // quad_perm [1,0,3,2]
+  if (n >= 4) v += dpp_move<0x4E>(0.f, v);        // quad_perm [2,3,0,1]
+  if (n >= 8) v += dpp_move<0x141>(0.f, v);       // row_half_mirror
+  if (n >= 16) v += dpp_move<0x140>(0.f, v);      // row_mirror
   return v;
 }
 

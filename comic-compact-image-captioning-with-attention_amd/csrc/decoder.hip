@@ -225,6 +225,8 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float* v)
 
 // sum over the `lph` consecutive lanes that share a head (lph is a power of two <= 64)
 __device__ __forceinline__ float head_sum(float v, int lph) {
+  if (lph == 1) return v;
+  if (lph <= 16) return group_sum_dpp(v, lph);
   for (int o = 1; o < lph; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
