@@ -360,6 +360,92 @@ __global__ __launch_bounds__(kFusedThreads) void input_grad_fused_kernel(InputGr
   }
 }
 
+// Wider variant (see lstm_step_fused_wide_kernel): NT adjacent feature tiles per workgroup share the
+// d-gates fragments; wave j runs the epilogue of tile j.
+template <int NT>
+__global__ __launch_bounds__(kFusedThreads) void input_grad_fused_wide_kernel(InputGradArgs a) {
+  __shared__ float4 red[kFusedWaves][NT][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int t0 = blockIdx.x * NT, m0 = blockIdx.y * 16;
+  const int N4 = 4 * a.D, Wd = a.E + a.A + a.D, EA = a.E + a.A;
+  const int n_tiles = (Wd + 15) >> 4;
+  const bool mok = m0 + r < a.B;
+  const float* grow = a.dg + (size_t)(mok ? m0 + r : 0) * N4;
+  const int KB = N4 >> 4;
+  const float* wpanel = a.K + ((size_t)t0 * KB * 16 + r) * 16 + 4 * kq;   // tile j: + j*KB*256 floats
+  // epilogue operands of wave j < NT (element: row m0 + 4*kq + i, feature c = 16*(t0 + j) + r)
+  const int c = 16 * (t0 + wave) + r;
+  const bool e_wave = wave < NT && t0 + wave < n_tiles;
+  float e_mk[4] = {1.f, 1.f, 1.f, 1.f}, e_old[4] = {0.f, 0.f, 0.f, 0.f};
+  bool e_fin[4] = {false, false, false, false};
+  if (e_wave && c < Wd) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = m0 + 4 * kq + i;
+      if (b >= a.B) continue;
+      if (c < EA && a.mask) e_mk[i] = a.mask[(size_t)b * EA + c];
+      if (c >= a.E) e_old[i] = c < EA ? a.datt[(size_t)b * a.A + (c - a.E)] : a.dh[(size_t)b * a.D + (c - EA)];
+      e_fin[i] = a.lens && a.t >= a.lens[b];
+    }
+  }
+  f32x4_t acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  constexpr int CH = 4;
+  for (int kp0 = wave; 2 * kp0 < KB; kp0 += kFusedWaves * (CH / 2)) {
+    float4 ga[CH], wb[CH][NT];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int kb = 2 * (kp0 + kFusedWaves * (i >> 1)) + (i & 1);
+      ga[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb < KB && mok) ga[i] = *(const float4*)(grow + kb * 16 + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        wb[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kb < KB && t0 + j < n_tiles) wb[i][j] = *(const float4*)(wpanel + ((size_t)j * KB + kb) * 256);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i].x, wb[i][j].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i].y, wb[i][j].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i].z, wb[i][j].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[i].w, wb[i][j].w, acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) red[wave][j][lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+  __syncthreads();
+  if (!e_wave || c >= Wd) return;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < kFusedWaves; ++w) {
+    const float4 p = red[w][wave][lane];
+    g[0] += p.x; g[1] += p.y; g[2] += p.z; g[3] += p.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = m0 + 4 * kq + i;
+    if (b >= a.B) continue;
+    float v = g[i];
+    if (c < EA) {
+      if (a.mask) v = (v / a.keep) * e_mk[i];
+      if (c < a.E) {
+        if (a.demb) a.demb[(size_t)b * a.E + c] = v;
+      } else {
+        a.datt[(size_t)b * a.A + (c - a.E)] = ((a.carry && !e_fin[i]) ? 0.f : e_old[i]) + v;
+      }
+    } else {
+      a.dh[(size_t)b * a.D + (c - EA)] = e_old[i] + v;
+    }
+  }
+}
+
 struct LstmGradArgs {
   const float* dq;        // [B][D]  d query of this step
   const float* Wq;        // backward panel of W_q [D][D]
@@ -553,7 +639,18 @@ int comic_input_grad_fused(const float* dg, const float* K, const float* mask, f
   COMIC_REQUIRE(D % 4 == 0 && ((uintptr_t)dg & 15) == 0 && ((uintptr_t)K & 15) == 0,
                 "input_grad_fused: D must be a multiple of 4 and the operands 16-byte aligned");
   InputGradArgs a{dg, K, mask, keep, demb, datt, dh, lens, t, carry, B, E, A, D};
-  hipLaunchKernelGGL(input_grad_fused_kernel, dim3(cdiv(E + A + D, 16), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  static int nt = -1;
+  if (nt < 0) {
+    const char* e = getenv("COMIC_IGRAD_NT");
+    nt = e ? atoi(e) : 2;
+  }
+  const int tiles = cdiv(E + A + D, 16);
+  if (nt == 4)
+    hipLaunchKernelGGL(input_grad_fused_wide_kernel<4>, dim3(cdiv(tiles, 4), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  else if (nt == 2)
+    hipLaunchKernelGGL(input_grad_fused_wide_kernel<2>, dim3(cdiv(tiles, 2), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL(input_grad_fused_kernel, dim3(tiles, cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
   COMIC_LAUNCH_CHECK("input_grad_fused");
   return 0;
 }
