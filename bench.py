@@ -215,6 +215,8 @@ def main():
 
     tr.use_graph = GRAPH_CNN and GRAPH_DEC
     overlap = os.environ.get('COMIC_OVERLAP', '1') == '1'
+    if overlap:
+        tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
     # the image batch lives in the encoder's input buffer (inputs resident in HBM)
     tr.encoder.bufs[plan.input].copy_(images)
     images = tr.encoder.bufs[plan.input]
@@ -266,6 +268,9 @@ def main():
     dt = float(t.item())
     cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     # the same forward alone on the GPU (not overlapped with the decoder), for reference
+    tr.enable_overlap(0)                 # full occupancy again (the overlapped forward ran 1 workgroup per CU)
+    for _ in range(3):
+        tr.encoder.forward(images, use_graph=GRAPH_CNN)
     iso = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
     for a, b in iso:
         a.record(); tr.encoder.forward(images, use_graph=GRAPH_CNN); b.record()
@@ -277,7 +282,12 @@ def main():
     if rank == 0:
         n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1))
         n_launch = sum(1 for o in plan.ops if o['kind'] in (0, 1) and not o.get('group')) + len({o['group'] for o in plan.ops if o.get('group')})
-        achieved = FLOP_PER_IMAGE_CNN * BATCH / (cnn_ms * 1e-3)
+        # Kernel quality is judged on the forward ALONE on the GPU (HIP events in this process, same graph /
+        # launches, right after the timed loop); inside the timed region the same forward is deliberately
+        # run at one workgroup per CU underneath the decoder step, so its wall time there says how well
+        # the two overlap, not how good the kernel is.  Both are reported.
+        achieved = FLOP_PER_IMAGE_CNN * BATCH / (cnn_iso_ms * 1e-3)
+        achieved_in = FLOP_PER_IMAGE_CNN * BATCH / (cnn_ms * 1e-3)
         out = {
             'metric': 'images/sec (decoder-mode XE training, COMIC-256, InceptionV3 frozen)',
             'value': round(BATCH * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
@@ -291,9 +301,13 @@ def main():
                                                     'step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
-                         'cnn_forward_ms': round(cnn_ms, 4), 'cnn_forward_ms_not_overlapped': round(cnn_iso_ms, 4),
-                         'note': 'achieved is measured inside the timed region, where the encoder forward of the '
-                                 'next batch runs concurrently with the decoder step (frozen CNN)' if overlap else ''},
+                         'cnn_forward_ms': round(cnn_iso_ms, 4),
+                         'in_timed_region': {'cnn_forward_ms': round(cnn_ms, 4), 'achieved': round(achieved_in / 1e12, 3),
+                                             'frac': round(achieved_in / PEAK_BF16_MFMA, 5), 'overlapped': bool(overlap)},
+                         'note': ('achieved/frac: the forward alone on the GPU, HIP events on its stream, measured in this '
+                                  'process after the timed loop (agrees with profiles/*kernel_stats.csv).  in_timed_region: '
+                                  'the same forward while it runs on a second stream under the decoder step of the '
+                                  'previous batch (frozen CNN) at one conv workgroup per CU') if overlap else ''},
             'final_loss': round(loss, 5),
         }
         tfile = os.path.join(ROOT, 'profiles', 'r01_cnn_hbm_traffic.json')

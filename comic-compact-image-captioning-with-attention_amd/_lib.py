@@ -53,6 +53,7 @@ _SIGS = {
     'comic_pack_conv_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'comic_fold_bn': (c_int, [P, P, P, c_float, P, P, c_int, P]),
     'comic_cnn_forward': (c_int, [P, c_int, P, P, P, c_int, c_int, P]),
+    'comic_conv_set_min_lds': (c_int, [c_int]),
     'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
     'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
     'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),

@@ -272,7 +272,7 @@ __device__ __forceinline__ float score_row(const AttnArgs& a, const float* kr, c
   return head_sum(part, lph);
 }
 
-constexpr int kAttnWaves = 16;   // waves per workgroup: each wave owns <= 2 memory rows at M=25
+constexpr int kAttnWaves = 16;   // waves per workgroup: each wave owns <= 2 memory rows at M=25 (8 waves measured: isolated step +0.15 ms, overlapped equal)
 constexpr int kAttnThreads = kAttnWaves * 64;
 
 template <int EPL>

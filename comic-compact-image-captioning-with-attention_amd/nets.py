@@ -358,6 +358,9 @@ class CnnEncoder:
         self._build_group_args()
         self._graph = None
         self._calls = 0
+        # > 0: conv workgroups request at least this much LDS (1 per CU at 84) -- for forwards that run on a
+        # second stream under other kernels (CaptionTrainer's overlapped encoder); set before the graph capture
+        self.polite_lds_kb = 0
 
     def load_params(self, params):
         """(Re)load every CNN variable from {slim name: array} into the flat masters IN PLACE (all
@@ -482,6 +485,16 @@ class CnnEncoder:
         torch.cuda.synchronize()
 
     def _run(self):
+        if self.polite_lds_kb:
+            L.check(self.lib.comic_conv_set_min_lds(self.polite_lds_kb * 1024), 'conv_set_min_lds')
+            try:
+                self._run_plan()
+            finally:
+                L.check(self.lib.comic_conv_set_min_lds(0), 'conv_set_min_lds')
+        else:
+            self._run_plan()
+
+    def _run_plan(self):
         if self._group_args is not None:
             L.check(self.lib.comic_cnn_forward_grouped(self._ops, len(self.plan.ops), self._bufptr, self._bufch,
                                                        self._wt, self.batch, self.dcode,

@@ -120,6 +120,13 @@ class CaptionTrainer:
         self.encoder.refresh_weights()
         return res
 
+    def enable_overlap(self, polite_lds_kb=84):
+        """Prepare the encoder for running under the decoder step (submit_images / xe_step_pending): its
+        conv workgroups take a whole CU's LDS each, so the decoder's kernels always find wave slots."""
+        if self.encoder.polite_lds_kb != polite_lds_kb:
+            self.encoder.polite_lds_kb = polite_lds_kb
+            self.encoder._graph, self.encoder._calls = None, 0      # re-capture with the new launch parameters
+
     def submit_images(self, images):
         """Start the encoder forward of a future step on the side stream (frozen-CNN modes)."""
         torch = self._torch

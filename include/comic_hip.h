@@ -92,6 +92,11 @@ int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
                       int dtype, void* stream);
 
+/* Occupancy knob for forwards that share the GPU with other work: lower bound (bytes, 0 = off) on the
+ * LDS a bf16 conv workgroup requests; 84 KiB = one conv workgroup per CU.  Process-wide; launches
+ * captured in a hipGraph keep the value they were captured with. */
+int comic_conv_set_min_lds(int bytes);
+
 /* Grouped execution of the same plan (bf16 plans): every run of ops with the same non-zero
  * `group` becomes ONE launch whose workgroups are spread over all member convolutions (a
  * 12x12 or 5x5 Inception stage has too few tiles per conv to fill 256 CUs at batch 64).
