@@ -199,6 +199,8 @@ def main():
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
     tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan)
+    if os.environ.get('COMIC_TUNE_POLITE', '0') == '1' and os.environ.get('COMIC_OVERLAP', '1') == '1':
+        tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
     if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
         tr.encoder.autotune(verbose=os.environ.get('COMIC_VERBOSE', '0') == '1')   # setup, untimed
     # identical initial parameters on every rank (C2: broadcast)

@@ -538,6 +538,14 @@ class CnnEncoder:
             return {}
         torch = self.torch
         st = L.stream_ptr()
+        if self.polite_lds_kb:        # tune under the occupancy the forward will run with
+            L.check(self.lib.comic_conv_set_min_lds(self.polite_lds_kb * 1024), 'conv_set_min_lds')
+        try:
+            return self._autotune(reps, verbose, torch, st)
+        finally:
+            L.check(self.lib.comic_conv_set_min_lds(0), 'conv_set_min_lds')
+
+    def _autotune(self, reps, verbose, torch, st):
         chosen = {}
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_ops = len(self.plan.ops)
