@@ -1733,7 +1733,7 @@ int wgrad_blocks_target() {
 template <typename T>
 int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
                   const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
-                  int64_t scratch_bytes, hipStream_t st) {
+                  int64_t scratch_bytes, hipStream_t st, bool filters_ready) {
   constexpr int EPC = Elem<T>::EPC;
   const bool stem = op->kind == 1;
   COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
@@ -1801,7 +1801,7 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   // backward-data: forward conv of dz with the flipped / transposed filter, accumulated into gx
   COMIC_REQUIRE(gr->w_bwd, "conv backward: missing backward-data filter buffer");
   const int K2 = op->KH * op->KW * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
-  {
+  if (!filters_ready) {
     const long n = (long)op->Cin * Kpad2;
     hipLaunchKernelGGL((pack_bwd_weights_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, gr->w_master,
                        (T*)gr->w_bwd, op->KH, op->KW, op->Cin, op->Cout, Kpad, Kpad2);
@@ -1838,9 +1838,26 @@ int pool_backward(const comic_cnn_op* op, const void* x, int xc, const void* gy,
 }
 
 template <typename T>
+int pack_bwd_filters_impl(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads, hipStream_t st) {
+  for (int i = 0; i < n_ops; ++i) {
+    const comic_cnn_op* op = ops + i;
+    if (op->kind != 0) continue;
+    const comic_conv_grad* gr = grads + op->weight;
+    COMIC_REQUIRE(gr->w_master && gr->w_bwd, "pack_bwd_filters: missing buffers for conv %d", i);
+    const int K = op->KH * op->KW * op->Cin, Kpad = (K + 63) / 64 * 64;
+    const int K2 = op->KH * op->KW * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
+    const long n = (long)op->Cin * Kpad2;
+    hipLaunchKernelGGL((pack_bwd_weights_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, gr->w_master,
+                       (T*)gr->w_bwd, op->KH, op->KW, op->Cin, op->Cout, Kpad, Kpad2);
+  }
+  COMIC_LAUNCH_CHECK("pack_bwd_filters");
+  return 0;
+}
+
+template <typename T>
 int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, const comic_conv_grad* grads,
-                      int batch, void* scratch, int64_t scratch_bytes, hipStream_t st) {
+                      int batch, void* scratch, int64_t scratch_bytes, hipStream_t st, bool filters_ready) {
   for (int i = n_ops - 1; i >= 0; --i) {
     const comic_cnn_op* op = ops + i;
     if (op->kind == 5 || op->kind == 6) continue;
@@ -1850,7 +1867,7 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
     const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
     if (op->kind <= 1) {
       if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
-                                    grads + op->weight, batch, scratch, scratch_bytes, st))
+                                    grads + op->weight, batch, scratch, scratch_bytes, st, filters_ready))
         return rc;
     } else if (op->kind <= 4) {
       if (!gx) continue;
@@ -1879,19 +1896,28 @@ extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int
   return (int64_t)best;
 }
 
+extern "C" int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads, int dtype,
+                                          void* stream) {
+  COMIC_REQUIRE(ops && grads, "comic_cnn_pack_bwd_filters: null argument");
+  if (dtype == COMIC_BF16) return pack_bwd_filters_impl<bf16_t>(ops, n_ops, grads, (hipStream_t)stream);
+  if (dtype == COMIC_F32) return pack_bwd_filters_impl<float>(ops, n_ops, grads, (hipStream_t)stream);
+  COMIC_REQUIRE(false, "unknown dtype %d", dtype);
+  return 2;
+}
+
 extern "C" int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
                                   const int32_t* buf_channels, const comic_conv_weight* weights,
-                                  const comic_conv_grad* grads, int batch, int dtype, void* scratch,
+                                  const comic_conv_grad* grads, int batch, int dtype, int filters_ready, void* scratch,
                                   int64_t scratch_bytes, void* stream) {
   COMIC_REQUIRE(ops && buffers && grad_buffers && buf_channels && weights && grads && scratch,
                 "comic_cnn_backward: null argument");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == COMIC_BF16)
     return cnn_backward_impl<bf16_t>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
-                                     scratch_bytes, st);
+                                     scratch_bytes, st, filters_ready != 0);
   if (dtype == COMIC_F32)
     return cnn_backward_impl<float>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
-                                    scratch_bytes, st);
+                                    scratch_bytes, st, filters_ready != 0);
   COMIC_REQUIRE(false, "unknown dtype %d", dtype);
   return 2;
 }

@@ -395,6 +395,19 @@ class CnnEncoder:
                                                    self.beta.data.data_ptr(), self.mean.data.data_ptr(),
                                                    self.scale.data.data_ptr(), self.shift.data.data_ptr(),
                                                    self.beta.numel, L.stream_ptr()), 'cnn_refresh_weights')
+        # masters changed: version stamp shared by every encoder aliasing them
+        self.w_master.__dict__['_ver'] = self.w_master.__dict__.get('_ver', 0) + 1
+        t = getattr(self, '_train', None)
+        if t is not None:
+            # the backward-data filters follow the masters: repack them on a second stream, off the
+            # critical path (the next forward / decoder step run meanwhile); backward() waits for the event
+            torch = self.torch
+            t.aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(t.aux):
+                L.check(self.lib.comic_cnn_pack_bwd_filters(self._ops, len(self.plan.ops), t.grads, self.dcode,
+                                                            L.stream_ptr()), 'cnn_pack_bwd_filters')
+                t.filters_ev.record(t.aux)
+            t.filters_ver = self.w_master.__dict__['_ver']
 
     def export_params(self):
         """Trainable CNN variables back in the slim checkpoint layout: {name: HWIO weights / beta}."""
@@ -448,6 +461,9 @@ class CnnEncoder:
         t.scratch_bytes = int(self.lib.comic_cnn_backward_scratch_bytes(self._ops, len(plan.ops), self.batch,
                                                                          self.dcode))
         t.scratch = torch.empty(t.scratch_bytes, dtype=torch.uint8, device=self.device)
+        t.aux = torch.cuda.Stream(device=self.device)
+        t.filters_ev = torch.cuda.Event()
+        t.filters_ver = -1
         self._train = t
         return t
 
@@ -462,9 +478,12 @@ class CnnEncoder:
             t.gbufs[self.plan.fm].view(-1).copy_(d_fm.reshape(-1))
         if d_im_embed is not None:
             t.gbufs[self.plan.pooled].view(-1).copy_(d_im_embed.reshape(-1))
+        ready = t.filters_ver == self.w_master.__dict__.get('_ver', 0)   # else: packed inline by the executor
+        if ready:
+            self.torch.cuda.current_stream().wait_event(t.filters_ev)
         L.check(self.lib.comic_cnn_backward(self._ops, len(self.plan.ops), self._bufptr, t.gptr, self._bufch, self._wt,
-                                            t.grads, self.batch, self.dcode, t.scratch.data_ptr(), t.scratch_bytes,
-                                            L.stream_ptr()), 'cnn_backward')
+                                            t.grads, self.batch, self.dcode, int(ready), t.scratch.data_ptr(),
+                                            t.scratch_bytes, L.stream_ptr()), 'cnn_backward')
         return t
 
     def _build_group_args(self):

@@ -138,7 +138,13 @@ int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int
 int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                        void* const* grad_buffers, const int32_t* buf_channels,
                        const comic_conv_weight* weights, const comic_conv_grad* grads, int batch,
-                       int dtype, void* scratch, int64_t scratch_bytes, void* stream);
+                       int dtype, int filters_ready /* 1: w_bwd already packed, see below */,
+                       void* scratch, int64_t scratch_bytes, void* stream);
+/* Packs the backward-data filters of every conv from the masters (what comic_cnn_backward does per
+ * conv when filters_ready == 0).  They only change with the optimiser step, so the caller can do
+ * this once per step off the critical path (e.g. on a second stream during the next forward). */
+int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads,
+                               int dtype, void* stream);
 int comic_cnn_refresh_weights(const float* master, void* plan_copy, int64_t n, const float* beta,
                               const float* mean, const float* scale, float* shift,
                               int64_t channels, void* stream);
