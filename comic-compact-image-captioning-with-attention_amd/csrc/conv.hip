@@ -1741,10 +1741,10 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   COMIC_REQUIRE(op->SH == op->SW && (op->SH == 1 || op->SH == 2), "conv backward: stride must be 1 or 2");
   const int K = op->KH * op->KW * op->Cin, Kpad = (K + 63) / 64 * 64;
   const int dil = op->SH;
-  // zero-dilated d conv geometry: H + KH - 1 - 2*PT' with PT' = KH - 1 - PT  (see the section header)
-  const int Hd = dil == 1 ? op->Ho : op->H - op->KH + 1 + 2 * op->PT;
-  const int Wd = dil == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
-  COMIC_REQUIRE(Hd >= (op->Ho - 1) * dil + 1 && Wd >= (op->Wo - 1) * dil + 1, "conv backward: dilated geometry");
+  // zero-dilated d conv geometry: output pixel (ho, wo) sits at (ho*dil, wo*dil); the backward-data
+  // conv pads PT' = KH - 1 - PT rows on top and reads zeros below the buffer (bounds checks)
+  const int Hd = (op->Ho - 1) * dil + 1;
+  const int Wd = (op->Wo - 1) * dil + 1;
   const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
   COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward: scratch too small (%zu needed)", dz_bytes);
   T* dz = (T*)scratch;
@@ -1888,8 +1888,8 @@ extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int
   for (int i = 0; i < n_ops; ++i) {
     const comic_cnn_op* op = ops + i;
     if (op->kind > 1) continue;
-    const int Hd = op->SH == 1 ? op->Ho : op->H - op->KH + 1 + 2 * op->PT;
-    const int Wd = op->SW == 1 ? op->Wo : op->W - op->KW + 1 + 2 * op->PL;
+    const int Hd = (op->Ho - 1) * op->SH + 1;
+    const int Wd = (op->Wo - 1) * op->SW + 1;
     const size_t dz = ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
     best = std::max(best, dz);
   }

@@ -53,7 +53,7 @@ class ModelBase(object):
                 tuple(c.cnn_input_size), c.cnn_fm_attention)
             share['plan'] = plan
             share['cnn_params'] = plan.init_params(seed=c.rand_seed % (2 ** 31))
-            fm = plan.buffers[plan.fm]
+            fm = plan.fm_dims()
             spec = cdec.DecoderSpec.from_config(c, (fm[0] * fm[1], fm[2]), plan.buffers[plan.pooled][2])
             share['spec'] = spec
             share['decoder'] = cdec.Decoder(spec, None, device, seed=c.rand_seed % (2 ** 31))

@@ -74,6 +74,30 @@ INCEPTION_V3_BLOCKS = [
 ]
 
 
+def _v1(c0, c1a, c1b, c2a, c2b, c3, quirk=False):
+    """Inception-V1 block (inception_v1.py:95-265): 1x1 | 1x1->3x3 | 1x1->3x3 | maxpool(3x3,s1,SAME)->1x1."""
+    return [[_c('Conv2d_0a_1x1', c0, 1)],
+            [_c('Conv2d_0a_1x1', c1a, 1), _c('Conv2d_0b_3x3', c1b, 3)],
+            [_c('Conv2d_0a_1x1', c2a, 1), _c('Conv2d_0a_3x3' if quirk else 'Conv2d_0b_3x3', c2b, 3)],
+            [('maxs1',), _c('Conv2d_0b_1x1', c3, 1)]]
+
+
+# ('pool', name, k) entries between blocks are SAME-padded stride-2 max pools
+INCEPTION_V1_STEM = [('c', 'Conv2d_1a_7x7', 64, (7, 7), 2, 'SAME'), ('pool', 'MaxPool_2a_3x3', 3),
+                     ('c', 'Conv2d_2b_1x1', 64, (1, 1), 1, 'SAME'), ('c', 'Conv2d_2c_3x3', 192, (3, 3), 1, 'SAME'),
+                     ('pool', 'MaxPool_3a_3x3', 3)]
+INCEPTION_V1_BLOCKS = [
+    ('Mixed_3b', _v1(64, 96, 128, 16, 32, 32)), ('Mixed_3c', _v1(128, 128, 192, 32, 96, 64)),
+    ('pool', 'MaxPool_4a_3x3', 3),
+    ('Mixed_4b', _v1(192, 96, 208, 16, 48, 64)), ('Mixed_4c', _v1(160, 112, 224, 24, 64, 64)),
+    ('Mixed_4d', _v1(128, 128, 256, 24, 64, 64)), ('Mixed_4e', _v1(112, 144, 288, 32, 64, 64)),
+    ('Mixed_4f', _v1(256, 160, 320, 32, 128, 128)),
+    ('pool', 'MaxPool_5a_2x2', 2),
+    ('Mixed_5b', _v1(256, 160, 320, 32, 128, 128, quirk=True)),      # reference scope-name quirk (:240)
+    ('Mixed_5c', _v1(384, 192, 384, 48, 128, 128)),
+]
+
+
 def _out(size, k, s, pad):
     if pad == 'SAME':
         o = -(-size // s)
@@ -87,12 +111,14 @@ class CnnPlan:
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
                  group_branches=True, layers=None):
-        if name not in ('inception_v3', 'chain'):
-            raise NotImplementedError('only inception_v3 is on the MI355X hot path (got %r)' % name)
+        if name not in ('inception_v3', 'inception_v1', 'chain'):
+            raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
         self.ops = []            # dicts
         self.buffers = []        # (H, W, C, f32)
-        self.weights = []        # (var_prefix, kh, kw, cin, cout, stem)
+        self.weights = []        # (var_prefix, kh, kw, cin, cout, stem)  -- the VARIABLE's (logical) shape
+        self.wphys = []          # (cin, cout) as laid out in the buffers (channels padded to a multiple of 16)
+        self.fm_src = None       # bf16 buffer the fp32 feature map is converted from (fm not the last block)
         self.end_points = {}     # name -> buffer id
         self.macs = 0
         self._lane = 0
@@ -101,8 +127,11 @@ class CnnPlan:
         self.group_branches = group_branches and not branch_streams
         self._depth = 0
         self._next_group = 1
+        self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
         if name == 'chain':
             self._build_chain(image_size, layers)
+        elif name == 'inception_v1':
+            self._build_v1(image_size, 'Mixed_4f' if final_endpoint == 'Mixed_7c' else final_endpoint)
         else:
             self._build_v3(image_size, final_endpoint)
 
@@ -113,15 +142,22 @@ class CnnPlan:
 
     def _conv(self, src, scope, spec, dst=None, dst_coff=0, out_f32=False):
         _, name, cout, (kh, kw), stride, pad = spec
-        H, W, Cin, _ = self.buffers[src]
+        H, W, Cin_p, _ = self.buffers[src]
+        Cin = self._logical.get(src, Cin_p)          # channels of the producing variable (the rest is zero padding)
         Ho, pt = _out(H, kh, stride, pad)
         Wo, pl = _out(W, kw, stride, pad)
+        cout_p = (cout + 15) // 16 * 16              # MFMA tile granularity; Inception-V1 has 24-channel reduces
         if dst is None:
-            dst = self._buf(Ho, Wo, cout, out_f32)
+            dst = self._buf(Ho, Wo, cout_p, out_f32)
+            if cout_p != cout:
+                self._logical[dst] = cout
+        else:
+            assert cout_p == cout, 'a conv that writes a concat slice needs Cout % 16 == 0'
         stem = Cin <= 4
         self.weights.append((scope + '/' + name, kh, kw, Cin, cout, stem))
+        self.wphys.append((Cin_p, cout_p))
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
-                             Cin=Cin, Cout=cout, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
+                             Cin=Cin_p, Cout=cout_p, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
                              weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32), lane=self._lane,
                              depth=self._depth))
         self.macs += Ho * Wo * kh * kw * Cin * cout
@@ -209,6 +245,58 @@ class CnnPlan:
         self.pooled = pooled
         self.end_points['AvgPool_1a'] = pooled
 
+    def _build_v1(self, image_size, fm_endpoint):
+        """inception_v1_base (inception_v1.py:29-266) + head (:319-327): conv / max-pool defaults stride 1,
+        SAME; feature map = `fm_endpoint` (reference default Mixed_4f, train.py:65), net = 7x7 VALID
+        average of Mixed_5c."""
+        H, W = image_size
+        cur = self._buf(H, W, 3, True)
+        self.input = cur
+        root = 'InceptionV1'
+        for op in INCEPTION_V1_STEM:
+            if op[0] == 'c':
+                cur, _ = self._conv(cur, root, op)
+            else:
+                cur, _ = self._pool(cur, 2, op[2], 2, 'SAME')
+            self.end_points[op[1]] = cur
+        for entry in INCEPTION_V1_BLOCKS:
+            if entry[0] == 'pool':
+                cur, _ = self._pool(cur, 2, entry[2], 2, 'SAME')
+                self.end_points[entry[1]] = cur
+                continue
+            bname, branches = entry
+            Hi, Wi, Ci, _ = self.buffers[cur]
+            Ctot = sum(b[-1][2] for b in branches)
+            last = bname == 'Mixed_5c'
+            blk = self._buf(Hi, Wi, Ctot, f32=last)          # pooled by the head in fp32 (as InceptionV3's last block)
+            first_op = len(self.ops)
+            coff = 0
+            for bi, branch in enumerate(branches):
+                scope = '%s/%s/Branch_%d' % (root, bname, bi)
+                x = cur
+                for oi, op in enumerate(branch):
+                    self._depth = oi
+                    if op[0] == 'maxs1':
+                        x, _ = self._pool(x, 2, 3, 1, 'SAME')
+                    elif oi == len(branch) - 1:
+                        self._conv(x, scope, op, blk, coff, out_f32=last)
+                    else:
+                        x, _ = self._conv(x, scope, op)
+                coff += branch[-1][2]
+            self._depth = 0
+            if self.group_branches:
+                self._schedule_by_depth(first_op)
+            cur = blk
+            self.end_points[bname] = cur
+        if fm_endpoint not in self.end_points:
+            raise ValueError('unknown feature-map end point %r' % fm_endpoint)
+        self._finish_head(cur)
+        if fm_endpoint != 'Mixed_5c':
+            # the attention feature map is an inner end point: kept in the plan dtype for the layers that
+            # follow and converted to fp32 for the decoder by the encoder (CnnEncoder.forward)
+            self.fm_src = self.end_points[fm_endpoint]
+            self.fm = None
+
     def _build_v3(self, image_size, final_endpoint):
         H, W = image_size
         cur = self._buf(H, W, 3, True)          # fp32 images in [-1, 1]
@@ -269,6 +357,10 @@ class CnnPlan:
                 break
         self._finish_head(cur)
 
+    def fm_dims(self):
+        """(H, W, C) of the attention feature map."""
+        return self.buffers[self.fm if self.fm is not None else self.fm_src][:3]
+
     # -- parameters -----------------------------------------------------------------------
     def param_shapes(self):
         out = {}
@@ -320,9 +412,10 @@ class CnnEncoder:
         else:
             wshapes, bshapes = {}, {}
             for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-                K = kh * kw * cin
-                wshapes['w%d' % i] = (K * cout,) if stem else (cout * ((K + 63) // 64 * 64),)
-                bshapes['b%d' % i] = (cout,)
+                cin_p, cout_p = plan.wphys[i]            # physical (padded) channel counts
+                K = kh * kw * cin_p
+                wshapes['w%d' % i] = (K * cout_p,) if stem else (cout_p * ((K + 63) // 64 * 64),)
+                bshapes['b%d' % i] = (cout_p,)
             self.w_master = FlatParams(wshapes, device)
             self.beta = FlatParams(bshapes, device)
             self.mean, self.scale, self.shift = self.beta.like(), self.beta.like(), self.beta.like()
@@ -361,28 +454,37 @@ class CnnEncoder:
         # > 0: conv workgroups request at least this much LDS (1 per CU at 84) -- for forwards that run on a
         # second stream under other kernels (CaptionTrainer's overlapped encoder); set before the graph capture
         self.polite_lds_kb = 0
+        self._fm_f32 = None
 
     def load_params(self, params):
         """(Re)load every CNN variable from {slim name: array} into the flat masters IN PLACE (all
         encoders that share them, and any optimiser bound to them, see the new values)."""
         torch, st = self.torch, L.stream_ptr()
         for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            cin_p, cout_p = self.plan.wphys[i]
             w = torch.from_numpy(np.ascontiguousarray(params[prefix + '/weights'], np.float32)).to(self.device)
             assert tuple(w.shape) == (kh, kw, cin, cout), prefix
             beta, mean, var = (torch.from_numpy(np.ascontiguousarray(
                 params[prefix + '/BatchNorm/' + s], np.float32)).to(self.device)
                 for s in ('beta', 'moving_mean', 'moving_variance'))
+            if (cin_p, cout_p) != (cin, cout):          # zero weights / beta 0, mean 0, var 1 on the padding channels
+                wp = torch.zeros((kh, kw, cin_p, cout_p), dtype=torch.float32, device=self.device)
+                wp[:, :, :cin, :cout] = w
+                w = wp
+                pad = lambda t, fill: torch.cat([t, torch.full((cout_p - cout,), fill, dtype=torch.float32,
+                                                               device=self.device)])
+                beta, mean, var = pad(beta, 0.0), pad(mean, 0.0), pad(var, 1.0)
             bk = 'b%d' % i
             self.beta.view(bk).copy_(beta)
             self.mean.view(bk).copy_(mean)
             L.check(self.lib.comic_fold_bn(beta.data_ptr(), mean.data_ptr(), var.data_ptr(), BN_EPS,
-                                           self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout, st),
+                                           self.scale.view(bk).data_ptr(), self.shift.view(bk).data_ptr(), cout_p, st),
                     'fold_bn')
             master = self.w_master.view('w%d' % i)
             if stem:
                 master.copy_(w.reshape(-1))
             else:
-                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin, cout, 0, st),
+                L.check(self.lib.comic_pack_conv_weights(w.data_ptr(), master.data_ptr(), kh, kw, cin_p, cout_p, 0, st),
                         'pack_conv_weights')
         self.refresh_weights()
         torch.cuda.synchronize()
@@ -409,15 +511,28 @@ class CnnEncoder:
                 t.filters_ev.record(t.aux)
             t.filters_ver = self.w_master.__dict__['_ver']
 
+    def _unpack(self, i, flat_w, flat_b):
+        """Packed master-layout buffers of weight i -> (HWIO array, per-channel vector) of the variable's shape."""
+        prefix, kh, kw, cin, cout, stem = self.plan.weights[i]
+        cin_p, cout_p = self.plan.wphys[i]
+        K = kh * kw * cin_p
+        m = flat_w.view('w%d' % i)
+        w = m.view(K, cout_p) if stem else m.view(cout_p, -1)[:, :K].t()
+        w = w.reshape(kh, kw, cin_p, cout_p)[:, :, :cin, :cout]
+        return w.contiguous().cpu().numpy(), flat_b.view('b%d' % i)[:cout].cpu().numpy().copy()
+
     def export_params(self):
         """Trainable CNN variables back in the slim checkpoint layout: {name: HWIO weights / beta}."""
         out = {}
         for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
-            K = kh * kw * cin
-            m = self.w_master.view('w%d' % i)
-            w = m.view(K, cout) if stem else m.view(cout, -1)[:, :K].t()
-            out[prefix + '/weights'] = w.reshape(kh, kw, cin, cout).contiguous().cpu().numpy()
-            out[prefix + '/BatchNorm/beta'] = self.beta.view('b%d' % i).cpu().numpy().copy()
+            out[prefix + '/weights'], out[prefix + '/BatchNorm/beta'] = self._unpack(i, self.w_master, self.beta)
+        return out
+
+    def export_grads(self):
+        """{variable name: gradient} of the last backward() in the slim layout."""
+        t, out = self._train, {}
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            out[prefix + '/weights'], out[prefix + '/BatchNorm/beta'] = self._unpack(i, t.dw, t.dbeta)
         return out
 
     # -- cnn_finetune ------------------------------------------------------------------------------
@@ -447,7 +562,7 @@ class CnnEncoder:
         t.gptr = (C.c_void_p * len(t.gbufs))(*[g.data_ptr() if g is not None else None for g in t.gbufs])
         esz = 4 if self.dcode == 0 else 2
         wb_off, n = [], 0
-        for (prefix, kh, kw, cin, cout, stem) in plan.weights:
+        for (prefix, kh, kw, cin, cout, stem), (cin, cout) in zip(plan.weights, plan.wphys):
             wb_off.append(n)
             if not stem:
                 n += (cin * ((kh * kw * cout + 63) // 64 * 64) * esz + 255) // 256 * 256
@@ -475,7 +590,8 @@ class CnnEncoder:
         t.dw.data.zero_()
         t.dbeta.data.zero_()
         if d_fm is not None:
-            t.gbufs[self.plan.fm].view(-1).copy_(d_fm.reshape(-1))
+            g = t.gbufs[self.plan.fm if self.plan.fm is not None else self.plan.fm_src]
+            g.view(-1).copy_(d_fm.reshape(-1))              # converts to the buffer's dtype
         if d_im_embed is not None:
             t.gbufs[self.plan.pooled].view(-1).copy_(d_im_embed.reshape(-1))
         ready = t.filters_ver == self.w_master.__dict__.get('_ver', 0)   # else: packed inline by the executor
@@ -542,9 +658,16 @@ class CnnEncoder:
         else:
             self._run()
         self._calls += 1
-        fm = self.bufs[self.plan.fm]
         pooled = self.bufs[self.plan.pooled]
         B = self.batch
+        if self.plan.fm is None:           # inner end point (Inception-V1 Mixed_4f): fp32 copy for the decoder
+            src = self.bufs[self.plan.fm_src]
+            if self._fm_f32 is None:
+                self._fm_f32 = self.torch.empty(src.shape, dtype=self.torch.float32, device=self.device)
+            self._fm_f32.copy_(src)
+            fm = self._fm_f32
+        else:
+            fm = self.bufs[self.plan.fm]
         return pooled.reshape(B, -1), fm.reshape(B, fm.shape[1] * fm.shape[2], fm.shape[3])
 
     def autotune(self, reps=5, verbose=False):
@@ -644,7 +767,7 @@ def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
     if is_training:
         raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
 
-    def network_fn(image_size=(224, 224), final_endpoint='Mixed_7c'):
-        return CnnPlan(name, image_size, final_endpoint)
-    network_fn.default_image_size = 299
+    def network_fn(image_size=(224, 224), final_endpoint=None):
+        return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'))
+    network_fn.default_image_size = 224 if name == 'inception_v1' else 299
     return network_fn

@@ -152,17 +152,18 @@ def max_pool_bwd(x, dy, k=3, stride=2, padding='VALID'):
     """MaxPoolGrad: the gradient of a window goes to its FIRST maximum in window scan order
     (kh-major) -- TF's CPU kernel (argmax from the forward pass).  Ties other than between
     ReLU zeros (whose gradient the producing conv masks anyway) do not occur in practice."""
-    assert padding == 'VALID'
     B, H, W, C = x.shape
-    Ho, Wo = (H - k) // stride + 1, (W - k) // stride + 1
-    win = np.stack([x[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+    Ho, pt, pb = out_size(H, k, stride, padding)
+    Wo, pl, pr = out_size(W, k, stride, padding)
+    xp = np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)), constant_values=-np.inf) if (pt or pb or pl or pr) else x
+    win = np.stack([xp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
                     for i in range(k) for j in range(k)], axis=0)          # [k*k, B, Ho, Wo, C]
     arg = np.argmax(win, axis=0)                                          # first maximum
-    dx = np.zeros_like(x)
+    dxp = np.zeros_like(xp)
     for t in range(k * k):
         i, j = divmod(t, k)
-        dx[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :] += np.where(arg == t, dy, 0)
-    return dx
+        dxp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :] += np.where(arg == t, dy, 0)
+    return dxp[:, pt:pt + H, pl:pl + W, :]
 
 
 def avg_pool_bwd(x_shape, dy, k=3, stride=1, padding='SAME'):
@@ -390,6 +391,78 @@ def _inception_v3_base(net: _Net, x, end_points):
         net.scope.pop()
     net.scope.pop()
     return x
+
+
+def _inception_v1_base(net: _Net, x, end_points):
+    """common/nets/inception_v1.py:29-266 (conv2d / max_pool2d default stride 1, SAME; conv +
+    BN(inference) + ReLU under inception_v1_arg_scope = inception_utils.inception_arg_scope)."""
+    net.scope.append('InceptionV1')
+    x = net.conv(x, 64, 7, 2, 'SAME', 'Conv2d_1a_7x7'); end_points['Conv2d_1a_7x7'] = x
+    x = net.max_pool(x, 3, 2, 'SAME'); end_points['MaxPool_2a_3x3'] = x
+    x = net.conv(x, 64, 1, 1, 'SAME', 'Conv2d_2b_1x1'); end_points['Conv2d_2b_1x1'] = x
+    x = net.conv(x, 192, 3, 1, 'SAME', 'Conv2d_2c_3x3'); end_points['Conv2d_2c_3x3'] = x
+    x = net.max_pool(x, 3, 2, 'SAME'); end_points['MaxPool_3a_3x3'] = x
+
+    def block(x, name, c0, c1a, c1b, c2a, c2b, c3, quirk=False):
+        net.scope.append(name)
+        net.scope.append('Branch_0'); b0 = net.conv(x, c0, 1, 1, 'SAME', 'Conv2d_0a_1x1'); net.scope.pop()
+        net.scope.append('Branch_1')
+        b1 = net.conv(x, c1a, 1, 1, 'SAME', 'Conv2d_0a_1x1'); b1 = net.conv(b1, c1b, 3, 1, 'SAME', 'Conv2d_0b_3x3')
+        net.scope.pop()
+        net.scope.append('Branch_2')
+        b2 = net.conv(x, c2a, 1, 1, 'SAME', 'Conv2d_0a_1x1')
+        b2 = net.conv(b2, c2b, 3, 1, 'SAME', 'Conv2d_0a_3x3' if quirk else 'Conv2d_0b_3x3')   # :240 scope quirk in Mixed_5b
+        net.scope.pop()
+        net.scope.append('Branch_3')
+        b3 = net.max_pool(x, 3, 1, 'SAME'); b3 = net.conv(b3, c3, 1, 1, 'SAME', 'Conv2d_0b_1x1'); net.scope.pop()
+        net.scope.pop()
+        y = net.concat([b0, b1, b2, b3])
+        end_points[name] = y
+        return y
+    x = block(x, 'Mixed_3b', 64, 96, 128, 16, 32, 32)
+    x = block(x, 'Mixed_3c', 128, 128, 192, 32, 96, 64)
+    x = net.max_pool(x, 3, 2, 'SAME'); end_points['MaxPool_4a_3x3'] = x
+    x = block(x, 'Mixed_4b', 192, 96, 208, 16, 48, 64)
+    x = block(x, 'Mixed_4c', 160, 112, 224, 24, 64, 64)
+    x = block(x, 'Mixed_4d', 128, 128, 256, 24, 64, 64)
+    x = block(x, 'Mixed_4e', 112, 144, 288, 32, 64, 64)
+    x = block(x, 'Mixed_4f', 256, 160, 320, 32, 128, 128)
+    x = net.max_pool(x, 2, 2, 'SAME'); end_points['MaxPool_5a_2x2'] = x
+    x = block(x, 'Mixed_5b', 256, 160, 320, 32, 128, 128, quirk=True)
+    x = block(x, 'Mixed_5c', 384, 192, 384, 48, 128, 128)
+    net.scope.pop()
+    return x
+
+
+def _run_v1(net: _Net, images):
+    end_points = OrderedDict()
+    x = _inception_v1_base(net, np.asarray(images, np.float32), end_points)
+    pooled = net.avg_pool(x, (7, 7), 1, 'VALID')        # inception_v1.py:326 (fixed 7x7 kernel)
+    end_points['AvgPool_0a_7x7'] = pooled
+    return pooled, end_points
+
+
+def init_params_v1(seed=0, image_size=224):
+    net = _Net(None, np.random.default_rng(seed), run=False)
+    _run_v1(net, np.zeros((1, image_size, image_size, 3), np.float32))
+    return net.params
+
+
+def inception_v1(params, images, act_dtype='f32'):
+    """-> (net [B,1,1,1024], end_points): get_network_fn('inception_v1', num_classes=None,
+    is_training=False) -- the reference's default backbone (train.py:56,65: Mixed_4f feature map)."""
+    return _run_v1(_Net(params, None, act_dtype=act_dtype, run=True), images)
+
+
+def inception_v1_grads(params, images, d_net, d_fm, fm_name='Mixed_4f', act_dtype='f32'):
+    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+    net, ep = _run_v1(n, images)
+    seeds = []
+    if d_net is not None:
+        seeds.append((net, np.asarray(d_net, np.float32).reshape(net.shape)))
+    if d_fm is not None:
+        seeds.append((ep[fm_name], np.asarray(d_fm, np.float32).reshape(ep[fm_name].shape)))
+    return n.backward(seeds), net, ep
 
 
 def _run(net: _Net, images):

@@ -74,3 +74,30 @@ def test_train_infer_scst_cli(tmp_path):
     assert not errs, open(errs[0]).read()
     scst_dirs = glob.glob(os.path.join(logs, 'mscoco', '*_cnnFT_SCST_beam_3_*'))
     assert scst_dirs and glob.glob(os.path.join(scst_dirs[0], 'model_compact-*.npz'))
+
+
+def test_train_infer_cli_default_backbone(tmp_path):
+    """The reference's default backbone and feature map (--cnn_name inception_v1, --cnn_fm_attention
+    Mixed_4f: train.py:56,65): one decoder-mode epoch and beam-3 inference through the CLIs."""
+    from tests import tiny_dataset
+    from comic_amd import configuration as conf
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=4, n_test=4)
+    logs = str(tmp_path / 'experiments')
+    _run(os.path.join(ROOT, 'src', 'train.py'), ['--dataset_dir', ds, '--log_root', logs, '--batch_size_eval', '4',
+                                                 '--rnn_size', '128', '--rnn_word_size', '64', '--train_mode', 'decoder',
+                                                 '--batch_size_train', '4', '--max_epoch', '1'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01')
+    c = conf.load_config(os.path.join(run_dir, 'config.pkl'))
+    assert c.cnn_name == 'inception_v1' and c.cnn_fm_attention == 'Mixed_4f'
+    ck = sorted(glob.glob(os.path.join(run_dir, 'model_compact-*.npz')))
+    assert ck
+    z = np.load(ck[-1])
+    assert z['Model/encoder/cnn/InceptionV1/Mixed_4c/Branch_2/Conv2d_0a_1x1/weights'].shape == (1, 1, 512, 24)
+    assert z['Model/decoder/rnn_decoder/memory_layer/kernel'].shape[0] == 832     # attention over Mixed_4f
+    _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--get_metric_score', ''])
+    caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
+    assert caps and len(json.load(open(caps[0]))) == 4

@@ -86,14 +86,53 @@ def test_grouped_branch_launch_is_bit_identical():
 
 def _cnn_grads_device(enc, t):
     """{variable name: gradient} in the slim layout from the packed fp32 gradient buffers."""
-    out = {}
-    for i, (prefix, kh, kw, cin, cout, stem) in enumerate(enc.plan.weights):
-        K = kh * kw * cin
-        g = t.dw.view('w%d' % i)
-        w = g.view(K, cout) if stem else g.view(cout, -1)[:, :K].t()
-        out[prefix + '/weights'] = w.reshape(kh, kw, cin, cout).cpu().numpy()
-        out[prefix + '/BatchNorm/beta'] = t.dbeta.view('b%d' % i).cpu().numpy()
-    return out
+    return enc.export_grads()
+
+
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 3e-2)])
+def test_inception_v1_forward_224(dtype, tol):
+    """The reference's default backbone (train.py:56,65): Inception-V1, feature map Mixed_4f
+    (14x14x832, an INNER end point handed over in fp32), net = 7x7 average of Mixed_5c; SAME-padded
+    7x7 stride-2 stem and max pools, stride-1 max pools inside the blocks, 24-channel reduces padded
+    to the MFMA tile."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params_v1(0), seed=1)
+    x = np.random.default_rng(3).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    plan = nets.CnnPlan('inception_v1', (224, 224), 'Mixed_4f')
+    assert sum(int(np.prod(v)) for v in plan.param_shapes().values()) == 5607184       # inception_v1_test.py:124-132
+    enc = nets.CnnEncoder(plan, params, B, dtype, DEV)
+    im, fm = enc.forward(dev(x))
+    sync()
+    net_ref, ep = cnn_ref.inception_v1(params, x, act_dtype=dtype)
+    assert fm.shape == (B, 196, 832) and im.shape == (B, 1024) and fm.dtype == torch.float32
+    for name in ('Conv2d_1a_7x7', 'MaxPool_2a_3x3', 'Conv2d_2c_3x3', 'Mixed_3c', 'Mixed_4b', 'Mixed_4e', 'Mixed_5b'):
+        got = enc.end_point(name).float().cpu().numpy()
+        assert_close(got[..., :ep[name].shape[-1]], ep[name], tol, '%s %s' % (name, dtype))
+    assert_close(fm.cpu().numpy().reshape(B, 14, 14, 832), ep['Mixed_4f'], tol, 'Mixed_4f ' + dtype)
+    assert_close(im.cpu().numpy(), net_ref.reshape(B, -1), tol, 'net ' + dtype)
+
+
+def test_inception_v1_backward_224_f32():
+    """cnn_finetune on the default backbone: gradients enter at the INNER feature map (Mixed_4f) and at
+    the pooled vector; d weights / d beta of all 57 convs vs the oracle's reverse pass (fp32)."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params_v1(0), seed=1)
+    rng = np.random.default_rng(13)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 196, 832)
+    d_net = (1 + 0.5 * rng.standard_normal((B, 1024))).astype(np.float32)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v1', (224, 224), 'Mixed_4f'), params, B, 'f32', DEV)
+    enc.forward(dev(x))
+    enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    got = enc.export_grads()
+    want, _, _ = cnn_ref.inception_v1_grads(params, x, d_net, d_fm)
+    assert set(got) == set(want) and len(want) == 114
+    errs = sorted((rel_err(got[k], want[k]), k) for k in want)
+    assert errs[-1][0] < 2e-3, errs[-1]
+    # every block has a 3x3 stride-1 max-pool branch, so arg-max flips between the two (1e-6 apart) forward
+    # passes reach every layer: the median is ~1e-4 here, against ~1e-6 for InceptionV3
+    assert errs[len(errs) // 2][0] < 5e-4, errs[len(errs) // 2]
 
 
 def _seeds(rng, B, M, C):

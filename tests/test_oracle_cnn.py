@@ -80,3 +80,24 @@ def test_forward_small_image_finite_and_deterministic():
     im2, fm2 = cnn_ref.encoder(params, x, act_dtype='bf16')
     rel = np.abs(fm2 - fm).max() / np.abs(fm).max()
     assert rel < 0.1
+
+
+def test_inception_v1_known_answers():
+    """inception_v1_test.py: end-point shapes at 224 (:91-122) and 5 607 184 model variables (:124-132);
+    MACs per image 1.497 G (SURVEY §8 a1')."""
+    p = cnn_ref.init_params_v1(0, 224)
+    assert sum(v.size for v in p.values()) == 5607184
+    x = np.random.default_rng(0).uniform(-1, 1, (1, 224, 224, 3)).astype(np.float32)
+    net, ep = cnn_ref.inception_v1(p, x)
+    want = {'Conv2d_1a_7x7': (112, 112, 64), 'MaxPool_2a_3x3': (56, 56, 64), 'Conv2d_2b_1x1': (56, 56, 64),
+            'Conv2d_2c_3x3': (56, 56, 192), 'MaxPool_3a_3x3': (28, 28, 192), 'Mixed_3b': (28, 28, 256),
+            'Mixed_3c': (28, 28, 480), 'MaxPool_4a_3x3': (14, 14, 480), 'Mixed_4b': (14, 14, 512),
+            'Mixed_4c': (14, 14, 512), 'Mixed_4d': (14, 14, 512), 'Mixed_4e': (14, 14, 528),
+            'Mixed_4f': (14, 14, 832), 'MaxPool_5a_2x2': (7, 7, 832), 'Mixed_5b': (7, 7, 832),
+            'Mixed_5c': (7, 7, 1024)}
+    for k, shp in want.items():
+        assert ep[k].shape == (1,) + shp, k
+    assert net.shape == (1, 1, 1, 1024) and np.isfinite(net).all()
+    n = cnn_ref._Net(None, np.random.default_rng(0), run=False)
+    cnn_ref._run_v1(n, np.zeros((1, 224, 224, 3), np.float32))
+    assert n.macs == 1497352192 and len(n.conv_log) == 57
