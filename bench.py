@@ -125,7 +125,8 @@ def extras(device, enc, cnn_params, plan):
     # ---- cnn_finetune step (configs[2]: CNN + decoder trainable, batch 32) ---------------------
     from comic_amd import trainer
     Bf = 32
-    tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16', device, seed=5, plan=plan)
+    plan_ft = nets.CnnPlan('inception_v3', (IMG, IMG))           # trainable CNN: the plain plan (has a backward)
+    tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16', device, seed=5, plan=plan_ft)
     tr.enable_cnn_finetune()
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bf, IMG, IMG, 3)).astype(np.float32)).to(device)
     caps = synth_captions(rng, Bf)
@@ -194,8 +195,10 @@ def main():
 
     from comic_amd import decoder as cdec, nets, trainer
     dp = trainer.DataParallel(dist if world > 1 else None)
+    # decoder mode: the CNN is frozen, so the plan may use the forward-only pool-branch rewrite
     plan = nets.CnnPlan('inception_v3', (IMG, IMG), branch_streams=os.environ.get('COMIC_CNN_LANES', '0') == '1',
-                        group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1')
+                        group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1',
+                        pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
     tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan)

@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
 class CnnOp(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
-        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group')]
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group', 'flags')]
 
 
 class ConvWeight(C.Structure):
@@ -33,7 +33,8 @@ class DecoderDesc(C.Structure):
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
 
 
-CONV_TILES = 12
+CONV_TILES = 21          # 1..12 im2col LDS-DMA variants, 13..18 patch-resident variants, 19..21 six-stage rings (single launches)
+GROUP_CONV_TILES = 12
 PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
 
 

@@ -35,6 +35,8 @@ struct ConvArgs {
   int blk0, tiles_m; // grouped launch: first flat workgroup id of this problem, its pixel-tile count
   int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index)
   int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
+  // patch-resident kernel (conv_patch.inc): tile geometry, filled by apply_geometry()
+  int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB;
 };
 
 template <typename T>
@@ -373,6 +375,50 @@ __global__ __launch_bounds__(256) void pool_kernel(ConvArgs a) {
   store_vec<T>((T*)a.y + (size_t)pix * a.y_cs + a.y_co + cv * EPC, acc);
 }
 
+// kind 7: 3x3 s1 SAME average (divisor = taps inside the image) of an fp32 map, then the folded
+// BatchNorm + ReLU of the projection that produced it.  One thread per (pixel, 4 channels).
+template <typename TOUT>
+__global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
+  const int cvecs = a.Cin / 4;
+  const long total = (long)a.M * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  int mm = (int)(idx / cvecs);
+  const int pix = mm;
+  const int wo = mm % a.Wo;
+  mm /= a.Wo;
+  const int ho = mm % a.Ho;
+  const int b = mm / a.Ho;
+  const float* __restrict__ xg = (const float*)a.x;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)a.H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)a.W) continue;
+      const float4 v = *(const float4*)(xg + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + cv * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      ++cnt;
+    }
+  }
+  const float c = (float)cnt;
+  const float4 sc = *(const float4*)(a.scale + cv * 4), sh = *(const float4*)(a.shift + cv * 4);
+  float v0 = acc.x / c * sc.x + sh.x, v1 = acc.y / c * sc.y + sh.y, v2 = acc.z / c * sc.z + sh.z, v3 = acc.w / c * sc.w + sh.w;
+  if (a.relu) {
+    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+  }
+  const size_t off = (size_t)pix * a.y_cs + a.y_co + cv * 4;
+  if constexpr (sizeof(TOUT) == 4)
+    *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+  else
+    *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+}
+
 // global KHxKW VALID average -> fp32 [B, Ho*Wo, C]; one thread per (pixel, channel vec)
 template <typename T>
 __global__ __launch_bounds__(256) void global_avgpool_kernel(ConvArgs a) {
@@ -467,6 +513,65 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>());
     static_for<I + 1, N>(f);
+  }
+}
+
+// Epilogue shared by the bf16 conv kernels: y = relu(acc * scale[n] + shift[n]) for a wave's TN x TM
+// 16x16 accumulator tiles.  Lane (mcol = lane & 15, nq = (lane >> 4) * 4) holds 4 consecutive output
+// channels n0..n0+3 of pixel mrow[j] (< 0: no such pixel).  Every scale / shift vector is loaded up
+// front and the arithmetic is branch-free, so the only vector-memory wait in here is the one for those
+// loads: with the loads inside the per-tile branches the compiler has to drain vmcnt(0) at the top of
+// every tile, i.e. each store waited for the previous store's round trip.
+template <int TN, int TM>
+__device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&acc)[TN][TM], const int nbase,
+                                                 const int nq, const int (&mrow)[TM]) {
+  float4 sc[TN], sh[TN];
+  bool nv[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    nv[i] = nbase + i * 16 < a.Cout;                     // wave-uniform: Cout is a multiple of 16
+    const int n0 = nv[i] ? nbase + i * 16 + nq : 0;
+    sc[i] = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    sh[i] = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n0 = nbase + i * 16 + nq;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      float v0 = acc[i][j][0] * sc[i].x + sh[i].x;
+      float v1 = acc[i][j][1] * sc[i].y + sh[i].y;
+      float v2 = acc[i][j][2] * sc[i].z + sh[i].z;
+      float v3 = acc[i][j][3] * sc[i].w + sh[i].w;
+      if (a.relu) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+        v2 = fmaxf(v2, 0.f);
+        v3 = fmaxf(v3, 0.f);
+      }
+      const bool ok = nv[i] & (mrow[j] >= 0);
+      const size_t off = (size_t)(ok ? mrow[j] : 0) * a.y_cs + a.y_co + n0;
+      if (a.out_f32) {
+        float4* yp = (float4*)((float*)a.y + off);
+        if (a.accum) {
+          if (ok) {
+            const float4 o = *yp;
+            v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+          }
+        }
+        if (ok) *yp = make_float4(v0, v1, v2, v3);
+      } else {
+        uint2* yp = (uint2*)((bf16_t*)a.y + off);
+        if (a.accum) {
+          if (ok) {
+            const uint2 o = *yp;
+            v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xFFFF0000u);
+            v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xFFFF0000u);
+          }
+        }
+        if (ok) *yp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
   }
 }
 
@@ -653,46 +758,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   }
 
   // ---- epilogue: y = relu(acc * scale[n] + shift[n]) ----------------------------------
-  const int mcol = lane & 15, nq = (lane >> 4) * 4;
+  int mrow[TM];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n0 = bn0 + wn * (BN / WN) + i * 16 + nq;
-    if (n0 >= a.Cout) continue;
-    const float4 sc = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 sh = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int m = bm0 + wm * (BM / WM) + j * 16 + mcol;
-      if (m >= a.M) continue;
-      float v0 = acc[i][j][0] * sc.x + sh.x;
-      float v1 = acc[i][j][1] * sc.y + sh.y;
-      float v2 = acc[i][j][2] * sc.z + sh.z;
-      float v3 = acc[i][j][3] * sc.w + sh.w;
-      if (a.relu) {
-        v0 = fmaxf(v0, 0.f);
-        v1 = fmaxf(v1, 0.f);
-        v2 = fmaxf(v2, 0.f);
-        v3 = fmaxf(v3, 0.f);
-      }
-      const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
-      if (a.out_f32) {
-        float4* yp = (float4*)((float*)a.y + off);
-        if (a.accum) {
-          const float4 o = *yp;
-          v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
-        }
-        *yp = make_float4(v0, v1, v2, v3);
-      } else {
-        uint2* yp = (uint2*)((bf16_t*)a.y + off);
-        if (a.accum) {
-          const uint2 o = *yp;
-          v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xFFFF0000u);
-          v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xFFFF0000u);
-        }
-        *yp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    }
+  for (int j = 0; j < TM; ++j) {
+    const int m = bm0 + wm * (BM / WM) + j * 16 + (lane & 15);
+    mrow[j] = m < a.M ? m : -1;
   }
+  conv_store_tiles<TN, TM>(a, acc, bn0 + wn * (BN / WN), (lane >> 4) * 4, mrow);
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i % 8), each with a private
@@ -765,6 +837,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_grouped_kernel(const ConvA
 static int g_conv_min_lds = 0;
 int conv_min_lds() { return g_conv_min_lds; }
 
+#include "conv_patch.inc"
+
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
   constexpr int lds0 = NSTAGE * (BM + BN) * 128;
@@ -831,6 +905,13 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 10: return launch_dma<32, 64, 1, 4, 4>(a, st);
     case 11: return launch_dma<64, 128, 2, 2, 4>(a, st);
     case 12: return launch_dma<128, 32, 4, 1, 4>(a, st);
+    // patch-resident variants (stride 1, Cin >= 32): 64*TM pixels x 16*TN channels
+    case 13: return launch_patch<4, 4>(a, st);
+    case 14: return launch_patch<4, 2>(a, st);
+    case 15: return launch_patch<4, 6>(a, st);
+    case 16: return launch_patch<2, 4>(a, st);
+    case 17: return launch_patch<2, 2>(a, st);
+    case 18: return launch_patch<2, 6>(a, st);
     default:
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
@@ -941,8 +1022,9 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.x = x;
   a.y = y;
   a.w = wt ? wt->w : nullptr;
-  a.scale = wt ? wt->scale : nullptr;
-  a.shift = wt ? wt->shift : nullptr;
+  const bool raw = op->kind == 0 && (op->flags & COMIC_OP_RAW);     // epilogue deferred to a kind-7 op
+  a.scale = (wt && !raw) ? wt->scale : nullptr;
+  a.shift = (wt && !raw) ? wt->shift : nullptr;
   a.B = batch;
   a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout;
   a.KH = op->KH; a.KW = op->KW; a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL;
@@ -974,7 +1056,7 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
   COMIC_REQUIRE(op->src_coff + op->Cin <= xc, "cnn op: source channel slice out of range");
   switch (op->kind) {
     case 0: {
-      COMIC_REQUIRE(wt && wt->w && (accum || (wt->scale && wt->shift)), "conv: missing weights");
+      COMIC_REQUIRE(wt && wt->w && (accum || (op->flags & COMIC_OP_RAW) || (wt->scale && wt->shift)), "conv: missing weights");
       COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0,
                     "conv: Cin/offset/stride must be multiples of %d", EPC);
       COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
@@ -1021,6 +1103,21 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "global pool: window exceeds input (VALID only)");
       const long total = (long)a.M * (op->Cin / EPC);
       hipLaunchKernelGGL((global_avgpool_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      break;
+    }
+    case 7: {
+      COMIC_REQUIRE(wt && wt->scale && wt->shift, "pool+bn: missing scale / shift");
+      COMIC_REQUIRE(op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1 && op->PT == 1 && op->PL == 1 &&
+                        op->Ho == op->H && op->Wo == op->W && op->Cin == op->Cout,
+                    "pool+bn: 3x3 stride-1 SAME only");
+      COMIC_REQUIRE(op->Cin % 4 == 0 && op->src_coff % 4 == 0 && xc % 4 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
+                    "pool+bn: channel counts/offsets must be multiples of 4");
+      COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool+bn: destination channel slice out of range");
+      const long total = (long)a.M * (op->Cin / 4);
+      if (op->out_f32 || sizeof(T) == 4)
+        hipLaunchKernelGGL((pool_bn_relu_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((pool_bn_relu_kernel<bf16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
       break;
     }
     default:
@@ -1096,7 +1193,8 @@ extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x
   COMIC_REQUIRE(op, "null op");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == COMIC_BF16 && op->src_f32) {
-    COMIC_REQUIRE(op->kind == 4, "src_f32 is only supported by the global average pool");
+    COMIC_REQUIRE(op->kind == 4 || op->kind == 7, "src_f32 is only supported by the global average pool and pool+bn");
+    if (op->kind == 7) return run_op<bf16_t>(op, x, x_channels, y, y_channels, wt, batch, st);
     return run_op<float>(op, x, x_channels, y, y_channels, wt, batch, st);
   }
   if (dtype == COMIC_BF16) return run_op<bf16_t>(op, x, x_channels, y, y_channels, wt, batch, st);
@@ -1180,7 +1278,7 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       st = lanes->s[op->lane - 1];
       used[op->lane - 1] = true;
     }
-    const comic_conv_weight* wt = (op->kind <= 1) ? weights + op->weight : nullptr;
+    const comic_conv_weight* wt = (op->kind <= 1 || op->kind == 7) ? weights + op->weight : nullptr;
     int rc = comic_conv2d_bn_relu(op, buffers[op->src], buf_channels[op->src], buffers[op->dst],
                                   buf_channels[op->dst], wt, batch, dtype, (void*)st);
     if (rc) return rc;

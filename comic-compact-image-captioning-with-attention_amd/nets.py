@@ -110,7 +110,7 @@ class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
-                 group_branches=True, layers=None):
+                 group_branches=True, layers=None, pool_after_projection=False):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -127,6 +127,11 @@ class CnnPlan:
         self.group_branches = group_branches and not branch_streams
         self._depth = 0
         self._next_group = 1
+        # forward-only rewrite of the Inception pool branches (avg-pool 3x3 -> 1x1 conv -> BN -> ReLU): the
+        # projection runs first, next to the other 1x1 convs of the block, into a small fp32 map, and the
+        # pool (kind 7, with the BN + ReLU epilogue) then averages Cout instead of Cin channels.  Exact in
+        # real arithmetic (the two linear maps act on different axes); frozen-CNN plans only (no backward).
+        self.pool_after_projection = pool_after_projection
         self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
         if name == 'chain':
             self._build_chain(image_size, layers)
@@ -140,7 +145,7 @@ class CnnPlan:
         self.buffers.append((H, W, Cc, f32))
         return len(self.buffers) - 1
 
-    def _conv(self, src, scope, spec, dst=None, dst_coff=0, out_f32=False):
+    def _conv(self, src, scope, spec, dst=None, dst_coff=0, out_f32=False, raw=False):
         _, name, cout, (kh, kw), stride, pad = spec
         H, W, Cin_p, _ = self.buffers[src]
         Cin = self._logical.get(src, Cin_p)          # channels of the producing variable (the rest is zero padding)
@@ -158,10 +163,18 @@ class CnnPlan:
         self.wphys.append((Cin_p, cout_p))
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
                              Cin=Cin_p, Cout=cout_p, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
-                             weight=len(self.weights) - 1, relu=1, out_f32=int(out_f32), lane=self._lane,
-                             depth=self._depth))
+                             weight=len(self.weights) - 1, relu=0 if raw else 1, out_f32=int(out_f32), lane=self._lane,
+                             depth=self._depth, flags=1 if raw else 0))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
+
+    def _pool_bn_relu(self, src, weight, dst, dst_coff, out_f32):
+        """kind 7: 3x3 s1 SAME average of the fp32 map `src` + BN (weight record `weight`) + ReLU -> dst slice."""
+        H, W, Cc, f32 = self.buffers[src]
+        assert f32
+        self.ops.append(dict(kind=7, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc,
+                             KH=3, KW=3, SH=1, SW=1, PT=1, PL=1, Ho=H, Wo=W, weight=weight, relu=1,
+                             out_f32=int(out_f32), src_f32=1, lane=self._lane, depth=self._depth))
 
     def _pool(self, src, kind, k, stride, pad, dst=None, dst_coff=0):
         H, W, Cc, _ = self.buffers[src]
@@ -323,6 +336,14 @@ class CnnPlan:
                 scope = '%s/%s/Branch_%d' % (root, bname, bi)
                 self._lane = bi if self.branch_streams else 0   # branch 0 stays on the caller's stream
                 x = cur
+                if (self.pool_after_projection and len(branch) == 2 and branch[0][0] == 'avg' and branch[1][0] == 'c'
+                        and branch[1][3] == (1, 1) and branch[1][2] % 16 == 0):
+                    self._depth = 0
+                    z, _ = self._conv(x, scope, branch[1], out_f32=True, raw=True)
+                    self._depth = 1
+                    self._pool_bn_relu(z, len(self.weights) - 1, blk, coff, out_f32=last)
+                    coff += outs[bi][2]
+                    continue
                 for oi, op in enumerate(branch):
                     final = oi == len(branch) - 1
                     self._depth = oi
@@ -543,6 +564,8 @@ class CnnEncoder:
         if self._train is not None:
             return self._train
         torch, plan = self.torch, self.plan
+        if plan.pool_after_projection:
+            raise ValueError('cnn_finetune needs a plan built with pool_after_projection=False (forward-only rewrite)')
         t = type('CnnTrainState', (), {})()
         t.dw, t.dbeta = self.w_master.like(), self.beta.like()
         sizes, total = [], 0
@@ -726,11 +749,16 @@ class CnnEncoder:
                                                           dst.shape[3], C.byref(wt), self.batch, self.dcode, st),
                             'conv (autotune)')
             best = (None, 0)
-            for tile in range(0, L.CONV_TILES + 1):
+            for tile in range(0, (L.GROUP_CONV_TILES if n > 1 else L.CONV_TILES) + 1):
                 op.tile = tile
                 if n > 1:
                     self._build_group_args()
-                run(); run()
+                try:
+                    run(); run()
+                except L.ComicHipError:
+                    if tile <= L.GROUP_CONV_TILES:
+                        raise
+                    continue              # a patch-resident variant this layer is not eligible for
                 ev0.record()
                 for _ in range(reps):
                     run()
@@ -767,7 +795,8 @@ def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
     if is_training:
         raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
 
-    def network_fn(image_size=(224, 224), final_endpoint=None):
-        return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'))
+    def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False):
+        return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'),
+                       pool_after_projection=pool_after_projection and name == 'inception_v3')
     network_fn.default_image_size = 224 if name == 'inception_v1' else 299
     return network_fn

@@ -32,7 +32,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 12
+#define COMIC_CONV_TILES 21
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -60,7 +60,12 @@ typedef struct comic_cnn_op {
                         2 max-pool  3 avg-pool 3x3 s1 SAME (count excludes padding)
                         4 global avg-pool KHxKW VALID -> fp32
                         5 fork: the branch lanes 1..3 start after everything issued so far
-                        6 join: the main lane waits for every branch lane */
+                        6 join: the main lane waits for every branch lane
+                        7 avg-pool 3x3 s1 SAME of an fp32 source (count excludes padding), then the
+                          folded BatchNorm of weight record `weight` and ReLU: the second half of an
+                          Inception pool branch whose 1x1 projection was applied BEFORE the pool
+                          (both are linear and act on different axes, so they commute; the pool then
+                          runs on Cout instead of Cin channels) */
   int32_t src, dst;  /* indices into the buffer table */
   int32_t src_coff, dst_coff; /* channel offsets inside src/dst (concat without a copy) */
   int32_t H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
@@ -77,7 +82,10 @@ typedef struct comic_cnn_op {
                         share a non-zero id are mutually independent (the same-depth convs of
                         the parallel Inception branches) and comic_cnn_forward_grouped runs
                         them as one launch */
+  int32_t flags;     /* bit 0 (COMIC_OP_RAW), conv: store the raw product (no BatchNorm, no ReLU);
+                        the epilogue is applied by a later kind-7 op */
 } comic_cnn_op;
+#define COMIC_OP_RAW 1
 
 typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */

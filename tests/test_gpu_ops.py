@@ -75,7 +75,7 @@ def test_gemm_f32_split3(M, N, K, ta, tb):
 
 
 # ------------------------------------------------------------------------ conv / pool -----
-def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, dst_coff=0, relu=1, out_f32=0):
+def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, dst_coff=0, relu=1, out_f32=0, tile=0):
     B, H, W, Cin = x.shape
     kh, kw, _, Cout = w.shape
     Ho, pt, _ = cnn_ref.out_size(H, kh, stride, padding)
@@ -98,7 +98,8 @@ def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, 
     ydt = torch.float32 if out_f32 else tdt
     y = torch.full((B, Ho, Wo, yc), -7.0, dtype=ydt, device=DEV)
     op = L.CnnOp(kind=1 if stem else 0, src=0, dst=1, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cin, Cout=Cout,
-                 KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=relu, out_f32=out_f32)
+                 KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=relu, out_f32=out_f32,
+                 tile=tile)
     wt = L.ConvWeight(packed.data_ptr(), scale.data_ptr(), shift.data_ptr())
     L.check(lib().comic_conv2d_bn_relu(C.byref(op), xd.data_ptr(), Cin, y.data_ptr(), yc, C.byref(wt), B, code,
                                        stream()), 'conv')
@@ -146,6 +147,49 @@ def test_conv_bn_relu(case, dtype):
     got2 = _run_conv(x, w, beta, mean, var, s, pad, dtype, dst_channels=Cout + 48, dst_coff=16)
     np.testing.assert_array_equal(got2[..., 16:16 + Cout], got)
     assert (got2[..., :16] == -7).all() and (got2[..., 16 + Cout:] == -7).all()
+
+
+# patch-resident variants (tile ids 13..18, conv_patch.inc): stride 1, Cin >= 32.  The tile spans image
+# boundaries (global output rows), ragged column tiles, SAME / VALID halos, the Kpad tail (K % 64 != 0),
+# channel counts with and without the 32-byte pixel padding, Cout ragged against the channel tile.
+PATCH_CASES = [
+    # B, H, W, Cin, Cout, (kh,kw), padding
+    (3, 17, 15, 32, 32, (3, 3), 'VALID'), (2, 37, 37, 32, 64, (3, 3), 'SAME'), (3, 19, 19, 80, 192, (3, 3), 'VALID'),
+    (5, 25, 25, 48, 64, (5, 5), 'SAME'), (5, 25, 25, 96, 96, (3, 3), 'SAME'), (7, 12, 12, 128, 128, (1, 7), 'SAME'),
+    (7, 12, 12, 160, 192, (7, 1), 'SAME'), (30, 5, 5, 448, 384, (3, 3), 'SAME'), (30, 5, 5, 384, 384, (1, 3), 'SAME'),
+    (3, 21, 21, 64, 80, (1, 1), 'VALID'), (1, 1, 1, 32, 16, (1, 1), 'SAME'), (2, 40, 70, 32, 48, (3, 3), 'SAME')]
+
+
+@pytest.mark.parametrize('tile', [13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize('case', PATCH_CASES)
+def test_conv_patch_variants(case, tile):
+    B, H, W, Cin, Cout, k, pad = case
+    rng = np.random.default_rng(B * 1000 + H * 7 + Cin + Cout + k[0] + tile)
+    x = cnn_ref.bf16_round(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    w = (rng.standard_normal((k[0], k[1], Cin, Cout)) / math.sqrt(k[0] * k[1] * Cin)).astype(np.float32)
+    beta = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    mean = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    ref = _ref_conv(x, w, beta, mean, var, 1, pad, 'bf16')
+    try:
+        got = _run_conv(x, w, beta, mean, var, 1, pad, 'bf16', tile=tile)
+    except L.ComicHipError as e:
+        assert 'not eligible' in str(e) and Cin >= 384      # the input window of a fat-Cin layer does not fit the LDS
+        pytest.skip(str(e))
+    assert_close(got, ref, 1e-2, 'patch conv %s tile %d' % (case, tile))
+    # same operands and k order per accumulator as the im2col kernel: identical bits
+    np.testing.assert_array_equal(got, _run_conv(x, w, beta, mean, var, 1, pad, 'bf16', tile=3))
+    got2 = _run_conv(x, w, beta, mean, var, 1, pad, 'bf16', dst_channels=Cout + 48, dst_coff=16, tile=tile)
+    np.testing.assert_array_equal(got2[..., 16:16 + Cout], got)
+    assert (got2[..., :16] == -7).all() and (got2[..., 16 + Cout:] == -7).all()
+
+
+def test_conv_patch_rejects_strided():
+    x = np.zeros((1, 9, 9, 32), np.float32)
+    w = np.zeros((3, 3, 32, 32), np.float32)
+    z, o = np.zeros(32, np.float32), np.ones(32, np.float32)
+    with pytest.raises(L.ComicHipError):
+        _run_conv(x, w, z, z, o, 2, 'VALID', 'bf16', tile=13)
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

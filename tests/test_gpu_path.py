@@ -35,6 +35,35 @@ def test_inception_v3_forward_224(cnn_params, dtype, tol):
     assert_close(im.cpu().numpy(), net_ref.reshape(B, -1), tol, 'im_embed ' + dtype)
 
 
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 3e-2)])
+def test_inception_v3_pool_after_projection(cnn_params, dtype, tol):
+    """Forward-only rewrite of the pool branches (1x1 projection first, then the 3x3 average with the
+    BN + ReLU epilogue, kind 7): same end points as the reference order, against the oracle and against
+    the plain plan; it shares the variables of a plain-plan encoder and refuses cnn_finetune."""
+    B = 3
+    x = np.random.default_rng(11).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    plain = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), cnn_params, B, dtype, DEV)
+    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    assert sum(1 for o in plan.ops if o['kind'] == 7) == 9 and not any(o['kind'] == 3 for o in plan.ops)
+    enc = nets.CnnEncoder(plan, cnn_params, B, dtype, DEV, weights_from=plain)
+    if dtype == 'bf16':
+        enc.autotune(reps=2)
+    im0, fm0 = (t.clone() for t in plain.forward(dev(x)))
+    im, fm = enc.forward(dev(x))
+    net_ref, ep = cnn_ref.inception_v3(cnn_params, x, act_dtype=dtype)
+    for name in ('Mixed_5b', 'Mixed_5d', 'Mixed_6b', 'Mixed_6e', 'Mixed_7b'):
+        assert_close(enc.end_point(name).float().cpu().numpy(), ep[name], tol, '%s %s' % (name, dtype))
+    assert_close(fm.cpu().numpy().reshape(B, 5, 5, 2048), ep['Mixed_7c'], tol, 'Mixed_7c ' + dtype)
+    assert_close(im.cpu().numpy(), net_ref.reshape(B, -1), tol, 'im_embed ' + dtype)
+    # against the reference op order on the same device arithmetic: only the rounding order differs
+    assert_close(fm.cpu().numpy(), fm0.cpu().numpy(), 1e-5 if dtype == 'f32' else 2e-2, 'fm vs plain plan')
+    im2, fm2 = enc.forward(dev(x), use_graph=True)
+    im2, fm2 = enc.forward(dev(x), use_graph=True)
+    assert torch.equal(fm2, fm) and torch.equal(im2, im)
+    with pytest.raises(ValueError):
+        enc.enable_training()
+
+
 def test_inception_v3_forward_299_f32():
     """The north-star's 8x8x2048 feature map needs 299x299 inputs."""
     params = cnn_ref.randomize_bn(cnn_ref.init_params(3, 299), seed=4)

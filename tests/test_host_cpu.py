@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     import ctypes as C
-    assert C.sizeof(L.CnnOp) == 24 * 4
+    assert C.sizeof(L.CnnOp) == 25 * 4
     assert C.sizeof(L.AttnDesc) == 8 * 4
     assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4
     assert C.sizeof(L.DecoderParams) == 14 * 8
