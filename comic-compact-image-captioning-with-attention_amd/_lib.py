@@ -33,7 +33,7 @@ class DecoderDesc(C.Structure):
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
 
 
-CONV_TILES = 21          # 1..12 im2col LDS-DMA variants, 13..18 patch-resident variants, 19..21 six-stage rings (single launches)
+CONV_TILES = 25          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants (single launches)
 GROUP_CONV_TILES = 12
 PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
 

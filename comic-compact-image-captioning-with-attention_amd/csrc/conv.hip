@@ -304,6 +304,82 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a) {
   }
 }
 
+// Stem convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, the same
+// arithmetic type as the kernel above): K = KH*KW*Cin <= 32 (3x3x3 = 27 -> 7 k-steps of 4), no padding.
+// A wave owns 64 consecutive output pixels = 4 column tiles of the swapped product D[cout][pixel];
+// the whole filter lives in registers as A fragments, the pixel operand is gathered straight from the
+// fp32 image (lane = (pixel, k & 3): 4 consecutive k are (almost always) 4 consecutive floats, and the
+// 16 pixels of a tile are SW*Cin floats apart, so a wave load covers a dense span of the image row).
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
+  constexpr int KS = 8;                      // k-steps of 4 (K <= 32)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* __restrict__ wg = (const float*)a.w;      // [K][Cout]
+  const float* __restrict__ xg = (const float*)a.x;
+  float wf[NT][KS];
+  int koff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + fg;
+    const bool kv = k < a.K;
+    const int kk = kv ? k : 0;
+    const int ci = kk % a.Cin, tap = kk / a.Cin;
+    const int kw = tap % a.KW, kh = tap / a.KW;
+    koff[s] = kv ? (kh * a.W + kw) * a.x_cs + ci : -1;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wf[i][s] = kv ? wg[kk * a.Cout + i * 16 + fr] : 0.f;
+  }
+  const int pix0 = (blockIdx.x * 4 + wave) * 64;
+  float xv[4][KS];
+  int mrow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int pix = pix0 + t * 16 + fr;
+    const bool ok = pix < a.M;
+    int mm = ok ? pix : 0;
+    const int wo = mm % a.Wo;
+    mm /= a.Wo;
+    const int ho = mm % a.Ho;
+    const int b = mm / a.Ho;
+    const int base = ((b * a.H + ho * a.SH) * a.W + wo * a.SW) * a.x_cs + a.x_co;
+    mrow[t] = ok ? pix : -1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xv[t][s] = (ok & (koff[s] >= 0)) ? xg[base + koff[s]] : 0.f;
+  }
+  f32x4_t acc[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][s], xv[t][s], acc[i][t], 0, 0, 0);
+  // epilogue: lane holds channels i*16 + fg*4 .. +3 of pixel mrow[t]
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int n0 = i * 16 + fg * 4;
+    const float4 sc = *(const float4*)(a.scale + n0), sh = *(const float4*)(a.shift + n0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v0 = fmaf(acc[i][t][0], sc.x, sh.x), v1 = fmaf(acc[i][t][1], sc.y, sh.y);
+      float v2 = fmaf(acc[i][t][2], sc.z, sh.z), v3 = fmaf(acc[i][t][3], sc.w, sh.w);
+      if (a.relu) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      }
+      if (mrow[t] < 0) continue;
+      const size_t off = (size_t)mrow[t] * a.y_cs + a.y_co + n0;
+      if (sizeof(T) == 4 || a.out_f32)
+        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+      else
+        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    }
+  }
+}
+
 // ---- pooling ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void load_vec(const T* p, float* v);
@@ -490,6 +566,12 @@ __global__ void fold_bn_kernel(const float* beta, const float* mean, const float
 // ds_read_b128 lane groups of the 16x16x32 operand fetch then hit 16 distinct slots.
 // Padding / out-of-range rows read from a 16-byte zero page.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+#ifdef COMIC_STAMPS
+__device__ unsigned long long g_stamps[16384 * 8];
+#define STAMP(i) if (tid == 0) g_stamps[(blockIdx.x & 16383) * 8 + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
@@ -534,25 +616,26 @@ __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&ac
     sc[i] = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
     sh[i] = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const float lo = a.relu ? 0.f : -INFINITY;             // relu as one v_max per value
+  const int esz = a.out_f32 ? 4 : 2;
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n0 = nbase + i * 16 + nq;
+  for (int j = 0; j < TM; ++j) {
+    const bool mok = mrow[j] >= 0;
+    // address of this lane's first channel in the pixel row; the tiles along n are 16 channels apart
+    unsigned char* yrow = (unsigned char*)a.y + ((size_t)(mok ? mrow[j] : 0) * a.y_cs + a.y_co + nbase + nq) * esz;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      float v0 = acc[i][j][0] * sc[i].x + sh[i].x;
-      float v1 = acc[i][j][1] * sc[i].y + sh[i].y;
-      float v2 = acc[i][j][2] * sc[i].z + sh[i].z;
-      float v3 = acc[i][j][3] * sc[i].w + sh[i].w;
-      if (a.relu) {
-        v0 = fmaxf(v0, 0.f);
-        v1 = fmaxf(v1, 0.f);
-        v2 = fmaxf(v2, 0.f);
-        v3 = fmaxf(v3, 0.f);
-      }
-      const bool ok = nv[i] & (mrow[j] >= 0);
-      const size_t off = (size_t)(ok ? mrow[j] : 0) * a.y_cs + a.y_co + n0;
+    for (int i = 0; i < TN; ++i) {
+      float v0 = fmaf(acc[i][j][0], sc[i].x, sh[i].x);
+      float v1 = fmaf(acc[i][j][1], sc[i].y, sh[i].y);
+      float v2 = fmaf(acc[i][j][2], sc[i].z, sh[i].z);
+      float v3 = fmaf(acc[i][j][3], sc[i].w, sh[i].w);
+      asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "s"(lo));
+      asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
+      asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
+      asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
+      const bool ok = nv[i] & mok;
       if (a.out_f32) {
-        float4* yp = (float4*)((float*)a.y + off);
+        float4* yp = (float4*)(yrow + i * 64);
         if (a.accum) {
           if (ok) {
             const float4 o = *yp;
@@ -561,7 +644,7 @@ __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&ac
         }
         if (ok) *yp = make_float4(v0, v1, v2, v3);
       } else {
-        uint2* yp = (uint2*)((bf16_t*)a.y + off);
+        uint2* yp = (uint2*)(yrow + i * 32);
         if (a.accum) {
           if (ok) {
             const uint2 o = *yp;
@@ -718,11 +801,19 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   // NSTAGE-1 tiles are in flight before the loop; at the top of iteration kt the tiles
   // kt .. min(kt+NSTAGE-2, nk-1) have been issued and tile kt must have landed.
   constexpr int AHEAD = NSTAGE - 1;
+  STAMP(0);
 #pragma unroll
   for (int p = 0; p < AHEAD; ++p)
     if (p < nk) issue(p, p);
+  STAMP(1);
+#ifdef COMIC_STAMPS
+  unsigned long long t_issue = 0, t_wait = 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int stage = kt % NSTAGE;
+#ifdef COMIC_STAMPS
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
     const int pending = min(AHEAD - 1, nk - 1 - kt);   // tiles allowed to stay in flight
     if (pending >= 2)
       wait_vmcnt<2 * LPT>();
@@ -731,7 +822,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
     else
       wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; the stage read in kt-1 is free
+#ifdef COMIC_STAMPS
+    const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
+    t_wait += ti0 - tw0;
+#endif
     if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
+#ifdef COMIC_STAMPS
+    t_issue += __builtin_amdgcn_s_memtime() - ti0;
+#endif
     const uint32_t sb = lds0 + stage * STAGE_BYTES;
     u32x4_t xf0[TM], xf1[TM], wf0[TN], wf1[TN];
     static_for<0, TN>([&](auto i) {
@@ -757,6 +855,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
     }
   }
 
+  STAMP(2);
+#ifdef COMIC_STAMPS
+  if (tid == 0) { g_stamps[(blockIdx.x & 16383) * 8 + 4] = t_issue; g_stamps[(blockIdx.x & 16383) * 8 + 5] = t_wait; g_stamps[(blockIdx.x & 16383) * 8 + 6] = nk; }
+#endif
   // ---- epilogue: y = relu(acc * scale[n] + shift[n]) ----------------------------------
   int mrow[TM];
 #pragma unroll
@@ -765,6 +867,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
     mrow[j] = m < a.M ? m : -1;
   }
   conv_store_tiles<TN, TM>(a, acc, bn0 + wn * (BN / WN), (lane >> 4) * 4, mrow);
+  STAMP(3);
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i % 8), each with a private
@@ -912,6 +1015,14 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 16: return launch_patch<2, 4>(a, st);
     case 17: return launch_patch<2, 2>(a, st);
     case 18: return launch_patch<2, 6>(a, st);
+    // patch-resident, 8 / 12 waves per workgroup (2-3 per SIMD) over one patch
+    case 19: return launch_patch<4, 4, 4, 2>(a, st);    // 256 px x 128 ch
+    case 20: return launch_patch<4, 4, 4, 3>(a, st);    // 256 px x 192 ch
+    case 21: return launch_patch<4, 4, 8, 1>(a, st);    // 512 px x 64 ch
+    case 22: return launch_patch<4, 2, 4, 2>(a, st);    // 256 px x 64 ch, 8 waves
+    case 23: return launch_patch<4, 6, 4, 2>(a, st);    // 256 px x 192 ch, 8 waves
+    case 24: return launch_patch<2, 4, 4, 2>(a, st);    // 128 px x 128 ch
+    case 25: return launch_patch<2, 6, 4, 2>(a, st);    // 128 px x 192 ch, 8 waves
     default:
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
@@ -1081,7 +1192,11 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       COMIC_REQUIRE(op->dst_coff % 4 == 0 && yc % 4 == 0, "stem conv: misaligned destination");
       const size_t lds = (size_t)a.K * a.Cout * sizeof(float);
       COMIC_REQUIRE(lds <= 64 * 1024, "stem conv: weights do not fit LDS");
-      hipLaunchKernelGGL((conv_stem_kernel<T>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a);
+      if (a.K <= 32 && a.Cout == 32 && a.PT == 0 && a.PL == 0 && (op->Ho - 1) * op->SH + op->KH <= op->H &&
+          (op->Wo - 1) * op->SW + op->KW <= op->W && op->tile != 1)
+        hipLaunchKernelGGL((conv_stem_mfma_kernel<T, 2>), dim3(cdiv(a.M, 256)), dim3(256), 0, st, a);   // VALID 3x3x3
+      else
+        hipLaunchKernelGGL((conv_stem_kernel<T>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a);
       break;
     }
     case 2:
@@ -2050,3 +2165,9 @@ extern "C" int comic_cnn_refresh_weights(const float* master, void* plan_copy, i
   COMIC_LAUNCH_CHECK("cnn_refresh_weights");
   return 0;
 }
+
+#ifdef COMIC_STAMPS
+extern "C" int comic_debug_read_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif

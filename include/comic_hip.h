@@ -32,7 +32,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 21
+#define COMIC_CONV_TILES 25
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
