@@ -205,7 +205,8 @@ def main():
     if os.environ.get('COMIC_TUNE_POLITE', '0') == '1' and os.environ.get('COMIC_OVERLAP', '1') == '1':
         tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
     if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
-        tr.encoder.autotune(verbose=os.environ.get('COMIC_VERBOSE', '0') == '1')   # setup, untimed
+        tr.encoder.autotune(verbose=os.environ.get('COMIC_VERBOSE', '0') == '1',    # setup, untimed
+                            cache=os.environ.get('COMIC_TUNE_CACHE') or None)
     # identical initial parameters on every rank (C2: broadcast)
     if world > 1:
         dist.broadcast(tr.decoder.params.data, 0)

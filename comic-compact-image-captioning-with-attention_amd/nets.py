@@ -14,7 +14,9 @@ Variable names follow the slim checkpoint (`InceptionV3/<scope>/weights`,
 from __future__ import annotations
 
 import ctypes as C
+import json
 import math
+import os
 
 import numpy as np
 
@@ -693,22 +695,42 @@ class CnnEncoder:
             fm = self.bufs[self.plan.fm]
         return pooled.reshape(B, -1), fm.reshape(B, fm.shape[1] * fm.shape[2], fm.shape[3])
 
-    def autotune(self, reps=5, verbose=False):
-        """Pick the fastest tile / pipeline-depth variant of the LDS-DMA conv kernel for every
-        conv of the plan at this batch size (times each variant with HIP events on the real
-        buffers; ~0.3 s).  Results are bit-identical across variants for a given op only up to
-        the fp32 summation order inside a k-tile, i.e. identical: the k order does not depend
-        on the tile shape."""
+    def _tune_key(self):
+        p = self.plan
+        H, W = p.buffers[p.input][:2]
+        return '%s:%dx%d:B%d:%s:%dops:polite%d' % (p.name, H, W, self.batch, 'par' if p.pool_after_projection else 'plain',
+                                                  len(p.ops), self.polite_lds_kb)
+
+    def autotune(self, reps=5, verbose=False, cache=None):
+        """Pick the fastest tile / pipeline-depth variant of the conv kernels for every conv of the plan
+        at this batch size (times each variant with HIP events on the real buffers; ~0.5 s).  Results
+        are bit-identical across variants: the k order per accumulator does not depend on the tile.
+        cache: path of a JSON file {plan key: [tile id per op]}: loaded when it holds this plan (no timing
+        runs -- e.g. under a profiler), written after a tuning run."""
         if self.dcode != 1:
             return {}
         torch = self.torch
         st = L.stream_ptr()
+        if cache and os.path.isfile(cache):
+            tiles = json.load(open(cache)).get(self._tune_key())
+            if tiles is not None and len(tiles) == len(self.plan.ops):
+                for i, t in enumerate(tiles):
+                    self._ops[i].tile = int(t)
+                if self._group_args is not None:
+                    self._build_group_args()
+                self._graph, self._calls = None, 0
+                return {i: (None, t) for i, t in enumerate(tiles)}
         if self.polite_lds_kb:        # tune under the occupancy the forward will run with
             L.check(self.lib.comic_conv_set_min_lds(self.polite_lds_kb * 1024), 'conv_set_min_lds')
         try:
-            return self._autotune(reps, verbose, torch, st)
+            chosen = self._autotune(reps, verbose, torch, st)
         finally:
             L.check(self.lib.comic_conv_set_min_lds(0), 'conv_set_min_lds')
+        if cache:
+            db = json.load(open(cache)) if os.path.isfile(cache) else {}
+            db[self._tune_key()] = [int(self._ops[i].tile) for i in range(len(self.plan.ops))]
+            json.dump(db, open(cache, 'w'))
+        return chosen
 
     def _autotune(self, reps, verbose, torch, st):
         chosen = {}

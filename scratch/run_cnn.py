@@ -3,10 +3,11 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from comic_amd import nets
 B = int(os.environ.get('B', '64'))
-plan = nets.CnnPlan('inception_v3', (224, 224), group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1')
+plan = nets.CnnPlan('inception_v3', (224, 224), group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1',
+                    pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
-    enc.autotune()
+    enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 x = torch.rand(B, 224, 224, 3, device='cuda:0') * 2 - 1
 for _ in range(3):
     enc.forward(x)
