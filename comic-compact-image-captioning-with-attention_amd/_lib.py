@@ -34,7 +34,7 @@ class DecoderDesc(C.Structure):
 
 
 CONV_TILES = 25          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants (single launches)
-GROUP_CONV_TILES = 12
+IM2COL_CONV_TILES = 12   # ids above are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
 
 

@@ -1056,7 +1056,7 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
 // Tile of a group: the explicit id of its first member, else the same fill rule as the
 // single-conv heuristic applied to the group's total tile count.
 int group_tile(const comic_cnn_op* ops, int n, int batch) {
-  if (ops[0].tile > 0 && ops[0].tile <= kNumConvTiles) return ops[0].tile;
+  if (ops[0].tile > 0 && ops[0].tile <= COMIC_CONV_TILES) return ops[0].tile;
   bool all128 = true;
   for (int i = 0; i < n; ++i) all128 = all128 && ops[i].Cout % 128 == 0;
   auto blocks = [&](int t) {
@@ -1069,6 +1069,22 @@ int group_tile(const comic_cnn_op* ops, int n, int batch) {
   if (blocks(2) >= 512) return 2;
   if (blocks(3) >= 384) return 3;
   return 4;
+}
+
+// Workgroup layout of one group member under tile id `tile`: sets a.tiles_m (and the patch geometry for the
+// patch-resident ids), returns its workgroup count or -1 when the member is not eligible; *lds = LDS it needs.
+long member_blocks(int tile, ConvArgs& a, int* lds) {
+  if (tile <= kNumConvTiles) {
+    a.tiles_m = cdiv(a.M, kTileBM[tile]);
+    *lds = 0;
+    return (long)a.tiles_m * cdiv(a.Cout, kTileBN[tile]);
+  }
+  const PatchTile pt = kPatchTiles[tile - 13];
+  PatchGeo g;
+  if (!patch_geometry(a, pt.BM, pt.BN, 3, g)) return -1;
+  apply_geometry(a, g);
+  *lds = g.lds_bytes;
+  return (long)a.tiles_m * cdiv(a.Cout, pt.BN);
 }
 
 int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
@@ -1294,8 +1310,11 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
       COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
       a.blk0 = blk;
       a.remap = 0;   // members differ in K: contiguous per-XCD ranges would put the heavy ones on few XCDs
-      a.tiles_m = cdiv(a.M, kTileBM[tile]);
-      blk += a.tiles_m * cdiv(a.Cout, kTileBN[tile]);
+      int lds = 0;
+      const long nb = member_blocks(tile, a, &lds);
+      COMIC_REQUIRE(nb >= 0, "grouped conv: member %d (stride %d, Cin %d) is not eligible for patch tile %d", j, op->SH,
+                    op->Cin, tile);
+      blk += (int)nb;
     }
     out += n;
     i += n;
@@ -1378,10 +1397,23 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       const int n = group_run(ops, n_ops, i);
       const int tile = group_tile(op, n, batch);
       long blocks = 0;
-      for (int j = 0; j < n; ++j)
-        blocks += (long)cdiv(batch * op[j].Ho * op[j].Wo, kTileBM[tile]) * cdiv(op[j].Cout, kTileBN[tile]);
+      int lds_max = 0;
+      for (int j = 0; j < n; ++j) {
+        ConvArgs a;
+        fill_args(a, op + j, buffers[op[j].src], buf_channels[op[j].src], buffers[op[j].dst], buf_channels[op[j].dst],
+                  weights + op[j].weight, batch);
+        int lds = 0;
+        const long nb = member_blocks(tile, a, &lds);
+        COMIC_REQUIRE(nb >= 0, "grouped launch: member %d is not eligible for patch tile %d", j, tile);
+        blocks += nb;
+        lds_max = std::max(lds_max, lds);
+      }
       COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
-      if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, main_st)) return rc;
+      if (tile > kNumConvTiles) {
+        if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, lds_max, main_st)) return rc;
+      } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, main_st)) {
+        return rc;
+      }
       COMIC_LAUNCH_CHECK("grouped conv");
       gargs += n;
       i += n - 1;

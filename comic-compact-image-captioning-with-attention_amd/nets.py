@@ -771,16 +771,16 @@ class CnnEncoder:
                                                           dst.shape[3], C.byref(wt), self.batch, self.dcode, st),
                             'conv (autotune)')
             best = (None, 0)
-            for tile in range(0, (L.GROUP_CONV_TILES if n > 1 else L.CONV_TILES) + 1):
+            for tile in range(0, L.CONV_TILES + 1):
                 op.tile = tile
-                if n > 1:
-                    self._build_group_args()
                 try:
+                    if n > 1:
+                        self._build_group_args()
                     run(); run()
                 except L.ComicHipError:
-                    if tile <= L.GROUP_CONV_TILES:
+                    if tile <= L.IM2COL_CONV_TILES:
                         raise
-                    continue              # a patch-resident variant this layer is not eligible for
+                    continue              # a patch-resident variant this layer (or a group member) is not eligible for
                 ev0.record()
                 for _ in range(reps):
                     run()
