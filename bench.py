@@ -305,8 +305,8 @@ def main():
                                    'frozen, batch 64/GPU, 224x224x3 (BASELINE configs[1])',
                        'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'image_size': IMG,
                        'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma(_grouped)_kernel<bf16> (%d convs in %d launches per '
-                                                    'step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma / conv_patch (+ _grouped) kernels <bf16> (%d convs in %d '
+                                                    'launches per step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
                          'cnn_forward_ms': round(cnn_iso_ms, 4),

@@ -37,6 +37,7 @@ struct ConvArgs {
   int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
   // patch-resident kernel (conv_patch.inc): tile geometry, filled by apply_geometry()
   int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB;
+  int member_kind;   // grouped launch: 0 conv tile, 1 pool + BN + ReLU (kind 7) work items
 };
 
 template <typename T>
@@ -453,12 +454,7 @@ __global__ __launch_bounds__(256) void pool_kernel(ConvArgs a) {
 
 // kind 7: 3x3 s1 SAME average (divisor = taps inside the image) of an fp32 map, then the folded
 // BatchNorm + ReLU of the projection that produced it.  One thread per (pixel, 4 channels).
-template <typename TOUT>
-__global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
-  const int cvecs = a.Cin / 4;
-  const long total = (long)a.M * cvecs;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ void pool_bn_relu_item(const ConvArgs& a, const long idx, const int cvecs) {
   const int cv = (int)(idx % cvecs);
   int mm = (int)(idx / cvecs);
   const int pix = mm;
@@ -489,10 +485,31 @@ __global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
   }
   const size_t off = (size_t)pix * a.y_cs + a.y_co + cv * 4;
-  if constexpr (sizeof(TOUT) == 4)
+  if (a.out_f32)
     *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
   else
     *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+}
+
+__global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
+  const int cvecs = a.Cin / 4;
+  const long total = (long)a.M * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < total) pool_bn_relu_item(a, idx, cvecs);
+}
+
+// The same work as a member of a grouped conv launch: workgroup `local` of this member handles
+// kPoolItemsPerThread x blockDim.x consecutive (pixel, 4-channel) items.
+constexpr int kPoolItemsPerThread = 4;
+__device__ __forceinline__ void pool_bn_relu_member(const ConvArgs& a, const int local) {
+  const int cvecs = a.Cin / 4;
+  const long total = (long)a.M * cvecs;
+  const long base = (long)local * blockDim.x * kPoolItemsPerThread + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < kPoolItemsPerThread; ++r) {
+    const long idx = base + (long)r * blockDim.x;
+    if (idx < total) pool_bn_relu_item(a, idx, cvecs);
+  }
 }
 
 // global KHxKW VALID average -> fp32 [B, Ho*Wo, C]; one thread per (pixel, channel vec)
@@ -918,6 +935,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_grouped_kernel(const ConvA
     if (bid >= args[i].blk0) p = i;
   const ConvArgs a = args[p];
   const int local = bid - a.blk0;
+  if (a.member_kind == 1) {
+    pool_bn_relu_member(a, local);
+    return;
+  }
   int bm, bn;
   if (remap) {
     const int tiles_n = (a.Cout + BN - 1) / BN;
@@ -1074,6 +1095,11 @@ int group_tile(const comic_cnn_op* ops, int n, int batch) {
 // Workgroup layout of one group member under tile id `tile`: sets a.tiles_m (and the patch geometry for the
 // patch-resident ids), returns its workgroup count or -1 when the member is not eligible; *lds = LDS it needs.
 long member_blocks(int tile, ConvArgs& a, int* lds) {
+  if (a.member_kind == 1) {          // pool + BN + ReLU items, kPoolItemsPerThread per thread of the launch's workgroup size
+    const int threads = tile <= kNumConvTiles ? 256 : kPatchTiles[tile - 13].threads;
+    *lds = 0;
+    return cdiv64((long)a.M * (a.Cin / 4), (long)threads * kPoolItemsPerThread);
+  }
   if (tile <= kNumConvTiles) {
     a.tiles_m = cdiv(a.M, kTileBM[tile]);
     *lds = 0;
@@ -1088,6 +1114,14 @@ long member_blocks(int tile, ConvArgs& a, int* lds) {
 }
 
 int dispatch_igemm_dma(const ConvArgs& a, hipStream_t st) {
+  // thin-channel stride-1 layers with many pixels (the 109x109 / 52x52 / 25x25 3x3 and 5x5 convs, forward and
+  // backward-data): the patch-resident kernel, variants as the autotuner picks them at batch 64
+  if (a.SH == 1 && a.SW == 1 && a.Cin >= 32 && a.Cin <= 96 && a.KH * a.KW > 1 && a.M >= 16384) {
+    PatchGeo g;
+    if (a.Cout <= 32 && patch_geometry(a, 256, 32, 3, g)) return launch_patch<4, 2>(a, st);
+    if (a.Cout == 96 && patch_geometry(a, 128, 96, 3, g)) return launch_patch<2, 6>(a, st);
+    if (patch_geometry(a, 256, 64, 3, g)) return launch_patch<4, 2, 4, 2>(a, st);
+  }
   const long b128x128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
   const long b128x64 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 64);
   const long b64x64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
@@ -1166,6 +1200,7 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.blk0 = 0;
   a.tiles_m = 0;
   a.accum = 0;
+  a.member_kind = 0;
   a.remap = xcd_remap_enabled();
   return 0;
 }
@@ -1245,10 +1280,8 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "pool+bn: channel counts/offsets must be multiples of 4");
       COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool+bn: destination channel slice out of range");
       const long total = (long)a.M * (op->Cin / 4);
-      if (op->out_f32 || sizeof(T) == 4)
-        hipLaunchKernelGGL((pool_bn_relu_kernel<float>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL((pool_bn_relu_kernel<bf16_t>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      a.out_f32 = (op->out_f32 || sizeof(T) == 4) ? 1 : 0;
+      hipLaunchKernelGGL(pool_bn_relu_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
       break;
     }
     default:
@@ -1259,6 +1292,18 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
 }
 
 int validate_grouped_conv(const comic_cnn_op* op, int xc, int yc, const comic_conv_weight* wt, int batch) {
+  if (op->kind == 7) {               // pool + BN + ReLU member (same checks as the stand-alone launch)
+    COMIC_REQUIRE(wt && wt->scale && wt->shift, "pool+bn: missing scale / shift");
+    COMIC_REQUIRE(op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1 && op->PT == 1 && op->PL == 1 &&
+                      op->Ho == op->H && op->Wo == op->W && op->Cin == op->Cout && op->src_f32,
+                  "pool+bn: 3x3 stride-1 SAME over an fp32 source only");
+    COMIC_REQUIRE(op->Cin % 4 == 0 && op->src_coff % 4 == 0 && xc % 4 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
+                  "pool+bn: channel counts/offsets must be multiples of 4");
+    COMIC_REQUIRE(op->src_coff + op->Cin <= xc && op->dst_coff + op->Cin <= yc, "pool+bn: channel slice out of range");
+    COMIC_REQUIRE((long)batch * op->H * op->W * xc < (1L << 31) && (long)batch * op->Ho * op->Wo * yc < (1L << 31),
+                  "pool+bn: tensor too large");
+    return 0;
+  }
   COMIC_REQUIRE(op->kind == 0, "grouped launch: op kind %d is not a conv", op->kind);
   COMIC_REQUIRE(wt && wt->w && wt->scale && wt->shift, "conv: missing weights");
   COMIC_REQUIRE(op->Cin % 8 == 0 && op->src_coff % 8 == 0 && xc % 8 == 0, "conv: Cin/offset/stride must be multiples of 8");
@@ -1308,6 +1353,7 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
       ConvArgs& a = out[j];
       fill_args(a, op, buffers[op->src], buf_channels[op->src], buffers[op->dst], buf_channels[op->dst], wt, batch);
       COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
+      a.member_kind = op->kind == 7 ? 1 : 0;
       a.blk0 = blk;
       a.remap = 0;   // members differ in K: contiguous per-XCD ranges would put the heavy ones on few XCDs
       int lds = 0;
@@ -1392,8 +1438,8 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       continue;
     }
     if (gargs && op->group > 0) {
-      COMIC_REQUIRE(dtype == COMIC_BF16 && op->kind == 0 && op->lane == 0,
-                    "grouped launch needs a bf16 plan and conv ops on the caller's stream");
+      COMIC_REQUIRE(dtype == COMIC_BF16 && (op->kind == 0 || op->kind == 7) && op->lane == 0,
+                    "grouped launch needs a bf16 plan and conv / pool+bn ops on the caller's stream");
       const int n = group_run(ops, n_ops, i);
       const int tile = group_tile(op, n, batch);
       long blocks = 0;
@@ -1402,6 +1448,7 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
         ConvArgs a;
         fill_args(a, op + j, buffers[op[j].src], buf_channels[op[j].src], buffers[op[j].dst], buf_channels[op[j].dst],
                   weights + op[j].weight, batch);
+        a.member_kind = op[j].kind == 7 ? 1 : 0;
         int lds = 0;
         const long nb = member_blocks(tile, a, &lds);
         COMIC_REQUIRE(nb >= 0, "grouped launch: member %d is not eligible for patch tile %d", j, tile);

@@ -112,7 +112,7 @@ class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
-                 group_branches=True, layers=None, pool_after_projection=False):
+                 group_branches=True, layers=None, pool_after_projection=False, ride_pools=False):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -134,6 +134,10 @@ class CnnPlan:
         # pool (kind 7, with the BN + ReLU epilogue) then averages Cout instead of Cin channels.  Exact in
         # real arithmetic (the two linear maps act on different axes); frozen-CNN plans only (no backward).
         self.pool_after_projection = pool_after_projection
+        # kind-7 ops as extra members of their depth's grouped conv launch instead of launches of their own.
+        # Measured slower at batch 64 (the pool workgroups inherit the conv kernel's LDS / register footprint and
+        # run at 2 per CU: 5x5|3x3|pool 29.0 us grouped vs 19.8 + 7.8 us), so off by default.
+        self.ride_pools = ride_pools
         self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
         if name == 'chain':
             self._build_chain(image_size, layers)
@@ -198,13 +202,20 @@ class CnnPlan:
         del self.ops[first_op:]
         for d in sorted({o['depth'] for o in block}):
             level = [o for o in block if o['depth'] == d]
-            self.ops += [o for o in level if o['kind'] != 0]
+            # pool + BN + ReLU ops (kind 7) ride in the conv launch of their depth as extra members (last, so the
+            # group's tile id stays on its first conv): elementwise work under the MFMA tiles instead of a launch
+            riders = [o for o in level if o['kind'] == 7] if self.ride_pools else []
+            self.ops += [o for o in level if o['kind'] != 0 and o not in riders]
             convs = sorted((o for o in level if o['kind'] == 0), key=lambda o: -(o['KH'] * o['KW'] * o['Cin']))
-            if len(convs) >= 2:
-                for o in convs:
+            if not convs:
+                self.ops += riders
+                continue
+            members = convs + riders
+            if len(members) >= 2:
+                for o in members:
                     o['group'] = self._next_group
                 self._next_group += 1
-            self.ops += convs
+            self.ops += members
 
     @staticmethod
     def _sync_op(kind):

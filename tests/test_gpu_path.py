@@ -43,8 +43,10 @@ def test_inception_v3_pool_after_projection(cnn_params, dtype, tol):
     B = 3
     x = np.random.default_rng(11).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
     plain = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), cnn_params, B, dtype, DEV)
-    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    # bf16: also with the pool ops riding in the grouped conv launches (comic_cnn_forward_grouped members of kind 7)
+    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, ride_pools=dtype == 'bf16')
     assert sum(1 for o in plan.ops if o['kind'] == 7) == 9 and not any(o['kind'] == 3 for o in plan.ops)
+    assert all((o.get('group', 0) > 0) == (dtype == 'bf16') for o in plan.ops if o['kind'] == 7)
     enc = nets.CnnEncoder(plan, cnn_params, B, dtype, DEV, weights_from=plain)
     if dtype == 'bf16':
         enc.autotune(reps=2)
