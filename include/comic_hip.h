@@ -76,8 +76,12 @@ typedef struct comic_cnn_op {
                         (global avg-pool over the fp32 attention feature map) */
   int32_t lane;      /* 0 = caller's stream; 1..3 = internal branch streams (independent
                         Inception branches run concurrently between a fork and a join) */
-  int32_t tile;      /* conv: 0 = built-in heuristic, 1..COMIC_CONV_TILES = explicit tile /
-                        pipeline-depth variant (chosen by the host-side autotuner) */
+  int32_t tile;      /* conv: 0 = built-in heuristic, 1..COMIC_CONV_TILES = explicit kernel variant (chosen by
+                        the host-side autotuner): 1..12 im2col LDS-DMA tiles / pipeline depths; 13..25
+                        patch-resident variants (stride-1 layers whose input window fits the LDS: the window
+                        is loaded once per tile, only the weight k-tiles stream; 4, 8 or 12 waves per
+                        workgroup).  An ineligible layer returns an error for ids 13..25.  In a group the
+                        id of the first member applies to all members.  Every variant gives identical bits. */
   int32_t group;     /* conv, bf16 plans: 0 = own launch; ops that are ADJACENT in the table and
                         share a non-zero id are mutually independent (the same-depth convs of
                         the parallel Inception branches) and comic_cnn_forward_grouped runs
@@ -108,6 +112,7 @@ int comic_conv_set_min_lds(int bytes);
 /* Grouped execution of the same plan (bf16 plans): every run of ops with the same non-zero
  * `group` becomes ONE launch whose workgroups are spread over all member convolutions (a
  * 12x12 or 5x5 Inception stage has too few tiles per conv to fill 256 CUs at batch 64).
+ * Members are convs (kind 0) and, optionally, kind-7 pool+BN+ReLU ops (elementwise work items).
  * The per-conv argument records are built once on the host and kept in device memory:
  *   n = comic_cnn_group_args_bytes(ops, n_ops)            bytes of records the plan needs
  *   comic_cnn_build_group_args(..., host_out)             fills `n` bytes (validates the ops)
