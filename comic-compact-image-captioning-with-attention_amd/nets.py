@@ -112,7 +112,7 @@ class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
-                 group_branches=True, layers=None, pool_after_projection=False, ride_pools=False):
+                 group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -138,6 +138,10 @@ class CnnPlan:
         # Measured slower at batch 64 (the pool workgroups inherit the conv kernel's LDS / register footprint and
         # run at 2 per CU: 5x5|3x3|pool 29.0 us grouped vs 19.8 + 7.8 us), so off by default.
         self.ride_pools = ride_pools
+        # kind-7 ops on a branch lane (fork after the block's 1x1 group, join at the block's end) so that the small
+        # elementwise kernel runs beside the depth-1..4 convs.  Measured slower under hipGraph replay (forward alone
+        # 1.17 -> 1.26 ms: a graph with side branches replays slower on this stack), so off by default.
+        self.side_pools = bool(side_pools)
         self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
         if name == 'chain':
             self._build_chain(image_size, layers)
@@ -200,12 +204,19 @@ class CnnPlan:
         early."""
         block = self.ops[first_op:]
         del self.ops[first_op:]
+        forked = False
         for d in sorted({o['depth'] for o in block}):
             level = [o for o in block if o['depth'] == d]
             # pool + BN + ReLU ops (kind 7) ride in the conv launch of their depth as extra members (last, so the
             # group's tile id stays on its first conv): elementwise work under the MFMA tiles instead of a launch
             riders = [o for o in level if o['kind'] == 7] if self.ride_pools else []
-            self.ops += [o for o in level if o['kind'] != 0 and o not in riders]
+            for o in level:
+                if o['kind'] != 0 and o not in riders:
+                    if o['kind'] == 7 and self.side_pools:
+                        o['lane'] = 1
+                        self.ops.append(self._sync_op(5))
+                        forked = True
+                    self.ops.append(o)
             convs = sorted((o for o in level if o['kind'] == 0), key=lambda o: -(o['KH'] * o['KW'] * o['Cin']))
             if not convs:
                 self.ops += riders
@@ -216,6 +227,8 @@ class CnnPlan:
                     o['group'] = self._next_group
                 self._next_group += 1
             self.ops += members
+        if forked:
+            self.ops.append(self._sync_op(6))
 
     @staticmethod
     def _sync_op(kind):
