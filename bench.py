@@ -23,6 +23,8 @@ IMG = 224
 FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
 PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
 GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
+EVENTS = os.environ.get('COMIC_NO_EVENTS', '0') != '1'
+STEP_TIMES = [] if os.environ.get('COMIC_STEP_TIMES', '0') == '1' else None      # diagnostic: per-step event / host stamps
 GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '0') == '1'   # hipGraph replay of the decoder step (eager measured faster)
 
 
@@ -238,8 +240,13 @@ def main():
         tr.opt.step(tr.decoder.grads, tr.lr())
     if overlap:
         tr.submit_images(images)          # batch of timed step 0 (its K-th sibling is issued in step K-1)
-    barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the timed region issues ~500 launches per step from Python: a generation-2 garbage collection in the middle
+    # of it stalls the host for tens of milliseconds (measured: one 45 ms stall = +1.3 ms per step at 30 steps)
+    import gc
+    gc.collect()
+    gc.disable()
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         cap = cap_sets[i % 4]
@@ -251,9 +258,9 @@ def main():
                 tr._ev_used.record(torch.cuda.current_stream())
                 tr._side.wait_event(tr._ev_used)
                 with torch.cuda.stream(tr._side):
-                    ev[i][0].record(tr._side)
+                    if EVENTS: ev[i][0].record(tr._side)
                     tr._pending = tr.encoder.forward(images, use_graph=GRAPH_CNN)
-                    ev[i][1].record(tr._side)
+                    if EVENTS: ev[i][1].record(tr._side)
                     tr._ev_cnn.record(tr._side)
             torch.cuda.current_stream().wait_event(tr._ev_cnn)
             im_embed, fm = tr._pending
@@ -261,20 +268,27 @@ def main():
             res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC,
                                         on_inputs_consumed=consumed)
         else:
-            ev[i][0].record()
+            if EVENTS: ev[i][0].record()
             im_embed, fm = tr.encoder.forward(images, use_graph=GRAPH_CNN)
-            ev[i][1].record()
+            if EVENTS: ev[i][1].record()
             denom = denoms[i % 4]
             res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC)
         scale = dp.average_(tr.decoder.grads.data)
         tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
+        if STEP_TIMES is not None:
+            e = torch.cuda.Event(enable_timing=True); e.record(); STEP_TIMES.append((e, time.perf_counter()))
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if STEP_TIMES:
+        print('per-step GPU ms :', ' '.join('%.2f' % STEP_TIMES[i][0].elapsed_time(STEP_TIMES[i + 1][0]) for i in range(len(STEP_TIMES) - 1)))
+        print('per-step host ms:', ' '.join('%.2f' % ((STEP_TIMES[i + 1][1] - STEP_TIMES[i][1]) * 1e3) for i in range(len(STEP_TIMES) - 1)))
+        print('first step host issue done at %.2f ms after t0; last sync took %.2f ms' % ((STEP_TIMES[0][1] - t0) * 1e3, (time.perf_counter() - STEP_TIMES[-1][1]) * 1e3))
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if EVENTS else float('nan')
     # the same forward alone on the GPU (not overlapped with the decoder), for reference
     tr.enable_overlap(0)                 # full occupancy again (the overlapped forward ran 1 workgroup per CU)
     for _ in range(3):

@@ -271,10 +271,13 @@ class Decoder:
         f32 = dict(dtype=torch.float32, device=dev)
         ctx.i32 = torch.zeros(2 * B * T + B, dtype=torch.int32, device=dev)      # inputs | targets | lens
         ctx.f32 = torch.zeros(3 * B * T, **f32)                                   # wmask | coef | row scale
-        ctx.i32_host = torch.zeros(2 * B * T + B, dtype=torch.int32).pin_memory()
-        ctx.f32_host = torch.zeros(3 * B * T, dtype=torch.float32).pin_memory()
+        # pinned staging, two slots used alternately: the host may run ahead of the GPU, and an async H2D copy
+        # reads its pinned source when the STREAM gets there, so a slot is rewritten only after the copy that last
+        # used it has executed (event per slot)
+        ctx.stage = [SimpleNamespace(i32=torch.zeros(2 * B * T + B, dtype=torch.int32).pin_memory(),
+                                     f32=torch.zeros(3 * B * T, dtype=torch.float32).pin_memory(),
+                                     seed=torch.zeros(1, dtype=torch.int64).pin_memory(), copied=None) for _ in range(2)]
         ctx.seed = torch.zeros(1, dtype=torch.int64, device=dev)
-        ctx.seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         ctx.fm = torch.empty((B, s.M, s.C), **f32)
         ctx.im = torch.empty((B, s.Cg), **f32)
         EA = s.E + s.A
@@ -354,20 +357,26 @@ class Decoder:
         use_masks = bool(training or masks is not None)
         ctx = self._train_ctx(B, T, Tp, use_masks, gen_masks, want_input_grads)
         BT = B * T
-        ih, fh = ctx.i32_host.numpy(), ctx.f32_host.numpy()
+        slot = ctx.stage[ctx.calls % 2]
+        if slot.copied is not None:
+            slot.copied.synchronize()
+        ih, fh = slot.i32.numpy(), slot.f32.numpy()
         ih[:BT] = inputs.reshape(-1); ih[BT:2 * BT] = targets.reshape(-1); ih[2 * BT:] = lens
         fh[:BT] = wmask.reshape(-1); fh[BT:2 * BT] = coef.reshape(-1); fh[2 * BT:] = rs.reshape(-1)
-        ctx.i32.copy_(ctx.i32_host, non_blocking=True)
-        ctx.f32.copy_(ctx.f32_host, non_blocking=True)
+        ctx.i32.copy_(slot.i32, non_blocking=True)
+        ctx.f32.copy_(slot.f32, non_blocking=True)
         if gen_masks:
             if seed is None:
                 self._dropout_calls += 1
                 seed = 0x9E3779B9 + self._dropout_calls
-            ctx.seed_host[0] = int(seed)
-            ctx.seed.copy_(ctx.seed_host, non_blocking=True)
+            slot.seed[0] = int(seed)
+            ctx.seed.copy_(slot.seed, non_blocking=True)
         elif masks is not None:
             for k, v in masks.items():
                 ctx.masks[k].copy_(v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, np.float32)))
+        if slot.copied is None:
+            slot.copied = torch.cuda.Event()
+        slot.copied.record(torch.cuda.current_stream())
         assert fm.shape == (B, s.M, s.C) and im_embed.shape == (B, s.Cg), (fm.shape, im_embed.shape)
         assert fm.dtype == torch.float32 and im_embed.dtype == torch.float32
         ctx.fm.copy_(fm)

@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 import numpy as np, torch
 from comic_amd import nets, _lib as L
 B = int(os.environ.get('B', '64'))
-plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (224, 224))
+plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (224, 224), pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     enc.autotune()
@@ -54,7 +54,7 @@ while i < n_ops:
         if q['kind'] < 2:
             fl += 2 * M * q['KH'] * q['KW'] * q['Cin'] * q['Cout']
         desc.append('%dx%d/%d %d->%d' % (q['KH'], q['KW'], q['SH'], q['Cin'], q['Cout']))
-    kind = {0: 'conv', 1: 'stem', 2: 'max', 3: 'avg', 4: 'gap'}.get(o['kind'], str(o['kind']))
+    kind = {0: 'conv', 1: 'stem', 2: 'max', 3: 'avg', 4: 'gap', 7: 'pbr'}.get(o['kind'], str(o['kind']))
     by_kind[kind] = by_kind.get(kind, 0) + us
     print('%3d %-4s x%d %3dx%-3d tile %2d %7.1f us %7.1f TF/s  %s' % (i, kind, n, o['Ho'], o['Wo'], op.tile, us,
                                                                     fl / us / 1e6, ' | '.join(desc)))
