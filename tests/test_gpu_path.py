@@ -351,6 +351,32 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
 
 
+def test_train_step_inputs_survive_host_run_ahead():
+    """The host issues steps faster than the GPU executes them: every step must train on ITS captions (the
+    pinned staging buffers of the async host-to-device copies are rewritten only after the copy that last used
+    them has executed).  A long kernel is queued first so that all four steps are issued before the first runs."""
+    spec, cfg = _spec_and_cfg()
+    B, Lc = 6, 11
+    fm, im, caps_a = _batch(spec, B, Lc, 21)
+    _, _, caps_b = _batch(spec, B, Lc, 22)
+    _, _, caps_c = _batch(spec, B, Lc, 23)
+    for c in (caps_b, caps_c):                       # same shape key (B, T, T') as caps_a: same context, same staging slots
+        c[0] = caps_a[0]
+    dec = cdec.Decoder(spec, _rand_params(cfg, 2), DEV)
+    fmd, imd = dev(fm), dev(im)
+    want = []
+    for c in (caps_a, caps_b, caps_c, caps_a):
+        want.append(float(dec.train_step(fmd, imd, c, training=False)['loss']))       # float(): synchronises
+    assert len({round(w, 6) for w in want[:3]}) == 3
+    big = torch.randn(8192, 8192, device=DEV)
+    sync()
+    for _ in range(40):
+        big = torch.mm(big, big) * 1e-4              # ~100 ms of queued work
+    got = [dec.train_step(fmd, imd, c, training=False)['loss'].clone() for c in (caps_a, caps_b, caps_c, caps_a)]
+    sync()
+    assert [float(g) for g in got] == want
+
+
 def test_cnn_finetune_step_end_to_end():
     """train_mode cnn_finetune on a shallow stack: CNN forward -> decoder XE step -> CNN backward
     -> TF-Adam on decoder AND CNN variables, against the oracle chain (cnn_ref reverse pass fed by
