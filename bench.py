@@ -145,6 +145,39 @@ def extras(device, enc, cnn_params, plan):
     return out
 
 
+def heaviest_conv_launch(enc, plan, reps=20):
+    """The single conv launch with the most FLOPs (InceptionV3 @224: Conv2d_4a_3x3, 52x52 3x3 80->192), alone on the
+    GPU with its autotuned kernel variant: HIP events on the launch stream around `reps` back-to-back launches."""
+    import ctypes as C
+    import torch
+    from comic_amd import _lib as L
+    best, bi = 0, None
+    for i, o in enumerate(plan.ops):
+        if o['kind'] == 0 and not o.get('group'):
+            fl = 2 * BATCH * o['Ho'] * o['Wo'] * o['KH'] * o['KW'] * o['Cin'] * o['Cout']
+            if fl > best:
+                best, bi = fl, i
+    if bi is None:
+        return None
+    o, st = plan.ops[bi], L.stream_ptr()
+    first = C.byref(enc._ops, bi * C.sizeof(L.CnnOp))
+
+    def run():
+        L.check(enc.lib.comic_cnn_forward(first, 1, enc._bufptr, enc._bufch, enc._wt, BATCH, 1, st), 'conv launch')
+    run(); run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record(); e1.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    tile = int(enc._ops[bi].tile)
+    return {'layer': '%dx%d %dx%d/%d %d->%d, batch %d' % (o['Ho'], o['Wo'], o['KH'], o['KW'], o['SH'], o['Cin'], o['Cout'], BATCH),
+            'kernel_variant': tile, 'kernel': 'conv_patch_kernel' if tile > 12 or tile == 0 else 'conv_igemm_dma_kernel',
+            'flop': best, 'us': round(us, 2), 'achieved': round(best / us / 1e6, 1), 'unit': 'TFLOP/s',
+            'frac': round(best / us / 1e6 / (PEAK_BF16_MFMA / 1e12), 4)}
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The oracle (numpy restatement of the reference graph: 'port') timed on this host's
     cores for the same step at the reference's CPU-runnable size (configs[0]: batch 2)."""
@@ -300,6 +333,7 @@ def main():
     cnn_iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso]))
     loss = float(res['loss'])
     assert np.isfinite(loss), 'non-finite loss'
+    top = heaviest_conv_launch(tr.encoder, plan) if rank == 0 else None
 
     if rank == 0:
         n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1))
@@ -323,7 +357,7 @@ def main():
                                                     'launches per step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
-                         'cnn_forward_ms': round(cnn_iso_ms, 4),
+                         'cnn_forward_ms': round(cnn_iso_ms, 4), 'heaviest_launch': top,
                          'in_timed_region': {'cnn_forward_ms': round(cnn_ms, 4), 'achieved': round(achieved_in / 1e12, 3),
                                              'frac': round(achieved_in / PEAK_BF16_MFMA, 5), 'overlapped': bool(overlap)},
                          'note': ('achieved/frac: the forward alone on the GPU, HIP events on its stream, measured in this '

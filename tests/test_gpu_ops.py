@@ -184,6 +184,47 @@ def test_conv_patch_variants(case, tile):
     assert (got2[..., :16] == -7).all() and (got2[..., 16 + Cout:] == -7).all()
 
 
+def test_conv_patch_random_sweep():
+    """Random stride-1 layer shapes, source / destination channel slices and batch sizes: every eligible
+    patch-resident variant gives the bits of the im2col kernel (same operands, same k order)."""
+    rng = np.random.default_rng(2024)
+    n_ok = 0
+    for case in range(40):
+        kh, kw = [(1, 1), (3, 3), (5, 5), (1, 7), (7, 1), (1, 3), (3, 1), (3, 5)][rng.integers(8)]
+        Cin = int(rng.choice([32, 48, 64, 80, 96, 112, 128, 160, 192]))
+        Cout = int(rng.choice([16, 32, 48, 64, 80, 96, 128, 192, 208]))
+        H, W, B = int(rng.integers(max(kh, 2), 40)), int(rng.integers(max(kw, 2), 40)), int(rng.integers(1, 9))
+        pad = ['SAME', 'VALID'][rng.integers(2)]
+        Ho, pt, _ = cnn_ref.out_size(H, kh, 1, pad)
+        Wo, pl, _ = cnn_ref.out_size(W, kw, 1, pad)
+        xc = Cin + int(rng.choice([0, 8, 64])); xo = int(rng.choice([0, 8])) if xc > Cin else 0
+        yc = Cout + int(rng.choice([0, 16, 48])); yo = int(rng.choice([0, 4, 16])) if yc >= Cout + 16 else 0
+        relu = int(rng.integers(2))
+        x = torch.randn(B, H, W, xc, device=DEV).to(torch.bfloat16)
+        K = kh * kw * Cin
+        wf = torch.randn(Cout, (K + 63) // 64 * 64, device=DEV) / K ** 0.5
+        wf[:, K:] = 0
+        w = wf.to(torch.bfloat16).contiguous()
+        scale, shift = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV) * 0.1
+        wt = L.ConvWeight(w.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        ref = None
+        for tile in [3] + list(range(13, 26)):
+            y = torch.full((B, Ho, Wo, yc), -7.0, dtype=torch.bfloat16, device=DEV)
+            op = L.CnnOp(kind=0, src=0, dst=1, src_coff=xo, dst_coff=yo, H=H, W=W, Cin=Cin, Cout=Cout, KH=kh, KW=kw, SH=1,
+                         SW=1, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=relu, out_f32=0, tile=tile)
+            rc = lib().comic_conv2d_bn_relu(C.byref(op), x.data_ptr(), xc, y.data_ptr(), yc, C.byref(wt), B, 1, stream())
+            sync()
+            if rc != 0:
+                assert tile != 3 and b'not eligible' in lib().comic_last_error()
+                continue
+            if tile == 3:
+                ref = y
+            else:
+                assert torch.equal(y, ref), (case, tile, B, H, W, Cin, Cout, kh, kw, pad, xc, xo, yc, yo)
+                n_ok += 1
+    assert n_ok > 300
+
+
 def test_conv_patch_rejects_strided():
     x = np.zeros((1, 9, 9, 32), np.float32)
     w = np.zeros((3, 3, 32, 32), np.float32)
