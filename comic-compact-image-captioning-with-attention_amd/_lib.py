@@ -75,6 +75,8 @@ _SIGS = {
     'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),
     'comic_dropout_mask': (c_int, [P, c_int64, c_float, c_uint64, c_uint64, P]),
     'comic_dropout_mask_dev': (c_int, [P, c_int64, c_float, P, c_uint64, P]),
+    'comic_dropout_masks4_dev': (c_int, [P, P, P, P, P]),
+    'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
     'comic_attn_step_fwd': (c_int, [P, P, P, P, P, P, P, P, P, c_float, P, P, P, P]),

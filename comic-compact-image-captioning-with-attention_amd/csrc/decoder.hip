@@ -103,6 +103,36 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, long n, float keep
   mask[i] = u < keep ? 1.f : 0.f;
 }
 
+// four consecutive masks (keep probability per segment) of one buffer in ONE launch; element i draws counter i,
+// i.e. the same bits as four comic_dropout_mask_dev calls with cumulative offsets
+struct MaskSegs {
+  long end[4];
+  float keep[4];
+};
+__global__ void dropout_masks4_kernel(float* __restrict__ mask, MaskSegs sg, const uint64_t* __restrict__ seed_dev) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sg.end[3]) return;
+  const float keep = i < sg.end[0] ? sg.keep[0] : i < sg.end[1] ? sg.keep[1] : i < sg.end[2] ? sg.keep[2] : sg.keep[3];
+  const uint64_t r = splitmix64(splitmix64(seed_dev[0]) ^ (uint64_t)i);
+  const float u = (float)(r >> 40) * (1.0f / 16777216.0f);
+  mask[i] = u < keep ? 1.f : 0.f;
+}
+
+// out[0] = sum_{t,b} rows[t*B + b] * w[b*T + t]   (sequence_loss reduction: time-major rows, [B,T] weights)
+__global__ __launch_bounds__(256) void weighted_sum_tb_kernel(const float* __restrict__ rows, const float* __restrict__ w,
+                                                              int T, int B, float* __restrict__ out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < T * B; i += 256) acc += rows[i] * w[(i % B) * T + i / B];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
 // ------------------------------------------------------------------ LSTM gates --------
 __global__ void lstm_gates_fwd_kernel(const float* __restrict__ g, const float* __restrict__ c_prev,
                                       const float* __restrict__ h_prev, float* __restrict__ gates_act,
@@ -744,6 +774,31 @@ extern "C" int comic_dropout_mask_dev(float* mask, int64_t n, float keep, const 
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, mask,
                      (long)n, keep, (uint64_t)0, seed_dev, offset);
   COMIC_LAUNCH_CHECK("dropout_mask_dev");
+  return 0;
+}
+
+extern "C" int comic_dropout_masks4_dev(float* mask, const int64_t* n4, const float* keep4, const uint64_t* seed_dev,
+                                        void* stream) {
+  COMIC_REQUIRE(mask && n4 && keep4 && seed_dev, "dropout_masks4_dev: null argument");
+  MaskSegs sg;
+  long end = 0;
+  for (int i = 0; i < 4; ++i) {
+    COMIC_REQUIRE(n4[i] >= 0, "dropout_masks4_dev: negative length");
+    end += n4[i];
+    sg.end[i] = end;
+    sg.keep[i] = keep4[i];
+  }
+  if (end == 0) return 0;
+  hipLaunchKernelGGL(dropout_masks4_kernel, dim3((unsigned)cdiv64(end, 256)), dim3(256), 0, (hipStream_t)stream, mask, sg,
+                     seed_dev);
+  COMIC_LAUNCH_CHECK("dropout_masks4_dev");
+  return 0;
+}
+
+extern "C" int comic_weighted_sum_tb(const float* rows_tb, const float* w_bt, int T, int B, float* out, void* stream) {
+  COMIC_REQUIRE(rows_tb && w_bt && out && T > 0 && B > 0, "weighted_sum_tb: bad argument");
+  hipLaunchKernelGGL(weighted_sum_tb_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows_tb, w_bt, T, B, out);
+  COMIC_LAUNCH_CHECK("weighted_sum_tb");
   return 0;
 }
 

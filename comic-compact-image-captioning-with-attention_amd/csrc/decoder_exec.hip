@@ -254,6 +254,18 @@ __global__ __launch_bounds__(256) void maploss_part_kernel(const float* __restri
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
+// the four attention-parameter gradients out of the column-summed [v | ln_g | ln_b | tau] row
+__global__ void scatter_pgrad_kernel(const float* __restrict__ row, float* __restrict__ v, float* __restrict__ ln_g,
+                                     float* __restrict__ ln_b, float* __restrict__ tau, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < D) {
+    v[i] = row[i];
+    ln_g[i] = row[D + i];
+    ln_b[i] = row[2 * D + i];
+  }
+  if (i == 0) tau[0] = row[3 * D];
+}
+
 __global__ __launch_bounds__(256) void maploss_final_kernel(const float* __restrict__ partial, int nparts, long n,
                                                             float scale, float* __restrict__ map_loss) {
   __shared__ float red[256];
@@ -672,9 +684,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dvalues = sep_values ? dvalues_buf : dkeys;
   RC(fill(dkeys, 0.f, (long)B * M * D, st));
   if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
-  RC(fill(dc, 0.f, (long)B * D, st));
-  RC(fill(dh, 0.f, (long)B * D, st));
-  RC(fill(datt, 0.f, (long)B * A, st));
+  RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));      // dc | dh | datt: consecutive workspace blocks
   // dy_all = dlogits * W_o^T ; dW_o, db_o
   RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
   RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
@@ -768,10 +778,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     // dg_all is free again here (its last reader, the dK GEMM, is ordered before on `st`).
     float* tmp = dg_all;
     RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
-    (void)hipMemcpyAsync(gr->v, tmp, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(gr->ln_g, tmp + D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(gr->ln_b, tmp + 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(gr->tau, tmp + 3 * D, sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);
   }
   COMIC_LAUNCH_CHECK("train_step");
   return 0;

@@ -269,22 +269,40 @@ class Decoder:
         from types import SimpleNamespace
         ctx = SimpleNamespace(key=key, calls=0, graph=None)
         f32 = dict(dtype=torch.float32, device=dev)
-        ctx.i32 = torch.zeros(2 * B * T + B, dtype=torch.int32, device=dev)      # inputs | targets | lens
-        ctx.f32 = torch.zeros(3 * B * T, **f32)                                   # wmask | coef | row scale
+        # ONE staging block per step: [seed int64 | inputs, targets, lens int32 | wmask, coef, row scale fp32]
+        n_i32, n_f32 = 2 * B * T + B, 3 * B * T
+        o_i32, o_f32 = 8, 8 + 4 * ((n_i32 + 1) // 2 * 2)
+        nbytes = o_f32 + 4 * n_f32
+
+        def views(buf):
+            return (buf[:8].view(torch.int64), buf[o_i32:o_i32 + 4 * n_i32].view(torch.int32),
+                    buf[o_f32:o_f32 + 4 * n_f32].view(torch.float32))
+        ctx.stage_dev = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        ctx.seed, ctx.i32, ctx.f32 = views(ctx.stage_dev)
         # pinned staging, two slots used alternately: the host may run ahead of the GPU, and an async H2D copy
         # reads its pinned source when the STREAM gets there, so a slot is rewritten only after the copy that last
         # used it has executed (event per slot)
-        ctx.stage = [SimpleNamespace(i32=torch.zeros(2 * B * T + B, dtype=torch.int32).pin_memory(),
-                                     f32=torch.zeros(3 * B * T, dtype=torch.float32).pin_memory(),
-                                     seed=torch.zeros(1, dtype=torch.int64).pin_memory(), copied=None) for _ in range(2)]
-        ctx.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        ctx.stage = []
+        for _ in range(2):
+            buf = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+            sd, i32, f32v = views(buf)
+            ctx.stage.append(SimpleNamespace(buf=buf, seed=sd, i32=i32, f32=f32v, copied=None))
         ctx.fm = torch.empty((B, s.M, s.C), **f32)
         ctx.im = torch.empty((B, s.Cg), **f32)
         EA = s.E + s.A
         ctx.masks = None
         if training:
-            ctx.masks = dict(init_in=torch.empty((B, EA), **f32), inp=torch.empty((Tp, B, EA), **f32),
-                             out=torch.empty((Tp, B, s.D), **f32), alpha=torch.empty((Tp, B, s.H, s.M), **f32))
+            # one buffer, four views (generated by ONE launch: comic_dropout_masks4_dev)
+            shapes = dict(init_in=(B, EA), inp=(Tp, B, EA), out=(Tp, B, s.D), alpha=(Tp, B, s.H, s.M))
+            sizes = [int(np.prod(v)) for v in shapes.values()]
+            ctx.mask_buf = torch.empty(sum(sizes), **f32)
+            ctx.masks, off = {}, 0
+            for (k, shp), n in zip(shapes.items(), sizes):
+                ctx.masks[k] = ctx.mask_buf[off:off + n].view(shp)
+                off += n
+            ctx.mask_n4 = (C.c_int64 * 4)(*sizes)
+            ctx.mask_keep4 = (C.c_float * 4)(1 - s.dropout_rnn_in, 1 - s.dropout_rnn_in, 1 - s.dropout_rnn_out,
+                                             s.attn_keep_prob)
         ctx.logits = torch.empty((T, B, s.V), **f32)
         ctx.ids = torch.empty((T, B), dtype=torch.int32, device=dev)
         ctx.hist = torch.empty((Tp, B, s.H, s.M), **f32)
@@ -306,13 +324,8 @@ class Decoder:
         st = L.stream_ptr()
         m = ctx.masks or {}
         if training and gen_masks:
-            off = 0
-            for name, keep in (('init_in', 1 - s.dropout_rnn_in), ('inp', 1 - s.dropout_rnn_in),
-                               ('out', 1 - s.dropout_rnn_out), ('alpha', s.attn_keep_prob)):
-                t = m[name]
-                L.check(self.lib.comic_dropout_mask_dev(t.data_ptr(), t.numel(), keep, ctx.seed.data_ptr(), off, st),
-                        'dropout_mask')
-                off += t.numel()
+            L.check(self.lib.comic_dropout_masks4_dev(ctx.mask_buf.data_ptr(), ctx.mask_n4, ctx.mask_keep4,
+                                                      ctx.seed.data_ptr(), st), 'dropout_masks4')
         BT = B * T
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()
@@ -325,8 +338,8 @@ class Decoder:
             ctx.map_loss.data_ptr(), L.ptr(ctx.dfm), L.ptr(ctx.dim), ctx.ws.data_ptr(), ctx.nbytes, st),
             'decoder_train_step')
         # sequence_loss reduction (model_base.py:337-347): rows carry xent*w; rs = 1/denominator (* reward/B)
-        rs_tb = f32[2 * BT:3 * BT].view(B, T).t()
-        ctx.loss.copy_((ctx.loss_rows.view(T, B) * rs_tb).sum().reshape(1))
+        L.check(self.lib.comic_weighted_sum_tb(ctx.loss_rows.data_ptr(), f32.data_ptr() + 4 * 2 * BT, T, B,
+                                               ctx.loss.data_ptr(), st), 'weighted_sum_tb')
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
                    want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None):
@@ -363,15 +376,13 @@ class Decoder:
         ih, fh = slot.i32.numpy(), slot.f32.numpy()
         ih[:BT] = inputs.reshape(-1); ih[BT:2 * BT] = targets.reshape(-1); ih[2 * BT:] = lens
         fh[:BT] = wmask.reshape(-1); fh[BT:2 * BT] = coef.reshape(-1); fh[2 * BT:] = rs.reshape(-1)
-        ctx.i32.copy_(slot.i32, non_blocking=True)
-        ctx.f32.copy_(slot.f32, non_blocking=True)
         if gen_masks:
             if seed is None:
                 self._dropout_calls += 1
                 seed = 0x9E3779B9 + self._dropout_calls
             slot.seed[0] = int(seed)
-            ctx.seed.copy_(slot.seed, non_blocking=True)
-        elif masks is not None:
+        ctx.stage_dev.copy_(slot.buf, non_blocking=True)
+        if masks is not None:
             for k, v in masks.items():
                 ctx.masks[k].copy_(v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, np.float32)))
         if slot.copied is None:

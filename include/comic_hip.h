@@ -214,6 +214,13 @@ int comic_dropout_mask(float* mask, int64_t n, float keep, uint64_t seed, uint64
 /* same generator, seed read from device memory at run time (hipGraph replays draw new masks) */
 int comic_dropout_mask_dev(float* mask, int64_t n, float keep, const uint64_t* seed_dev,
                            uint64_t offset, void* stream);
+/* The four consecutive masks of a training step (n4[i] elements with keep probability keep4[i], one buffer) in one
+ * launch: the same bits as four comic_dropout_mask_dev calls with cumulative offsets. */
+int comic_dropout_masks4_dev(float* mask, const int64_t* n4, const float* keep4, const uint64_t* seed_dev,
+                             void* stream);
+/* out[0] = sum_{t,b} rows_tb[t*B + b] * w_bt[b*T + t]: the tf.contrib.seq2seq.sequence_loss reduction
+ * (model_base.py:337-347) over the per-row cross-entropies of comic_decoder_train_step. */
+int comic_weighted_sum_tb(const float* rows_tb, const float* w_bt, int T, int B, float* out, void* stream);
 
 /* BasicLSTMCell gate math (model_base.py:618-621; gate order i,j,f,o; forget_bias 1).
  *  g [B,4D] pre-activations (bias included).  Writes activated gates [B,4D] (for bwd),
