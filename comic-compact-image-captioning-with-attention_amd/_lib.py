@@ -18,6 +18,11 @@ class CnnOp(C.Structure):
         'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group', 'flags')]
 
 
+class ImageDesc(C.Structure):           # struct comic_image_desc
+    _fields_ = [('offset', C.c_int64), ('in_h', c_int32), ('in_w', c_int32), ('flip', c_int32), ('oy', c_int32),
+                ('ox', c_int32), ('sy', C.c_float), ('sx', C.c_float)]
+
+
 class ConvWeight(C.Structure):
     _fields_ = [('w', c_void_p), ('scale', c_void_p), ('shift', c_void_p)]
 
@@ -76,6 +81,7 @@ _SIGS = {
     'comic_dropout_mask': (c_int, [P, c_int64, c_float, c_uint64, c_uint64, P]),
     'comic_dropout_mask_dev': (c_int, [P, c_int64, c_float, P, c_uint64, P]),
     'comic_dropout_masks4_dev': (c_int, [P, P, P, P, P]),
+    'comic_image_preprocess': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),

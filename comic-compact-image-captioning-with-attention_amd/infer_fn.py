@@ -25,6 +25,7 @@ def run_inference(config, curr_ckpt_path, device='cuda:0'):
     ckpt_num = P_CKPT.findall(ckpt_file)[0]
     mdl.reset_default_graph()
     inputs_man = inputs.InputManager(config, is_inference=True)
+    inputs_man.enable_device_preprocess(device)
     c = inputs_man.config
     batch_size = c.batch_size_infer
     c.checkpoint_path = curr_ckpt_path

@@ -18,6 +18,8 @@ import json
 import os
 import random
 import string
+import queue
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -40,21 +42,120 @@ def resize_bilinear_tf1(img, out_h, out_w):
     return (top * (1 - wy) + bot * wy).astype(np.float32)
 
 
-def preprocess_image(path_or_array, height, width, augment, rng):
+class Prefetch(object):
+    """Iterator over `gen` that a daemon thread keeps `depth` items ahead of the consumer (the
+    `dataset.prefetch` of the reference's tf.data pipeline): decoding / resizing of the next batches
+    overlaps the GPU step.  Order is the generator's order; an exception in the producer is re-raised
+    at the consumer's next() call."""
+    _END = object()
+
+    def __init__(self, gen, depth=4):
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._t = threading.Thread(target=self._run, args=(gen,), daemon=True)
+        self._t.start()
+
+    def _run(self, gen):
+        try:
+            for item in gen:
+                self._q.put((item, None))
+            self._q.put((self._END, None))
+        except BaseException as e:           # noqa: B902 -- handed to the consumer
+            self._q.put((self._END, e))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item, err = self._q.get()
+        if item is self._END:
+            self._q.put((self._END, err))    # stay exhausted
+            if err is not None:
+                raise err
+            raise StopIteration
+        return item
+
+
+def draw_augmentation(augment, height, width, rng):
+    """(flip, oy, ox) of one image, drawn in the PRODUCER thread so that the augmentation stream is a function of
+    the seed and the sample order, not of how the decode threads are scheduled."""
+    if not augment:
+        return False, (256 - height) // 2, (256 - width) // 2
+    flip = rng.random() < 0.5
+    return flip, rng.randrange(0, 256 - height + 1), rng.randrange(0, 256 - width + 1)
+
+
+def decode_image(path_or_array):
+    """JPEG / PNG file (or an already decoded array) -> uint8 RGB [H, W, 3].  The only per-image host work when the
+    rest of the preprocessing runs on the device (DevicePreprocessor)."""
     if isinstance(path_or_array, np.ndarray):
-        img = path_or_array
-    else:
-        from PIL import Image
-        with Image.open(path_or_array) as im:
-            img = np.asarray(im.convert('RGB'))
+        return path_or_array
+    from PIL import Image
+    with Image.open(path_or_array) as im:
+        return np.asarray(im.convert('RGB'))
+
+
+class DevicePreprocessor(object):
+    """resize / flip / crop / scale of a batch in ONE launch of comic_image_preprocess (csrc/preprocess.hip): the
+    decoded uint8 images go to the device back to back through a pinned staging block (two slots with events: the
+    producer thread may be a batch ahead of the copy engine), the result is a device tensor [n, h, w, 3] fp32 with
+    the bits of `preprocess_image`."""
+
+    def __init__(self, device, height, width, resize=256):
+        import torch
+        from . import _lib as L
+        self.torch, self.L, self.lib = torch, L, L.load()
+        self.device, self.h, self.w, self.resize = device, int(height), int(width), int(resize)
+        self._slots = [dict(blob=None, desc=None, ev=None) for _ in range(2)]
+        self._dev_blob = None
+        self._n = 0
+
+    def __call__(self, images_u8, params):
+        torch, L = self.torch, self.L
+        import ctypes as C
+        n = len(images_u8)
+        total = sum(int(im.shape[0]) * int(im.shape[1]) * 3 for im in images_u8)
+        slot = self._slots[self._n % 2]
+        self._n += 1
+        if slot['ev'] is not None:
+            slot['ev'].synchronize()
+        if slot['blob'] is None or slot['blob'].numel() < total:
+            slot['blob'] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        if slot['desc'] is None or slot['desc'].numel() < n * C.sizeof(L.ImageDesc):
+            slot['desc'] = torch.empty(max(n, 64) * C.sizeof(L.ImageDesc), dtype=torch.uint8).pin_memory()
+        blob = slot['blob'].numpy()
+        desc = (L.ImageDesc * n).from_buffer(slot['desc'].numpy())
+        off = 0
+        for i, (im, (flip, oy, ox)) in enumerate(zip(images_u8, params)):
+            assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, (im.dtype, im.shape)
+            ih, iw = int(im.shape[0]), int(im.shape[1])
+            nb = ih * iw * 3
+            blob[off:off + nb] = im.reshape(-1)
+            d = desc[i]
+            d.offset, d.in_h, d.in_w, d.flip, d.oy, d.ox = off, ih, iw, int(bool(flip)), int(oy), int(ox)
+            d.sy, d.sx = np.float32(ih / self.resize), np.float32(iw / self.resize)
+            off += nb
+        with torch.cuda.device(self.device):
+            if self._dev_blob is None or self._dev_blob.numel() < slot['blob'].numel():
+                self._dev_blob = torch.empty(slot['blob'].numel(), dtype=torch.uint8, device=self.device)
+            dev_desc = torch.empty(n * C.sizeof(L.ImageDesc), dtype=torch.uint8, device=self.device)
+            self._dev_blob[:total].copy_(slot['blob'][:total], non_blocking=True)
+            dev_desc.copy_(slot['desc'][:n * C.sizeof(L.ImageDesc)], non_blocking=True)
+            out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
+            L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
+                                                    self.h, self.w, self.resize, L.stream_ptr()), 'image_preprocess')
+            if slot['ev'] is None:
+                slot['ev'] = torch.cuda.Event()
+            slot['ev'].record(torch.cuda.current_stream())
+        return out
+
+
+def preprocess_image(path_or_array, height, width, augment, rng, params=None):
+    img = decode_image(path_or_array)
     img = img.astype(np.float32) / np.float32(255.0)
     img = resize_bilinear_tf1(img, 256, 256)
-    if augment:
-        if rng.random() < 0.5:
-            img = img[:, ::-1]
-        oy = rng.randrange(0, 256 - height + 1); ox = rng.randrange(0, 256 - width + 1)
-    else:
-        oy = (256 - height) // 2; ox = (256 - width) // 2
+    flip, oy, ox = params if params is not None else draw_augmentation(augment, height, width, rng)
+    if flip:
+        img = img[:, ::-1]
     img = img[oy:oy + height, ox:ox + width]
     return np.ascontiguousarray((img - np.float32(0.5)) * np.float32(2.0))
 
@@ -75,7 +176,10 @@ class InputManager(object):
         self.config = c = config
         self.is_inference = is_inference
         self._rng = random.Random(c.rand_seed)            # random.seed(c.rand_seed), :58
-        self._pool = ThreadPoolExecutor(max_workers=3)     # num_parallel_calls=3, :169
+        # decode / resize workers (the reference maps with num_parallel_calls=3, :169; one MI355X consumes three
+        # orders of magnitude more images per second than a TF-1 CPU pipeline) and batches kept ahead of the step
+        self._pool = ThreadPoolExecutor(max_workers=int(getattr(c, 'loader_threads', 0)) or min(16, os.cpu_count() or 3))
+        self._prefetch_depth = int(getattr(c, 'loader_prefetch', 4))
         self._get_vocab()
         if is_inference:
             if 'coco' in c.infer_set:
@@ -151,7 +255,7 @@ class InputManager(object):
                 assert len(data) % batch_size == 0
         augment = is_training and c.cnn_input_augment
         print('INFO: Augment {} images: {}'.format(split, augment))
-        return self._batches(data, batch_size, is_training, augment)
+        return Prefetch(self._batches(data, batch_size, is_training, augment), self._prefetch_depth)
 
     def _gen(self, data, is_training):
         c = self.config
@@ -163,9 +267,23 @@ class InputManager(object):
             if is_training:
                 self._rng.shuffle(data)
 
-    def _load(self, path, augment):
+    def _load(self, path, augment, params=None):
         h, w = self.config.cnn_input_size
-        return preprocess_image(path, h, w, augment, self._rng)
+        return preprocess_image(path, h, w, augment, self._rng, params)
+
+    def enable_device_preprocess(self, device='cuda:0'):
+        """From the next batch on: the host only decodes (thread pool), resize / flip / crop / scale run on `device`
+        and the batches carry device tensors (bit-identical values; `CaptionModel` takes either)."""
+        h, w = self.config.cnn_input_size
+        self._devpre = DevicePreprocessor(device, h, w)
+
+    def _load_many(self, paths, augment):
+        h, w = self.config.cnn_input_size
+        params = [draw_augmentation(augment, h, w, self._rng) for _ in paths]
+        devpre = getattr(self, '_devpre', None)
+        if devpre is not None:
+            return devpre(list(self._pool.map(decode_image, paths)), params)
+        return np.stack(list(self._pool.map(lambda a: self._load(a[0], augment, a[1]), zip(paths, params))))
 
     def _batches(self, data, batch_size, is_training, augment):
         """bucket_by_sequence_length(boundaries=self.buckets, pad -> wtoi['<PAD>']) (:177-183)."""
@@ -177,12 +295,12 @@ class InputManager(object):
             buckets[k].append((path, cap))
             if len(buckets[k]) == batch_size:
                 items, buckets[k] = buckets[k], []
-                ims = list(self._pool.map(lambda it: self._load(it[0], augment), items))
+                ims = self._load_many([it[0] for it in items], augment)
                 L = max(len(it[1]) for it in items)
                 caps = np.full((batch_size, L), pad, np.int32)
                 for i, it in enumerate(items):
                     caps[i, :len(it[1])] = it[1]
-                yield np.stack(ims), caps
+                yield ims, caps
 
 
 class InputManager_Radix(InputManager):
@@ -244,7 +362,7 @@ class InputManager_SCST(InputManager_Radix):
         batch_size = c.batch_size_train
         c.max_step = int(len(data) / batch_size * c.max_epoch / getattr(c, 'accum_grads_step', 1))
         augment = is_training and c.cnn_input_augment
-        return self._scst_batches(data, batch_size, augment)
+        return Prefetch(self._scst_batches(data, batch_size, augment), self._prefetch_depth)
 
     def _scst_batches(self, data, batch_size, augment):
         c = self.config
@@ -252,10 +370,9 @@ class InputManager_SCST(InputManager_Radix):
         while True:
             for i in range(0, len(data) - batch_size + 1, batch_size):      # batch_and_drop_remainder
                 items = data[i:i + batch_size]
-                ims = list(self._pool.map(
-                    lambda it: self._load(pjoin(c.dataset_dir, it[0]) if not os.path.isabs(it[0]) else it[0], augment),
-                    items))
-                yield np.stack(ims), [list(it[1][:5]) for it in items]
+                ims = self._load_many([pjoin(c.dataset_dir, it[0]) if not os.path.isabs(it[0]) else it[0]
+                                        for it in items], augment)
+                yield ims, [list(it[1][:5]) for it in items]
             self._rng.shuffle(data)
 
     def captions_to_batched_ids(self, hypos):

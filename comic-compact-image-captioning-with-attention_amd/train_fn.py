@@ -43,6 +43,7 @@ def train_fn(config, device='cuda:0', dp=None):
     print('INFO: Logging to `{}`.'.format(config.log_path))
     mdl.reset_default_graph()
     inputs_man = _manager(config)
+    inputs_man.enable_device_preprocess(device)        # host: JPEG decode only
     c = inputs_man.config
     num_batches = int(c.split_sizes['train'] / c.batch_size_train)
     lr = c.lr_start
@@ -102,6 +103,7 @@ def train_fn_scst(config, idx_ngram=False, device='cuda:0', dp=None):
     print('INFO: Logging to `{}`.'.format(config.log_path))
     mdl.reset_default_graph()
     inputs_man = inputs.InputManager_SCST(config)
+    inputs_man.enable_device_preprocess(device)
     c = inputs_man.config
     num_batches = int(c.split_sizes['train'] / c.batch_size_train)
     lr = c.lr_start

@@ -127,6 +127,21 @@ int comic_cnn_forward_grouped(const comic_cnn_op* ops, int n_ops, void* const* b
                               const int32_t* buf_channels, const comic_conv_weight* weights,
                               int batch, int dtype, const void* group_args_dev, void* stream);
 
+/* ---- input pipeline on the device ------------------------------------------
+ * The decoded uint8 RGB images of a batch -> the network input: float [0,1], TF-1 bilinear resize to
+ * `resize` x `resize` (256; tf.image.resize_images with align_corners=False), optional horizontal flip, crop of
+ * out_h x out_w at (oy, ox), (x - 0.5) * 2.  Replaces inception_preprocessing_radix.preprocess_image as called by
+ * manager_image_caption.py:111-228; bit-identical to the numpy restatement comic_amd.inputs.preprocess_image.
+ * `blob`: the images back to back (device memory); `desc`: n records (device memory). */
+typedef struct comic_image_desc {
+  int64_t offset;        /* byte offset of image i in `blob` (in_h x in_w x 3 uint8, row-major) */
+  int32_t in_h, in_w;
+  int32_t flip, oy, ox;  /* augmentation: flip of the resized image, crop origin in the resized image */
+  float sy, sx;          /* float32(in_h / resize), float32(in_w / resize) */
+} comic_image_desc;
+int comic_image_preprocess(const uint8_t* blob, const void* desc, int n, float* dst /* [n,out_h,out_w,3] */,
+                           int out_h, int out_w, int resize, void* stream);
+
 /* ---- cnn_finetune: backward of the plan (train.py:241-249; model_base.py:76,834-849) ------
  * The CNN variables (conv weights, BN beta) become trainable; BN stays in inference mode, so a
  * conv contributes d beta = sum(1[y>0] dy), d w (backward-weight) and d x (backward-data).

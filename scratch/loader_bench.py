@@ -1,0 +1,32 @@
+"""Loader throughput: JPEG decode on host threads + resize / flip / crop / scale on the device vs everything in numpy."""
+import sys, os, time, tempfile, random
+sys.path.insert(0, '.')
+import numpy as np, torch
+from PIL import Image
+from concurrent.futures import ThreadPoolExecutor
+from comic_amd import inputs
+d = tempfile.mkdtemp()
+rng = np.random.default_rng(0)
+paths = []
+for i in range(256):
+    a = (rng.random((30, 40, 3)) * 255).astype(np.uint8)
+    p = os.path.join(d, '%d.jpg' % i); Image.fromarray(a).resize((640, 480), Image.BICUBIC).save(p, quality=90); paths.append(p)
+r = random.Random(0)
+pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
+for nt in (1, 4, 8, 16, 32):
+    pool = ThreadPoolExecutor(max_workers=nt)
+    for mode in ('numpy', 'device'):
+        n, t0 = 0, time.time()
+        for rep in range(2 if mode == 'numpy' else 6):
+            for b in range(0, len(paths), 64):
+                ps = paths[b:b + 64]
+                params = [inputs.draw_augmentation(True, 224, 224, r) for _ in ps]
+                if mode == 'numpy':
+                    ims = np.stack(list(pool.map(lambda a: inputs.preprocess_image(a[0], 224, 224, True, r, a[1]), zip(ps, params))))
+                    t = torch.from_numpy(ims).to('cuda:0')
+                else:
+                    t = pre(list(pool.map(inputs.decode_image, ps)), params)
+                n += len(ps)
+        torch.cuda.synchronize()
+        print('threads %2d  %-6s : %6.0f images/s' % (nt, mode, n / (time.time() - t0)))
+print('cpus', os.cpu_count())

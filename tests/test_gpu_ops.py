@@ -265,6 +265,27 @@ def _run_pool(x, kind, k, s, pad, dtype, dst_channels=None, dst_coff=0):
     return y.float().cpu().numpy()
 
 
+def test_device_image_preprocess_matches_numpy_pipeline():
+    """comic_image_preprocess (uint8 -> [0,1] -> TF-1 bilinear 256x256 -> flip -> crop -> [-1,1]) against the numpy
+    restatement of the reference's preprocessing, bit for bit: odd sizes, up- and down-scaling, flips, crop offsets;
+    staging slots re-used across calls."""
+    from comic_amd import inputs
+    rng = np.random.default_rng(5)
+    pre = inputs.DevicePreprocessor(DEV, 224, 224)
+    for rep in range(3):
+        sizes = [(480, 640), (333, 500), (100, 77), (256, 256), (1, 1), (257, 1023)][:6 - rep]
+        ims = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+        params = [(bool(rng.integers(2)), int(rng.integers(0, 33)), int(rng.integers(0, 33))) for _ in ims]
+        got = pre(ims, params).cpu().numpy()
+        for i, (im, prm) in enumerate(zip(ims, params)):
+            want = inputs.preprocess_image(im, 224, 224, True, None, prm)
+            np.testing.assert_array_equal(got[i], want, err_msg='image %d %s %s' % (i, im.shape, prm))
+    pre299 = inputs.DevicePreprocessor(DEV, 256, 256)          # no crop margin
+    im = rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(pre299([im], [(True, 0, 0)]).cpu().numpy()[0],
+                                  inputs.preprocess_image(im, 256, 256, True, None, (True, 0, 0)))
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_pools(dtype):
     rng = np.random.default_rng(1)

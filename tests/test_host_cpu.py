@@ -170,6 +170,37 @@ def test_input_managers_on_tiny_dataset(tmp_path):
     assert ids.tolist() == [[256, 0, 1, 257, -1], [256, 2, c.wtoi['<UNK>'], 3, 257]]
 
 
+def test_loader_prefetch_and_deterministic_augmentation(tmp_path):
+    """The batches come from a prefetch thread (order = generator order, producer exceptions re-raised at next()),
+    and the augmentation stream is drawn in the producer thread: two managers with the same seed yield the same
+    augmented pixels whatever the decode threads do."""
+    from tests import tiny_dataset
+    from comic_amd import inputs
+    pf = inputs.Prefetch(iter(range(10)), depth=3)
+    assert list(pf) == list(range(10))
+    with pytest.raises(StopIteration):
+        next(pf)
+
+    def boom():
+        yield 1
+        raise ValueError('decode failed')
+    pf = inputs.Prefetch(boom(), depth=2)
+    assert next(pf) == 1
+    with pytest.raises(ValueError, match='decode failed'):
+        next(pf)
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=2, n_test=2)
+    kw = dict(dataset_dir=ds, dataset_file_pattern='mscoco_{}_w5_s20_include_restval', cnn_name='inception_v3',
+              cnn_input_size=[224, 224], cnn_input_augment=True, batch_size_train=4, batch_size_eval=2, max_epoch=3,
+              rand_seed=7, token_type='radix', radix_base=256)
+    a = inputs.InputManager_Radix(conf.Config(loader_threads=8, **kw))
+    b = inputs.InputManager_Radix(conf.Config(loader_threads=1, loader_prefetch=1, **kw))
+    assert isinstance(a.batch_train, inputs.Prefetch)
+    for _ in range(3):
+        (ia, ca), (ib, cb) = next(a.batch_train), next(b.batch_train)
+        np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(ca, cb)
+
+
 def test_tf1_bilinear_resize_matches_definition():
     from comic_amd.inputs import resize_bilinear_tf1
     img = np.arange(2 * 3 * 1, dtype=np.float32).reshape(2, 3, 1)
