@@ -274,6 +274,8 @@ class InputManager(object):
     def enable_device_preprocess(self, device='cuda:0'):
         """From the next batch on: the host only decodes (thread pool), resize / flip / crop / scale run on `device`
         and the batches carry device tensors (bit-identical values; `CaptionModel` takes either)."""
+        if not str(device).startswith('cuda'):
+            return
         h, w = self.config.cnn_input_size
         self._devpre = DevicePreprocessor(device, h, w)
 
