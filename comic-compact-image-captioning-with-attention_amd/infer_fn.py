@@ -2,7 +2,9 @@
 `run_inference`, `evaluate_model` and the same output files (`captions___N.json`,
 `outputs___N.pkl`, `infer_speed.txt`; infer_fn.py:166-184).  The Java COCO scorers
 (METEOR / SPICE / PTB tokenizer) are outside the hot path: `evaluate_model`
-runs inference and hands the JSON to an optional external evaluator."""
+runs inference and hands the JSON to an evaluator callable -- `comic_amd.coco_eval.evaluate_captions`
+(native BLEU-1..4 / ROUGE-L / CIDEr, pinned against the reference's Python scorers) when infer.py finds the
+annotation file."""
 from __future__ import annotations
 
 import json

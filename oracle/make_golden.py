@@ -8,6 +8,7 @@ is copied into the repo: the fixtures hold inputs and expected outputs only.
   * CIDEr-D ............ imported as-is from common/scst/cider_ruotianluo
   * BLEU, captionScorer, prepro_ngrams ... py2-only syntax; a temp copy under a
     TemporaryDirectory gets a `lib2to3 -w -n` pass and is imported from there
+  * pycocoevalcap Bleu / Rouge / Cider (corpus-level evaluation, eval.py) ... temp 2to3 copy, as BLEU
   * number_to_base, _baseN_arr_to_dec, id_to_caption, radix table,
     captions_to_batched_ids ... `ast`-extracted function bodies exec'd with stubs
     (their modules import tensorflow at top level).
@@ -161,6 +162,60 @@ def make_scorer_golden():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_cocoeval_golden():
+    """Corpus-level BLEU-1..4, ROUGE-L and CIDEr of the reference's pycocoevalcap scorers (eval.py:18-62 runs them
+    after the Java PTB tokenizer; here on already tokenized strings) -> tests/golden/cocoeval_golden.json."""
+    tmp = tempfile.mkdtemp(prefix='comic_golden_')
+    try:
+        pkg = os.path.join(tmp, 'pycocoevalcap')
+        shutil.copytree(os.path.join(REF, 'common/coco_caption/pycocoevalcap'), pkg)
+        subprocess.run([sys.executable, '-m', 'lib2to3', '-w', '-n'] +
+                       [os.path.join(pkg, d) for d in ('bleu', 'rouge', 'cider')],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sys.path.insert(0, tmp)
+        for m in [k for k in sys.modules if k == 'pycocoevalcap' or k.startswith('pycocoevalcap.')]:
+            sys.modules.pop(m)
+        from pycocoevalcap.bleu import bleu as bleu_mod        # noqa: temp 2to3 copies of the reference
+        from pycocoevalcap.rouge import rouge as rouge_mod     # noqa
+        from pycocoevalcap.cider import cider as cider_mod     # noqa
+        fake = json.load(open(os.path.join(REF, 'common/coco_caption/results/captions_val2014_fakecap_results.json')))
+        caps = [d['caption'] for d in fake]
+        rnd = random.Random(99)
+        n_img = 80
+        gts = {i: caps[i * 5:(i + 1) * 5] for i in range(n_img)}
+        res = {}
+        for i in range(n_img):
+            w = rnd.choice(gts[i]).split() if rnd.random() < 0.8 else rnd.choice(caps[500:]).split()
+            op = rnd.randrange(5)
+            if op == 0 and len(w) > 2:
+                del w[rnd.randrange(len(w))]
+            elif op == 1:
+                w.insert(rnd.randrange(len(w) + 1), rnd.choice(['a', 'the', 'zebra']))
+            elif op == 2:
+                rnd.shuffle(w)
+            elif op == 3:
+                w = w[:max(1, len(w) // 2)]
+            res[i] = [' '.join(w)]
+        res[0] = [gts[0][0]]            # exact copy of a reference
+        res[1] = ['dog']                # single word
+        res[2] = ['xyzzy plugh']        # nothing in common
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            b_mean, b_scores = bleu_mod.Bleu(4).compute_score(gts, res)
+        r_mean, r_scores = rouge_mod.Rouge().compute_score(gts, res)
+        c_mean, c_scores = cider_mod.Cider().compute_score(gts, res)
+        golden = dict(note='generated by oracle/make_golden.py from the reference pycocoevalcap (bleu, rouge, cider)',
+                      gts={str(k): v for k, v in gts.items()}, res={str(k): v for k, v in res.items()},
+                      bleu=dict(mean=[float(x) for x in b_mean], scores=[[float(x) for x in row] for row in b_scores]),
+                      rouge=dict(mean=float(r_mean), scores=[float(x) for x in r_scores]),
+                      cider=dict(mean=float(c_mean), scores=[float(x) for x in c_scores]))
+        with open(os.path.join(OUT, 'cocoeval_golden.json'), 'w') as f:
+            json.dump(golden, f)
+        print('cocoeval_golden.json: %d images, Bleu_4 %.4f ROUGE_L %.4f CIDEr %.4f' % (n_img, b_mean[3], r_mean, c_mean))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def make_text_golden():
     ns = {'np': np}
     extract(os.path.join(REF, 'common/ops.py'), ['number_to_base'], ns)
@@ -248,5 +303,9 @@ def make_text_golden():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cocoeval':      # only the corpus-level scorer fixture
+        make_cocoeval_golden()
+        sys.exit(0)
     make_text_golden()
     make_scorer_golden()
+    make_cocoeval_golden()

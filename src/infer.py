@@ -73,7 +73,17 @@ def main(argv=None):
     for ckpt_num in c.infer_checkpoints:
         path = pjoin(c.infer_checkpoints_dir, ckpt_prefix + ckpt_num)
         path = path + '.npz' if os.path.isfile(path + '.npz') else path       # else: TF bundle prefix
-        infer.evaluate_model(config=c, curr_ckpt_path=path, scores_combined=scores_combined)
+        # metric scores: the native BLEU / ROUGE-L / CIDEr scorers when the annotation file is there (the reference
+        # shells out to the Java COCO toolkit for METEOR / SPICE / PTB tokenisation as well, infer_fn.py:295-315)
+        ann = c.annotations_file if os.path.isabs(c.annotations_file) else pjoin(c.dataset_dir, 'captions', c.annotations_file)
+        evaluator = None
+        if c.get_metric_score and os.path.isfile(ann):
+            from comic_amd import coco_eval
+            c.annotations_file = ann
+            evaluator = coco_eval.evaluate_captions
+        elif c.get_metric_score:
+            print('INFO: annotation file `{}` not found: captions are written, metric scores skipped.'.format(ann))
+        infer.evaluate_model(config=c, curr_ckpt_path=path, scores_combined=scores_combined, evaluate_captions=evaluator)
         print('\n')
 
 

@@ -201,6 +201,34 @@ def test_loader_prefetch_and_deterministic_augmentation(tmp_path):
         np.testing.assert_array_equal(ca, cb)
 
 
+def test_native_coco_metrics_match_reference_goldens(golden_dir, tmp_path):
+    """Corpus BLEU-1..4, ROUGE-L and CIDEr (comic_amd.coco_eval) against the reference's pycocoevalcap scorers on
+    the committed fixture (oracle/make_golden.py cocoeval), and the file-level entry point of infer.py."""
+    from comic_amd import coco_eval
+    g = _golden(golden_dir, 'cocoeval_golden.json')
+    keys = sorted(g['gts'], key=int)
+    gts = {k: g['gts'][k] for k in keys}
+    res = {k: g['res'][k] for k in keys}
+    b_mean, b_scores = coco_eval.Bleu(4).compute_score(gts, res)
+    np.testing.assert_allclose(b_mean, g['bleu']['mean'], rtol=1e-12)
+    np.testing.assert_allclose(b_scores, g['bleu']['scores'], rtol=1e-12)
+    r_mean, r_scores = coco_eval.Rouge().compute_score(gts, res)
+    np.testing.assert_allclose(r_mean, g['rouge']['mean'], rtol=1e-12)
+    np.testing.assert_allclose(r_scores, g['rouge']['scores'], rtol=1e-12)
+    c_mean, c_scores = coco_eval.Cider().compute_score(gts, res)
+    np.testing.assert_allclose(c_mean, g['cider']['mean'], rtol=1e-12)
+    np.testing.assert_allclose(c_scores, g['cider']['scores'], rtol=1e-12, atol=1e-15)
+    # tokenizer stand-in: lower case, punctuation dropped, clitics kept with their word
+    assert coco_eval.tokenize("A man, riding a horse -- it's BIG!") == "a man riding a horse it's big"
+    ann = dict(annotations=[dict(image_id=int(k), caption=c.capitalize() + ' .') for k in keys for c in gts[k]])
+    results = [dict(image_id=int(k), caption=res[k][0]) for k in keys]
+    fa, fr = tmp_path / 'ann.json', tmp_path / 'res.json'
+    fa.write_text(json.dumps(ann)); fr.write_text(json.dumps(results))
+    out = coco_eval.evaluate_captions(str(fa), str(fr))
+    assert abs(out['Bleu_4'] - g['bleu']['mean'][3]) < 1e-12 and abs(out['CIDEr'] - g['cider']['mean']) < 1e-12
+    assert abs(out['ROUGE_L'] - g['rouge']['mean']) < 1e-12
+
+
 def test_tf1_bilinear_resize_matches_definition():
     from comic_amd.inputs import resize_bilinear_tf1
     img = np.arange(2 * 3 * 1, dtype=np.float32).reshape(2, 3, 1)
