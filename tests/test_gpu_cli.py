@@ -43,13 +43,17 @@ def test_train_infer_scst_cli(tmp_path):
     # ---- inference ----
     _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
                                                  '--infer_set', 'test', '--batch_size_infer', '4',
-                                                 '--get_metric_score', ''])
+                                                 '--annotations_file', 'captions_test_annotations.json'])
     out_dir = os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0')
     caps = glob.glob(os.path.join(out_dir, 'captions___*.json'))
     assert caps
     data = json.load(open(caps[0]))
     assert len(data) == 4 and all(set(d) == {'image_id', 'caption'} for d in data)
     assert os.path.isfile(os.path.join(out_dir, 'infer_speed.txt'))
+    # native metric scores (BLEU-1..4, ROUGE-L, CIDEr) in the reference's report files
+    scores = open(os.path.join(out_dir, 'metric_scores.txt')).read()
+    assert all(m in scores for m in ('Bleu_1', 'Bleu_4', 'ROUGE_L', 'CIDEr')) and 'METEOR' not in scores
+    assert len(open(os.path.join(out_dir, 'metric_scores.csv')).read().strip().split(',')) == 7
     # ---- CNN fine-tune: restores the decoder run, trains CNN + decoder, saves both ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '8',
                                                           '--max_epoch', '1', '--checkpoint_format', 'tf'])

@@ -29,6 +29,7 @@ def make(root, n_train=16, n_valid=4, n_test=4, seed=0, pattern='mscoco_{}_w5_s2
         n = int(rng.integers(4, 9))
         return ' '.join(rng.choice(words, n))
     refs_all = []
+    annotations = []          # COCO-style annotation file of the test split (for the native metric scores)
     for split, n_img in (('train', n_train), ('valid', n_valid), ('test', n_test)):
         lines, names = [], []
         for i in range(n_img):
@@ -41,11 +42,15 @@ def make(root, n_train=16, n_valid=4, n_test=4, seed=0, pattern='mscoco_{}_w5_s2
                 refs_all.append(caps)
             for cpt in caps:
                 lines.append('%s,<GO> %s <EOS>' % (rel, cpt))
+            if split == 'test':
+                annotations += [dict(image_id=i + 1, caption=c_) for c_ in caps + [caption()]]
         with open(os.path.join(root, 'captions', pattern.format(split) + '.txt'), 'w', newline='') as f:
             f.write('\r\n'.join(lines))
         if split != 'train':
             with open(os.path.join(root, 'captions', 'filenames_%s.txt' % split), 'w') as f:
                 f.write('\n'.join(names))
+    with open(os.path.join(root, 'captions', 'captions_test_annotations.json'), 'w') as f:
+        json.dump(dict(annotations=annotations), f)
     df = scorer_ref.build_df_from_refs(refs_all)
     with open(os.path.join(root, 'captions', pattern.format('scst-words') + '.p'), 'wb') as f:
         pickle.dump({'document_frequency': dict(df['document_frequency']), 'ref_len': df['ref_len']}, f, 2)
