@@ -35,6 +35,33 @@ __device__ __forceinline__ ValIdx block_argmax(float v, int i, ValIdx* sh) {
   return r;
 }
 
+// 256-thread argmax with ONE barrier per call: wave-level butterfly, the four wave winners through LDS slots that
+// alternate with `parity` (so a call needs no trailing barrier before the next one reuses the other slots).
+__device__ __forceinline__ ValIdx block_argmax_1b(float v, int i, ValIdx* sh8, int parity) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (better(ov, oi, v, i)) {
+      v = ov;
+      i = oi;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sh8[parity * 4 + wave].v = v;
+    sh8[parity * 4 + wave].i = i;
+  }
+  __syncthreads();
+  ValIdx r = sh8[parity * 4];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const ValIdx o = sh8[parity * 4 + w];
+    if (better(o.v, o.i, r.v, r.i)) r = o;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
                                                           int V) {
   __shared__ ValIdx sh[256];
@@ -172,6 +199,7 @@ __global__ __launch_bounds__(256) void beam_stats_kernel(const float* __restrict
   }
 }
 
+template <int KLOCAL>
 __global__ __launch_bounds__(256) void beam_chunk_topk_kernel(const float* __restrict__ logits,
                                                               const float* __restrict__ log_probs,
                                                               const int32_t* __restrict__ finished,
@@ -184,21 +212,79 @@ __global__ __launch_bounds__(256) void beam_chunk_topk_kernel(const float* __res
   __shared__ int s_fin[64], s_sel[64];
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* lg = logits + (size_t)b * W * V;
-  for (int w = tid; w < W; w += 256) {
-    const float* pm = pmax + ((size_t)b * W + w) * chunks;
-    const float* ps = psum + ((size_t)b * W + w) * chunks;
-    float mx = -INFINITY;
-    for (int k = 0; k < chunks; ++k) mx = fmaxf(mx, pm[k]);
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += ps[k] * expf(pm[k] - mx);
-    s_max[w] = mx;
-    s_logsum[w] = logf(s);
-    s_lp[w] = log_probs[b * W + w];
-    s_fin[w] = finished[b * W + w];
+  // log-softmax constants of every beam from the per-chunk partials: one wave per beam, one lane per chunk
+  // (chunks <= 32), partials combined in chunk order by lane 0 so that every workgroup of the entry gets the same bits
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int w = wave; w < W; w += 4) {
+      const float pm = lane < chunks ? pmax[((size_t)b * W + w) * chunks + lane] : -INFINITY;
+      const float ps = lane < chunks ? psum[((size_t)b * W + w) * chunks + lane] : 0.f;
+      const float mx = wave_max(pm);
+      const float term = lane < chunks ? ps * expf(pm - mx) : 0.f;
+      float s = 0.f;
+      for (int k = 0; k < chunks; ++k) s += __shfl(term, k, 64);      // fixed order: chunk 0, 1, ...
+      if (lane == 0) {
+        s_max[w] = mx;
+        s_logsum[w] = logf(s);
+        s_lp[w] = log_probs[b * W + w];
+        s_fin[w] = finished[b * W + w];
+      }
+    }
   }
   __syncthreads();
   const int per = (V + chunks - 1) / chunks, v0 = c * per, v1 = min(V, v0 + per), nv = max(0, v1 - v0);
   const int total = W * nv;
+  // Fast path: a thread's share of the W * nv candidates (column v0 + tid + 256*k of every beam) fits in registers.
+  // ONE pass over the logits with all loads in flight together, then W selection rounds on the register copy
+  // (the rescanning form below pays an L2 round trip per element and round: 31 -> 9 us at W = 3, V = 25 599).
+  constexpr int kLocal = KLOCAL > 0 ? KLOCAL : 1;   // capacity chosen by the launcher (16 / 40; 0 = rescanning form)
+  const int kper = (nv + 255) >> 8;                 // columns per thread and beam
+  if (KLOCAL > 0 && W * kper <= kLocal) {
+    __shared__ ValIdx sh8[8];
+    float tv[kLocal];
+    int ti[kLocal];
+#pragma unroll
+    for (int e = 0; e < kLocal; ++e) {
+      tv[e] = -INFINITY;
+      ti[e] = 0x7fffffff;
+    }
+    int w = 0, k = 0;                               // (beam, column slot) of register slot e: scalar counters
+#pragma unroll
+    for (int e = 0; e < kLocal; ++e) {
+      const int v = v0 + tid + 256 * k;
+      if (w < W && v < v1) {
+        const int f = w * V + v;
+        const float x = lg[f];
+        const float step = s_fin[w] ? ((v == end_id) ? 0.f : -FLT_MAX) : (x - s_max[w]) - s_logsum[w];
+        tv[e] = s_lp[w] + step;
+        ti[e] = f;
+      }
+      if (++k == kper) {
+        k = 0;
+        ++w;
+      }
+    }
+    for (int r = 0; r < W; ++r) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < kLocal; ++e)
+        if (ti[e] != 0x7fffffff && better(tv[e], ti[e], bv, bi)) {
+          bv = tv[e];
+          bi = ti[e];
+        }
+      const ValIdx best = block_argmax_1b(bv, bi, sh8, r & 1);
+#pragma unroll
+      for (int e = 0; e < kLocal; ++e)
+        if (ti[e] == best.i) ti[e] = 0x7fffffff;    // taken (flat indices are unique; 0x7fffffff marks "none")
+      if (tid == 0) {
+        const size_t o = ((size_t)b * chunks + c) * W + r;
+        cand_v[o] = best.v;
+        cand_i[o] = best.i;
+      }
+    }
+    return;
+  }
   for (int r = 0; r < W; ++r) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -369,9 +455,17 @@ int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished,
   float* cand_v = psum + (size_t)B * W * chunks;
   int32_t* cand_i = (int32_t*)(cand_v + (size_t)B * chunks * W);
   hipLaunchKernelGGL(beam_stats_kernel, dim3(chunks, W, B), dim3(256), 0, st, logits, pmax, psum, W, V, chunks);
-  hipLaunchKernelGGL(beam_chunk_topk_kernel, dim3(chunks, B), dim3(256), 0, st, logits, (const float*)log_probs,
-                     (const int32_t*)finished, (const float*)pmax, (const float*)psum, cand_v, cand_i, W, V, chunks,
-                     end_id);
+  {
+    const int per = (V + chunks - 1) / chunks, kper = (per + 255) / 256;
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(chunks, B), dim3(256), 0, st, logits, (const float*)log_probs,
+                         (const int32_t*)finished, (const float*)pmax, (const float*)psum, cand_v, cand_i, W, V, chunks,
+                         end_id);
+    };
+    if (W * kper <= 16) launch(beam_chunk_topk_kernel<16>);
+    else if (W * kper <= 40) launch(beam_chunk_topk_kernel<40>);
+    else launch(beam_chunk_topk_kernel<0>);
+  }
   hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, st, (const float*)cand_v, (const int32_t*)cand_i,
                      log_probs, finished, lengths, word_ids, parent_ids, scores, W, V, chunks, end_id);
   COMIC_LAUNCH_CHECK("beam_step (split)");

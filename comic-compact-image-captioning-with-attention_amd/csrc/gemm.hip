@@ -292,31 +292,38 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  float4 ar[ACH], br[BCH];
+  // Register staging TWO k-tiles deep: tile t travels in register set t & 1; at the top of iteration kt the load of
+  // tile kt+2 is issued into the set tile kt has just left, so a global load has two compute phases to land (one
+  // phase left the skinny products -- e.g. the per-step 150 x 512 x 25 599 logits of beam search -- waiting on HBM).
+  float4 ar[2][ACH], br[2][BCH];
   const int kbeg = a.k_per_slice > 0 ? blockIdx.z * a.k_per_slice : 0;
   const int kend = a.k_per_slice > 0 ? min(a.K, kbeg + a.k_per_slice) : a.K;
   const int nk = (kend - kbeg + BKx - 1) / BKx;
-  x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg, kend, tid, a_vec, ar);
-  x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg, kend, tid, b_vec, br);
-  x3_store_tile<BM, A_KC, ACH>(Ah, Al, tid, ar);
-  x3_store_tile<BN, B_KC, BCH>(Bh, Bl, tid, br);
+  x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg, kend, tid, a_vec, ar[0]);
+  x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg, kend, tid, b_vec, br[0]);
+  if (nk > 1) {
+    x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + BKx, kend, tid, a_vec, ar[1]);
+    x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + BKx, kend, tid, b_vec, br[1]);
+  }
+  x3_store_tile<BM, A_KC, ACH>(Ah, Al, tid, ar[0]);
+  x3_store_tile<BN, B_KC, BCH>(Bh, Bl, tid, br[0]);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + (kt + 1) * BKx, kend, tid, a_vec, ar);
-      x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + (kt + 1) * BKx, kend, tid, b_vec, br);
+  auto step = [&](const int kt, auto par) {
+    constexpr int P = decltype(par)::value;          // kt & 1: LDS buffer of tile kt, register set of tile kt + 2
+    if (kt + 2 < nk) {
+      x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + (kt + 2) * BKx, kend, tid, a_vec, ar[P]);
+      x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + (kt + 2) * BKx, kend, tid, b_vec, br[P]);
     }
     bf16x8_t bh[TN], bl[TN], ah[TM], al[TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      bh[i] = x3_frag<BN, B_KC>(Bh + buf * BBYTES, wn * (BN / 2) + i * 16, lane);
-      bl[i] = x3_frag<BN, B_KC>(Bl + buf * BBYTES, wn * (BN / 2) + i * 16, lane);
+      bh[i] = x3_frag<BN, B_KC>(Bh + P * BBYTES, wn * (BN / 2) + i * 16, lane);
+      bl[i] = x3_frag<BN, B_KC>(Bl + P * BBYTES, wn * (BN / 2) + i * 16, lane);
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      ah[j] = x3_frag<BM, A_KC>(Ah + buf * ABYTES, wm * (BM / 2) + j * 16, lane);
-      al[j] = x3_frag<BM, A_KC>(Al + buf * ABYTES, wm * (BM / 2) + j * 16, lane);
+      ah[j] = x3_frag<BM, A_KC>(Ah + P * ABYTES, wm * (BM / 2) + j * 16, lane);
+      al[j] = x3_frag<BM, A_KC>(Al + P * ABYTES, wm * (BM / 2) + j * 16, lane);
     }
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -326,11 +333,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
       }
-    if (kt + 1 < nk) {
-      x3_store_tile<BM, A_KC, ACH>(Ah + (buf ^ 1) * ABYTES, Al + (buf ^ 1) * ABYTES, tid, ar);
-      x3_store_tile<BN, B_KC, BCH>(Bh + (buf ^ 1) * BBYTES, Bl + (buf ^ 1) * BBYTES, tid, br);
+    if (kt + 1 < nk) {      // tile kt + 1 (register set P ^ 1, loaded one iteration ago) -> the other LDS buffer
+      x3_store_tile<BM, A_KC, ACH>(Ah + (P ^ 1) * ABYTES, Al + (P ^ 1) * ABYTES, tid, ar[P ^ 1]);
+      x3_store_tile<BN, B_KC, BCH>(Bh + (P ^ 1) * BBYTES, Bl + (P ^ 1) * BBYTES, tid, br[P ^ 1]);
     }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, std::integral_constant<int, 0>());
+    if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>());
   }
 
   // epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15)
