@@ -696,7 +696,12 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
     a.slab = (float*)ws;
     S = cdiv(K, a.k_per_slice);
   }
-  int rc = big ? launch_x3<128>(a, trans_a, trans_b, st) : launch_x3<64>(a, trans_a, trans_b, st);
+  // decode-step shapes (beam rows x hidden x vocabulary): a tile as tall as ALL rows streams the big operand once
+  const bool tall = S == 1 && M > 128 && M <= 192 && cdiv(N, 128) >= 64;
+  int rc;
+  if (tall && M <= 160) rc = launch_x3<160>(a, trans_a, trans_b, st);
+  else if (tall) rc = launch_x3<192>(a, trans_a, trans_b, st);
+  else rc = big ? launch_x3<128>(a, trans_a, trans_b, st) : launch_x3<64>(a, trans_a, trans_b, st);
   if (rc) return rc;
   if (S > 1) {
     const long total = (long)M * N;

@@ -44,7 +44,9 @@ def test_gemm_f32(M, N, K, ta, tb):
 
 @pytest.mark.parametrize('M,N,K,ta,tb', [
     (1600, 512, 2048, 0, 0), (1856, 258, 512, 0, 0), (1856, 512, 258, 0, 1), (1280, 2048, 1856, 1, 0),
-    (512, 258, 1856, 1, 0), (2048, 512, 1600, 1, 0), (33, 70, 19, 1, 1), (130, 131, 45, 0, 1), (257, 129, 64, 0, 0)])
+    (512, 258, 1856, 1, 0), (2048, 512, 1600, 1, 0), (33, 70, 19, 1, 1), (130, 131, 45, 0, 1), (257, 129, 64, 0, 0),
+    # decode-step shapes: all rows in one 160- / 192-row tile over a wide (unaligned / aligned) vocabulary
+    (150, 8195, 512, 0, 0), (150, 8196, 96, 0, 1), (190, 8200, 100, 0, 0), (161, 8300, 64, 1, 0)])
 def test_gemm_f32_split3(M, N, K, ta, tb):
     """bf16 hi/lo split products (hi*hi + hi*lo + lo*hi, fp32 accumulate): every layout, ragged tiles,
     alpha/beta/bias and a strided C; error bound 5e-5 of the result's max-norm (measured ~2e-6)."""
