@@ -269,9 +269,9 @@ __device__ __forceinline__ bf16x8_t x3_frag(const unsigned char* base, int row16
   }
 }
 
-template <int BM, bool A_KC, bool B_KC>
+template <int BM, bool A_KC, bool B_KC, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
-  constexpr int BN = 128, BKx = 32;
+  constexpr int BKx = 32;
   constexpr int TM = BM / 32, TN = BN / 32;               // 16x16 tiles per wave (2 x 2 waves)
   constexpr int ACH = BM * BKx / 4 / 256, BCH = BN * BKx / 4 / 256;   // float4 chunks per thread
   constexpr int ABYTES = X3Tile<BM, A_KC>::BYTES, BBYTES = X3Tile<BN, B_KC>::BYTES;
@@ -379,23 +379,23 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   }
 }
 
-template <int BM>
+template <int BM, int BN = 128>
 int launch_x3(const GemmArgs& a, int ta, int tb, hipStream_t st) {
-  dim3 grid(cdiv(a.M, BM), cdiv(a.N, 128), a.k_per_slice > 0 ? cdiv(a.K, a.k_per_slice) : 1);
+  dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), a.k_per_slice > 0 ? cdiv(a.K, a.k_per_slice) : 1);
   const bool a_kc = (ta == 0), b_kc = (tb == 1);
 #define COMIC_X3(AK, BK_)                                                                                              \
   do {                                                                                                                 \
-    constexpr int lds = 4 * (X3Tile<BM, AK>::BYTES + X3Tile<128, BK_>::BYTES);                                         \
+    constexpr int lds = 4 * (X3Tile<BM, AK>::BYTES + X3Tile<BN, BK_>::BYTES);                                          \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, AK, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+      if (hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<BM, AK, BK_, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               lds) != hipSuccess) {                                                                    \
         comic_set_error("gemm_bf16x3: cannot reserve %d bytes of LDS", lds);                                           \
         return 1;                                                                                                      \
       }                                                                                                                \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, AK, BK_>), grid, dim3(256), lds, st, a);                                \
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, AK, BK_, BN>), grid, dim3(256), lds, st, a);                                \
   } while (0)
   if (a_kc && b_kc) COMIC_X3(true, true);
   else if (a_kc && !b_kc) COMIC_X3(true, false);
@@ -699,8 +699,10 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
   // decode-step shapes (beam rows x hidden x vocabulary): a tile as tall as ALL rows streams the big operand once
   const bool tall = S == 1 && M > 128 && M <= 192 && cdiv(N, 128) >= 64;
   int rc;
-  if (tall && M <= 160) rc = launch_x3<160>(a, trans_a, trans_b, st);
-  else if (tall) rc = launch_x3<192>(a, trans_a, trans_b, st);
+  // ... in 64-column tiles: twice the workgroups (two per CU) hide each other's load latency (PMC: a wave of the
+  // 128-column form spent half its life in s_waitcnt at one wave per SIMD)
+  if (tall && M <= 160) rc = launch_x3<160, 64>(a, trans_a, trans_b, st);
+  else if (tall) rc = launch_x3<192, 64>(a, trans_a, trans_b, st);
   else rc = big ? launch_x3<128>(a, trans_a, trans_b, st) : launch_x3<64>(a, trans_a, trans_b, st);
   if (rc) return rc;
   if (S > 1) {
