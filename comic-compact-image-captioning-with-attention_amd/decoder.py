@@ -396,7 +396,7 @@ class Decoder:
             on_inputs_consumed()
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self._train_device(ctx)
             ctx.graph = g
         if use_graph and ctx.graph is not None:
@@ -459,7 +459,7 @@ class Decoder:
         torch = self.torch
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 launch()
             ctx.graph = g
         if use_graph and ctx.graph is not None:

@@ -699,7 +699,9 @@ class CnnEncoder:
             inp.copy_(images)
         if use_graph and self._graph is None and self._calls >= 1:
             g = self.torch.cuda.CUDAGraph()
-            with self.torch.cuda.graph(g):
+            # thread_local: the input pipeline's prefetch thread allocates, copies and launches on this device
+            # meanwhile; only the capturing thread is held to the capture rules
+            with self.torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self._run()
             self._graph = g
         if use_graph and self._graph is not None:
