@@ -342,6 +342,24 @@ def test_dropout_mask_and_apply():
     np.testing.assert_array_equal(y.cpu().numpy(), (x.cpu().numpy() / np.float32(0.65)) * mm)
 
 
+def test_dropout_masks4_equals_four_calls():
+    """comic_dropout_masks4_dev (the four masks of a training step in one launch, keep probability per segment) gives
+    the bits of four comic_dropout_mask calls with cumulative counter offsets."""
+    n4 = [1000, 70001, 33333, 257]
+    keep4 = [0.65, 0.65, 0.5, 0.9]
+    seed = 0x9E3779B9 + 5
+    buf = torch.empty(sum(n4), device=DEV)
+    seed_dev = torch.tensor([seed], dtype=torch.int64, device=DEV)
+    L.check(lib().comic_dropout_masks4_dev(buf.data_ptr(), (C.c_int64 * 4)(*n4), (C.c_float * 4)(*keep4),
+                                           seed_dev.data_ptr(), stream()))
+    off = 0
+    for n, keep in zip(n4, keep4):
+        m = torch.empty(n, device=DEV)
+        L.check(lib().comic_dropout_mask(m.data_ptr(), n, keep, seed, off, stream()))
+        assert torch.equal(m, buf[off:off + n]), (n, keep)
+        off += n
+
+
 def test_lstm_gates_fwd_bwd():
     rng = np.random.default_rng(3)
     B, D = 6, 128
