@@ -21,7 +21,9 @@
 
 #include "../../include/comic_hip.h"
 
+#include "common.h"
 static thread_local char g_err[512] = "";
+thread_local ComicStop g_comic_stop;
 
 void comic_set_error(const char* fmt, ...) {
   va_list ap;

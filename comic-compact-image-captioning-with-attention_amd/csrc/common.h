@@ -12,6 +12,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 void comic_set_error(const char* fmt, ...);
 
+// Decode loops (beam search): `steps_executed` in device memory becomes t0 + 1 at the first step t0 after which every
+// beam is finished.  The executor publishes (pointer, t) here for the launches of step t, the launch helpers copy it
+// into their kernel arguments, and the per-step kernels return at once when the loop has already ended
+// (`comic_stopped`): the remaining steps of a fixed-length, graph-replayed loop cost a few microseconds of empty
+// launches instead of full decode steps -- dynamic_decode's early exit without a host round trip.  Null elsewhere.
+struct ComicStop {
+  const int32_t* p = nullptr;
+  int t = 0;
+};
+extern thread_local ComicStop g_comic_stop;
+__device__ __forceinline__ bool comic_stopped(const int32_t* p, int t) { return p && p[0] <= t; }
+
 #define COMIC_LAUNCH_CHECK(name)                                               \
   do {                                                                         \
     hipError_t e__ = hipGetLastError();                                        \

@@ -83,12 +83,14 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logits, float* __restrict__ log_probs,
                                                         int32_t* __restrict__ finished, int64_t* __restrict__ lengths,
                                                         int32_t* __restrict__ word_ids, int32_t* __restrict__ parent_ids,
-                                                        float* __restrict__ scores, int W, int V, int end_id) {
+                                                        float* __restrict__ scores, int W, int V, int end_id,
+                                                        const int32_t* __restrict__ stop, int stop_t) {
   __shared__ ValIdx sh[256];
   __shared__ float s_max[64], s_logsum[64], s_lp[64];
   __shared__ int s_fin[64], s_sel[64];
   __shared__ float s_selv[64];
   __shared__ long long s_len[64];
+  if (comic_stopped(stop, stop_t)) return;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* lg = logits + (size_t)b * W * V;
   for (int w = tid; w < W; w += 256) {
@@ -175,7 +177,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
 //   beam_merge_kernel ..... per entry: top-W of the chunks' candidates + bookkeeping
 // The global top-W under a total order is the top-W of the union of the per-chunk top-W lists.
 __global__ __launch_bounds__(256) void beam_stats_kernel(const float* __restrict__ logits, float* __restrict__ pmax,
-                                                         float* __restrict__ psum, int W, int V, int chunks) {
+                                                         float* __restrict__ psum, int W, int V, int chunks,
+                                                         const int32_t* __restrict__ stop, int stop_t) {
+  if (comic_stopped(stop, stop_t)) return;
   __shared__ float sh[4];
   const int c = blockIdx.x, w = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (V + chunks - 1) / chunks, v0 = c * per, v1 = min(V, v0 + per);
@@ -206,10 +210,11 @@ __global__ __launch_bounds__(256) void beam_chunk_topk_kernel(const float* __res
                                                               const float* __restrict__ pmax,
                                                               const float* __restrict__ psum, float* __restrict__ cand_v,
                                                               int32_t* __restrict__ cand_i, int W, int V, int chunks,
-                                                              int end_id) {
+                                                              int end_id, const int32_t* __restrict__ stop, int stop_t) {
   __shared__ ValIdx sh[256];
   __shared__ float s_max[64], s_logsum[64], s_lp[64];
   __shared__ int s_fin[64], s_sel[64];
+  if (comic_stopped(stop, stop_t)) return;
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const float* lg = logits + (size_t)b * W * V;
   // log-softmax constants of every beam from the per-chunk partials: one wave per beam, one lane per chunk
@@ -320,9 +325,11 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict
                                                          float* __restrict__ log_probs, int32_t* __restrict__ finished,
                                                          int64_t* __restrict__ lengths, int32_t* __restrict__ word_ids,
                                                          int32_t* __restrict__ parent_ids, float* __restrict__ scores,
-                                                         int W, int V, int chunks, int end_id) {
+                                                         int W, int V, int chunks, int end_id,
+                                                         const int32_t* __restrict__ stop, int stop_t) {
   __shared__ ValIdx sh[256];
   __shared__ int s_fin[64], s_sel[64];
+  if (comic_stopped(stop, stop_t)) return;
   __shared__ float s_selv[64];
   __shared__ long long s_len[64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -433,7 +440,7 @@ extern "C" int comic_beam_step(const float* logits, float* log_probs, int32_t* f
   COMIC_REQUIRE(W >= 1 && W <= 64, "beam_step: beam width must be in [1,64] (got %d)", W);
   COMIC_REQUIRE((long)W * V < (1L << 31) && W <= V, "beam_step: beam*V too large or beam > V");
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, log_probs, finished,
-                     lengths, word_ids, parent_ids, scores, W, V, end_id);
+                     lengths, word_ids, parent_ids, scores, W, V, end_id, g_comic_stop.p, g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_step");
   return 0;
 }
@@ -454,20 +461,22 @@ int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished,
   float* psum = pmax + (size_t)B * W * chunks;
   float* cand_v = psum + (size_t)B * W * chunks;
   int32_t* cand_i = (int32_t*)(cand_v + (size_t)B * chunks * W);
-  hipLaunchKernelGGL(beam_stats_kernel, dim3(chunks, W, B), dim3(256), 0, st, logits, pmax, psum, W, V, chunks);
+  hipLaunchKernelGGL(beam_stats_kernel, dim3(chunks, W, B), dim3(256), 0, st, logits, pmax, psum, W, V, chunks,
+                     g_comic_stop.p, g_comic_stop.t);
   {
     const int per = (V + chunks - 1) / chunks, kper = (per + 255) / 256;
     auto launch = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(chunks, B), dim3(256), 0, st, logits, (const float*)log_probs,
                          (const int32_t*)finished, (const float*)pmax, (const float*)psum, cand_v, cand_i, W, V, chunks,
-                         end_id);
+                         end_id, g_comic_stop.p, g_comic_stop.t);
     };
     if (W * kper <= 16) launch(beam_chunk_topk_kernel<16>);
     else if (W * kper <= 40) launch(beam_chunk_topk_kernel<40>);
     else launch(beam_chunk_topk_kernel<0>);
   }
   hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(256), 0, st, (const float*)cand_v, (const int32_t*)cand_i,
-                     log_probs, finished, lengths, word_ids, parent_ids, scores, W, V, chunks, end_id);
+                     log_probs, finished, lengths, word_ids, parent_ids, scores, W, V, chunks, end_id, g_comic_stop.p,
+                     g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_step (split)");
   return 0;
 }

@@ -226,6 +226,8 @@ struct AttnArgs {
   int q_parts;              // > 1: q is [q_parts][B][D] split-K partials; the reduced row goes to q_out
   float* q_out;
   int pgrad_overwrite;      // backward: 1 = store this step's parameter-gradient row instead of adding to it
+  const int32_t* stop;      // decode loops: see comic_stopped (common.h)
+  int stop_t;
 };
 
 template <int EPL>
@@ -307,6 +309,7 @@ constexpr int kAttnThreads = kAttnWaves * 64;
 
 template <int EPL>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int B = a.d.B, M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
   (void)B;
@@ -861,6 +864,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.alpha = alpha; a.alpha_d = alpha_d; a.ctx = ctx;
   a.lens = lens; a.t = t; a.att_prev = att_prev; a.att_next = att_next; a.xh_next = xh_next; a.xh_ld = xh_ld;
   a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in; a.q_parts = q_parts; a.q_out = q_out;
+  a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
   const size_t lds = (size_t)d->H * d->M * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);

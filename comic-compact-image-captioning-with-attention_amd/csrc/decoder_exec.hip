@@ -143,12 +143,15 @@ __global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_
 __global__ void infer_prep_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
                                   const int32_t* __restrict__ parent, int W, const float* __restrict__ att,
                                   const float* __restrict__ h, const float* __restrict__ c, float* __restrict__ xh,
-                                  float* __restrict__ c_in, int R, int E, int A, int D, int V) {
+                                  float* __restrict__ c_in, int R, int E, int A, int D, int V,
+                                  const int32_t* __restrict__ stop, int stop_t) {
+  // after the loop has ended the previous step's ids / parents were never written: nothing to gather
+  if (comic_stopped(stop, stop_t)) return;
   const int Wd = E + A + D, cols = Wd + D;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)R * cols) return;
   const int r = (int)(i / cols), k = (int)(i % cols);
-  const int src = parent ? (r / W) * W + parent[r] : r;
+  const int src = parent ? (r / W) * W + min(max(parent[r], 0), W - 1) : r;
   if (k < E) {
     const int id = ids[r];
     xh[(size_t)r * Wd + k] = (id >= 0 && id < V) ? table[(size_t)id * E + k] : 0.f;
@@ -487,7 +490,7 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
   {
     const long n = (long)rows * (Wd + D);
     hipLaunchKernelGGL(infer_prep_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, ids, parent, W,
-                       att_src, h_src, c_src, sb.xh, c_in, rows, E, A, D, d->V);
+                       att_src, h_src, c_src, sb.xh, c_in, rows, E, A, D, d->V, g_comic_stop.p, g_comic_stop.t);
     COMIC_LAUNCH_CHECK("infer_prep");
   }
   RC(comic_lstm_step_fused(sb.xh, Wd, kpanel, p->b, c_in, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0,
@@ -961,7 +964,17 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   int ld_wo = V;
   const float* w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
   int cur = 0;
+  struct StopScope {          // whatever way this call returns, no later launch sees the flag
+    ~StopScope() { g_comic_stop = ComicStop(); }
+  } stop_scope;
   for (int t = 0; t < max_steps; ++t) {
+    // the launches of step t return at once when the loop ended at an earlier step (see common.h, ComicStop);
+    // fused path only: every kernel of its step honours the flag (the unfused path's gathers index through
+    // the parents of the step before, which a skipped step leaves unwritten)
+    if (fused) {
+      g_comic_stop.p = steps_executed;
+      g_comic_stop.t = t;
+    }
     int32_t* word = step_ids + (size_t)t * R;
     int32_t* parent = parent_ids + (size_t)t * R;
     const int nxt = cur ^ 1;

@@ -73,11 +73,14 @@ struct LstmStepArgs {
   float* xh_next;    // recurrent part of the next step's operand rows, or NULL
   int xh_ld;
   int B, D, Wd;
+  const int32_t* stop = nullptr;   // decode loops: see comic_stopped (common.h)
+  int stop_t = 0;
 };
 
 // grid (D/4, ceil(B/(16*MT))): a workgroup owns 4 hidden units (16 gate columns) of 16*MT batch rows.
 template <int MT>
 __global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_kernel(LstmStepArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
   __shared__ float4 red[kFusedWaves - 1][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_kernel(LstmStep
 // cross-wave combine, wave j runs the epilogue of unit tile j.
 template <int NT>
 __global__ __launch_bounds__(kFusedThreads) void lstm_step_fused_wide_kernel(LstmStepArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
   static_assert(NT >= 2 && NT <= kFusedWaves, "unit tiles per workgroup");
   __shared__ float4 red[kFusedWaves][NT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -605,6 +609,8 @@ int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const floa
                 "lstm_step_fused: D, Wd and the operand stride must be multiples of 4 (16-byte rows)");
   LstmStepArgs a{xh, ld_xh, K, bias, c_prev, h_prev, gates_act, c_new, y, mask_out, keep_out, lens, t,
                  c_state, h_state, xh_next, xh_ld, B, D, Wd};
+  a.stop = g_comic_stop.p;
+  a.stop_t = g_comic_stop.t;
   // rows per workgroup: 16 keeps the most workgroups in flight and measured fastest at 64 rows (training)
   // and at 150-224 rows (beam search); 32 / 64 stay selectable for experiments
   static int mt_env = -1;

@@ -26,6 +26,8 @@ struct GemmArgs {
   float alpha, beta;
   int k_per_slice = 0;   // bf16x3 kernel: > 0 = blockIdx.z owns k in [z*k_per_slice, ...) and writes a raw
   float* slab = nullptr; //   partial tile to slab[z][M][N] (combined by splitk_reduce_kernel)
+  const int32_t* stop = nullptr;   // decode loops: see comic_stopped (common.h)
+  int stop_t = 0;
 };
 
 constexpr int BK = 16;
@@ -271,6 +273,7 @@ __device__ __forceinline__ bf16x8_t x3_frag(const unsigned char* base, int row16
 
 template <int BM, bool A_KC, bool B_KC, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
   constexpr int BKx = 32;
   constexpr int TM = BM / 32, TN = BN / 32;               // 16x16 tiles per wave (2 x 2 waves)
   constexpr int ACH = BM * BKx / 4 / 256, BCH = BN * BKx / 4 / 256;   // float4 chunks per thread
@@ -429,6 +432,8 @@ struct SkinnyArgs {
   float alpha, beta;
   int kb_per_slice;  // k16-blocks per gridDim.y slice
   int direct;        // 1: write alpha*acc + bias + beta*C to C ; 0: write raw partial
+  const int32_t* stop = nullptr;   // decode loops: see comic_stopped (common.h)
+  int stop_t = 0;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ base, long off, int nvalid, bool vec) {
@@ -443,6 +448,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* __restrict__ base, long
 
 template <bool B_KC>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
   constexpr int MT = 4;
   __shared__ __attribute__((aligned(16))) float red[3 * 64 * 16 * MT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -620,6 +626,8 @@ int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, 
   while (S > 1 && (int64_t)S * M * N * 4 > ws_bytes) --S;
   COMIC_REQUIRE((int64_t)S * M * N * 4 <= ws_bytes, "gemm_partial: workspace too small");
   SkinnyArgs a{A, B, (float*)ws, nullptr, M, N, K, lda, ldb, N, 1.f, 0.f, cdiv(KB, S), 0};
+  a.stop = g_comic_stop.p;
+  a.stop_t = g_comic_stop.t;
   S = cdiv(KB, a.kb_per_slice);
   dim3 grid(NB, S, MB);
   if (trans_b)
@@ -682,6 +690,8 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
   COMIC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16x3: bad shape %d %d %d", M, N, K);
   COMIC_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, "gemm_bf16x3: leading dimension too small");
   GemmArgs a{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta};
+  a.stop = g_comic_stop.p;
+  a.stop_t = g_comic_stop.t;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128);
   const bool big = blocks128 >= 200;
   const long tiles = big ? blocks128 : (long)cdiv(M, 64) * cdiv(N, 128);

@@ -439,8 +439,10 @@ class Decoder:
                 ctx.logits = torch.empty((max_steps, B, s.V), **f32) if want_logits else None
                 ctx.first_eos = torch.empty(B, **i32)
             else:
-                ctx.step_ids = torch.empty((max_steps, B, W), **i32)
-                ctx.parent_ids = torch.empty((max_steps, B, W), **i32)
+                # rows past the executed steps are never written (device-side early exit): poison them so a
+                # kernel that indexes through them fails the same way every time
+                ctx.step_ids = torch.full((max_steps, B, W), 0x7f7f7f7f, **i32)
+                ctx.parent_ids = torch.full((max_steps, B, W), 0x7f7f7f7f, **i32)
                 ctx.scores = torch.empty((max_steps, B, W), **f32)
                 ctx.lengths = torch.empty((B, W), dtype=torch.int64, device=self.device)
                 ctx.finished = torch.empty((B, W), **i32)

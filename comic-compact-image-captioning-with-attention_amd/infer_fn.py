@@ -27,6 +27,13 @@ def run_inference(config, curr_ckpt_path, device='cuda:0'):
     ckpt_num = P_CKPT.findall(ckpt_file)[0]
     mdl.reset_default_graph()
     inputs_man = inputs.InputManager(config, is_inference=True)
+    try:
+        return _inference_loop(inputs_man, curr_ckpt_path, ckpt_dir, ckpt_file, ckpt_num, device)
+    finally:
+        inputs_man.close()
+
+
+def _inference_loop(inputs_man, curr_ckpt_path, ckpt_dir, ckpt_file, ckpt_num, device):
     inputs_man.enable_device_preprocess(device)
     c = inputs_man.config
     batch_size = c.batch_size_infer

@@ -49,18 +49,48 @@ class Prefetch(object):
     at the consumer's next() call."""
     _END = object()
 
-    def __init__(self, gen, depth=4):
+    def __init__(self, gen, depth=4, finish=None):
+        # finish(item) -> item runs in the CONSUMER thread at next() (e.g. the device half of the preprocessing:
+        # the producer thread never touches the GPU runtime)
+        self._finish = finish
+        self._closed = False
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._t = threading.Thread(target=self._run, args=(gen,), daemon=True)
         self._t.start()
 
+    def _put(self, entry):
+        while not self._closed:
+            try:
+                self._q.put(entry, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
     def _run(self, gen):
         try:
             for item in gen:
-                self._q.put((item, None))
-            self._q.put((self._END, None))
+                if not self._put((item, None)):
+                    return
+            self._put((self._END, None))
         except BaseException as e:           # noqa: B902 -- handed to the consumer
-            self._q.put((self._END, e))
+            self._put((self._END, e))
+
+    def close(self):
+        """Stops the producer (an endless training generator would otherwise stay parked on a full queue, holding
+        its batches, for the life of the process)."""
+        self._closed = True
+        while True:
+            try:
+                self._q.get_nowait()
+            except queue.Empty:
+                break
+        if self._t is not threading.current_thread():
+            self._t.join(timeout=10.0)
+        try:
+            self._q.put_nowait((self._END, None))
+        except queue.Full:
+            pass
 
     def __iter__(self):
         return self
@@ -72,7 +102,7 @@ class Prefetch(object):
             if err is not None:
                 raise err
             raise StopIteration
-        return item
+        return self._finish(item) if self._finish is not None else item
 
 
 def draw_augmentation(augment, height, width, rng):
@@ -94,36 +124,58 @@ def decode_image(path_or_array):
         return np.asarray(im.convert('RGB'))
 
 
-class DevicePreprocessor(object):
-    """resize / flip / crop / scale of a batch in ONE launch of comic_image_preprocess (csrc/preprocess.hip): the
-    decoded uint8 images go to the device back to back through a pinned staging block (two slots with events: the
-    producer thread may be a batch ahead of the copy engine), the result is a device tensor [n, h, w, 3] fp32 with
-    the bits of `preprocess_image`."""
+class PackedImages(object):
+    """A batch of decoded images packed back to back (+ one comic_image_desc per image) by the producer thread."""
+    __slots__ = ('slot', 'blob', 'desc', 'n', 'total')
 
-    def __init__(self, device, height, width, resize=256):
+    def __init__(self, slot, blob, desc, n, total):
+        self.slot, self.blob, self.desc, self.n, self.total = slot, blob, desc, n, total
+
+
+class DevicePreprocessor(object):
+    """resize / flip / crop / scale of a batch in ONE launch of comic_image_preprocess (csrc/preprocess.hip); the
+    result is a device tensor [n, h, w, 3] fp32 with the bits of `preprocess_image`.
+
+    Two halves, because the GPU runtime is only ever called from the consumer (training) thread -- concurrent
+    allocation / copy / launch calls from a loader thread next to hipGraph captures and replays aborted the process
+    intermittently:
+      pack(images, params)   producer thread, CPU only: the decoded uint8 images back to back + their descriptors
+                             into a pinned staging slot taken from the free list (plain numpy arrays while no slot
+                             is free or large enough)
+      finish(packed)         consumer thread: host-to-device copies + the launch; staging slots come back to the free
+                             list once the event recorded behind their copies has completed (polled here)."""
+
+    def __init__(self, device, height, width, resize=256, slots=8):
         import torch
         from . import _lib as L
         self.torch, self.L, self.lib = torch, L, L.load()
         self.device, self.h, self.w, self.resize = device, int(height), int(width), int(resize)
-        self._slots = [dict(blob=None, desc=None, ev=None) for _ in range(2)]
+        self._max_slots = int(slots)
+        self._n_slots = 0
+        self._free = queue.Queue()
+        self._pending = []                       # (slot, event) in issue order
         self._dev_blob = None
-        self._n = 0
 
-    def __call__(self, images_u8, params):
-        torch, L = self.torch, self.L
+    # ---- producer side (no GPU calls) -------------------------------------------------------------------------
+    def pack(self, images_u8, params):
         import ctypes as C
+        L = self.L
         n = len(images_u8)
         total = sum(int(im.shape[0]) * int(im.shape[1]) * 3 for im in images_u8)
-        slot = self._slots[self._n % 2]
-        self._n += 1
-        if slot['ev'] is not None:
-            slot['ev'].synchronize()
-        if slot['blob'] is None or slot['blob'].numel() < total:
-            slot['blob'] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
-        if slot['desc'] is None or slot['desc'].numel() < n * C.sizeof(L.ImageDesc):
-            slot['desc'] = torch.empty(max(n, 64) * C.sizeof(L.ImageDesc), dtype=torch.uint8).pin_memory()
-        blob = slot['blob'].numpy()
-        desc = (L.ImageDesc * n).from_buffer(slot['desc'].numpy())
+        dbytes = n * C.sizeof(L.ImageDesc)
+        slot = None
+        try:
+            slot = self._free.get_nowait()
+        except queue.Empty:
+            pass
+        if slot is not None and (slot['blob'].numel() < total or slot['desc'].numel() < dbytes):
+            self._free.put(slot)                 # too small for this batch: the consumer will make a larger one
+            slot = None
+        if slot is not None:
+            blob, dbuf = slot['blob'].numpy(), slot['desc'].numpy()
+        else:
+            blob, dbuf = np.empty(total, np.uint8), np.zeros(dbytes, np.uint8)
+        desc = (L.ImageDesc * n).from_buffer(dbuf)
         off = 0
         for i, (im, (flip, oy, ox)) in enumerate(zip(images_u8, params)):
             assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, (im.dtype, im.shape)
@@ -134,19 +186,49 @@ class DevicePreprocessor(object):
             d.offset, d.in_h, d.in_w, d.flip, d.oy, d.ox = off, ih, iw, int(bool(flip)), int(oy), int(ox)
             d.sy, d.sx = np.float32(ih / self.resize), np.float32(iw / self.resize)
             off += nb
+        del desc
+        return PackedImages(slot, blob, dbuf, n, total)
+
+    # ---- consumer side ------------------------------------------------------------------------------------------
+    def _reap(self):
+        while self._pending and self._pending[0][1].query():
+            self._free.put(self._pending.pop(0)[0])
+
+    def finish(self, packed):
+        import ctypes as C
+        torch, L = self.torch, self.L
+        self._reap()
+        n, total = packed.n, packed.total
+        dbytes = n * C.sizeof(L.ImageDesc)
+        slot = packed.slot
+        if slot is None:
+            # no pinned slot was available to the producer: stage through a new (or a larger) one, made here
+            slot = dict(blob=torch.empty(int(total * 1.3) + 4096, dtype=torch.uint8).pin_memory(),
+                        desc=torch.empty(max(dbytes, 64 * C.sizeof(L.ImageDesc)), dtype=torch.uint8).pin_memory())
+            slot['blob'].numpy()[:total] = packed.blob[:total]
+            slot['desc'].numpy()[:dbytes] = packed.desc[:dbytes]
+            recycle = self._n_slots < self._max_slots          # joins the free list once its copy has executed
+            self._n_slots += int(recycle)
+        else:
+            recycle = True
         with torch.cuda.device(self.device):
-            if self._dev_blob is None or self._dev_blob.numel() < slot['blob'].numel():
-                self._dev_blob = torch.empty(slot['blob'].numel(), dtype=torch.uint8, device=self.device)
-            dev_desc = torch.empty(n * C.sizeof(L.ImageDesc), dtype=torch.uint8, device=self.device)
+            if self._dev_blob is None or self._dev_blob.numel() < total:
+                self._dev_blob = torch.empty(int(total * 1.3) + 4096, dtype=torch.uint8, device=self.device)
+            dev_desc = torch.empty(dbytes, dtype=torch.uint8, device=self.device)
             self._dev_blob[:total].copy_(slot['blob'][:total], non_blocking=True)
-            dev_desc.copy_(slot['desc'][:n * C.sizeof(L.ImageDesc)], non_blocking=True)
+            dev_desc.copy_(slot['desc'][:dbytes], non_blocking=True)
             out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
             L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
                                                     self.h, self.w, self.resize, L.stream_ptr()), 'image_preprocess')
-            if slot['ev'] is None:
-                slot['ev'] = torch.cuda.Event()
-            slot['ev'].record(torch.cuda.current_stream())
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        if recycle:
+            self._pending.append((slot, ev))
         return out
+
+    def __call__(self, images_u8, params):
+        """Both halves in the calling thread (tests, single-threaded use)."""
+        return self.finish(self.pack(images_u8, params))
 
 
 def preprocess_image(path_or_array, height, width, augment, rng, params=None):
@@ -170,6 +252,14 @@ class InputManager(object):
         if not (isinstance(s, list) and len(s) == 2 and 0 not in s):
             c.cnn_input_size = [self._default_image_size[c.cnn_name]] * 2
         self._setup(c, is_inference)
+
+    def close(self):
+        """End of a train / eval / inference stage: stop the prefetch threads and the decode pool."""
+        for name in ('batch_train', 'batch_eval', 'batch_infer'):
+            it = getattr(self, name, None)
+            if isinstance(it, Prefetch):
+                it.close()
+        self._pool.shutdown(wait=False)
 
     def _setup(self, config, is_inference):
         config.split_sizes = {}
@@ -255,7 +345,7 @@ class InputManager(object):
                 assert len(data) % batch_size == 0
         augment = is_training and c.cnn_input_augment
         print('INFO: Augment {} images: {}'.format(split, augment))
-        return Prefetch(self._batches(data, batch_size, is_training, augment), self._prefetch_depth)
+        return Prefetch(self._batches(data, batch_size, is_training, augment), self._prefetch_depth, self._finish_batch)
 
     def _gen(self, data, is_training):
         c = self.config
@@ -279,12 +369,19 @@ class InputManager(object):
         h, w = self.config.cnn_input_size
         self._devpre = DevicePreprocessor(device, h, w)
 
+    def _finish_batch(self, item):
+        """Consumer-thread half of a batch: packed images -> device tensor (see DevicePreprocessor)."""
+        ims, rest = item[0], item[1:]
+        if isinstance(ims, PackedImages):
+            ims = self._devpre.finish(ims)
+        return (ims,) + tuple(rest)
+
     def _load_many(self, paths, augment):
         h, w = self.config.cnn_input_size
         params = [draw_augmentation(augment, h, w, self._rng) for _ in paths]
         devpre = getattr(self, '_devpre', None)
-        if devpre is not None:
-            return devpre(list(self._pool.map(decode_image, paths)), params)
+        if devpre is not None:       # CPU half here (producer thread); the device half runs in Prefetch's consumer hook
+            return devpre.pack(list(self._pool.map(decode_image, paths)), params)
         return np.stack(list(self._pool.map(lambda a: self._load(a[0], augment, a[1]), zip(paths, params))))
 
     def _batches(self, data, batch_size, is_training, augment):
@@ -364,7 +461,7 @@ class InputManager_SCST(InputManager_Radix):
         batch_size = c.batch_size_train
         c.max_step = int(len(data) / batch_size * c.max_epoch / getattr(c, 'accum_grads_step', 1))
         augment = is_training and c.cnn_input_augment
-        return Prefetch(self._scst_batches(data, batch_size, augment), self._prefetch_depth)
+        return Prefetch(self._scst_batches(data, batch_size, augment), self._prefetch_depth, self._finish_batch)
 
     def _scst_batches(self, data, batch_size, augment):
         c = self.config

@@ -43,6 +43,13 @@ def train_fn(config, device='cuda:0', dp=None):
     print('INFO: Logging to `{}`.'.format(config.log_path))
     mdl.reset_default_graph()
     inputs_man = _manager(config)
+    try:
+        return _train_loop(inputs_man, device, dp)
+    finally:
+        inputs_man.close()                             # stops the prefetch threads of this stage
+
+
+def _train_loop(inputs_man, device, dp):
     inputs_man.enable_device_preprocess(device)        # host: JPEG decode only
     c = inputs_man.config
     num_batches = int(c.split_sizes['train'] / c.batch_size_train)
@@ -88,7 +95,7 @@ def train_fn(config, device='cuda:0', dp=None):
                 _run_eval_loop(c, m_valid, global_step)
         if (step + 1) % num_batches == 0:
             if getattr(c, 'legacy', False):
-                lr = _lr_reduce_check(config, epoch, lr)
+                lr = _lr_reduce_check(c, epoch, lr)
                 m_train.update_lr(lr)
             t = time.time() - start_epoch
             print('\n\n>>> Epoch {:3d} complete'.format(epoch))
@@ -103,6 +110,13 @@ def train_fn_scst(config, idx_ngram=False, device='cuda:0', dp=None):
     print('INFO: Logging to `{}`.'.format(config.log_path))
     mdl.reset_default_graph()
     inputs_man = inputs.InputManager_SCST(config)
+    try:
+        return _scst_loop(inputs_man, idx_ngram, device, dp)
+    finally:
+        inputs_man.close()
+
+
+def _scst_loop(inputs_man, idx_ngram, device, dp):
     inputs_man.enable_device_preprocess(device)
     c = inputs_man.config
     num_batches = int(c.split_sizes['train'] / c.batch_size_train)

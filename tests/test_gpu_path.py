@@ -459,9 +459,16 @@ def test_greedy_and_beam_match_oracle(kw):
     np.testing.assert_array_equal(ids, g_ids)                                  # bit-exact argmax ids
     assert_close(logits.cpu().numpy(), g_logits, F32_RTOL, 'greedy logits')
     assert_close(amap.cpu().numpy(), g_map, F32_RTOL, 'greedy attention maps')
-    for W in (3, 7):
+    for W, eos_bias in ((3, 1.5), (7, 1.5), (3, 9.0)):
+        if eos_bias != 1.5:
+            # every beam ends within a few steps: the remaining launches of the fixed-length loop return at once
+            # (device-side early exit, common.h ComicStop) and the outputs are those of the executed steps
+            p = dict(p); p['b_o'] = p['b_o'].copy(); p['b_o'][spec.end_id] = eos_bias
+            dec = cdec.Decoder(spec, p, DEV)
         pred, scores, hist, dbg = beam_ref.beam_search_decode(p, cfg, fm, im, W, max_steps, return_debug=True)
         res = dec.beam_search(dev(fm), dev(im), W, max_steps)
+        if eos_bias != 1.5:
+            assert res['step_ids'].shape[0] < max_steps
         np.testing.assert_array_equal(res['step_ids'], dbg['step_ids'])
         np.testing.assert_array_equal(res['parent_ids'], dbg['parent_ids'])
         np.testing.assert_array_equal(res['predicted_ids'], pred)              # bit-exact beam ids
