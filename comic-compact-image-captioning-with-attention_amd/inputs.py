@@ -80,13 +80,13 @@ class Prefetch(object):
         """Stops the producer (an endless training generator would otherwise stay parked on a full queue, holding
         its batches, for the life of the process)."""
         self._closed = True
+        if self._t is not threading.current_thread():
+            self._t.join(timeout=10.0)       # the producer leaves its put() within one poll interval
         while True:
             try:
                 self._q.get_nowait()
             except queue.Empty:
                 break
-        if self._t is not threading.current_thread():
-            self._t.join(timeout=10.0)
         try:
             self._q.put_nowait((self._END, None))
         except queue.Full:

@@ -199,6 +199,12 @@ def test_loader_prefetch_and_deterministic_augmentation(tmp_path):
         (ia, ca), (ib, cb) = next(a.batch_train), next(b.batch_train)
         np.testing.assert_array_equal(ia, ib)
         np.testing.assert_array_equal(ca, cb)
+    # end of a stage: the endless training generators stop instead of staying parked on a full queue
+    threads = [a.batch_train._t, b.batch_train._t]
+    a.close(); b.close()
+    assert not any(t.is_alive() for t in threads)
+    with pytest.raises(StopIteration):
+        next(a.batch_train)
 
 
 def test_native_coco_metrics_match_reference_goldens(golden_dir, tmp_path):
