@@ -22,6 +22,7 @@ BATCH = 64
 IMG = 224
 FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
 PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
+DEFAULT_ENC_GROUP = 5                         # steps per encoder forward in the pipelined frozen-CNN step
 GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
 EVENTS = os.environ.get('COMIC_NO_EVENTS', '0') != '1'
 STEP_TIMES = [] if os.environ.get('COMIC_STEP_TIMES', '0') == '1' else None      # diagnostic: per-step event / host stamps
@@ -154,7 +155,7 @@ def heaviest_conv_launch(enc, plan, reps=20):
     best, bi = 0, None
     for i, o in enumerate(plan.ops):
         if o['kind'] == 0 and not o.get('group'):
-            fl = 2 * BATCH * o['Ho'] * o['Wo'] * o['KH'] * o['KW'] * o['Cin'] * o['Cout']
+            fl = 2 * enc.batch * o['Ho'] * o['Wo'] * o['KH'] * o['KW'] * o['Cin'] * o['Cout']
             if fl > best:
                 best, bi = fl, i
     if bi is None:
@@ -163,7 +164,7 @@ def heaviest_conv_launch(enc, plan, reps=20):
     first = C.byref(enc._ops, bi * C.sizeof(L.CnnOp))
 
     def run():
-        L.check(enc.lib.comic_cnn_forward(first, 1, enc._bufptr, enc._bufch, enc._wt, BATCH, 1, st), 'conv launch')
+        L.check(enc.lib.comic_cnn_forward(first, 1, enc._bufptr, enc._bufch, enc._wt, enc.batch, 1, st), 'conv launch')
     run(); run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -172,7 +173,7 @@ def heaviest_conv_launch(enc, plan, reps=20):
     e1.record(); e1.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     tile = int(enc._ops[bi].tile)
-    return {'layer': '%dx%d %dx%d/%d %d->%d, batch %d' % (o['Ho'], o['Wo'], o['KH'], o['KW'], o['SH'], o['Cin'], o['Cout'], BATCH),
+    return {'layer': '%dx%d %dx%d/%d %d->%d, batch %d' % (o['Ho'], o['Wo'], o['KH'], o['KW'], o['SH'], o['Cin'], o['Cout'], enc.batch),
             'kernel_variant': tile, 'kernel': 'conv_patch_kernel' if tile > 12 or tile == 0 else 'conv_igemm_dma_kernel',
             'flop': best, 'us': round(us, 2), 'achieved': round(best / us / 1e6, 1), 'unit': 'TFLOP/s',
             'frac': round(best / us / 1e6 / (PEAK_BF16_MFMA / 1e12), 4)}
@@ -236,7 +237,12 @@ def main():
                         pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
-    tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan)
+    overlap = os.environ.get('COMIC_OVERLAP', '1') == '1'
+    # frozen CNN: one encoder forward covers the image batches of GROUP consecutive steps (trainer.CaptionTrainer)
+    GROUP = int(os.environ.get('COMIC_ENC_GROUP', str(DEFAULT_ENC_GROUP)))
+    ENC_BATCH = BATCH * GROUP
+    tr = trainer.CaptionTrainer(cnn_params, spec, None, BATCH, (IMG, IMG), 'bf16', device, dp=dp, seed=1, plan=plan,
+                                encoder_group=GROUP)
     if os.environ.get('COMIC_TUNE_POLITE', '0') == '1' and os.environ.get('COMIC_OVERLAP', '1') == '1':
         tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
     if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
@@ -246,7 +252,7 @@ def main():
     if world > 1:
         dist.broadcast(tr.decoder.params.data, 0)
     rng = np.random.default_rng(48964896 + rank)                # train.py:203 seed
-    images = torch.from_numpy(rng.uniform(-1, 1, (BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+    images = torch.from_numpy(rng.uniform(-1, 1, (ENC_BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
     cap_sets = [synth_captions(rng, BATCH) for _ in range(4)]
 
     def barrier():
@@ -261,7 +267,6 @@ def main():
         for j, c in enumerate(cap_sets):
             denoms[j] = dp.global_tokens(float((c[:, 1:] >= 0).sum()), device) / world + 1e-12
     tr.use_graph = GRAPH_CNN and GRAPH_DEC
-    overlap = os.environ.get('COMIC_OVERLAP', '1') == '1'
     if overlap:
         tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
     # the image batch lives in the encoder's input buffer (inputs resident in HBM)
@@ -269,11 +274,12 @@ def main():
     images = tr.encoder.bufs[plan.input]
     for i in range(args.warmup):
         im_embed, fm = tr.encoder.forward(images, use_graph=GRAPH_CNN)
-        tr.decoder.train_step(fm, im_embed, cap_sets[i % 4], training=True, use_graph=GRAPH_DEC)
+        tr.decoder.train_step(fm[:BATCH], im_embed[:BATCH], cap_sets[i % 4], training=True, use_graph=GRAPH_DEC)
         tr.opt.step(tr.decoder.grads, tr.lr())
     if overlap:
-        tr.submit_images(images)          # batch of timed step 0 (its K-th sibling is issued in step K-1)
+        tr.submit_images(images)          # batch(es) of the first timed step(s); the siblings are issued in the loop
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    n_fwd = [0]                           # encoder forwards issued inside the timed region
     # the timed region issues ~500 launches per step from Python: a generation-2 garbage collection in the middle
     # of it stalls the host for tens of milliseconds (measured: one 45 ms stall = +1.3 ms per step at 30 steps)
     import gc
@@ -283,7 +289,20 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         cap = cap_sets[i % 4]
-        if overlap:
+        if overlap and GROUP > 1:
+            # steps are served from groups of GROUP batches: the forward of the NEXT group (GROUP*BATCH images) is
+            # issued on the side stream once the first step of this group holds its rows; K timed steps issue
+            # ceil(K/GROUP) forwards = at least K*BATCH images
+            im_embed, fm, release = tr.take_features()
+
+            def consumed():
+                if release():
+                    tr.submit_images(images, ev[n_fwd[0]] if EVENTS else None)
+                    n_fwd[0] += 1
+            res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denoms[i % 4], use_graph=GRAPH_DEC,
+                                        on_inputs_consumed=consumed)
+        elif overlap:
+            n_fwd[0] += 1
             # step i: decoder(batch i) on the main stream; the encoder forward of batch i+1 is issued on the
             # side stream as soon as the decoder holds its copy of batch i's features.  K timed steps issue
             # K encoder forwards and K decoder steps; HIP events on the side stream bracket the encoder.
@@ -301,9 +320,13 @@ def main():
             res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC,
                                         on_inputs_consumed=consumed)
         else:
-            if EVENTS: ev[i][0].record()
-            im_embed, fm = tr.encoder.forward(images, use_graph=GRAPH_CNN)
-            if EVENTS: ev[i][1].record()
+            j = i % GROUP
+            if j == 0:                      # serial: the forward of this group of steps, then its decoder steps
+                if EVENTS: ev[n_fwd[0]][0].record()
+                feats = tr.encoder.forward(images, use_graph=GRAPH_CNN)
+                if EVENTS: ev[n_fwd[0]][1].record()
+                n_fwd[0] += 1
+            im_embed, fm = feats[0][j * BATCH:(j + 1) * BATCH], feats[1][j * BATCH:(j + 1) * BATCH]
             denom = denoms[i % 4]
             res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC)
         scale = dp.average_(tr.decoder.grads.data)
@@ -321,7 +344,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if EVENTS else float('nan')
+    assert n_fwd[0] * ENC_BATCH >= args.steps * BATCH, 'fewer images encoded than consumed inside the timed region'
+    cnn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[:n_fwd[0]]])) if EVENTS else float('nan')
     # the same forward alone on the GPU (not overlapped with the decoder), for reference
     tr.enable_overlap(0)                 # full occupancy again (the overlapped forward ran 1 workgroup per CU)
     for _ in range(3):
@@ -342,8 +366,8 @@ def main():
         # launches, right after the timed loop); inside the timed region the same forward is deliberately
         # run at one workgroup per CU underneath the decoder step, so its wall time there says how well
         # the two overlap, not how good the kernel is.  Both are reported.
-        achieved = FLOP_PER_IMAGE_CNN * BATCH / (cnn_iso_ms * 1e-3)
-        achieved_in = FLOP_PER_IMAGE_CNN * BATCH / (cnn_ms * 1e-3)
+        achieved = FLOP_PER_IMAGE_CNN * ENC_BATCH / (cnn_iso_ms * 1e-3)
+        achieved_in = FLOP_PER_IMAGE_CNN * ENC_BATCH / (cnn_ms * 1e-3)
         out = {
             'metric': 'images/sec (decoder-mode XE training, COMIC-256, InceptionV3 frozen)',
             'value': round(BATCH * world * args.steps / dt, 2), 'unit': 'images/sec', 'n_gpus': world,
@@ -352,24 +376,29 @@ def main():
             'config': {'workload': 'MS-COCO decoder-mode XE, COMIC-256 (radix-256, 8 heads, tied), InceptionV3 '
                                    'frozen, batch 64/GPU, 224x224x3 (BASELINE configs[1])',
                        'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'image_size': IMG,
-                       'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world},
+                       'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world,
+                       'encoder_group': GROUP, 'encoder_forwards_in_timed_region': n_fwd[0]},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma / conv_patch (+ _grouped) kernels <bf16> (%d convs in %d '
-                                                    'launches per step, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch),
+                                                    'launches per forward of %d images, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch, ENC_BATCH),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
-                         'cnn_forward_ms': round(cnn_iso_ms, 4), 'heaviest_launch': top,
+                         'cnn_forward_ms': round(cnn_iso_ms, 4), 'images_per_forward': ENC_BATCH, 'heaviest_launch': top,
                          'in_timed_region': {'cnn_forward_ms': round(cnn_ms, 4), 'achieved': round(achieved_in / 1e12, 3),
                                              'frac': round(achieved_in / PEAK_BF16_MFMA, 5), 'overlapped': bool(overlap)},
                          'note': ('achieved/frac: the forward alone on the GPU, HIP events on its stream, measured in this '
                                   'process after the timed loop (agrees with profiles/*kernel_stats.csv).  in_timed_region: '
                                   'the same forward while it runs on a second stream under the decoder step of the '
-                                  'previous batch (frozen CNN) at one conv workgroup per CU') if overlap else ''},
+                                  'previous batch%s (frozen CNN) at one conv workgroup per CU' %
+                                  (' group: one forward per %d steps' % GROUP if GROUP > 1 else '')) if overlap else ''},
             'final_loss': round(loss, 5),
         }
         tfile = os.path.join(ROOT, 'profiles', 'r01_cnn_hbm_traffic.json')
         if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
-            out['roofline']['traffic'] = json.load(open(tfile))['per_forward']['conv_only_bytes_corrected']
-            out['roofline']['traffic_source'] = 'profiles/r01_cnn_hbm_traffic.json (bytes per InceptionV3 forward at batch 64, conv kernels)'
+            tj = json.load(open(tfile))
+            if int(tj.get('images_per_forward', 64)) == ENC_BATCH:
+                out['roofline']['traffic'] = tj['per_forward']['conv_only_bytes_corrected']
+                out['roofline']['traffic_source'] = ('profiles/r01_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
+                                                     'images, conv kernels)' % ENC_BATCH)
         if not args.no_extras and world == 1:
             try:
                 out['extras'] = extras(device, tr.encoder, cnn_params, plan)

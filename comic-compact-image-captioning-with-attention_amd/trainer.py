@@ -47,9 +47,14 @@ class DataParallel:
 class CaptionTrainer:
     def __init__(self, cnn_params, dec_spec, dec_params=None, batch=64, image_size=(224, 224), cnn_dtype='bf16',
                  device='cuda:0', lr_start=1e-2, lr_end=1e-5, max_step=100000, adam_epsilon=1e-2, dp=None, seed=0,
-                 plan=None):
+                 plan=None, encoder_group=1):
         self.plan = plan or nets.CnnPlan('inception_v3', image_size)
-        self.encoder = nets.CnnEncoder(self.plan, cnn_params, batch, cnn_dtype, device)
+        # encoder_group S > 1 (frozen-CNN pipelining only): ONE encoder forward covers the image batches of S
+        # consecutive steps (batch S*B: fuller tiles, S times fewer launches per image); the decoder steps take
+        # their B rows from a double-buffered copy of its outputs (submit_images / xe_step_pending)
+        self.group = int(encoder_group)
+        assert self.group >= 1
+        self.encoder = nets.CnnEncoder(self.plan, cnn_params, batch * self.group, cnn_dtype, device)
         self.decoder = cdec.Decoder(dec_spec, dec_params, device, seed)
         self.opt = optim.AdamTF(self.decoder.params, epsilon=adam_epsilon, l2_decay=dec_spec.l2_decay)
         self.dp = dp or DataParallel(None)
@@ -66,6 +71,10 @@ class CaptionTrainer:
         self._ev_cnn = torch.cuda.Event()
         self._ev_used = torch.cuda.Event()
         self._pending = None
+        self._stage = None                                  # group > 1: two (im_embed, fm) copies of a group's outputs
+        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._n_sub = self._n_taken = 0
 
     @property
     def global_step(self):
@@ -127,21 +136,64 @@ class CaptionTrainer:
             self.encoder.polite_lds_kb = polite_lds_kb
             self.encoder._graph, self.encoder._calls = None, 0      # re-capture with the new launch parameters
 
-    def submit_images(self, images):
-        """Start the encoder forward of a future step on the side stream (frozen-CNN modes)."""
+    def submit_images(self, images, events=None):
+        """Start the encoder forward of a future step (group > 1: of the next `group` steps, images
+        [group*B,H,W,3]) on the side stream (frozen-CNN modes).  events: an optional (start, end) pair of timing
+        events recorded on the side stream around the forward."""
         torch = self._torch
         main = torch.cuda.current_stream()
-        self._side.wait_stream(main) if self._pending is None else self._side.wait_event(self._ev_used)
+        if self.group == 1:
+            self._side.wait_stream(main) if self._pending is None else self._side.wait_event(self._ev_used)
+            with torch.cuda.stream(self._side):
+                if events: events[0].record(self._side)
+                self._pending = self.encoder.forward(images, use_graph=self.use_graph)
+                if events: events[1].record(self._side)
+                self._ev_cnn.record(self._side)
+            return
+        par = self._n_sub % 2
+        self._ev_used.record(main)                          # the images (and everything before) are ready
+        self._side.wait_event(self._ev_used)
+        if self._n_sub >= 2:
+            self._side.wait_event(self._ev_free[par])       # every step of the group two back has taken its rows
         with torch.cuda.stream(self._side):
-            self._pending = self.encoder.forward(images, use_graph=self.use_graph)
-            self._ev_cnn.record(self._side)
+            if events: events[0].record(self._side)
+            im, fm = self.encoder.forward(images, use_graph=self.use_graph)
+            if events: events[1].record(self._side)
+            if self._stage is None:
+                self._stage = [(torch.empty_like(im), torch.empty_like(fm)) for _ in range(2)]
+            self._stage[par][0].copy_(im)
+            self._stage[par][1].copy_(fm)
+            self._ev_done[par].record(self._side)
+        self._n_sub += 1
+
+    def take_features(self):
+        """(im_embed, fm, release) of the next step out of the submitted groups; call release() once the decoder
+        holds its copy (it returns True when this was the FIRST step of its group: the moment to submit the
+        next group, which then has the whole group's decoder steps to run under)."""
+        assert self.group > 1 and self._n_taken < self._n_sub * self.group, 'submit_images() first'
+        main = self._torch.cuda.current_stream()
+        g, j = divmod(self._n_taken, self.group)
+        par = g % 2
+        if j == 0:
+            main.wait_event(self._ev_done[par])
+        self._n_taken += 1
+        B = self.batch
+        im, fm = self._stage[par]
+
+        def release():
+            if j == self.group - 1:
+                self._ev_free[par].record(main)
+            return j == 0
+        return im[j * B:(j + 1) * B], fm[j * B:(j + 1) * B], release
 
     def xe_step_pending(self, captions, next_images=None, masks=None, training=True):
         """XE step on the batch submitted earlier; `next_images` (if given) are submitted as soon
         as the decoder has taken its copy of the encoder outputs, overlapping with this step."""
-        assert self._pending is not None, 'submit_images() first'
         torch = self._torch
         main = torch.cuda.current_stream()
+        if self.group > 1:
+            return self._xe_step_grouped(captions, next_images, masks, training)
+        assert self._pending is not None, 'submit_images() first'
         main.wait_event(self._ev_cnn)
         im_embed, fm = self._pending
         cap = np.asarray(captions)
@@ -157,6 +209,24 @@ class CaptionTrainer:
                                       use_graph=self.use_graph_decoder, on_inputs_consumed=consumed)
         if next_images is None:
             self._pending = None
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
+        return res
+
+    def _xe_step_grouped(self, captions, next_images, masks, training):
+        """xe_step_pending with encoder_group > 1: `next_images` ([group*B,H,W,3], the batches of the NEXT group
+        of steps) are taken at the first step of a group and ignored at the others."""
+        im_embed, fm, release = self.take_features()
+        cap = np.asarray(captions)
+        denom = None
+        if self.dp.world > 1:
+            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
+
+        def consumed():
+            if release() and next_images is not None:
+                self.submit_images(next_images)
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+                                      use_graph=self.use_graph_decoder, on_inputs_consumed=consumed)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res

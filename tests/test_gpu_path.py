@@ -377,6 +377,43 @@ def test_train_step_inputs_survive_host_run_ahead():
     assert [float(g) for g in got] == want
 
 
+@pytest.mark.parametrize('group', [1, 2, 3])
+def test_pipelined_xe_steps_equal_serial_steps(group):
+    """Frozen-CNN pipelining (trainer.submit_images / xe_step_pending): the encoder forward of the next step -- with
+    encoder_group S, ONE forward over the batches of the next S steps -- runs on a second stream under the
+    decoder step.  Six steps on six different image batches must give the losses and the final parameters of the
+    serial xe_step sequence, bit for bit (same kernels on the same rows: the CNN is batch-independent)."""
+    from comic_amd import trainer
+    B, size, Lc, steps = 3, 63, 9, 6
+    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN)
+    cnn_p = cnn_ref.randomize_bn(plan.init_params(seed=3), seed=4)
+    Hf, Wf, Cf, _ = plan.buffers[plan.fm]
+    spec, cfg = _spec_and_cfg(C=Cf, Cg=Cf, M=Hf * Wf)
+    p = _rand_params(cfg, 3)
+    rng = np.random.default_rng(23)
+    xs = [dev(rng.uniform(-1, 1, (B, size, size, 3)).astype(np.float32)) for _ in range(steps)]
+    caps = [_batch(spec, B, Lc, 30 + i)[2] for i in range(steps)]
+    for c in caps:
+        c[0] = caps[0][0]                            # same (B, T, T') key: one decoder context
+    kw = dict(lr_start=1e-2, lr_end=1e-2, max_step=10, plan=plan)
+    ser = trainer.CaptionTrainer(cnn_p, spec, p, B, (size, size), 'f32', DEV, **kw)
+    want = [float(ser.xe_step(xs[i], caps[i], training=False)['loss']) for i in range(steps)]
+    assert len({round(w, 6) for w in want}) == steps
+    tr = trainer.CaptionTrainer(cnn_p, spec, p, B, (size, size), 'f32', DEV, encoder_group=group, **kw)
+    tr.enable_overlap()
+    groups = [torch.cat(xs[g:g + group]) for g in range(0, steps, group)]
+    tr.submit_images(groups[0])
+    got = []
+    for i in range(steps):
+        g, j = divmod(i, group)
+        nxt = groups[g + 1] if g + 1 < len(groups) else None
+        got.append(tr.xe_step_pending(caps[i], next_images=nxt if group > 1 else (xs[i + 1] if i + 1 < steps else None),
+                                      training=False)['loss'].clone())
+    sync()
+    assert [float(v) for v in got] == want
+    np.testing.assert_array_equal(tr.decoder.params.data.cpu().numpy(), ser.decoder.params.data.cpu().numpy())
+
+
 def test_cnn_finetune_step_end_to_end():
     """train_mode cnn_finetune on a shallow stack: CNN forward -> decoder XE step -> CNN backward
     -> TF-Adam on decoder AND CNN variables, against the oracle chain (cnn_ref reverse pass fed by
