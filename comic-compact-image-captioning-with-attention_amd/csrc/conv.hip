@@ -682,12 +682,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
   constexpr int STAGE_BYTES = ROWS * 128;
-  constexpr int IPW_A = BM / 32;                // 8-row DMA instructions per wave per stage (A)
-  constexpr int IPW_B = BN / 32;
+  constexpr int NW = WM * WN;                   // waves per workgroup (4 or 8)
+  constexpr int IPW_A = BM / (8 * NW);          // 8-row DMA instructions per wave per stage (A)
+  constexpr int IPW_B = BN / (8 * NW);
   constexpr int LPT = IPW_A + IPW_B;            // DMA instructions per wave per stage
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
-  static_assert(WM * WN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile shape");
+  static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0 &&
+                    BN % (16 * WN) == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
@@ -900,7 +902,7 @@ __device__ __forceinline__ int xcd_tile_index(int total) {
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(ConvArgs a) {
   const int tiles_n = (a.Cout + BN - 1) / BN;
   int bm, bn;
   if (a.remap) {
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs a) {
 // launch then carries 2-4x the workgroups of a single 12x12 / 5x5 layer, which is what those
 // layers lack to fill 256 CUs at batch 64.
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256) void conv_igemm_dma_grouped_kernel(const ConvArgs* __restrict__ args, int n, int total) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_grouped_kernel(const ConvArgs* __restrict__ args, int n, int total) {
   int bid = blockIdx.x;
   const int remap = args[0].remap;
   if (remap) {
@@ -977,20 +979,20 @@ int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStr
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_dma_grouped_kernel<BM, BN, WM, WN, NSTAGE>), dim3((total_blocks + 7) / 8 * 8),
-                     dim3(256), lds, st, args_dev, n, total_blocks);
+                     dim3(WM * WN * 64), lds, st, args_dev, n, total_blocks);
   return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
-  static_assert(NSTAGE == 3 || NSTAGE == 4, "pipeline depth");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "pipeline depth");
   constexpr int lds0 = NSTAGE * (BM + BN) * 128;
   const int lds = std::max(lds0, conv_min_lds());
   static_assert(lds0 <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
@@ -1007,16 +1009,30 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   }
   dim3 grid((unsigned)((total + 7) / 8 * 8));
   if (a.Cin % 64 == 0)
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, st, b);
   else
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, st, b);
   return 0;
 }
 
 // explicit tile selection (comic_cnn_op.tile, filled by the host-side autotuner)
 constexpr int kNumConvTiles = 12;
+// ids 26..28: two-stage wide im2col tiles.  The L2 -> LDS fill (about 30 B/clk/CU) bounds the im2col kernel: a k-tile
+// costs (BM+BN)*128 bytes of fill for BM*BN/32 MFMA cycles, so 64x128 cannot pass ~31 % of the MFMA peak, 128x128
+// 47 %, 128x192 56 %; with two stages (instead of three) two such workgroups still share a CU.
+constexpr int kWideTile0 = 26, kNumWideTiles = 9;      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
+inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles); }
 int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
   switch (tile) {
+    case 26: return launch_dma<128, 128, 2, 2, 2>(a, st);
+    case 27: return launch_dma<128, 192, 2, 2, 2>(a, st);
+    case 28: return launch_dma<192, 128, 2, 2, 2>(a, st);
+    case 29: return launch_dma<256, 128, 4, 2, 2>(a, st);
+    case 30: return launch_dma<256, 192, 2, 4, 2>(a, st);
+    case 31: return launch_dma<256, 256, 2, 4, 2>(a, st);
+    case 32: return launch_dma<128, 160, 2, 2, 2>(a, st);      // 160-channel layers without a ragged column tile
+    case 33: return launch_dma<256, 64, 4, 1, 2>(a, st);
+    case 34: return launch_dma<192, 96, 2, 2, 2>(a, st);
     case 1: return launch_dma<128, 128, 2, 2, 3>(a, st);
     case 2: return launch_dma<128, 64, 2, 2, 3>(a, st);
     case 3: return launch_dma<64, 64, 2, 2, 3>(a, st);
@@ -1053,9 +1069,23 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
 // (BM, BN) of the explicit tile ids above
 constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 128, 64, 32, 64, 128};
 constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
+constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192};
+constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96};
+inline int im2col_tile_threads(int t) { return t >= 29 && t <= 31 ? 512 : 256; }
+inline int tile_bm(int t) { return t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
+inline int tile_bn(int t) { return t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
 
 int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
   switch (tile) {
+    case 26: return launch_dma_grouped<128, 128, 2, 2, 2>(args_dev, n, total_blocks, st);
+    case 27: return launch_dma_grouped<128, 192, 2, 2, 2>(args_dev, n, total_blocks, st);
+    case 28: return launch_dma_grouped<192, 128, 2, 2, 2>(args_dev, n, total_blocks, st);
+    case 29: return launch_dma_grouped<256, 128, 4, 2, 2>(args_dev, n, total_blocks, st);
+    case 30: return launch_dma_grouped<256, 192, 2, 4, 2>(args_dev, n, total_blocks, st);
+    case 31: return launch_dma_grouped<256, 256, 2, 4, 2>(args_dev, n, total_blocks, st);
+    case 32: return launch_dma_grouped<128, 160, 2, 2, 2>(args_dev, n, total_blocks, st);
+    case 33: return launch_dma_grouped<256, 64, 4, 1, 2>(args_dev, n, total_blocks, st);
+    case 34: return launch_dma_grouped<192, 96, 2, 2, 2>(args_dev, n, total_blocks, st);
     case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
@@ -1096,14 +1126,14 @@ int group_tile(const comic_cnn_op* ops, int n, int batch) {
 // patch-resident ids), returns its workgroup count or -1 when the member is not eligible; *lds = LDS it needs.
 long member_blocks(int tile, ConvArgs& a, int* lds) {
   if (a.member_kind == 1) {          // pool + BN + ReLU items, kPoolItemsPerThread per thread of the launch's workgroup size
-    const int threads = tile <= kNumConvTiles ? 256 : kPatchTiles[tile - 13].threads;
+    const int threads = is_im2col_tile(tile) ? im2col_tile_threads(tile) : kPatchTiles[tile - 13].threads;
     *lds = 0;
     return cdiv64((long)a.M * (a.Cin / 4), (long)threads * kPoolItemsPerThread);
   }
-  if (tile <= kNumConvTiles) {
-    a.tiles_m = cdiv(a.M, kTileBM[tile]);
+  if (is_im2col_tile(tile)) {
+    a.tiles_m = cdiv(a.M, tile_bm(tile));
     *lds = 0;
-    return (long)a.tiles_m * cdiv(a.Cout, kTileBN[tile]);
+    return (long)a.tiles_m * cdiv(a.Cout, tile_bn(tile));
   }
   const PatchTile pt = kPatchTiles[tile - 13];
   PatchGeo g;
@@ -1456,7 +1486,7 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
         lds_max = std::max(lds_max, lds);
       }
       COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
-      if (tile > kNumConvTiles) {
+      if (!is_im2col_tile(tile)) {
         if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, lds_max, main_st)) return rc;
       } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, main_st)) {
         return rc;

@@ -804,15 +804,18 @@ class CnnEncoder:
                         self._build_group_args()
                     run(); run()
                 except L.ComicHipError:
-                    if tile <= L.IM2COL_CONV_TILES:
+                    if L.is_im2col_tile(tile):
                         raise
                     continue              # a patch-resident variant this layer (or a group member) is not eligible for
-                ev0.record()
-                for _ in range(reps):
-                    run()
-                ev1.record()
-                ev1.synchronize()
-                t = ev0.elapsed_time(ev1) / reps
+                t = None
+                for _ in range(2):        # best of two timed blocks: variants are often within the run-to-run jitter
+                    ev0.record()
+                    for _ in range(reps):
+                        run()
+                    ev1.record()
+                    ev1.synchronize()
+                    tb = ev0.elapsed_time(ev1) / reps
+                    t = tb if t is None else min(t, tb)
                 if best[0] is None or t < best[0]:
                     best = (t, tile)
             op.tile = best[1]

@@ -151,6 +151,25 @@ def test_conv_bn_relu(case, dtype):
     assert (got2[..., :16] == -7).all() and (got2[..., 16 + Cout:] == -7).all()
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[i] for i in (1, 3, 5, 7, 8, 11, 12)])
+def test_conv_im2col_tile_variants_identical_bits(case):
+    """Every im2col LDS-DMA variant (ids 1..12: tile shapes x pipeline depths; 26..34: wide two-stage tiles, 4 or 8 waves) is a
+    different blocking of the same sums in the same k order: bit-identical outputs, ragged row / channel tiles
+    included, and correct against the oracle."""
+    B, H, W, Cin, Cout, k, s, pad = case
+    rng = np.random.default_rng(B * 1000 + H * 7 + Cin + Cout + k[0] + 5)
+    x = cnn_ref.bf16_round(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    w = (rng.standard_normal((k[0], k[1], Cin, Cout)) / math.sqrt(k[0] * k[1] * Cin)).astype(np.float32)
+    beta = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    mean = 0.2 * rng.standard_normal(Cout).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    base = _run_conv(x, w, beta, mean, var, s, pad, 'bf16', tile=3)
+    assert_close(base, _ref_conv(x, w, beta, mean, var, s, pad, 'bf16'), 1e-2, 'conv %s' % (case,))
+    for tile in list(range(1, 13)) + list(range(26, 35)):
+        got = _run_conv(x, w, beta, mean, var, s, pad, 'bf16', tile=tile)
+        np.testing.assert_array_equal(got, base, err_msg='tile %d %s' % (tile, case))
+
+
 # patch-resident variants (tile ids 13..25, conv_patch.inc; 4, 8 and 12 waves per workgroup): stride 1, Cin >= 32.  The tile spans image
 # boundaries (global output rows), ragged column tiles, SAME / VALID halos, the Kpad tail (K % 64 != 0),
 # channel counts with and without the 32-byte pixel padding, Cout ragged against the channel tile.
