@@ -33,7 +33,9 @@ struct ConvArgs {
   int relu, out_f32;
   const void* zero;  // 16 zero bytes in device memory (source of padding / out-of-range DMA lanes)
   int blk0, tiles_m; // grouped launch: first flat workgroup id of this problem, its pixel-tile count
-  int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index)
+  int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index); 2: grouped launch whose members
+                     // read the SAME im2col matrix (the 1x1 convs of one Inception block): see shared_input_group
+  int grp_nt;        // remap 2: out-channel tiles of all members together; blk0 = those of the members before this one
   int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
   // patch-resident kernel (conv_patch.inc): tile geometry, filled by apply_geometry()
   int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB;
@@ -932,6 +934,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_grouped_kernel(co
   } else if (bid >= total) {
     return;
   }
+  if (remap == 2) {
+    // shared input: logical id = (pixel tile, out-channel tile over ALL members), pixel tile slowest, and every
+    // XCD owns a contiguous range of logical ids -- the members' workgroups of one pixel tile run together on one
+    // XCD, so the activation rows come from the memory side once instead of once per member
+    const int R = args[0].grp_nt;
+    const int bm = bid / R, r = bid - bm * R;
+    int p = 0;
+    for (int i = 1; i < n; ++i)
+      if (r >= args[i].blk0) p = i;
+    const ConvArgs a = args[p];
+    if (a.Cin % 64 == 0)
+      conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, true>(a, bm, r - a.blk0);
+    else
+      conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, false>(a, bm, r - a.blk0);
+    return;
+  }
   int p = 0;
   for (int i = 1; i < n; ++i)
     if (bid >= args[i].blk0) p = i;
@@ -1346,6 +1364,21 @@ int validate_grouped_conv(const comic_cnn_op* op, int xc, int yc, const comic_co
   return 0;
 }
 
+// All members of a grouped launch are convolutions over the SAME im2col matrix (same source slice, filter window,
+// stride and padding -- the 1x1 convs at the head of an Inception block): the launch may then order its
+// workgroups by pixel tile (ConvArgs::remap == 2).
+bool shared_input_group(const ConvArgs* a, int n) {
+  if (n < 2) return false;
+  for (int j = 0; j < n; ++j) {
+    if (a[j].member_kind != 0) return false;
+    if (a[j].x != a[0].x || a[j].x_co != a[0].x_co || a[j].x_cs != a[0].x_cs || a[j].Cin != a[0].Cin ||
+        a[j].KH != a[0].KH || a[j].KW != a[0].KW || a[j].SH != a[0].SH || a[j].SW != a[0].SW || a[j].PT != a[0].PT ||
+        a[j].PL != a[0].PL || a[j].M != a[0].M || a[j].tiles_m != a[0].tiles_m)
+      return false;
+  }
+  return true;
+}
+
 // length of the group run starting at ops[i] (1 when ungrouped)
 int group_run(const comic_cnn_op* ops, int n_ops, int i) {
   if (ops[i].group <= 0) return 1;
@@ -1391,6 +1424,15 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
       COMIC_REQUIRE(nb >= 0, "grouped conv: member %d (stride %d, Cin %d) is not eligible for patch tile %d", j, op->SH,
                     op->Cin, tile);
       blk += (int)nb;
+    }
+    if (is_im2col_tile(tile) && shared_input_group(out, n)) {
+      int nt = 0;
+      for (int j = 0; j < n; ++j) {
+        out[j].remap = 2;
+        out[j].blk0 = nt;
+        nt += cdiv(out[j].Cout, tile_bn(tile));
+      }
+      for (int j = 0; j < n; ++j) out[j].grp_nt = nt;
     }
     out += n;
     i += n;
