@@ -244,10 +244,50 @@ class CaptionModel(ModelBase):
         self.dec_log_ppl = None
         print('INFO: Model `{}` initialisation complete.'.format(mode))
 
+    # ---- frozen-CNN pipelining (decoder mode): trainer.EncoderPipeline behind the reference API -------------
+    def _pipelined(self, batch):
+        c = self._config
+        return (batch is None and not self.cnn_trainable and getattr(c, 'pipeline_encoder', True)
+                and str(self.device).startswith('cuda'))
+
+    def _submit_group(self):
+        """Pull the batches of the next `encoder_group` steps from the input pipeline and start their ONE encoder
+        forward on the side stream; the captions wait in a queue for their steps."""
+        torch, pipe = self.torch, self._pipe
+        batches = [next(self.batch_ops) for _ in range(pipe.group)]
+        imgs = [b[0] if torch.is_tensor(b[0]) else torch.from_numpy(np.ascontiguousarray(b[0], np.float32)).to(self.device)
+                for b in batches]
+        pipe.submit(imgs[0] if len(imgs) == 1 else torch.cat(imgs))
+        self._cap_queue.extend(b[1] for b in batches)
+
+    def _next_features(self):
+        """-> (im_embed, fm, captions, consumed) of the next training step."""
+        if getattr(self, '_pipe', None) is None:
+            from .trainer import EncoderPipeline
+            import collections
+            group = max(1, int(getattr(self._config, 'encoder_group', 1)))
+            enc = self._encoder_for(self._batch_size * group)
+            enc.polite_lds_kb = int(getattr(self._config, 'encoder_polite_lds_kb', 84))   # see CaptionTrainer.enable_overlap
+            self._pipe = EncoderPipeline(enc, self._batch_size, group, self.device)
+            self._cap_queue = collections.deque()
+            self._submit_group()
+        im_embed, fm, release = self._pipe.take()
+
+        def consumed():
+            if release():
+                self._submit_group()
+        return im_embed, fm, self._cap_queue.popleft(), consumed
+
     def run_train_step(self, batch=None):
-        """== sess.run(m_train.dec_log_ppl): one XE update (train_fn.py:120-121)."""
-        images, captions = batch if batch is not None else next(self.batch_ops)
-        im_embed, fm = self._encode(images)
+        """== sess.run(m_train.dec_log_ppl): one XE update (train_fn.py:120-121).  With a frozen CNN and batches
+        drawn from the input pipeline the encoder forward of the NEXT step(s) runs on a second stream under this
+        step's decoder (config.pipeline_encoder, default on; config.encoder_group steps per forward, default 1)."""
+        consumed = None
+        if self._pipelined(batch):
+            im_embed, fm, captions, consumed = self._next_features()
+        else:
+            images, captions = batch if batch is not None else next(self.batch_ops)
+            im_embed, fm = self._encode(images)
         cap = np.asarray(captions)
         denom = None
         if self.dp.world > 1:
@@ -255,7 +295,7 @@ class CaptionModel(ModelBase):
         lr = self.lr
         ft = self.cnn_trainable
         res = self.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=not ft,
-                                      want_input_grads=ft)
+                                      want_input_grads=ft, on_inputs_consumed=consumed)
         if ft:
             self._cnn_update(res, lr)
         scale = self.dp.average_(self.decoder.grads.data)

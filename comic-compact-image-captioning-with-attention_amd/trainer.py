@@ -44,6 +44,71 @@ class DataParallel:
         return 1.0 / self.world
 
 
+class EncoderPipeline:
+    """Frozen-CNN pipelining: ONE encoder forward covers the image batches of the next `group` training steps
+    (batch group*B) and runs on a second stream under the decoder steps of the current group; its outputs go to one
+    of two staging copies from which the steps take their B rows.  Used by CaptionTrainer (bench.py) and by
+    CaptionModel.run_train_step (the reference-API path)."""
+
+    def __init__(self, encoder, batch, group, device, use_graph=True):
+        import torch
+        self._torch = torch
+        self.encoder, self.batch, self.group, self.use_graph = encoder, int(batch), int(group), use_graph
+        assert self.group >= 1 and encoder.batch == self.batch * self.group
+        self.side = torch.cuda.Stream(device=device)
+        self._ev_ready = torch.cuda.Event()
+        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._stage = None
+        self._n_sub = self._n_taken = 0
+
+    @property
+    def steps_ready(self):
+        """training steps whose features are submitted and not yet taken"""
+        return self._n_sub * self.group - self._n_taken
+
+    def submit(self, images, events=None):
+        """Start the forward of the next group (images [group*B,H,W,3] fp32 on the device) on the side stream.
+        events: an optional (start, end) pair of timing events recorded on the side stream around the forward."""
+        torch = self._torch
+        main = torch.cuda.current_stream()
+        par = self._n_sub % 2
+        self._ev_ready.record(main)                         # the images (and everything before) are ready
+        self.side.wait_event(self._ev_ready)
+        if self._n_sub >= 2:
+            self.side.wait_event(self._ev_free[par])        # every step of the group two back has taken its rows
+        with torch.cuda.stream(self.side):
+            if events: events[0].record(self.side)
+            im, fm = self.encoder.forward(images, use_graph=self.use_graph)
+            if events: events[1].record(self.side)
+            if self._stage is None:
+                self._stage = [(torch.empty_like(im), torch.empty_like(fm)) for _ in range(2)]
+            self._stage[par][0].copy_(im)
+            self._stage[par][1].copy_(fm)
+            self._ev_done[par].record(self.side)
+        self._n_sub += 1
+
+    def take(self):
+        """(im_embed, fm, release) of the next step out of the submitted groups; call release() once the decoder
+        holds its copy (it returns True when this was the FIRST step of its group: the moment to submit the
+        next group, which then has the whole group's decoder steps to run under)."""
+        assert self.steps_ready > 0, 'submit() first'
+        main = self._torch.cuda.current_stream()
+        g, j = divmod(self._n_taken, self.group)
+        par = g % 2
+        if j == 0:
+            main.wait_event(self._ev_done[par])
+        self._n_taken += 1
+        B = self.batch
+        im, fm = self._stage[par]
+
+        def release():
+            if j == self.group - 1:
+                self._ev_free[par].record(main)
+            return j == 0
+        return im[j * B:(j + 1) * B], fm[j * B:(j + 1) * B], release
+
+
 class CaptionTrainer:
     def __init__(self, cnn_params, dec_spec, dec_params=None, batch=64, image_size=(224, 224), cnn_dtype='bf16',
                  device='cuda:0', lr_start=1e-2, lr_end=1e-5, max_step=100000, adam_epsilon=1e-2, dp=None, seed=0,
@@ -71,10 +136,7 @@ class CaptionTrainer:
         self._ev_cnn = torch.cuda.Event()
         self._ev_used = torch.cuda.Event()
         self._pending = None
-        self._stage = None                                  # group > 1: two (im_embed, fm) copies of a group's outputs
-        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
-        self._n_sub = self._n_taken = 0
+        self._pipe = EncoderPipeline(self.encoder, batch, self.group, device) if self.group > 1 else None
 
     @property
     def global_step(self):
@@ -150,41 +212,12 @@ class CaptionTrainer:
                 if events: events[1].record(self._side)
                 self._ev_cnn.record(self._side)
             return
-        par = self._n_sub % 2
-        self._ev_used.record(main)                          # the images (and everything before) are ready
-        self._side.wait_event(self._ev_used)
-        if self._n_sub >= 2:
-            self._side.wait_event(self._ev_free[par])       # every step of the group two back has taken its rows
-        with torch.cuda.stream(self._side):
-            if events: events[0].record(self._side)
-            im, fm = self.encoder.forward(images, use_graph=self.use_graph)
-            if events: events[1].record(self._side)
-            if self._stage is None:
-                self._stage = [(torch.empty_like(im), torch.empty_like(fm)) for _ in range(2)]
-            self._stage[par][0].copy_(im)
-            self._stage[par][1].copy_(fm)
-            self._ev_done[par].record(self._side)
-        self._n_sub += 1
+        self._pipe.use_graph = self.use_graph
+        self._pipe.submit(images, events)
 
     def take_features(self):
-        """(im_embed, fm, release) of the next step out of the submitted groups; call release() once the decoder
-        holds its copy (it returns True when this was the FIRST step of its group: the moment to submit the
-        next group, which then has the whole group's decoder steps to run under)."""
-        assert self.group > 1 and self._n_taken < self._n_sub * self.group, 'submit_images() first'
-        main = self._torch.cuda.current_stream()
-        g, j = divmod(self._n_taken, self.group)
-        par = g % 2
-        if j == 0:
-            main.wait_event(self._ev_done[par])
-        self._n_taken += 1
-        B = self.batch
-        im, fm = self._stage[par]
-
-        def release():
-            if j == self.group - 1:
-                self._ev_free[par].record(main)
-            return j == 0
-        return im[j * B:(j + 1) * B], fm[j * B:(j + 1) * B], release
+        """group > 1: (im_embed, fm, release) of the next step (EncoderPipeline.take)."""
+        return self._pipe.take()
 
     def xe_step_pending(self, captions, next_images=None, masks=None, training=True):
         """XE step on the batch submitted earlier; `next_images` (if given) are submitted as soon

@@ -105,3 +105,45 @@ def test_train_infer_cli_default_backbone(tmp_path):
                                                  '--get_metric_score', ''])
     caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
     assert caps and len(json.load(open(caps[0]))) == 4
+
+
+def test_run_train_step_pipelined_equals_serial(tmp_path):
+    """CaptionModel.run_train_step (the reference-API entry, == sess.run(m_train.dec_log_ppl)) with the frozen-CNN
+    pipelining on -- the encoder forward of the next step(s) on a second stream, `encoder_group` steps per forward --
+    gives the losses and the parameters of the serial step sequence bit for bit, on batches drawn from the real
+    input pipeline (JPEG decode -> device preprocessing -> bucketed captions)."""
+    import importlib.util
+    import torch
+    from tests import tiny_dataset
+    from comic_amd import model as mdl, train_fn as train
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=32, n_valid=4, n_test=4)
+    spec = importlib.util.spec_from_file_location('cli_train_probe', os.path.join(ROOT, 'src', 'train.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    args = cli.create_parser().parse_args(
+        ['--dataset_dir', ds, '--log_root', str(tmp_path / 'experiments'), '--cnn_name', 'inception_v3',
+         '--cnn_fm_attention', 'Mixed_7c', '--cnn_input_size', '139,139', '--batch_size_eval', '4', '--rnn_size', '128',
+         '--rnn_word_size', '64', '--train_mode', 'decoder', '--batch_size_train', '4', '--max_epoch', '2'])
+    kwargs, _, overwrite = cli.build_kwargs(args)
+    runs = []
+
+    def probe(config):
+        for pipe, group in ((False, 1), (True, 1), (True, 2)):
+            mdl.reset_default_graph()
+            config.pipeline_encoder, config.encoder_group = pipe, group
+            man = train._manager(config)
+            try:
+                man.enable_device_preprocess('cuda:0')
+                m = mdl.CaptionModel(config, mode='train', batch_ops=man.batch_train, reuse=False, name='train',
+                                     device='cuda:0')
+                losses = [float(m.run_train_step()) for _ in range(7)]
+                torch.cuda.synchronize()
+                runs.append((losses, m.decoder.params.data.cpu().numpy().copy()))
+            finally:
+                man.close()
+    train.try_to_train(train_fn=probe, try_block=False, overwrite=overwrite, **kwargs)
+    (l0, p0), (l1, p1), (l2, p2) = runs
+    assert len(set(round(v, 6) for v in l0)) == len(l0)        # the steps see different batches
+    assert l1 == l0 and l2 == l0
+    np.testing.assert_array_equal(p1, p0)
+    np.testing.assert_array_equal(p2, p0)
