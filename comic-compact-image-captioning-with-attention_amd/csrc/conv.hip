@@ -465,18 +465,28 @@ __device__ __forceinline__ void pool_bn_relu_item(const ConvArgs& a, const long 
   const int ho = mm % a.Ho;
   const int b = mm / a.Ho;
   const float* __restrict__ xg = (const float*)a.x;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int cnt = 0;
+  // all nine taps are loaded unconditionally from clamped coordinates (nine independent 16-byte loads in flight);
+  // taps outside the image are then skipped in the sum, in the same (kh, kw) order as a branchy loop
+  float4 v[9];
+  bool ok[9];
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int hi = ho - 1 + kh;
-    if ((unsigned)hi >= (unsigned)a.H) continue;
+    const int hc = min(max(hi, 0), a.H - 1);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       const int wi = wo - 1 + kw;
-      if ((unsigned)wi >= (unsigned)a.W) continue;
-      const float4 v = *(const float4*)(xg + ((size_t)(b * a.H + hi) * a.W + wi) * a.x_cs + a.x_co + cv * 4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      const int wc = min(max(wi, 0), a.W - 1);
+      ok[kh * 3 + kw] = ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+      v[kh * 3 + kw] = *(const float4*)(xg + ((size_t)(b * a.H + hc) * a.W + wc) * a.x_cs + a.x_co + cv * 4);
+    }
+  }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (ok[t]) {
+      acc.x += v[t].x; acc.y += v[t].y; acc.z += v[t].z; acc.w += v[t].w;
       ++cnt;
     }
   }
