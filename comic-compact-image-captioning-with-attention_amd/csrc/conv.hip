@@ -320,11 +320,17 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   const float* __restrict__ wg = (const float*)a.w;      // [K][Cout]
   const float* __restrict__ xg = (const float*)a.x;
+  // bf16 plans: the 32-deep product runs on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi of the fp32 operands split
+  // into two bf16 halves (three 16x16x32 MFMAs of 16 cycles instead of eight fp32 16x16x4 MFMAs of 32: the fp32 form
+  // kept the stem matrix-bound at 180 us per 320 images); the dropped lo*lo terms are 2^-16 relative, far below the
+  // bf16 rounding of the store.  fp32 plans keep the exact fp32 MFMA.  SPLIT changes the lane -> k map: a lane holds
+  // k = 8*fg .. 8*fg+7 (one bf16x8 operand) instead of k = 4*s + fg.
+  constexpr bool SPLIT = sizeof(T) == 2;
   float wf[NT][KS];
   int koff[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    const int k = 4 * s + fg;
+    const int k = SPLIT ? 8 * fg + s : 4 * s + fg;
     const bool kv = k < a.K;
     const int kk = kv ? k : 0;
     const int ci = kk % a.Cin, tap = kk / a.Cin;
@@ -333,7 +339,11 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) wf[i][s] = kv ? wg[kk * a.Cout + i * 16 + fr] : 0.f;
   }
-  const int pix0 = (blockIdx.x * 4 + wave) * 64;
+  // a workgroup walks kStemChunks chunks of 256 pixels with the weight fragments it loaded once
+  constexpr int kStemChunks = 4;
+  for (int chunk = 0; chunk < kStemChunks; ++chunk) {
+  const int pix0 = ((blockIdx.x * kStemChunks + chunk) * 4 + wave) * 64;
+  if (pix0 >= a.M) break;
   float xv[4][KS];
   int mrow[4];
 #pragma unroll
@@ -355,13 +365,70 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if constexpr (SPLIT) {
+    auto split8 = [](const float (&v)[KS], bf16x8_t& hi, bf16x8_t& lo) {
+      uint32_t h[4], l[4];
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
+      for (int e = 0; e < 4; ++e) {
+        h[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        l[e] = pack_bf16x2(v[2 * e] - __uint_as_float(h[e] << 16), v[2 * e + 1] - __uint_as_float(h[e] & 0xFFFF0000u));
+      }
+      hi = __builtin_bit_cast(bf16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+      lo = __builtin_bit_cast(bf16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+    };
+    bf16x8_t wh[NT], wl[NT], xh[4], xl[4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) split8(wf[i], wh[i], wl[i]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) split8(xv[t], xh[t], xl[t]);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][s], xv[t][s], acc[i][t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) {
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[t], acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[t], acc[i][t], 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[t], acc[i][t], 0, 0, 0);
+      }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][s], xv[t][s], acc[i][t], 0, 0, 0);
+  }
   // epilogue: lane holds channels i*16 + fg*4 .. +3 of pixel mrow[t]
+  if constexpr (NT == 2 && sizeof(T) == 2) {
+    // 32 bf16 channels: the two tiles are exchanged row-wise (see conv_store_tiles) and a lane stores 16 bytes
+    if (!a.out_f32 && (((a.y_cs | a.y_co) & 7) == 0)) {
+      float4 sc[2], sh[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        sc[i] = *(const float4*)(a.scale + i * 16 + fg * 4);
+        sh[i] = *(const float4*)(a.shift + i * 16 + fg * 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v0 = fmaf(acc[i][t][0], sc[i].x, sh[i].x), v1 = fmaf(acc[i][t][1], sc[i].y, sh[i].y);
+          float v2 = fmaf(acc[i][t][2], sc[i].z, sh[i].z), v3 = fmaf(acc[i][t][3], sc[i].w, sh[i].w);
+          if (a.relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          pk[i][0] = pack_bf16x2(v0, v1);
+          pk[i][1] = pack_bf16x2(v2, v3);
+        }
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        if (mrow[t] >= 0)
+          *(uint4*)((bf16_t*)a.y + (size_t)mrow[t] * a.y_cs + a.y_co + (fg & 1) * 16 + (fg >> 1) * 8) =
+              make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      }
+      continue;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int n0 = i * 16 + fg * 4;
@@ -380,6 +447,7 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
       else
         *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
     }
+  }
   }
 }
 
@@ -1351,7 +1419,7 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       COMIC_REQUIRE(lds <= 64 * 1024, "stem conv: weights do not fit LDS");
       if (a.K <= 32 && a.Cout == 32 && a.PT == 0 && a.PL == 0 && (op->Ho - 1) * op->SH + op->KH <= op->H &&
           (op->Wo - 1) * op->SW + op->KW <= op->W && op->tile != 1)
-        hipLaunchKernelGGL((conv_stem_mfma_kernel<T, 2>), dim3(cdiv(a.M, 256)), dim3(256), 0, st, a);   // VALID 3x3x3
+        hipLaunchKernelGGL((conv_stem_mfma_kernel<T, 2>), dim3(cdiv(a.M, 1024)), dim3(256), 0, st, a);   // VALID 3x3x3
       else
         hipLaunchKernelGGL((conv_stem_kernel<T>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a);
       break;
