@@ -805,24 +805,37 @@ __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&ac
 
 // ALIGNED (Cin % 64 == 0): a whole k-tile lies inside one filter tap, so the tap walk (kh, kw, c0)
 // is wave-uniform scalar state and the per-lane part of a source address is a constant.
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
+// NSTAGE_ = kLoaderWaves + n: n ring stages and WAVE SPECIALISATION -- the WM x WN waves only read fragments and issue
+// MFMAs, four more waves only issue the LDS-DMA pieces.  An LDS-DMA instruction holds its wave for ~70 cycles (stamps:
+// 700 of the 1950 cycles of a 128x192 k-tile went into issuing its 10 pieces); on a wave of its own that time runs
+// beside the matrix work instead of in front of it.  Both roles execute one s_barrier per k-tile.
+constexpr int kLoaderWaves = 20;
+constexpr int ring_stages(int nstage) { return nstage % 10; }
+constexpr int dma_threads(int wm, int wn, int nstage) { return (wm * wn + (nstage >= kLoaderWaves ? 4 : 0)) * 64; }
+
+template <int BM, int BN, int WM, int WN, int NSTAGE_, bool ALIGNED>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int block_m, const int block_n) {
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
   constexpr int STAGE_BYTES = ROWS * 128;
-  constexpr int NW = WM * WN;                   // waves per workgroup (4 or 8)
+  constexpr int NSTAGE = ring_stages(NSTAGE_);
+  constexpr bool SPEC = NSTAGE_ >= kLoaderWaves;
+  constexpr int NWC = WM * WN;                  // waves that own output tiles (4 or 8)
+  constexpr int NW = SPEC ? 4 : NWC;            // waves that issue the LDS-DMA pieces
   constexpr int IPW_A = BM / (8 * NW);          // 8-row DMA instructions per wave per stage (A)
   constexpr int IPW_B = BN / (8 * NW);
   constexpr int LPT = IPW_A + IPW_B;            // DMA instructions per wave per stage
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
-  static_assert((NW == 4 || NW == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0 &&
+  static_assert((NWC == 4 || NWC == 8) && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0 &&
                     BN % (16 * WN) == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS DMA bases become SGPR math
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS DMA bases become SGPR math
+  const bool loader = SPEC && wave_id >= NWC;
+  const int wave = loader ? wave_id - NWC : wave_id;           // index inside its role
   const int wm = wave / WN, wn = wave % WN;
   const int bm0 = block_m * BM, bn0 = block_n * BN;
   const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
@@ -949,9 +962,30 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   // kt .. min(kt+NSTAGE-2, nk-1) have been issued and tile kt must have landed.
   constexpr int AHEAD = NSTAGE - 1;
   STAMP(0);
+  if constexpr (SPEC) {
+    if (loader) {
+      // loader waves: keep AHEAD tiles in flight; tile kt must have landed before barrier kt releases its readers
 #pragma unroll
-  for (int p = 0; p < AHEAD; ++p)
-    if (p < nk) issue(p, p);
+      for (int p = 0; p < AHEAD; ++p)
+        if (p < nk) issue(p, p);
+      for (int kt = 0; kt < nk; ++kt) {
+        const int pending = min(AHEAD - 1, nk - 1 - kt);
+        if (pending >= 2)
+          wait_vmcnt<2 * LPT>();
+        else if (pending == 1)
+          wait_vmcnt<LPT>();
+        else
+          wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
+      }
+      return;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+      if (p < nk) issue(p, p);
+  }
   STAMP(1);
 #ifdef COMIC_STAMPS
   unsigned long long t_issue = 0, t_wait = 0;
@@ -961,19 +995,23 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
 #ifdef COMIC_STAMPS
     const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int pending = min(AHEAD - 1, nk - 1 - kt);   // tiles allowed to stay in flight
-    if (pending >= 2)
-      wait_vmcnt<2 * LPT>();
-    else if (pending == 1)
-      wait_vmcnt<LPT>();
-    else
-      wait_vmcnt<0>();
+    if constexpr (!SPEC) {
+      const int pending = min(AHEAD - 1, nk - 1 - kt);   // tiles allowed to stay in flight
+      if (pending >= 2)
+        wait_vmcnt<2 * LPT>();
+      else if (pending == 1)
+        wait_vmcnt<LPT>();
+      else
+        wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();   // every wave's share of tile kt landed; the stage read in kt-1 is free
 #ifdef COMIC_STAMPS
     const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
     t_wait += ti0 - tw0;
 #endif
-    if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
+    if constexpr (!SPEC) {
+      if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
+    }
 #ifdef COMIC_STAMPS
     t_issue += __builtin_amdgcn_s_memtime() - ti0;
 #endif
@@ -1030,7 +1068,7 @@ __device__ __forceinline__ int xcd_tile_index(int total) {
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_kernel(ConvArgs a) {
   const int tiles_n = (a.Cout + BN - 1) / BN;
   int bm, bn;
   if (a.remap) {
@@ -1051,7 +1089,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_kernel(ConvArgs a
 // launch then carries 2-4x the workgroups of a single 12x12 / 5x5 layer, which is what those
 // layers lack to fill 256 CUs at batch 64.
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_dma_grouped_kernel(const ConvArgs* __restrict__ args, int n, int total) {
+__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_grouped_kernel(const ConvArgs* __restrict__ args, int n, int total) {
   int bid = blockIdx.x;
   const int remap = args[0].remap;
   if (remap) {
@@ -1111,7 +1149,7 @@ int conv_min_lds() { return g_conv_min_lds; }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
-  constexpr int lds0 = NSTAGE * (BM + BN) * 128;
+  constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
   const int lds = std::max(lds0, conv_min_lds());
   static bool attr_set = false;
   if (!attr_set) {
@@ -1123,14 +1161,14 @@ int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStr
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_dma_grouped_kernel<BM, BN, WM, WN, NSTAGE>), dim3((total_blocks + 7) / 8 * 8),
-                     dim3(WM * WN * 64), lds, st, args_dev, n, total_blocks);
+                     dim3(dma_threads(WM, WN, NSTAGE)), lds, st, args_dev, n, total_blocks);
   return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
-  static_assert(NSTAGE >= 2 && NSTAGE <= 4, "pipeline depth");
-  constexpr int lds0 = NSTAGE * (BM + BN) * 128;
+  static_assert(ring_stages(NSTAGE) >= 2 && ring_stages(NSTAGE) <= 4, "pipeline depth");
+  constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
   const int lds = std::max(lds0, conv_min_lds());
   static_assert(lds0 <= 160 * 1024, "LDS");
   static bool attr_set = false;
@@ -1153,9 +1191,9 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   }
   dim3 grid((unsigned)((total + 7) / 8 * 8));
   if (a.Cin % 64 == 0)
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(WM * WN * 64), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(dma_threads(WM, WN, NSTAGE)), lds, st, b);
   else
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(WM * WN * 64), lds, st, b);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(dma_threads(WM, WN, NSTAGE)), lds, st, b);
   return 0;
 }
 
@@ -1164,7 +1202,7 @@ constexpr int kNumConvTiles = 12;
 // ids 26..28: two-stage wide im2col tiles.  The L2 -> LDS fill (about 30 B/clk/CU) bounds the im2col kernel: a k-tile
 // costs (BM+BN)*128 bytes of fill for BM*BN/32 MFMA cycles, so 64x128 cannot pass ~31 % of the MFMA peak, 128x128
 // 47 %, 128x192 56 %; with two stages (instead of three) two such workgroups still share a CU.
-constexpr int kWideTile0 = 26, kNumWideTiles = 9;      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
+constexpr int kWideTile0 = 26, kNumWideTiles = 19;      // 35..44: four MFMA waves + four loader waves      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
 inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles); }
 int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
   switch (tile) {
@@ -1177,6 +1215,16 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 32: return launch_dma<128, 160, 2, 2, 2>(a, st);      // 160-channel layers without a ragged column tile
     case 33: return launch_dma<256, 64, 4, 1, 2>(a, st);
     case 34: return launch_dma<192, 96, 2, 2, 2>(a, st);
+    case 35: return launch_dma<128, 192, 2, 2, kLoaderWaves + 3>(a, st);
+    case 36: return launch_dma<128, 128, 2, 2, kLoaderWaves + 3>(a, st);
+    case 37: return launch_dma<128, 256, 2, 2, kLoaderWaves + 3>(a, st);
+    case 38: return launch_dma<192, 128, 2, 2, kLoaderWaves + 3>(a, st);
+    case 39: return launch_dma<128, 160, 2, 2, kLoaderWaves + 3>(a, st);
+    case 40: return launch_dma<192, 192, 2, 2, kLoaderWaves + 2>(a, st);
+    case 41: return launch_dma<128, 192, 2, 2, kLoaderWaves + 4>(a, st);
+    case 42: return launch_dma<160, 192, 2, 2, kLoaderWaves + 3>(a, st);
+    case 43: return launch_dma<192, 160, 2, 2, kLoaderWaves + 3>(a, st);
+    case 44: return launch_dma<192, 192, 2, 2, kLoaderWaves + 3>(a, st);
     case 1: return launch_dma<128, 128, 2, 2, 3>(a, st);
     case 2: return launch_dma<128, 64, 2, 2, 3>(a, st);
     case 3: return launch_dma<64, 64, 2, 2, 3>(a, st);
@@ -1213,9 +1261,9 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
 // (BM, BN) of the explicit tile ids above
 constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 128, 64, 32, 64, 128};
 constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
-constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192};
-constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96};
-inline int im2col_tile_threads(int t) { return t >= 29 && t <= 31 ? 512 : 256; }
+constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192, 128, 128, 128, 192, 128, 192, 128, 160, 192, 192};
+constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96, 192, 128, 256, 128, 160, 192, 192, 192, 160, 192};
+inline int im2col_tile_threads(int t) { return (t >= 29 && t <= 31) || t >= 35 ? 512 : 256; }
 inline int tile_bm(int t) { return t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
 inline int tile_bn(int t) { return t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
 
@@ -1230,6 +1278,16 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
     case 32: return launch_dma_grouped<128, 160, 2, 2, 2>(args_dev, n, total_blocks, st);
     case 33: return launch_dma_grouped<256, 64, 4, 1, 2>(args_dev, n, total_blocks, st);
     case 34: return launch_dma_grouped<192, 96, 2, 2, 2>(args_dev, n, total_blocks, st);
+    case 35: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 36: return launch_dma_grouped<128, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 37: return launch_dma_grouped<128, 256, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 38: return launch_dma_grouped<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 39: return launch_dma_grouped<128, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 40: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 2>(args_dev, n, total_blocks, st);
+    case 41: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, st);
+    case 42: return launch_dma_grouped<160, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 43: return launch_dma_grouped<192, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 44: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
     case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
