@@ -38,7 +38,7 @@ class DecoderDesc(C.Structure):
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
 
 
-CONV_TILES = 44          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..44 wide two-stage im2col variants
+CONV_TILES = 47          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
 

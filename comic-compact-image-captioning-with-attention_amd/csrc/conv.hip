@@ -1202,7 +1202,7 @@ constexpr int kNumConvTiles = 12;
 // ids 26..28: two-stage wide im2col tiles.  The L2 -> LDS fill (about 30 B/clk/CU) bounds the im2col kernel: a k-tile
 // costs (BM+BN)*128 bytes of fill for BM*BN/32 MFMA cycles, so 64x128 cannot pass ~31 % of the MFMA peak, 128x128
 // 47 %, 128x192 56 %; with two stages (instead of three) two such workgroups still share a CU.
-constexpr int kWideTile0 = 26, kNumWideTiles = 19;      // 35..44: four MFMA waves + four loader waves      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
+constexpr int kWideTile0 = 26, kNumWideTiles = 22;      // 35..47: four MFMA waves + four loader waves      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
 inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles); }
 int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
   switch (tile) {
@@ -1225,6 +1225,9 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 42: return launch_dma<160, 192, 2, 2, kLoaderWaves + 3>(a, st);
     case 43: return launch_dma<192, 160, 2, 2, kLoaderWaves + 3>(a, st);
     case 44: return launch_dma<192, 192, 2, 2, kLoaderWaves + 3>(a, st);
+    case 45: return launch_dma<64, 128, 2, 2, kLoaderWaves + 3>(a, st);        // small-batch shapes
+    case 46: return launch_dma<128, 64, 2, 2, kLoaderWaves + 3>(a, st);
+    case 47: return launch_dma<64, 64, 2, 2, kLoaderWaves + 4>(a, st);
     case 1: return launch_dma<128, 128, 2, 2, 3>(a, st);
     case 2: return launch_dma<128, 64, 2, 2, 3>(a, st);
     case 3: return launch_dma<64, 64, 2, 2, 3>(a, st);
@@ -1261,8 +1264,8 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
 // (BM, BN) of the explicit tile ids above
 constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 128, 64, 32, 64, 128};
 constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
-constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192, 128, 128, 128, 192, 128, 192, 128, 160, 192, 192};
-constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96, 192, 128, 256, 128, 160, 192, 192, 192, 160, 192};
+constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192, 128, 128, 128, 192, 128, 192, 128, 160, 192, 192, 64, 128, 64};
+constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96, 192, 128, 256, 128, 160, 192, 192, 192, 160, 192, 128, 64, 64};
 inline int im2col_tile_threads(int t) { return (t >= 29 && t <= 31) || t >= 35 ? 512 : 256; }
 inline int tile_bm(int t) { return t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
 inline int tile_bn(int t) { return t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
@@ -1288,6 +1291,9 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
     case 42: return launch_dma_grouped<160, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
     case 43: return launch_dma_grouped<192, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
     case 44: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 45: return launch_dma_grouped<64, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 46: return launch_dma_grouped<128, 64, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
+    case 47: return launch_dma_grouped<64, 64, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, st);
     case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
     case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, st);

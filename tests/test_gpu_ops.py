@@ -153,7 +153,7 @@ def test_conv_bn_relu(case, dtype):
 
 @pytest.mark.parametrize('case', [CONV_CASES[i] for i in (1, 3, 5, 7, 8, 11, 12)])
 def test_conv_im2col_tile_variants_identical_bits(case):
-    """Every im2col LDS-DMA variant (ids 1..12: tile shapes x pipeline depths; 26..44: wide tiles (35..44 with loader waves), 4 or 8 waves) is a
+    """Every im2col LDS-DMA variant (ids 1..12: tile shapes x pipeline depths; 26..47: wide tiles (35..47 with loader waves), 4 or 8 waves) is a
     different blocking of the same sums in the same k order: bit-identical outputs, ragged row / channel tiles
     included, and correct against the oracle."""
     B, H, W, Cin, Cout, k, s, pad = case
@@ -165,7 +165,7 @@ def test_conv_im2col_tile_variants_identical_bits(case):
     var = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
     base = _run_conv(x, w, beta, mean, var, s, pad, 'bf16', tile=3)
     assert_close(base, _ref_conv(x, w, beta, mean, var, s, pad, 'bf16'), 1e-2, 'conv %s' % (case,))
-    for tile in list(range(1, 13)) + list(range(26, 45)):
+    for tile in list(range(1, 13)) + list(range(26, 48)):
         got = _run_conv(x, w, beta, mean, var, s, pad, 'bf16', tile=tile)
         np.testing.assert_array_equal(got, base, err_msg='tile %d %s' % (tile, case))
 
