@@ -38,13 +38,13 @@ class DecoderDesc(C.Structure):
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
 
 
-CONV_TILES = 47          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
+CONV_TILES = 53          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
 
 def is_im2col_tile(tile):
     """Every layer is eligible for these ids (a failure is an error); the patch-resident ids may refuse a layer."""
-    return tile <= IM2COL_CONV_TILES or 26 <= tile <= CONV_TILES
+    return tile <= IM2COL_CONV_TILES or 26 <= tile <= 47        # 48..53: patch-resident with loader waves
 PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
 
 

@@ -1255,6 +1255,13 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 23: return launch_patch<4, 6, 4, 2>(a, st);    // 256 px x 192 ch, 8 waves
     case 24: return launch_patch<2, 4, 4, 2>(a, st);    // 128 px x 128 ch
     case 25: return launch_patch<2, 6, 4, 2>(a, st);    // 128 px x 192 ch, 8 waves
+    // patch-resident, four MFMA waves + four loader waves
+    case 48: return launch_patch<4, 4, 4, 1, kLoaderWaves + 3>(a, st);   // 256 px x 64 ch
+    case 49: return launch_patch<4, 2, 4, 1, kLoaderWaves + 3>(a, st);   // 256 px x 32 ch
+    case 50: return launch_patch<4, 6, 4, 1, kLoaderWaves + 3>(a, st);   // 256 px x 96 ch
+    case 51: return launch_patch<2, 6, 4, 1, kLoaderWaves + 3>(a, st);   // 128 px x 96 ch
+    case 52: return launch_patch<4, 6, 2, 2, kLoaderWaves + 3>(a, st);   // 128 px x 192 ch
+    case 53: return launch_patch<4, 4, 2, 2, kLoaderWaves + 3>(a, st);   // 128 px x 128 ch
     default:
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
@@ -1334,7 +1341,7 @@ int group_tile(const comic_cnn_op* ops, int n, int batch) {
 // patch-resident ids), returns its workgroup count or -1 when the member is not eligible; *lds = LDS it needs.
 long member_blocks(int tile, ConvArgs& a, int* lds) {
   if (a.member_kind == 1) {          // pool + BN + ReLU items, kPoolItemsPerThread per thread of the launch's workgroup size
-    const int threads = is_im2col_tile(tile) ? im2col_tile_threads(tile) : kPatchTiles[tile - 13].threads;
+    const int threads = is_im2col_tile(tile) ? im2col_tile_threads(tile) : kPatchTiles[patch_tile_index(tile)].threads;
     *lds = 0;
     return cdiv64((long)a.M * (a.Cin / 4), (long)threads * kPoolItemsPerThread);
   }
@@ -1343,7 +1350,7 @@ long member_blocks(int tile, ConvArgs& a, int* lds) {
     *lds = 0;
     return (long)a.tiles_m * cdiv(a.Cout, tile_bn(tile));
   }
-  const PatchTile pt = kPatchTiles[tile - 13];
+  const PatchTile pt = kPatchTiles[patch_tile_index(tile)];
   PatchGeo g;
   if (!patch_geometry(a, pt.BM, pt.BN, 3, g)) return -1;
   apply_geometry(a, g);

@@ -32,7 +32,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 47
+#define COMIC_CONV_TILES 53
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -81,7 +81,8 @@ typedef struct comic_cnn_op {
                         patch-resident variants (stride-1 layers whose input window fits the LDS: the window
                         is loaded once per tile, only the weight k-tiles stream; 4, 8 or 12 waves per
                         workgroup); 26..47 wide two-stage im2col tiles (128x128 .. 256x256, 4 or 8 waves: less LDS
-                        fill per MFMA).  An ineligible layer returns an error for ids 13..25.  In a group the
+                        fill per MFMA).  Ids 48..53: patch-resident variants with
+                        loader waves.  An ineligible layer returns an error for ids 13..25 and 48..53.  In a group the
                         id of the first member applies to all members.  Every variant gives identical bits. */
   int32_t group;     /* conv, bf16 plans: 0 = own launch; ops that are ADJACENT in the table and
                         share a non-zero id are mutually independent (the same-depth convs of

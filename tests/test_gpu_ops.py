@@ -181,7 +181,7 @@ PATCH_CASES = [
     (3, 21, 21, 64, 80, (1, 1), 'VALID'), (1, 1, 1, 32, 16, (1, 1), 'SAME'), (2, 40, 70, 32, 48, (3, 3), 'SAME')]
 
 
-@pytest.mark.parametrize('tile', list(range(13, 26)))
+@pytest.mark.parametrize('tile', list(range(13, 26)) + list(range(48, 54)))
 @pytest.mark.parametrize('case', PATCH_CASES)
 def test_conv_patch_variants(case, tile):
     B, H, W, Cin, Cout, k, pad = case
@@ -229,7 +229,7 @@ def test_conv_patch_random_sweep():
         scale, shift = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV) * 0.1
         wt = L.ConvWeight(w.data_ptr(), scale.data_ptr(), shift.data_ptr())
         ref = None
-        for tile in [3] + list(range(13, 26)):
+        for tile in [3] + list(range(13, 26)) + list(range(48, 54)):
             y = torch.full((B, Ho, Wo, yc), -7.0, dtype=torch.bfloat16, device=DEV)
             op = L.CnnOp(kind=0, src=0, dst=1, src_coff=xo, dst_coff=yo, H=H, W=W, Cin=Cin, Cout=Cout, KH=kh, KW=kw, SH=1,
                          SW=1, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=relu, out_f32=0, tile=tile)
