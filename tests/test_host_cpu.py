@@ -43,6 +43,17 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.ConvWeight) == 3 * 8
 
 
+def test_conv_variant_ids_match_header():
+    """The kernel-variant id space of comic_cnn_op.tile: the Python mirror agrees with include/comic_hip.h, and the
+    always-eligible (im2col) and may-refuse (patch-resident) ids partition 1..COMIC_CONV_TILES."""
+    header = open(os.path.join(ROOT, 'include', 'comic_hip.h')).read()
+    assert int(re.search(r'#define COMIC_CONV_TILES (\d+)', header).group(1)) == L.CONV_TILES
+    im2col = [t for t in range(1, L.CONV_TILES + 1) if L.is_im2col_tile(t)]
+    patch = [t for t in range(1, L.CONV_TILES + 1) if not L.is_im2col_tile(t)]
+    assert im2col == list(range(1, 13)) + list(range(26, 48))
+    assert patch == list(range(13, 26)) + list(range(48, 54))
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, '_lib', None)
     monkeypatch.setattr(L, 'LIB_PATH', '/nonexistent/libcomic_hip.so')
