@@ -422,6 +422,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   // state-gradient form: only live rows pass d(att state) into the context (finished rows
   // kept their previous state)
   const float live = (a.lens && a.t >= a.lens[b]) ? 0.f : 1.f;
+  // split mode (grid (B, 2), executor only): the two workgroups of a batch row each own half of the memory rows for
+  // the expensive parts (score recomputation, LayerNorm / tanh backward, d keys); both compute the cheap d alpha of
+  // ALL rows (the probability backward needs the full sum).  d q and the parameter-gradient row are then sums of two
+  // contributions, added atomically into zero-filled buffers: with exactly two addends the result does not depend
+  // on their order.
+  const bool split = gridDim.y == 2;
+  const int m0 = split ? (int)blockIdx.y * ((M + 1) >> 1) : 0;
+  const int m1 = split ? min(M, m0 + ((M + 1) >> 1)) : M;
 
   // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
   // tied values: the value row IS the key row (one load), and the alpha_d * dctx term of
@@ -439,8 +447,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
     const size_t go = ((size_t)b * H + headv) * M + m;
     const float al = a.alpha_in[go];
     const float mk = a.mask_alpha ? a.mask_alpha[go] : 1.f;
-    const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
-    if ((lane % lph) == 0) ss[head * M + m] = raw / scale;
+    const bool own = m >= m0 && m < m1;          // wave-uniform
+    if (own) {
+      const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
+      if ((lane % lph) == 0) ss[head * M + m] = raw / scale;
+    }
     // alpha_d of this lane's value head
     const float ad = a.mask_alpha ? (al / a.keep_alpha) * mk : al;
     float part = 0.f;
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
       for (int i = 0; i < eplv; ++i) {
         const float dc = dctx[c0 + i] * live;
         part = fmaf(dc, vr[i], part);
-        dvr[i] += ad * dc;
+        if (own) dvr[i] += ad * dc;
       }
     }
     part = head_sum(part, lphv);
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
       dot = wave_sum(dot);
       for (int m = lane; m < M; m += 64) {
         const float ds = a.alpha_in[go + m] * (drow[m] - dot);
-        dtau -= ds * srow[m];
+        if (m >= m0 && m < m1) dtau -= ds * srow[m];
         drow[m] = ds / scale;
       }
     } else {
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
         const float sg = sigmoidf_(srow[m]);
         const float dsg = drow[m] / S - dsum / (S * S);
         const float ds = dsg * sg * (1.f - sg);
-        dtau -= ds * srow[m];
+        if (m >= m0 && m < m1) dtau -= ds * srow[m];
         drow[m] = ds / scale;
       }
     }
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   float dq_acc[EPL], dv_acc[EPL], dg_acc[EPL], db_acc[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) dq_acc[i] = dv_acc[i] = dg_acc[i] = db_acc[i] = 0.f;
-  for (int m = wave; m < M; m += kAttnWaves) {
+  for (int m = m0 + wave; m < m1; m += kAttnWaves) {
     float kr[EPL], th[EPL], xh[EPL], rstd = 0.f;
     const float* kp = a.keys + ((size_t)b * M + m) * D + k0;
     float* dkp = a.dkeys + ((size_t)b * M + m) * D + k0;
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   // cross-wave reductions (4 waves), one array at a time through `red`
   // cross-wave reductions, one array at a time through `red` ([kAttnWaves][<=512] floats,
   // processed in 512-channel chunks so the LDS footprint is independent of D)
-  auto reduce_store = [&](const float* acc, float* dst, bool accumulate) {
+  auto reduce_store = [&](const float* acc, float* dst, int mode) {       // 0 store, 1 +=, 2 atomic add
     for (int cb = 0; cb < D; cb += 512) {
       const int cw = min(512, D - cb);
       __syncthreads();
@@ -564,24 +575,30 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kAttnWaves; ++w) s += red[w * 512 + k];
-        if (accumulate)
+        if (mode == 2)
+          unsafeAtomicAdd(dst + cb + k, s);
+        else if (mode == 1)
           dst[cb + k] += s;
         else
           dst[cb + k] = s;
       }
     }
   };
-  reduce_store(dq_acc, a.dq + (size_t)b * D, false);
+  reduce_store(dq_acc, a.dq + (size_t)b * D, split ? 2 : 0);
   if (a.d.method == 0 && a.pgrad) {
     float* pg = a.pgrad + (size_t)b * (3 * D + 1);
-    const bool add = a.pgrad_overwrite == 0;   // executor: one row per (step, batch row), summed once at the end
-    reduce_store(dv_acc, pg, add);
-    reduce_store(dg_acc, pg + D, add);
-    reduce_store(db_acc, pg + 2 * D, add);
+    // executor: one row per (step, batch row), summed once at the end (overwrite; split: two atomic contributions)
+    const int mode = split ? 2 : (a.pgrad_overwrite == 0 ? 1 : 0);
+    reduce_store(dv_acc, pg, mode);
+    reduce_store(dg_acc, pg + D, mode);
+    reduce_store(db_acc, pg + 2 * D, mode);
     if (tid == 0) {
       float dt = 0.f;
       for (int w = 0; w < kAttnWaves; ++w) dt += misc[w];
-      pg[3 * D] = (add ? pg[3 * D] : 0.f) + dt / a.tau[0];
+      if (mode == 2)
+        unsafeAtomicAdd(pg + 3 * D, dt / a.tau[0]);
+      else
+        pg[3 * D] = (mode == 1 ? pg[3 * D] : 0.f) + dt / a.tau[0];
     }
   }
 }
@@ -888,9 +905,12 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.alpha_in = alpha; a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.dctx = dctx; a.dmap = dmap;
   a.dq = dq; a.dkeys = dkeys; a.dvalues = dvalues; a.pgrad = pgrad; a.lens = lens; a.t = t;
   a.pgrad_overwrite = pgrad_overwrite;
+  COMIC_REQUIRE(pgrad_overwrite != 2 || d->prob == 0, "attn_bwd: the split form needs the softmax probability fn");
   const size_t lds = ((size_t)d->H * d->M * 3 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
   int rc = attn_dispatch(d->D, [&](auto epl) {
-    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
+    // pgrad_overwrite == 2: split mode -- two workgroups per batch row; the caller zero-filled dq and the pgrad rows
+    const bool split = pgrad_overwrite == 2;
+    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B, split ? 2 : 1), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_bwd");

@@ -74,6 +74,16 @@ int comic_input_grad_fused(const float* dg, const float* K, const float* mask, f
 namespace {
 
 // COMIC_FUSED_STEP=0 keeps the split-K GEMM + element-wise kernel chain (A/B switch for profiling)
+// COMIC_SPLIT_ATTN_BWD=0 keeps one attention-backward workgroup per batch row (A/B measurements)
+bool split_attn_bwd_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("COMIC_SPLIT_ATTN_BWD");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 bool fused_step_enabled() {
   static int v = -1;
   if (v < 0) {
@@ -702,6 +712,13 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
   RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
+  // softmax attention: the backward kernel runs as two workgroups per batch row (half of the memory rows each), whose
+  // d q / parameter-gradient contributions are added into zero-filled rows (comic_attn_bwd_ex, pgrad_overwrite 2)
+  const int attn_bwd_mode = (d->prob == 0 && split_attn_bwd_enabled()) ? 2 : 1;
+  if (attn_bwd_mode == 2) {
+    RC(fill(dq_all, 0.f, (long)Tp * B * D, st));
+    RC(fill(pgrad, 0.f, (long)Tp * B * (3 * D + 1), st));
+  }
   for (int t = Tp - 1; t >= 0; --t) {
     const float* ctx_t = ctx_all + (size_t)t * B * Cv;
     float* dq_t = dq_all + (size_t)t * B * D;
@@ -712,7 +729,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, datt,
                            use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
-                           pgrad + (size_t)t * B * (3 * D + 1), lens, t, st, 1));
+                           pgrad + (size_t)t * B * (3 * D + 1), lens, t, st, attn_bwd_mode));
       carry = 1;
     } else {
       hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
@@ -722,7 +739,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, dctx,
                            use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
-                           pgrad + (size_t)t * B * (3 * D + 1), nullptr, 0, st, 1));
+                           pgrad + (size_t)t * B * (3 * D + 1), nullptr, 0, st, attn_bwd_mode));
       carry = 0;
     }
     float* dy_t = dy_all + (size_t)t * B * D;
