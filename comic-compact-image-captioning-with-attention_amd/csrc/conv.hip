@@ -1017,27 +1017,32 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
 #endif
     const uint32_t sb = lds0 + stage * STAGE_BYTES;
     u32x4_t xf0[TM], xf1[TM], wf0[TN], wf1[TN];
-    static_for<0, TN>([&](auto i) {
-      wf0[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off0);
-      wf1[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off1);
-    });
-    static_for<0, TM>([&](auto j) {
-      xf0[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off0);
-      xf1[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off1);
-    });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // both 32-deep halves of the k-tile are requested at once; the first half's MFMAs start as soon as ITS fragments
+    // have landed (the LDS returns in order: lgkmcnt <= TM+TN leaves exactly the second half outstanding), so the
+    // second half's read latency runs under them.  Per accumulator the order stays half 0, then half 1.
+    static_assert(TM + TN <= 15, "lgkmcnt holds 4 bits");
+    static_for<0, TN>([&](auto i) { wf0[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off0); });
+    static_for<0, TM>([&](auto j) { xf0[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off0); });
+    static_for<0, TN>([&](auto i) { wf1[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off1); });
+    static_for<0, TM>([&](auto j) { xf1[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off1); });
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     // n-tiles beyond Cout multiply zero-filled weight rows (no branch: keeps the accumulators in place)
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
+      for (int j = 0; j < TM; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]),
                                                             __builtin_bit_cast(bf16x8_t, xf0[j]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]),
                                                             __builtin_bit_cast(bf16x8_t, xf1[j]), acc[i][j], 0, 0, 0);
-      }
-    }
   }
 
   STAMP(2);
