@@ -72,8 +72,18 @@ class ModelBase(object):
         if batch_size not in encs:
             dtype = getattr(self._config, 'cnn_dtype', 'bf16')
             first = next(iter(encs.values()), None)
-            encs[batch_size] = nets.CnnEncoder(self.plan, self._share['cnn_params'], batch_size, dtype, self.device,
-                                               weights_from=first)
+            enc = encs[batch_size] = nets.CnnEncoder(self.plan, self._share['cnn_params'], batch_size, dtype, self.device,
+                                                     weights_from=first)
+            # kernel variants per conv launch, timed once on this GPU at this batch size (a few seconds; cached in the
+            # run directory).  Every variant gives the same bits.  Skipped for toy problem sizes and when
+            # config.cnn_autotune is False; the trainable CNN keeps the heuristic choice (its plan differs).
+            H, W = self.plan.buffers[self.plan.input][:2]
+            c = self._config
+            if (getattr(c, 'cnn_autotune', True) and dtype == 'bf16' and str(self.device).startswith('cuda')
+                    and batch_size * H * W >= 16 * 224 * 224 and getattr(c, 'freeze_scopes', 'Model/encoder/cnn')):
+                log_path = getattr(c, 'log_path', None)
+                cache = os.path.join(log_path, 'conv_variants.json') if log_path and os.path.isdir(log_path) else None
+                enc.autotune(cache=cache)
         return encs[batch_size]
 
     @property

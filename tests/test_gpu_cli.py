@@ -147,3 +147,44 @@ def test_run_train_step_pipelined_equals_serial(tmp_path):
     assert l1 == l0 and l2 == l0
     np.testing.assert_array_equal(p1, p0)
     np.testing.assert_array_equal(p2, p0)
+
+
+def test_model_autotunes_encoder_and_caches_variants(tmp_path):
+    """At real problem sizes the reference-API model picks the conv kernel variants by timing them once
+    (CnnEncoder.autotune) and caches the choice in the run directory; a second model of the same shape loads the cache
+    and trains to the same loss (every variant gives the same bits)."""
+    import importlib.util
+    import torch
+    from tests import tiny_dataset
+    from comic_amd import model as mdl, train_fn as train
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=32, n_valid=4, n_test=4)
+    spec = importlib.util.spec_from_file_location('cli_train_probe2', os.path.join(ROOT, 'src', 'train.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    args = cli.create_parser().parse_args(
+        ['--dataset_dir', ds, '--log_root', str(tmp_path / 'experiments'), '--cnn_name', 'inception_v3',
+         '--cnn_fm_attention', 'Mixed_7c', '--cnn_input_size', '224,224', '--batch_size_eval', '4', '--rnn_size', '128',
+         '--rnn_word_size', '64', '--train_mode', 'decoder', '--batch_size_train', '16', '--max_epoch', '2'])
+    kwargs, _, overwrite = cli.build_kwargs(args)
+    out = []
+
+    def probe(config):
+        cache = os.path.join(config.log_path, 'conv_variants.json')
+        for _ in range(2):
+            mdl.reset_default_graph()
+            man = train._manager(config)
+            try:
+                man.enable_device_preprocess('cuda:0')
+                m = mdl.CaptionModel(config, mode='train', batch_ops=man.batch_train, reuse=False, name='train',
+                                     device='cuda:0')
+                enc = m._encoder_for(16)
+                tiles = [int(enc._ops[i].tile) for i in range(len(m.plan.ops))]
+                losses = [float(m.run_train_step()) for _ in range(2)]
+                torch.cuda.synchronize()
+                out.append((tiles, losses, os.path.isfile(cache)))
+            finally:
+                man.close()
+    train.try_to_train(train_fn=probe, try_block=False, overwrite=overwrite, **kwargs)
+    (t0, l0, c0), (t1, l1, c1) = out
+    assert c0 and c1 and any(t > 0 for t in t0), 'the encoder was not tuned / the cache was not written'
+    assert t1 == t0 and l1 == l0
