@@ -63,6 +63,9 @@ def extras(device, enc, cnn_params, plan):
     # ---- beam-3 inference, word baseline --------------------------------------------------
     B = 50
     enc50 = nets.CnnEncoder(plan, cnn_params, B, 'bf16', device)
+    tune = os.environ.get('COMIC_AUTOTUNE', '1') == '1'
+    if tune:
+        enc50.autotune()                   # setup, untimed (as for the training encoder)
     imgs = torch.from_numpy(rng.uniform(-1, 1, (B, IMG, IMG, 3)).astype(np.float32)).to(device)
     V = 25599
     spec = cdec.DecoderSpec(V=V, H=1, fm_projection=None, token_type='word', start_id=V - 2, end_id=V - 1)
@@ -99,6 +102,8 @@ def extras(device, enc, cnn_params, plan):
     dec.params.view('b_o')[257] = 2.0
     opt = optim.AdamTF(dec.params)
     enc_s = nets.CnnEncoder(plan, cnn_params, Bs, 'bf16', device)
+    if tune:
+        enc_s.autotune()
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bs, IMG, IMG, 3)).astype(np.float32)).to(device)
     iters = 40                                   # infer_max_length 20 x 2 radix digits
 
@@ -131,6 +136,8 @@ def extras(device, enc, cnn_params, plan):
     plan_ft = nets.CnnPlan('inception_v3', (IMG, IMG))           # trainable CNN: the plain plan (has a backward)
     tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16', device, seed=5, plan=plan_ft)
     tr.enable_cnn_finetune()
+    if tune:
+        tr.encoder.autotune()              # forward variants of the plain plan (setup, untimed)
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bf, IMG, IMG, 3)).astype(np.float32)).to(device)
     caps = synth_captions(rng, Bf)
     for _ in range(3):
