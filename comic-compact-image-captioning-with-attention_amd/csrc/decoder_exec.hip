@@ -341,12 +341,25 @@ __global__ void tile_rows_kernel(const float* __restrict__ in, float* __restrict
   const long r = i / cols;
   out[i] = in[(size_t)(r / W) * cols + (i % cols)];
 }
-// greedy bookkeeping: first_eos[b] = min(first_eos[b], t) when ids[b] == end
-__global__ void eos_track_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ first_eos, int t, int end_id,
-                                 int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  if (ids[b] == end_id && first_eos[b] > t) first_eos[b] = t;
+// greedy bookkeeping: first_eos[b] = min(first_eos[b], t) when ids[b] == end,
+// in one workgroup, plus the loop end -- steps_done = t+1 at the first step after which
+// every row has emitted EOS (dynamic_decode stops there; later steps' kernels return at once, see ComicStop)
+__global__ void eos_track_done_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ first_eos, int t,
+                                      int end_id, int B, int32_t* __restrict__ steps_done, int max_steps) {
+  __shared__ int any_live;
+  if (threadIdx.x == 0) any_live = 0;
+  __syncthreads();
+  if (steps_done[0] <= t) return;                 // loop already over: ids of this step were never produced
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int fe = first_eos[b];
+    if (ids[b] == end_id && fe > t) {
+      fe = t;
+      first_eos[b] = t;
+    }
+    if (fe > t) any_live = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && !any_live && steps_done[0] == max_steps) steps_done[0] = t + 1;
 }
 // beam bookkeeping: steps_executed = t+1 at the first step after which every beam is finished
 __global__ void all_finished_kernel(const int32_t* __restrict__ finished, int32_t* __restrict__ steps_executed, int t,
@@ -906,12 +919,21 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   RC(fill(ws.att[0], 0.f, (long)B * A, st));
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)B);
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, first_eos, max_steps, (long)B);
+  int32_t* steps_done = ws.parents;        // beam-only buffer: its first word is this loop's end marker
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps_done, max_steps, 1L);
   COMIC_LAUNCH_CHECK("greedy init");
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
   if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   int ld_wo = V;
   const float* w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
+  struct StopScope {          // whatever way this call returns, no later launch sees the flag
+    ~StopScope() { g_comic_stop = ComicStop(); }
+  } stop_scope;
   for (int t = 0; t < max_steps; ++t) {
+    if (fused) {              // the step's kernels return at once when the loop ended earlier (fused path only)
+      g_comic_stop.p = steps_done;
+      g_comic_stop.t = t;
+    }
     const int cur = t & 1, nxt = cur ^ 1;
     ws.sb.c2 = ws.c[nxt];
     ws.sb.h2 = ws.h[nxt];
@@ -933,8 +955,8 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
     RC(gemm(sb.y, w_o, lg, p->b_o, B, V, D, D, ld_wo, V, 0, 0, 0.f, st));
     int32_t* ids_out = ids_tb + (size_t)t * B;
     RC(comic_argmax_rows(lg, ids_out, B, V, (void*)st));
-    hipLaunchKernelGGL(eos_track_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, (const int32_t*)ids_out, first_eos, t,
-                       d->end_id, B);
+    hipLaunchKernelGGL(eos_track_done_kernel, dim3(1), dim3(256), 0, st, (const int32_t*)ids_out, first_eos, t,
+                       d->end_id, B, steps_done, max_steps);
     COMIC_LAUNCH_CHECK("eos_track");
   }
   (void)Cv; (void)M;

@@ -496,6 +496,17 @@ def test_greedy_and_beam_match_oracle(kw):
     np.testing.assert_array_equal(ids, g_ids)                                  # bit-exact argmax ids
     assert_close(logits.cpu().numpy(), g_logits, F32_RTOL, 'greedy logits')
     assert_close(amap.cpu().numpy(), g_map, F32_RTOL, 'greedy attention maps')
+    # the loop ends on the device once every row has emitted EOS: a strong EOS bias ends it after 1-3 steps; the
+    # executed prefix must equal the oracle's (which stops there too), called eagerly and replayed from the graph
+    pe = dict(p); pe['b_o'] = p['b_o'].copy(); pe['b_o'][spec.end_id] = 9.0
+    dece = cdec.Decoder(spec, pe, DEV)
+    e_ids, e_logits, e_map = beam_ref.greedy_decode(pe, cfg, fm, im, max_steps)
+    assert e_ids.shape[1] < max_steps, 'the early-exit case did not exit early'
+    for _ in range(3):
+        ids2, amap2, logits2 = dece.greedy(dev(fm), dev(im), max_steps, want_logits=True)
+        np.testing.assert_array_equal(ids2, e_ids)
+        assert_close(logits2.cpu().numpy(), e_logits, F32_RTOL, 'greedy logits (early exit)')
+        assert_close(amap2.cpu().numpy(), e_map, F32_RTOL, 'greedy attention maps (early exit)')
     for W, eos_bias in ((3, 1.5), (7, 1.5), (3, 9.0)):
         if eos_bias != 1.5:
             # every beam ends within a few steps: the remaining launches of the fixed-length loop return at once
