@@ -251,7 +251,8 @@ def main():
     # decoder mode: the CNN is frozen, so the plan may use the forward-only pool-branch rewrite
     plan = nets.CnnPlan('inception_v3', (IMG, IMG), branch_streams=os.environ.get('COMIC_CNN_LANES', '0') == '1',
                         group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1',
-                        pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
+                        pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1',
+                        fuse_pools=os.environ.get('COMIC_POOL_REWRITE', '1') == '1' and os.environ.get('COMIC_FUSE_POOLS', '1') == '1')
     cnn_params = plan.init_params(seed=0)                       # random-init weights (no checkpoints offline)
     spec = cdec.DecoderSpec()                                   # COMIC-256 on a 5x5x2048 map
     overlap = os.environ.get('COMIC_OVERLAP', '1') == '1'

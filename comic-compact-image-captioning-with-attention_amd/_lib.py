@@ -38,7 +38,9 @@ class DecoderDesc(C.Structure):
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
 
 
-CONV_TILES = 53          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
+CONV_TILES = 54          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
+WS_TILE = 54             # weight-stationary 1x1 groups (csrc/conv_ws.hip)
+OP_RAW, OP_POOLED_SRC = 1, 2
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
 

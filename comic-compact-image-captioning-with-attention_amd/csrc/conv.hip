@@ -14,44 +14,12 @@
 // (row = lane&15, chunk = lane>>4): 8 bf16 for v_mfma_f32_16x16x32_bf16, or 4 floats fed to
 // four v_mfma_f32_16x16x4_f32 (exact fp32 parity mode; both operands use the same
 // k-permutation so the sum over k is unchanged).
-#include <type_traits>
-
-#include "common.h"
+#include "conv_common.h"
+#include "conv_ws.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
-
-struct ConvArgs {
-  const void* x;
-  const void* w;
-  const float* scale;
-  const float* shift;
-  void* y;
-  int B, H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
-  int x_cs, x_co, y_cs, y_co;  // channel stride / offset of the src and dst pixel
-  int K, Kpad, M;
-  int relu, out_f32;
-  const void* zero;  // 16 zero bytes in device memory (source of padding / out-of-range DMA lanes)
-  int blk0, tiles_m; // grouped launch: first flat workgroup id of this problem, its pixel-tile count
-  int remap;         // 1: XCD-aware workgroup -> tile mapping (see xcd_tile_index); 2: grouped launch whose members
-                     // read the SAME im2col matrix (the 1x1 convs of one Inception block): see shared_input_group
-  int grp_nt;        // remap 2: out-channel tiles of all members together; blk0 = those of the members before this one
-  int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
-  // patch-resident kernel (conv_patch.inc): tile geometry, filled by apply_geometry()
-  int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB;
-  int member_kind;   // grouped launch: 0 conv tile, 1 pool + BN + ReLU (kind 7) work items
-};
-
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-  static constexpr int EPC = 4;  // elements per 16-byte chunk
-};
-template <>
-struct Elem<bf16_t> {
-  static constexpr int EPC = 8;
-};
 
 constexpr int kRowBytes = 80;  // 64 B of k + 16 B pad (spreads ds_read_b128 over the banks)
 
@@ -578,6 +546,48 @@ __global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
   if (idx < total) pool_bn_relu_item(a, idx, cvecs);
 }
 
+// The same op as one thread per (image row, 4 channels): the thread walks the row and keeps the sums of the last three
+// columns over the (up to three) valid source rows, so every source element is loaded once per output ROW that needs it
+// (3 loads per output instead of 9).  Summation order: rows inside a column first, then the columns left to right.
+__global__ __launch_bounds__(256) void pool_bn_relu_rows_kernel(ConvArgs a) {
+  const int cvecs = a.Cin / 4;
+  const long total = (long)a.B * a.H * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  const int q = (int)(idx / cvecs);
+  const int ho = q % a.H, b = q / a.H;
+  const float* __restrict__ xg = (const float*)a.x;
+  const int r0 = max(ho - 1, 0), r1 = min(ho + 1, a.H - 1);
+  const float nrows = (float)(r1 - r0 + 1);
+  const float4 sc = *(const float4*)(a.scale + cv * 4), sh = *(const float4*)(a.shift + cv * 4);
+  const float lo = a.relu ? 0.f : -INFINITY;
+  auto colsum = [&](int w) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = r0; r <= r1; ++r) {
+      const float4 v = *(const float4*)(xg + ((size_t)(b * a.H + r) * a.W + w) * a.x_cs + a.x_co + cv * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    return s;
+  };
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = colsum(0), c2;
+  for (int wo = 0; wo < a.W; ++wo) {
+    const bool right = wo + 1 < a.W;
+    c2 = right ? colsum(wo + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float cnt = nrows * (float)(1 + (wo > 0) + right);
+    float v0 = ((c0.x + c1.x) + c2.x) / cnt * sc.x + sh.x, v1 = ((c0.y + c1.y) + c2.y) / cnt * sc.y + sh.y;
+    float v2 = ((c0.z + c1.z) + c2.z) / cnt * sc.z + sh.z, v3 = ((c0.w + c1.w) + c2.w) / cnt * sc.w + sh.w;
+    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+    const size_t off = ((size_t)(b * a.H + ho) * a.W + wo) * a.y_cs + a.y_co + cv * 4;
+    if (a.out_f32)
+      *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+    else
+      *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    c0 = c1;
+    c1 = c2;
+  }
+}
+
 // The same work as a member of a grouped conv launch: workgroup `local` of this member handles
 // kPoolItemsPerThread x blockDim.x consecutive (pixel, 4-channel) items.
 constexpr int kPoolItemsPerThread = 4;
@@ -663,145 +673,7 @@ __global__ void fold_bn_kernel(const float* beta, const float* mean, const float
 // ds_read_b128 lane groups of the 16x16x32 operand fetch then hit 16 distinct slots.
 // Padding / out-of-range rows read from a 16-byte zero page.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
-#ifdef COMIC_STAMPS
-__device__ unsigned long long g_stamps[16384 * 8];
-#define STAMP(i) if (tid == 0) g_stamps[(blockIdx.x & 16383) * 8 + (i)] = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP(i)
-#endif
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-template <int OFF>
-__device__ __forceinline__ u32x4_t lds_read128(uint32_t addr) {
-  u32x4_t v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
-}
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
-                                   (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
-}
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>());
-    static_for<I + 1, N>(f);
-  }
-}
-
-// Epilogue shared by the bf16 conv kernels: y = relu(acc * scale[n] + shift[n]) for a wave's TN x TM
-// 16x16 accumulator tiles.  Lane (mcol = lane & 15, nq = (lane >> 4) * 4) holds 4 consecutive output
-// channels n0..n0+3 of pixel mrow[j] (< 0: no such pixel).  Every scale / shift vector is loaded up
-// front and the arithmetic is branch-free, so the only vector-memory wait in here is the one for those
-// loads: with the loads inside the per-tile branches the compiler has to drain vmcnt(0) at the top of
-// every tile, i.e. each store waited for the previous store's round trip.
-template <int TN, int TM>
-__device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&acc)[TN][TM], const int nbase,
-                                                 const int nq, const int (&mrow)[TM]) {
-  float4 sc[TN], sh[TN];
-  bool nv[TN];
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    nv[i] = nbase + i * 16 < a.Cout;                     // wave-uniform: Cout is a multiple of 16
-    const int n0 = nv[i] ? nbase + i * 16 + nq : 0;
-    sc[i] = a.scale ? *(const float4*)(a.scale + n0) : make_float4(1.f, 1.f, 1.f, 1.f);
-    sh[i] = a.scale ? *(const float4*)(a.shift + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  const float lo = a.relu ? 0.f : -INFINITY;             // relu as one v_max per value
-  const int esz = a.out_f32 ? 4 : 2;
-  // bf16, plain store, 16-byte aligned pixel rows: pairs of channel tiles are written as 16 B per lane.  A lane
-  // holds channels [4q, 4q+4) of both tiles (q = lane >> 4); v_permlane16_swap exchanges the odd 16-lane rows of
-  // tile i with the even rows of tile i+1, after which rows 0 / 2 hold channels [0,8) / [8,16) of tile i and rows
-  // 1 / 3 the same of tile i+1: half the store instructions, 64 contiguous bytes per pixel instead of 4 x 8.
-  if (!a.out_f32 && !a.accum && (((a.y_cs | a.y_co) & 7) == 0) && TN >= 2) {
-    const int q = nq >> 2;
-    const int choff = (q >> 1) * 8;                       // channel offset inside the lane's tile after the swap
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const bool mok = mrow[j] >= 0;
-      unsigned char* ypix = (unsigned char*)a.y + ((size_t)(mok ? mrow[j] : 0) * a.y_cs + a.y_co + nbase) * 2;
-#pragma unroll
-      for (int i = 0; i + 1 < TN; i += 2) {
-        uint32_t pk[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          float v0 = fmaf(acc[i + t][j][0], sc[i + t].x, sh[i + t].x);
-          float v1 = fmaf(acc[i + t][j][1], sc[i + t].y, sh[i + t].y);
-          float v2 = fmaf(acc[i + t][j][2], sc[i + t].z, sh[i + t].z);
-          float v3 = fmaf(acc[i + t][j][3], sc[i + t].w, sh[i + t].w);
-          asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "s"(lo));
-          asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
-          asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
-          asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
-          pk[t][0] = pack_bf16x2(v0, v1);
-          pk[t][1] = pack_bf16x2(v2, v3);
-        }
-        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-        const int tsel = i + (q & 1);                     // the tile this lane stores
-        const bool ok = mok & ((q & 1) ? nv[i + 1] : nv[i]);
-        if (ok) *(uint4*)(ypix + (tsel * 16 + choff) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-      }
-      if constexpr (TN & 1) {                             // odd tile count: the last one 8 bytes per lane
-        constexpr int i = TN - 1;
-        float v0 = fmaf(acc[i][j][0], sc[i].x, sh[i].x);
-        float v1 = fmaf(acc[i][j][1], sc[i].y, sh[i].y);
-        float v2 = fmaf(acc[i][j][2], sc[i].z, sh[i].z);
-        float v3 = fmaf(acc[i][j][3], sc[i].w, sh[i].w);
-        asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "s"(lo));
-        asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
-        asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
-        asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
-        if (nv[i] & mok) *(uint2*)(ypix + (i * 16 + nq) * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const bool mok = mrow[j] >= 0;
-    // address of this lane's first channel in the pixel row; the tiles along n are 16 channels apart
-    unsigned char* yrow = (unsigned char*)a.y + ((size_t)(mok ? mrow[j] : 0) * a.y_cs + a.y_co + nbase + nq) * esz;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      float v0 = fmaf(acc[i][j][0], sc[i].x, sh[i].x);
-      float v1 = fmaf(acc[i][j][1], sc[i].y, sh[i].y);
-      float v2 = fmaf(acc[i][j][2], sc[i].z, sh[i].z);
-      float v3 = fmaf(acc[i][j][3], sc[i].w, sh[i].w);
-      asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "s"(lo));
-      asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
-      asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
-      asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
-      const bool ok = nv[i] & mok;
-      if (a.out_f32) {
-        float4* yp = (float4*)(yrow + i * 64);
-        if (a.accum) {
-          if (ok) {
-            const float4 o = *yp;
-            v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
-          }
-        }
-        if (ok) *yp = make_float4(v0, v1, v2, v3);
-      } else {
-        uint2* yp = (uint2*)(yrow + i * 32);
-        if (a.accum) {
-          if (ok) {
-            const uint2 o = *yp;
-            v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xFFFF0000u);
-            v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xFFFF0000u);
-          }
-        }
-        if (ok) *yp = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-      }
-    }
-  }
-}
 
 // ALIGNED (Cin % 64 == 0): a whole k-tile lies inside one filter tap, so the tap walk (kh, kw, c0)
 // is wave-uniform scalar state and the per-lane part of a source address is a constant.
@@ -1060,17 +932,6 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   STAMP(3);
 }
 
-// Workgroups are dealt round-robin to the 8 XCDs (workgroup i -> XCD i % 8), each with a private
-// L2.  xcd_tile_index turns the hardware id into a logical tile index such that every XCD owns one
-// CONTIGUOUS range of logical tiles; with the out-channel tile as the fastest logical dimension,
-// all out-channel tiles of a pixel tile (and its halo neighbours) run on the same XCD, so an
-// activation row is pulled from the memory side into exactly one L2 instead of up to 8.
-// The grid is padded to a multiple of 8; ids past `total` exit.
-__device__ __forceinline__ int xcd_tile_index(int total) {
-  const int per = gridDim.x >> 3;
-  const int l = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  return l < total ? l : -1;
-}
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
 __global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_kernel(ConvArgs a) {
@@ -1326,8 +1187,82 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
 
 // Tile of a group: the explicit id of its first member, else the same fill rule as the
 // single-conv heuristic applied to the group's total tile count.
+
+// ---- weight-stationary 1x1 groups (conv_ws.hip) ---------------------------------------------------------------
+// ops[0..n) qualify when they are 1x1 / stride-1 / unpadded convolutions over the SAME source slice (the convs at
+// the head of an Inception block, or a single conv), Cin and the concatenated Cout fit the register-resident
+// weight layout, and -- with COMIC_OP_POOLED_SRC -- every member reads through the same 3x3 / 2 VALID max-pool.
+bool ws_group_eligible(const comic_cnn_op* ops, int n) {
+  if (n < 1 || n > 4) return false;
+  int tiles = 0;
+  for (int j = 0; j < n; ++j) {
+    const comic_cnn_op& o = ops[j];
+    if (o.kind != 0 || o.KH != 1 || o.KW != 1 || o.SH != 1 || o.SW != 1 || o.PT != 0 || o.PL != 0) return false;
+    if (o.src != ops[0].src || o.src_coff != ops[0].src_coff || o.Cin != ops[0].Cin || o.H != ops[0].H ||
+        o.W != ops[0].W || o.Ho != ops[0].Ho || o.Wo != ops[0].Wo || (o.flags & COMIC_OP_POOLED_SRC) != (ops[0].flags & COMIC_OP_POOLED_SRC))
+      return false;
+    if (o.Cout % 16 != 0) return false;
+    tiles += o.Cout / 16;
+  }
+  const comic_cnn_op& o = ops[0];
+  if (o.flags & COMIC_OP_POOLED_SRC) {
+    if (o.Ho != (o.H - 3) / 2 + 1 || o.Wo != (o.W - 3) / 2 + 1) return false;
+  } else if (o.Ho != o.H || o.Wo != o.W) {
+    return false;
+  }
+  return comic_ws_supported(o.Cin, tiles);
+}
+
+int run_ws_group(const comic_cnn_op* ops, int n, void* const* buffers, const int32_t* buf_channels,
+                 const comic_conv_weight* weights, int batch, hipStream_t st) {
+  COMIC_REQUIRE(ws_group_eligible(ops, n), "conv_ws: ops are not an eligible 1x1 group (kind %d, %dx%d, Cin %d)", ops[0].kind,
+                ops[0].KH, ops[0].KW, ops[0].Cin);
+  ComicWsArgs a;
+  memset(&a, 0, sizeof(a));
+  const comic_cnn_op& o = ops[0];
+  const int xc = buf_channels[o.src];
+  COMIC_REQUIRE(buffers[o.src] && o.src_coff + o.Cin <= xc && xc % 8 == 0 && o.src_coff % 8 == 0, "conv_ws: bad source slice");
+  COMIC_REQUIRE((long)batch * o.H * o.W * xc * 2 < (1L << 31), "conv_ws: activation tensor too large");
+  a.x = (const bf16_t*)buffers[o.src];
+  a.B = batch; a.H = o.H; a.W = o.W; a.x_cs = xc; a.x_co = o.src_coff; a.Cin = o.Cin;
+  a.Kpad = (o.Cin + 63) / 64 * 64;
+  a.Ho = o.Ho; a.Wo = o.Wo; a.M = batch * o.Ho * o.Wo;
+  a.pooled = (o.flags & COMIC_OP_POOLED_SRC) ? 1 : 0;
+  a.n_members = n;
+  a.tiles_m = cdiv(a.M, 64);
+  int t0 = 0;
+  for (int j = 0; j < n; ++j) {
+    const comic_cnn_op& q = ops[j];
+    const comic_conv_weight* wt = weights + q.weight;
+    const bool raw = (q.flags & COMIC_OP_RAW) != 0;
+    const int yc = buf_channels[q.dst];
+    COMIC_REQUIRE(wt->w && (raw || (wt->scale && wt->shift)), "conv_ws: missing weights");
+    COMIC_REQUIRE(buffers[q.dst] && q.dst_coff + q.Cout <= yc && q.dst_coff % 4 == 0 && yc % 4 == 0, "conv_ws: bad destination slice");
+    COMIC_REQUIRE((long)a.M * yc < (1L << 31), "conv_ws: output tensor too large");
+    ComicWsMember& m = a.m[j];
+    m.w = (const bf16_t*)wt->w;
+    m.scale = raw ? nullptr : wt->scale;
+    m.shift = raw ? nullptr : wt->shift;
+    m.y = buffers[q.dst];
+    m.y_cs = yc; m.y_co = q.dst_coff; m.cout = q.Cout; m.relu = q.relu; m.out_f32 = q.out_f32;
+    m.tile0 = t0;
+    t0 += q.Cout / 16;
+  }
+  a.n_tiles = t0;
+  if (int rc = comic_ws_launch(a, st)) return rc;
+  COMIC_LAUNCH_CHECK("conv_ws");
+  return 0;
+}
+// WS is the default (tile id 0) for an eligible group with enough pixel tiles to occupy every CU
+bool ws_group_selected(const comic_cnn_op* ops, int n, int batch) {
+  if (!ws_group_eligible(ops, n)) return false;
+  if (ops[0].flags & COMIC_OP_POOLED_SRC) return true;
+  if (ops[0].tile == COMIC_WS_TILE) return true;
+  return ops[0].tile == 0 && (long)batch * ops[0].Ho * ops[0].Wo >= 64L * 256;
+}
+
 int group_tile(const comic_cnn_op* ops, int n, int batch) {
-  if (ops[0].tile > 0 && ops[0].tile <= COMIC_CONV_TILES) return ops[0].tile;
+  if (ops[0].tile > 0 && ops[0].tile < COMIC_WS_TILE) return ops[0].tile;
   bool all128 = true;
   for (int i = 0; i < n; ++i) all128 = all128 && ops[i].Cout % 128 == 0;
   auto blocks = [&](int t) {
@@ -1531,7 +1466,12 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool+bn: destination channel slice out of range");
       const long total = (long)a.M * (op->Cin / 4);
       a.out_f32 = (op->out_f32 || sizeof(T) == 4) ? 1 : 0;
-      hipLaunchKernelGGL(pool_bn_relu_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+      // row-walking form when there are enough rows to occupy the chip (op->tile: 1 forces it, 2 forces the per-pixel form)
+      if (op->tile == 1 || (op->tile == 0 && (long)batch * op->H * (op->Cin / 4) >= 256L * 256))
+        hipLaunchKernelGGL(pool_bn_relu_rows_kernel, dim3((unsigned)cdiv64((long)batch * op->H * (op->Cin / 4), 256)), dim3(256),
+                           0, st, a);
+      else
+        hipLaunchKernelGGL(pool_bn_relu_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
       break;
     }
     default:
@@ -1608,6 +1548,13 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
       ++i;
       continue;
     }
+    if (ws_group_selected(ops + i, n, batch)) {       // conv_ws.hip takes its arguments by value
+      memset(out, 0, sizeof(ConvArgs) * n);
+      out += n;
+      i += n;
+      continue;
+    }
+    COMIC_REQUIRE(ops[i].tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
     const int tile = group_tile(ops + i, n, batch);
     int blk = 0;
     for (int j = 0; j < n; ++j) {
@@ -1646,6 +1593,17 @@ extern "C" int comic_conv2d_bn_relu(const comic_cnn_op* op, const void* x, int x
                                     const comic_conv_weight* wt, int batch, int dtype, void* stream) {
   COMIC_REQUIRE(op, "null op");
   hipStream_t st = (hipStream_t)stream;
+  if (op->kind == 0 && dtype == COMIC_BF16 &&
+      ((op->flags & COMIC_OP_POOLED_SRC) || op->tile == COMIC_WS_TILE || (op->tile == 0 && ws_group_selected(op, 1, batch)))) {
+    // a single 1x1 conv on the weight-stationary kernel (conv_ws.hip): one-member group over a two-entry buffer table
+    comic_cnn_op o = *op;
+    o.src = 0; o.dst = 1; o.weight = 0;
+    void* const bufs[2] = {(void*)x, y};
+    const int32_t chans[2] = {x_channels, y_channels};
+    COMIC_REQUIRE(wt, "conv: missing weights");
+    return run_ws_group(&o, 1, bufs, chans, wt, batch, st);
+  }
+  COMIC_REQUIRE(!(op->kind == 0 && (op->flags & COMIC_OP_POOLED_SRC)), "conv: COMIC_OP_POOLED_SRC needs a bf16 plan");
   if (dtype == COMIC_BF16 && op->src_f32) {
     COMIC_REQUIRE(op->kind == 4 || op->kind == 7, "src_f32 is only supported by the global average pool and pool+bn");
     if (op->kind == 7) return run_op<bf16_t>(op, x, x_channels, y, y_channels, wt, batch, st);
@@ -1715,6 +1673,13 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       COMIC_REQUIRE(dtype == COMIC_BF16 && (op->kind == 0 || op->kind == 7) && op->lane == 0,
                     "grouped launch needs a bf16 plan and conv / pool+bn ops on the caller's stream");
       const int n = group_run(ops, n_ops, i);
+      if (ws_group_selected(op, n, batch)) {
+        if (int rc = run_ws_group(op, n, buffers, buf_channels, weights, batch, main_st)) return rc;
+        gargs += n;
+        i += n - 1;
+        continue;
+      }
+      COMIC_REQUIRE(op->tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
       const int tile = group_tile(op, n, batch);
       long blocks = 0;
       int lds_max = 0;

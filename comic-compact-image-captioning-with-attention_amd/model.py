@@ -52,7 +52,7 @@ class ModelBase(object):
             # frozen CNN (every mode but cnn_finetune): forward-only plan with the pool branches rewritten
             frozen = bool(getattr(c, 'freeze_scopes', 'Model/encoder/cnn'))
             plan = nets.get_network_fn(c.cnn_name, num_classes=None, is_training=False)(
-                tuple(c.cnn_input_size), c.cnn_fm_attention, pool_after_projection=frozen)
+                tuple(c.cnn_input_size), c.cnn_fm_attention, pool_after_projection=frozen, fuse_pools=frozen)
             share['plan'] = plan
             share['cnn_params'] = plan.init_params(seed=c.rand_seed % (2 ** 31))
             fm = plan.fm_dims()

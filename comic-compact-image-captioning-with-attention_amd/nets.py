@@ -112,7 +112,8 @@ class CnnPlan:
     """Flat op list + buffer table for one backbone at one input size."""
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
-                 group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None):
+                 group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None,
+                 fuse_pools=False):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -142,6 +143,13 @@ class CnnPlan:
         # elementwise kernel runs beside the depth-1..4 convs.  Measured slower under hipGraph replay (forward alone
         # 1.17 -> 1.26 ms: a graph with side branches replays slower on this stack), so off by default.
         self.side_pools = bool(side_pools)
+        # second forward-only rewrite (bf16 plans): a 3x3 / 2 max-pool whose only consumers are 1x1 convs
+        # (MaxPool_3a -> Conv2d_3b_1x1, MaxPool_5a -> the four 1x1 convs at the head of Mixed_5b) is folded into
+        # their loads (COMIC_OP_POOLED_SRC, csrc/conv_ws.hip): the pooled map is never written or re-read.
+        self.fuse_pools = bool(fuse_pools)
+        if self.fuse_pools and not (pool_after_projection and name == 'inception_v3'):
+            raise ValueError('fuse_pools needs an inception_v3 plan with pool_after_projection=True')
+        self._pooled_src = None  # (buffer id, pooled H, pooled W) while a folded max-pool waits for its consumers
         self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
         if name == 'chain':
             self._build_chain(image_size, layers)
@@ -159,8 +167,13 @@ class CnnPlan:
         _, name, cout, (kh, kw), stride, pad = spec
         H, W, Cin_p, _ = self.buffers[src]
         Cin = self._logical.get(src, Cin_p)          # channels of the producing variable (the rest is zero padding)
-        Ho, pt = _out(H, kh, stride, pad)
-        Wo, pl = _out(W, kw, stride, pad)
+        pooled = self._pooled_src is not None and self._pooled_src[0] == src
+        if pooled:
+            assert (kh, kw, stride) == (1, 1, 1), 'a folded max-pool feeds 1x1 convs only'
+            Ho, Wo, pt, pl = self._pooled_src[1], self._pooled_src[2], 0, 0
+        else:
+            Ho, pt = _out(H, kh, stride, pad)
+            Wo, pl = _out(W, kw, stride, pad)
         cout_p = (cout + 15) // 16 * 16              # MFMA tile granularity; Inception-V1 has 24-channel reduces
         if dst is None:
             dst = self._buf(Ho, Wo, cout_p, out_f32)
@@ -174,7 +187,7 @@ class CnnPlan:
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
                              Cin=Cin_p, Cout=cout_p, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
                              weight=len(self.weights) - 1, relu=0 if raw else 1, out_f32=int(out_f32), lane=self._lane,
-                             depth=self._depth, flags=1 if raw else 0))
+                             depth=self._depth, flags=(L.OP_RAW if raw else 0) | (L.OP_POOLED_SRC if pooled else 0)))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
 
@@ -344,11 +357,20 @@ class CnnPlan:
         for op in _STEM:
             if op[0] == 'c':
                 cur, _ = self._conv(cur, root, op)
+                self._pooled_src = None
+            elif self.fuse_pools:
+                Hc, Wc = self.buffers[cur][:2]
+                self._pooled_src = (cur, _out(Hc, 3, 2, 'VALID')[0], _out(Wc, 3, 2, 'VALID')[0])
+                continue
             else:
                 cur, _ = self._pool(cur, 2, 3, 2, 'VALID')
             self.end_points[op[1]] = cur
         for bname, branches in INCEPTION_V3_BLOCKS:
             Hi, Wi, Ci, _ = self.buffers[cur]
+            if self._pooled_src is not None:         # the block reads `cur` through the folded MaxPool_5a
+                assert self._pooled_src[0] == cur and all(b[0][0] == 'c' and b[0][3] == (1, 1) or b[0][0] == 'avg'
+                                                          for b in branches)
+                Hi, Wi = self._pooled_src[1:]
             outs = [self._branch_out(b, Hi, Wi, Ci) for b in branches]
             Ho, Wo = outs[0][0], outs[0][1]
             Ctot = sum(o[2] for o in outs)
@@ -394,6 +416,7 @@ class CnnPlan:
                 coff += outs[bi][2]
             self._lane = 0
             self._depth = 0
+            self._pooled_src = None
             if self.group_branches:
                 self._schedule_by_depth(first_op)
             if self.branch_streams:
@@ -443,6 +466,8 @@ class CnnEncoder:
         self.lib = L.load()
         self.plan, self.batch, self.dtype, self.device = plan, batch, dtype, device
         self.dcode = 1 if dtype == 'bf16' else 0
+        if getattr(plan, 'fuse_pools', False) and dtype != 'bf16':
+            raise ValueError('fuse_pools plans run on the bf16 kernels only')
         tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
         self._tdt = tdt
         st = L.stream_ptr()
@@ -724,7 +749,8 @@ class CnnEncoder:
     def _tune_key(self):
         p = self.plan
         H, W = p.buffers[p.input][:2]
-        return '%s:%dx%d:B%d:%s:%dops:polite%d' % (p.name, H, W, self.batch, 'par' if p.pool_after_projection else 'plain',
+        return '%s:%dx%d:B%d:%s%s:%dops:polite%d' % (p.name, H, W, self.batch, 'par' if p.pool_after_projection else 'plain',
+                                                    '+fp' if getattr(p, 'fuse_pools', False) else '',
                                                   len(p.ops), self.polite_lds_kb)
 
     def autotune(self, reps=5, verbose=False, cache=None):
@@ -775,6 +801,13 @@ class CnnEncoder:
                 i += 1
                 continue
             op = self._ops[i]
+            if o.get('flags', 0) & L.OP_POOLED_SRC:   # one kernel serves these (conv_ws.hip): nothing to choose
+                n = 1
+                while i + n < n_ops and op.group > 0 and self._ops[i + n].group == op.group:
+                    n += 1
+                rec += n if (grouped and op.group > 0) else 0
+                i += n
+                continue
             n = 1
             if grouped and op.group > 0:
                 while i + n < n_ops and self._ops[i + n].group == op.group:
@@ -857,8 +890,9 @@ def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
     if is_training:
         raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
 
-    def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False):
+    def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False, fuse_pools=False):
+        par = pool_after_projection and name == 'inception_v3'
         return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'),
-                       pool_after_projection=pool_after_projection and name == 'inception_v3')
+                       pool_after_projection=par, fuse_pools=fuse_pools and par)
     network_fn.default_image_size = 224 if name == 'inception_v1' else 299
     return network_fn

@@ -32,7 +32,8 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 53
+#define COMIC_CONV_TILES 54
+#define COMIC_WS_TILE 54     /* weight-stationary 1x1 group kernel (csrc/conv_ws.hip) */
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -82,7 +83,10 @@ typedef struct comic_cnn_op {
                         is loaded once per tile, only the weight k-tiles stream; 4, 8 or 12 waves per
                         workgroup); 26..47 wide two-stage im2col tiles (128x128 .. 256x256, 4 or 8 waves: less LDS
                         fill per MFMA).  Ids 48..53: patch-resident variants with
-                        loader waves.  An ineligible layer returns an error for ids 13..25 and 48..53.  In a group the
+                        loader waves.  Id 54 (COMIC_WS_TILE): weight-stationary kernel for 1x1 convs / groups of 1x1 convs
+                        over one source with Cin <= 288 and <= 256 output channels in total (all weights in registers,
+                        persistent workgroups, activation tiles streamed once).  An ineligible layer returns an error
+                        for ids 13..25 and 48..54.  In a group the
                         id of the first member applies to all members.  Every variant gives identical bits. */
   int32_t group;     /* conv, bf16 plans: 0 = own launch; ops that are ADJACENT in the table and
                         share a non-zero id are mutually independent (the same-depth convs of
@@ -92,6 +96,9 @@ typedef struct comic_cnn_op {
                         the epilogue is applied by a later kind-7 op */
 } comic_cnn_op;
 #define COMIC_OP_RAW 1
+#define COMIC_OP_POOLED_SRC 2   /* bit 1, 1x1 conv of a bf16 plan: the conv reads its source through a 3x3 / stride-2 VALID
+                                   max-pool (H, W = the un-pooled source, Ho, Wo = the pooled grid); the pooled map is never
+                                   materialised (slim.max_pool2d + slim.conv2d 1x1, inception_v3.py:111-114,124-199) */
 
 typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */

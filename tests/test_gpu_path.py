@@ -66,6 +66,46 @@ def test_inception_v3_pool_after_projection(cnn_params, dtype, tol):
         enc.enable_training()
 
 
+def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
+    """Second forward-only rewrite (bf16): MaxPool_3a / MaxPool_5a folded into the loads of the 1x1 convs behind them
+    and the thin 1x1 groups of Mixed_5b-d on the weight-stationary kernel (csrc/conv_ws.hip; reference
+    inception_v3.py:111-114,124-199): against the oracle, and bit for bit against the plain forward-only plan with
+    every conv on an im2col tile (same k order per accumulator, exact max).  Ragged batch: the last 64-pixel tile of
+    every layer is partial."""
+    B = 3
+    x = np.random.default_rng(12).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    pa = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    pb = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    assert sum(1 for o in pb.ops if o['kind'] == 2) == sum(1 for o in pa.ops if o['kind'] == 2) - 2
+    assert sum(1 for o in pb.ops if o.get('flags', 0) & 2) == 5 and pb.macs == pa.macs
+    ea = nets.CnnEncoder(pa, cnn_params, B, 'bf16', DEV)
+    eb = nets.CnnEncoder(pb, cnn_params, B, 'bf16', DEV, weights_from=ea)
+    for i, o in enumerate(pa.ops):
+        if o['kind'] == 0:
+            ea._ops[i].tile = 3                    # 64x64 im2col tile everywhere
+    for i, o in enumerate(pb.ops):                 # batch 3 is below the default's size threshold: ask for the kernel
+        if o['kind'] == 0 and o['KH'] == 1 and o['Cin'] in (256, 288) and o['Ho'] == 25:
+            eb._ops[i].tile = nets.L.WS_TILE
+    for e, plan in ((ea, pa), (eb, pb)):           # the row-walking pool + BN + ReLU kernel (default only at large batches)
+        for i, o in enumerate(plan.ops):
+            if o['kind'] == 7:
+                e._ops[i].tile = 1
+    ea._build_group_args()
+    eb._build_group_args()
+    ima, fma = (t.clone() for t in ea.forward(dev(x)))
+    imb, fmb = eb.forward(dev(x))
+    sync()
+    net_ref, ep = cnn_ref.inception_v3(cnn_params, x, act_dtype='bf16')
+    for name in ('Conv2d_3b_1x1', 'Mixed_5b', 'Mixed_5c', 'Mixed_5d', 'Mixed_6c', 'Mixed_7b'):
+        assert_close(eb.end_point(name).float().cpu().numpy(), ep[name], 3e-2, name)
+        assert torch.equal(eb.end_point(name).view(torch.int16), ea.end_point(name).view(torch.int16)), name
+    assert torch.equal(fma, fmb) and torch.equal(ima, imb)
+    with pytest.raises(ValueError):
+        nets.CnnEncoder(pb, cnn_params, B, 'f32', DEV)
+    with pytest.raises(ValueError):
+        nets.CnnPlan('inception_v3', (224, 224), fuse_pools=True)
+
+
 def test_inception_v3_forward_299_f32():
     """The north-star's 8x8x2048 feature map needs 299x299 inputs."""
     params = cnn_ref.randomize_bn(cnn_ref.init_params(3, 299), seed=4)

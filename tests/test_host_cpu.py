@@ -51,7 +51,9 @@ def test_conv_variant_ids_match_header():
     im2col = [t for t in range(1, L.CONV_TILES + 1) if L.is_im2col_tile(t)]
     patch = [t for t in range(1, L.CONV_TILES + 1) if not L.is_im2col_tile(t)]
     assert im2col == list(range(1, 13)) + list(range(26, 48))
-    assert patch == list(range(13, 26)) + list(range(48, 54))
+    assert patch == list(range(13, 26)) + list(range(48, 54)) + [L.WS_TILE]     # may-refuse ids (incl. the 1x1 weight-stationary kernel)
+    assert int(re.search(r'#define COMIC_WS_TILE (\d+)', header).group(1)) == L.WS_TILE
+    assert int(re.search(r'#define COMIC_OP_POOLED_SRC (\d+)', header).group(1)) == L.OP_POOLED_SRC
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,14 +1,17 @@
 """Per-launch timing of the InceptionV3 plan (after autotune): every op or group on its own, HIP events."""
 import os, sys, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from comic_amd import nets, _lib as L
 B = int(os.environ.get('B', '64'))
-plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (224, 224), pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1')
+plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (int(os.environ.get('IMG', '224')),) * 2,
+                    pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1',
+                    fuse_pools=os.environ.get('FUSE', '1') == '1')
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
-    enc.autotune()
-x = torch.rand(B, 224, 224, 3, device='cuda:0') * 2 - 1
+    enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE'))
+IMG = int(os.environ.get('IMG', '224'))
+x = torch.rand(B, IMG, IMG, 3, device='cuda:0') * 2 - 1
 for _ in range(3):
     enc.forward(x)
 torch.cuda.synchronize()
