@@ -16,6 +16,7 @@
 // k-permutation so the sum over k is unchanged).
 #include "conv_common.h"
 #include "conv_ws.h"
+#include "conv_stem.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -1710,6 +1711,38 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       COMIC_REQUIRE(lanes && op->lane <= 3, "branch lane %d outside a fork/join region", op->lane);
       st = lanes->s[op->lane - 1];
       used[op->lane - 1] = true;
+    }
+    if (op->kind == 8) {      // streaming Conv2d_2a -> Conv2d_2b -> MaxPool_3a (conv_stem.hip); weights[op->weight], [op->weight + 1]
+      COMIC_REQUIRE(dtype == COMIC_BF16 && op->lane == 0, "stem stream: bf16 plans on the caller's stream only");
+      COMIC_REQUIRE(op->Cin == 32 && op->Cout == 64 && op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1,
+                    "stem stream: expects the 32 -> 32 -> 64 3x3 stem (got Cin %d, Cout %d)", op->Cin, op->Cout);
+      COMIC_REQUIRE(comic_stem_stream_supported(op->H, op->W), "stem stream: map %dx%d is not supported", op->H, op->W);
+      const int Hp = (op->H - 2 - 3) / 2 + 1, Wp = (op->W - 2 - 3) / 2 + 1;
+      COMIC_REQUIRE(op->Ho == Hp && op->Wo == Wp, "stem stream: Ho/Wo must be the pooled grid %dx%d", Hp, Wp);
+      const comic_conv_weight* wa = weights + op->weight;
+      const comic_conv_weight* wb = weights + op->weight + 1;
+      const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
+      COMIC_REQUIRE(buffers[op->src] && buffers[op->dst] && wa->w && wb->w && wa->scale && wa->shift && wb->scale && wb->shift,
+                    "stem stream: null buffer / weights");
+      COMIC_REQUIRE(op->src_coff + 32 <= xc && xc % 8 == 0 && op->src_coff % 8 == 0 && op->dst_coff + 64 <= yc &&
+                        yc % 4 == 0 && op->dst_coff % 4 == 0, "stem stream: bad channel slices");
+      COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31) && (long)batch * Hp * Wp * yc * 2 < (1L << 31),
+                    "stem stream: tensor too large");
+      ComicStemArgs sa;
+      sa.x = (const bf16_t*)buffers[op->src];
+      sa.B = batch; sa.H0 = op->H; sa.W0 = op->W; sa.x_cs = xc; sa.x_co = op->src_coff;
+      sa.w1 = (const bf16_t*)wa->w; sa.w2 = (const bf16_t*)wb->w; sa.Kpad = (9 * 32 + 63) / 64 * 64;
+      sa.sc1 = wa->scale; sa.sh1 = wa->shift; sa.sc2 = wb->scale; sa.sh2 = wb->shift;
+      sa.y = (bf16_t*)buffers[op->dst]; sa.y_cs = yc; sa.y_co = op->dst_coff; sa.Hp = Hp; sa.Wp = Wp;
+      sa.n_tasks = 2 * batch;
+      {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("COMIC_STEM_DBG"); dbg = e ? atoi(e) : 0; }
+        sa.dbg = dbg;
+      }
+      if (int rc = comic_stem_stream_launch(sa, main_st)) return rc;
+      COMIC_LAUNCH_CHECK("stem stream");
+      continue;
     }
     const comic_conv_weight* wt = (op->kind <= 1 || op->kind == 7) ? weights + op->weight : nullptr;
     int rc = comic_conv2d_bn_relu(op, buffers[op->src], buf_channels[op->src], buffers[op->dst],

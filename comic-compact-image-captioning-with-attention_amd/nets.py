@@ -100,6 +100,11 @@ INCEPTION_V1_BLOCKS = [
 ]
 
 
+def stem_stream_supported(H0, W0):
+    """Mirror of comic_stem_stream_supported (csrc/conv_stem.hip): two waves x four tiles x seven pooled columns."""
+    return H0 >= 7 and W0 >= 7 and (W0 - 2 - 3) // 2 + 1 <= 56
+
+
 def _out(size, k, s, pad):
     if pad == 'SAME':
         o = -(-size // s)
@@ -190,6 +195,29 @@ class CnnPlan:
                              depth=self._depth, flags=(L.OP_RAW if raw else 0) | (L.OP_POOLED_SRC if pooled else 0)))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
+
+    @staticmethod
+    def _stem_dims(H, W):
+        """(H0, W0) of Conv2d_1a_3x3's output (3x3 / 2 VALID) for an H x W image."""
+        return _out(H, 3, 2, 'VALID')[0], _out(W, 3, 2, 'VALID')[0]
+
+    def _stem_stream(self, src, scope, spec_a, spec_b):
+        """kind 8: conv 3x3 VALID 32 -> 32, conv 3x3 SAME 32 -> 64 (+ BN + ReLU each), max-pool 3x3 / 2 VALID in one
+        streaming pass; the weight records of the two convs are adjacent."""
+        H0, W0, Cin, _ = self.buffers[src]
+        assert Cin == 32 and spec_a[2:] == (32, (3, 3), 1, 'VALID') and spec_b[2:] == (64, (3, 3), 1, 'SAME')
+        H1, W1 = H0 - 2, W0 - 2
+        Hp, Wp = _out(H1, 3, 2, 'VALID')[0], _out(W1, 3, 2, 'VALID')[0]
+        dst = self._buf(Hp, Wp, 64)
+        self.weights.append((scope + '/' + spec_a[1], 3, 3, 32, 32, False))
+        self.wphys.append((32, 32))
+        self.weights.append((scope + '/' + spec_b[1], 3, 3, 32, 64, False))
+        self.wphys.append((32, 64))
+        self.ops.append(dict(kind=8, src=src, dst=dst, src_coff=0, dst_coff=0, H=H0, W=W0, Cin=32, Cout=64, KH=3, KW=3,
+                             SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=len(self.weights) - 2, relu=1, out_f32=0,
+                             lane=0, depth=0))
+        self.macs += H1 * W1 * 9 * 32 * 32 + H1 * W1 * 9 * 32 * 64
+        return dst
 
     def _pool_bn_relu(self, src, weight, dst, dst_coff, out_f32):
         """kind 7: 3x3 s1 SAME average of the fp32 map `src` + BN (weight record `weight`) + ReLU -> dst slice."""
@@ -354,7 +382,15 @@ class CnnPlan:
         cur = self._buf(H, W, 3, True)          # fp32 images in [-1, 1]
         self.input = cur
         root = 'InceptionV3'
-        for op in _STEM:
+        stem = list(_STEM)
+        if self.fuse_pools and stem_stream_supported(*self._stem_dims(H, W)):
+            # Conv2d_2a -> Conv2d_2b -> MaxPool_3a as one streaming op (kind 8, csrc/conv_stem.hip)
+            cur, _ = self._conv(cur, root, stem[0])
+            self.end_points[stem[0][1]] = cur
+            cur = self._stem_stream(cur, root, stem[1], stem[2])
+            self.end_points[stem[3][1]] = cur
+            stem = stem[4:]
+        for op in stem:
             if op[0] == 'c':
                 cur, _ = self._conv(cur, root, op)
                 self._pooled_src = None

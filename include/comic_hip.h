@@ -66,7 +66,12 @@ typedef struct comic_cnn_op {
                           folded BatchNorm of weight record `weight` and ReLU: the second half of an
                           Inception pool branch whose 1x1 projection was applied BEFORE the pool
                           (both are linear and act on different axes, so they commute; the pool then
-                          runs on Cout instead of Cin channels) */
+                          runs on Cout instead of Cin channels)
+                        8 (bf16 plans) streaming stem: conv 3x3 VALID 32 -> 32 (weight record `weight`), conv 3x3
+                          SAME 32 -> 64 (record `weight` + 1), each + BatchNorm + ReLU, then max-pool 3x3 / 2 VALID,
+                          as ONE line-buffered pass (csrc/conv_stem.hip; inception_v3.py:104-111): H, W = the source
+                          map, Cin 32, Cout 64, KH = KW = 3, Ho, Wo = the pooled grid; the two intermediate maps
+                          are never materialised */
   int32_t src, dst;  /* indices into the buffer table */
   int32_t src_coff, dst_coff; /* channel offsets inside src/dst (concat without a copy) */
   int32_t H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;
