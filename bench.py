@@ -83,6 +83,19 @@ def extras(device, enc, cnn_params, plan):
     dt = (time.perf_counter() - t0) / n
     out['beam3_captions_per_sec'] = round(B / dt, 1)
     out['beam3_config'] = 'word tokens V=25599, 1 head, fm_projection none, batch 50, max 30 steps, %d steps executed' % r['predicted_ids'].shape[0]
+    # decode loop alone against the HBM roofline of the vocabulary projection (per step D*V*s bytes of
+    # W_o + rows*V*4 bytes of logits; s = 4: the decoder is fp32)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+    torch.cuda.synchronize()
+    steps_ex = int(r['predicted_ids'].shape[0])
+    us_step = (time.perf_counter() - t0) / n / steps_ex * 1e6
+    bytes_step = spec.D * V * 4 + B * 3 * V * 4
+    out['beam3_roofline'] = {'bound': 'hbm', 'bytes_per_step': bytes_step, 'us_per_step': round(us_step, 1),
+                             'achieved': round(bytes_step / us_step / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': round(bytes_step / us_step / 1e3 / 8000.0, 4),
+                             'note': 'whole decode step (LSTM, attention, logits GEMM, chunked top-k) over the logits bytes'}
     del dec, enc50
     # ---- SCST step, COMIC-256 -------------------------------------------------------------
     Bs, W = 32, 7
@@ -127,6 +140,7 @@ def extras(device, enc, cnn_params, plan):
         scst_step()
     torch.cuda.synchronize()
     out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
+    out['scst_conv_mfma_frac'] = round(out['scst_images_per_sec'] * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
     out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-hypothesis step (encoder once, features tiled)'
     del enc_s, dec, opt
     torch.cuda.empty_cache()
@@ -150,6 +164,36 @@ def extras(device, enc, cnn_params, plan):
     out['cnn_finetune_images_per_sec'] = round(Bf * n / (time.perf_counter() - t0), 1)
     out['cnn_finetune_config'] = ('COMIC-256 + InceptionV3 trainable (94 conv weights + BN betas, bf16 activations / '
                                   'fp32 masters), batch 32, 224x224; loss %.4f' % float(res['loss']))
+    # forward + backward-data + backward-weight = 3x the forward conv FLOPs per image
+    out['cnn_finetune_conv_mfma_frac'] = round(out['cnn_finetune_images_per_sec'] * 3 * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
+    del tr
+    torch.cuda.empty_cache()
+    # ---- decoder-mode XE at 299 x 299: the north star's 8x8x2048 map (M = 64), batch 64, serial steps ----------------
+    plan299 = nets.CnnPlan('inception_v3', (299, 299), pool_after_projection=True, fuse_pools=True)
+    tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(M=64), None, BATCH, (299, 299), 'bf16', device, seed=6, plan=plan299)
+    if tune:
+        tr.encoder.autotune()
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (BATCH, 299, 299, 3)).astype(np.float32)).to(device)
+    caps = synth_captions(rng, BATCH)
+    for _ in range(3):
+        tr.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    n, t0 = 10, time.perf_counter()
+    for _ in range(n):
+        res = tr.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        tr.encoder.forward(imgs, use_graph=True)
+    e1.record(); e1.synchronize()
+    fwd_ms = e0.elapsed_time(e1) / 5
+    flop299 = 2 * plan299.macs
+    out['xe_299'] = {'images_per_sec': round(BATCH / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'feature_map': '8x8x2048 (M = 64)',
+                     'config': 'COMIC-256, InceptionV3 frozen, batch 64, 299x299x3, one forward per step (no grouping, no overlap)',
+                     'cnn_forward_ms': round(fwd_ms, 3), 'flop_per_image': flop299,
+                     'cnn_mfma_frac': round(flop299 * BATCH / (fwd_ms * 1e-3) / PEAK_BF16_MFMA, 5), 'loss': round(float(res['loss']), 4)}
     return out
 
 
@@ -209,9 +253,29 @@ def cpu_baseline(seconds_budget=20.0):
         if time.time() - t0 > seconds_budget or n >= 8:
             break
     dt = time.time() - t0
-    return dict(value=round(n * B / dt, 3), unit='images/sec', cores=os.cpu_count(), kind='port',
-                sample='%d decoder-mode XE steps at batch %d (InceptionV3 fwd + decoder fwd/bwd + SGD update), '
-                       'numpy/OpenBLAS oracle on all host cores' % (n, B))
+    out = dict(value=round(n * B / dt, 3), unit='images/sec', cores=os.cpu_count(), kind='port',
+               sample='%d decoder-mode XE steps at batch %d (InceptionV3 fwd + decoder fwd/bwd + SGD update), '
+                      'numpy/OpenBLAS oracle on all host cores' % (n, B))
+    # the "framework CPU path" stand-in of BASELINE.md section 3.2(b): the same step on torch-CPU (oneDNN convolutions,
+    # autograd backward of the decoder, TF-Adam), fp32 -- the literal TF-1 binary is not installable here
+    try:
+        import torch
+        from oracle import torch_ref
+        p32 = {k: v.astype(np.float32) for k, v in dr.init_params(cfg, 0).items()}
+        state = None
+        torch_ref.torch_train_step(params, p32, cfg, x, caps, state=None)          # warm-up (oneDNN primitive caches)
+        m, t1 = 0, time.time()
+        while True:
+            _, state = torch_ref.torch_train_step(params, p32, cfg, x, caps, state=state)
+            m += 1
+            if time.time() - t1 > 10.0 or m >= 8:
+                break
+        out['torch_cpu'] = dict(value=round(m * B / (time.time() - t1), 3), unit='images/sec', threads=torch.get_num_threads(),
+                                sample='%d steps at batch %d: torch %s CPU, oneDNN conv forward + autograd decoder backward + '
+                                       'TF-Adam, fp32' % (m, B, torch.__version__))
+    except Exception as e:
+        out['torch_cpu'] = {'error': repr(e)}
+    return out
 
 
 def pick_encoder_group(steps):
@@ -270,7 +334,12 @@ def main():
     if world > 1:
         dist.broadcast(tr.decoder.params.data, 0)
     rng = np.random.default_rng(48964896 + rank)                # train.py:203 seed
-    images = torch.from_numpy(rng.uniform(-1, 1, (ENC_BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+    # N_IMG_SETS distinct image groups (resident in HBM) are served in rotation, so consecutive encoder forwards do not
+    # re-read the same 385 MB; each forward starts with a device-to-device copy into the encoder's input buffer
+    N_IMG_SETS = max(1, int(os.environ.get('COMIC_IMG_SETS', '2')))
+    image_sets = [torch.from_numpy(rng.uniform(-1, 1, (ENC_BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+                  for _ in range(N_IMG_SETS)]
+    images = image_sets[0]
     cap_sets = [synth_captions(rng, BATCH) for _ in range(4)]
 
     def barrier():
@@ -278,30 +347,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # XE is normalised by the GLOBAL token count: one scalar all-reduce per caption set, done here
-    # during setup (the four synthetic sets repeat), so the timed loop has no host synchronisation
-    denoms = [None] * len(cap_sets)
-    if world > 1:
-        for j, c in enumerate(cap_sets):
-            denoms[j] = dp.global_tokens(float((c[:, 1:] >= 0).sum()), device) / world + 1e-12
+    # XE is normalised by the GLOBAL token count: every step all-reduces its token count as a device
+    # scalar on the stream (Decoder.train_step(dp=...)); the host never waits for it
     tr.use_graph = GRAPH_CNN and GRAPH_DEC
     if overlap:
         tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))
-    # the image batch lives in the encoder's input buffer (inputs resident in HBM)
+    # the image groups live in HBM; a forward copies its group into the encoder's input buffer (device to device)
     tr.encoder.bufs[plan.input].copy_(images)
     # COMIC_BENCH_H2D=1 (not the headline line): every group's images come from pinned host memory over PCIe, copied
     # on the encoder's stream in front of its forward -- the PCIe-inclusive rate noted in DESIGN.md §5
     h2d = os.environ.get('COMIC_BENCH_H2D', '0') == '1' and overlap and GROUP > 1
     images_host = images.cpu().pin_memory() if h2d else None
-    images = tr.encoder.bufs[plan.input]
+    inbuf = tr.encoder.bufs[plan.input]
+    n_sub = [0]
+
+    def next_images():
+        n_sub[0] += 1
+        return image_sets[n_sub[0] % N_IMG_SETS]
 
     def submit(evp=None):
         if h2d:
             side = tr._pipe.side
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                images.copy_(images_host, non_blocking=True)
-        tr.submit_images(images, evp)
+                inbuf.copy_(images_host, non_blocking=True)
+            tr.submit_images(inbuf, evp)
+        else:
+            tr.submit_images(next_images(), evp)
     # setup (untimed, like the autotune): the encoder's hipGraph is captured on its second call and the decoder
     # allocates its buffers per caption shape on first use -- neither belongs to a timed step, whatever --warmup is.
     # No optimiser step here: the parameters the W warmup / K timed steps train are untouched.
@@ -337,7 +409,7 @@ def main():
                 if release():
                     submit(ev[n_fwd[0]] if EVENTS else None)
                     n_fwd[0] += 1
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denoms[i % 4], use_graph=GRAPH_DEC,
+            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
                                         on_inputs_consumed=consumed)
         elif overlap:
             n_fwd[0] += 1
@@ -349,24 +421,22 @@ def main():
                 tr._side.wait_event(tr._ev_used)
                 with torch.cuda.stream(tr._side):
                     if EVENTS: ev[i][0].record(tr._side)
-                    tr._pending = tr.encoder.forward(images, use_graph=GRAPH_CNN)
+                    tr._pending = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
                     if EVENTS: ev[i][1].record(tr._side)
                     tr._ev_cnn.record(tr._side)
             torch.cuda.current_stream().wait_event(tr._ev_cnn)
             im_embed, fm = tr._pending
-            denom = denoms[i % 4]
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC,
+            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
                                         on_inputs_consumed=consumed)
         else:
             j = i % GROUP
             if j == 0:                      # serial: the forward of this group of steps, then its decoder steps
                 if EVENTS: ev[n_fwd[0]][0].record()
-                feats = tr.encoder.forward(images, use_graph=GRAPH_CNN)
+                feats = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
                 if EVENTS: ev[n_fwd[0]][1].record()
                 n_fwd[0] += 1
             im_embed, fm = feats[0][j * BATCH:(j + 1) * BATCH], feats[1][j * BATCH:(j + 1) * BATCH]
-            denom = denoms[i % 4]
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=GRAPH_DEC)
+            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC)
         scale = dp.average_(tr.decoder.grads.data)
         tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
         if STEP_TIMES is not None:
@@ -389,8 +459,8 @@ def main():
     for _ in range(3):
         tr.encoder.forward(images, use_graph=GRAPH_CNN)
     iso = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-    for a, b in iso:
-        a.record(); tr.encoder.forward(images, use_graph=GRAPH_CNN); b.record()
+    for a, b in iso:      # the input buffer already holds a group: the forward itself, no copy
+        a.record(); tr.encoder.forward(inbuf, use_graph=GRAPH_CNN); b.record()
     torch.cuda.synchronize()
     cnn_iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso]))
     loss = float(res['loss'])
@@ -416,7 +486,8 @@ def main():
                        'per_gpu_batch': BATCH, 'global_batch': BATCH * world, 'image_size': IMG,
                        'feature_map': '5x5x2048', 'decoder_dtype': 'f32', 'parallelism': 'dp%d' % world,
                        'encoder_group': GROUP, 'encoder_forwards_in_timed_region': n_fwd[0],
-                       'inputs': 'pinned host memory, H2D copy per group inside the timed region' if h2d else 'resident in HBM'},
+                       'inputs': 'pinned host memory, H2D copy per group inside the timed region' if h2d else
+                                 'resident in HBM, %d distinct image groups in rotation' % N_IMG_SETS},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma / conv_patch (+ _grouped) kernels <bf16> (%d convs in %d '
                                                     'launches per forward of %d images, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch, ENC_BATCH),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',

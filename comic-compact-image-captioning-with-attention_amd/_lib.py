@@ -101,6 +101,9 @@ _SIGS = {
     'comic_gather_tree': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'comic_adam_tf': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     'comic_colsum': (c_int, [P, P, c_int, c_int, c_float, P]),
+    'comic_ln_tanh_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
+    'comic_ln_tanh_bwd_rows': (c_int, [P, P, P, P, P, c_int, c_int, P]),
+    'comic_momentum_tf': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
     'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),

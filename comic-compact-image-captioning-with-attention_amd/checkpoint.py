@@ -77,17 +77,17 @@ def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None,
 
 
 def latest_checkpoint(directory, prefix='model'):
-    """tf.train.latest_checkpoint counterpart: the newest `<prefix>-N.npz`, else the newest TF
-    bundle `<prefix>-N.index` (returned as its prefix path)."""
+    """tf.train.latest_checkpoint counterpart: the `<prefix>-N.npz` file or TF bundle `<prefix>-N.index` (returned as its
+    prefix path) with the highest step N."""
+    best = None
     for ext in (r'\.npz', r'\.index'):
         pat = re.compile(r'^%s-(\d+)%s$' % (re.escape(prefix), ext))
-        best = None
         for f in os.listdir(directory):
             m = pat.match(f)
-            if m and (best is None or int(m.group(1)) > best[0]):
+            if m and (best is None or int(m.group(1)) > best[0]):       # the highest step wins, whatever its container
                 best = (int(m.group(1)), os.path.join(directory, f))
-        if best:
-            return best[1] if best[1].endswith('.npz') else best[1][:-len('.index')]
+    if best:
+        return best[1] if best[1].endswith('.npz') else best[1][:-len('.index')]
     return None
 
 
@@ -131,17 +131,28 @@ def adam_from_tf(dec_spec, arrays):
             {k: arrays[ADAM_SCOPE + n + '/Adam_1'] for k, n in names.items()})
 
 
-def restore(path, cnn_param_names, dec_spec, resume_training=False, exclude_scopes=None):
+def restore(path, cnn_param_names, dec_spec, resume_training=False, exclude_scopes=None, head_names='unset'):
     """ModelBase.restore_model logic: returns (cnn_params | None, dec_params | None, extra).
     * every model variable present -> whole `Model/` (and, when resuming, step + Adam slots)
-    * otherwise -> CNN only, names with the `Model/encoder/cnn/` prefix stripped (slim ckpt)."""
-    arrays = load(path)
+    * otherwise -> CNN only, names with the `Model/encoder/cnn/` prefix stripped (slim ckpt).
+    head_names (a list of further `Model/` variable names, or None: the legacy encoder head, model_base.py:80-91):
+    when given, they count as model variables and a 4-tuple (cnn, dec, extra, head arrays | None) is returned."""
+    if head_names != 'unset':
+        hn = list(head_names or [])
+        arrays = load(path)
+        r = _restore(arrays, path, cnn_param_names, dec_spec, resume_training, exclude_scopes, hn)
+        head = {n: arrays[n] for n in hn} if (r[1] is not None and hn) else None
+        return r + (head,)
+    return _restore(load(path), path, cnn_param_names, dec_spec, resume_training, exclude_scopes, [])
+
+
+def _restore(arrays, path, cnn_param_names, dec_spec, resume_training, exclude_scopes, more_model_vars):
     exc = [s.strip() for s in (exclude_scopes or '').split(',') if s.strip()]
 
     def excluded(name):
         return any(re.search(e, name) for e in exc)
     names = decoder_var_names(dec_spec)
-    model_vars = [CNN_SCOPE + n for n in cnn_param_names] + list(names.values())
+    model_vars = [CNN_SCOPE + n for n in cnn_param_names] + list(names.values()) + list(more_model_vars)
     if all(v in arrays for v in model_vars):
         cnn = {n: arrays[CNN_SCOPE + n] for n in cnn_param_names if not excluded(CNN_SCOPE + n)}
         dec = {k: arrays[v] for k, v in names.items() if not excluded(v)}

@@ -686,6 +686,71 @@ __global__ void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ 
   w[i] = wi - (mi * lr_t) / (sqrtf(vi) + eps);
 }
 
+// ---- legacy encoder head (model_base.py:80-91): y = tanh(LayerNorm(x) * gamma + beta), eps 1e-12, over the last axis ----
+// One workgroup per row; xhat is kept for the backward.  C <= 8 * 256.
+__global__ __launch_bounds__(256) void ln_tanh_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          float* __restrict__ xhat, int C, float eps) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xr = x + (size_t)b * C;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    v[i] = c < C ? xr[c] : 0.f;
+    s += v[i];
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    const float d = c < C ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float var = (red[4] + red[5] + red[6] + red[7]) / (float)C;     // biased variance (tf.nn.moments)
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i;
+    if (c < C) {
+      const float xh = (v[i] - mean) * rstd;
+      xhat[(size_t)b * C + c] = xh;
+      y[(size_t)b * C + c] = tanhf(xh * gamma[c] + beta[c]);
+    }
+  }
+}
+// rows of the parameter gradients: pg[b][c] = dy * (1 - y^2) * xhat, pb[b][c] = dy * (1 - y^2) (column sums follow)
+__global__ void ln_tanh_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                        const float* __restrict__ xhat, float* __restrict__ pg, float* __restrict__ pb,
+                                        long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t = dy[i] * (1.f - y[i] * y[i]);
+  pg[i] = t * xhat[i];
+  pb[i] = t;
+}
+
+// tf.train.MomentumOptimizer (use_nesterov=False), ApplyMomentum [TF-1.9]: accum = momentum*accum + g; w -= lr*accum
+__global__ void momentum_tf_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ accum, long n,
+                                   float lr, float momentum, float l2, float gscale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float wi = w[i];
+  const float ge = g[i] * gscale + l2 * wi;
+  const float ai = accum[i] * momentum + ge;
+  accum[i] = ai;
+  w[i] = wi - lr * ai;
+}
+
 // out[j] = beta*out[j] + sum_i in[i*cols+j]; one thread per column (coalesced over j)
 __global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, float beta) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -959,6 +1024,33 @@ extern "C" int comic_adam_tf(float* w, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
                      (long)n, lr_t, beta1, beta2, eps, l2, gscale);
   COMIC_LAUNCH_CHECK("adam_tf");
+  return 0;
+}
+
+extern "C" int comic_ln_tanh_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat, int B,
+                                 int C, float eps, void* stream) {
+  COMIC_REQUIRE(x && gamma && beta && y && xhat && B > 0 && C > 0 && C <= 2048, "ln_tanh_fwd: bad arguments (C %d)", C);
+  hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, xhat, C, eps);
+  COMIC_LAUNCH_CHECK("ln_tanh_fwd");
+  return 0;
+}
+
+extern "C" int comic_ln_tanh_bwd_rows(const float* dy, const float* y, const float* xhat, float* pgamma, float* pbeta,
+                                      int B, int C, void* stream) {
+  COMIC_REQUIRE(dy && y && xhat && pgamma && pbeta && B > 0 && C > 0, "ln_tanh_bwd_rows: bad arguments");
+  const long n = (long)B * C;
+  hipLaunchKernelGGL(ln_tanh_bwd_rows_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                     xhat, pgamma, pbeta, n);
+  COMIC_LAUNCH_CHECK("ln_tanh_bwd_rows");
+  return 0;
+}
+
+extern "C" int comic_momentum_tf(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
+                                 float gscale, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(momentum_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, accum,
+                     (long)n, lr, momentum, l2, gscale);
+  COMIC_LAUNCH_CHECK("momentum_tf");
   return 0;
 }
 

@@ -226,6 +226,7 @@ class Decoder:
         self._ws = None
         self._ws_bytes = 0
         self._dropout_calls = 0
+        self.set_dropout_stream(seed, 0)
         self._ctx = {}
 
     # ------------------------------------------------------------------ helpers --------
@@ -317,6 +318,13 @@ class Decoder:
         self._ctx[key] = ctx
         return ctx
 
+    def set_dropout_stream(self, seed, rank=0):
+        """Base of the per-step dropout seeds: a function of the run's seed (tf.set_random_seed(rand_seed), train_fn.py:35)
+        and of the data-parallel rank, so that runs 1/2/3 and the ranks of one run draw different masks."""
+        x = (int(seed) & 0xFFFFFFFF) * 0x9E3779B97F4A7C15 + (int(rank) + 1) * 0xBF58476D1CE4E5B9
+        x ^= x >> 31
+        self._dropout_base = (x * 0x94D049BB133111EB) & 0x3FFFFFFFFFFFFFFF
+
     def _train_device(self, ctx):
         """Device-only part of a training step (no host sync, no host memcpy): capturable."""
         torch, s = self.torch, self.spec
@@ -342,13 +350,16 @@ class Decoder:
                                                ctx.loss.data_ptr(), st), 'weighted_sum_tb')
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
-                   want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None):
+                   want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None, dp=None):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
         mean_b(xent_b * reward_b) (model_base.py:342-347).
         xe_denom: override of the XE normaliser sum(w)+1e-12 (data parallel: global token count / world size,
         so that the rank-mean of the gradients equals the single-process gradient of the global batch).
+        dp: a trainer.DataParallel with world > 1 -> the same normaliser formed ON THE DEVICE: the token count of
+        this rank's batch is summed from the staged mask, all-reduced on the stream, and the per-token coefficients
+        the kernels read are rescaled in place -- no host synchronisation in the step.
         use_graph: replay the step from a hipGraph captured per (B, T, T') shape (the second call with
         a shape captures it) -- removes the ~450 host launches of a step from the critical path.
         Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device views
@@ -379,12 +390,17 @@ class Decoder:
         if gen_masks:
             if seed is None:
                 self._dropout_calls += 1
-                seed = 0x9E3779B9 + self._dropout_calls
+                seed = (self._dropout_base + self._dropout_calls) & 0x7FFFFFFFFFFFFFFF
             slot.seed[0] = int(seed)
         ctx.stage_dev.copy_(slot.buf, non_blocking=True)
         if masks is not None:
             for k, v in masks.items():
                 ctx.masks[k].copy_(v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v, np.float32)))
+        if dp is not None and dp.world > 1 and rewards is None:
+            f = ctx.f32                                  # device views [wmask | coef | row scale]
+            inv = 1.0 / dp.global_xe_denominator(f[:BT])
+            torch.mul(f[:BT], inv, out=f[BT:2 * BT])
+            f[2 * BT:3 * BT] = inv
         if slot.copied is None:
             slot.copied = torch.cuda.Event()
         slot.copied.record(torch.cuda.current_stream())

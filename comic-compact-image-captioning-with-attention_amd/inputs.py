@@ -266,6 +266,12 @@ class InputManager(object):
         self.config = c = config
         self.is_inference = is_inference
         self._rng = random.Random(c.rand_seed)            # random.seed(c.rand_seed), :58
+        # data parallel (config.dp_world ranks): every rank shuffles with the SAME stream and takes every dp_world-th
+        # item, so the shards are disjoint and their union is the single-process order; the augmentation draws come
+        # from a per-rank stream (they must not advance the shuffle stream by rank-dependent amounts)
+        self._world = max(1, int(getattr(c, 'dp_world', 1) or 1))
+        self._rank = int(getattr(c, 'dp_rank', 0) or 0)
+        self._aug_rng = random.Random(c.rand_seed + 7919 * (self._rank + 1)) if self._world > 1 else self._rng
         # decode / resize workers (the reference maps with num_parallel_calls=3, :169; one MI355X consumes three
         # orders of magnitude more images per second than a TF-1 CPU pipeline) and batches kept ahead of the step
         self._pool = ThreadPoolExecutor(max_workers=int(getattr(c, 'loader_threads', 0)) or min(16, os.cpu_count() or 3))
@@ -339,7 +345,7 @@ class InputManager(object):
             if is_training:
                 gs = getattr(c, 'accum_grads_step', 1)
                 batch_size = c.batch_size_train
-                c.max_step = int(len(data) / batch_size * c.max_epoch / gs)
+                c.max_step = int(len(data) / (batch_size * self._world) * c.max_epoch / gs)    # global batch
             else:
                 batch_size = c.batch_size_eval
                 assert len(data) % batch_size == 0
@@ -347,19 +353,26 @@ class InputManager(object):
         print('INFO: Augment {} images: {}'.format(split, augment))
         return Prefetch(self._batches(data, batch_size, is_training, augment), self._prefetch_depth, self._finish_batch)
 
+    def _shard(self, data):
+        """This rank's share of the (commonly shuffled) list: items rank, rank + W, ...; equal counts on every rank."""
+        if self._world == 1:
+            return data
+        n = len(data) // self._world * self._world
+        return data[self._rank:n:self._world]
+
     def _gen(self, data, is_training):
         c = self.config
         if is_training:
             self._rng.shuffle(data)
         while True:
-            for d in data:
+            for d in (self._shard(data) if is_training else data):
                 yield pjoin(c.dataset_dir, d[0]) if not os.path.isabs(d[0]) else d[0], self._encode(d[1])
             if is_training:
                 self._rng.shuffle(data)
 
     def _load(self, path, augment, params=None):
         h, w = self.config.cnn_input_size
-        return preprocess_image(path, h, w, augment, self._rng, params)
+        return preprocess_image(path, h, w, augment, self._aug_rng, params)
 
     def enable_device_preprocess(self, device='cuda:0'):
         """From the next batch on: the host only decodes (thread pool), resize / flip / crop / scale run on `device`
@@ -378,7 +391,7 @@ class InputManager(object):
 
     def _load_many(self, paths, augment):
         h, w = self.config.cnn_input_size
-        params = [draw_augmentation(augment, h, w, self._rng) for _ in paths]
+        params = [draw_augmentation(augment, h, w, self._aug_rng) for _ in paths]
         devpre = getattr(self, '_devpre', None)
         if devpre is not None:       # CPU half here (producer thread); the device half runs in Prefetch's consumer hook
             return devpre.pack(list(self._pool.map(decode_image, paths)), params)
@@ -459,7 +472,7 @@ class InputManager_SCST(InputManager_Radix):
         data = list(groups.items())
         c.split_sizes[split] = len(data)
         batch_size = c.batch_size_train
-        c.max_step = int(len(data) / batch_size * c.max_epoch / getattr(c, 'accum_grads_step', 1))
+        c.max_step = int(len(data) / (batch_size * self._world) * c.max_epoch / getattr(c, 'accum_grads_step', 1))
         augment = is_training and c.cnn_input_augment
         return Prefetch(self._scst_batches(data, batch_size, augment), self._prefetch_depth, self._finish_batch)
 
@@ -467,8 +480,9 @@ class InputManager_SCST(InputManager_Radix):
         c = self.config
         self._rng.shuffle(data)
         while True:
-            for i in range(0, len(data) - batch_size + 1, batch_size):      # batch_and_drop_remainder
-                items = data[i:i + batch_size]
+            mine = self._shard(data)
+            for i in range(0, len(mine) - batch_size + 1, batch_size):      # batch_and_drop_remainder
+                items = mine[i:i + batch_size]
                 ims = self._load_many([pjoin(c.dataset_dir, it[0]) if not os.path.isabs(it[0]) else it[0]
                                         for it in items], augment)
                 yield ims, [list(it[1][:5]) for it in items]

@@ -24,7 +24,7 @@ import numpy as np
 
 from . import checkpoint as ckpt
 from . import decoder as cdec
-from . import nets, optim
+from . import encoder_head, nets, optim
 from .trainer import DataParallel
 
 _SHARED = {}          # variable store of the current "graph" (tf.variable_scope('Model', AUTO_REUSE))
@@ -56,14 +56,23 @@ class ModelBase(object):
             share['plan'] = plan
             share['cnn_params'] = plan.init_params(seed=c.rand_seed % (2 ** 31))
             fm = plan.fm_dims()
-            spec = cdec.DecoderSpec.from_config(c, (fm[0] * fm[1], fm[2]), plan.buffers[plan.pooled][2])
+            c_net = plan.buffers[plan.pooled][2]
+            share['head'] = None
+            if getattr(c, 'legacy', False):
+                # model_base.py:80-91: LN_tanh + linear(1024) between the pooled CNN output and the decoder
+                share['head'] = encoder_head.LegacyEncoderHead(c_net, None, device, seed=c.rand_seed % (2 ** 31))
+                c_net = encoder_head.HEAD_DIM
+            spec = cdec.DecoderSpec.from_config(c, (fm[0] * fm[1], fm[2]), c_net)
             share['spec'] = spec
             share['decoder'] = cdec.Decoder(spec, None, device, seed=c.rand_seed % (2 ** 31))
             share['encoders'] = {}
         self.plan, self.spec, self.decoder = share['plan'], share['spec'], share['decoder']
+        self.head = share['head']
         self._share = share
         self._encoder_for(batch_size)
         self.dp = dp or DataParallel(None)
+        if self.dp.world > 1:
+            self.decoder.set_dropout_stream(c.rand_seed, self.dp.rank)
 
     def _encoder_for(self, batch_size):
         """One encoder (activation buffers, hipGraph) per batch size over ONE set of CNN variables,
@@ -97,7 +106,12 @@ class ModelBase(object):
         enc = self._encoder_for(int(images.shape[0]))
         if not self.torch.is_tensor(images):
             images = self.torch.from_numpy(np.ascontiguousarray(images)).to(self.device)
-        return enc.forward(images, use_graph=True)
+        im_embed, fm = enc.forward(images, use_graph=True)
+        return self._embed(im_embed), fm
+
+    def _embed(self, net):
+        """`self.im_embed` of ModelBase._encoder: the squeezed pooled output, or its legacy LN_tanh + linear head."""
+        return net if self.head is None else self.head.forward(net.contiguous())
 
     def is_training(self):
         return self.mode == 'train'
@@ -106,10 +120,22 @@ class ModelBase(object):
         """cnn_finetune: encoder backward from the decoder's input gradients, rank-mean of the CNN
         gradients, TF-Adam on the fp32 masters, refresh of what the forward reads."""
         enc = self._encoder_for(self._batch_size)
-        t = enc.backward(res['dfm'], res['dim_embed'])
         ow, ob, mult = self._share['opt_cnn']
-        s1 = self.dp.average_(t.dw.data)
-        self.dp.average_(t.dbeta.data)
+        if self.dp.world > 1:
+            # bucketed exchange: the decoder gradient and every finished bucket of the CNN gradient are all-reduced on
+            # the communication stream while the backward of the earlier blocks runs (SURVEY section 8e)
+            self.dp.reduce_async(self.decoder.grads.data)
+            self._dec_reduced = True
+            buckets = self.__dict__.setdefault('_buckets', enc.grad_buckets(int(getattr(self._config, 'grad_buckets', 6))))
+
+            def exchange(t, bk):
+                self.dp.reduce_async(t.dw.data[bk[2][0]:bk[2][1]])
+                self.dp.reduce_async(t.dbeta.data[bk[3][0]:bk[3][1]])
+            t = enc.backward(res['dfm'], res['dim_embed'], buckets, exchange)
+            s1 = self.dp.wait_all()
+        else:
+            t = enc.backward(res['dfm'], res['dim_embed'])
+            s1 = 1.0
         ow.t = ob.t = self.opt.t            # one global step for every variable
         ow.step(t.dw, lr, grad_scale=s1 * mult)
         ob.step(t.dbeta, lr, grad_scale=s1 * mult)
@@ -119,18 +145,20 @@ class ModelBase(object):
     def _create_optimiser(self):
         c, share = self._config, self._share
         if 'opt' not in share:
-            if c.optimiser != 'adam':
-                raise NotImplementedError('only optimiser=adam is on the MI355X hot path')
-            share['opt'] = optim.AdamTF(self.decoder.params, epsilon=c.adam_epsilon, l2_decay=getattr(c, 'l2_decay', 1e-5))
+            share['opt'] = optim.make_optimiser(c.optimiser, self.decoder.params, epsilon=c.adam_epsilon,
+                                                l2_decay=getattr(c, 'l2_decay', 1e-5))
             share['legacy_lr'] = c.lr_start
         self.opt = share['opt']
+        if self.head is not None and 'opt_head' not in share:
+            share['opt_head'] = optim.make_optimiser(c.optimiser, self.head.params, epsilon=c.adam_epsilon,
+                                                     l2_decay=getattr(c, 'l2_decay', 1e-5))
         if self.cnn_trainable and 'opt_cnn' not in share:
             # gradient_multipliers scale the whole CNN gradient, L2 term included (model_base.py:388-401)
             enc = self._encoder_for(self._batch_size)
             mult = float(getattr(c, 'cnn_grad_multiplier', 1.0))
             l2 = getattr(c, 'l2_decay', 1e-5) * mult
-            share['opt_cnn'] = (optim.AdamTF(enc.w_master, epsilon=c.adam_epsilon, l2_decay=l2),
-                                optim.AdamTF(enc.beta, epsilon=c.adam_epsilon, l2_decay=l2), mult)
+            share['opt_cnn'] = (optim.make_optimiser(c.optimiser, enc.w_master, epsilon=c.adam_epsilon, l2_decay=l2),
+                                optim.make_optimiser(c.optimiser, enc.beta, epsilon=c.adam_epsilon, l2_decay=l2), mult)
 
     @property
     def global_step(self):
@@ -160,8 +188,11 @@ class ModelBase(object):
         if path is None or not (os.path.isfile(path) or os.path.isfile(path + '.index')):
             raise ValueError('checkpoint not found: %s' % c.checkpoint_path)
         cnn_names = list(self.plan.param_shapes())
-        cnn, dec, extra = ckpt.restore(path, cnn_names, self.spec, getattr(c, 'resume_training', False),
-                                       getattr(c, 'checkpoint_exclude_scopes', ''))
+        head_names = list(encoder_head.TF_NAMES.values()) if self.head is not None else None
+        cnn, dec, extra, head = ckpt.restore(path, cnn_names, self.spec, getattr(c, 'resume_training', False),
+                                             getattr(c, 'checkpoint_exclude_scopes', ''), head_names=head_names)
+        if head:
+            self.head.load_named(head)
         if cnn:
             self._share['cnn_params'].update(cnn)
             for enc in list(self._share['encoders'].values())[:1]:
@@ -184,6 +215,10 @@ class ModelBase(object):
                 if slots:
                     o.m.load(slots[0])
                     o.v.load(slots[1])
+            if 'optimise/caption/head_adam_m' in extra and 'opt_head' in self._share:
+                oh = self._share['opt_head']
+                oh.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/head_adam_m']))
+                oh.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/head_adam_v']))
             if 'optimise/caption/cnn_w_adam_m' in extra and 'opt_cnn' in self._share:
                 ow, ob, _ = self._share['opt_cnn']
                 ow.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_m']))
@@ -197,6 +232,34 @@ class ModelBase(object):
             self.update_lr(lr)
         return self.lr
 
+    def sync_parameters(self):
+        """Data parallel: broadcast every variable and optimiser slot from rank 0 (parameters initialised or restored
+        per rank would otherwise differ wherever a checkpoint does not cover them, and the replicas would never agree).
+        The reference is single-GPU; this is part of the DP extension."""
+        dp = self.dp
+        if dp.world <= 1 or dp.dist is None:
+            return
+        bufs = [self.decoder.params.data]
+        if self.head is not None:
+            bufs.append(self.head.params.data)
+        for enc in list(self._share['encoders'].values())[:1]:
+            bufs += [enc.w_master.data, enc.beta.data, enc.mean.data, enc.scale.data, enc.shift.data]
+        for key in ('opt', 'opt_head'):
+            if key in self._share:
+                bufs += [self._share[key].m.data, self._share[key].v.data]
+        if 'opt_cnn' in self._share:
+            for o in self._share['opt_cnn'][:2]:
+                bufs += [o.m.data, o.v.data]
+        for b in bufs:
+            dp.dist.broadcast(b, 0)
+        step = self.torch.tensor([self.global_step], dtype=self.torch.int64, device=self.device)
+        dp.dist.broadcast(step, 0)
+        for key in ('opt', 'opt_head'):
+            if key in self._share:
+                self._share[key].t = int(step.item())
+        for enc in list(self._share['encoders'].values())[:1]:
+            enc.refresh_weights()
+
     def save(self, save_path, compact=True, max_to_keep=None):
         extra = {}
         fmt = getattr(self._config, 'checkpoint_format', 'npz')
@@ -207,6 +270,12 @@ class ModelBase(object):
             else:
                 extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(),
                          'optimise/caption/adam_v': o.v.data.cpu().numpy()}
+        if self.head is not None:
+            extra.update(self.head.export_params())
+            if not compact and 'opt_head' in self._share:
+                oh = self._share['opt_head']
+                extra.update({'optimise/caption/head_adam_m': oh.m.data.cpu().numpy(),
+                              'optimise/caption/head_adam_v': oh.v.data.cpu().numpy()})
         if 'opt_cnn' in self._share:      # fine-tuned CNN variables back into the checkpoint layout
             self._share['cnn_params'].update(next(iter(self._share['encoders'].values())).export_params())
             if not compact:
@@ -295,20 +364,26 @@ class CaptionModel(ModelBase):
         consumed = None
         if self._pipelined(batch):
             im_embed, fm, captions, consumed = self._next_features()
+            im_embed = self._embed(im_embed)
         else:
             images, captions = batch if batch is not None else next(self.batch_ops)
             im_embed, fm = self._encode(images)
         cap = np.asarray(captions)
-        denom = None
-        if self.dp.world > 1:
-            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
         lr = self.lr
         ft = self.cnn_trainable
-        res = self.decoder.train_step(fm, im_embed, cap, training=True, xe_denom=denom, use_graph=not ft,
-                                      want_input_grads=ft, on_inputs_consumed=consumed)
+        want_in = ft or self.head is not None
+        res = self.decoder.train_step(fm, im_embed, cap, training=True, dp=self.dp, use_graph=not want_in,
+                                      want_input_grads=want_in, on_inputs_consumed=consumed)
+        self._dec_reduced = False
         if ft:
             self._cnn_update(res, lr)
-        scale = self.dp.average_(self.decoder.grads.data)
+        scale = 1.0 / self.dp.world if self._dec_reduced else self.dp.average_(self.decoder.grads.data)
+        if self.head is not None:          # legacy head: its variables train with the decoder (model_base.py:834-849)
+            hg = self.head.backward(res['dim_embed'])
+            self.dp.average_(hg.data)
+            oh = self._share['opt_head']
+            oh.t = self.opt.t
+            oh.step(hg, lr, grad_scale=scale)
         self.opt.step(self.decoder.grads, lr, grad_scale=scale)
         self.dec_log_ppl = res['loss']
         self.last = res

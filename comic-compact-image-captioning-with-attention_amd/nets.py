@@ -156,6 +156,7 @@ class CnnPlan:
             raise ValueError('fuse_pools needs an inception_v3 plan with pool_after_projection=True')
         self._pooled_src = None  # (buffer id, pooled H, pooled W) while a folded max-pool waits for its consumers
         self._logical = {}       # buffer id -> logical channel count where it differs from the padded one
+        self.block_ranges = []   # [first op, end op) of the stem and of every block, in execution order (gradient buckets)
         if name == 'chain':
             self._build_chain(image_size, layers)
         elif name == 'inception_v1':
@@ -324,6 +325,9 @@ class CnnPlan:
                              src_f32=int(f32), lane=0))
         self.pooled = pooled
         self.end_points['AvgPool_1a'] = pooled
+        if not self.block_ranges:
+            self.block_ranges.append([0, len(self.ops)])
+        self.block_ranges[-1][1] = len(self.ops)       # the head pool belongs to the last range
 
     def _build_v1(self, image_size, fm_endpoint):
         """inception_v1_base (inception_v1.py:29-266) + head (:319-327): conv / max-pool defaults stride 1,
@@ -339,10 +343,12 @@ class CnnPlan:
             else:
                 cur, _ = self._pool(cur, 2, op[2], 2, 'SAME')
             self.end_points[op[1]] = cur
+        self.block_ranges.append([0, len(self.ops)])
         for entry in INCEPTION_V1_BLOCKS:
             if entry[0] == 'pool':
                 cur, _ = self._pool(cur, 2, entry[2], 2, 'SAME')
                 self.end_points[entry[1]] = cur
+                self.block_ranges[-1][1] = len(self.ops)
                 continue
             bname, branches = entry
             Hi, Wi, Ci, _ = self.buffers[cur]
@@ -366,6 +372,7 @@ class CnnPlan:
             self._depth = 0
             if self.group_branches:
                 self._schedule_by_depth(first_op)
+            self.block_ranges.append([first_op, len(self.ops)])
             cur = blk
             self.end_points[bname] = cur
         if fm_endpoint not in self.end_points:
@@ -401,8 +408,10 @@ class CnnPlan:
             else:
                 cur, _ = self._pool(cur, 2, 3, 2, 'VALID')
             self.end_points[op[1]] = cur
+        self.block_ranges.append([0, len(self.ops)])
         for bname, branches in INCEPTION_V3_BLOCKS:
             Hi, Wi, Ci, _ = self.buffers[cur]
+            block_first = len(self.ops)
             if self._pooled_src is not None:         # the block reads `cur` through the folded MaxPool_5a
                 assert self._pooled_src[0] == cur and all(b[0][0] == 'c' and b[0][3] == (1, 1) or b[0][0] == 'avg'
                                                           for b in branches)
@@ -457,6 +466,7 @@ class CnnPlan:
                 self._schedule_by_depth(first_op)
             if self.branch_streams:
                 self.ops.append(self._sync_op(6))      # join
+            self.block_ranges.append([block_first, len(self.ops)])
             cur = blk
             self.end_points[bname] = cur
             if last:
@@ -518,12 +528,7 @@ class CnnEncoder:
             self.w_master, self.beta, self.mean, self.scale, self.shift = o.w_master, o.beta, o.mean, o.scale, o.shift
             self.w_plan, wt = o.w_plan, o._wt
         else:
-            wshapes, bshapes = {}, {}
-            for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-                cin_p, cout_p = plan.wphys[i]            # physical (padded) channel counts
-                K = kh * kw * cin_p
-                wshapes['w%d' % i] = (K * cout_p,) if stem else (cout_p * ((K + 63) // 64 * 64),)
-                bshapes['b%d' % i] = (cout_p,)
+            wshapes, bshapes = flat_layout(plan)
             self.w_master = FlatParams(wshapes, device)
             self.beta = FlatParams(bshapes, device)
             self.mean, self.scale, self.shift = self.beta.like(), self.beta.like(), self.beta.like()
@@ -692,9 +697,59 @@ class CnnEncoder:
         self._train = t
         return t
 
-    def backward(self, d_fm, d_im_embed):
+    def grad_buckets(self, n=6):
+        """Partition of the backward pass for the data-parallel gradient exchange: runs of whole
+        blocks, LAST block first (the order the backward produces gradients), of roughly equal weight bytes.
+        -> [(op_lo, op_hi, (w_lo, w_hi), (b_lo, b_hi))]: op range and the element ranges of the flat dw / dbeta buffers
+        that are complete once the backward of those ops has been issued."""
+        return plan_grad_buckets(self.plan, self.w_master, self.beta, n)
+
+
+def flat_layout(plan):
+    """Shapes of the flat master buffers: packed conv weights ([Cout][Kpad]; stem [K][Cout]) and per-channel vectors."""
+    wshapes, bshapes = {}, {}
+    for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+        cin_p, cout_p = plan.wphys[i]            # physical (padded) channel counts
+        K = kh * kw * cin_p
+        wshapes['w%d' % i] = (K * cout_p,) if stem else (cout_p * ((K + 63) // 64 * 64),)
+        bshapes['b%d' % i] = (cout_p,)
+    return wshapes, bshapes
+
+
+def plan_grad_buckets(plan, w_flat, b_flat, n=6):
+    """See CnnEncoder.grad_buckets; w_flat / b_flat: the FlatParams of the weights / betas (offsets only)."""
+    if True:
+        ranges = [tuple(r) for r in plan.block_ranges]
+        assert ranges and ranges[0][0] == 0 and ranges[-1][1] == len(plan.ops)
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), 'block ranges must tile the op list'
+
+        def widx(r):
+            ws = [plan.ops[i]['weight'] for i in range(*r) if plan.ops[i].get('weight', -1) >= 0 and plan.ops[i]['kind'] in (0, 1, 8)]
+            return (min(ws), max(ws) + 1) if ws else None
+        nW = len(plan.weights)
+        woff = [w_flat.offsets['w%d' % i] for i in range(nW)] + [w_flat.numel]
+        boff = [b_flat.offsets['b%d' % i] for i in range(nW)] + [b_flat.numel]
+        total = woff[-1]
+        out, hi_op, hi_w, acc_target = [], len(plan.ops), nW, total / float(max(1, n))
+        lo_w = nW
+        for k in range(len(ranges) - 1, -1, -1):
+            wr = widx(ranges[k])
+            if wr is not None:
+                assert wr[1] <= lo_w or wr[1] == hi_w, 'weights of a block must form one range below the later blocks'
+                lo_w = min(lo_w, wr[0])
+            size = woff[hi_w] - woff[lo_w]
+            if (size >= acc_target and len(out) < n - 1) or k == 0:
+                out.append((ranges[k][0], hi_op, (woff[lo_w], woff[hi_w]), (boff[lo_w], boff[hi_w])))
+                hi_op, hi_w = ranges[k][0], lo_w
+        assert out[-1][0] == 0 and out[-1][2][0] == 0
+        return out
+
+    def backward(self, d_fm, d_im_embed, buckets=None, on_bucket=None):
         """d_fm [B, M, C] / d_im_embed [B, C_g] fp32 (the gradients of `forward`'s two outputs; either
-        may be None) -> fills the weight / beta gradients of `enable_training()`'s state."""
+        may be None) -> fills the weight / beta gradients of `enable_training()`'s state.
+        buckets (from grad_buckets) + on_bucket(train_state, bucket): the backward is issued bucket by bucket and the
+        callback runs after each one -- the data-parallel step starts that bucket's all-reduce there, under the
+        backward of the earlier blocks."""
         t = self.enable_training()
         t.gflat.zero_()
         t.dw.data.zero_()
@@ -707,9 +762,14 @@ class CnnEncoder:
         ready = t.filters_ver == self.w_master.__dict__.get('_ver', 0)   # else: packed inline by the executor
         if ready:
             self.torch.cuda.current_stream().wait_event(t.filters_ev)
-        L.check(self.lib.comic_cnn_backward(self._ops, len(self.plan.ops), self._bufptr, t.gptr, self._bufch, self._wt,
-                                            t.grads, self.batch, self.dcode, int(ready), t.scratch.data_ptr(),
-                                            t.scratch_bytes, L.stream_ptr()), 'cnn_backward')
+        for bk in (buckets or [(0, len(self.plan.ops), None, None)]):
+            lo, hi = bk[0], bk[1]
+            first = C.byref(self._ops, lo * C.sizeof(L.CnnOp))
+            L.check(self.lib.comic_cnn_backward(first, hi - lo, self._bufptr, t.gptr, self._bufch, self._wt,
+                                                t.grads, self.batch, self.dcode, int(ready), t.scratch.data_ptr(),
+                                                t.scratch_bytes, L.stream_ptr()), 'cnn_backward')
+            if on_bucket is not None:
+                on_bucket(t, bk)
         return t
 
     def _build_group_args(self):

@@ -1,6 +1,6 @@
 """Optimiser and learning-rate schedule of the reference, on the flat parameter buffer.
 
-`tf.train.AdamOptimizer` through `slim.learning.create_train_op` (reference
+`tf.train.AdamOptimizer` / `tf.train.MomentumOptimizer` through `slim.learning.create_train_op` (reference
 src/model_base.py:387-401, :852-883) with the TF-1.9 ApplyAdam formula (eps outside the
 bias correction), L2 regularisation over every trainable variable
 (model_base.py:408-417, common/ops.py:184-190) folded into the update as grad += decay*w,
@@ -51,3 +51,36 @@ class AdamTF:
         self.t = int(sd['t'])
         self.m.data.copy_(sd['m'])
         self.v.data.copy_(sd['v'])
+
+
+class MomentumTF:
+    """tf.train.MomentumOptimizer(lr, momentum=0.9, use_nesterov=False) (reference src/model_base.py:867-880;
+    `--optimiser sgd`): accum = momentum*accum + g, w -= lr*accum, with the same L2 fold as AdamTF.  Same interface
+    (`t`, `step`, `m` = the accumulator; `v` stays zero so checkpoints keep one layout)."""
+
+    def __init__(self, params, momentum=0.9, l2_decay=1e-5, **_):
+        self.lib = L.load()
+        self.params = params
+        self.m = params.like()
+        self.v = params.like()
+        self.momentum, self.l2 = momentum, l2_decay
+        self.beta1, self.beta2, self.eps = momentum, 0.0, 0.0
+        self.t = 0
+
+    def step(self, grads, lr, grad_scale=1.0):
+        self.t += 1
+        L.check(self.lib.comic_momentum_tf(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
+                                           self.params.numel, lr, self.momentum, self.l2, grad_scale, L.stream_ptr()),
+                'momentum_tf')
+
+    state_dict = AdamTF.state_dict
+    load_state_dict = AdamTF.load_state_dict
+
+
+def make_optimiser(name, params, epsilon=1e-2, l2_decay=1e-5):
+    """`_get_optimiser` (model_base.py:852-883)."""
+    if name == 'adam':
+        return AdamTF(params, epsilon=epsilon, l2_decay=l2_decay)
+    if name == 'sgd':
+        return MomentumTF(params, l2_decay=l2_decay)
+    raise ValueError('Unknown optimiser.')

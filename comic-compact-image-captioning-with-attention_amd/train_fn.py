@@ -52,7 +52,7 @@ def train_fn(config, device='cuda:0', dp=None):
 def _train_loop(inputs_man, device, dp):
     inputs_man.enable_device_preprocess(device)        # host: JPEG decode only
     c = inputs_man.config
-    num_batches = int(c.split_sizes['train'] / c.batch_size_train)
+    num_batches = int(c.split_sizes['train'] / (c.batch_size_train * max(1, int(getattr(c, 'dp_world', 1) or 1))))   # global batches
     lr = c.lr_start
     n_steps_log = int(num_batches / c.num_logs_per_epoch)
     m_train = mdl.CaptionModel(c, mode='train', batch_ops=inputs_man.batch_train, reuse=False, name='train',
@@ -64,6 +64,7 @@ def _train_loop(inputs_man, device, dp):
                                    device=device, dp=dp)
         m_valid.dset_size = c.split_sizes['valid']
     lr = m_train.restore_model(lr)
+    m_train.sync_parameters()                        # data parallel: every rank starts from rank 0's variables
     _model_size_report(m_train, c.log_path)
     start_step = m_train.global_step
     n_steps_log = max(1, int(n_steps_log / 5))
@@ -119,7 +120,7 @@ def train_fn_scst(config, idx_ngram=False, device='cuda:0', dp=None):
 def _scst_loop(inputs_man, idx_ngram, device, dp):
     inputs_man.enable_device_preprocess(device)
     c = inputs_man.config
-    num_batches = int(c.split_sizes['train'] / c.batch_size_train)
+    num_batches = int(c.split_sizes['train'] / (c.batch_size_train * max(1, int(getattr(c, 'dp_world', 1) or 1))))   # global batches
     lr = c.lr_start
     n_steps_log = int(num_batches / c.num_logs_per_epoch)
     m_train = mdl.CaptionModel_SCST(c, scst_mode='train', reuse=False, device=device, dp=dp)
@@ -131,6 +132,7 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
     scorer = captionScorer(path_to_cached_tokens=idf_fp,
                            metric_weights=dict(ciderD=c.scst_weight_ciderD, bleu=c.scst_weight_bleu))
     lr = m_train.restore_model(lr)
+    m_train.sync_parameters()                        # data parallel: every rank starts from rank 0's variables
     _model_size_report(m_train, c.log_path)
     start_step = m_train.global_step
     n_steps_log = max(1, int(n_steps_log / 5))
@@ -206,6 +208,15 @@ def _run_eval_loop(c, m, global_step):
     return avg_ppl
 
 
+def _dp_barrier():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+    except ImportError:
+        pass
+
+
 def try_to_train(train_fn, try_block=True, overwrite=False, **kargs):
     """Wrapper for the main training function."""
     config = conf.Config(**kargs)
@@ -217,8 +228,13 @@ def try_to_train(train_fn, try_block=True, overwrite=False, **kargs):
         config.checkpoint_path = kargs.pop('log_path')
         config.lr_end = kargs.pop('lr_end')
         config.max_epoch = kargs.pop('max_epoch')
+        for k in ('dp_world', 'dp_rank'):              # of THIS launch, not of the run that wrote config.pkl
+            if k in kargs:
+                setattr(config, k, kargs[k])
     else:
-        config.save_config_to_file()
+        if int(kargs.get('dp_rank', 0) or 0) == 0:     # one writer; the other ranks wait for the files
+            config.save_config_to_file()
+        _dp_barrier()
     if not try_block:
         return train_fn(config)
     try:

@@ -36,6 +36,43 @@ class DataParallel:
         self.dist.all_reduce(t)
         return float(t.item())
 
+    def global_xe_denominator(self, wmask_dev):
+        """Device tensor (1 element) = sum of the XE weights over ALL ranks / world + 1e-12: the sequence_loss
+        normaliser (model_base.py:337-340) a rank uses so that the rank-mean of the gradients equals the gradient of
+        the global batch.  The all-reduce is stream-ordered; nothing is read back to the host."""
+        t = wmask_dev.sum().reshape(1)
+        if self.dist:
+            self.dist.all_reduce(t)
+        return t / self.world + 1e-12
+
+    # ---- bucketed gradient exchange: buckets are reduced on a side stream while the backward pass goes on ----------
+    def reduce_async(self, flat_slice):
+        """Start the sum all-reduce of `flat_slice` (a contiguous view of a flat gradient buffer whose producers have
+        been enqueued on the current stream).  CUDA tensors: the collective is issued from a communication stream
+        that first waits for the current stream, so later kernels of the caller are not ordered behind it; finish
+        with `wait_all()`.  CPU tensors (gloo tests): reduced at once."""
+        if not self.dist:
+            return
+        if not flat_slice.is_cuda:
+            self.dist.all_reduce(flat_slice)
+            return
+        import torch
+        if getattr(self, '_comm', None) is None:
+            self._comm = torch.cuda.Stream(device=flat_slice.device)
+            self._pending = []
+        self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            self._pending.append(self.dist.all_reduce(flat_slice, async_op=True))
+
+    def wait_all(self):
+        """Order the current stream behind every collective started with reduce_async (no host wait).
+        Returns the 1/world factor for the optimiser's grad_scale."""
+        for w in getattr(self, '_pending', None) or []:
+            w.wait()                      # ProcessGroupNCCL: makes the CURRENT stream wait for the collective
+        if getattr(self, '_pending', None):
+            self._pending = []
+        return 1.0 / self.world
+
     def average_(self, flat):
         """In-place rank-mean of a flat gradient tensor (sum all-reduce, then 1/W in the
         optimiser's grad_scale to save a pass)."""
@@ -149,11 +186,7 @@ class CaptionTrainer:
         """images [B,H,W,3] fp32 device tensor, captions [B,L] int (PAD -1) -> dict(loss, map_loss)."""
         im_embed, fm = self.encoder.forward(images, use_graph=self.use_graph)
         cap = np.asarray(captions)
-        local_tokens = float((cap[:, 1:] >= 0).sum())
-        denom = None
-        if self.dp.world > 1:
-            denom = self.dp.global_tokens(local_tokens, self.device) / self.dp.world + 1e-12
-        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, dp=self.dp,
                                       use_graph=self.use_graph_decoder)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
@@ -173,17 +206,25 @@ class CaptionTrainer:
         assert getattr(self, 'opt_cnn', None), 'enable_cnn_finetune() first'
         im_embed, fm = self.encoder.forward(images, use_graph=self.use_graph)
         cap = np.asarray(captions)
-        denom = None
-        if self.dp.world > 1:
-            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
-        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, dp=self.dp,
                                       use_graph=False, want_input_grads=True)
-        t = self.encoder.backward(res['dfm'], res['dim_embed'])
         lr = self.lr()
         ow, ob, mult = self.opt_cnn
-        scale = self.dp.average_(self.decoder.grads.data)
-        self.dp.average_(t.dw.data)
-        self.dp.average_(t.dbeta.data)
+        if self.dp.world > 1:
+            # decoder gradient first, then each finished bucket of the CNN gradient, reduced on the communication
+            # stream under the backward of the earlier blocks
+            self.dp.reduce_async(self.decoder.grads.data)
+            if getattr(self, '_buckets', None) is None:
+                self._buckets = self.encoder.grad_buckets(6)
+
+            def exchange(t, bk):
+                self.dp.reduce_async(t.dw.data[bk[2][0]:bk[2][1]])
+                self.dp.reduce_async(t.dbeta.data[bk[3][0]:bk[3][1]])
+            t = self.encoder.backward(res['dfm'], res['dim_embed'], self._buckets, exchange)
+            scale = self.dp.wait_all()
+        else:
+            t = self.encoder.backward(res['dfm'], res['dim_embed'])
+            scale = 1.0
         self.opt.step(self.decoder.grads, lr, grad_scale=scale)
         ow.t = ob.t = self.opt.t - 1
         ow.step(t.dw, lr, grad_scale=scale * mult)
@@ -230,15 +271,12 @@ class CaptionTrainer:
         main.wait_event(self._ev_cnn)
         im_embed, fm = self._pending
         cap = np.asarray(captions)
-        denom = None
-        if self.dp.world > 1:
-            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
 
         def consumed():
             self._ev_used.record(main)
             if next_images is not None:
                 self.submit_images(next_images)
-        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, dp=self.dp,
                                       use_graph=self.use_graph_decoder, on_inputs_consumed=consumed)
         if next_images is None:
             self._pending = None
@@ -251,14 +289,11 @@ class CaptionTrainer:
         of steps) are taken at the first step of a group and ignored at the others."""
         im_embed, fm, release = self.take_features()
         cap = np.asarray(captions)
-        denom = None
-        if self.dp.world > 1:
-            denom = self.dp.global_tokens(float((cap[:, 1:] >= 0).sum()), self.device) / self.dp.world + 1e-12
 
         def consumed():
             if release() and next_images is not None:
                 self.submit_images(next_images)
-        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, xe_denom=denom,
+        res = self.decoder.train_step(fm, im_embed, cap, masks=masks, training=training, dp=self.dp,
                                       use_graph=self.use_graph_decoder, on_inputs_consumed=consumed)
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)

@@ -325,6 +325,20 @@ int comic_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const 
  * w -= lr_t*m/(sqrt(v)+eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
 int comic_adam_tf(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
                   float beta2, float eps, float l2, float gscale, void* stream);
+/* Legacy encoder head (`--legacy`, model_base.py:80-91): ops.layer_norm_activate('LN_tanh', squeeze(net), tanh)
+ * (common/ops.py:241-275: tf.contrib.layers.layer_norm over the last axis, eps 1e-12, center + scale) followed by
+ * ops.linear('im_embed', 1024, no bias) = comic_gemm_f32.  y = tanh(xhat*gamma + beta), xhat = (x-mean)*rsqrt(var+eps)
+ * (kept for the backward).  comic_ln_tanh_bwd_rows writes the per-row terms of d gamma / d beta
+ * (dy*(1-y^2)*xhat and dy*(1-y^2)); their column sums (comic_colsum) are the parameter gradients.  The head is never
+ * back-propagated into the CNN: train.py:241-249 refuses cnn_finetune / scst with --legacy. */
+int comic_ln_tanh_fwd(const float* x, const float* gamma, const float* beta, float* y, float* xhat, int B, int C,
+                      float eps, void* stream);
+int comic_ln_tanh_bwd_rows(const float* dy, const float* y, const float* xhat, float* pgamma, float* pbeta, int B,
+                           int C, void* stream);
+/* tf.train.MomentumOptimizer(momentum 0.9, use_nesterov=False) (model_base.py:867-880; ApplyMomentum, TF-1.9):
+ * g_eff = g*gscale + l2*w; accum = momentum*accum + g_eff; w -= lr*accum. */
+int comic_momentum_tf(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
+                      float gscale, void* stream);
 /* out[j] = sum_i in[i*cols + j]  (deterministic column sums; parameter-partial reduce) */
 int comic_colsum(const float* in, float* out, int rows, int cols, float beta, void* stream);
 int comic_axpy(float* y, const float* x, float a, int64_t n, void* stream);

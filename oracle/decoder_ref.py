@@ -557,3 +557,36 @@ def adam_tf_update(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-2):
     v[...] = v + (g * g - v) * f(1 - beta2)
     w[...] = w - (m * lr_t) / (np.sqrt(v) + f(eps))
     return w, m, v
+
+
+def momentum_tf_update(w, g, accum, lr, momentum=0.9):
+    """tf.train.MomentumOptimizer.ApplyMomentum, use_nesterov=False [TF-1.9] (model_base.py:867-880):
+    accum = momentum*accum + g; w -= lr*accum."""
+    f = np.float32
+    accum[...] = accum * f(momentum) + g
+    w[...] = w - f(lr) * accum
+    return w, accum
+
+
+# --------------------------------------------------------------------------- #
+# legacy encoder head (model_base.py:80-91; common/ops.py:200-275)
+# --------------------------------------------------------------------------- #
+def legacy_head_forward(p, net, eps=1e-12):
+    """im_embed = tanh(layer_norm(net)) . W  (LayerNorm over the last axis, biased variance, eps 1e-12 [TF-1.9
+    tf.contrib.layers.layer_norm]; ops.linear without bias).  -> (im_embed, cache)."""
+    x = np.asarray(net, np.float64)
+    mean = x.mean(axis=1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=1, keepdims=True)
+    xhat = (x - mean) / np.sqrt(var + eps)
+    z = np.tanh(xhat * p['ln_gamma'].astype(np.float64) + p['ln_beta'].astype(np.float64))
+    return (z @ p['W'].astype(np.float64)).astype(np.float32), dict(z=z, xhat=xhat)
+
+
+def legacy_head_backward(p, cache, d_im):
+    """-> {ln_gamma, ln_beta, W} gradients (the gradient w.r.t. `net` is not needed: the CNN is frozen with --legacy)."""
+    d = np.asarray(d_im, np.float64)
+    z, xhat = cache['z'], cache['xhat']
+    dz = d @ p['W'].astype(np.float64).T
+    t = dz * (1.0 - z * z)
+    return dict(W=(z.T @ d).astype(np.float32), ln_gamma=(t * xhat).sum(axis=0).astype(np.float32),
+                ln_beta=t.sum(axis=0).astype(np.float32))

@@ -134,7 +134,25 @@ def build_kwargs(args):
                   log_path=log_path, save_path=pjoin(log_path, 'model'))
     kwargs.update(args.__dict__)
     kwargs.pop('log_root', None)
+    check_supported(kwargs)
     return kwargs, train_fn_name, overwrite
+
+
+def check_supported(kw):
+    """Options of the reference that this hot path does not implement fail HERE instead of silently training a different
+    model (model_base.py:622-629 LN_LSTM / GRU, :645 variational recurrent dropout, :394-401 gradient clipping)."""
+    bad = []
+    if kw.get('rnn_name', 'LSTM') != 'LSTM':
+        bad.append('--rnn_name %s (only LSTM)' % kw['rnn_name'])
+    if kw.get('rnn_recurr_dropout') and not kw.get('legacy'):
+        bad.append('--rnn_recurr_dropout (variational recurrent dropout)')
+    if kw.get('clip_gradient_norm'):
+        bad.append('clip_gradient_norm != 0')
+    # --initialiser: `he` / `none` select TensorFlow's default initialiser in the reference (model_base.py:823-831:
+    # every value but `xavier` returns None), which for these float variables is glorot_uniform == Xavier-uniform
+    # [TF-1.9 get_variable default]: all three choices build the same model, here too.
+    if bad:
+        raise NotImplementedError('not implemented on the MI355X hot path: ' + '; '.join(bad))
 
 
 def main(argv=None):
@@ -152,7 +170,9 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group('nccl', device_id=torch.device(device))
         dp = DataParallel(dist)
-        kwargs['rand_seed'] += dp.rank            # disjoint shuffles per rank
+        # rand_seed stays the SAME on every rank: it seeds the parameter initialisers and the common shuffle; the
+        # input managers shard the shuffled list by rank (config.dp_world / dp_rank)
+        kwargs['dp_world'], kwargs['dp_rank'] = dp.world, dp.rank
     fn = getattr(train, train_fn_name)
     train.try_to_train(train_fn=lambda cfg: fn(cfg, device=device, dp=dp), try_block=True, overwrite=overwrite, **kwargs)
     if world > 1:

@@ -60,6 +60,51 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _bucket_worker(rank, world, port, ret):
+    """Bucketed exchange (reduce_async per bucket, last block first, + wait_all) against ONE flat all-reduce of the same
+    buffers, and the device-side XE denominator, on CPU tensors over gloo."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from comic_amd import nets
+    from comic_amd.decoder import FlatParams
+    from comic_amd.trainer import DataParallel
+    dp = DataParallel(dist)
+    plan = nets.CnnPlan('inception_v3', (224, 224))
+    ws, bs = nets.flat_layout(plan)
+    W, Bt = FlatParams(ws, 'cpu'), FlatParams(bs, 'cpu')
+    buckets = nets.plan_grad_buckets(plan, W, Bt, 6)
+    g = torch.Generator().manual_seed(100 + rank)
+    dw = torch.randn(W.numel, generator=g)
+    db = torch.randn(Bt.numel, generator=g)
+    flat_w, flat_b = dw.clone(), db.clone()
+    dp.average_(flat_w)
+    dp.average_(flat_b)
+    for bk in buckets:                                    # the order the backward finishes them
+        dp.reduce_async(dw[bk[2][0]:bk[2][1]])
+        dp.reduce_async(db[bk[3][0]:bk[3][1]])
+    scale = dp.wait_all()
+    wm = torch.zeros(40)
+    wm[:13 + 5 * rank] = 1.0
+    den = dp.global_xe_denominator(wm)
+    if rank == 0:
+        ret['equal'] = bool(torch.equal(dw, flat_w) and torch.equal(db, flat_b))
+        ret['scale'] = scale
+        ret['den'] = float(den)
+        ret['n_buckets'] = len(buckets)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_exchange_equals_flat_all_reduce():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret['equal'] and ret['scale'] == 0.5 and 4 <= ret['n_buckets'] <= 6
+    assert abs(ret['den'] - ((13 + 18) / 2 + 1e-12)) < 1e-9
+
+
 @pytest.mark.timeout(300)
 def test_rank_mean_gradient_equals_global_batch_gradient():
     world, port = 2, _free_port()

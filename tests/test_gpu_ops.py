@@ -592,3 +592,41 @@ def test_adam_tf_matches_oracle():
     assert_close(dw.cpu().numpy(), w, 1e-5, 'adam w')
     assert_close(dm.cpu().numpy(), m, 1e-5, 'adam m')
     assert_close(dv.cpu().numpy(), v, 1e-5, 'adam v')
+
+
+def test_momentum_tf_matches_oracle():
+    """--optimiser sgd: tf.train.MomentumOptimizer(0.9, use_nesterov=False) (model_base.py:867-880), two updates."""
+    rng = np.random.default_rng(8)
+    n = 70001
+    w = rng.standard_normal(n).astype(np.float32)
+    acc = np.zeros(n, np.float32)
+    dw, dacc = dev(w), dev(acc)
+    lr, l2 = 1e-2, 1e-5
+    for it in range(2):
+        g = rng.standard_normal(n).astype(np.float32)
+        L.check(lib().comic_momentum_tf(dw.data_ptr(), dev(g).data_ptr(), dacc.data_ptr(), n, lr, 0.9, l2, 0.5, stream()))
+        dr.momentum_tf_update(w, np.float32(0.5) * g + np.float32(l2) * w, acc, lr)
+    assert_close(dw.cpu().numpy(), w, 1e-6, 'momentum w')
+    assert_close(dacc.cpu().numpy(), acc, 1e-6, 'momentum accum')
+
+
+def test_legacy_encoder_head_matches_oracle():
+    """--legacy image embedding (model_base.py:80-91): LN_tanh + linear(1024) forward and parameter gradients."""
+    from comic_amd import encoder_head
+    rng = np.random.default_rng(9)
+    B, C_ = 6, 1024
+    net = (rng.standard_normal((B, C_)) * 1.5 + 0.2).astype(np.float32)
+    p = encoder_head.init_params(C_, seed=1)
+    p['ln_gamma'] = rng.uniform(0.5, 1.5, C_).astype(np.float32)
+    p['ln_beta'] = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    head = encoder_head.LegacyEncoderHead(C_, p, DEV)
+    out = head.forward(dev(net))
+    ref, cache = dr.legacy_head_forward(p, net)
+    assert_close(out.cpu().numpy(), ref, 1e-3, 'legacy im_embed')
+    d = rng.standard_normal(ref.shape).astype(np.float32)
+    g = head.backward(dev(d)).to_numpy()
+    gref = dr.legacy_head_backward(p, cache, d)
+    for k in gref:
+        assert_close(g[k], gref[k], 1e-3, 'legacy d ' + k)
+    assert set(head.export_params()) == {'Model/encoder/LN_tanh/beta', 'Model/encoder/LN_tanh/gamma',
+                                         'Model/encoder/im_embed/weight'}

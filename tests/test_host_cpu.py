@@ -457,3 +457,46 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
     tb.write_bundle(slim, cnn)
     c3, d3, _ = ckpt.restore(slim, list(cnn), spec)
     assert d3 is None and all(np.array_equal(c3[k], cnn[k]) for k in cnn)
+
+
+def test_cli_refuses_options_it_does_not_implement(tmp_path):
+    """LN_LSTM / GRU cells, variational recurrent dropout and gradient clipping fail at argument time instead of
+    training a different model; sgd, every --initialiser value (all Xavier-uniform in the reference, model_base.py:
+    823-831) and --legacy build."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('train_cli2', os.path.join(ROOT, 'src', 'train.py'))
+    train = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(train)
+    base = ['--log_root', str(tmp_path)]
+    for bad in (['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM'], ['--rnn_recurr_dropout', 'True']):
+        with pytest.raises(NotImplementedError):
+            train.build_kwargs(train.create_parser().parse_args(base + bad))
+    kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base))
+    kw['clip_gradient_norm'] = 5.0
+    with pytest.raises(NotImplementedError):
+        train.check_supported(kw)
+    for ok in (['--optimiser', 'sgd'], ['--initialiser', 'he'], ['--initialiser', 'none'], ['--legacy', 'True']):
+        kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base + ok))
+    assert kw['legacy'] and kw['cnn_name'] == 'inception_v1' and kw['adam_epsilon'] == 1e-6
+
+
+def test_data_parallel_shards_are_disjoint_and_cover_the_epoch(tmp_path):
+    """Input managers under data parallelism: a common shuffle, rank r takes items r, r+W, ..; max_step counts global
+    batches; same rand_seed (= same parameter initialisation) on every rank."""
+    from tests import tiny_dataset
+    from comic_amd import inputs
+    d = tiny_dataset.make(str(tmp_path), n_train=8, n_valid=4)
+    seen, steps, n_items = [], [], None
+    for rank in range(2):
+        c = conf.Config(dataset_dir=d, dataset_file_pattern='mscoco_{}_w5_s20_include_restval', token_type='radix',
+                        radix_base=256, batch_size_train=4, batch_size_eval=4, max_epoch=2, cnn_input_size=[64, 64],
+                        cnn_input_augment=True, rand_seed=7, dp_world=2, dp_rank=rank, loader_threads=1, loader_prefetch=1)
+        m = inputs.InputManager_Radix(c)
+        steps.append(c.max_step)
+        data = list(m._read_split('train'))
+        n_items = len(data)
+        gen = m._gen(data, True)
+        seen.append([(p, tuple(int(v) for v in cap)) for (p, cap), _ in zip(gen, range(n_items // 2))])
+        m.close()
+    assert n_items == 40 and steps[0] == steps[1] == int(n_items / (4 * 2) * 2)
+    assert len(set(seen[0]) & set(seen[1])) == 0 and len(seen[0]) + len(seen[1]) == n_items

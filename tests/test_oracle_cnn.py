@@ -101,3 +101,29 @@ def test_inception_v1_known_answers():
     n = cnn_ref._Net(None, np.random.default_rng(0), run=False)
     cnn_ref._run_v1(n, np.zeros((1, 224, 224, 3), np.float32))
     assert n.macs == 1497352192 and len(n.conv_log) == 57
+
+
+def test_whole_network_vs_torch_formulation():
+    """oracle.torch_ref walks the same layer table with torch NCHW convolutions (oneDNN) and autograd: the whole
+    InceptionV3 forward and the conv-weight / BN-beta gradients of the numpy oracle agree with it (small image: every
+    layer type, SAME / VALID, stride 2, the asymmetric-free V3 paddings)."""
+    import torch
+    from oracle import torch_ref
+    p = cnn_ref.randomize_bn(cnn_ref.init_params(0, 107), 2)
+    x = np.random.default_rng(5).uniform(-1, 1, (2, 107, 107, 3)).astype(np.float32)
+    im, fm, net = torch_ref.torch_encoder(p, x)
+    im_ref, fm_ref = cnn_ref.encoder(p, x)
+    assert np.abs(fm.detach().numpy() - fm_ref).max() <= 2e-5 * np.abs(fm_ref).max()
+    assert np.abs(im.detach().numpy() - im_ref).max() <= 2e-5 * np.abs(im_ref).max()
+    rng = np.random.default_rng(6)
+    d_im = rng.standard_normal(im_ref.shape).astype(np.float32)
+    d_fm = rng.standard_normal(fm_ref.shape).astype(np.float32)
+    (im * torch.from_numpy(d_im)).sum().add((fm * torch.from_numpy(d_fm)).sum()).backward()
+    grads, _, _ = cnn_ref.inception_v3_grads(p, x, d_im, d_fm)
+    worst = 0.0
+    for wn, (w, scale, mean, beta) in net.tw.items():
+        gw = w.grad.numpy().transpose(2, 3, 1, 0)                       # OIHW -> HWIO
+        worst = max(worst, np.abs(gw - grads[wn]).max() / (np.abs(grads[wn]).max() + 1e-30))
+        bn = wn.replace('weights', 'BatchNorm/beta')
+        worst = max(worst, np.abs(beta.grad.numpy() - grads[bn]).max() / (np.abs(grads[bn]).max() + 1e-30))
+    assert len(net.tw) == 94 and worst < 2e-3, worst

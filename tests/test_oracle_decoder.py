@@ -34,86 +34,7 @@ def make_batch(cfg, B=5, M=7, L=9, seed=0, dtype=np.float64):
     return fm, im, caps
 
 
-def torch_forward(p, cfg, fm, im, caps, masks, rewards=None):
-    """Independent formulation: torch ops, F.layer_norm, F.cross_entropy, autograd."""
-    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
-    fm_t = torch.tensor(fm, dtype=torch.float64, requires_grad=True)
-    im_t = torch.tensor(im, dtype=torch.float64, requires_grad=True)
-    D, E, H = cfg.rnn_size, cfg.rnn_word_size, cfg.attn_num_heads
-    caps_t = torch.tensor(caps)
-    wmask = torch.sign((caps_t[:, 1:] + 1).double())
-    lens = wmask.sum(1).long()
-    inputs = caps_t[:, :-1]
-    if cfg.token_type == 'word':
-        inputs = inputs.clamp(min=0)
-    targets = caps_t.clamp(min=0)[:, 1:]
-    B, T = inputs.shape
-    Tp = int(lens.max())
-    M = fm.shape[1]
-    mk = (lambda k: None) if masks is None else (lambda k: torch.tensor(masks[k], dtype=torch.float64))
-
-    def drop(x, m, keep):
-        return x if m is None else x / keep * m
-
-    keys = fm_t @ tp['W_m']
-    if cfg.cnn_fm_projection == 'tied':
-        values = keys
-    elif cfg.cnn_fm_projection == 'independent':
-        values = fm_t @ tp['W_v']
-    else:
-        values = fm_t
-    Cv = values.shape[-1]
-
-    def lstm(xin, c, h):
-        g = torch.cat([xin, h], 1) @ tp['K'] + tp['b']
-        i, j, f, o = g.chunk(4, dim=1)
-        c2 = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
-        return c2, torch.tanh(c2) * torch.sigmoid(o)
-
-    z0 = torch.zeros(B, D, dtype=torch.float64)
-    if cfg.rnn_init_method == 'project_hidden':
-        h, c = im_t @ tp['W_init'], z0
-    else:
-        c, h = lstm(drop(im_t @ tp['W_init'], mk('init_in'), 1 - cfg.dropout_rnn_in), z0, z0)
-    att = torch.zeros(B, cfg.attn_size, dtype=torch.float64)
-    onehot = F.one_hot(inputs.clamp(min=0), cfg.softmax_size).double() * (inputs >= 0)[..., None]
-    emb = onehot @ tp['emb']
-    logits, alphas = [], []
-    mi, mo, ma = mk('inp'), mk('out'), mk('alpha')
-    for t in range(Tp):
-        fin = (t >= lens)[:, None]
-        u = drop(torch.cat([emb[:, t], att], 1), None if mi is None else mi[t], 1 - cfg.dropout_rnn_in)
-        c2, h2 = lstm(u, c, h)
-        y = drop(h2, None if mo is None else mo[t], 1 - cfg.dropout_rnn_out)
-        q = y @ tp['W_q']
-        if cfg.attn_alignment_method == 'add_LN':
-            zz = F.layer_norm(keys + q[:, None, :], (D,), tp['ln_g'], tp['ln_b'], eps=1e-12)
-            sc = (torch.tanh(zz) * tp['v']).view(B, M, H, D // H).sum(-1).permute(0, 2, 1) / tp['tau']
-        else:
-            sc = (keys * q[:, None, :]).view(B, M, H, D // H).sum(-1).permute(0, 2, 1) / math.sqrt(D / H)
-        if cfg.attn_probability_fn == 'softmax':
-            al = torch.softmax(sc, -1)
-        else:
-            sg = torch.sigmoid(sc)
-            al = sg / sg.sum(-1, keepdim=True)
-        al = drop(al, None if ma is None else ma[t], cfg.attn_keep_prob)
-        ctx = torch.matmul(al[:, :, None, :], values.view(B, M, H, Cv // H).permute(0, 2, 1, 3))
-        ctx = ctx.squeeze(2).reshape(B, Cv)
-        att2 = ctx @ tp['W_a'] if cfg.attn_context_layer else ctx
-        lg = y @ tp['W_o'] + tp['b_o']
-        logits.append(torch.where(fin, torch.zeros_like(lg), lg))
-        alphas.append(al)
-        c, h, att = torch.where(fin, c, c2), torch.where(fin, h, h2), torch.where(fin, att, att2)
-    logits = torch.stack(logits + [logits[-1]] * (T - Tp), 1)           # [B,T,V]
-    amap = torch.stack(alphas, 2)                                        # [B,H,T',M]
-    ce = F.cross_entropy(logits.reshape(B * T, -1), targets.reshape(-1), reduction='none').view(B, T) * wmask
-    if rewards is None:
-        xe = ce.sum() / (wmask.sum() + 1e-12)
-    else:
-        xe = ((ce.sum(1) / (wmask.sum(1) + 1e-12)) * torch.tensor(rewards, dtype=torch.float64)).mean()
-    map_loss = ((1.0 - amap.sum(1)) ** 2).mean() * cfg.rnn_map_loss_scale
-    l2 = sum(cfg.l2_decay * 0.5 * (v ** 2).sum() for v in tp.values())
-    return xe, map_loss, l2, logits, amap, tp, fm_t, im_t
+from oracle.torch_ref import torch_forward      # the independent torch formulation (also timed by bench.py)
 
 
 VARIANTS = [
@@ -264,3 +185,29 @@ def test_beam1_equals_greedy_until_eos_and_beam_invariants():
     ids, sc, amap = beam_ref.post_process_beam(pred, scores, hist, cfg, 3, top_beam=True)
     assert ids.shape == (B, T) and amap.shape == (B, cfg.attn_num_heads, T, fm.shape[1])
     np.testing.assert_allclose(amap.sum(-1), 1.0, rtol=1e-5)
+
+
+def test_legacy_head_oracle_vs_torch_autograd():
+    """Legacy encoder head (model_base.py:80-91): LN (eps 1e-12) + tanh + linear without bias."""
+    rng = np.random.default_rng(3)
+    B, C_, N = 5, 48, 20
+    p = dict(ln_gamma=rng.uniform(0.5, 1.5, C_), ln_beta=0.1 * rng.standard_normal(C_), W=rng.standard_normal((C_, N)) / 7)
+    net = rng.standard_normal((B, C_)) * 2 + 0.3
+    out, cache = dr.legacy_head_forward(p, net)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    y = torch.tanh(F.layer_norm(torch.tensor(net), (C_,), tp['ln_gamma'], tp['ln_beta'], eps=1e-12)) @ tp['W']
+    np.testing.assert_allclose(out, y.detach().numpy(), rtol=1e-6, atol=1e-6)
+    d = rng.standard_normal((B, N))
+    (y * torch.tensor(d)).sum().backward()
+    g = dr.legacy_head_backward(p, cache, d)
+    for k in g:
+        np.testing.assert_allclose(g[k], tp[k].grad.numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_momentum_oracle_formula():
+    w, acc = np.ones(3, np.float32), np.zeros(3, np.float32)
+    g = np.array([1, -2, 0.5], np.float32)
+    dr.momentum_tf_update(w, g, acc, 0.1)
+    dr.momentum_tf_update(w, g, acc, 0.1)
+    np.testing.assert_allclose(acc, 1.9 * g, rtol=1e-6)                 # 0.9*g + g
+    np.testing.assert_allclose(w, 1 - 0.1 * g - 0.1 * 1.9 * g, rtol=1e-6)
