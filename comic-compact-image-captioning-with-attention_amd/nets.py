@@ -501,6 +501,45 @@ class CnnPlan:
         return p
 
 
+def flat_layout(plan):
+    """Shapes of the flat master buffers: packed conv weights ([Cout][Kpad]; stem [K][Cout]) and per-channel vectors."""
+    wshapes, bshapes = {}, {}
+    for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+        cin_p, cout_p = plan.wphys[i]            # physical (padded) channel counts
+        K = kh * kw * cin_p
+        wshapes['w%d' % i] = (K * cout_p,) if stem else (cout_p * ((K + 63) // 64 * 64),)
+        bshapes['b%d' % i] = (cout_p,)
+    return wshapes, bshapes
+
+
+def plan_grad_buckets(plan, w_flat, b_flat, n=6):
+    """See CnnEncoder.grad_buckets; w_flat / b_flat: the FlatParams of the weights / betas (offsets only)."""
+    ranges = [tuple(r) for r in plan.block_ranges]
+    assert ranges and ranges[0][0] == 0 and ranges[-1][1] == len(plan.ops)
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), 'block ranges must tile the op list'
+
+    def widx(r):
+        ws = [plan.ops[i]['weight'] for i in range(*r) if plan.ops[i].get('weight', -1) >= 0 and plan.ops[i]['kind'] in (0, 1, 8)]
+        return (min(ws), max(ws) + 1) if ws else None
+    nW = len(plan.weights)
+    woff = [w_flat.offsets['w%d' % i] for i in range(nW)] + [w_flat.numel]
+    boff = [b_flat.offsets['b%d' % i] for i in range(nW)] + [b_flat.numel]
+    total = woff[-1]
+    out, hi_op, hi_w, acc_target = [], len(plan.ops), nW, total / float(max(1, n))
+    lo_w = nW
+    for k in range(len(ranges) - 1, -1, -1):
+        wr = widx(ranges[k])
+        if wr is not None:
+            assert wr[1] <= lo_w or wr[1] == hi_w, 'weights of a block must form one range below the later blocks'
+            lo_w = min(lo_w, wr[0])
+        size = woff[hi_w] - woff[lo_w]
+        if (size >= acc_target and len(out) < n - 1) or k == 0:
+            out.append((ranges[k][0], hi_op, (woff[lo_w], woff[hi_w]), (boff[lo_w], boff[hi_w])))
+            hi_op, hi_w = ranges[k][0], lo_w
+    assert out[-1][0] == 0 and out[-1][2][0] == 0
+    return out
+
+
 class CnnEncoder:
     """Device-resident encoder: packed weights, folded BN, activation buffers, one native
     forward call.  `dtype` 'bf16' (throughput path) or 'f32' (exact-fp32 MFMA, parity path)."""
@@ -704,45 +743,6 @@ class CnnEncoder:
         that are complete once the backward of those ops has been issued."""
         return plan_grad_buckets(self.plan, self.w_master, self.beta, n)
 
-
-def flat_layout(plan):
-    """Shapes of the flat master buffers: packed conv weights ([Cout][Kpad]; stem [K][Cout]) and per-channel vectors."""
-    wshapes, bshapes = {}, {}
-    for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
-        cin_p, cout_p = plan.wphys[i]            # physical (padded) channel counts
-        K = kh * kw * cin_p
-        wshapes['w%d' % i] = (K * cout_p,) if stem else (cout_p * ((K + 63) // 64 * 64),)
-        bshapes['b%d' % i] = (cout_p,)
-    return wshapes, bshapes
-
-
-def plan_grad_buckets(plan, w_flat, b_flat, n=6):
-    """See CnnEncoder.grad_buckets; w_flat / b_flat: the FlatParams of the weights / betas (offsets only)."""
-    if True:
-        ranges = [tuple(r) for r in plan.block_ranges]
-        assert ranges and ranges[0][0] == 0 and ranges[-1][1] == len(plan.ops)
-        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), 'block ranges must tile the op list'
-
-        def widx(r):
-            ws = [plan.ops[i]['weight'] for i in range(*r) if plan.ops[i].get('weight', -1) >= 0 and plan.ops[i]['kind'] in (0, 1, 8)]
-            return (min(ws), max(ws) + 1) if ws else None
-        nW = len(plan.weights)
-        woff = [w_flat.offsets['w%d' % i] for i in range(nW)] + [w_flat.numel]
-        boff = [b_flat.offsets['b%d' % i] for i in range(nW)] + [b_flat.numel]
-        total = woff[-1]
-        out, hi_op, hi_w, acc_target = [], len(plan.ops), nW, total / float(max(1, n))
-        lo_w = nW
-        for k in range(len(ranges) - 1, -1, -1):
-            wr = widx(ranges[k])
-            if wr is not None:
-                assert wr[1] <= lo_w or wr[1] == hi_w, 'weights of a block must form one range below the later blocks'
-                lo_w = min(lo_w, wr[0])
-            size = woff[hi_w] - woff[lo_w]
-            if (size >= acc_target and len(out) < n - 1) or k == 0:
-                out.append((ranges[k][0], hi_op, (woff[lo_w], woff[hi_w]), (boff[lo_w], boff[hi_w])))
-                hi_op, hi_w = ranges[k][0], lo_w
-        assert out[-1][0] == 0 and out[-1][2][0] == 0
-        return out
 
     def backward(self, d_fm, d_im_embed, buckets=None, on_bucket=None):
         """d_fm [B, M, C] / d_im_embed [B, C_g] fp32 (the gradients of `forward`'s two outputs; either
