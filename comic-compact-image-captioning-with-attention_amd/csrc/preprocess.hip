@@ -4,9 +4,10 @@
 // common/inputs/preprocessing/inception_preprocessing_radix.py:158-278 as used by
 // manager_image_caption.py:111-228): uint8 -> float [0,1] -> TF-1 bilinear resize to 256x256
 // (tf.image.resize_images, align_corners=False: src = dst * in/out, no half-pixel offset) -> optional horizontal
-// flip -> 224x224 (or any h x w) crop at (oy, ox) -> (x - 0.5) * 2.  The host keeps JPEG decoding only; the numpy
-// restatement comic_amd/inputs.preprocess_image is the parity reference (same rounding points: float32 pixel values,
-// float64 interpolation, one rounding to float32, float32 rescale -- bit-identical results).
+// flip -> 224x224 (or any h x w) crop at (oy, ox) -> (x - 0.5) * 2.  The host keeps JPEG decoding only.  float32
+// arithmetic at TF-1.9's rounding points (convert_image_dtype: cast * (1/255); resize_bilinear_op.cc compute_lerp:
+// top = tl + (tr - tl) * xl, bottom likewise, out = top + (bottom - top) * yl); every operation is an explicit _rn
+// intrinsic so nothing is contracted into an FMA.  Parity reference: oracle/preprocess_ref.py (bit-identical).
 #include "common.h"
 
 namespace {
@@ -18,10 +19,9 @@ struct ImgDesc {
   float sy, sx;       // float32(in_h / 256), float32(in_w / 256)
 };
 
-// a * (1 - w) + b * w as numpy evaluates the restatement: the weights (ys - y0) are float64 there (float32 minus
-// int64 promotes), so the interpolation runs in float64 and is rounded to float32 once at the end
-__device__ __forceinline__ double lerp_rn(double a, double b, double w) {
-  return __dadd_rn(__dmul_rn(a, __dsub_rn(1.0, w)), __dmul_rn(b, w));
+// a + (b - a) * w, three roundings (resize_bilinear_op.cc compute_lerp [TF-1.9])
+__device__ __forceinline__ float lerp_rn(float a, float b, float w) {
+  return __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), w));
 }
 
 __global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __restrict__ blob,
@@ -36,18 +36,19 @@ __global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __
   const int X = d.flip ? resize - 1 - (d.ox + x) : d.ox + x;
   const float ys = __fmul_rn((float)Y, d.sy), xs = __fmul_rn((float)X, d.sx);
   const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
-  const int y1 = min(y0 + 1, d.in_h - 1), x1 = min(x0 + 1, d.in_w - 1);
-  const double wy = __dsub_rn((double)ys, (double)y0), wx = __dsub_rn((double)xs, (double)x0);
+  const int y1 = min((int)ceilf(ys), d.in_h - 1), x1 = min((int)ceilf(xs), d.in_w - 1);
+  const float wy = __fsub_rn(ys, (float)y0), wx = __fsub_rn(xs, (float)x0);
+  const float inv255 = (float)(1.0 / 255);
   const uint8_t* src = blob + d.offset;
   const uint8_t* r0 = src + (size_t)y0 * d.in_w * 3;
   const uint8_t* r1 = src + (size_t)y1 * d.in_w * 3;
   float* o = dst + ((size_t)i * out_h * out_w + p) * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const double p00 = __fdiv_rn((float)r0[x0 * 3 + c], 255.0f), p01 = __fdiv_rn((float)r0[x1 * 3 + c], 255.0f);
-    const double p10 = __fdiv_rn((float)r1[x0 * 3 + c], 255.0f), p11 = __fdiv_rn((float)r1[x1 * 3 + c], 255.0f);
-    const double top = lerp_rn(p00, p01, wx), bot = lerp_rn(p10, p11, wx);
-    const float v = (float)lerp_rn(top, bot, wy);
+    const float p00 = __fmul_rn((float)r0[x0 * 3 + c], inv255), p01 = __fmul_rn((float)r0[x1 * 3 + c], inv255);
+    const float p10 = __fmul_rn((float)r1[x0 * 3 + c], inv255), p11 = __fmul_rn((float)r1[x1 * 3 + c], inv255);
+    const float top = lerp_rn(p00, p01, wx), bot = lerp_rn(p10, p11, wx);
+    const float v = lerp_rn(top, bot, wy);
     o[c] = __fmul_rn(__fsub_rn(v, 0.5f), 2.0f);
   }
 }

@@ -30,16 +30,18 @@ pjoin = os.path.join
 
 
 def resize_bilinear_tf1(img, out_h, out_w):
-    """tf.image.resize_images(..., BILINEAR, align_corners=False) [TF-1.9]: src = dst * in/out."""
+    """tf.image.resize_bilinear(..., align_corners=False) [TF-1.9 resize_bilinear_op.cc]: src = dst * in/out, float32
+    interpolation a + (b - a) * w (host path for CPU-only use; the training path runs csrc/preprocess.hip)."""
+    f = np.float32
     in_h, in_w = img.shape[:2]
-    ys = np.arange(out_h, dtype=np.float32) * np.float32(in_h / out_h)
-    xs = np.arange(out_w, dtype=np.float32) * np.float32(in_w / out_w)
+    ys = np.arange(out_h, dtype=np.float32) * f(in_h / f(out_h))
+    xs = np.arange(out_w, dtype=np.float32) * f(in_w / f(out_w))
     y0 = np.floor(ys).astype(np.int64); x0 = np.floor(xs).astype(np.int64)
-    y1 = np.minimum(y0 + 1, in_h - 1); x1 = np.minimum(x0 + 1, in_w - 1)
-    wy = (ys - y0)[:, None, None]; wx = (xs - x0)[None, :, None]
-    top = img[y0][:, x0] * (1 - wx) + img[y0][:, x1] * wx
-    bot = img[y1][:, x0] * (1 - wx) + img[y1][:, x1] * wx
-    return (top * (1 - wy) + bot * wy).astype(np.float32)
+    y1 = np.minimum(np.ceil(ys).astype(np.int64), in_h - 1); x1 = np.minimum(np.ceil(xs).astype(np.int64), in_w - 1)
+    wy = (ys - y0.astype(np.float32))[:, None, None]; wx = (xs - x0.astype(np.float32))[None, :, None]
+    top = img[y0][:, x0] + (img[y0][:, x1] - img[y0][:, x0]) * wx
+    bot = img[y1][:, x0] + (img[y1][:, x1] - img[y1][:, x0]) * wx
+    return top + (bot - top) * wy
 
 
 class Prefetch(object):
@@ -233,7 +235,7 @@ class DevicePreprocessor(object):
 
 def preprocess_image(path_or_array, height, width, augment, rng, params=None):
     img = decode_image(path_or_array)
-    img = img.astype(np.float32) / np.float32(255.0)
+    img = img.astype(np.float32) * np.float32(1.0 / 255)      # tf.image.convert_image_dtype [TF-1.9]
     img = resize_bilinear_tf1(img, 256, 256)
     flip, oy, ox = params if params is not None else draw_augmentation(augment, height, width, rng)
     if flip:

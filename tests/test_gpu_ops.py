@@ -287,10 +287,11 @@ def _run_pool(x, kind, k, s, pad, dtype, dst_channels=None, dst_coff=0):
 
 
 def test_device_image_preprocess_matches_numpy_pipeline():
-    """comic_image_preprocess (uint8 -> [0,1] -> TF-1 bilinear 256x256 -> flip -> crop -> [-1,1]) against the numpy
-    restatement of the reference's preprocessing, bit for bit: odd sizes, up- and down-scaling, flips, crop offsets;
-    staging slots re-used across calls."""
+    """comic_image_preprocess (uint8 -> [0,1] -> TF-1 bilinear 256x256 -> flip -> crop -> [-1,1]) against the ORACLE's
+    restatement of inception_preprocessing_radix.py:158-278 (oracle/preprocess_ref.py), bit for bit: odd sizes, up- and
+    down-scaling, flips, crop offsets; staging slots re-used across calls; and the product's own host path against it."""
     from comic_amd import inputs
+    from oracle import preprocess_ref
     rng = np.random.default_rng(5)
     pre = inputs.DevicePreprocessor(DEV, 224, 224)
     for rep in range(3):
@@ -299,12 +300,13 @@ def test_device_image_preprocess_matches_numpy_pipeline():
         params = [(bool(rng.integers(2)), int(rng.integers(0, 33)), int(rng.integers(0, 33))) for _ in ims]
         got = pre(ims, params).cpu().numpy()
         for i, (im, prm) in enumerate(zip(ims, params)):
-            want = inputs.preprocess_image(im, 224, 224, True, None, prm)
+            want = preprocess_ref.preprocess_image(im, 224, 224, *prm)
             np.testing.assert_array_equal(got[i], want, err_msg='image %d %s %s' % (i, im.shape, prm))
+            np.testing.assert_array_equal(inputs.preprocess_image(im, 224, 224, True, None, prm), want)
     pre299 = inputs.DevicePreprocessor(DEV, 256, 256)          # no crop margin
     im = rng.integers(0, 256, (300, 300, 3), dtype=np.uint8)
     np.testing.assert_array_equal(pre299([im], [(True, 0, 0)]).cpu().numpy()[0],
-                                  inputs.preprocess_image(im, 256, 256, True, None, (True, 0, 0)))
+                                  preprocess_ref.preprocess_image(im, 256, 256, True, 0, 0))
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

@@ -500,3 +500,34 @@ def test_data_parallel_shards_are_disjoint_and_cover_the_epoch(tmp_path):
         m.close()
     assert n_items == 40 and steps[0] == steps[1] == int(n_items / (4 * 2) * 2)
     assert len(set(seen[0]) & set(seen[1])) == 0 and len(seen[0]) + len(seen[1]) == n_items
+
+
+def test_preprocess_oracle_against_scalar_loop_and_host_path():
+    """oracle/preprocess_ref.py (vectorised float32) against a scalar restatement of TF-1.9's resize_bilinear loop on a
+    small image, and the product's CPU path (inputs.preprocess_image) against the oracle, bit for bit."""
+    from comic_amd import inputs
+    from oracle import preprocess_ref as pr
+    rng = np.random.default_rng(2)
+    im = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    f = np.float32
+    x = im.astype(np.float32) * f(1.0 / 255)
+    out = np.zeros((256, 256, 3), np.float32)
+    sy, sx = f(7 / f(256)), f(5 / f(256))
+    for yy in range(0, 256, 37):
+        for xx in range(0, 256, 41):
+            iy, ix = f(yy) * sy, f(xx) * sx
+            y0, x0 = int(np.floor(iy)), int(np.floor(ix))
+            y1, x1 = min(int(np.ceil(iy)), 6), min(int(np.ceil(ix)), 4)
+            yl, xl = f(iy - f(y0)), f(ix - f(x0))
+            top = x[y0, x0] + (x[y0, x1] - x[y0, x0]) * xl
+            bot = x[y1, x0] + (x[y1, x1] - x[y1, x0]) * xl
+            out[yy, xx] = top + (bot - top) * yl
+    ref = pr.resize_bilinear(x)
+    for yy in range(0, 256, 37):
+        for xx in range(0, 256, 41):
+            np.testing.assert_array_equal(ref[yy, xx], out[yy, xx])
+    big = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(inputs.preprocess_image(big, 224, 224, True, None, (True, 5, 30)),
+                                  pr.preprocess_image(big, 224, 224, True, 5, 30))
+    np.testing.assert_array_equal(inputs.preprocess_image(big, 224, 224, False, None), pr.preprocess_image(big, 224, 224))
+    assert pr.preprocess_image(big, 224, 224).min() >= -1.0 and pr.preprocess_image(big, 224, 224).max() <= 1.0

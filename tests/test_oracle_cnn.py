@@ -37,6 +37,18 @@ def test_endpoint_shapes_299():
     assert pooled.shape == (1, 1, 1, 2048)                        # inception_v3_test.py:46-56
 
 
+def test_half_size_images_150():
+    """inception_v3_test.py:210-222 (testHalfSizeImages): 150 x 150 inputs give a 3 x 3 x 2048 Mixed_7c; the product's
+    plan builder agrees (and with the 224 / 299 maps of SURVEY section 0)."""
+    net = cnn_ref._Net(None, np.random.default_rng(0), run=False)
+    pooled, ep = cnn_ref._run(net, np.zeros((5, 150, 150, 3), np.float32))
+    assert ep['Mixed_7c'].shape == (5, 3, 3, 2048) and pooled.shape == (5, 1, 1, 2048)
+    from comic_amd import nets
+    for size, fm in ((150, (3, 3, 2048)), (224, (5, 5, 2048)), (299, (8, 8, 2048))):
+        assert nets.CnnPlan('inception_v3', (size, size)).fm_dims() == fm
+        assert nets.CnnPlan('inception_v3', (size, size), pool_after_projection=True, fuse_pools=True).fm_dims() == fm
+
+
 def test_primitives_vs_torch():
     rng = np.random.default_rng(0)
     x = rng.standard_normal((2, 13, 11, 8)).astype(np.float32)

@@ -115,6 +115,25 @@ def test_known_answer_param_count():
     assert dr.count_params(dr.init_params(cfg3)) == 5707011
 
 
+def test_readme_decoder_sizes_are_reproduced():
+    """README.md:219-233 lists four decoder sizes for Inception-V1 / Mixed_4f (C = 832, C_g = 1024; parameters of scope
+    Model/decoder/rnn_decoder, train_fn.py:83): COMIC-256 4.3 M (default) and 4.0 M (legacy: project_hidden init, the
+    LN_tanh + im_embed head sits under Model/encoder and is not counted), word baseline (word tokens, 1 head, no
+    feature-map projection: README.md:92-104) 12.7 M (default) and 12.2 M (legacy).  The two baseline figures pin the
+    MS-COCO vocabulary to 9958..9970 softmax classes; every one of them reproduces both."""
+    def count(**kw):
+        return dr.count_params(dr.init_params(dr.DecoderConfig(fm_channels=832, im_embed_size=1024, **kw)))
+    assert count() == 4297987 and round(count() / 1e6, 1) == 4.3
+    legacy_comic = count(rnn_init_method='project_hidden')
+    assert legacy_comic == 4297987 - 1024 * (256 + 512) + 1024 * 512 == 4035843 and round(legacy_comic / 1e6, 1) == 4.0
+    base = dict(token_type='word', attn_num_heads=1, cnn_fm_projection=None)
+    for V in (9958, 9962, 9970):
+        n = count(softmax_size=V, start_id=V - 2, end_id=V - 1, **base)
+        assert n == 5082625 + 769 * V and round(n / 1e6, 1) == 12.7
+        n_leg = count(softmax_size=V, start_id=V - 2, end_id=V - 1, rnn_init_method='project_hidden', **base)
+        assert n_leg == n - 1024 * (256 + 832) + 1024 * 512 and round(n_leg / 1e6, 1) == 12.2
+
+
 def test_process_inputs_masks():
     caps = np.array([[256, 3, 4, 257, -1, -1], [256, 9, 8, 7, 6, 257]])
     inp, tgt, m, lens = dr.process_inputs(caps, 'radix')
