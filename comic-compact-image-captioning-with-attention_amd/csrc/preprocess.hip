@@ -6,8 +6,8 @@
 // (tf.image.resize_images, align_corners=False: src = dst * in/out, no half-pixel offset) -> optional horizontal
 // flip -> 224x224 (or any h x w) crop at (oy, ox) -> (x - 0.5) * 2.  The host keeps JPEG decoding only.  float32
 // arithmetic at TF-1.9's rounding points (convert_image_dtype: cast * (1/255); resize_bilinear_op.cc compute_lerp:
-// top = tl + (tr - tl) * xl, bottom likewise, out = top + (bottom - top) * yl); every operation is an explicit _rn
-// intrinsic so nothing is contracted into an FMA.  Parity reference: oracle/preprocess_ref.py (bit-identical).
+// top = tl + (tr - tl) * xl, bottom likewise, out = top + (bottom - top) * yl); contraction into FMAs is
+// switched off (#pragma clang fp contract(off)) so every operation rounds on its own.  Parity reference: oracle/preprocess_ref.py (bit-identical).
 #include "common.h"
 
 namespace {
@@ -19,14 +19,20 @@ struct ImgDesc {
   float sy, sx;       // float32(in_h / 256), float32(in_w / 256)
 };
 
-// a + (b - a) * w, three roundings (resize_bilinear_op.cc compute_lerp [TF-1.9])
+// a + (b - a) * w, three roundings (resize_bilinear_op.cc compute_lerp [TF-1.9]).  HIP's __f*_rn intrinsics are plain
+// operators on AMD and hipcc contracts a + b * c into an FMA by default (-ffp-contract=fast): contraction is switched
+// off for these functions, the TF kernel (built without FMA) rounds after the product.
 __device__ __forceinline__ float lerp_rn(float a, float b, float w) {
-  return __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), w));
+#pragma clang fp contract(off)
+  const float d = b - a;
+  const float m = d * w;
+  return a + m;
 }
 
 __global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __restrict__ blob,
                                                                const ImgDesc* __restrict__ desc, float* __restrict__ dst,
                                                                int out_h, int out_w, int resize) {
+#pragma clang fp contract(off)
   const int i = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= out_h * out_w) return;
@@ -34,10 +40,10 @@ __global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __
   const int y = p / out_w, x = p % out_w;
   const int Y = d.oy + y;
   const int X = d.flip ? resize - 1 - (d.ox + x) : d.ox + x;
-  const float ys = __fmul_rn((float)Y, d.sy), xs = __fmul_rn((float)X, d.sx);
+  const float ys = (float)Y * d.sy, xs = (float)X * d.sx;
   const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
   const int y1 = min((int)ceilf(ys), d.in_h - 1), x1 = min((int)ceilf(xs), d.in_w - 1);
-  const float wy = __fsub_rn(ys, (float)y0), wx = __fsub_rn(xs, (float)x0);
+  const float wy = ys - (float)y0, wx = xs - (float)x0;
   const float inv255 = (float)(1.0 / 255);
   const uint8_t* src = blob + d.offset;
   const uint8_t* r0 = src + (size_t)y0 * d.in_w * 3;
@@ -45,11 +51,12 @@ __global__ __launch_bounds__(256) void image_preprocess_kernel(const uint8_t* __
   float* o = dst + ((size_t)i * out_h * out_w + p) * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float p00 = __fmul_rn((float)r0[x0 * 3 + c], inv255), p01 = __fmul_rn((float)r0[x1 * 3 + c], inv255);
-    const float p10 = __fmul_rn((float)r1[x0 * 3 + c], inv255), p11 = __fmul_rn((float)r1[x1 * 3 + c], inv255);
+    const float p00 = (float)r0[x0 * 3 + c] * inv255, p01 = (float)r0[x1 * 3 + c] * inv255;
+    const float p10 = (float)r1[x0 * 3 + c] * inv255, p11 = (float)r1[x1 * 3 + c] * inv255;
     const float top = lerp_rn(p00, p01, wx), bot = lerp_rn(p10, p11, wx);
     const float v = lerp_rn(top, bot, wy);
-    o[c] = __fmul_rn(__fsub_rn(v, 0.5f), 2.0f);
+    const float centred = v - 0.5f;
+    o[c] = centred * 2.0f;
   }
 }
 

@@ -188,7 +188,11 @@ def avg_pool_bwd(x_shape, dy, k=3, stride=1, padding='SAME'):
 # network builder: used both to create parameters and to run the forward pass
 # --------------------------------------------------------------------------- #
 class _Net:
-    def __init__(self, params=None, rng=None, act_dtype='f32', run=True, tape=False):
+    def __init__(self, params=None, rng=None, act_dtype='f32', run=True, tape=False, override=None):
+        # override(weights name, y) -> y': hook applied to every conv output.  The backward parity tests substitute
+        # the DEVICE's activation there (after comparing it with y), so the oracle's reverse pass sees the same ReLU
+        # masks and pool arg-maxima as the kernels and the gradient comparison measures arithmetic, not mask flips
+        self.override = override
         self.tape = [] if tape else None     # reverse-mode records: (kind, inputs, output, ctx)
         self.params = params if params is not None else OrderedDict()
         self.create = params is None
@@ -228,6 +232,8 @@ class _Net:
             y = conv2d(_q(x, self.act_dtype), _q(w, self.act_dtype), stride, padding)
             y = batch_norm_inference(y, self.params[bn], self.params[mn], self.params[vn])
             y = _q(np.maximum(y, 0), self.act_dtype)
+            if self.override is not None:
+                y = self.override(wn, y)
             if self.tape is not None:
                 self.tape.append(('conv', [x], y, (wn, bn, vn, stride, padding)))
         else:
@@ -454,8 +460,8 @@ def inception_v1(params, images, act_dtype='f32'):
     return _run_v1(_Net(params, None, act_dtype=act_dtype, run=True), images)
 
 
-def inception_v1_grads(params, images, d_net, d_fm, fm_name='Mixed_4f', act_dtype='f32'):
-    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+def inception_v1_grads(params, images, d_net, d_fm, fm_name='Mixed_4f', act_dtype='f32', override=None):
+    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True, override=override)
     net, ep = _run_v1(n, images)
     seeds = []
     if d_net is not None:
@@ -503,13 +509,13 @@ def inception_v3(params, images, act_dtype='f32'):
     return _run(net, images)
 
 
-def inception_v3_grads(params, images, d_net, d_fm, fm_name='Mixed_7c', act_dtype='f32'):
+def inception_v3_grads(params, images, d_net, d_fm, fm_name='Mixed_7c', act_dtype='f32', override=None):
     """Gradients of the CNN variables given d(net [B,1,1,C]) and d(end_points[fm_name]) (the
     two tensors ModelBase._encoder hands to the decoder, model_base.py:93-104).
     -> (grads {name: array}, net, end_points)."""
     # act_dtype='bf16': the taped forward emulates the product's bf16 storage (so the ReLU masks and
     # pool arg-maxima are those of a bf16 forward); the reverse pass itself stays fp32
-    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+    n = _Net(params, None, act_dtype=act_dtype, run=True, tape=True, override=override)
     net, ep = _run(n, images)
     seeds = []
     if d_net is not None:

@@ -199,13 +199,35 @@ def test_inception_v1_backward_224_f32():
     enc.backward(dev(d_fm), dev(d_net))
     sync()
     got = enc.export_grads()
-    want, _, _ = cnn_ref.inception_v1_grads(params, x, d_net, d_fm)
+    # the oracle differentiates through the device's activations (same ReLU masks / pool arg-maxima: every block has a
+    # 3x3 stride-1 max-pool branch whose arg-max flips between two free-running forwards reach every layer)
+    worst = [0.0]
+    want, _, _ = cnn_ref.inception_v1_grads(params, x, d_net, d_fm, override=_device_activation_hook(enc, 1e-4, worst))
     assert set(got) == set(want) and len(want) == 114
     errs = sorted((rel_err(got[k], want[k]), k) for k in want)
-    assert errs[-1][0] < 2e-3, errs[-1]
-    # every block has a 3x3 stride-1 max-pool branch, so arg-max flips between the two (1e-6 apart) forward
-    # passes reach every layer: the median is ~1e-4 here, against ~1e-6 for InceptionV3
-    assert errs[len(errs) // 2][0] < 5e-4, errs[len(errs) // 2]
+    assert errs[-1][0] < F32_RTOL, errs[-1]
+    assert errs[len(errs) // 2][0] < 1e-4, errs[len(errs) // 2]
+
+
+def _device_activation_hook(enc, layer_tol, worst):
+    """override hook for cnn_ref._Net: compares the oracle's output of every conv with the DEVICE's activation (max-norm,
+    `layer_tol`; the largest error is kept in worst[0]) and hands the device's values to the rest of the oracle's pass,
+    so the reverse pass sees the kernels' own ReLU masks and pool arg-maxima."""
+    plan = enc.plan
+    by_name = {}
+    for o in plan.ops:
+        if o['kind'] in (0, 1):
+            by_name[plan.weights[o['weight']][0] + '/weights'] = o
+
+    def hook(wn, y):
+        o = by_name[wn]
+        cout = plan.weights[o['weight']][4]
+        act = enc.bufs[o['dst']][..., o['dst_coff']:o['dst_coff'] + cout].float().cpu().numpy()
+        e = rel_err(act, y)
+        worst[0] = max(worst[0], e)
+        assert e <= layer_tol, '%s: forward rel err %.3e > %.1e' % (wn, e, layer_tol)
+        return act
+    return hook
 
 
 def _seeds(rng, B, M, C):
@@ -218,10 +240,10 @@ def _seeds(rng, B, M, C):
 
 def test_inception_v3_backward_224_f32():
     """cnn_finetune: d(conv weights), d(BN beta) of all 94 convs from seeded gradients of the two
-    encoder outputs, against the oracle's reverse pass.  fp32 plan; the tolerance (max-norm per
-    variable) is 2e-3 rather than 1e-3 because ReLU masks of near-zero activations differ between
-    the two forward passes in the 109x109 / 54x54 stem layers (median error over the 188
-    variables is ~1e-6, asserted below)."""
+    encoder outputs, against the oracle's reverse pass, 1e-3 per variable (max-norm) -- the north star's bound.  The
+    oracle's pass runs layer by layer on the DEVICE's activations (each first checked against the oracle's own output
+    of that layer at 1e-4), so both sides differentiate through the same ReLU masks and pool arg-maxima; a free-running
+    oracle forward differs in ~1e-6 of the masks of the 109x109 stem maps, which alone moved single variables by 2e-3."""
     B = 2
     params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
     rng = np.random.default_rng(11)
@@ -232,10 +254,11 @@ def test_inception_v3_backward_224_f32():
     t = enc.backward(dev(d_fm), dev(d_net))
     sync()
     got = _cnn_grads_device(enc, t)
-    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm)
+    worst = [0.0]
+    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm, override=_device_activation_hook(enc, 1e-4, worst))
     assert set(got) == set(want) and len(want) == 188
     errs = sorted((rel_err(got[k], want[k]), k) for k in want)
-    assert errs[-1][0] < 2e-3, errs[-1]
+    assert errs[-1][0] < F32_RTOL, errs[-1]
     assert errs[len(errs) // 2][0] < 1e-5, errs[len(errs) // 2]
     # the trainable copies export back to the checkpoint layout unchanged
     ex = enc.export_params()
@@ -292,9 +315,10 @@ def test_cnn_backward_chain(dtype, tol, B, size):
 
 
 def test_inception_v3_backward_224_bf16_sanity():
-    """Whole-network bf16 backward against the fp32-arithmetic oracle over a bf16-emulating
-    forward.  After ~45 bf16 layers the two forwards differ by up to 3e-2 (forward test), so a few
-    per cent of the ReLU masks differ; the per-kernel bf16 bound is test_cnn_backward_chain's."""
+    """Whole-network bf16 backward (the path the cnn_finetune extra times) against the fp32-arithmetic oracle.  The
+    oracle's pass consumes the device's bf16 activations layer by layer (each within 2e-2 of the oracle's bf16-emulating
+    output of that layer: one layer of bf16 products, not 45), so the masks agree and every variable is held to the
+    per-kernel bf16 bound of test_cnn_backward_chain (4e-2) instead of the 0.2 a free-running forward needed."""
     B = 2
     params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
     rng = np.random.default_rng(11)
@@ -305,10 +329,12 @@ def test_inception_v3_backward_224_bf16_sanity():
     t = enc.backward(dev(d_fm), dev(d_net))
     sync()
     got = _cnn_grads_device(enc, t)
-    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm, act_dtype='bf16')
+    worst = [0.0]
+    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm, act_dtype='bf16',
+                                            override=_device_activation_hook(enc, 2e-2, worst))
     errs = sorted((rel_err(got[k], want[k]), k) for k in want)
-    assert errs[-1][0] < 0.2, errs[-1]
-    assert errs[len(errs) // 2][0] < 6e-2, errs[len(errs) // 2]
+    assert errs[-1][0] < 4e-2, errs[-1]
+    assert errs[len(errs) // 2][0] < 1e-2, errs[len(errs) // 2]
     assert all(np.isfinite(v).all() for v in got.values())
 
 
@@ -488,7 +514,9 @@ def test_cnn_finetune_step_end_to_end():
     for step in (1, 2):
         res = tr.finetune_step(dev(x), caps, training=False)
         sync()
-        n = cnn_ref._Net(ow, None, act_dtype='f32', run=True, tape=True)
+        # the oracle walks the device's activations of THIS step (same masks / arg-maxima, see _device_activation_hook)
+        n = cnn_ref._Net(ow, None, act_dtype='f32', run=True, tape=True,
+                         override=_device_activation_hook(tr.encoder, 1e-3, [0.0]))
         n.scope.append('Chain')
         h = x
         for op in _CHAIN:
@@ -497,7 +525,7 @@ def test_cnn_finetune_step_end_to_end():
         pooled = n.avg_pool(h, (h.shape[1], h.shape[2]), 1, 'VALID')
         out = dr.train_forward(dp_, cfg, h.reshape(B, Hf * Wf, Cf), pooled.reshape(B, Cf), caps, None, None)
         grads, dfm, dim = dr.train_backward(dp_, cfg, out)
-        assert abs(float(res['loss']) - float(out['xe'])) <= 2e-3 * abs(float(out['xe'])) + 1e-6, step
+        assert abs(float(res['loss']) - float(out['xe'])) <= F32_RTOL * abs(float(out['xe'])) + 1e-6, step
         g = n.backward([(pooled, dim.reshape(pooled.shape)), (h, dfm.reshape(h.shape))])
         for k in names:
             dr.adam_tf_update(ow[k], np.asarray(g[k], np.float32), om[k], ov[k], step, lr, eps=eps)
@@ -506,10 +534,10 @@ def test_cnn_finetune_step_end_to_end():
     got = tr.encoder.export_params()
     for k in names:
         # compare the UPDATE (w - w0): the variables themselves barely move in two steps
-        assert_close(got[k] - cnn_p[k], ow[k] - cnn_p[k], 5e-3, 'finetune update ' + k)
+        assert_close(got[k] - cnn_p[k], ow[k] - cnn_p[k], F32_RTOL, 'finetune update ' + k)
     gd = tr.decoder.params.to_numpy()
     for k in ('K', 'W_q', 'W_m', 'W_o'):
-        assert_close(gd[k] - p[k], dp_[k] - p[k], 5e-3, 'decoder update ' + k)
+        assert_close(gd[k] - p[k], dp_[k] - p[k], F32_RTOL, 'decoder update ' + k)
 
 
 def test_known_answer_param_count_on_device():
