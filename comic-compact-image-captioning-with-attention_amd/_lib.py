@@ -133,6 +133,14 @@ def load():
         raise ComicHipError(
             'HIP library not built: %s is missing (run `python -c "import __graft_entry__ as g; g.build()"`). '
             'There is no CPU fallback.' % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64.so, and the process must end up with ONE HIP runtime.  Loaded
+    # after torch, libcomic_hip.so binds to the runtime torch brought in; loaded before it, /opt/rocm's copy comes in,
+    # torch adds its own and this library's kernels are registered with a runtime that never sees the device
+    # ("no ROCm-capable device is detected" at the first launch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         try:
