@@ -612,3 +612,92 @@ def test_train_step_full_batch_properties():
     ra = dec.train_step(dev(fm[:32]), dev(im[:32]), caps[:32], training=False)
     Ta = ra['logits'].shape[1]
     assert_close(ra['logits'].cpu().numpy(), lg1[:32, :Ta].cpu().numpy(), 1e-5, 'half-batch logits')
+
+
+def test_fullsize_word_baseline_beam3_properties():
+    """BASELINE configs[4] at full size (word tokens, V = 25 599, 1 head, no feature-map projection, batch 50, beam 3,
+    30 steps) -- beyond what the oracle finishes in seconds, so size-independent properties: ids inside the vocabulary,
+    the final beams ordered by score, parents inside the beam, beam-1 == greedy up to the first EOS, determinism."""
+    V = 25599
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048, V=V, H=1, fm_projection=None, token_type='word',
+                              start_id=V - 2, end_id=V - 1)
+    p = _rand_params(cfg, 9)
+    p['b_o'][spec.end_id] = 2.5
+    B, steps = 50, 30
+    fm, im, _ = _batch(spec, B, 6, 33)
+    dec = cdec.Decoder(spec, p, DEV)
+    r = dec.beam_search(dev(fm), dev(im), 3, steps, want_attention=False)
+    T = r['predicted_ids'].shape[0]
+    assert 1 <= T <= steps and r['predicted_ids'].shape[1:] == (B, 3)
+    assert r['predicted_ids'].min() >= 0 and r['predicted_ids'].max() < V
+    assert r['parent_ids'].min() >= 0 and r['parent_ids'].max() < 3
+    sc = r['scores'][T - 1]                                            # cumulative log-probabilities of the final beams
+    assert np.all(np.diff(sc, axis=1) <= 1e-6), 'beams are not ordered by score'
+    fin = np.isfinite(r['scores'])
+    assert np.all(np.diff(np.where(fin, r['scores'], -1e30)[:, :, 0], axis=0) <= 1e-5), 'best score must not increase'
+    r2 = dec.beam_search(dev(fm), dev(im), 3, steps, want_attention=False)
+    np.testing.assert_array_equal(r['predicted_ids'], r2['predicted_ids'])
+    g_ids, _, _ = dec.greedy(dev(fm), dev(im), steps)
+    b1 = dec.beam_search(dev(fm), dev(im), 1, steps, want_attention=False)['predicted_ids'][:, :, 0].T     # [B, T1]
+    for b in range(B):
+        eos = np.flatnonzero(g_ids[b] == spec.end_id)
+        n = min((eos[0] + 1) if len(eos) else g_ids.shape[1], b1.shape[1], g_ids.shape[1])
+        np.testing.assert_array_equal(b1[b, :n], g_ids[b, :n], err_msg='row %d' % b)
+
+
+def test_fullsize_scst_step_properties():
+    """BASELINE configs[3] at full size: the reward-weighted step on 32 x 7 = 224 hypothesis rows (COMIC-256, 5x5x2048
+    map).  Deterministic bit for bit; the gradient is LINEAR in the rewards (model_base.py:342-347: mean_b(xent_b *
+    reward_b); map loss off here); rows with reward 0 contribute nothing; every gradient finite."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048, map_loss_scale=0.0)
+    rows = 224
+    fm, im, caps = _batch(spec, rows, 22, 5)
+    rng = np.random.default_rng(6)
+    r1 = rng.standard_normal(rows).astype(np.float32)
+    r2 = rng.standard_normal(rows).astype(np.float32)
+    dec = cdec.Decoder(spec, _rand_params(cfg, 2), DEV)
+    dec.spec.l2_decay = 0.0
+
+    def grads(r):
+        dec.train_step(dev(fm), dev(im), caps, rewards=r, training=False)
+        return dec.grads.data.clone()
+    ga, gb, gab = grads(r1), grads(r2), grads(r1 + r2)
+    assert torch.equal(ga, grads(r1)), 'the SCST step is not deterministic'
+    assert torch.isfinite(gab).all()
+    den = float(gab.abs().max())
+    assert float((ga + gb - gab).abs().max()) <= 1e-4 * den, 'gradient is not linear in the rewards'
+    half = r1.copy(); half[112:] = 0
+    g_half = grads(half)
+    dec.train_step(dev(fm[:112]), dev(im[:112]), caps[:112], rewards=r1[:112] * np.float32(112 / 224), training=False)
+    assert float((g_half - dec.grads.data).abs().max()) <= 1e-4 * float(g_half.abs().max()), 'zero-reward rows leak'
+
+
+def test_fullsize_cnn_finetune_step_properties():
+    """BASELINE configs[2] at its per-GPU size (batch 32, 224 x 224, bf16 activations, fp32 masters): two trainers from
+    the same state take the same step (fp32 atomics in dW: 1e-5), the loss falls over three steps on a fixed batch,
+    every updated variable is finite and has moved."""
+    from comic_amd import trainer
+    B = 32
+    cnn_p = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    p = _rand_params(cfg, 4)
+    rng = np.random.default_rng(8)
+    x = dev(rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32))
+    _, _, caps = _batch(spec, B, 24, 9)
+    outs = []
+    for rep in range(2):
+        tr = trainer.CaptionTrainer(cnn_p, spec, p, B, (224, 224), 'bf16', DEV, lr_start=1e-3, lr_end=1e-3, max_step=10)
+        tr.use_graph = False
+        tr.enable_cnn_finetune()
+        losses = [float(tr.finetune_step(x, caps, training=False)['loss']) for _ in range(3)]
+        sync()
+        outs.append((losses, tr.encoder.w_master.data.clone(), tr.decoder.params.data.clone()))
+        del tr
+    (l0, w0, d0), (l1, w1, d1) = outs
+    assert all(np.isfinite(l0)) and l0[2] < l0[0], l0
+    assert abs(l0[2] - l1[2]) <= 1e-4 * abs(l0[2])
+    assert torch.isfinite(w0).all() and torch.isfinite(d0).all()
+    assert float((w0 - w1).abs().max()) <= 1e-4 * float(w0.abs().max())
+    assert float((d0 - d1).abs().max()) <= 1e-4 * float(d0.abs().max())
+    w_init = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), cnn_p, 1, 'bf16', DEV).w_master.data
+    assert float((w0 - w_init).abs().max()) > 0
