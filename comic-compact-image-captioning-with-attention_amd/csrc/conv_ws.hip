@@ -65,6 +65,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ComicWsArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntile_w = a.tiles_m;
+  // a workgroup owns a CONTIGUOUS range of pixel tiles: consecutive tiles share input rows of their pooling windows
+  // (and DRAM pages), which then stay in this CU's L2 instead of being fetched again by another XCD
+  const int per_wg = (ntile_w + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tile_begin = blockIdx.x * per_wg, tile_end = min(ntile_w, tile_begin + per_wg);
 
   if (wave >= 4) {
     // ---------------------------------------------------------------- loader waves -------------
@@ -154,32 +158,32 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ComicWsArgs a) {
       }
     };
 
-    int tile = blockIdx.x;
+    int tile = tile_begin;
     if (a.pooled) {
-      if (tile < ntile_w) pooled_tile(tile, 0);
+      if (tile < tile_end) pooled_tile(tile, 0);
       WS_BARRIER();
       int it = 0;
-      for (; tile < ntile_w; tile += gridDim.x, ++it) {
-        const int nxt = tile + gridDim.x;
-        if (nxt < ntile_w) pooled_tile(nxt, (it + 1) & 1);
+      for (; tile < tile_end; ++tile, ++it) {
+        const int nxt = tile + 1;
+        if (nxt < tile_end) pooled_tile(nxt, (it + 1) & 1);
         WS_BARRIER();
       }
     } else {
       uint4 cur[KS], nx[KS];
 #pragma unroll
       for (int i = 0; i < KS; ++i) cur[i] = nx[i] = make_uint4(0, 0, 0, 0);
-      if (tile < ntile_w) {
+      if (tile < tile_end) {
         load_plain(tile, cur);
         store_tile(0, cur);
       }
-      if (tile + (int)gridDim.x < ntile_w) load_plain(tile + gridDim.x, cur);
+      if (tile + 1 < tile_end) load_plain(tile + 1, cur);
       WS_BARRIER();
       int it = 0;
-      for (; tile < ntile_w; tile += gridDim.x, ++it) {
-        const int nxt = tile + gridDim.x;          // its loads are in `cur`
-        const int nxt2 = nxt + gridDim.x;
-        if (nxt2 < ntile_w) load_plain(nxt2, nx);
-        if (nxt < ntile_w) store_tile((it + 1) & 1, cur);
+      for (; tile < tile_end; ++tile, ++it) {
+        const int nxt = tile + 1;                  // its loads are in `cur`
+        const int nxt2 = nxt + 1;
+        if (nxt2 < tile_end) load_plain(nxt2, nx);
+        if (nxt < tile_end) store_tile((it + 1) & 1, cur);
 #pragma unroll
         for (int i = 0; i < KS; ++i) cur[i] = nx[i];
         WS_BARRIER();
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ComicWsArgs a) {
 
   WS_BARRIER();      // tile 0 + the scale / shift table are in LDS
   int it = 0;
-  for (int tile = blockIdx.x; tile < ntile_w; tile += gridDim.x, ++it) {
+  for (int tile = tile_begin; tile < tile_end; ++tile, ++it) {
     const unsigned char* buf = abuf + (it & 1) * ABYTES;
     f32x4_t acc[NT][4];
 #pragma unroll

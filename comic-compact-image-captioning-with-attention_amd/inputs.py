@@ -126,6 +126,84 @@ def decode_image(path_or_array):
         return np.asarray(im.convert('RGB'))
 
 
+class DecodePool(object):
+    """Multi-process JPEG decode into shared-memory staging blocks (config.loader_processes > 0).
+
+    The producer thread reads the image sizes from the file headers, lays the batch out back to back in a free block
+    and hands (path, block, offset) tasks to `spawn`ed workers (`_decode_worker.decode_into`), which write the decoded
+    pixels in place; the consumer registers each block once as pinned host memory (cudaHostRegister) and copies from
+    it directly.  Blocks return to the free list when the event behind their copy has completed."""
+
+    def __init__(self, processes, blocks=6, block_bytes=None, slot_bytes=640 * 640 * 3, max_batch=64):
+        import multiprocessing as mp
+        self.slot_bytes = int(slot_bytes)                     # MS-COCO images are at most 640 x 640
+        block_bytes = int(block_bytes or self.slot_bytes * max_batch)
+        from multiprocessing import shared_memory
+        # `spawn` re-imports the parent's __main__ in every worker (train.py, pytest, a notebook ...): the workers need
+        # none of it, so the main module is hidden from the preparation data while they start
+        import sys
+        main = sys.modules.get('__main__')
+        saved = (getattr(main, '__file__', None), getattr(main, '__spec__', None))
+        try:
+            if main is not None:
+                main.__file__, main.__spec__ = None, None
+            self._pool = mp.get_context('spawn').Pool(int(processes))
+        finally:
+            if main is not None:
+                main.__file__, main.__spec__ = saved
+        self._blocks = [shared_memory.SharedMemory(create=True, size=int(block_bytes)) for _ in range(int(blocks))]
+        self._free = queue.Queue()
+        for b in self._blocks:
+            self._free.put(b)
+        self.block_bytes = int(block_bytes)
+
+    def decode_batch(self, paths):
+        """-> (block, [(offset, h, w)], bytes spanned); waits for the pixels."""
+        blk, off, res = self.decode_batch_async(paths)
+        return blk, self.geometry(paths, res), off
+
+    def decode_batch_async(self, paths):
+        """-> (block, bytes spanned, async result).  Every image gets a fixed slot of `slot_bytes` in a free staging
+        block (no header parsing in the producer thread: its Python work per image capped the loader before), the
+        workers decode in place while the caller goes on (the loader keeps `loader_prefetch` batches in flight);
+        `geometry(paths, result)` waits and returns [(offset, h, w)].  Blocks only when every block is in flight."""
+        from . import _decode_worker as W
+        n = len(paths)
+        if n * self.slot_bytes > self.block_bytes:
+            raise ValueError('batch of %d images x %d bytes exceeds the decode staging block (%d)'
+                             % (n, self.slot_bytes, self.block_bytes))
+        blk = self._free.get()
+        res = self._pool.map_async(W.decode_into, [(p, blk.name, i * self.slot_bytes, self.slot_bytes)
+                                                   for i, p in enumerate(paths)])
+        return blk, n * self.slot_bytes, res
+
+    def geometry(self, paths, res):
+        out = []
+        for i, (p, (h, w)) in enumerate(zip(paths, res.get())):
+            if h < 0:
+                raise ValueError('%s decodes to %dx%d: larger than the loader slot of %d bytes (config.loader_slot_bytes)'
+                                 % (p, -h, -w, self.slot_bytes))
+            out.append((i * self.slot_bytes, h, w))
+        return out
+
+    def release(self, blk):
+        self._free.put(blk)
+
+    def close(self):
+        self._pool.terminate()
+        self._pool.join()
+        for b in self._blocks:
+            try:
+                b.unlink()               # the name goes now; the pages when the last mapping does
+            except FileNotFoundError:
+                pass
+            try:
+                b.close()
+            except BufferError:          # a pinned host tensor of the consumer still maps the block
+                pass
+        self._blocks = []
+
+
 class PackedImages(object):
     """A batch of decoded images packed back to back (+ one comic_image_desc per image) by the producer thread."""
     __slots__ = ('slot', 'blob', 'desc', 'n', 'total')
@@ -191,10 +269,49 @@ class DevicePreprocessor(object):
         del desc
         return PackedImages(slot, blob, dbuf, n, total)
 
+    def pack_paths(self, pool, paths, params):
+        """Producer half for a DecodePool: the worker processes decode straight into a shared-memory block (no copy in
+        this thread); only the descriptors are filled here."""
+        import ctypes as C
+        L = self.L
+        blk, total, pending = pool.decode_batch_async(paths)
+        return PackedImages(('shm', pool, blk, pending, list(paths), list(params)), None, None, len(paths), total)
+
+    def _fill_desc(self, geo, params):
+        import ctypes as C
+        L = self.L
+        n = len(geo)
+        dbuf = np.zeros(n * C.sizeof(L.ImageDesc), np.uint8)
+        desc = (L.ImageDesc * n).from_buffer(dbuf)
+        for i, ((off, ih, iw), (flip, oy, ox)) in enumerate(zip(geo, params)):
+            d = desc[i]
+            d.offset, d.in_h, d.in_w, d.flip, d.oy, d.ox = off, ih, iw, int(bool(flip)), int(oy), int(ox)
+            d.sy, d.sx = np.float32(ih / self.resize), np.float32(iw / self.resize)
+        del desc
+        return dbuf
+
     # ---- consumer side ------------------------------------------------------------------------------------------
     def _reap(self):
         while self._pending and self._pending[0][1].query():
-            self._free.put(self._pending.pop(0)[0])
+            slot = self._pending.pop(0)[0]
+            if isinstance(slot, tuple):          # shared-memory block of a DecodePool
+                slot[1].release(slot[2])
+            else:
+                self._free.put(slot)
+
+    def _shm_tensor(self, blk):
+        """uint8 host tensor over a DecodePool block, registered once as pinned memory (so the H2D copy is asynchronous
+        and DMA-able in place)."""
+        torch = self.torch
+        cache = self.__dict__.setdefault('_shm_tensors', {})
+        t = cache.get(blk.name)
+        if t is None:
+            t = torch.frombuffer(blk.buf, dtype=torch.uint8)
+            rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel(), 0)
+            if int(rc) != 0:
+                raise RuntimeError('cudaHostRegister of a decode staging block failed (%s)' % rc)
+            cache[blk.name] = t
+        return t
 
     def finish(self, packed):
         import ctypes as C
@@ -203,6 +320,26 @@ class DevicePreprocessor(object):
         n, total = packed.n, packed.total
         dbytes = n * C.sizeof(L.ImageDesc)
         slot = packed.slot
+        if isinstance(slot, tuple):
+            try:
+                geo = slot[1].geometry(slot[4], slot[3])      # waits: the workers have written every image of this batch
+            except Exception:
+                slot[1].release(slot[2])
+                raise
+            packed.desc = self._fill_desc(geo, slot[5])
+            host = self._shm_tensor(slot[2])
+            with torch.cuda.device(self.device):
+                if self._dev_blob is None or self._dev_blob.numel() < total:
+                    self._dev_blob = torch.empty(int(total * 1.3) + 4096, dtype=torch.uint8, device=self.device)
+                dev_desc = torch.from_numpy(packed.desc[:dbytes]).to(self.device)
+                self._dev_blob[:total].copy_(host[:total], non_blocking=True)
+                out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
+                L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
+                                                        self.h, self.w, self.resize, L.stream_ptr()), 'image_preprocess')
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+            self._pending.append((slot, ev))
+            return out
         if slot is None:
             # no pinned slot was available to the producer: stage through a new (or a larger) one, made here
             slot = dict(blob=torch.empty(int(total * 1.3) + 4096, dtype=torch.uint8).pin_memory(),
@@ -262,6 +399,9 @@ class InputManager(object):
             if isinstance(it, Prefetch):
                 it.close()
         self._pool.shutdown(wait=False)
+        if getattr(self, '_decode_pool', None) is not None:
+            self._decode_pool.close()
+            self._decode_pool = None
 
     def _setup(self, config, is_inference):
         config.split_sizes = {}
@@ -383,6 +523,13 @@ class InputManager(object):
             return
         h, w = self.config.cnn_input_size
         self._devpre = DevicePreprocessor(device, h, w)
+        nproc = int(getattr(self.config, 'loader_processes', 0) or 0)
+        if nproc > 0 and getattr(self, '_decode_pool', None) is None:
+            c = self.config
+            self._decode_pool = DecodePool(nproc, blocks=self._prefetch_depth + 2,
+                                           slot_bytes=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)),
+                                           max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
+                                                         getattr(c, 'batch_size_infer', 1)))
 
     def _finish_batch(self, item):
         """Consumer-thread half of a batch: packed images -> device tensor (see DevicePreprocessor)."""
@@ -395,6 +542,9 @@ class InputManager(object):
         h, w = self.config.cnn_input_size
         params = [draw_augmentation(augment, h, w, self._aug_rng) for _ in paths]
         devpre = getattr(self, '_devpre', None)
+        dpool = getattr(self, '_decode_pool', None)
+        if devpre is not None and dpool is not None and all(isinstance(p, str) for p in paths):
+            return devpre.pack_paths(dpool, paths, params)      # decode in worker processes, straight into staging
         if devpre is not None:       # CPU half here (producer thread); the device half runs in Prefetch's consumer hook
             return devpre.pack(list(self._pool.map(decode_image, paths)), params)
         return np.stack(list(self._pool.map(lambda a: self._load(a[0], augment, a[1]), zip(paths, params))))

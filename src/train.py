@@ -73,6 +73,8 @@ def create_parser():
     a('--checkpoint_format', type=str, default='npz', choices=['npz', 'tf'],
       help='Container of saved checkpoints: .npz or the TF checkpoint-V2 tensor bundle (both restore).')
     a('--log_root', type=str, default='', help='Root of the experiments directory (default: ../experiments).')
+    a('--loader_processes', type=int, default=0,
+      help='JPEG decode in this many worker processes (shared-memory staging); 0 = decode threads in this process.')
     return p
 
 

@@ -632,3 +632,31 @@ def test_legacy_encoder_head_matches_oracle():
         assert_close(g[k], gref[k], 1e-3, 'legacy d ' + k)
     assert set(head.export_params()) == {'Model/encoder/LN_tanh/beta', 'Model/encoder/LN_tanh/gamma',
                                          'Model/encoder/im_embed/weight'}
+
+
+def test_process_decode_pool_equals_thread_decode(tmp_path):
+    """inputs.DecodePool (spawned workers decoding JPEGs into shared-memory staging, registered as pinned memory) feeds
+    the device preprocessing the same bytes as the in-process PIL decode: identical output tensors, blocks recycled
+    over several batches, an image larger than its slot is refused with a clear error."""
+    from PIL import Image
+    from comic_amd import inputs
+    rng = np.random.default_rng(4)
+    paths = []
+    for i, (h, w) in enumerate([(48, 64), (33, 50), (64, 64), (20, 31), (57, 40)]):
+        p = str(tmp_path / ('%d.jpg' % i))
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(p, quality=92)
+        paths.append(p)
+    params = [(bool(i & 1), i, 2 * i) for i in range(len(paths))]
+    pre = inputs.DevicePreprocessor(DEV, 224, 224)
+    want = pre([inputs.decode_image(p) for p in paths], params).cpu()
+    pool = inputs.DecodePool(2, blocks=2, slot_bytes=64 * 64 * 3, max_batch=8)
+    try:
+        for _ in range(5):                                   # more batches than blocks: they are recycled
+            got = pre.finish(pre.pack_paths(pool, paths, params)).cpu()
+            assert torch.equal(got, want)
+        big = str(tmp_path / 'big.jpg')
+        Image.fromarray(rng.integers(0, 256, (80, 80, 3), dtype=np.uint8)).save(big)
+        with pytest.raises(ValueError, match='loader slot'):
+            pre.finish(pre.pack_paths(pool, [big], [(False, 0, 0)]))
+    finally:
+        pool.close()

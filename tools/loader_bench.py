@@ -1,6 +1,7 @@
-"""Loader throughput: JPEG decode on host threads + resize / flip / crop / scale on the device vs everything in numpy."""
+"""Loader throughput on 640x480 JPEGs: all-numpy, thread decode + device preprocessing, process decode (DecodePool) + device
+preprocessing (the output tensors of the last two are compared bit for bit)."""
 import sys, os, time, tempfile, random
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from PIL import Image
 from concurrent.futures import ThreadPoolExecutor
@@ -13,7 +14,7 @@ for i in range(256):
     p = os.path.join(d, '%d.jpg' % i); Image.fromarray(a).resize((640, 480), Image.BICUBIC).save(p, quality=90); paths.append(p)
 r = random.Random(0)
 pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
-for nt in (1, 4, 8, 16, 32):
+for nt in (1, 4, 16):
     pool = ThreadPoolExecutor(max_workers=nt)
     for mode in ('numpy', 'device'):
         n, t0 = 0, time.time()
@@ -29,4 +30,24 @@ for nt in (1, 4, 8, 16, 32):
                 n += len(ps)
         torch.cuda.synchronize()
         print('threads %2d  %-6s : %6.0f images/s' % (nt, mode, n / (time.time() - t0)))
+ref = pre(list(map(inputs.decode_image, paths[:64])), [(False, 16, 16)] * 64).cpu()
+for nproc in (8, 16):
+    pool = inputs.DecodePool(nproc)
+    got = pre.finish(pre.pack_paths(pool, paths[:64], [(False, 16, 16)] * 64)).cpu()
+    assert torch.equal(got, ref), 'process decode differs from thread decode'
+    n, t0 = 0, time.time()
+    inflight = []                        # as the loader's prefetch thread does: a few batches decode at once
+    for rep in range(12):
+        for b in range(0, len(paths), 64):
+            ps = paths[b:b + 64]
+            params = [inputs.draw_augmentation(True, 224, 224, r) for _ in ps]
+            inflight.append(pre.pack_paths(pool, ps, params))
+            if len(inflight) > 3:
+                t = pre.finish(inflight.pop(0))
+            n += len(ps)
+    while inflight:
+        t = pre.finish(inflight.pop(0))
+    torch.cuda.synchronize()
+    print('processes %2d device : %6.0f images/s' % (nproc, n / (time.time() - t0)))
+    pool.close()
 print('cpus', os.cpu_count())
