@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "decoder_persist.h"
 
 // internal cross-file entries (gemm.hip, decoder.hip)
 int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -91,6 +92,12 @@ bool fused_step_enabled() {
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v == 1;
+}
+
+// read at every call (tests flip it inside one process): COMIC_PERSIST=0 keeps the per-step launch chain
+bool persist_enabled() {
+  const char* e = getenv("COMIC_PERSIST");
+  return !(e && e[0] == '0');
 }
 
 #define RC(x)               \
@@ -557,6 +564,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
   w.take<float>(D * D);                                                        // W_q panel
+  w.take<unsigned>(kPersistSyncWords);                                         // persistent loop: counters + error word
   return (int64_t)w.off;
 }
 
@@ -622,6 +630,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* kpanel_f = w.take<float>(comic_lstm_panel_floats(D, Wd, 0));
   float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
   float* wq_panel = w.take<float>((long)D * D);
+  unsigned* persist_sync = w.take<unsigned>(kPersistSyncWords);
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
 
   const comic_attn_desc ad = attn_desc(d, B);
@@ -634,6 +643,10 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
   RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, st));
   RC(fill(att_all, 0.f, (long)B * A, st));
+  // the whole time loop as one persistent launch (decoder_persist.hip) when the shape allows it
+  const bool persist = fused && persist_enabled() &&
+                       comic_persist_fwd_supported(B, D, E, A, M, H, Cv, d->method, d->context_layer, ad.tied);
+  if (persist) RC(comic_persist_prepare(xh_all, (long)Tp * B * Wd, y_all, (long)Tp * B * D, q_all, (long)Tp * B * D, st));
   hipLaunchKernelGGL(transpose_ids_kernel, dim3(cdiv(Tp * B, 256)), dim3(256), 0, st, inputs_bt, in_tb, B, T, Tp);
   COMIC_LAUNCH_CHECK("transpose_ids");
   // x part of every step's [x ; att ; h] operand row: embedding lookup + input dropout, hoisted
@@ -649,7 +662,21 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, hs, hs, (const int32_t*)nullptr, 0,
                      hs, xh_all + EA, Wd, (const float*)nullptr, 0, 1.f, B, D);
   COMIC_LAUNCH_CHECK("step0 operand");
-  for (int t = 0; t < Tp; ++t) {
+  if (persist) {
+    ComicPersistFwdArgs pa{};
+    pa.K_panel = kpanel_f; pa.bias = p->b; pa.W_q = p->W_q; pa.keys = keys; pa.values = values;
+    pa.ln_g = p->ln_g; pa.ln_b = p->ln_b; pa.v = p->v; pa.tau = p->tau; pa.lens = lens;
+    pa.mask_in = drop_in ? mask_in : nullptr; pa.mask_out = drop_out ? mask_out : nullptr;
+    pa.mask_alpha = drop_al ? mask_alpha : nullptr;
+    pa.keep_in = d->keep_in; pa.keep_out = d->keep_out; pa.keep_alpha = d->keep_alpha;
+    pa.xh_all = xh_all; pa.gates_all = gates_all; pa.cnew_all = cnew_all; pa.y_all = y_all; pa.q_all = q_all;
+    pa.cs = cs; pa.hs = hs; pa.att_all = att_all; pa.alpha_all = alpha_all; pa.attn_hist = attn_hist;
+    pa.ctx_all = ctx_all; pa.sync = persist_sync;
+    pa.B = B; pa.D = D; pa.E = E; pa.Wd = Wd; pa.M = M; pa.H = H; pa.Tp = Tp;
+    pa.method = d->method; pa.prob = d->prob; pa.tied = ad.tied;
+    RC(comic_persist_fwd_launch(pa, st));
+  }
+  for (int t = 0; t < (persist ? 0 : Tp); ++t) {
     float* xh_t = xh_all + (size_t)t * B * Wd;
     float* xh_n = (t + 1 < Tp) ? xh_all + (size_t)(t + 1) * B * Wd : nullptr;
     const float* c_prev = cs + (size_t)t * B * D;
@@ -712,6 +739,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                        map_loss);
     COMIC_LAUNCH_CHECK("maploss");
   }
+  if (persist) RC(comic_persist_check(persist_sync, map_loss, st));
 
   // ------------------------------------------------------------------ backward -----------
   const bool use_map = d->map_loss_scale > 0.f;

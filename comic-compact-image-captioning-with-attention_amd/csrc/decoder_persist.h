@@ -1,0 +1,47 @@
+// Persistent forward time loop of the training decoder (decoder_persist.hip).
+#pragma once
+#include "common.h"
+
+struct ComicPersistFwdArgs {
+  // resident operands
+  const float* K_panel;   // forward panel of the LSTM kernel (comic_pack_lstm_panels, mode 0)
+  const float* bias;      // [4D]
+  const float* W_q;       // [D][D]
+  const float* keys;      // [B][M][D]
+  const float* values;    // [B][M][D] (== keys when tied)
+  const float *ln_g, *ln_b, *v, *tau;
+  const int32_t* lens;    // [B]
+  // dropout masks (null = off)
+  const float* mask_in;   // [T][B][E+A]
+  const float* mask_out;  // [T][B][D]
+  const float* mask_alpha;// [T][B][H][M]
+  float keep_in, keep_out, keep_alpha;
+  // per-step buffers, time-major
+  float* xh_all;          // [Tp][B][Wd]   operand rows [x ; att ; h]; x parts and row 0 filled by the caller
+  float* gates_all;       // [Tp][B][4D]
+  float* cnew_all;        // [Tp][B][D]
+  float* y_all;           // [Tp][B][D]
+  float* q_all;           // [Tp][B][D]
+  float* cs;              // [Tp+1][B][D]  row 0 = initial state
+  float* hs;              // [Tp+1][B][D]
+  float* att_all;         // [Tp+1][B][D]  row 0 = zeros
+  float* alpha_all;       // [Tp][B][H][M]
+  float* attn_hist;       // [Tp][B][H][M]
+  float* ctx_all;         // [Tp][B][D]
+  unsigned long long* stamps;   // diagnostic phase clock of workgroup 0 (null = off)
+  unsigned* sync;         // kPersistSyncWords words: the error word (the launch clears it)
+  int B, D, E, Wd, M, H, Tp;
+  int method, prob, tied;
+};
+
+constexpr int kPersistSyncWords = 32;       // the error word on a 128-byte line of its own
+// "not written yet" pattern of the handed-off buffers (xh_all, y_all, q_all): comic_persist_prepare fills them
+#define COMIC_PERSIST_SENTINEL 0xFFFFDEADu
+
+bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
+                                 int tied);
+// fills the hand-off buffers with the sentinel; call BEFORE the kernels that write the x parts and the step-0 row
+int comic_persist_prepare(float* xh_all, long xh_n, float* y_all, long y_n, float* q_all, long q_n, hipStream_t st);
+int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
+// poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)
+int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st);

@@ -1,0 +1,560 @@
+// Persistent forward time loop of the attention-LSTM decoder (training, fp32) for gfx950.
+//
+// Replaces the per-step launch chain of comic_decoder_train_step's forward loop -- BasicLSTMCell + DropoutWrapper
+// (src/model_base.py:606-648), the query layer and MultiHeadAddLN / MultiHeadDot + MultiHeadAttentionWrapperV3.call
+// (common/ops_rnn.py:531-565, :611-632, :660-755), TrainingHelper / impute_finished of rnn_decoder_training
+// (common/ops_rnn.py:183-243) -- with ONE launch that runs all T' steps.
+//
+// Why: the recurrence is a chain of three dependent ~10 us kernels per step whose bodies are bound by what a CU can
+// pull from L2 (about 70 GB/s): every step re-streams the 10.5 MB LSTM kernel, W_q and the 3.3 MB of keys.  Here the
+// operands that do not change over time never leave the CU:
+//   * a workgroup keeps ITS 32 gate columns of the LSTM kernel (160 KB) in the registers of its eight waves, ITS
+//     eight columns of W_q (16 KB) and the keys (= values when tied) of ITS batch row (M*D*4 = 51 KB) in LDS;
+//   * the c / h state and the previous attention vector of the elements a workgroup owns stay in registers.
+// Per step only activations cross workgroups: [x ; att ; h] rows (LSTM operand), y (query operand), q.
+//
+// Decomposition.  The batch splits into independent groups of 16 rows; a group is served by 64 workgroups (one per
+// CU; four groups fill the chip at batch 64) that never exchange anything with another group.  Workgroup i of a
+// group runs, per step:
+//   L  units [8i, 8i+8) x 16 rows:  gates = [x ; att ; h] * K + b (exact fp32 MFMA, the eight waves split K, fixed-
+//      order combine) -> cell, output dropout, finished-row select       writes y_t, h part of the next operand row
+//   Q  query columns [8i, 8i+8) x 16 rows:  q = y * W_q                                                  writes q_t
+//   A  batch row (i % 16), channel quarter (i / 16):  LayerNorm statistics of keys + q over all D (from the
+//      resident keys), tanh / v scores of the quarter's heads, softmax (or sigmoid norm) over M, dropout, context of
+//      its channels, finished-row select, input dropout                   writes the att part of the next operand row
+// The x and h thirds of the next step's LSTM product do not depend on the attention: they run between Q and A,
+// under the latency of the q hand-off; only the att third sits on the critical path.
+//
+// Hand-offs carry no flag and need no barrier: THE DATA IS THE FLAG.  Every handed-off buffer (operand rows, y, q)
+// is time-major, so each 4-byte word is written exactly once per launch; the caller fills them with a NaN pattern no
+// computation produces (kSentinel) before the launch, producers write them with sc1 (write-through) stores, and a
+// consumer re-reads with sc1 loads (registers only, never L1) until none of its words holds the pattern -- the
+// granule form of MI355X_MICROARCH.md's hand-off recipes ("Persistent kernels: synchronisation and hand-off price
+// list", handoff-1to1 / allgather; cdna_hip_programming.md Guideline 16, R2) with a 4-byte granule: an aligned dword
+// store is never torn and a word needs no ordering against any other word.  A counter barrier cost 3.0 us of the
+// 24.7 us step three times over (measured, profiles/r02_persist_phases.txt); a validated load costs one more round
+// trip only when the data is late.  Data that only later kernels read (saved gates, alpha, ...) uses plain stores.
+// Every spin is bounded: a wave that polls more than kSpinLimit times raises the error word, every wave that sees it
+// stops waiting, and comic_persist_check poisons the step's loss with NaN so that the host sees it.  One workgroup
+// per CU (the launch reserves more than half of the LDS): with 256 CUs all workgroups of a launch are resident.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "decoder_persist.h"
+
+#include "decoder_math.h"
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kGroupWgs = 64;          // workgroups per batch group
+constexpr int kGroupRows = 16;
+constexpr int kMaxGroups = 4;
+constexpr int kD = 512;                // = 8 units per workgroup x 64 workgroups
+constexpr unsigned kSpinLimit = 1u << 20;
+constexpr int kSc1 = 16;               // cache-policy bit of raw buffer loads / stores: sc1
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, kSc1);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+  const u32x4_t u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)byte_off, 0, kSc1);
+}
+__device__ __forceinline__ void store4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)byte_off, 0, kSc1);
+}
+
+constexpr unsigned kSentinel = COMIC_PERSIST_SENTINEL;   // "not written yet": a NaN pattern no operation produces
+
+__device__ __forceinline__ bool unwritten(float4 v) {
+  return __float_as_uint(v.x) == kSentinel || __float_as_uint(v.y) == kSentinel || __float_as_uint(v.z) == kSentinel ||
+         __float_as_uint(v.w) == kSentinel;
+}
+
+// A wave's view of the launch-wide failure state: once `dead`, waits are skipped (the outputs are garbage anyway and
+// comic_persist_check reports it).
+struct Waiter {
+  unsigned* err;
+  bool dead;
+  // one more unsuccessful poll; true = give up
+  __device__ __forceinline__ bool spin(unsigned& spins) {
+    __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");                             // the re-read that follows is a new load
+    ++spins;
+    if ((spins & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) dead = true;
+    if (spins > kSpinLimit) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dead = true;
+    }
+    return dead;
+  }
+};
+
+// Re-read (sc1) the 16-byte pieces x[i] (i in `want`, a wave-uniform bit set) at byte offsets off[i] until no lane of
+// the wave sees an unwritten word in any of them.
+template <int N>
+__device__ __forceinline__ void wait_written(float4 (&x)[N], __amdgpu_buffer_rsrc_t r, unsigned base,
+                                             const unsigned (&off)[N], unsigned want, Waiter& w) {
+  if (w.dead) return;
+  unsigned spins = 0;
+  for (;;) {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (((want >> i) & 1u) && __any(unwritten(x[i]))) bad |= 1u << i;
+    if (!bad) return;
+    if (w.spin(spins)) return;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if ((bad >> i) & 1u) x[i] = load16_sc1(r, base + off[i]);
+  }
+}
+
+// diagnostic (COMIC_PERSIST_STAMPS=1): workgroup 0 records the 100 MHz clock at the phase edges of every step
+__device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) st[t * 8 + i] = __builtin_amdgcn_s_memrealtime();
+}
+
+// A wave's k16-blocks of the operand row [x ; att ; h]: NX of the x third (block wave + 8 i), then four of the att third
+// and four of the h third (pairs of adjacent blocks: the two loads of a row share a 128-B line).
+template <int NX, bool WQ_LDS>
+__global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicPersistFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = kD;
+  const int M = a.M, H = a.H, Wd = a.Wd, E = a.E, EA = a.E + D, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;
+  const int row0 = grp * kGroupRows;
+  Waiter wt{a.sync, false};
+
+  // ---- LDS carve-up ---------------------------------------------------------------------------------------------
+  float* keys_l = (float*)smem;                                // [M][D]  keys of this workgroup's attention row
+  float* vals_l = a.tied ? keys_l : keys_l + M * D;            // [M][D]  values (independent projection)
+  float4* red = (float4*)(vals_l + M * D);                     // [8 waves][2 tiles][64 lanes]   cross-wave combine
+  float* q_l = (float*)(red + kWaves * 2 * 64);                // [D]      q row of the attention phase
+  float* sc_l = q_l + D;                                       // [<= 4 heads][64]
+  float* wq_l = sc_l + 4 * 64;                                 // [D][8] + 4 floats per 16 rows: eight W_q columns
+
+  const __amdgpu_buffer_rsrc_t xh_r = make_rsrc(a.xh_all, (long)a.Tp * B * Wd * 4);
+  const __amdgpu_buffer_rsrc_t y_r = make_rsrc(a.y_all, (long)a.Tp * B * D * 4);
+  const __amdgpu_buffer_rsrc_t q_r = make_rsrc(a.q_all, (long)a.Tp * B * D * 4);
+
+  // ---- attention-phase identity: batch row + channel quarter --------------------------------------------------------
+  const int ab = row0 + (wi & 15), aq = wi >> 4;
+  const bool a_live = ab < B;
+  const int cq0 = aq * (D / 4);                                // first channel of the quarter
+  const int dh = D / H, hq = (D / 4) / dh, lph = dh / 2;       // head width, heads per quarter, lanes per head
+  {
+    const int arow = a_live ? ab : 0;
+    const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
+    for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
+    if (!a.tied) {
+      const float4* vs = (const float4*)(a.values + (size_t)arow * M * D);
+      for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)vals_l)[i] = vs[i];
+    }
+    if (WQ_LDS) {   // row k at 8k + 4(k >> 4) floats: a thread's 16 rows are 528 B from its neighbour's (no bank conflict)
+      for (int k = tid; k < D; k += kThreads) {
+        float* dst = wq_l + 8 * k + 4 * (k >> 4);
+        *(float4*)dst = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi);
+        *(float4*)(dst + 4) = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi + 4);
+      }
+    }
+  }
+
+  // ---- L phase residents: this wave's k-blocks of the two unit tiles' weight panels -----------------------------------
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int KB = (Wd + 15) >> 4;
+  constexpr int NB = NX + 8;
+  const int xb = E >> 4;                                       // k16-blocks of the x third
+  float4 wreg[NB][2];
+  unsigned kb_off[NB];                                         // byte offset of the (clamped) block in an operand row
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int j = i - NX;
+    const int kb = i < NX ? wave + kWaves * i : xb + (j >> 2) * (D / 16) + 2 * (wave + kWaves * ((j >> 1) & 1)) + (j & 1);
+    const bool real = i >= NX || kb < xb;                      // an x block past the third has zero weights
+    kb_off[i] = (unsigned)(real ? kb : 0) * 64u;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const float* panel = a.K_panel + ((size_t)(2 * wi + jt) * KB * 16 + r16) * 16 + 4 * kq;
+      wreg[i][jt] = real ? *(const float4*)(panel + (size_t)kb * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // epilogue lanes (wave j = unit tile j): state of (row, unit) lives in registers across the steps
+  const int e_row = row0 + r16, e_d = 8 * wi + 4 * wave + kq;
+  const bool e_lane = wave < 2 && e_row < B;
+  float e_c = 0.f, e_h = 0.f, e_b[4] = {0.f, 0.f, 0.f, 0.f};
+  int e_len = 0;
+  if (e_lane) {
+    e_c = a.cs[(size_t)e_row * D + e_d];
+    e_h = a.hs[(size_t)e_row * D + e_d];
+    e_b[0] = a.bias[e_d]; e_b[1] = a.bias[D + e_d]; e_b[2] = a.bias[2 * D + e_d]; e_b[3] = a.bias[3 * D + e_d];
+    e_len = a.lens[e_row];
+  }
+  const int l_row = min(row0 + r16, B - 1);                    // operand row of this lane (clamped: results unused)
+  // attention epilogue threads (tid < D/4): previous attention state of (row, channel)
+  const int a_c = cq0 + tid;
+  float att_prev = 0.f;
+  const int a_len = a_live ? a.lens[ab] : 0;
+  float lnp[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // gamma, beta, v of this lane's two quarter channels
+  if (a.method == 0) {
+    const int c = cq0 + 2 * lane;
+    lnp[0][0] = a.ln_g[c]; lnp[0][1] = a.ln_g[c + 1];
+    lnp[1][0] = a.ln_b[c]; lnp[1][1] = a.ln_b[c + 1];
+    lnp[2][0] = a.v[c]; lnp[2][1] = a.v[c + 1];
+  }
+  const float scale = a.method == 0 ? a.tau[0] : sqrtf((float)dh);
+  __syncthreads();
+
+  // The LSTM product of a step in two parts: blocks [I0, I1) of the wave.
+  f32x4_t acc[2];
+  auto lstm_part = [&](int t, auto i0_, auto i1_) {
+    constexpr int I0 = decltype(i0_)::value, I1 = decltype(i1_)::value, N = I1 - I0;
+    const unsigned xo = (unsigned)((((size_t)t * B + l_row) * Wd + 4 * kq) * 4);
+    float4 xa[N];
+    unsigned off[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      off[i] = kb_off[I0 + i];
+      xa[i] = load16_sc1(xh_r, xo + off[i]);
+    }
+    wait_written<N>(xa, xh_r, xo, off, (1u << N) - 1u, wt);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[I0 + i][j].x, xa[i].x, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[I0 + i][j].y, xa[i].y, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[I0 + i][j].z, xa[i].z, acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[I0 + i][j].w, xa[i].w, acc[j], 0, 0, 0);
+    }
+  };
+  using std::integral_constant;
+  const integral_constant<int, 0> c0;
+  const integral_constant<int, NX> cx;
+  const integral_constant<int, NX + 4> ca;
+  const integral_constant<int, NX + 8> ch;
+  acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  lstm_part(0, c0, cx);
+  lstm_part(0, ca, ch);
+
+  for (int t = 0; t < a.Tp; ++t) {
+    // masks of this step: fetched ahead of the phases that use them
+    float m_out = 1.f, m_in = 1.f, m_al = 1.f;
+    const size_t e_i = ((size_t)t * B + e_row) * D + e_d;
+    if (a.mask_out && e_lane) m_out = a.mask_out[e_i];
+    if (a.mask_in && a_live && tid < D / 4 && t + 1 < a.Tp) m_in = a.mask_in[((size_t)(t + 1) * B + ab) * EA + E + a_c];
+    if (a.mask_alpha && a_live && wave < hq && lane < M)
+      m_al = a.mask_alpha[(((size_t)t * B + ab) * H + aq * hq + wave) * M + lane];
+    // =============================================================== L: LSTM cell (att third) ========================
+    stamp(a.stamps, t, 0);
+    lstm_part(t, cx, ca);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) red[(wave * 2 + j) * 64 + lane] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+    __syncthreads();
+    stamp(a.stamps, t, 1);
+    if (wave < 2) {
+      float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {                        // fixed order: deterministic
+        const float4 pp = red[(w * 2 + wave) * 64 + lane];
+        g[0] += pp.x; g[1] += pp.y; g[2] += pp.z; g[3] += pp.w;
+      }
+      const float si = sigmoidf_(g[0] + e_b[0]), tj = tanhf(g[1] + e_b[1]);
+      const float sf = sigmoidf_(g[2] + e_b[2] + 1.0f), so = sigmoidf_(g[3] + e_b[3]);   // forget_bias = 1
+      const float c2 = e_c * sf + si * tj;
+      const float h2 = tanhf(c2) * so;
+      const float yv = a.mask_out ? (h2 / a.keep_out) * m_out : h2;
+      const bool fin = t >= e_len;
+      e_c = fin ? e_c : c2;
+      e_h = fin ? e_h : h2;
+      // the four units of a row sit in lanes r16 + 16 kq: gather them into the kq == 0 lane, one 16-byte store each
+      float y4[4], h4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        y4[k] = __shfl(yv, r16 + 16 * k, 64);
+        h4[k] = __shfl(e_h, r16 + 16 * k, 64);
+      }
+      if (kq == 0 && e_row < B) {
+        const size_t i4 = ((size_t)t * B + e_row) * D + 8 * wi + 4 * wave;
+        store16_sc1(y_r, (unsigned)(i4 * 4), make_float4(y4[0], y4[1], y4[2], y4[3]));
+        if (t + 1 < a.Tp)
+          store16_sc1(xh_r, (unsigned)((((size_t)(t + 1) * B + e_row) * Wd + EA + 8 * wi + 4 * wave) * 4),
+                      make_float4(h4[0], h4[1], h4[2], h4[3]));
+      }
+      if (e_lane) {
+        float* ga = a.gates_all + ((size_t)t * B + e_row) * 4 * D;
+        ga[e_d] = si; ga[D + e_d] = tj; ga[2 * D + e_d] = sf; ga[3 * D + e_d] = so;
+        a.cnew_all[e_i] = c2;
+        a.cs[((size_t)(t + 1) * B + e_row) * D + e_d] = e_c;
+        a.hs[((size_t)(t + 1) * B + e_row) * D + e_d] = e_h;
+      }
+    }
+    stamp(a.stamps, t, 2);
+    // =============================================================== Q: query layer =================================
+    {
+      if (!WQ_LDS) asm volatile("" ::: "memory");               // W_q from L2 every step: 128 registers would not fit
+      const int rl = tid >> 5, part = tid & 31;                 // row of the group, k range [16 part, 16 part + 16)
+      const int row = min(row0 + rl, B - 1);
+      const unsigned yo = (unsigned)((((size_t)t * B + row) * D + 16 * part) * 4);
+      const unsigned yoff[4] = {0u, 16u, 32u, 48u};
+      float4 yv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yv[i] = load16_sc1(y_r, yo + yoff[i]);
+      wait_written<4>(yv, y_r, yo, yoff, 15u, wt);
+      stamp(a.stamps, t, 3);
+      float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ys[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
+        if (!WQ_LDS) asm volatile("" ::: "memory");             // at most eight W_q loads in flight (registers)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 16 * part + 4 * i + e;
+          float4 w0, w1;
+          if (WQ_LDS) {
+            const float* src = wq_l + 8 * k + 4 * part;
+            w0 = *(const float4*)src;
+            w1 = *(const float4*)(src + 4);
+          } else {
+            w0 = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi);
+            w1 = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi + 4);
+          }
+          q8[0] = fmaf(ys[e], w0.x, q8[0]); q8[1] = fmaf(ys[e], w0.y, q8[1]);
+          q8[2] = fmaf(ys[e], w0.z, q8[2]); q8[3] = fmaf(ys[e], w0.w, q8[3]);
+          q8[4] = fmaf(ys[e], w1.x, q8[4]); q8[5] = fmaf(ys[e], w1.y, q8[5]);
+          q8[6] = fmaf(ys[e], w1.z, q8[6]); q8[7] = fmaf(ys[e], w1.w, q8[7]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        q8[e] = group_sum_dpp(q8[e], 16);
+        q8[e] += __shfl_xor(q8[e], 16, 64);
+      }
+      if (part == 0 && row0 + rl < B) {
+        const unsigned qo = (unsigned)((((size_t)t * B + row0 + rl) * D + 8 * wi) * 4);
+        store16_sc1(q_r, qo, make_float4(q8[0], q8[1], q8[2], q8[3]));
+        store16_sc1(q_r, qo + 16, make_float4(q8[4], q8[5], q8[6], q8[7]));
+      }
+    }
+    stamp(a.stamps, t, 4);
+    // ============================================ next step's x and h thirds, under the q hand-off ====================
+    acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < a.Tp) {
+      lstm_part(t + 1, c0, cx);
+      lstm_part(t + 1, ca, ch);
+    }
+    stamp(a.stamps, t, 5);
+    // =============================================================== A: attention ===================================
+    if (a_live) {
+      if (wave < 2) {
+        const unsigned qo = (unsigned)((((size_t)t * B + ab) * D + 4 * tid) * 4);
+        const unsigned zoff[1] = {0u};
+        float4 qv[1] = {load16_sc1(q_r, qo)};
+        wait_written<1>(qv, q_r, qo, zoff, 1u, wt);
+        *(float4*)(q_l + 4 * tid) = qv[0];
+      }
+      __syncthreads();
+      stamp(a.stamps, t, 6);
+      // scores of this quarter's heads; a wave owns memory rows m = wave, wave + 8, ...
+      for (int m = wave; m < M; m += kWaves) {
+        const float* kr = keys_l + m * D;
+        const int c = cq0 + 2 * lane;                           // this lane's two channels of the quarter
+        float part0 = 0.f;
+        if (a.method == 0) {
+          constexpr int EPL = 8;                                // statistics over all D = 64 lanes x 8 channels
+          float z[EPL], s = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; i += 4) {
+            const float4 kv = *(const float4*)(kr + lane * EPL + i), qv = *(const float4*)(q_l + lane * EPL + i);
+            z[i] = kv.x + qv.x; z[i + 1] = kv.y + qv.y; z[i + 2] = kv.z + qv.z; z[i + 3] = kv.w + qv.w;
+            s += (z[i] + z[i + 1]) + (z[i + 2] + z[i + 3]);
+          }
+          const float mean = wave_sum(s) / (float)D;
+          float s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float cc = z[i] - mean;
+            s2 += cc * cc;
+          }
+          const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float zz = kr[c + e] + q_l[c + e];
+            const float inv = rstd * lnp[0][e];
+            const float zh = zz * inv + (lnp[1][e] - mean * inv);   // tf.nn.batch_normalization form
+            part0 += fast_tanh(zh) * lnp[2][e];
+          }
+        } else {
+          part0 = kr[c] * q_l[c] + kr[c + 1] * q_l[c + 1];
+        }
+        float hsum = part0;                                     // sum over the lanes of a head (power of two <= 64)
+        for (int o = 1; o < lph; o <<= 1) hsum += __shfl_xor(hsum, o, 64);
+        if ((lane % lph) == 0) sc_l[(lane / lph) * 64 + m] = hsum / scale;
+      }
+      __syncthreads();
+      // probability fn per head (a wave per head of the quarter), dropout; sc <- alpha_d
+      if (wave < hq) {
+        const int h = aq * hq + wave;
+        float* srow = sc_l + wave * 64;
+        const size_t go = (((size_t)t * B + ab) * H + h) * M;
+        const float sv = lane < M ? srow[lane] : -INFINITY;
+        float al;
+        if (a.prob == 0) {
+          const float mx = wave_max(sv);
+          const float ex = lane < M ? expf(sv - mx) : 0.f;
+          al = ex / wave_sum(ex);
+        } else {
+          const float sg = lane < M ? sigmoidf_(sv) : 0.f;
+          al = sg / wave_sum(sg);
+        }
+        if (lane < M) {
+          a.alpha_all[go + lane] = al;
+          const float ad = a.mask_alpha ? (al / a.keep_alpha) * m_al : al;
+          a.attn_hist[go + lane] = ad;
+          srow[lane] = ad;
+        }
+      }
+      __syncthreads();
+      if (wave < 2) {
+        const float* al = sc_l + (tid / dh) * 64;
+        const float* vp = vals_l + a_c;
+        float cx = 0.f;
+        for (int m = 0; m < M; ++m) cx = fmaf(al[m], vp[m * D], cx);
+        a.ctx_all[((size_t)t * B + ab) * D + a_c] = cx;
+        const bool fin = t >= a_len;
+        att_prev = fin ? att_prev : cx;
+        a.att_all[((size_t)(t + 1) * B + ab) * D + a_c] = att_prev;
+        if (t + 1 < a.Tp) {
+          const float xv = a.mask_in ? (att_prev / a.keep_in) * m_in : att_prev;
+          const float x1 = __shfl_down(xv, 1, 64), x2 = __shfl_down(xv, 2, 64), x3 = __shfl_down(xv, 3, 64);
+          if ((lane & 3) == 0)
+            store16_sc1(xh_r, (unsigned)((((size_t)(t + 1) * B + ab) * Wd + E + a_c) * 4), make_float4(xv, x1, x2, x3));
+        }
+      }
+    }
+    stamp(a.stamps, t, 7);
+  }
+}
+
+__global__ void sentinel_fill_kernel(uint4* p0, long n0, uint4* p1, long n1, uint4* p2, long n2) {
+  const uint4 v = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) p0[i] = v;
+  else if (i < n0 + n1) p1[i - n0] = v;
+  else if (i < n0 + n1 + n2) p2[i - n0 - n1] = v;
+}
+
+__global__ void persist_check_kernel(const unsigned* err, float* loss) {
+  if (err[0] != 0u) loss[0] = __int_as_float(0x7fc00000);
+}
+
+int64_t lds_bytes(int M, int tied, bool wq_lds) {
+  return (int64_t)(tied ? 1 : 2) * M * kD * 4 + kWaves * 2 * 64 * 16 + kD * 4 + 4 * 64 * 4 +
+         (wq_lds ? kD * 32 + (kD / 16) * 16 : 0);
+}
+constexpr int64_t kLdsMax = 160 * 1024;
+constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at most one workgroup per CU
+
+template <int NX, bool WQ_LDS>
+int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st) {
+  auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess) {
+      comic_set_error("persistent decoder: cannot reserve LDS");
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  COMIC_LAUNCH_CHECK("persistent decoder forward");
+  return 0;
+}
+
+}  // namespace
+
+bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
+                                 int tied) {
+  if (context_layer || B < 1 || B > kMaxGroups * kGroupRows) return false;
+  if (D != kD || A != D || Cv != D || E < 16 || E % 16 != 0 || E > 512) return false;
+  if (H != 4 && H != 8 && H != 16) return false;                  // a channel quarter holds 1, 2 or 4 whole heads
+  if (M < 1 || M > 64) return false;
+  if (method != 0 && method != 1) return false;
+  return lds_bytes(M, tied, false) <= kLdsMax;
+}
+
+// COMIC_PERSIST_STAMPS=1: print the previous launch's mean phase times (a host synchronisation per launch: diagnostic)
+static unsigned long long* stamps_buffer(int Tp, hipStream_t st) {
+  static int on = -1;
+  static unsigned long long* dev = nullptr;
+  static int prev_tp = 0;
+  if (on < 0) {
+    const char* e = getenv("COMIC_PERSIST_STAMPS");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (!on) return nullptr;
+  if (!dev && hipMalloc((void**)&dev, 8 * 8 * 256) != hipSuccess) return nullptr;
+  if (prev_tp > 0 && hipStreamSynchronize(st) == hipSuccess) {
+    unsigned long long h[8 * 256];
+    if (hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum[8] = {0};
+      for (int t = 0; t + 1 < prev_tp; ++t)
+        for (int i = 0; i < 8; ++i) sum[i] += (double)(h[i < 7 ? t * 8 + i + 1 : (t + 1) * 8] - h[t * 8 + i]);
+      fprintf(stderr, "[persist stamps] per step (us): L-att %.2f  L-epi %.2f  y-wait %.2f  Q %.2f  L-xh %.2f  q-wait %.2f  A %.2f  (next) %.2f | step %.2f\n",
+              sum[0] / (prev_tp - 1) / 100, sum[1] / (prev_tp - 1) / 100, sum[2] / (prev_tp - 1) / 100,
+              sum[3] / (prev_tp - 1) / 100, sum[4] / (prev_tp - 1) / 100, sum[5] / (prev_tp - 1) / 100,
+              sum[6] / (prev_tp - 1) / 100, sum[7] / (prev_tp - 1) / 100, (double)(h[(prev_tp - 1) * 8] - h[0]) / (prev_tp - 1) / 100);
+    }
+  }
+  prev_tp = Tp < 256 ? Tp : 0;
+  return prev_tp ? dev : nullptr;
+}
+
+int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
+  ComicPersistFwdArgs a = a_in;
+  a.stamps = stamps_buffer(a.Tp, st);
+  const bool wq_lds = lds_bytes(a.M, a.tied, true) <= kLdsMax;
+  int64_t lds = lds_bytes(a.M, a.tied, wq_lds);
+  if (lds < kLdsMin) lds = kLdsMin;
+  if (hipMemsetAsync(a.sync, 0, kPersistSyncWords * sizeof(unsigned), st) != hipSuccess) {   // the error word
+    comic_set_error("persistent decoder: memset failed");
+    return 1;
+  }
+  const int groups = (a.B + kGroupRows - 1) / kGroupRows;
+  const int nx = (a.E / 16 + kWaves - 1) / kWaves;                // x blocks per wave
+  int rc = 2;
+  if (nx <= 1) rc = wq_lds ? launch<1, true>(a, groups, lds, st) : launch<1, false>(a, groups, lds, st);
+  else if (nx == 2) rc = wq_lds ? launch<2, true>(a, groups, lds, st) : launch<2, false>(a, groups, lds, st);
+  else if (nx <= 4) rc = wq_lds ? launch<4, true>(a, groups, lds, st) : launch<4, false>(a, groups, lds, st);
+  else comic_set_error("persistent decoder: word size %d not supported", a.E);
+  return rc;
+}
+
+int comic_persist_prepare(float* xh_all, long xh_n, float* y_all, long y_n, float* q_all, long q_n, hipStream_t st) {
+  COMIC_REQUIRE(xh_n % 4 == 0 && y_n % 4 == 0 && q_n % 4 == 0, "persistent decoder: buffer sizes must be multiples of 4");
+  const long n = (xh_n + y_n + q_n) / 4;
+  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (uint4*)xh_all, xh_n / 4,
+                     (uint4*)y_all, y_n / 4, (uint4*)q_all, q_n / 4);
+  COMIC_LAUNCH_CHECK("persistent decoder prepare");
+  return 0;
+}
+
+int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st) {
+  hipLaunchKernelGGL(persist_check_kernel, dim3(1), dim3(1), 0, st, sync, loss);
+  COMIC_LAUNCH_CHECK("persistent decoder check");
+  return 0;
+}

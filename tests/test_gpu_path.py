@@ -383,6 +383,9 @@ TRAIN_VARIANTS = [
          start_id=298, end_id=299),                                            # InstaPIC-style baseline (config 5)
     dict(fm_projection=None, context_layer=True, method='dot', H=4),
     dict(method='dot', H=2, M=64),
+    # persistent time loop (decoder_persist.hip; D = 512 only): the other memory / alignment / probability forms
+    dict(D=512, E=256, fm_projection='independent', prob='sigmoid', H=4),
+    dict(D=512, E=128, method='dot', H=16, M=64),                               # W_q columns from L2 (keys fill the LDS)
 ]
 
 
@@ -417,6 +420,35 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
         assert_close(g[k], grads[k], F32_RTOL, 'grad ' + k)
     assert_close(res['dfm'].cpu().numpy(), dfm, F32_RTOL, 'dfm')
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
+
+
+@pytest.mark.parametrize('B', [64, 23])
+def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
+    """The one-launch forward time loop (decoder_persist.hip: 64 workgroups per 16 batch rows, sc1 hand-offs, counter
+    barriers) against the per-step launch chain it replaces, at the bench geometry with every dropout on: same saved
+    activations up to fp32 summation order.  Two different batches through the same buffers: a stale hand-off (a byte
+    of the previous launch read in place of this one's) would show in the second."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    Lc = 30
+    dec = cdec.Decoder(spec, _rand_params(cfg, 5), DEV)
+    for seed in (31, 32):
+        fm, im, caps = _batch(spec, B, Lc, seed)
+        _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+        masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, seed)
+        got = {}
+        for mode in ('1', '0'):
+            monkeypatch.setenv('COMIC_PERSIST', mode)
+            res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+            sync()
+            got[mode] = dict(logits=res['logits'].cpu().numpy(), maps=res['attn_maps'].cpu().numpy(),
+                             loss=float(res['loss']), map_loss=float(res['map_loss']), dfm=res['dfm'].cpu().numpy(),
+                             g=dec.grads.data.cpu().numpy().copy())
+        assert np.isfinite(got['1']['loss']) and np.isfinite(got['1']['map_loss'])
+        assert_close(got['1']['logits'], got['0']['logits'], 2e-5, 'logits')
+        assert_close(got['1']['maps'], got['0']['maps'], 2e-5, 'attention maps')
+        assert_close(got['1']['dfm'], got['0']['dfm'], 1e-4, 'd feature map')
+        assert_close(got['1']['g'], got['0']['g'], 1e-4, 'flat gradient')
+        assert abs(got['1']['loss'] - got['0']['loss']) <= 1e-5 * abs(got['0']['loss'])
 
 
 def test_train_step_inputs_survive_host_run_ahead():
