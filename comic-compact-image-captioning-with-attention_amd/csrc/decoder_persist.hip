@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
     lnp[1][0] = a.ln_b[c]; lnp[1][1] = a.ln_b[c + 1];
     lnp[2][0] = a.v[c]; lnp[2][1] = a.v[c + 1];
   }
-  const float scale = a.method == 0 ? a.tau[0] : sqrtf((float)dh);
+  const float inv_scale = 1.0f / (a.method == 0 ? a.tau[0] : sqrtf((float)dh));
   __syncthreads();
 
   // The LSTM product of a step in two parts: blocks [I0, I1) of the wave.
@@ -303,6 +303,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         a.hs[((size_t)(t + 1) * B + e_row) * D + e_d] = e_h;
       }
     }
+    __syncthreads();   // the six other waves start polling y only after this workgroup's own stores are on their way
     stamp(a.stamps, t, 2);
     // =============================================================== Q: query layer =================================
     {
@@ -315,7 +316,6 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
 #pragma unroll
       for (int i = 0; i < 4; ++i) yv[i] = load16_sc1(y_r, yo + yoff[i]);
       wait_written<4>(yv, y_r, yo, yoff, 15u, wt);
-      stamp(a.stamps, t, 3);
       float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -350,14 +350,13 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         store16_sc1(q_r, qo + 16, make_float4(q8[4], q8[5], q8[6], q8[7]));
       }
     }
-    stamp(a.stamps, t, 4);
+    stamp(a.stamps, t, 3);
     // ============================================ next step's x and h thirds, under the q hand-off ====================
     acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (t + 1 < a.Tp) {
       lstm_part(t + 1, c0, cx);
       lstm_part(t + 1, ca, ch);
     }
-    stamp(a.stamps, t, 5);
     // =============================================================== A: attention ===================================
     if (a_live) {
       if (wave < 2) {
@@ -368,44 +367,77 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         *(float4*)(q_l + 4 * tid) = qv[0];
       }
       __syncthreads();
-      stamp(a.stamps, t, 6);
-      // scores of this quarter's heads; a wave owns memory rows m = wave, wave + 8, ...
-      for (int m = wave; m < M; m += kWaves) {
-        const float* kr = keys_l + m * D;
+      stamp(a.stamps, t, 4);
+      // scores of this quarter's heads; a wave owns memory rows m = wave, wave + 8, ... and takes two per pass (the
+      // reductions of the two rows interleave); the phase is VALU-bound (about 150 wave instructions per row)
+      auto score_rows = [&](int m0, auto nr_) {
+        constexpr int NR = decltype(nr_)::value;
         const int c = cq0 + 2 * lane;                           // this lane's two channels of the quarter
-        float part0 = 0.f;
+        const float* kr[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) kr[r] = keys_l + (m0 + r * kWaves) * D;
+        float part0[NR];
         if (a.method == 0) {
           constexpr int EPL = 8;                                // statistics over all D = 64 lanes x 8 channels
-          float z[EPL], s = 0.f;
+          float z[NR][EPL], s[NR];
+          const float4 qa = *(const float4*)(q_l + lane * EPL), qb = *(const float4*)(q_l + lane * EPL + 4);
 #pragma unroll
-          for (int i = 0; i < EPL; i += 4) {
-            const float4 kv = *(const float4*)(kr + lane * EPL + i), qv = *(const float4*)(q_l + lane * EPL + i);
-            z[i] = kv.x + qv.x; z[i + 1] = kv.y + qv.y; z[i + 2] = kv.z + qv.z; z[i + 3] = kv.w + qv.w;
-            s += (z[i] + z[i + 1]) + (z[i + 2] + z[i + 3]);
+          for (int r = 0; r < NR; ++r) {
+            const float4 ka = *(const float4*)(kr[r] + lane * EPL), kb = *(const float4*)(kr[r] + lane * EPL + 4);
+            z[r][0] = ka.x + qa.x; z[r][1] = ka.y + qa.y; z[r][2] = ka.z + qa.z; z[r][3] = ka.w + qa.w;
+            z[r][4] = kb.x + qb.x; z[r][5] = kb.y + qb.y; z[r][6] = kb.z + qb.z; z[r][7] = kb.w + qb.w;
+            s[r] = ((z[r][0] + z[r][1]) + (z[r][2] + z[r][3])) + ((z[r][4] + z[r][5]) + (z[r][6] + z[r][7]));
           }
-          const float mean = wave_sum(s) / (float)D;
-          float s2 = 0.f;
+          float mean[NR], s2[NR], rstd[NR];
 #pragma unroll
-          for (int i = 0; i < EPL; ++i) {
-            const float cc = z[i] - mean;
-            s2 += cc * cc;
+          for (int r = 0; r < NR; ++r) mean[r] = wave_sum(s[r]) * (1.0f / (float)D);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            s2[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              const float cc = z[r][i] - mean[r];
+              s2[r] = fmaf(cc, cc, s2[r]);
+            }
           }
-          const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float zz = kr[c + e] + q_l[c + e];
-            const float inv = rstd * lnp[0][e];
-            const float zh = zz * inv + (lnp[1][e] - mean * inv);   // tf.nn.batch_normalization form
-            part0 += fast_tanh(zh) * lnp[2][e];
+          for (int r = 0; r < NR; ++r) rstd[r] = __frsqrt_rn(wave_sum(s2[r]) * (1.0f / (float)D) + kLnEps);
+          const float2 qc = *(const float2*)(q_l + c);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const float2 kc = *(const float2*)(kr[r] + c);
+            const float zz[2] = {kc.x + qc.x, kc.y + qc.y};
+            part0[r] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float inv = rstd[r] * lnp[0][e];
+              const float zh = zz[e] * inv + (lnp[1][e] - mean[r] * inv);   // tf.nn.batch_normalization form
+              part0[r] += fast_tanh(zh) * lnp[2][e];
+            }
           }
         } else {
-          part0 = kr[c] * q_l[c] + kr[c + 1] * q_l[c + 1];
+          const float2 qc = *(const float2*)(q_l + c);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const float2 kc = *(const float2*)(kr[r] + c);
+            part0[r] = kc.x * qc.x + kc.y * qc.y;
+          }
         }
-        float hsum = part0;                                     // sum over the lanes of a head (power of two <= 64)
-        for (int o = 1; o < lph; o <<= 1) hsum += __shfl_xor(hsum, o, 64);
-        if ((lane % lph) == 0) sc_l[(lane / lph) * 64 + m] = hsum / scale;
+        // sum over the lanes of a head (16, 32 or 64): the total lands in the head's LAST lane
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float hsum = group_sum_dpp(part0[r], 16);
+          if (lph >= 32) hsum += dpp_move<0x142, 0xA>(0.f, hsum);   // row_bcast:15 into rows 1, 3
+          if (lph == 64) hsum += dpp_move<0x143, 0xC>(0.f, hsum);   // row_bcast:31 into rows 2, 3
+          if ((lane % lph) == lph - 1) sc_l[(lane / lph) * 64 + m0 + r * kWaves] = hsum * inv_scale;
+        }
+      };
+      for (int m0 = wave; m0 < M; m0 += 2 * kWaves) {
+        if (m0 + kWaves < M) score_rows(m0, integral_constant<int, 2>());
+        else score_rows(m0, integral_constant<int, 1>());
       }
       __syncthreads();
+      stamp(a.stamps, t, 5);
       // probability fn per head (a wave per head of the quarter), dropout; sc <- alpha_d
       if (wave < hq) {
         const int h = aq * hq + wave;
@@ -429,11 +461,18 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         }
       }
       __syncthreads();
+      stamp(a.stamps, t, 6);
       if (wave < 2) {
         const float* al = sc_l + (tid / dh) * 64;
         const float* vp = vals_l + a_c;
-        float cx = 0.f;
-        for (int m = 0; m < M; ++m) cx = fmaf(al[m], vp[m * D], cx);
+        float c4[4] = {0.f, 0.f, 0.f, 0.f};                     // four interleaved partial sums (fixed order)
+        int m = 0;
+        for (; m + 4 <= M; m += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c4[k] = fmaf(al[m + k], vp[(m + k) * D], c4[k]);
+        }
+        for (; m < M; ++m) c4[0] = fmaf(al[m], vp[m * D], c4[0]);
+        const float cx = (c4[0] + c4[1]) + (c4[2] + c4[3]);
         a.ctx_all[((size_t)t * B + ab) * D + a_c] = cx;
         const bool fin = t >= a_len;
         att_prev = fin ? att_prev : cx;
@@ -445,6 +484,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
             store16_sc1(xh_r, (unsigned)((((size_t)(t + 1) * B + ab) * Wd + E + a_c) * 4), make_float4(xv, x1, x2, x3));
         }
       }
+      __syncthreads();   // as after the cell epilogue: poll the next operand only once our own att stores are issued
     }
     stamp(a.stamps, t, 7);
   }
@@ -514,7 +554,7 @@ static unsigned long long* stamps_buffer(int Tp, hipStream_t st) {
       double sum[8] = {0};
       for (int t = 0; t + 1 < prev_tp; ++t)
         for (int i = 0; i < 8; ++i) sum[i] += (double)(h[i < 7 ? t * 8 + i + 1 : (t + 1) * 8] - h[t * 8 + i]);
-      fprintf(stderr, "[persist stamps] per step (us): L-att %.2f  L-epi %.2f  y-wait %.2f  Q %.2f  L-xh %.2f  q-wait %.2f  A %.2f  (next) %.2f | step %.2f\n",
+      fprintf(stderr, "[persist stamps] per step (us): att-wait+L %.2f  L-epi %.2f  y-wait+Q %.2f  L-xh+q-wait %.2f  scores %.2f  prob %.2f  ctx %.2f  (masks) %.2f | step %.2f\n",
               sum[0] / (prev_tp - 1) / 100, sum[1] / (prev_tp - 1) / 100, sum[2] / (prev_tp - 1) / 100,
               sum[3] / (prev_tp - 1) / 100, sum[4] / (prev_tp - 1) / 100, sum[5] / (prev_tp - 1) / 100,
               sum[6] / (prev_tp - 1) / 100, sum[7] / (prev_tp - 1) / 100, (double)(h[(prev_tp - 1) * 8] - h[0]) / (prev_tp - 1) / 100);
