@@ -100,6 +100,11 @@ bool persist_enabled() {
   return !(e && e[0] == '0');
 }
 
+bool persist_bwd_enabled() {
+  const char* e = getenv("COMIC_PERSIST_BWD");
+  return !(e && e[0] == '0');
+}
+
 #define RC(x)               \
   do {                      \
     int rc__ = (x);         \
@@ -564,7 +569,9 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
   w.take<float>(D * D);                                                        // W_q panel
-  w.take<unsigned>(kPersistSyncWords);                                         // persistent loop: counters + error word
+  w.take<unsigned>(kPersistSyncWords);                                         // persistent loops: error word
+  w.take<float>(TB * 4 * D); w.take<float>(TB * 2 * D);                        // persistent backward: d q partials, d att | d h
+  w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
   return (int64_t)w.off;
 }
 
@@ -631,6 +638,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
   float* wq_panel = w.take<float>((long)D * D);
   unsigned* persist_sync = w.take<unsigned>(kPersistSyncWords);
+  float* dq_part = w.take<float>(TB * 4 * D);
+  float* dstate = w.take<float>(TB * 2 * D);
+  float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
 
   const comic_attn_desc ad = attn_desc(d, B);
@@ -745,9 +755,16 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const bool use_map = d->map_loss_scale > 0.f;
   const bool sep_values = d->fm_projection != 2;
   float* dvalues = sep_values ? dvalues_buf : dkeys;
-  RC(fill(dkeys, 0.f, (long)B * M * D, st));
-  if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
-  RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));      // dc | dh | datt: consecutive workspace blocks
+  // the whole backward time loop as one persistent launch (decoder_persist_bwd.hip) when the forward one ran
+  const bool persist_b = persist && persist_bwd_enabled() &&
+                         comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
+  if (!persist_b) {
+    RC(fill(dkeys, 0.f, (long)B * M * D, st));
+    if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
+    RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));    // dc | dh | datt: consecutive workspace blocks
+  } else {
+    RC(comic_persist_prepare(dq_part, (long)Tp * B * 4 * D, dg_all, (long)Tp * B * 4 * D, dstate, (long)Tp * B * 2 * D, st));
+  }
   // dy_all = dlogits * W_o^T ; dW_o, db_o
   RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
   RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
@@ -756,11 +773,28 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // softmax attention: the backward kernel runs as two workgroups per batch row (half of the memory rows each), whose
   // d q / parameter-gradient contributions are added into zero-filled rows (comic_attn_bwd_ex, pgrad_overwrite 2)
   const int attn_bwd_mode = (d->prob == 0 && split_attn_bwd_enabled()) ? 2 : 1;
-  if (attn_bwd_mode == 2) {
+  if (persist_b) {
+    ComicPersistBwdArgs pb{};
+    pb.K_panel_b = kpanel_b; pb.W_q = p->W_q; pb.keys = keys;
+    pb.ln_g = p->ln_g; pb.ln_b = p->ln_b; pb.v = p->v; pb.tau = p->tau; pb.lens = lens;
+    pb.mask_in = drop_in ? mask_in : nullptr; pb.mask_out = drop_out ? mask_out : nullptr;
+    pb.mask_alpha = drop_al ? mask_alpha : nullptr;
+    pb.keep_in = d->keep_in; pb.keep_out = d->keep_out; pb.keep_alpha = d->keep_alpha;
+    pb.q_all = q_all; pb.alpha_all = alpha_all; pb.gates_all = gates_all; pb.cs = cs; pb.cnew_all = cnew_all;
+    pb.dy_all = dy_all; pb.dmap = use_map ? dmap : nullptr;
+    pb.dq_part = dq_part; pb.dg_all = dg_all; pb.dstate = dstate;
+    pb.dq_all = dq_all; pb.dc = dc; pb.dh = dh; pb.dkeys = dkeys; pb.pgrad = pgrad4; pb.sync = persist_sync;
+    pb.B = B; pb.E = E; pb.M = M; pb.H = H; pb.Tp = Tp; pb.method = d->method;
+    RC(comic_persist_bwd_launch(pb, st));
+    // the embedding third of d gates * K^T, all steps at once, and its input dropout
+    RC(gemm_big(dg_all, p->K, demb, nullptr, Tp * B, E, 4 * D, 4 * D, 4 * D, E, 0, 1, 0.f, st));
+    if (drop_in) RC(comic_dropout_rows(demb, mask_in, d->keep_in, (long)Tp * B, E, EA, st));
+    RC(comic_persist_check(persist_sync, map_loss, st));
+  } else if (attn_bwd_mode == 2) {
     RC(fill(dq_all, 0.f, (long)Tp * B * D, st));
     RC(fill(pgrad, 0.f, (long)Tp * B * (3 * D + 1), st));
   }
-  for (int t = Tp - 1; t >= 0; --t) {
+  for (int t = persist_b ? -1 : Tp - 1; t >= 0; --t) {
     const float* ctx_t = ctx_all + (size_t)t * B * Cv;
     float* dq_t = dq_all + (size_t)t * B * D;
     const float* mal = drop_al ? mask_alpha + (size_t)t * B * H * M : nullptr;
@@ -847,7 +881,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter.
     // dg_all is free again here (its last reader, the dK GEMM, is ordered before on `st`).
     float* tmp = dg_all;
-    RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
+    if (persist_b) RC(comic_colsum_ws(pgrad4, tmp, 4 * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
+    else RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
     hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);
   }
   COMIC_LAUNCH_CHECK("train_step");

@@ -45,3 +45,42 @@ int comic_persist_prepare(float* xh_all, long xh_n, float* y_all, long y_n, floa
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
 // poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)
 int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st);
+
+// ---- backward loop (decoder_persist_bwd.hip) ---------------------------------------------------------------------------
+struct ComicPersistBwdArgs {
+  const float* K_panel_b; // backward panel of the LSTM kernel (comic_pack_lstm_panels, mode 1)
+  const float* W_q;       // [D][D]
+  const float* keys;      // [B][M][D] (tied: also the values)
+  const float *ln_g, *ln_b, *v, *tau;
+  const int32_t* lens;
+  const float* mask_in;   // [T][B][E+A] or null
+  const float* mask_out;  // [T][B][D] or null
+  const float* mask_alpha;// [T][B][H][M] or null
+  float keep_in, keep_out, keep_alpha;
+  // saved by the forward loop
+  const float* q_all;     // [Tp][B][D]
+  const float* alpha_all; // [Tp][B][H][M]
+  const float* gates_all; // [Tp][B][4D]
+  const float* cs;        // [Tp+1][B][D]
+  const float* cnew_all;  // [Tp][B][D]
+  const float* dy_all;    // [Tp][B][D]  d cell output from the logits path
+  const float* dmap;      // [Tp][B][M] map-loss term of d alpha_d, or null
+  // hand-off buffers, sentinel-filled by the caller
+  float* dq_part;         // [Tp][B][4][D]
+  float* dg_all;          // [Tp][B][4D]   (also the operand of the d K / d b reductions after the loop)
+  float* dstate;          // [Tp][B][2D]   d att | d h of the step's operand row
+  // outputs
+  float* dq_all;          // [Tp][B][D]
+  float* dc;              // [B][D] gradient of the initial cell state
+  float* dh;              // [B][D]
+  float* dkeys;           // [B][M][D]
+  float* pgrad;           // [4B][3D+1] rows of [d v | d ln_g | d ln_b | d tau]
+  unsigned* sync;         // the error word (cleared by the forward launch of the same step)
+  int B, E, M, H, Tp;
+  int method;
+};
+
+bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,
+                                 int context_layer, int tied);
+int comic_persist_bwd_launch(const ComicPersistBwdArgs& a, hipStream_t st);
+int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st);

@@ -1,0 +1,510 @@
+// Persistent backward time loop of the attention-LSTM decoder (training, fp32) for gfx950: the reverse of
+// decoder_persist.hip's loop, one launch for all T' steps.
+//
+// Replaces the per-step launches of comic_decoder_train_step's backward loop (attn_bwd_kernel, lstm_grad_fused_kernel,
+// input_grad_fused_kernel: 36 us of kernel time and three launch gaps per step) -- the gradient of
+// MultiHeadAttentionWrapperV3.call (common/ops_rnn.py:660-755), of MultiHeadAddLN / MultiHeadDot (:531-565, :611-632),
+// of BasicLSTMCell + DropoutWrapper (src/model_base.py:606-648) and of impute_finished (common/ops_rnn.py:183-243).
+// tf.gradients builds the same chain in the reference; here it is written out by hand (oracle/decoder_ref.py
+// train_backward is the CPU restatement the tests compare against).
+//
+// Same geometry and hand-off rule as the forward loop (decoder_persist_dev.h): groups of 16 batch rows x 64
+// workgroups, one per CU; every handed-off buffer is time-major, sentinel-filled by the caller, written once with
+// sc1 stores and read with validated sc1 loads.  Workgroup i of a group runs, per step t = T'-1 .. 0:
+//   A' batch row (i % 16), memory rows m = (i / 16) mod 4 (one per wave): recomputes LayerNorm / tanh of its rows from
+//      the resident keys and the saved q_t, d alpha of ALL rows (cheap), the probability backward, then tanh /
+//      LayerNorm backward of its rows                      writes its quarter of d q_t (four partials per batch row)
+//      d keys of its rows and the attention-parameter gradients accumulate in REGISTERS over all steps.
+//   G  units [8i, 8i+8) x 16 rows:  d y = d y_logits + (sum of the four d q partials) * W_q^T (its W_q rows in LDS),
+//      output-dropout and BasicLSTMCell backward; d c and the kept part of d h stay in registers
+//                                                          writes d gates_t (also the operand of the d K GEMM)
+//   I  operand features [16i, 16i+16) of the att and h thirds x 16 rows:  d gates_t * K^T (its 16 rows of K^T, 128 KB,
+//      in registers; exact fp32 MFMA), input dropout       writes d att / d h of step t (read by A' / G of step t-1)
+// The x third of d gates * K^T (the embedding gradient) does not feed the recurrence: one GEMM after the loop.
+// What bounds a step: G and I each gather 128 KB per workgroup (3.6 us at the 70 GB/s a CU pulls, measured with
+// tools/micro/gather_bench.hip); A' is VALU-bound (about 2 us).
+#include <type_traits>
+
+#include "decoder_persist_dev.h"
+
+#include "decoder_math.h"
+
+namespace {
+
+constexpr int kMaxOwn = 8;   // memory rows a workgroup owns (one per wave): M <= 32
+
+// sum over the lph (2, 4, 8 or 16) consecutive lanes of a head: every lane of the head gets the total
+__device__ __forceinline__ float head_total(float v, int lph) { return group_sum_dpp(v, lph); }
+
+// demb[r][c] = (demb[r][c] / keep) * mask[r * ld + c]: the input dropout of the embedding third
+__global__ void dropout_rows_kernel(float* __restrict__ x, const float* __restrict__ mask, float keep, long rows, int cols,
+                                    int ld) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  const int c = (int)(i % cols);
+  x[i] = (x[i] / keep) * mask[r * ld + c];
+}
+
+__global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicPersistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = kD, EPL = 8;
+  const int M = a.M, H = a.H, E = a.E, EA = a.E + D, B = a.B, Tp = a.Tp, N4 = 4 * D;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;
+  const int row0 = grp * kGroupRows;
+  Waiter wt{a.sync, false};
+
+  // ---- LDS carve-up ---------------------------------------------------------------------------------------------
+  float* keys_l = (float*)smem;                                // [M][D]   keys (= values) of the attention row
+  float* wq_l = keys_l + M * D;                                // [8][32 parts x 20]  W_q rows of this workgroup's units
+  float4* red_i = (float4*)(wq_l + 8 * 640);                   // [8 waves][64]       I phase cross-wave combine
+  float* red_q = (float*)(red_i + kWaves * 64);                // [8 waves][D]        d q combine (A')
+  float* ss = red_q + kWaves * D;                              // [H][32] scaled scores of own rows
+  float* sd = ss + 16 * 32;                                    // [H][32] d alpha_d, then d raw
+  float* sa = sd + 16 * 32;                                    // [H][32] alpha_d
+  float* lnp_l = sa + 16 * 32;                                 // [3][D]  ln gamma | ln beta | v (read in A' only)
+
+  const __amdgpu_buffer_rsrc_t dqp_r = make_rsrc(a.dq_part, (long)Tp * B * 4 * D * 4);
+  const __amdgpu_buffer_rsrc_t dg_r = make_rsrc(a.dg_all, (long)Tp * B * N4 * 4);
+  const __amdgpu_buffer_rsrc_t ds_r = make_rsrc(a.dstate, (long)Tp * B * 2 * D * 4);
+
+  // ---- A' identity: batch row, owned memory rows ---------------------------------------------------------------------
+  const int ab = row0 + (wi & 15), aq = wi >> 4;
+  const bool a_live = ab < B;
+  const int dh = D / H, lph = dh / EPL;                        // lanes per head (8 channels per lane)
+  const int k0 = lane * EPL, head = k0 / dh;
+  const int m_own = aq + 4 * wave;                             // this wave's memory row
+  const bool has_own = a_live && m_own < M;
+  const int a_len = a_live ? a.lens[ab] : 0;
+  {
+    const int arow = a_live ? ab : 0;
+    const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
+    for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
+    for (int i = tid; i < 8 * D; i += kThreads) {              // W_q row 8 wi + u, k: at u*640 + (k/16)*20 + k%16
+      const int u = i >> 9, k = i & (D - 1);
+      wq_l[u * 640 + (k >> 4) * 20 + (k & 15)] = a.W_q[(size_t)(8 * wi + u) * D + k];
+    }
+    for (int i = tid; i < kWaves * D; i += kThreads) red_q[i] = 0.f;   // waves without a row never write theirs
+    lnp_l[tid] = a.method == 0 ? a.ln_g[tid] : 0.f;
+    lnp_l[D + tid] = a.method == 0 ? a.ln_b[tid] : 0.f;
+    lnp_l[2 * D + tid] = a.method == 0 ? a.v[tid] : 0.f;
+  }
+  const float scale = a.method == 0 ? a.tau[0] : sqrtf((float)dh);
+  const float inv_scale = 1.0f / scale;
+  float datt_state[EPL], dk_acc[EPL], dv_acc[EPL], dgm_acc[EPL], db_acc[EPL], dtau = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = dv_acc[i] = dgm_acc[i] = db_acc[i] = 0.f;
+
+  // ---- G identity: thread (row rl, k part) ; epilogue element (row rl, unit 8 wi + part) for part < 8 ------------------
+  const int g_rl = tid >> 5, g_part = tid & 31;
+  const int g_row = row0 + g_rl, g_d = 8 * wi + g_part;
+  const bool g_elem = g_part < 8 && g_row < B;
+  const int g_len = g_row < B ? a.lens[g_row] : 0;
+  float g_dc = 0.f, g_dhk = 0.f;                               // d c state, kept part of d h state
+
+  // ---- I identity: feature tile wi of the att | h thirds; this wave's sixteen k16-blocks of d gates --------------------
+  const int r16 = lane & 15, kq = lane >> 4;
+  constexpr int KBI = 4 * D / 16, NBI = KBI / kWaves;          // 128 blocks, 16 per wave
+  float4 wreg[NBI];
+  unsigned gb_off[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; ++i) {
+    const int kb = 2 * (wave + kWaves * (i >> 1)) + (i & 1);
+    gb_off[i] = (unsigned)kb * 64u;
+    wreg[i] = *(const float4*)(a.K_panel_b + (((size_t)(E / 16 + wi) * KBI + kb) * 16 + r16) * 16 + 4 * kq);
+  }
+  const int i_row = min(row0 + r16, B - 1);                    // operand row of this lane (clamped)
+  __syncthreads();
+
+  for (int t = Tp - 1; t >= 0; --t) {
+    // ===================================================================== A': attention backward =====================
+    if (a_live) {
+      const float live = t < a_len ? 1.f : 0.f;
+      // saved forward values and masks of this step (plain loads: written by earlier launches)
+      float qv[EPL];
+      {
+        const float4 q0 = *(const float4*)(a.q_all + ((size_t)t * B + ab) * D + k0);
+        const float4 q1 = *(const float4*)(a.q_all + ((size_t)t * B + ab) * D + k0 + 4);
+        qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+      }
+      // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
+      if (t + 1 < Tp) {
+        const unsigned so = (unsigned)((((size_t)(t + 1) * B + ab) * 2 * D + k0) * 4);
+        const unsigned off2[2] = {0u, 16u};
+        float4 dv2[2] = {load16_sc1(ds_r, so), load16_sc1(ds_r, so + 16)};
+        wait_written<2>(dv2, ds_r, so, off2, 3u, wt);
+        const float keepf = (t + 1 >= a_len) ? 1.f : 0.f;
+        const float vin[EPL] = {dv2[0].x, dv2[0].y, dv2[0].z, dv2[0].w, dv2[1].x, dv2[1].y, dv2[1].z, dv2[1].w};
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) datt_state[i] = datt_state[i] * keepf + vin[i];
+      }
+      float dcl[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) dcl[i] = datt_state[i] * live;
+      float gv[EPL], bv[EPL], vv[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        gv[i] = lnp_l[k0 + i];
+        bv[i] = lnp_l[D + k0 + i];
+        vv[i] = lnp_l[2 * D + k0 + i];
+      }
+      // (i) own row: LayerNorm / tanh recomputed, scaled scores of every head
+      float th[EPL], xh[EPL], kro[EPL], rstd = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) th[i] = xh[i] = kro[i] = 0.f;
+      if (has_own) {
+        const float* kr = keys_l + m_own * D + k0;
+        const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+        kro[0] = ka.x; kro[1] = ka.y; kro[2] = ka.z; kro[3] = ka.w; kro[4] = kb.x; kro[5] = kb.y; kro[6] = kb.z; kro[7] = kb.w;
+        float part = 0.f;
+        if (a.method == 0) {
+          float z[EPL], s = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            z[i] = kro[i] + qv[i];
+            s += z[i];
+          }
+          const float mean = wave_sum(s) / (float)D;
+          float s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float cc = z[i] - mean;
+            s2 += cc * cc;
+          }
+          rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float inv = rstd * gv[i];
+            const float zh = z[i] * inv + (bv[i] - mean * inv);   // tf.nn.batch_normalization form
+            th[i] = fast_tanh(zh);
+            xh[i] = (z[i] - mean) * rstd;
+            part += th[i] * vv[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) part += kro[i] * qv[i];
+        }
+        part = head_total(part, lph);
+        if ((lane % lph) == 0) ss[head * 32 + m_own] = part * inv_scale;
+      }
+      // (ii) d alpha_d of ALL memory rows (the probability backward needs whole rows of it): d ctx . values
+      for (int m = wave; m < M; m += kWaves) {
+        const float* kr = keys_l + m * D + k0;
+        const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+        float part = dcl[0] * ka.x;
+        part = fmaf(dcl[1], ka.y, part); part = fmaf(dcl[2], ka.z, part); part = fmaf(dcl[3], ka.w, part);
+        part = fmaf(dcl[4], kb.x, part); part = fmaf(dcl[5], kb.y, part); part = fmaf(dcl[6], kb.z, part);
+        part = fmaf(dcl[7], kb.w, part);
+        part = head_total(part, lph);
+        if ((lane % lph) == 0) sd[head * 32 + m] = part + (a.dmap ? a.dmap[((size_t)t * B + ab) * M + m] : 0.f);
+      }
+      __syncthreads();
+      // through the dropout and the probability fn (a wave per head, lanes = memory rows); sd <- d raw, sa <- alpha_d
+      for (int h = wave; h < H; h += kWaves) {
+        const size_t go = (((size_t)t * B + ab) * H + h) * M;
+        const bool in = lane < M;
+        const float al = in ? a.alpha_all[go + lane] : 0.f;
+        const float mk = (in && a.mask_alpha) ? a.mask_alpha[go + lane] : 1.f;
+        float da = in ? sd[h * 32 + lane] : 0.f;
+        if (a.mask_alpha) da = (da / a.keep_alpha) * mk;
+        const bool own = in && (lane & 3) == aq;
+        const float sown = own ? ss[h * 32 + lane] : 0.f;
+        const float dot = wave_sum(al * da);                    // softmax backward (the launch requires prob == 0)
+        const float dsv = al * (da - dot);
+        if (own) dtau -= dsv * sown;
+        if (in) {
+          sd[h * 32 + lane] = dsv * inv_scale;
+          sa[h * 32 + lane] = a.mask_alpha ? (al / a.keep_alpha) * mk : al;
+        }
+      }
+      __syncthreads();
+      // own row: through tanh / LayerNorm (or the dot product); d keys and parameter gradients stay in registers
+      float dqv[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) dqv[i] = 0.f;
+      if (has_own) {
+        const float draw = sd[head * 32 + m_own], adm = sa[head * 32 + m_own];
+        if (a.method == 0) {
+          float dxh[EPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            dv_acc[i] += draw * th[i];
+            const float dzh = draw * vv[i] * (1.f - th[i] * th[i]);
+            dgm_acc[i] += dzh * xh[i];
+            db_acc[i] += dzh;
+            dxh[i] = dzh * gv[i];
+            s1 += dxh[i];
+            s2 += dxh[i] * xh[i];
+          }
+          const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
+            dk_acc[i] += dz + adm * dcl[i];
+            dqv[i] = dz;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            dk_acc[i] += draw * qv[i] + adm * dcl[i];
+            dqv[i] = draw * kro[i];
+          }
+        }
+        *(float4*)(red_q + wave * D + k0) = make_float4(dqv[0], dqv[1], dqv[2], dqv[3]);
+        *(float4*)(red_q + wave * D + k0 + 4) = make_float4(dqv[4], dqv[5], dqv[6], dqv[7]);
+      }
+      __syncthreads();
+      if (wave < 2) {                                           // this workgroup's partial of d q_t: 4 channels a thread
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {                      // fixed order: deterministic
+          const float4 pp = *(const float4*)(red_q + w * D + 4 * tid);
+          sum.x += pp.x; sum.y += pp.y; sum.z += pp.z; sum.w += pp.w;
+        }
+        store16_sc1(dqp_r, (unsigned)(((((size_t)t * B + ab) * 4 + aq) * D + 4 * tid) * 4), sum);
+      }
+      __syncthreads();   // polls of the next phase start after this workgroup's own stores are on their way
+    }
+    // ===================================================================== G: query layer + LSTM cell backward =========
+    {
+      // saved forward values of the epilogue element (plain loads)
+      float e_g[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f, e_cn = 0.f, e_dy = 0.f, e_mk = 1.f;
+      if (g_elem) {
+        const size_t e = ((size_t)t * B + g_row) * D + g_d;
+        const float* ga = a.gates_all + ((size_t)t * B + g_row) * N4;
+        e_g[0] = ga[g_d]; e_g[1] = ga[D + g_d]; e_g[2] = ga[2 * D + g_d]; e_g[3] = ga[3 * D + g_d];
+        e_cp = a.cs[e];
+        e_cn = a.cnew_all[e];
+        e_dy = a.dy_all[e];
+        if (a.mask_out) e_mk = a.mask_out[e];
+      }
+      const int row = min(g_row, B - 1);
+      const unsigned qo = (unsigned)(((((size_t)t * B + row) * 4) * D + 16 * g_part) * 4);
+      const unsigned off4[4] = {0u, 16u, 32u, 48u};
+      float4 pj[4][4];                                          // the four partials of this thread's 16 k
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pj[j][i] = load16_sc1(dqp_r, qo + (unsigned)j * D * 4u + off4[i]);
+      float4 dq4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dq4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                             // fixed order: deterministic
+        wait_written<4>(pj[j], dqp_r, qo + (unsigned)j * D * 4u, off4, 15u, wt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dq4[i].x += pj[j][i].x; dq4[i].y += pj[j][i].y; dq4[i].z += pj[j][i].z; dq4[i].w += pj[j][i].w;
+        }
+      }
+      // the summed d q_t (operand of the d W_q GEMM after the loop): this workgroup writes columns [8 wi, 8 wi + 8)
+      if (g_part == (wi >> 1) && g_row < B) {
+        float* dst = a.dq_all + ((size_t)t * B + g_row) * D + 8 * wi;
+        if (wi & 1) {
+          *(float4*)dst = dq4[2];
+          *(float4*)(dst + 4) = dq4[3];
+        } else {
+          *(float4*)dst = dq4[0];
+          *(float4*)(dst + 4) = dq4[1];
+        }
+      }
+      float p8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* wr = wq_l + u * 640 + g_part * 20;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 w4 = *(const float4*)(wr + 4 * i);
+          acc = fmaf(dq4[i].x, w4.x, acc); acc = fmaf(dq4[i].y, w4.y, acc);
+          acc = fmaf(dq4[i].z, w4.z, acc); acc = fmaf(dq4[i].w, w4.w, acc);
+        }
+        acc = group_sum_dpp(acc, 16);
+        p8[u] = acc + __shfl_xor(acc, 16, 64);
+      }
+      float dyq = p8[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) dyq = g_part == u ? p8[u] : dyq;
+      // d h of step t+1's operand (h third), then the cell backward of (row, unit)
+      float dgv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (g_part < 8) {
+        float vh = 0.f;
+        if (t + 1 < Tp) {
+          const unsigned so = (unsigned)((((size_t)(t + 1) * B + row) * 2 * D + D + 8 * wi) * 4);
+          const unsigned off2[2] = {0u, 16u};
+          float4 hv[2] = {load16_sc1(ds_r, so), load16_sc1(ds_r, so + 16)};
+          wait_written<2>(hv, ds_r, so, off2, 3u, wt);
+          const float h8[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
+          vh = h8[0];
+#pragma unroll
+          for (int u = 1; u < 8; ++u) vh = g_part == u ? h8[u] : vh;
+        }
+        const float live = t < g_len ? 1.f : 0.f;
+        const float dh_in = g_dhk + vh;
+        const float si = e_g[0], tj = e_g[1], sf = e_g[2], so_ = e_g[3];
+        const float tc = tanhf(e_cn);
+        float dyv = e_dy + dyq;
+        if (a.mask_out) dyv = (dyv / a.keep_out) * e_mk;
+        const float dh2 = dh_in * live + dyv;
+        float dc2 = g_dc * live;
+        const float dso = dh2 * tc;
+        dc2 += dh2 * so_ * (1.f - tc * tc);
+        const float dsf = dc2 * e_cp, dsi = dc2 * tj, dtj = dc2 * si;
+        dgv[0] = dsi * si * (1.f - si);
+        dgv[1] = dtj * (1.f - tj * tj);
+        dgv[2] = dsf * sf * (1.f - sf);
+        dgv[3] = dso * so_ * (1.f - so_);
+        g_dc = g_dc * (1.f - live) + dc2 * sf;
+        g_dhk = dh_in * (1.f - live);
+      }
+      // d gates: lanes part = 0..7 of a row hold 8 consecutive units of each gate: two 16-byte stores per gate
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float x1 = __shfl_down(dgv[g], 1, 64), x2 = __shfl_down(dgv[g], 2, 64), x3 = __shfl_down(dgv[g], 3, 64);
+        if ((g_part == 0 || g_part == 4) && g_row < B)
+          store16_sc1(dg_r, (unsigned)((((size_t)t * B + g_row) * N4 + g * D + g_d) * 4), make_float4(dgv[g], x1, x2, x3));
+      }
+      __syncthreads();
+    }
+    // ===================================================================== I: d gates * K^T (att and h thirds) ==========
+    {
+      float mk4[4] = {1.f, 1.f, 1.f, 1.f};
+      const int c = 16 * wi + r16;                              // feature of the att | h thirds
+      if (wave == 0 && a.mask_in && c < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = row0 + 4 * kq + i;
+          if (b < B) mk4[i] = a.mask_in[((size_t)t * B + b) * EA + E + c];
+        }
+      }
+      const unsigned go = (unsigned)((((size_t)t * B + i_row) * N4 + 4 * kq) * 4);
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      float4 ga[NBI];
+#pragma unroll
+      for (int i = 0; i < NBI; ++i) ga[i] = load16_sc1(dg_r, go + gb_off[i]);
+#pragma unroll
+      for (int c4 = 0; c4 < NBI; c4 += 4) {                     // validate and multiply four blocks at a time
+        float4 x4[4] = {ga[c4], ga[c4 + 1], ga[c4 + 2], ga[c4 + 3]};
+        const unsigned o4[4] = {gb_off[c4], gb_off[c4 + 1], gb_off[c4 + 2], gb_off[c4 + 3]};
+        wait_written<4>(x4, dg_r, go, o4, 15u, wt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[i].x, wreg[c4 + i].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[i].y, wreg[c4 + i].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[i].z, wreg[c4 + i].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[i].w, wreg[c4 + i].w, acc, 0, 0, 0);
+        }
+      }
+      red_i[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      __syncthreads();
+      if (wave == 0) {
+        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {                      // fixed order: deterministic
+          const float4 pp = red_i[w * 64 + lane];
+          g4[0] += pp.x; g4[1] += pp.y; g4[2] += pp.z; g4[3] += pp.w;
+        }
+        // D[m][n]: lane (r16 = feature, kq) holds rows 4 kq + i; four lanes r16 = 4j .. 4j+3 make one 16-byte store
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = g4[i];
+          if (a.mask_in && c < D) v = (v / a.keep_in) * mk4[i];
+          const float x1 = __shfl_down(v, 1, 64), x2 = __shfl_down(v, 2, 64), x3 = __shfl_down(v, 3, 64);
+          const int b = row0 + 4 * kq + i;
+          if ((r16 & 3) == 0 && b < B)
+            store16_sc1(ds_r, (unsigned)((((size_t)t * B + b) * 2 * D + c) * 4), make_float4(v, x1, x2, x3));
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- after step 0: final states and the register accumulators ---------------------------------------------------------
+  if (g_part < 8) {                                             // d h of the initial state = kept part + d h of step 0's operand
+    const int row = min(g_row, B - 1);
+    const unsigned so = (unsigned)((((size_t)row) * 2 * D + D + 8 * wi) * 4);
+    const unsigned off2[2] = {0u, 16u};
+    float4 hv[2] = {load16_sc1(ds_r, so), load16_sc1(ds_r, so + 16)};
+    wait_written<2>(hv, ds_r, so, off2, 3u, wt);
+    const float h8[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
+    float vh = h8[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) vh = g_part == u ? h8[u] : vh;
+    if (g_elem) {
+      a.dc[(size_t)g_row * D + g_d] = g_dc;
+      a.dh[(size_t)g_row * D + g_d] = g_dhk + vh;
+    }
+  }
+  if (a_live) {
+    if (has_own) {
+      float* dk = a.dkeys + ((size_t)ab * M + m_own) * D + k0;
+      *(float4*)dk = make_float4(dk_acc[0], dk_acc[1], dk_acc[2], dk_acc[3]);
+      *(float4*)(dk + 4) = make_float4(dk_acc[4], dk_acc[5], dk_acc[6], dk_acc[7]);
+    }
+    // parameter-gradient row of this workgroup: [d v | d ln_g | d ln_b | d tau], summed over its waves in fixed order
+    float* pg = a.pgrad + ((size_t)ab * 4 + aq) * (3 * D + 1);
+    auto reduce_store = [&](const float (&accv)[EPL], float* dst) {
+      __syncthreads();
+      *(float4*)(red_q + wave * D + k0) = make_float4(accv[0], accv[1], accv[2], accv[3]);
+      *(float4*)(red_q + wave * D + k0 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
+      __syncthreads();
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) s += red_q[w * D + tid];
+      dst[tid] = s;
+    };
+    reduce_store(dv_acc, pg);
+    reduce_store(dgm_acc, pg + D);
+    reduce_store(db_acc, pg + 2 * D);
+    __syncthreads();
+    const float dt = wave_sum(dtau);
+    if (lane == 0) red_q[wave] = dt;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int w = 0; w < kWaves; ++w) s += red_q[w];
+      pg[3 * D] = a.method == 0 ? s / a.tau[0] : 0.f;
+    }
+  }
+}
+
+int64_t bwd_lds_bytes(int M) {
+  return (int64_t)M * kD * 4 + 8 * 640 * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4;
+}
+
+}  // namespace
+
+bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,
+                                 int context_layer, int tied) {
+  if (!comic_persist_fwd_supported(B, D, E, A, M, H, Cv, method, context_layer, tied)) return false;
+  if (!tied || prob != 0) return false;                        // d values folded into d keys; softmax probability
+  if (M > 32 || E % 16 != 0) return false;                     // one owned memory row per wave
+  return bwd_lds_bytes(M) <= 160 * 1024;
+}
+
+int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st) {
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)cdiv64(rows * cols, 256)), dim3(256), 0, st, x, mask, keep, rows,
+                     cols, ld);
+  COMIC_LAUNCH_CHECK("dropout_rows");
+  return 0;
+}
+
+int comic_persist_bwd_launch(const ComicPersistBwdArgs& a, hipStream_t st) {
+  int64_t lds = bwd_lds_bytes(a.M);
+  if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)decoder_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      comic_set_error("persistent decoder backward: cannot reserve LDS");
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int groups = (a.B + kGroupRows - 1) / kGroupRows;
+  hipLaunchKernelGGL(decoder_bwd_persistent_kernel, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  COMIC_LAUNCH_CHECK("persistent decoder backward");
+  return 0;
+}

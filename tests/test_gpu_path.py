@@ -436,19 +436,25 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
         _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
         masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, seed)
         got = {}
-        for mode in ('1', '0'):
-            monkeypatch.setenv('COMIC_PERSIST', mode)
+        for mode in ('11', '10', '00'):                    # forward + backward loops | forward loop only | launches
+            monkeypatch.setenv('COMIC_PERSIST', mode[0])
+            monkeypatch.setenv('COMIC_PERSIST_BWD', mode[1])
             res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
             sync()
             got[mode] = dict(logits=res['logits'].cpu().numpy(), maps=res['attn_maps'].cpu().numpy(),
                              loss=float(res['loss']), map_loss=float(res['map_loss']), dfm=res['dfm'].cpu().numpy(),
-                             g=dec.grads.data.cpu().numpy().copy())
-        assert np.isfinite(got['1']['loss']) and np.isfinite(got['1']['map_loss'])
-        assert_close(got['1']['logits'], got['0']['logits'], 2e-5, 'logits')
-        assert_close(got['1']['maps'], got['0']['maps'], 2e-5, 'attention maps')
-        assert_close(got['1']['dfm'], got['0']['dfm'], 1e-4, 'd feature map')
-        assert_close(got['1']['g'], got['0']['g'], 1e-4, 'flat gradient')
-        assert abs(got['1']['loss'] - got['0']['loss']) <= 1e-5 * abs(got['0']['loss'])
+                             dim=res['dim_embed'].cpu().numpy(), g=dec.grads.to_numpy())
+        ref = got['00']
+        for mode in ('11', '10'):
+            g = got[mode]
+            assert np.isfinite(g['loss']) and np.isfinite(g['map_loss']), mode
+            assert_close(g['logits'], ref['logits'], 2e-5, mode + ' logits')
+            assert_close(g['maps'], ref['maps'], 2e-5, mode + ' attention maps')
+            assert_close(g['dfm'], ref['dfm'], 1e-4, mode + ' d feature map')
+            assert_close(g['dim'], ref['dim'], 1e-4, mode + ' d image embedding')
+            for k in ref['g']:
+                assert_close(g['g'][k], ref['g'][k], 1e-4, mode + ' grad ' + k)
+            assert abs(g['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
 
 
 def test_train_step_inputs_survive_host_run_ahead():
