@@ -570,7 +570,9 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
   w.take<float>(D * D);                                                        // W_q panel
   w.take<unsigned>(kPersistSyncWords);                                         // persistent loops: error word
-  w.take<float>(TB * 4 * D); w.take<float>(TB * 2 * D);                        // persistent backward: d q partials, d att | d h
+  w.take<float>(TB * 4 * D); w.take<float>((long)T * ((B + 15) / 16) * 16 * 4 * D);  // persistent backward: d q partials, d gates (blocked)
+  w.take<float>((long)T * ((B + 15) / 16) * 16 * D);                                  // summed d q (blocked)
+  w.take<float>(TB * 2 * D);                                                   // d att | d h
   w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
   return (int64_t)w.off;
 }
@@ -638,7 +640,10 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
   float* wq_panel = w.take<float>((long)D * D);
   unsigned* persist_sync = w.take<unsigned>(kPersistSyncWords);
+  const long TB16 = (long)T * ((B + 15) / 16) * 16;
   float* dq_part = w.take<float>(TB * 4 * D);
+  float* dg_blk = w.take<float>(TB16 * 4 * D);
+  float* dq_sum = w.take<float>(TB16 * D);
   float* dstate = w.take<float>(TB * 2 * D);
   float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
@@ -763,7 +768,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
     RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));    // dc | dh | datt: consecutive workspace blocks
   } else {
-    RC(comic_persist_prepare(dq_part, (long)Tp * B * 4 * D, dg_all, (long)Tp * B * 4 * D, dstate, (long)Tp * B * 2 * D, st));
+    const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
+    RC(comic_persist_prepare(dq_part, (long)Tp * B * 4 * D, dg_blk, 4 * n16, dstate, (long)Tp * B * 2 * D, st));
+    RC(comic_persist_prepare(dq_sum, n16, nullptr, 0, nullptr, 0, st));
   }
   // dy_all = dlogits * W_o^T ; dW_o, db_o
   RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
@@ -782,7 +789,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pb.keep_in = d->keep_in; pb.keep_out = d->keep_out; pb.keep_alpha = d->keep_alpha;
     pb.q_all = q_all; pb.alpha_all = alpha_all; pb.gates_all = gates_all; pb.cs = cs; pb.cnew_all = cnew_all;
     pb.dy_all = dy_all; pb.dmap = use_map ? dmap : nullptr;
-    pb.dq_part = dq_part; pb.dg_all = dg_all; pb.dstate = dstate;
+    pb.dq_part = dq_part; pb.dq_sum = dq_sum; pb.dg_blk = dg_blk; pb.dg_all = dg_all; pb.dstate = dstate;
     pb.dq_all = dq_all; pb.dc = dc; pb.dh = dh; pb.dkeys = dkeys; pb.pgrad = pgrad4; pb.sync = persist_sync;
     pb.B = B; pb.E = E; pb.M = M; pb.H = H; pb.Tp = Tp; pb.method = d->method;
     RC(comic_persist_bwd_launch(pb, st));

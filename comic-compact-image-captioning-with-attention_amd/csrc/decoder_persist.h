@@ -66,21 +66,25 @@ struct ComicPersistBwdArgs {
   const float* dy_all;    // [Tp][B][D]  d cell output from the logits path
   const float* dmap;      // [Tp][B][M] map-loss term of d alpha_d, or null
   // hand-off buffers, sentinel-filled by the caller
-  float* dq_part;         // [Tp][B][4][D]
-  float* dg_all;          // [Tp][B][4D]   (also the operand of the d K / d b reductions after the loop)
+  float* dq_part;         // [Tp][B][4][D]   the four partials of d q_t
+  float* dq_sum;          // [Tp][groups][32][16][16]      blocked (see decoder_persist_bwd.hip), groups = ceil(B / 16)
+  float* dg_blk;          // [Tp][groups][128][16][16]     blocked
   float* dstate;          // [Tp][B][2D]   d att | d h of the step's operand row
   // outputs
   float* dq_all;          // [Tp][B][D]
+  float* dg_all;          // [Tp][B][4D]   row-major (operand of the d K / d b / d emb reductions after the loop)
   float* dc;              // [B][D] gradient of the initial cell state
   float* dh;              // [B][D]
   float* dkeys;           // [B][M][D]
   float* pgrad;           // [4B][3D+1] rows of [d v | d ln_g | d ln_b | d tau]
   unsigned* sync;         // the error word (cleared by the forward launch of the same step)
+  unsigned long long* stamps;   // diagnostic phase clock of workgroup 0 (null = off)
   int B, E, M, H, Tp;
   int method;
 };
 
 bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,
                                  int context_layer, int tied);
+unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st);
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a, hipStream_t st);
 int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st);

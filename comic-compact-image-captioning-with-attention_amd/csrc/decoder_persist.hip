@@ -465,36 +465,45 @@ bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int C
   return lds_bytes(M, tied, false) <= kLdsMax;
 }
 
-// COMIC_PERSIST_STAMPS=1: print the previous launch's mean phase times (a host synchronisation per launch: diagnostic)
-static unsigned long long* stamps_buffer(int Tp, hipStream_t st) {
+// COMIC_PERSIST_STAMPS=1: print the previous launch's mean phase times (a host synchronisation per launch: diagnostic).
+// which = 0 forward loop, 1 backward loop; workgroup 0 stores eight 100 MHz clock values per step.
+unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st) {
   static int on = -1;
-  static unsigned long long* dev = nullptr;
-  static int prev_tp = 0;
+  static unsigned long long* dev[2] = {nullptr, nullptr};
+  static int prev_tp[2] = {0, 0};
+  static const char* names[2][8] = {
+      {"att-wait+L", "L-epi", "y-wait+Q", "L-xh+q-wait", "scores", "prob", "ctx", "(masks)"},
+      {"A'", "dq-sum", "dq-gather+dyq", "cell", "dg-stores", "sync", "dg-wait+I", "I-epi"}};
   if (on < 0) {
     const char* e = getenv("COMIC_PERSIST_STAMPS");
     on = (e && e[0] == '1') ? 1 : 0;
   }
   if (!on) return nullptr;
-  if (!dev && hipMalloc((void**)&dev, 8 * 8 * 256) != hipSuccess) return nullptr;
-  if (prev_tp > 0 && hipStreamSynchronize(st) == hipSuccess) {
+  if (!dev[which] && hipMalloc((void**)&dev[which], 8 * 8 * 256) != hipSuccess) return nullptr;
+  const int n = prev_tp[which];
+  if (n > 1 && hipStreamSynchronize(st) == hipSuccess) {
     unsigned long long h[8 * 256];
-    if (hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+    if (hipMemcpy(h, dev[which], sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      // steps are stored at index t; the backward loop runs t downwards, so "next step" is t - 1 there
       double sum[8] = {0};
-      for (int t = 0; t + 1 < prev_tp; ++t)
-        for (int i = 0; i < 8; ++i) sum[i] += (double)(h[i < 7 ? t * 8 + i + 1 : (t + 1) * 8] - h[t * 8 + i]);
-      fprintf(stderr, "[persist stamps] per step (us): att-wait+L %.2f  L-epi %.2f  y-wait+Q %.2f  L-xh+q-wait %.2f  scores %.2f  prob %.2f  ctx %.2f  (masks) %.2f | step %.2f\n",
-              sum[0] / (prev_tp - 1) / 100, sum[1] / (prev_tp - 1) / 100, sum[2] / (prev_tp - 1) / 100,
-              sum[3] / (prev_tp - 1) / 100, sum[4] / (prev_tp - 1) / 100, sum[5] / (prev_tp - 1) / 100,
-              sum[6] / (prev_tp - 1) / 100, sum[7] / (prev_tp - 1) / 100, (double)(h[(prev_tp - 1) * 8] - h[0]) / (prev_tp - 1) / 100);
+      const int dir = which == 0 ? 1 : -1, first = which == 0 ? 0 : n - 1;
+      for (int s = 0; s + 1 < n; ++s) {
+        const int t = first + dir * s;
+        for (int i = 0; i < 8; ++i) sum[i] += (double)(h[i < 7 ? t * 8 + i + 1 : (t + dir) * 8] - h[t * 8 + i]);
+      }
+      fprintf(stderr, "[persist stamps %s] per step (us):", which == 0 ? "fwd" : "bwd");
+      for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.2f", names[which][i], sum[i] / (n - 1) / 100);
+      const int last = first + dir * (n - 1);
+      fprintf(stderr, " | step %.2f\n", (double)(h[last * 8] - h[first * 8]) / (n - 1) / 100);
     }
   }
-  prev_tp = Tp < 256 ? Tp : 0;
-  return prev_tp ? dev : nullptr;
+  prev_tp[which] = Tp < 256 ? Tp : 0;
+  return prev_tp[which] ? dev[which] : nullptr;
 }
 
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   ComicPersistFwdArgs a = a_in;
-  a.stamps = stamps_buffer(a.Tp, st);
+  a.stamps = comic_persist_stamps(0, a.Tp, st);
   const bool wq_lds = lds_bytes(a.M, a.tied, true) <= kLdsMax;
   int64_t lds = lds_bytes(a.M, a.tied, wq_lds);
   if (lds < kLdsMin) lds = kLdsMin;

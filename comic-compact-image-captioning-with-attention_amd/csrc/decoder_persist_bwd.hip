@@ -46,6 +46,10 @@ __global__ void dropout_rows_kernel(float* __restrict__ x, const float* __restri
   x[i] = (x[i] / keep) * mask[r * ld + c];
 }
 
+__device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
+  if (st && blockIdx.x == 0 && threadIdx.x == 0) st[t * 8 + i] = __builtin_amdgcn_s_memrealtime();
+}
+
 __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicPersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = kD, EPL = 8;
@@ -58,16 +62,24 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
 
   // ---- LDS carve-up ---------------------------------------------------------------------------------------------
   float* keys_l = (float*)smem;                                // [M][D]   keys (= values) of the attention row
-  float* wq_l = keys_l + M * D;                                // [8][32 parts x 20]  W_q rows of this workgroup's units
-  float4* red_i = (float4*)(wq_l + 8 * 640);                   // [8 waves][64]       I phase cross-wave combine
+  float* wq_l = keys_l + M * D;                                // [32 k16-blocks][8 units][4][4]  W_q rows of its units
+  float4* red_i = (float4*)(wq_l + 8 * D);                     // [8 waves][64]  cross-wave combine of the G and I products
   float* red_q = (float*)(red_i + kWaves * 64);                // [8 waves][D]        d q combine (A')
   float* ss = red_q + kWaves * D;                              // [H][32] scaled scores of own rows
   float* sd = ss + 16 * 32;                                    // [H][32] d alpha_d, then d raw
   float* sa = sd + 16 * 32;                                    // [H][32] alpha_d
   float* lnp_l = sa + 16 * 32;                                 // [3][D]  ln gamma | ln beta | v (read in A' only)
+  float* pacc = lnp_l + 3 * D;                                 // [3][8 waves][D]  d v | d ln_g | d ln_b accumulators of the waves
 
-  const __amdgpu_buffer_rsrc_t dqp_r = make_rsrc(a.dq_part, (long)Tp * B * 4 * D * 4);
-  const __amdgpu_buffer_rsrc_t dg_r = make_rsrc(a.dg_all, (long)Tp * B * N4 * 4);
+  // hand-off buffers in BLOCKED layouts: a k16-block of the 16 rows of a group is one contiguous KiB (16 rows x 64
+  // bytes), which is exactly what one MFMA-operand load of a wave reads: whole 128-byte lines instead of 16 half lines
+  //   dq_sum [t][group][k16-block 32][row 16][16]     dg_blk [t][group][k16-block 128][row 16][16]
+  const int G = gridDim.x / kGroupWgs;
+  const __amdgpu_buffer_rsrc_t dqp_r = make_rsrc(a.dq_part, (long)Tp * B * 4 * D * 4);     // [t][row][partial 4][D]
+  const __amdgpu_buffer_rsrc_t dqs_r = make_rsrc(a.dq_sum, (long)Tp * G * 16 * D * 4);
+  const __amdgpu_buffer_rsrc_t dg_r = make_rsrc(a.dg_blk, (long)Tp * G * 16 * N4 * 4);
+  const int rows_here = min(kGroupRows, B - row0);              // rows of this group that exist
+  const int r16c = min(lane & 15, rows_here - 1);               // MFMA-operand row of this lane (clamped: unused rows)
   const __amdgpu_buffer_rsrc_t ds_r = make_rsrc(a.dstate, (long)Tp * B * 2 * D * 4);
 
   // ---- A' identity: batch row, owned memory rows ---------------------------------------------------------------------
@@ -82,9 +94,9 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
     const int arow = a_live ? ab : 0;
     const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
     for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
-    for (int i = tid; i < 8 * D; i += kThreads) {              // W_q row 8 wi + u, k: at u*640 + (k/16)*20 + k%16
+    for (int i = tid; i < 8 * D; i += kThreads) {              // W_q[8 wi + u][k] at ((k/16 * 8 + u) * 4 + (k%16)/4) * 4 + k%4
       const int u = i >> 9, k = i & (D - 1);
-      wq_l[u * 640 + (k >> 4) * 20 + (k & 15)] = a.W_q[(size_t)(8 * wi + u) * D + k];
+      wq_l[(((k >> 4) * 8 + u) * 4 + ((k & 15) >> 2)) * 4 + (k & 3)] = a.W_q[(size_t)(8 * wi + u) * D + k];
     }
     for (int i = tid; i < kWaves * D; i += kThreads) red_q[i] = 0.f;   // waves without a row never write theirs
     lnp_l[tid] = a.method == 0 ? a.ln_g[tid] : 0.f;
@@ -93,9 +105,13 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   }
   const float scale = a.method == 0 ? a.tau[0] : sqrtf((float)dh);
   const float inv_scale = 1.0f / scale;
-  float datt_state[EPL], dk_acc[EPL], dv_acc[EPL], dgm_acc[EPL], db_acc[EPL], dtau = 0.f;
+  float datt_state[EPL], dk_acc[EPL], dtau = 0.f;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = dv_acc[i] = dgm_acc[i] = db_acc[i] = 0.f;
+  for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = 0.f;
+  for (int i = tid; i < 3 * kWaves * D; i += kThreads) pacc[i] = 0.f;
+  float* pa_v = pacc + wave * D + k0;                          // this lane's slices
+  float* pa_g = pa_v + kWaves * D;
+  float* pa_b = pa_g + kWaves * D;
 
   // ---- G identity: thread (row rl, k part) ; epilogue element (row rl, unit 8 wi + part) for part < 8 ------------------
   const int g_rl = tid >> 5, g_part = tid & 31;
@@ -112,14 +128,14 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
 #pragma unroll
   for (int i = 0; i < NBI; ++i) {
     const int kb = 2 * (wave + kWaves * (i >> 1)) + (i & 1);
-    gb_off[i] = (unsigned)kb * 64u;
+    gb_off[i] = (unsigned)kb * 1024u;
     wreg[i] = *(const float4*)(a.K_panel_b + (((size_t)(E / 16 + wi) * KBI + kb) * 16 + r16) * 16 + 4 * kq);
   }
-  const int i_row = min(row0 + r16, B - 1);                    // operand row of this lane (clamped)
   __syncthreads();
 
   for (int t = Tp - 1; t >= 0; --t) {
     // ===================================================================== A': attention backward =====================
+    stamp(a.stamps, t, 0);
     if (a_live) {
       const float live = t < a_len ? 1.f : 0.f;
       // saved forward values and masks of this step (plain loads: written by earlier launches)
@@ -227,17 +243,23 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
       if (has_own) {
         const float draw = sd[head * 32 + m_own], adm = sa[head * 32 + m_own];
         if (a.method == 0) {
-          float dxh[EPL], s1 = 0.f, s2 = 0.f;
+          float dxh[EPL], s1 = 0.f, s2 = 0.f, av[EPL], ag[EPL], abb[EPL];
+          *(float4*)av = *(const float4*)pa_v; *(float4*)(av + 4) = *(const float4*)(pa_v + 4);
+          *(float4*)ag = *(const float4*)pa_g; *(float4*)(ag + 4) = *(const float4*)(pa_g + 4);
+          *(float4*)abb = *(const float4*)pa_b; *(float4*)(abb + 4) = *(const float4*)(pa_b + 4);
 #pragma unroll
           for (int i = 0; i < EPL; ++i) {
-            dv_acc[i] += draw * th[i];
+            av[i] += draw * th[i];
             const float dzh = draw * vv[i] * (1.f - th[i] * th[i]);
-            dgm_acc[i] += dzh * xh[i];
-            db_acc[i] += dzh;
+            ag[i] += dzh * xh[i];
+            abb[i] += dzh;
             dxh[i] = dzh * gv[i];
             s1 += dxh[i];
             s2 += dxh[i] * xh[i];
           }
+          *(float4*)pa_v = *(const float4*)av; *(float4*)(pa_v + 4) = *(const float4*)(av + 4);
+          *(float4*)pa_g = *(const float4*)ag; *(float4*)(pa_g + 4) = *(const float4*)(ag + 4);
+          *(float4*)pa_b = *(const float4*)abb; *(float4*)(pa_b + 4) = *(const float4*)(abb + 4);
           const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
           for (int i = 0; i < EPL; ++i) {
@@ -267,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
       }
       __syncthreads();   // polls of the next phase start after this workgroup's own stores are on their way
     }
+    stamp(a.stamps, t, 1);
     // ===================================================================== G: query layer + LSTM cell backward =========
     {
       // saved forward values of the epilogue element (plain loads)
@@ -281,61 +304,71 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         if (a.mask_out) e_mk = a.mask_out[e];
       }
       const int row = min(g_row, B - 1);
-      const unsigned qo = (unsigned)(((((size_t)t * B + row) * 4) * D + 16 * g_part) * 4);
-      const unsigned off4[4] = {0u, 16u, 32u, 48u};
-      float4 pj[4][4];                                          // the four partials of this thread's 16 k
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pj[j][i] = load16_sc1(dqp_r, qo + (unsigned)j * D * 4u + off4[i]);
+      // d h of step t+1's operand (h third), issued ahead of the d q gather: written one phase ago
+      const unsigned hso = (unsigned)((((size_t)(t + 1) * B + row) * 2 * D + D + 8 * wi) * 4);
+      const unsigned off2[2] = {0u, 16u};
+      float4 hv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+      if (t + 1 < Tp && g_part < 8) {
+        hv[0] = load16_sc1(ds_r, hso);
+        hv[1] = load16_sc1(ds_r, hso + 16);
+      }
+      // G1: this workgroup sums the four partials of ITS eight columns [8 wi, 8 wi + 8) of d q_t for the 16 rows (2 KB
+      // gathered) and publishes them: the summed d q (operand of the d W_q GEMM after the loop, row-major) and the
+      // blocked copy every workgroup of the group then gathers (32 KB instead of the 128 KB of all partials).
+      if (wave < 2) {
+        const int r = tid >> 3, hf = (tid >> 2) & 1, j = tid & 3;   // row, half of the eight columns, partial
+        const int rr = min(row0 + r, B - 1);
+        const unsigned po = (unsigned)(((((size_t)t * B + rr) * 4 + j) * D + 8 * wi + 4 * hf) * 4);
+        const unsigned z1[1] = {0u};
+        float4 pv[1] = {load16_sc1(dqp_r, po)};
+        wait_written<1>(pv, dqp_r, po, z1, 1u, wt);
+        float4 sm = pv[0];                                      // (p0 + p1) + (p2 + p3): fixed order
+        sm.x += dpp_move<0xB1>(0.f, sm.x); sm.y += dpp_move<0xB1>(0.f, sm.y);
+        sm.z += dpp_move<0xB1>(0.f, sm.z); sm.w += dpp_move<0xB1>(0.f, sm.w);
+        sm.x += dpp_move<0x4E>(0.f, sm.x); sm.y += dpp_move<0x4E>(0.f, sm.y);
+        sm.z += dpp_move<0x4E>(0.f, sm.z); sm.w += dpp_move<0x4E>(0.f, sm.w);
+        if (j == 0 && row0 + r < B) {
+          const int k = 8 * wi + 4 * hf;
+          store16_sc1(dqs_r, (unsigned)((((((size_t)t * G + grp) * 32 + (k >> 4)) * 16 + r) * 16 + (k & 15)) * 4), sm);
+          *(float4*)(a.dq_all + ((size_t)t * B + row0 + r) * D + k) = sm;
+        }
+      }
+      __syncthreads();   // the gather below starts after this workgroup's own stores are on their way
+      stamp(a.stamps, t, 2);
+      // G2: d y_q = d q * W_q^T as an fp32 MFMA: lane (row r16, kq) of wave w loads k16-blocks 4 w .. 4 w + 3
+      const unsigned qo = (unsigned)((((((size_t)t * G + grp) * 32 + 4 * wave) * 16 + r16c) * 16 + 4 * kq) * 4);
+      const unsigned off4[4] = {0u, 1024u, 2048u, 3072u};
       float4 dq4[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dq4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {                             // fixed order: deterministic
-        wait_written<4>(pj[j], dqp_r, qo + (unsigned)j * D * 4u, off4, 15u, wt);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          dq4[i].x += pj[j][i].x; dq4[i].y += pj[j][i].y; dq4[i].z += pj[j][i].z; dq4[i].w += pj[j][i].w;
-        }
-      }
-      // the summed d q_t (operand of the d W_q GEMM after the loop): this workgroup writes columns [8 wi, 8 wi + 8)
-      if (g_part == (wi >> 1) && g_row < B) {
-        float* dst = a.dq_all + ((size_t)t * B + g_row) * D + 8 * wi;
-        if (wi & 1) {
-          *(float4*)dst = dq4[2];
-          *(float4*)(dst + 4) = dq4[3];
-        } else {
-          *(float4*)dst = dq4[0];
-          *(float4*)(dst + 4) = dq4[1];
-        }
-      }
-      float p8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float* wr = wq_l + u * 640 + g_part * 20;
-        float acc = 0.f;
+      for (int i = 0; i < 4; ++i) dq4[i] = load16_sc1(dqs_r, qo + off4[i]);
+      wait_written<4>(dq4, dqs_r, qo, off4, 15u, wt);
+      {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float4 w4 = *(const float4*)(wr + 4 * i);
-          acc = fmaf(dq4[i].x, w4.x, acc); acc = fmaf(dq4[i].y, w4.y, acc);
-          acc = fmaf(dq4[i].z, w4.z, acc); acc = fmaf(dq4[i].w, w4.w, acc);
+          const float4 w4 = r16 < 8 ? *(const float4*)(wq_l + (((4 * wave + i) * 8 + r16) * 4 + kq) * 4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dq4[i].x, w4.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dq4[i].y, w4.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dq4[i].z, w4.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dq4[i].w, w4.w, acc, 0, 0, 0);
         }
-        acc = group_sum_dpp(acc, 16);
-        p8[u] = acc + __shfl_xor(acc, 16, 64);
+        red_i[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);   // D[row 4 kq + i][unit r16]
       }
-      float dyq = p8[0];
+      __syncthreads();
+      float dyq = 0.f;
+      if (g_part < 8) {
+        const float* rp = (const float*)red_i + (g_part + 16 * (g_rl >> 2)) * 4 + (g_rl & 3);
 #pragma unroll
-      for (int u = 1; u < 8; ++u) dyq = g_part == u ? p8[u] : dyq;
-      // d h of step t+1's operand (h third), then the cell backward of (row, unit)
+        for (int w = 0; w < kWaves; ++w) dyq += rp[w * 256];    // fixed order: deterministic
+      }
+      stamp(a.stamps, t, 3);
+      // the cell backward of (row, unit)
       float dgv[4] = {0.f, 0.f, 0.f, 0.f};
       if (g_part < 8) {
         float vh = 0.f;
         if (t + 1 < Tp) {
-          const unsigned so = (unsigned)((((size_t)(t + 1) * B + row) * 2 * D + D + 8 * wi) * 4);
-          const unsigned off2[2] = {0u, 16u};
-          float4 hv[2] = {load16_sc1(ds_r, so), load16_sc1(ds_r, so + 16)};
-          wait_written<2>(hv, ds_r, so, off2, 3u, wt);
+          wait_written<2>(hv, ds_r, hso, off2, 3u, wt);
           const float h8[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
           vh = h8[0];
 #pragma unroll
@@ -359,15 +392,22 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         g_dc = g_dc * (1.f - live) + dc2 * sf;
         g_dhk = dh_in * (1.f - live);
       }
+      stamp(a.stamps, t, 4);
       // d gates: lanes part = 0..7 of a row hold 8 consecutive units of each gate: two 16-byte stores per gate
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float x1 = __shfl_down(dgv[g], 1, 64), x2 = __shfl_down(dgv[g], 2, 64), x3 = __shfl_down(dgv[g], 3, 64);
-        if ((g_part == 0 || g_part == 4) && g_row < B)
-          store16_sc1(dg_r, (unsigned)((((size_t)t * B + g_row) * N4 + g * D + g_d) * 4), make_float4(dgv[g], x1, x2, x3));
+        if ((g_part == 0 || g_part == 4) && g_row < B) {
+          const float4 v4 = make_float4(dgv[g], x1, x2, x3);
+          const int k = g * D + g_d;
+          store16_sc1(dg_r, (unsigned)((((((size_t)t * G + grp) * 128 + (k >> 4)) * 16 + g_rl) * 16 + (k & 15)) * 4), v4);
+          *(float4*)(a.dg_all + ((size_t)t * B + g_row) * N4 + k) = v4;   // row-major copy for the GEMMs after the loop
+        }
       }
+      stamp(a.stamps, t, 5);
       __syncthreads();
     }
+    stamp(a.stamps, t, 6);
     // ===================================================================== I: d gates * K^T (att and h thirds) ==========
     {
       float mk4[4] = {1.f, 1.f, 1.f, 1.f};
@@ -379,16 +419,26 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           if (b < B) mk4[i] = a.mask_in[((size_t)t * B + b) * EA + E + c];
         }
       }
-      const unsigned go = (unsigned)((((size_t)t * B + i_row) * N4 + 4 * kq) * 4);
+      const unsigned go = (unsigned)((((((size_t)t * G + grp) * 128) * 16 + r16c) * 16 + 4 * kq) * 4);
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      // the first four blocks come first (see the d q gather above), then the other twelve in one go
       float4 ga[NBI];
 #pragma unroll
-      for (int i = 0; i < NBI; ++i) ga[i] = load16_sc1(dg_r, go + gb_off[i]);
+      for (int i = 0; i < 4; ++i) ga[i] = load16_sc1(dg_r, go + gb_off[i]);
+      {
+        float4 x4[4] = {ga[0], ga[1], ga[2], ga[3]};
+        const unsigned o4[4] = {gb_off[0], gb_off[1], gb_off[2], gb_off[3]};
+        wait_written<4>(x4, dg_r, go, o4, 15u, wt);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ga[i] = x4[i];
+      }
+#pragma unroll
+      for (int i = 4; i < NBI; ++i) ga[i] = load16_sc1(dg_r, go + gb_off[i]);
 #pragma unroll
       for (int c4 = 0; c4 < NBI; c4 += 4) {                     // validate and multiply four blocks at a time
         float4 x4[4] = {ga[c4], ga[c4 + 1], ga[c4 + 2], ga[c4 + 3]};
         const unsigned o4[4] = {gb_off[c4], gb_off[c4 + 1], gb_off[c4 + 2], gb_off[c4 + 3]};
-        wait_written<4>(x4, dg_r, go, o4, 15u, wt);
+        if (c4 > 0) wait_written<4>(x4, dg_r, go, o4, 15u, wt);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[i].x, wreg[c4 + i].x, acc, 0, 0, 0);
@@ -399,6 +449,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
       }
       red_i[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
       __syncthreads();
+      stamp(a.stamps, t, 7);
       if (wave == 0) {
         float g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -445,19 +496,13 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
     }
     // parameter-gradient row of this workgroup: [d v | d ln_g | d ln_b | d tau], summed over its waves in fixed order
     float* pg = a.pgrad + ((size_t)ab * 4 + aq) * (3 * D + 1);
-    auto reduce_store = [&](const float (&accv)[EPL], float* dst) {
-      __syncthreads();
-      *(float4*)(red_q + wave * D + k0) = make_float4(accv[0], accv[1], accv[2], accv[3]);
-      *(float4*)(red_q + wave * D + k0 + 4) = make_float4(accv[4], accv[5], accv[6], accv[7]);
-      __syncthreads();
-      float s = 0.f;
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) {
+      float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) s += red_q[w * D + tid];
-      dst[tid] = s;
-    };
-    reduce_store(dv_acc, pg);
-    reduce_store(dgm_acc, pg + D);
-    reduce_store(db_acc, pg + 2 * D);
+      for (int w = 0; w < kWaves; ++w) sum += pacc[(k * kWaves + w) * D + tid];   // fixed order: deterministic
+      pg[k * D + tid] = sum;
+    }
     __syncthreads();
     const float dt = wave_sum(dtau);
     if (lane == 0) red_q[wave] = dt;
@@ -471,7 +516,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
 }
 
 int64_t bwd_lds_bytes(int M) {
-  return (int64_t)M * kD * 4 + 8 * 640 * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4;
+  return (int64_t)M * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4 + 3 * kWaves * kD * 4;
 }
 
 }  // namespace
@@ -491,7 +536,9 @@ int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int c
   return 0;
 }
 
-int comic_persist_bwd_launch(const ComicPersistBwdArgs& a, hipStream_t st) {
+int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
+  ComicPersistBwdArgs a = a_in;
+  a.stamps = comic_persist_stamps(1, a.Tp, st);
   int64_t lds = bwd_lds_bytes(a.M);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
   static bool attr_set = false;
