@@ -393,54 +393,68 @@ def main():
     # the timed region issues ~500 launches per step from Python: a generation-2 garbage collection in the middle
     # of it stalls the host for tens of milliseconds (measured: one 45 ms stall = +1.3 ms per step at 30 steps)
     import gc
+    main_prio = int(os.environ.get('COMIC_MAIN_PRIORITY', '0'))
+    main_stream = torch.cuda.Stream(device=device, priority=main_prio) if (overlap and main_prio != 0) else None
     gc.collect()
     gc.disable()
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        cap = cap_sets[i % 4]
-        if overlap and GROUP > 1:
-            # steps are served from groups of GROUP batches: the forward of the NEXT group (GROUP*BATCH images) is
-            # issued on the side stream once the first step of this group holds its rows; K timed steps issue
-            # ceil(K/GROUP) forwards = at least K*BATCH images
-            im_embed, fm, release = tr.take_features()
+    def run_steps():
+        res = None
+        for i in range(args.steps):
+            cap = cap_sets[i % 4]
+            if overlap and GROUP > 1:
+                # steps are served from groups of GROUP batches: the forward of the NEXT group (GROUP*BATCH images) is
+                # issued on the side stream once the first step of this group holds its rows; K timed steps issue
+                # ceil(K/GROUP) forwards = at least K*BATCH images
+                im_embed, fm, release = tr.take_features()
 
-            def consumed():
-                if release():
-                    submit(ev[n_fwd[0]] if EVENTS else None)
-                    n_fwd[0] += 1
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
-                                        on_inputs_consumed=consumed)
-        elif overlap:
-            n_fwd[0] += 1
-            # step i: decoder(batch i) on the main stream; the encoder forward of batch i+1 is issued on the
-            # side stream as soon as the decoder holds its copy of batch i's features.  K timed steps issue
-            # K encoder forwards and K decoder steps; HIP events on the side stream bracket the encoder.
-            def consumed(i=i):
-                tr._ev_used.record(torch.cuda.current_stream())
-                tr._side.wait_event(tr._ev_used)
-                with torch.cuda.stream(tr._side):
-                    if EVENTS: ev[i][0].record(tr._side)
-                    tr._pending = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
-                    if EVENTS: ev[i][1].record(tr._side)
-                    tr._ev_cnn.record(tr._side)
-            torch.cuda.current_stream().wait_event(tr._ev_cnn)
-            im_embed, fm = tr._pending
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
-                                        on_inputs_consumed=consumed)
-        else:
-            j = i % GROUP
-            if j == 0:                      # serial: the forward of this group of steps, then its decoder steps
-                if EVENTS: ev[n_fwd[0]][0].record()
-                feats = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
-                if EVENTS: ev[n_fwd[0]][1].record()
+                def consumed():
+                    if release():
+                        submit(ev[n_fwd[0]] if EVENTS else None)
+                        n_fwd[0] += 1
+                res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
+                                            on_inputs_consumed=consumed)
+            elif overlap:
                 n_fwd[0] += 1
-            im_embed, fm = feats[0][j * BATCH:(j + 1) * BATCH], feats[1][j * BATCH:(j + 1) * BATCH]
-            res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC)
-        scale = dp.average_(tr.decoder.grads.data)
-        tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
-        if STEP_TIMES is not None:
-            e = torch.cuda.Event(enable_timing=True); e.record(); STEP_TIMES.append((e, time.perf_counter()))
+                # step i: decoder(batch i) on the main stream; the encoder forward of batch i+1 is issued on the
+                # side stream as soon as the decoder holds its copy of batch i's features.  K timed steps issue
+                # K encoder forwards and K decoder steps; HIP events on the side stream bracket the encoder.
+                def consumed(i=i):
+                    tr._ev_used.record(torch.cuda.current_stream())
+                    tr._side.wait_event(tr._ev_used)
+                    with torch.cuda.stream(tr._side):
+                        if EVENTS: ev[i][0].record(tr._side)
+                        tr._pending = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
+                        if EVENTS: ev[i][1].record(tr._side)
+                        tr._ev_cnn.record(tr._side)
+                torch.cuda.current_stream().wait_event(tr._ev_cnn)
+                im_embed, fm = tr._pending
+                res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
+                                            on_inputs_consumed=consumed)
+            else:
+                j = i % GROUP
+                if j == 0:                      # serial: the forward of this group of steps, then its decoder steps
+                    if EVENTS: ev[n_fwd[0]][0].record()
+                    feats = tr.encoder.forward(next_images(), use_graph=GRAPH_CNN)
+                    if EVENTS: ev[n_fwd[0]][1].record()
+                    n_fwd[0] += 1
+                im_embed, fm = feats[0][j * BATCH:(j + 1) * BATCH], feats[1][j * BATCH:(j + 1) * BATCH]
+                res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC)
+            scale = dp.average_(tr.decoder.grads.data)
+            tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
+            if STEP_TIMES is not None:
+                e = torch.cuda.Event(enable_timing=True); e.record(); STEP_TIMES.append((e, time.perf_counter()))
+        return res
+    # COMIC_MAIN_PRIORITY=-1 puts the decoder's launches on a high-priority stream above the encoder's side stream
+    # (measured SLOWER, 2.04 vs 1.89 ms per step: the workgroups of the persistent loops then grab CUs one by one
+    # and spin until the encoder's kernel has drained from all of them); default 0 = the same priority
+    if main_stream is not None:
+        main_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main_stream):
+            res = run_steps()
+    else:
+        res = run_steps()
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()

@@ -81,6 +81,13 @@ class DataParallel:
         return 1.0 / self.world
 
 
+def side_stream(torch, device):
+    """The stream the frozen encoder's forward runs on beside the decoder.  Priorities on this runtime are 0 (default,
+    lowest) and -1; raising either stream above the other measured slower (COMIC_SIDE_PRIORITY to experiment)."""
+    import os
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get('COMIC_SIDE_PRIORITY', '0')))
+
+
 class EncoderPipeline:
     """Frozen-CNN pipelining: ONE encoder forward covers the image batches of the next `group` training steps
     (batch group*B) and runs on a second stream under the decoder steps of the current group; its outputs go to one
@@ -92,7 +99,7 @@ class EncoderPipeline:
         self._torch = torch
         self.encoder, self.batch, self.group, self.use_graph = encoder, int(batch), int(group), use_graph
         assert self.group >= 1 and encoder.batch == self.batch * self.group
-        self.side = torch.cuda.Stream(device=device)
+        self.side = side_stream(torch, device)
         self._ev_ready = torch.cuda.Event()
         self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
@@ -169,7 +176,7 @@ class CaptionTrainer:
         # does not depend on this step's update and runs on a second stream under the decoder
         import torch
         self._torch = torch
-        self._side = torch.cuda.Stream(device=device)
+        self._side = side_stream(torch, device)
         self._ev_cnn = torch.cuda.Event()
         self._ev_used = torch.cuda.Event()
         self._pending = None
