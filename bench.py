@@ -414,7 +414,7 @@ def main():
                         submit(ev[n_fwd[0]] if EVENTS else None)
                         n_fwd[0] += 1
                 res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC,
-                                            on_inputs_consumed=consumed)
+                                            on_inputs_consumed=consumed, copy_inputs=False)
             elif overlap:
                 n_fwd[0] += 1
                 # step i: decoder(batch i) on the main stream; the encoder forward of batch i+1 is issued on the

@@ -159,6 +159,34 @@ __global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_
   xh[(size_t)r * Wd + e] = v;
 }
 
+// The operand rows before the time loop, one launch: x parts of EVERY step (embedding lookup + input dropout, ids read
+// from the batch-major table and also written time-major for the embedding backward), and step 0's att part (zero;
+// att_all[0] too) and h part (h0).
+__global__ void embed_step0_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids_bt,
+                                   int32_t* __restrict__ ids_tb, const float* __restrict__ mask, float keep,
+                                   float* __restrict__ xh, float* __restrict__ att0, const float* __restrict__ h0, int Tp,
+                                   int B, int T, int E, int A, int D, int V) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_x = (long)Tp * B * E;
+  const int EA = E + A, Wd = E + A + D;
+  if (i < n_x) {
+    const long r = i / E;
+    const int e = (int)(i % E), t = (int)(r / B), b = (int)(r % B);
+    const int id = ids_bt[(size_t)b * T + t];
+    if (e == 0) ids_tb[r] = id;
+    float v = (id >= 0 && id < V) ? table[(size_t)id * E + e] : 0.f;
+    if (mask) v = (v / keep) * mask[(size_t)r * EA + e];
+    xh[(size_t)r * Wd + e] = v;
+  } else if (i < n_x + (long)B * A) {
+    const long j = i - n_x;
+    att0[j] = 0.f;
+    xh[(size_t)(j / A) * Wd + E + (j % A)] = 0.f;
+  } else if (i < n_x + (long)B * A + (long)B * D) {
+    const long j = i - n_x - (long)B * A;
+    xh[(size_t)(j / D) * Wd + EA + (j % D)] = h0[j];
+  }
+}
+
 // inference step operand: xh[r] = [ emb[ids[r]] ; att[src(r)] ; h[src(r)] ], c_in[r] = c[src(r)] with
 // src(r) = the beam-search parent of row r in the previous step (identity for greedy / step 0): the
 // embedding lookup, the three state gathers and the concat of one step in a single pass.
@@ -652,31 +680,39 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const float* values = nullptr;
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, Wd);
   const bool fused_q = fused && D % 16 == 0;
-  if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, kpanel_b, D, Wd, st));
-  if (fused_q) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
+  // the time loops as persistent launches (decoder_persist.hip, decoder_persist_bwd.hip) when the shape allows it
+  const bool persist = fused && persist_enabled() &&
+                       comic_persist_fwd_supported(B, D, E, A, M, H, Cv, d->method, d->context_layer, ad.tied);
+  const bool persist_b = persist && persist_bwd_enabled() &&
+                         comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
+  // weight panels of the fused step kernels; the persistent backward reads K and W_q in place
+  if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
+  if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
+  if (persist) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
+    ComicPersistRanges pr{};
+    const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
+    pr.p[0] = xh_all; pr.n[0] = (long)Tp * B * Wd;
+    pr.p[1] = y_all; pr.n[1] = (long)Tp * B * D;
+    pr.p[2] = q_all; pr.n[2] = (long)Tp * B * D;
+    if (persist_b) {
+      pr.p[3] = dq_part; pr.n[3] = (long)Tp * B * 4 * D;
+      pr.p[4] = dg_blk; pr.n[4] = 4 * n16;
+      pr.p[5] = dstate; pr.n[5] = (long)Tp * B * 2 * D;
+      pr.p[6] = dq_sum; pr.n[6] = n16;
+    }
+    RC(comic_persist_prepare(pr, persist_sync, st));
+  }
   // ------------------------------------------------------------------ forward ------------
   RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
   RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, st));
-  RC(fill(att_all, 0.f, (long)B * A, st));
-  // the whole time loop as one persistent launch (decoder_persist.hip) when the shape allows it
-  const bool persist = fused && persist_enabled() &&
-                       comic_persist_fwd_supported(B, D, E, A, M, H, Cv, d->method, d->context_layer, ad.tied);
-  if (persist) RC(comic_persist_prepare(xh_all, (long)Tp * B * Wd, y_all, (long)Tp * B * D, q_all, (long)Tp * B * D, st));
-  hipLaunchKernelGGL(transpose_ids_kernel, dim3(cdiv(Tp * B, 256)), dim3(256), 0, st, inputs_bt, in_tb, B, T, Tp);
-  COMIC_LAUNCH_CHECK("transpose_ids");
-  // x part of every step's [x ; att ; h] operand row: embedding lookup + input dropout, hoisted
+  // operand rows before the loop: the x part of every step (embedding lookup + input dropout, hoisted) and step 0's
+  // att part (zero: dropout of 0 is 0) and h part (h0)
   {
-    const long n = (long)Tp * B * E;
-    hipLaunchKernelGGL(embed_to_xh_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, in_tb,
-                       drop_in ? mask_in : nullptr, d->keep_in, xh_all, (long)Tp * B, E, V, EA, Wd);
-    COMIC_LAUNCH_CHECK("embed_to_xh");
+    const long n = (long)Tp * B * E + (long)B * A + (long)B * D;
+    hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, inputs_bt, in_tb,
+                       drop_in ? mask_in : nullptr, d->keep_in, xh_all, att_all, hs, Tp, B, T, E, A, D, V);
+    COMIC_LAUNCH_CHECK("embed_step0");
   }
-  // step 0 operand: att = 0 (dropout of 0 is 0), h = h0
-  hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_all, att_all,
-                     (const int32_t*)nullptr, 0, att_all, xh_all + E, Wd, (const float*)nullptr, 0, 1.f, B, A);
-  hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, hs, hs, (const int32_t*)nullptr, 0,
-                     hs, xh_all + EA, Wd, (const float*)nullptr, 0, 1.f, B, D);
-  COMIC_LAUNCH_CHECK("step0 operand");
   if (persist) {
     ComicPersistFwdArgs pa{};
     pa.K_panel = kpanel_f; pa.bias = p->b; pa.W_q = p->W_q; pa.keys = keys; pa.values = values;
@@ -754,23 +790,16 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                        map_loss);
     COMIC_LAUNCH_CHECK("maploss");
   }
-  if (persist) RC(comic_persist_check(persist_sync, map_loss, st));
+  if (persist && !persist_b) RC(comic_persist_check(persist_sync, map_loss, st));
 
   // ------------------------------------------------------------------ backward -----------
   const bool use_map = d->map_loss_scale > 0.f;
   const bool sep_values = d->fm_projection != 2;
   float* dvalues = sep_values ? dvalues_buf : dkeys;
-  // the whole backward time loop as one persistent launch (decoder_persist_bwd.hip) when the forward one ran
-  const bool persist_b = persist && persist_bwd_enabled() &&
-                         comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
   if (!persist_b) {
     RC(fill(dkeys, 0.f, (long)B * M * D, st));
     if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
     RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));    // dc | dh | datt: consecutive workspace blocks
-  } else {
-    const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
-    RC(comic_persist_prepare(dq_part, (long)Tp * B * 4 * D, dg_blk, 4 * n16, dstate, (long)Tp * B * 2 * D, st));
-    RC(comic_persist_prepare(dq_sum, n16, nullptr, 0, nullptr, 0, st));
   }
   // dy_all = dlogits * W_o^T ; dW_o, db_o
   RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
@@ -782,7 +811,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const int attn_bwd_mode = (d->prob == 0 && split_attn_bwd_enabled()) ? 2 : 1;
   if (persist_b) {
     ComicPersistBwdArgs pb{};
-    pb.K_panel_b = kpanel_b; pb.W_q = p->W_q; pb.keys = keys;
+    pb.K = p->K; pb.W_q = p->W_q; pb.keys = keys;
     pb.ln_g = p->ln_g; pb.ln_b = p->ln_b; pb.v = p->v; pb.tau = p->tau; pb.lens = lens;
     pb.mask_in = drop_in ? mask_in : nullptr; pb.mask_out = drop_out ? mask_out : nullptr;
     pb.mask_alpha = drop_al ? mask_alpha : nullptr;

@@ -40,15 +40,20 @@ constexpr int kPersistSyncWords = 32;       // the error word on a 128-byte line
 
 bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
                                  int tied);
-// fills the hand-off buffers with the sentinel; call BEFORE the kernels that write the x parts and the step-0 row
-int comic_persist_prepare(float* xh_all, long xh_n, float* y_all, long y_n, float* q_all, long q_n, hipStream_t st);
+// fills the hand-off buffers (up to eight ranges of floats, sizes multiples of 4) with the sentinel and clears the
+// sync words; call BEFORE the kernels that write the x parts and the step-0 row
+struct ComicPersistRanges {
+  float* p[8];
+  long n[8];
+};
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st);
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
 // poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)
 int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st);
 
 // ---- backward loop (decoder_persist_bwd.hip) ---------------------------------------------------------------------------
 struct ComicPersistBwdArgs {
-  const float* K_panel_b; // backward panel of the LSTM kernel (comic_pack_lstm_panels, mode 1)
+  const float* K;         // [Wd][4D] LSTM kernel, row-major (rows E.. are read in place: a row is one operand feature)
   const float* W_q;       // [D][D]
   const float* keys;      // [B][M][D] (tied: also the values)
   const float *ln_g, *ln_b, *v, *tau;

@@ -418,12 +418,19 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   }
 }
 
-__global__ void sentinel_fill_kernel(uint4* p0, long n0, uint4* p1, long n1, uint4* p2, long n2) {
+__global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync) {
   const uint4 v = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n0) p0[i] = v;
-  else if (i < n0 + n1) p1[i - n0] = v;
-  else if (i < n0 + n1 + n2) p2[i - n0 - n1] = v;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < kPersistSyncWords) sync[i] = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long n4 = r.n[k] >> 2;
+    if (i < n4) {
+      ((uint4*)r.p[k])[i] = v;
+      return;
+    }
+    i -= n4;
+  }
 }
 
 __global__ void persist_check_kernel(const unsigned* err, float* loss) {
@@ -507,10 +514,6 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   const bool wq_lds = lds_bytes(a.M, a.tied, true) <= kLdsMax;
   int64_t lds = lds_bytes(a.M, a.tied, wq_lds);
   if (lds < kLdsMin) lds = kLdsMin;
-  if (hipMemsetAsync(a.sync, 0, kPersistSyncWords * sizeof(unsigned), st) != hipSuccess) {   // the error word
-    comic_set_error("persistent decoder: memset failed");
-    return 1;
-  }
   const int groups = (a.B + kGroupRows - 1) / kGroupRows;
   const int nx = (a.E / 16 + kWaves - 1) / kWaves;                // x blocks per wave
   int rc = 2;
@@ -521,11 +524,14 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   return rc;
 }
 
-int comic_persist_prepare(float* xh_all, long xh_n, float* y_all, long y_n, float* q_all, long q_n, hipStream_t st) {
-  COMIC_REQUIRE(xh_n % 4 == 0 && y_n % 4 == 0 && q_n % 4 == 0, "persistent decoder: buffer sizes must be multiples of 4");
-  const long n = (xh_n + y_n + q_n) / 4;
-  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (uint4*)xh_all, xh_n / 4,
-                     (uint4*)y_all, y_n / 4, (uint4*)q_all, q_n / 4);
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st) {
+  long n = 0;
+  for (int k = 0; k < 8; ++k) {
+    COMIC_REQUIRE(r.n[k] % 4 == 0 && (r.n[k] == 0 || r.p[k]), "persistent decoder: bad hand-off range %d", k);
+    n += r.n[k] / 4;
+  }
+  if (n < kPersistSyncWords) n = kPersistSyncWords;
+  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, r, sync);
   COMIC_LAUNCH_CHECK("persistent decoder prepare");
   return 0;
 }

@@ -19,7 +19,7 @@
 //      output-dropout and BasicLSTMCell backward; d c and the kept part of d h stay in registers
 //                                                          writes d gates_t (also the operand of the d K GEMM)
 //   I  operand features [16i, 16i+16) of the att and h thirds x 16 rows:  d gates_t * K^T (its 16 rows of K^T, 128 KB,
-//      in registers; exact fp32 MFMA), input dropout       writes d att / d h of step t (read by A' / G of step t-1)
+//      in registers, read in place; exact fp32 MFMA), input dropout       writes d att / d h of step t (read by A' / G of step t-1)
 // The x third of d gates * K^T (the embedding gradient) does not feed the recurrence: one GEMM after the loop.
 // What bounds a step: G and I each gather 128 KB per workgroup (3.6 us at the 70 GB/s a CU pulls, measured with
 // tools/micro/gather_bench.hip); A' is VALU-bound (about 2 us).
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   for (int i = 0; i < NBI; ++i) {
     const int kb = 2 * (wave + kWaves * (i >> 1)) + (i & 1);
     gb_off[i] = (unsigned)kb * 1024u;
-    wreg[i] = *(const float4*)(a.K_panel_b + (((size_t)(E / 16 + wi) * KBI + kb) * 16 + r16) * 16 + 4 * kq);
+    wreg[i] = *(const float4*)(a.K + (size_t)(E + 16 * wi + r16) * N4 + 16 * kb + 4 * kq);   // K[feature][k], in place
   }
   __syncthreads();
 

@@ -338,7 +338,7 @@ class Decoder:
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()
         L.check(self.lib.comic_decoder_train_step(
-            C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm.data_ptr(), ctx.im.data_ptr(),
+            C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm_in.data_ptr(), ctx.im_in.data_ptr(),
             i32.data_ptr(), i32.data_ptr() + 4 * BT, f32.data_ptr(), f32.data_ptr() + 4 * BT,
             i32.data_ptr() + 8 * BT, B, T, Tp,
             L.ptr(m.get('init_in')), L.ptr(m.get('inp')), L.ptr(m.get('out')), L.ptr(m.get('alpha')),
@@ -350,7 +350,8 @@ class Decoder:
                                                ctx.loss.data_ptr(), st), 'weighted_sum_tb')
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
-                   want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None, dp=None):
+                   want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None, dp=None,
+                   copy_inputs=True):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
@@ -360,6 +361,10 @@ class Decoder:
         dp: a trainer.DataParallel with world > 1 -> the same normaliser formed ON THE DEVICE: the token count of
         this rank's batch is summed from the staged mask, all-reduced on the stream, and the per-token coefficients
         the kernels read are rescaled in place -- no host synchronisation in the step.
+        copy_inputs=False: the step reads `fm` / `im_embed` in place instead of from its own copies (13 MB less
+        device-to-device traffic per step at batch 64).  The caller then keeps both tensors unchanged until the step has
+        EXECUTED (stream order: anything it enqueues on this stream afterwards is safe) and `on_inputs_consumed` is
+        called after the step's launches rather than before them.  Ignored with use_graph (a graph holds addresses).
         use_graph: replay the step from a hipGraph captured per (B, T, T') shape (the second call with
         a shape captures it) -- removes the ~450 host launches of a step from the critical path.
         Returns dict(loss, map_loss, logits [B,T,V], ids [B,T], attn_maps [B,H,T',M]) (device views
@@ -406,10 +411,15 @@ class Decoder:
         slot.copied.record(torch.cuda.current_stream())
         assert fm.shape == (B, s.M, s.C) and im_embed.shape == (B, s.Cg), (fm.shape, im_embed.shape)
         assert fm.dtype == torch.float32 and im_embed.dtype == torch.float32
-        ctx.fm.copy_(fm)
-        ctx.im.copy_(im_embed)
-        if on_inputs_consumed is not None:      # the encoder buffers may be overwritten from here on
-            on_inputs_consumed()
+        direct = (not copy_inputs and not use_graph and fm.is_contiguous() and im_embed.is_contiguous())
+        if direct:
+            ctx.fm_in, ctx.im_in = fm, im_embed
+        else:
+            ctx.fm.copy_(fm)
+            ctx.im.copy_(im_embed)
+            ctx.fm_in, ctx.im_in = ctx.fm, ctx.im
+            if on_inputs_consumed is not None:      # the encoder buffers may be overwritten from here on
+                on_inputs_consumed()
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -419,6 +429,8 @@ class Decoder:
             ctx.graph.replay()
         else:
             self._train_device(ctx)
+        if direct and on_inputs_consumed is not None:   # stream order: whatever the caller enqueues now runs after the step
+            on_inputs_consumed()
         ctx.calls += 1
         return dict(loss=ctx.loss[0], map_loss=ctx.map_loss[0], logits=ctx.logits.permute(1, 0, 2), ids=ctx.ids.t(),
                     attn_maps=ctx.hist.permute(1, 2, 0, 3), dfm=ctx.dfm, dim_embed=ctx.dim, Tp=Tp)

@@ -373,7 +373,8 @@ class CaptionModel(ModelBase):
         ft = self.cnn_trainable
         want_in = ft or self.head is not None
         res = self.decoder.train_step(fm, im_embed, cap, training=True, dp=self.dp, use_graph=not want_in,
-                                      want_input_grads=want_in, on_inputs_consumed=consumed)
+                                      want_input_grads=want_in, on_inputs_consumed=consumed,
+                                      copy_inputs=consumed is None)
         self._dec_reduced = False
         if ft:
             self._cnn_update(res, lr)
