@@ -521,7 +521,7 @@ def main():
             tj = json.load(open(tfile))
             if int(tj.get('images_per_forward', 64)) == ENC_BATCH:
                 out['roofline']['traffic'] = tj['per_forward']['conv_only_bytes_corrected']
-                out['roofline']['traffic_source'] = ('profiles/r01_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
+                out['roofline']['traffic_source'] = ('profiles/r02_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
                                                      'images, conv kernels)' % ENC_BATCH)
         if not args.no_extras and world == 1:
             try:

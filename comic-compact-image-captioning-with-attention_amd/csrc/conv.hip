@@ -1735,11 +1735,6 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       sa.sc1 = wa->scale; sa.sh1 = wa->shift; sa.sc2 = wb->scale; sa.sh2 = wb->shift;
       sa.y = (bf16_t*)buffers[op->dst]; sa.y_cs = yc; sa.y_co = op->dst_coff; sa.Hp = Hp; sa.Wp = Wp;
       sa.n_tasks = 2 * batch;
-      {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("COMIC_STEM_DBG"); dbg = e ? atoi(e) : 0; }
-        sa.dbg = dbg;
-      }
       if (int rc = comic_stem_stream_launch(sa, main_st)) return rc;
       COMIC_LAUNCH_CHECK("stem stream");
       continue;

@@ -12,7 +12,6 @@ struct ComicStemArgs {
   bf16_t* y;              // pooled output [B][Hp][Wp][y_cs], channels [y_co, y_co + 64)
   int y_cs, y_co, Hp, Wp;
   int n_tasks;            // 2 * B: (image, half of the pooled rows)
-  int dbg;                // timing experiments (COMIC_STEM_DBG): 1 no Y1 MFMAs, 2 no Y2 MFMAs, 4 no pooling epilogue, 8 no row loads
 };
 
 bool comic_stem_stream_supported(int H0, int W0);

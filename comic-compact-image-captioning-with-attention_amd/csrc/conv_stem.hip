@@ -135,14 +135,14 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
       STEM_BARRIER();                                // rows qa .. qa+2 are in the ring
       for (int t = 0; t < nsteps; ++t) {
         const int q = qa + t;
-        if (!(a.dbg & 8)) r2 = load_row(b, q + 5);
+        r2 = load_row(b, q + 5);
         // ---- Y1 row q (rows -1 and H1 are the zero padding of the SAME conv that follows) -------------------------
         if (q <= r_last + 1 && y1_work) {
           const bool real = q >= 0 && q < H1;
           f32x4_t acc[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (real && !(a.dbg & 1)) {
+          if (real) {
             bf16x8_t xf[4][4];
             auto frags = [&](int tap, bf16x8_t (&f)[4]) {
               const int kh = tap / 3, kw = tap % 3;
@@ -282,9 +282,7 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
           const float o2 = fmaxf(fmaf(o[2], sc2[i].z, sh2[i].z), 0.f), o3 = fmaxf(fmaf(o[3], sc2[i].w, sh2[i].w), 0.f);
           const int x = y2_start + j * kTileStep + fr;
           const int jc = x >> 1;
-          if (a.dbg & 16) {
-            asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3));
-          } else if ((fr & 1) == 0 && fr <= 12 && jc < a.Wp) {
+          if ((fr & 1) == 0 && fr <= 12 && jc < a.Wp) {
             bf16_t* yp = a.y + ((size_t)((b * a.Hp + prow) * a.Wp + jc)) * a.y_cs + a.y_co + (2 * p + i) * 16 + fg * 4;
             *(uint2*)yp = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
           }
@@ -295,8 +293,8 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
     for (int t = 0; t < nsteps; ++t) {
       const int r = qa + t - 2;
       if (y2_work && r >= r_first && r <= r_last) {
-        if (!(a.dbg & 2)) mfma_row(r, acc);
-        if (!(a.dbg & 4)) pool_row(r, acc);
+        mfma_row(r, acc);
+        pool_row(r, acc);
       }
       STEM_BARRIER();
     }

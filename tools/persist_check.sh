@@ -1,7 +1,7 @@
 #!/bin/bash
 # persistent decoder loop: one small parity case under a short timeout, then the rest, then the phase clock
 set -e
-out=gpurun_out/r2_persist; mkdir -p $out
+out=gpurun_out/persist; mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 240 python -m pytest tests/test_gpu_path.py -x -q -m gpu -k "test_decoder_train_step_matches_oracle and kw1 and False-False" > $out/t1.log 2>&1 || { tail -30 $out/t1.log; exit 1; }
 tail -3 $out/t1.log

@@ -5,7 +5,7 @@ import numpy as np, torch
 from comic_amd import _lib as L
 L.LIB_PATH = L.LIB_PATH.replace('libcomic_hip.so', 'libcomic_hip_dbg.so')
 lib = L.load()
-exec(open('scratch/one_conv.py').read().split("for tile in tiles:")[0].split("lib = L.load()")[1])
+exec(open('tools/one_conv.py').read().split("for tile in tiles:")[0].split("lib = L.load()")[1])
 for tile in tiles:
     op = L.CnnOp(kind=0, src=0, dst=1, src_coff=0, dst_coff=0, H=H, W=W, Cin=Cin, Cout=Cout, KH=kh, KW=kw, SH=s, SW=s,
                  PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=0, relu=1, out_f32=0, tile=tile)
