@@ -682,7 +682,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const bool fused_q = fused && D % 16 == 0;
   // the time loops as persistent launches (decoder_persist.hip, decoder_persist_bwd.hip) when the shape allows it
   const bool persist = fused && persist_enabled() &&
-                       comic_persist_fwd_supported(B, D, E, A, M, H, Cv, d->method, d->context_layer, ad.tied);
+                       comic_persist_fwd_supported(B, D, E, A, M, H, Cv, d->method, d->context_layer, ad.tied) &&
+                       comic_persist_fits_device(B);
   const bool persist_b = persist && persist_bwd_enabled() &&
                          comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
   // weight panels of the fused step kernels; the persistent backward reads K and W_q in place

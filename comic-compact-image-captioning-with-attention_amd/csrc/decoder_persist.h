@@ -47,6 +47,7 @@ struct ComicPersistRanges {
   long n[8];
 };
 int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st);
+bool comic_persist_fits_device(int B);   // CUs of the current device >= workgroups of the launch
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
 // poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)
 int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st);

@@ -536,6 +536,20 @@ int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream
   return 0;
 }
 
+// The loops need every workgroup resident at once (one per CU): refuse devices with fewer CUs than the launch has
+// workgroups (the per-step kernels run instead).  Cached per device.
+bool comic_persist_fits_device(int B) {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] >= ((B + kGroupRows - 1) / kGroupRows) * kGroupWgs;
+}
+
 int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st) {
   hipLaunchKernelGGL(persist_check_kernel, dim3(1), dim3(1), 0, st, sync, loss);
   COMIC_LAUNCH_CHECK("persistent decoder check");

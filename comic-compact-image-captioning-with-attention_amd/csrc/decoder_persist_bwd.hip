@@ -145,20 +145,15 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         const float4 q1 = *(const float4*)(a.q_all + ((size_t)t * B + ab) * D + k0 + 4);
         qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
       }
-      // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
+      // d att of step t+1's operand: requested now, needed after the recomputation of the own row (which depends
+      // only on saved forward values and covers the hand-off's latency)
+      const unsigned dso = (unsigned)((((size_t)(t + 1) * B + ab) * 2 * D + k0) * 4);
+      const unsigned off2[2] = {0u, 16u};
+      float4 dv2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
       if (t + 1 < Tp) {
-        const unsigned so = (unsigned)((((size_t)(t + 1) * B + ab) * 2 * D + k0) * 4);
-        const unsigned off2[2] = {0u, 16u};
-        float4 dv2[2] = {load16_sc1(ds_r, so), load16_sc1(ds_r, so + 16)};
-        wait_written<2>(dv2, ds_r, so, off2, 3u, wt);
-        const float keepf = (t + 1 >= a_len) ? 1.f : 0.f;
-        const float vin[EPL] = {dv2[0].x, dv2[0].y, dv2[0].z, dv2[0].w, dv2[1].x, dv2[1].y, dv2[1].z, dv2[1].w};
-#pragma unroll
-        for (int i = 0; i < EPL; ++i) datt_state[i] = datt_state[i] * keepf + vin[i];
+        dv2[0] = load16_sc1(ds_r, dso);
+        dv2[1] = load16_sc1(ds_r, dso + 16);
       }
-      float dcl[EPL];
-#pragma unroll
-      for (int i = 0; i < EPL; ++i) dcl[i] = datt_state[i] * live;
       float gv[EPL], bv[EPL], vv[EPL];
 #pragma unroll
       for (int i = 0; i < EPL; ++i) {
@@ -205,6 +200,17 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         part = head_total(part, lph);
         if ((lane % lph) == 0) ss[head * 32 + m_own] = part * inv_scale;
       }
+      // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
+      if (t + 1 < Tp) {
+        wait_written<2>(dv2, ds_r, dso, off2, 3u, wt);
+        const float keepf = (t + 1 >= a_len) ? 1.f : 0.f;
+        const float vin[EPL] = {dv2[0].x, dv2[0].y, dv2[0].z, dv2[0].w, dv2[1].x, dv2[1].y, dv2[1].z, dv2[1].w};
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) datt_state[i] = datt_state[i] * keepf + vin[i];
+      }
+      float dcl[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) dcl[i] = datt_state[i] * live;
       // (ii) d alpha_d of ALL memory rows (the probability backward needs whole rows of it): d ctx . values
       for (int m = wave; m < M; m += kWaves) {
         const float* kr = keys_l + m * D + k0;
@@ -410,15 +416,11 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
     stamp(a.stamps, t, 6);
     // ===================================================================== I: d gates * K^T (att and h thirds) ==========
     {
-      float mk4[4] = {1.f, 1.f, 1.f, 1.f};
+      // epilogue element of wave w < 4: row 4 kq + w, feature c; its input-dropout mask is fetched ahead
       const int c = 16 * wi + r16;                              // feature of the att | h thirds
-      if (wave == 0 && a.mask_in && c < D) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int b = row0 + 4 * kq + i;
-          if (b < B) mk4[i] = a.mask_in[((size_t)t * B + b) * EA + E + c];
-        }
-      }
+      const int eb = row0 + 4 * kq + wave;
+      float mk = 1.f;
+      if (wave < 4 && a.mask_in && c < D && eb < B) mk = a.mask_in[((size_t)t * B + eb) * EA + E + c];
       const unsigned go = (unsigned)((((((size_t)t * G + grp) * 128) * 16 + r16c) * 16 + 4 * kq) * 4);
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       // the first four blocks come first (see the d q gather above), then the other twelve in one go
@@ -450,23 +452,16 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
       red_i[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
       __syncthreads();
       stamp(a.stamps, t, 7);
-      if (wave == 0) {
-        float g4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (wave < 4) {   // D[m][n]: lane (r16 = feature, kq) of every wave's partial holds rows 4 kq + i; wave w takes i = w
+        const float* rp = (const float*)red_i + lane * 4 + wave;
+        float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {                      // fixed order: deterministic
-          const float4 pp = red_i[w * 64 + lane];
-          g4[0] += pp.x; g4[1] += pp.y; g4[2] += pp.z; g4[3] += pp.w;
-        }
-        // D[m][n]: lane (r16 = feature, kq) holds rows 4 kq + i; four lanes r16 = 4j .. 4j+3 make one 16-byte store
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = g4[i];
-          if (a.mask_in && c < D) v = (v / a.keep_in) * mk4[i];
-          const float x1 = __shfl_down(v, 1, 64), x2 = __shfl_down(v, 2, 64), x3 = __shfl_down(v, 3, 64);
-          const int b = row0 + 4 * kq + i;
-          if ((r16 & 3) == 0 && b < B)
-            store16_sc1(ds_r, (unsigned)((((size_t)t * B + b) * 2 * D + c) * 4), make_float4(v, x1, x2, x3));
-        }
+        for (int w = 0; w < kWaves; ++w) v += rp[w * 256];      // fixed order: deterministic
+        if (a.mask_in && c < D) v = (v / a.keep_in) * mk;
+        // four lanes r16 = 4j .. 4j+3 make one 16-byte store
+        const float x1 = __shfl_down(v, 1, 64), x2 = __shfl_down(v, 2, 64), x3 = __shfl_down(v, 3, 64);
+        if ((r16 & 3) == 0 && eb < B)
+          store16_sc1(ds_r, (unsigned)((((size_t)t * B + eb) * 2 * D + c) * 4), make_float4(v, x1, x2, x3));
       }
       __syncthreads();
     }

@@ -457,6 +457,25 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
             assert abs(g['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
 
 
+def test_persistent_time_loops_replay_from_a_hipgraph():
+    """The step with both persistent loops captured in a hipGraph (CaptionModel.run_train_step's path) and replayed
+    equals the eager step: the sentinel fill, the loops and their error check are all nodes of the graph."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    B, Lc = 32, 14
+    dec = cdec.Decoder(spec, _rand_params(cfg, 6), DEV)
+    fm, im, caps = _batch(spec, B, Lc, 41)
+    _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+    masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, 41)
+    ref = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True)
+    sync()
+    want = (float(ref['loss']), float(ref['map_loss']), dec.grads.data.clone())
+    for _ in range(3):                                   # eager, capture, replay
+        res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, use_graph=True)
+        sync()
+        assert float(res['loss']) == want[0] and float(res['map_loss']) == want[1]
+        assert torch.equal(dec.grads.data, want[2])
+
+
 def test_train_step_inputs_survive_host_run_ahead():
     """The host issues steps faster than the GPU executes them: every step must train on ITS captions (the
     pinned staging buffers of the async host-to-device copies are rewritten only after the copy that last used
