@@ -13,6 +13,8 @@
 // Both forms give lane-group g the physical k = 4g+s at MFMA step s, so the k-sums agree.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -693,7 +695,12 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
   a.stop = g_comic_stop.p;
   a.stop_t = g_comic_stop.t;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128);
-  const bool big = blocks128 >= 200;
+  static int big_min = -1;     // COMIC_X3_BIG_MIN: 128-row tiles from this many 128 x 128 output blocks on
+  if (big_min < 0) {
+    const char* e = getenv("COMIC_X3_BIG_MIN");
+    big_min = e ? atoi(e) : 40;      // measured on the decoder step's products: 314 -> 288 us per step against 200
+  }
+  const bool big = blocks128 >= big_min;
   const long tiles = big ? blocks128 : (long)cdiv(M, 64) * cdiv(N, 128);
   int S = 1;
   if (ws && tiles < 512) {
