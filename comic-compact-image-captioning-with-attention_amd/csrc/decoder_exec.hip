@@ -100,6 +100,31 @@ bool persist_enabled() {
   return !(e && e[0] == '0');
 }
 
+// A second stream inside the training executor: the weight-gradient products after the backward loop are independent
+// chains of mid-sized GEMMs and small reductions; two lanes fill each other's tails and launch gaps
+// (COMIC_GRAD_LANES=0: one stream).  Fork / join with events, so a hipGraph capture of the step takes both lanes.
+struct SideLane {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+SideLane* side_lane() {
+  static SideLane lanes[64];
+  const char* e = getenv("COMIC_GRAD_LANES");
+  if (e && e[0] == '0') return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideLane* L = &lanes[dev];
+  if (!L->s) {
+    if (hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&L->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&L->join, hipEventDisableTiming) != hipSuccess) {
+      L->s = nullptr;
+      return nullptr;
+    }
+  }
+  return L;
+}
+
 bool persist_bwd_enabled() {
   const char* e = getenv("COMIC_PERSIST_BWD");
   return !(e && e[0] == '0');
@@ -594,6 +619,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(TB * (3 * D + 1)); w.take<float>(TB * M);                      // pgrad rows, dmap
   w.take<float>(B * (E + A));                                                  // dx_init
   w.take<char>(kSplitKBytes);                                                  // split-K partials
+  w.take<char>(kSplitKBytes);                                                  // ... of the second gradient lane
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
   w.take<float>(D * D);                                                        // W_q panel
@@ -664,6 +690,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dmap = w.take<float>(TB * M);
   float* dx_init = w.take<float>((long)B * EA);
   g_splitk_ws = w.take<char>(kSplitKBytes);
+  void* splitk_ws_b = w.take<char>(kSplitKBytes);
   float* kpanel_f = w.take<float>(comic_lstm_panel_floats(D, Wd, 0));
   float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
   float* wq_panel = w.take<float>((long)D * D);
@@ -704,8 +731,20 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     RC(comic_persist_prepare(pr, persist_sync, st));
   }
   // ------------------------------------------------------------------ forward ------------
+  // the rnn init state (a chain of small products) on the side lane, beside the memory projections
+  SideLane* L = side_lane();
+  void* const ws_a = g_splitk_ws;
+  if (L) {
+    COMIC_REQUIRE(hipEventRecord(L->fork, st) == hipSuccess && hipStreamWaitEvent(L->s, L->fork, 0) == hipSuccess,
+                  "train_step: cannot fork the side lane");
+    g_splitk_ws = splitk_ws_b;
+  }
+  RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, L ? L->s : st));
+  g_splitk_ws = ws_a;
   RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
-  RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, st));
+  if (L)
+    COMIC_REQUIRE(hipEventRecord(L->join, L->s) == hipSuccess && hipStreamWaitEvent(st, L->join, 0) == hipSuccess,
+                  "train_step: cannot join the side lane");
   // operand rows before the loop: the x part of every step (embedding lookup + input dropout, hoisted) and step 0's
   // att part (zero: dropout of 0 is 0) and h part (h0)
   {
@@ -802,10 +841,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (sep_values) RC(fill(dvalues_buf, 0.f, (long)B * M * Cv, st));
     RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));    // dc | dh | datt: consecutive workspace blocks
   }
-  // dy_all = dlogits * W_o^T ; dW_o, db_o
+  // dy_all = dlogits * W_o^T (d W_o, d b_o: after the loop, on the gradient lanes)
   RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
-  RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, st));
-  RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
   // softmax attention: the backward kernel runs as two workgroups per batch row (half of the memory rows each), whose
   // d q / parameter-gradient contributions are added into zero-filled rows (comic_attn_bwd_ex, pgrad_overwrite 2)
@@ -823,9 +860,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pb.dq_all = dq_all; pb.dc = dc; pb.dh = dh; pb.dkeys = dkeys; pb.pgrad = pgrad4; pb.sync = persist_sync;
     pb.B = B; pb.E = E; pb.M = M; pb.H = H; pb.Tp = Tp; pb.method = d->method;
     RC(comic_persist_bwd_launch(pb, st));
-    // the embedding third of d gates * K^T, all steps at once, and its input dropout
-    RC(gemm_big(dg_all, p->K, demb, nullptr, Tp * B, E, 4 * D, 4 * D, 4 * D, E, 0, 1, 0.f, st));
-    if (drop_in) RC(comic_dropout_rows(demb, mask_in, d->keep_in, (long)Tp * B, E, EA, st));
     RC(comic_persist_check(persist_sync, map_loss, st));
   } else if (attn_bwd_mode == 2) {
     RC(fill(dq_all, 0.f, (long)Tp * B * D, st));
@@ -880,13 +914,44 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       COMIC_LAUNCH_CHECK("input_bwd");
     }
   }
-  // time-batched weight gradients
+  // ---- gradients that do not feed the recurrence, on two lanes (side_lane) ------------------------------------------
+  hipStream_t sb = st;
+  if (L) {
+    COMIC_REQUIRE(hipEventRecord(L->fork, st) == hipSuccess && hipStreamWaitEvent(L->s, L->fork, 0) == hipSuccess,
+                  "train_step: cannot fork the gradient lane");
+    sb = L->s;
+    g_splitk_ws = splitk_ws_b;
+  }
+  // lane B: output projection, embedding, query layer, memory projections, attention parameters
+  RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, sb));
+  if (persist_b) {   // the embedding third of d gates * K^T, all steps at once, and its input dropout
+    RC(gemm_big(dg_all, p->K, demb, nullptr, Tp * B, E, 4 * D, 4 * D, 4 * D, E, 0, 1, 0.f, sb));
+    if (drop_in) RC(comic_dropout_rows(demb, mask_in, d->keep_in, (long)Tp * B, E, EA, sb));
+  }
+  RC(fill(gr->emb, 0.f, (long)V * E, sb));
+  RC(comic_embed_bwd(in_tb, demb, gr->emb, Tp * B, E, V, (void*)sb));
+  RC(gemm_big(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, sb));
+  RC(gemm_big(fm, dkeys, gr->W_m, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, sb));
+  if (dfm) RC(gemm_big(dkeys, p->W_m, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 0.f, sb));
+  if (d->fm_projection == 1) {
+    RC(gemm_big(fm, dvalues_buf, gr->W_v, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, sb));
+    if (dfm) RC(gemm_big(dvalues_buf, p->W_v, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 1.f, sb));
+  } else if (d->fm_projection == 0 && dfm) {
+    RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)sb));
+  }
+  if (d->method == 0) {
+    // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter (dxh is free after the loop)
+    float* tmp = dxh;
+    COMIC_REQUIRE(3 * D + 1 <= B * Wd, "train_step: parameter-gradient scratch too small");
+    if (persist_b) RC(comic_colsum_ws(pgrad4, tmp, 4 * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, sb));
+    else RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, sb));
+    hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, sb, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);
+  }
+  g_splitk_ws = ws_a;
+  // lane A: output bias, LSTM kernel and bias, then the rnn init (which accumulates into both)
+  RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
   RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
-  RC(gemm_big(y_all, dq_all, gr->W_q, nullptr, D, D, Tp * B, D, D, D, 1, 0, 0.f, st));
-  RC(fill(gr->emb, 0.f, (long)V * E, st));
-  RC(comic_embed_bwd(in_tb, demb, gr->emb, Tp * B, E, V, (void*)st));
-  // rnn init
   float* dx_im = nullptr;  // gradient w.r.t. (im_embed * W_init)
   int n_init = 0;
   if (d->init_method == 1) {
@@ -904,24 +969,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   }
   RC(gemm_big(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
   if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
-  // memory projections
-  RC(gemm_big(fm, dkeys, gr->W_m, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
-  if (dfm) RC(gemm_big(dkeys, p->W_m, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 0.f, st));
-  if (d->fm_projection == 1) {
-    RC(gemm_big(fm, dvalues_buf, gr->W_v, nullptr, d->C, D, B * M, d->C, D, D, 1, 0, 0.f, st));
-    if (dfm) RC(gemm_big(dvalues_buf, p->W_v, dfm, nullptr, B * M, d->C, D, D, D, d->C, 0, 1, 1.f, st));
-  } else if (d->fm_projection == 0 && dfm) {
-    RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)st));
-  }
-  // attention parameters
-  if (d->method == 0) {
-    // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter.
-    // dg_all is free again here (its last reader, the dK GEMM, is ordered before on `st`).
-    float* tmp = dg_all;
-    if (persist_b) RC(comic_colsum_ws(pgrad4, tmp, 4 * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
-    else RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, st));
-    hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);
-  }
+  if (L)
+    COMIC_REQUIRE(hipEventRecord(L->join, sb) == hipSuccess && hipStreamWaitEvent(st, L->join, 0) == hipSuccess,
+                  "train_step: cannot join the gradient lane");
   COMIC_LAUNCH_CHECK("train_step");
   return 0;
 }
