@@ -106,6 +106,7 @@ _SIGS = {
     'comic_momentum_tf': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
     'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
+    'comic_decoder_train_path': (c_int, []),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
                                          P, P, P, P, P, c_int64, P]),

@@ -596,6 +596,9 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
 
 }  // namespace
 
+thread_local int g_train_path = 0;
+extern "C" int comic_decoder_train_path(void) { return g_train_path; }
+
 extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, int B, int T) {
   if (!d) return -1;
   Bump w(nullptr, 0);
@@ -713,6 +716,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                        comic_persist_fits_device(B);
   const bool persist_b = persist && persist_bwd_enabled() &&
                          comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
+  g_train_path = (persist ? 1 : 0) | (persist_b ? 2 : 0);
   // weight panels of the fused step kernels; the persistent backward reads K and W_q in place
   if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
   if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));

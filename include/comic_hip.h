@@ -385,6 +385,12 @@ int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_pa
                              float* map_loss, float* dfm, float* dim_embed, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* Which form of the time loops the LAST comic_decoder_train_step of this thread used: bit 0 = forward loop as one
+ * persistent launch (csrc/decoder_persist.hip), bit 1 = backward loop as one persistent launch
+ * (csrc/decoder_persist_bwd.hip); 0 = per-step launches.  The choice depends on the shape (D = 512, B <= 64, ...), the
+ * device (one workgroup per CU must be resident) and the COMIC_PERSIST / COMIC_PERSIST_BWD switches. */
+int comic_decoder_train_path(void);
+
 /* Greedy decode (rnn_decoder_search, ops_rnn.py:115-180): runs `max_steps` steps on the
  * device without host sync; ids [max_steps,B], attn [max_steps,B,H,M]; finished-at step per
  * row in first_eos [B] (max_steps when no EOS).  The host trims to the executed length. */

@@ -441,6 +441,7 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
             monkeypatch.setenv('COMIC_PERSIST_BWD', mode[1])
             res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
             sync()
+            assert dec.lib.comic_decoder_train_path() == {'11': 3, '10': 1, '00': 0}[mode]   # the loops really ran
             got[mode] = dict(logits=res['logits'].cpu().numpy(), maps=res['attn_maps'].cpu().numpy(),
                              loss=float(res['loss']), map_loss=float(res['map_loss']), dfm=res['dfm'].cpu().numpy(),
                              dim=res['dim_embed'].cpu().numpy(), g=dec.grads.to_numpy())
