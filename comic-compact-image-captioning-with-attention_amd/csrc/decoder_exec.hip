@@ -944,9 +944,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)sb));
   }
   if (d->method == 0) {
-    // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter (dxh is free after the loop)
-    float* tmp = dxh;
-    COMIC_REQUIRE(3 * D + 1 <= B * Wd, "train_step: parameter-gradient scratch too small");
+    // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the batch, then scatter (g_tmp [B][4D] is free after
+    // the loops and holds 3D + 1 floats at any batch size)
+    float* tmp = g_tmp;
     if (persist_b) RC(comic_colsum_ws(pgrad4, tmp, 4 * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, sb));
     else RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, sb));
     hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, sb, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);

@@ -458,6 +458,39 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
             assert abs(g['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
 
 
+@pytest.mark.parametrize('kw,B,Lc', [
+    (dict(E=64, H=4, M=1), 1, 4),                                  # one row, one memory row, one x block per wave
+    (dict(E=512, H=16, M=28), 17, 9),                              # second group holds a single row; widest x third
+    (dict(E=128, M=7, method='dot'), 33, 6),                       # three groups, dot scores
+    (dict(E=256, M=25, fm_projection='independent'), 50, 12),      # untied values: forward loop only
+    (dict(E=256, M=25, prob='sigmoid'), 64, 5),                    # sigmoid probability: forward loop only
+])
+def test_persistent_time_loops_odd_shapes(kw, B, Lc, monkeypatch):
+    """Shapes at the edges of what the persistent loops accept (ragged groups, a single row, one memory row, every x-third
+    width, 4 and 16 heads, configurations only the forward loop covers) against the per-step launches."""
+    spec, cfg = _spec_and_cfg(D=512, C=96, Cg=64, **kw)
+    dec = cdec.Decoder(spec, _rand_params(cfg, 8), DEV)
+    fm, im, caps = _batch(spec, B, Lc, 51)
+    _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+    masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, 52)
+    got = {}
+    for mode in ('11', '00'):
+        monkeypatch.setenv('COMIC_PERSIST', mode[0])
+        monkeypatch.setenv('COMIC_PERSIST_BWD', mode[1])
+        res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+        sync()
+        got[mode] = (dec.lib.comic_decoder_train_path(), res['logits'].cpu().numpy(), res['attn_maps'].cpu().numpy(),
+                     res['dfm'].cpu().numpy(), dec.grads.to_numpy(), float(res['loss']))
+    full = spec.fm_projection == 'tied' and spec.prob == 'softmax'
+    assert got['11'][0] == (3 if full else 1) and got['00'][0] == 0
+    assert_close(got['11'][1], got['00'][1], 2e-5, 'logits')
+    assert_close(got['11'][2], got['00'][2], 2e-5, 'attention maps')
+    assert_close(got['11'][3], got['00'][3], 1e-4, 'd feature map')
+    for k in got['00'][4]:
+        assert_close(got['11'][4][k], got['00'][4][k], 1e-4, 'grad ' + k)
+    assert abs(got['11'][5] - got['00'][5]) <= 1e-5 * abs(got['00'][5])
+
+
 def test_persistent_time_loops_replay_from_a_hipgraph():
     """The step with both persistent loops captured in a hipGraph (CaptionModel.run_train_step's path) and replayed
     equals the eager step: the sentinel fill, the loops and their error check are all nodes of the graph."""
