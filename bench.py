@@ -26,7 +26,7 @@ DEFAULT_ENC_GROUP = 10                        # steps per encoder forward in the
 GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
 EVENTS = os.environ.get('COMIC_NO_EVENTS', '0') != '1'
 STEP_TIMES = [] if os.environ.get('COMIC_STEP_TIMES', '0') == '1' else None      # diagnostic: per-step event / host stamps
-GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '0') == '1'   # hipGraph replay of the decoder step (eager measured faster)
+GRAPH_DEC = os.environ.get('COMIC_GRAPH_DEC', '1') == '1'   # hipGraph replay of the decoder step (round 2, persistent loops: 1.78 vs 1.80 ms eager; round 1's per-step launches were faster eager)
 
 
 def synth_captions(rng, B):

@@ -486,6 +486,8 @@ unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st) {
     on = (e && e[0] == '1') ? 1 : 0;
   }
   if (!on) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // the read-back synchronises: never inside a graph capture
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
   if (!dev[which] && hipMalloc((void**)&dev[which], 8 * 8 * 256) != hipSuccess) return nullptr;
   const int n = prev_tp[which];
   if (n > 1 && hipStreamSynchronize(st) == hipSuccess) {
