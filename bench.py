@@ -516,7 +516,7 @@ def main():
                                   (' group: one forward per %d steps' % GROUP if GROUP > 1 else '')) if overlap else ''},
             'final_loss': round(loss, 5),
         }
-        tfile = os.path.join(ROOT, 'profiles', 'r01_cnn_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r02_cnn_hbm_traffic.json')
         if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
             tj = json.load(open(tfile))
             if int(tj.get('images_per_forward', 64)) == ENC_BATCH:
