@@ -194,6 +194,23 @@ def extras(device, enc, cnn_params, plan):
                      'config': 'COMIC-256, InceptionV3 frozen, batch 64, 299x299x3, one forward per step (no grouping, no overlap)',
                      'cnn_forward_ms': round(fwd_ms, 3), 'flop_per_image': flop299,
                      'cnn_mfma_frac': round(flop299 * BATCH / (fwd_ms * 1e-3) / PEAK_BF16_MFMA, 5), 'loss': round(float(res['loss']), 4)}
+    del tr
+    torch.cuda.empty_cache()
+    # ---- the 224 x 224 encoder at 64 images per forward (no grouping): the same roofline definition as `roofline.frac` --
+    enc64 = nets.CnnEncoder(plan, cnn_params, BATCH, 'bf16', device)
+    if tune:
+        enc64.autotune()
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+    for _ in range(3):
+        enc64.forward(imgs, use_graph=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        enc64.forward(imgs, use_graph=True)
+    e1.record(); e1.synchronize()
+    ms64 = e0.elapsed_time(e1) / 10
+    out['cnn_frac_at_batch64'] = {'cnn_forward_ms': round(ms64, 4), 'images_per_forward': BATCH,
+                                  'frac': round(FLOP_PER_IMAGE_CNN * BATCH / (ms64 * 1e-3) / PEAK_BF16_MFMA, 5)}
     return out
 
 
@@ -477,6 +494,21 @@ def main():
         a.record(); tr.encoder.forward(inbuf, use_graph=GRAPH_CNN); b.record()
     torch.cuda.synchronize()
     cnn_iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso]))
+    # the decoder step alone on the GPU (forward + backward + Adam on resident features, nothing beside it), HIP events
+    dfm, dim = fm[:BATCH].clone(), im_embed[:BATCH].clone()
+    for i in range(3):
+        tr.decoder.train_step(dfm, dim, cap_sets[i % 4], training=True, use_graph=GRAPH_DEC)
+        tr.opt.step(tr.decoder.grads, tr.lr())
+    dec_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+    for i, (a, b) in enumerate(dec_ev):
+        a.record()
+        rd = tr.decoder.train_step(dfm, dim, cap_sets[i % 4], training=True, use_graph=GRAPH_DEC)
+        tr.opt.step(tr.decoder.grads, tr.lr())
+        b.record()
+    torch.cuda.synchronize()
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec_ev]))
+    dec_Tp = int(rd['Tp'])
+    dec_path = int(tr.decoder.lib.comic_decoder_train_path())
     loss = float(res['loss'])
     assert np.isfinite(loss), 'non-finite loss'
     top = heaviest_conv_launch(tr.encoder, plan) if rank == 0 else None
@@ -516,6 +548,23 @@ def main():
                                   (' group: one forward per %d steps' % GROUP if GROUP > 1 else '')) if overlap else ''},
             'final_loss': round(loss, 5),
         }
+        # Second roofline entry: the decoder chain.  Algorithmic HBM bytes of one decoder step = every tensor of the step
+        # moved once in each direction it is needed: parameters read in forward and backward, gradients written, Adam
+        # (p, g, m, v read; p, m, v written), the feature map read by the key projection and by d W_m, and the per-step
+        # activations the backward needs written once and read once.
+        sp = tr.decoder.spec
+        n_par = int(tr.decoder.params.numel)
+        Tq, Bq, Dq, Wdq = dec_Tp, BATCH, sp.D, sp.E + sp.A + sp.D
+        act = Tq * Bq * (Wdq + 4 * Dq + 3 * Dq + 2 * Dq + 2 * sp.H * sp.M + 2 * Dq + sp.V * 2 + 2 * Dq + 4 * Dq + sp.E)
+        dec_bytes = 4 * (n_par * 10 + 2 * Bq * sp.M * sp.C + 2 * Bq * sp.M * Dq + 2 * act)
+        out['decoder_roofline'] = {
+            'bound': 'hbm', 'kernel': 'decoder training step alone (forward + backward time loops%s, time-batched GEMMs, '
+                                      'TF-Adam), HIP events' % (' as persistent launches' if dec_path == 3 else ''),
+            'bytes_per_step': dec_bytes, 'ms_per_step': round(dec_ms, 4), 'time_steps': Tq,
+            'achieved': round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+            'frac': round(dec_bytes / (dec_ms * 1e-3) / 8e12, 5), 'loops_persistent': dec_path,
+            'note': 'the chain is latency-bound, not bandwidth-bound: 2 x T\' dependent phases of three to four '
+                    'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
         tfile = os.path.join(ROOT, 'profiles', 'r02_cnn_hbm_traffic.json')
         if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
             tj = json.load(open(tfile))
