@@ -22,7 +22,7 @@ BATCH = 64
 IMG = 224
 FLOP_PER_IMAGE_CNN = 2 * 2835873120          # 94 convs @224 (SURVEY Appendix B / BASELINE.md §2)
 PEAK_BF16_MFMA = 2.5e15                       # dense bf16, MI355X_MICROARCH.md chip table
-DEFAULT_ENC_GROUP = 10                        # steps per encoder forward in the pipelined frozen-CNN step
+DEFAULT_ENC_GROUP = 30                        # steps per encoder forward in the pipelined frozen-CNN step (measured 35.7k / 35.9k / 36.2k images/s at 10 / 15 / 30)
 GRAPH_CNN = os.environ.get('COMIC_GRAPH_CNN', '1') == '1'   # hipGraph replay of the CNN plan
 EVENTS = os.environ.get('COMIC_NO_EVENTS', '0') != '1'
 STEP_TIMES = [] if os.environ.get('COMIC_STEP_TIMES', '0') == '1' else None      # diagnostic: per-step event / host stamps
@@ -296,13 +296,13 @@ def cpu_baseline(seconds_budget=20.0):
 
 
 def pick_encoder_group(steps):
-    """Steps per encoder forward: DEFAULT_ENC_GROUP when it divides the timed step count, otherwise the nearest size
-    in 2..8 that does (5 first) (K timed steps then issue exactly K*BATCH images of encoder work); if none divides, the
-    default with a last partly used group (more encoder work than consumed, never less)."""
-    for g in (DEFAULT_ENC_GROUP, 5, 6, 4, 7, 3, 8, 2):
+    """Steps per encoder forward: the largest divisor of the timed step count up to DEFAULT_ENC_GROUP (K timed steps
+    then issue exactly K*BATCH images of encoder work); if none divides (a prime K above the default), the default with
+    a last partly used group (more encoder work than consumed, never less)."""
+    for g in range(min(DEFAULT_ENC_GROUP, steps), 1, -1):
         if steps % g == 0:
             return g
-    return DEFAULT_ENC_GROUP
+    return 1 if steps <= 1 else DEFAULT_ENC_GROUP
 
 
 def main():

@@ -14,7 +14,7 @@ for i in range(256):
     p = os.path.join(d, '%d.jpg' % i); Image.fromarray(a).resize((640, 480), Image.BICUBIC).save(p, quality=90); paths.append(p)
 r = random.Random(0)
 pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
-for nt in (1, 4, 16):
+for nt in [int(v) for v in os.environ.get('THREADS', '1,4,16').split(',') if v]:
     pool = ThreadPoolExecutor(max_workers=nt)
     for mode in ('numpy', 'device'):
         n, t0 = 0, time.time()
@@ -31,7 +31,7 @@ for nt in (1, 4, 16):
         torch.cuda.synchronize()
         print('threads %2d  %-6s : %6.0f images/s' % (nt, mode, n / (time.time() - t0)))
 ref = pre(list(map(inputs.decode_image, paths[:64])), [(False, 16, 16)] * 64).cpu()
-for nproc in (8, 16):
+for nproc in [int(v) for v in os.environ.get('NPROCS', '8,16').split(',') if v]:
     pool = inputs.DecodePool(nproc)
     got = pre.finish(pre.pack_paths(pool, paths[:64], [(False, 16, 16)] * 64)).cpu()
     assert torch.equal(got, ref), 'process decode differs from thread decode'
@@ -50,4 +50,4 @@ for nproc in (8, 16):
     torch.cuda.synchronize()
     print('processes %2d device : %6.0f images/s' % (nproc, n / (time.time() - t0)))
     pool.close()
-print('cpus', os.cpu_count())
+print('cpus', os.cpu_count(), 'usable', len(os.sched_getaffinity(0)))

@@ -3,7 +3,7 @@
 set -e
 out=gpurun_out/prof_round
 bash tools/prof_bench.sh $out
-B=640 python3 tools/pmc_traffic.py $out $out/cnn_hbm_traffic.json > $out/pmc_traffic.log 2>&1
+B=1920 python3 tools/pmc_traffic.py $out $out/cnn_hbm_traffic.json > $out/pmc_traffic.log 2>&1
 export TMPDIR=/tmp
 export COMIC_TUNE_CACHE=$out/tiles.json
 COMIC_PERSIST_STAMPS=1 COMIC_GRAPH_DEC=0 COMIC_OVERLAP=0 timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $out/bench_stamps.log 2>&1
