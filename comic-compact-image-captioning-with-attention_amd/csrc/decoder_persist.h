@@ -1,4 +1,5 @@
-// Persistent forward time loop of the training decoder (decoder_persist.hip).
+// Persistent time loops of the training decoder: host-side interface of decoder_persist.hip (forward) and
+// decoder_persist_bwd.hip (backward), used by comic_decoder_train_step (decoder_exec.hip).
 #pragma once
 #include "common.h"
 
@@ -29,7 +30,7 @@ struct ComicPersistFwdArgs {
   float* attn_hist;       // [Tp][B][H][M]
   float* ctx_all;         // [Tp][B][D]
   unsigned long long* stamps;   // diagnostic phase clock of workgroup 0 (null = off)
-  unsigned* sync;         // kPersistSyncWords words: the error word (the launch clears it)
+  unsigned* sync;         // kPersistSyncWords words: the error word (comic_persist_prepare clears it)
   int B, D, E, Wd, M, H, Tp;
   int method, prob, tied;
 };

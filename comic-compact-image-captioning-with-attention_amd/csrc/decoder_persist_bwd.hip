@@ -31,8 +31,6 @@
 
 namespace {
 
-constexpr int kMaxOwn = 8;   // memory rows a workgroup owns (one per wave): M <= 32
-
 // sum over the lph (2, 4, 8 or 16) consecutive lanes of a head: every lane of the head gets the total
 __device__ __forceinline__ float head_total(float v, int lph) { return group_sum_dpp(v, lph); }
 
@@ -520,7 +518,7 @@ bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int C
                                  int context_layer, int tied) {
   if (!comic_persist_fwd_supported(B, D, E, A, M, H, Cv, method, context_layer, tied)) return false;
   if (!tied || prob != 0) return false;                        // d values folded into d keys; softmax probability
-  if (M > 32 || E % 16 != 0) return false;                     // one owned memory row per wave
+  if (M > 4 * kWaves || E % 16 != 0) return false;             // one owned memory row per wave (4 workgroups a batch row)
   return bwd_lds_bytes(M) <= 160 * 1024;
 }
 
