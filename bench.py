@@ -567,8 +567,8 @@ def main():
                     'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
         tfile = os.path.join(ROOT, 'profiles', 'r02_cnn_hbm_traffic.json')
         if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
-            tj = json.load(open(tfile))
-            if int(tj.get('images_per_forward', 64)) == ENC_BATCH:
+            tj = json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH))
+            if tj:
                 out['roofline']['traffic'] = tj['per_forward']['conv_only_bytes_corrected']
                 out['roofline']['traffic_source'] = ('profiles/r02_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
                                                      'images, conv kernels)' % ENC_BATCH)
