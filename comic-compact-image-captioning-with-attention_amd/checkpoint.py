@@ -62,6 +62,7 @@ def save(path_prefix, global_step, cnn_params, dec_spec, dec_params, extra=None,
                 for f in (p + '.index', tf_bundle.data_path(p)):
                     if os.path.isfile(os.path.join(d or '.', f)):
                         os.remove(os.path.join(d or '.', f))
+            tf_bundle.prune_checkpoint_state(d or '.', set(mine[:-max_to_keep]))
         return prefix
     arrays['global_step'] = np.asarray(global_step, np.int32)
     path = '%s-%d.npz' % (path_prefix, int(global_step))

@@ -437,6 +437,17 @@ def update_checkpoint_state(directory, prefix_basename, keep=None):
     return allp
 
 
+def prune_checkpoint_state(directory, removed):
+    """Drop deleted prefixes from `all_model_checkpoint_paths` (what tf.train.Saver does when max_to_keep evicts)."""
+    path = os.path.join(directory, 'checkpoint')
+    if not removed or not os.path.isfile(path):
+        return
+    lines = [l for l in open(path)
+             if not (l.startswith('all_model_checkpoint_paths:') and l.split(':', 1)[1].strip().strip('"') in removed)]
+    with open(path, 'w') as f:
+        f.writelines(lines)
+
+
 def latest_checkpoint(directory):
     """tf.train.latest_checkpoint: the prefix named by the `checkpoint` state file."""
     path = os.path.join(directory, 'checkpoint')

@@ -457,6 +457,13 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
     tb.write_bundle(slim, cnn)
     c3, d3, _ = ckpt.restore(slim, list(cnn), spec)
     assert d3 is None and all(np.array_equal(c3[k], cnn[k]) for k in cnn)
+    # max_to_keep evicts the oldest bundles AND their entries of the `checkpoint` state file
+    for step in (8, 9, 10):
+        ckpt.save(str(tmp_path / 'model'), step, cnn, spec, dec, extra, max_to_keep=2, fmt='tf')
+    state = open(str(tmp_path / 'checkpoint')).read()
+    assert 'model-7"' not in state and 'model-8"' not in state and 'model-9"' in state and 'model-10"' in state
+    assert not os.path.isfile(str(tmp_path / 'model-8.index')) and os.path.isfile(str(tmp_path / 'model-10.index'))
+    assert ckpt.latest_checkpoint(str(tmp_path), 'model').endswith('model-10')
 
 
 def test_cli_refuses_options_it_does_not_implement(tmp_path):
