@@ -13,6 +13,8 @@
 // all weight-gradient GEMMs batched over time), states are kept per step for the backward
 // pass instead of TF's TensorArray stack, and dropout masks are explicit inputs.
 #include <stdlib.h>
+
+#include <algorithm>
 #include <string.h>
 
 #include "common.h"
@@ -769,7 +771,12 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pa.ctx_all = ctx_all; pa.sync = persist_sync;
     pa.B = B; pa.D = D; pa.E = E; pa.Wd = Wd; pa.M = M; pa.H = H; pa.Tp = Tp;
     pa.method = d->method; pa.prob = d->prob; pa.tied = ad.tied;
-    RC(comic_persist_fwd_launch(pa, st));
+    const int n_grp = (B + 15) / 16;                     // a launch serves up to four 16-row groups (256 CUs)
+    for (int g0 = 0; g0 < n_grp; g0 += 4) {
+      pa.grp0 = g0;
+      pa.n_groups = std::min(4, n_grp - g0);
+      RC(comic_persist_fwd_launch(pa, st));
+    }
   }
   for (int t = 0; t < (persist ? 0 : Tp); ++t) {
     float* xh_t = xh_all + (size_t)t * B * Wd;
@@ -863,7 +870,12 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pb.dq_part = dq_part; pb.dq_sum = dq_sum; pb.dg_blk = dg_blk; pb.dg_all = dg_all; pb.dstate = dstate;
     pb.dq_all = dq_all; pb.dc = dc; pb.dh = dh; pb.dkeys = dkeys; pb.pgrad = pgrad4; pb.sync = persist_sync;
     pb.B = B; pb.E = E; pb.M = M; pb.H = H; pb.Tp = Tp; pb.method = d->method;
-    RC(comic_persist_bwd_launch(pb, st));
+    const int n_grp = (B + 15) / 16;
+    for (int g0 = 0; g0 < n_grp; g0 += 4) {
+      pb.grp0 = g0;
+      pb.n_groups = std::min(4, n_grp - g0);
+      RC(comic_persist_bwd_launch(pb, st));
+    }
     RC(comic_persist_check(persist_sync, map_loss, st));
   } else if (attn_bwd_mode == 2) {
     RC(fill(dq_all, 0.f, (long)Tp * B * D, st));

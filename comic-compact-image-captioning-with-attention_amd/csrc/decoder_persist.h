@@ -33,6 +33,7 @@ struct ComicPersistFwdArgs {
   unsigned* sync;         // kPersistSyncWords words: the error word (comic_persist_prepare clears it)
   int B, D, E, Wd, M, H, Tp;
   int method, prob, tied;
+  int grp0, n_groups;     // this launch serves the 16-row groups [grp0, grp0 + n_groups) of the batch (n_groups <= 4)
 };
 
 constexpr int kPersistSyncWords = 32;       // the error word on a 128-byte line of its own
@@ -88,6 +89,7 @@ struct ComicPersistBwdArgs {
   unsigned long long* stamps;   // diagnostic phase clock of workgroup 0 (null = off)
   int B, E, M, H, Tp;
   int method;
+  int grp0, n_groups;     // as in ComicPersistFwdArgs
 };
 
 bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,

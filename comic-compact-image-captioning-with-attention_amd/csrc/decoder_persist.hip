@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   const int M = a.M, H = a.H, Wd = a.Wd, E = a.E, EA = a.E + D, B = a.B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;
+  const int grp = a.grp0 + blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;   // group index over the whole batch
   const int row0 = grp * kGroupRows;
   Waiter wt{a.sync, false};
 
@@ -464,7 +464,7 @@ int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st
 
 bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
                                  int tied) {
-  if (context_layer || B < 1 || B > kMaxGroups * kGroupRows) return false;
+  if (context_layer || B < 1 || B > kMaxLaunches * kMaxGroups * kGroupRows) return false;
   if (D != kD || A != D || Cv != D || E < 16 || E % 16 != 0 || E > 512) return false;
   if (H != 4 && H != 8 && H != 16) return false;                  // a channel quarter holds 1, 2 or 4 whole heads
   if (M < 1 || M > 64) return false;
@@ -512,11 +512,15 @@ unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st) {
 
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   ComicPersistFwdArgs a = a_in;
-  a.stamps = comic_persist_stamps(0, a.Tp, st);
+  a.stamps = a.grp0 == 0 ? comic_persist_stamps(0, a.Tp, st) : nullptr;
   const bool wq_lds = lds_bytes(a.M, a.tied, true) <= kLdsMax;
   int64_t lds = lds_bytes(a.M, a.tied, wq_lds);
   if (lds < kLdsMin) lds = kLdsMin;
-  const int groups = (a.B + kGroupRows - 1) / kGroupRows;
+  const int groups = a.n_groups;
+  if (groups < 1 || groups > kMaxGroups || (a.grp0 + groups - 1) * kGroupRows >= a.B) {
+    comic_set_error("persistent decoder: bad group range %d + %d at batch %d", a.grp0, groups, a.B);
+    return 2;
+  }
   const int nx = (a.E / 16 + kWaves - 1) / kWaves;                // x blocks per wave
   int rc = 2;
   if (nx <= 1) rc = wq_lds ? launch<1, true>(a, groups, lds, st) : launch<1, false>(a, groups, lds, st);
@@ -549,7 +553,8 @@ bool comic_persist_fits_device(int B) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
     cus[dev] = n > 0 ? n : -1;
   }
-  return cus[dev] >= ((B + kGroupRows - 1) / kGroupRows) * kGroupWgs;
+  const int groups = (B + kGroupRows - 1) / kGroupRows;
+  return cus[dev] >= (groups < kMaxGroups ? groups : kMaxGroups) * kGroupWgs;
 }
 
 int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st) {

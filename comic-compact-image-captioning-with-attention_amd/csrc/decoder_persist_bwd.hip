@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   const int M = a.M, H = a.H, E = a.E, EA = a.E + D, B = a.B, Tp = a.Tp, N4 = 4 * D;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;
+  const int grp = a.grp0 + blockIdx.x / kGroupWgs, wi = blockIdx.x % kGroupWgs;   // group index over the whole batch
   const int row0 = grp * kGroupRows;
   Waiter wt{a.sync, false};
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   // hand-off buffers in BLOCKED layouts: a k16-block of the 16 rows of a group is one contiguous KiB (16 rows x 64
   // bytes), which is exactly what one MFMA-operand load of a wave reads: whole 128-byte lines instead of 16 half lines
   //   dq_sum [t][group][k16-block 32][row 16][16]     dg_blk [t][group][k16-block 128][row 16][16]
-  const int G = gridDim.x / kGroupWgs;
+  const int G = (B + kGroupRows - 1) / kGroupRows;             // groups of the whole batch
   const __amdgpu_buffer_rsrc_t dqp_r = make_rsrc(a.dq_part, (long)Tp * B * 4 * D * 4);     // [t][row][partial 4][D]
   const __amdgpu_buffer_rsrc_t dqs_r = make_rsrc(a.dq_sum, (long)Tp * G * 16 * D * 4);
   const __amdgpu_buffer_rsrc_t dg_r = make_rsrc(a.dg_blk, (long)Tp * G * 16 * N4 * 4);
@@ -531,7 +531,7 @@ int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int c
 
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
   ComicPersistBwdArgs a = a_in;
-  a.stamps = comic_persist_stamps(1, a.Tp, st);
+  a.stamps = a.grp0 == 0 ? comic_persist_stamps(1, a.Tp, st) : nullptr;
   int64_t lds = bwd_lds_bytes(a.M);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
   static bool attr_set = false;
@@ -543,7 +543,11 @@ int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
     }
     attr_set = true;
   }
-  const int groups = (a.B + kGroupRows - 1) / kGroupRows;
+  const int groups = a.n_groups;
+  if (groups < 1 || groups > kMaxGroups || (a.grp0 + groups - 1) * kGroupRows >= a.B) {
+    comic_set_error("persistent decoder backward: bad group range %d + %d at batch %d", a.grp0, groups, a.B);
+    return 2;
+  }
   hipLaunchKernelGGL(decoder_bwd_persistent_kernel, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
   COMIC_LAUNCH_CHECK("persistent decoder backward");
   return 0;

@@ -10,7 +10,8 @@ constexpr int kThreads = 512;
 constexpr int kWaves = 8;
 constexpr int kGroupWgs = 64;          // workgroups per batch group
 constexpr int kGroupRows = 16;
-constexpr int kMaxGroups = 4;
+constexpr int kMaxGroups = 4;         // groups of one launch (256 CUs); larger batches run as consecutive launches
+constexpr int kMaxLaunches = 4;       // ... up to this many (beyond, the per-step kernels are better filled)
 constexpr int kD = 512;                // = 8 units per workgroup x 64 workgroups
 constexpr unsigned kSpinLimit = 1u << 20;
 constexpr int kSc1 = 16;               // cache-policy bit of raw buffer loads / stores: sc1

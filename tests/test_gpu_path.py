@@ -464,6 +464,8 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
     (dict(E=128, M=7, method='dot'), 33, 6),                       # three groups, dot scores
     (dict(E=256, M=25, fm_projection='independent'), 50, 12),      # untied values: forward loop only
     (dict(E=256, M=25, prob='sigmoid'), 64, 5),                    # sigmoid probability: forward loop only
+    (dict(E=256, M=25), 100, 7),                                   # 7 groups: two consecutive launches (4 + 3 groups)
+    (dict(E=256, M=25), 224, 6),                                   # the SCST step's 224 hypotheses: four launches
 ])
 def test_persistent_time_loops_odd_shapes(kw, B, Lc, monkeypatch):
     """Shapes at the edges of what the persistent loops accept (ragged groups, a single row, one memory row, every x-third
