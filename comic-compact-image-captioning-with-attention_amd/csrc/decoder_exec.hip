@@ -719,9 +719,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const bool persist_b = persist && persist_bwd_enabled() &&
                          comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
   g_train_path = (persist ? 1 : 0) | (persist_b ? 2 : 0);
-  // weight panels of the fused step kernels; the persistent backward reads K and W_q in place
-  if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
-  if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
   if (persist) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
     ComicPersistRanges pr{};
     const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
@@ -745,7 +742,14 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                   "train_step: cannot fork the side lane");
     g_splitk_ws = splitk_ws_b;
   }
-  RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, L ? L->s : st));
+  {
+    hipStream_t sl = L ? L->s : st;
+    // weight panels of the fused step kernels (the persistent backward reads K and W_q in place): needed by the time
+    // loop only, so they are packed on the side lane too
+    if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, sl));
+    if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, sl));
+    RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, sl));
+  }
   g_splitk_ws = ws_a;
   RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
   if (L)
