@@ -538,3 +538,19 @@ def test_preprocess_oracle_against_scalar_loop_and_host_path():
                                   pr.preprocess_image(big, 224, 224, True, 5, 30))
     np.testing.assert_array_equal(inputs.preprocess_image(big, 224, 224, False, None), pr.preprocess_image(big, 224, 224))
     assert pr.preprocess_image(big, 224, 224).min() >= -1.0 and pr.preprocess_image(big, 224, 224).max() <= 1.0
+
+
+def test_bench_encoder_group_divides_the_timed_steps():
+    """bench.py: steps per encoder forward = the largest divisor of K up to DEFAULT_ENC_GROUP, so K timed steps issue
+    exactly K * BATCH images of encoder work (the driver runs --steps 20, the default run 30)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.pick_encoder_group(30) == 30 and bench.pick_encoder_group(20) == 20 and bench.pick_encoder_group(5) == 5
+    assert bench.pick_encoder_group(50) == 25 and bench.pick_encoder_group(100) == 25 and bench.pick_encoder_group(7) == 7
+    assert bench.pick_encoder_group(1) == 1 and bench.pick_encoder_group(37) == bench.DEFAULT_ENC_GROUP   # prime above the cap
+    for k in range(1, 121):
+        g = bench.pick_encoder_group(k)
+        assert 1 <= g <= max(bench.DEFAULT_ENC_GROUP, 1) and (k % g == 0 or g == bench.DEFAULT_ENC_GROUP)
+
