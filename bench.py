@@ -133,15 +133,30 @@ def extras(device, enc, cnn_params, plan):
         opt.step(dec.grads, 1e-3)
         return res
     for _ in range(2):
-        scst_step()
+        res = scst_step()
     torch.cuda.synchronize()
     n, t0 = 5, time.perf_counter()
     for _ in range(n):
-        scst_step()
+        res = scst_step()
     torch.cuda.synchronize()
     out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
     out['scst_conv_mfma_frac'] = round(out['scst_images_per_sec'] * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
-    out['scst_config'] = 'COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-hypothesis step (encoder once, features tiled)'
+    out['scst_config'] = ('COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-hypothesis '
+                          'step (encoder once, features tiled); random weights with an EOS bias of +2: the rollouts END AFTER %d '
+                          'STEP(S) (device-side early exit) -- the lower bound of the step' % int(res['Tp']))
+    # the upper bound: EOS never emitted, every rollout and the training step run all 40 time steps
+    dec.params.view('b_o')[257] = -30.0
+    for _ in range(2):
+        res = scst_step()
+    torch.cuda.synchronize()
+    n, t0 = 3, time.perf_counter()
+    for _ in range(n):
+        res = scst_step()
+    torch.cuda.synchronize()
+    out['scst_full_length'] = {'images_per_sec': round(Bs * n / (time.perf_counter() - t0), 1), 'time_steps': int(res['Tp']),
+                               'config': 'the same step with EOS suppressed: greedy + beam-7 run all 40 steps, the 224-hypothesis '
+                                         'training step has T\' = %d (persistent loops in four launches: path %d)'
+                                         % (int(res['Tp']), int(dec.lib.comic_decoder_train_path()))}
     del enc_s, dec, opt
     torch.cuda.empty_cache()
     # ---- cnn_finetune step (configs[2]: CNN + decoder trainable, batch 32) ---------------------

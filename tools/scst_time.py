@@ -28,7 +28,7 @@ df = prepro_ngrams.build(['i%d,<GO> %s <EOS>' % (i, r) for i, rl in enumerate(re
 scorer = captionScorer(df, dict(ciderD=1.0, bleu=[0, 0, 0, 2]))
 spec = cdec.DecoderSpec()
 dec = cdec.Decoder(spec, None, device, seed=4)
-dec.params.view('b_o')[257] = 2.0
+dec.params.view('b_o')[257] = float(os.environ.get('EOS_BIAS', '2.0'))
 opt = optim.AdamTF(dec.params)
 enc_s = nets.CnnEncoder(plan, cnn_params, Bs, 'bf16', device)
 enc_s.autotune()
