@@ -45,15 +45,27 @@ def id_to_caption(ids, config):
         base = config.radix_base
         vocab_size = len(config.itow)
         word_len = len(number_to_base(vocab_size, base))
+        # word list indexed by id, built once per itow table (the SCST loop decodes (1 + beam) * batch rows per step)
+        cache = getattr(config, '_itow_list', None)
+        if cache is None or cache[0] is not config.itow:
+            cache = (config.itow, [config.itow.get(str(i)) for i in range(vocab_size)])   # ids run to len - 2: '-1' is <PAD>
+            try:
+                config._itow_list = cache
+            except AttributeError:
+                pass
+        words_of = cache[1]
+        weights = base ** np.arange(word_len - 1, -1, -1, dtype=np.int64)       # most significant digit first
         for row in ids:
-            keep = row[(row >= 0) & (row < base)].tolist()
-            if len(keep) % word_len:
-                keep.pop()
-            words = []
-            for j in range(0, len(keep), word_len):
-                wid = base_n_to_dec(keep[j:j + word_len], base)
-                if wid < vocab_size:
-                    words.append(config.itow[str(wid)])
+            keep = row[(row >= 0) & (row < base)]
+            if len(keep) % word_len:                     # the reference pops ONE id, whatever the remainder
+                keep = keep[:-1]
+            n = len(keep) // word_len
+            wid = keep[:n * word_len].reshape(n, word_len).astype(np.int64) @ weights
+            if len(keep) > n * word_len:                 # word_len > 2: a short last group decodes as it stands
+                wid = np.append(wid, base_n_to_dec(keep[n * word_len:].tolist(), base))
+            words = [words_of[w] for w in wid[wid < vocab_size].tolist()]
+            if None in words:                             # the dict lookup of the reference raises here
+                raise KeyError(str(int(wid[wid < vocab_size][words.index(None)])))
             captions.append(' '.join(words))
         return captions
     eos = config.wtoi['<EOS>']
