@@ -48,12 +48,38 @@ def id_to_caption(ids, config):
         # word list indexed by id, built once per itow table (the SCST loop decodes (1 + beam) * batch rows per step)
         cache = getattr(config, '_itow_list', None)
         if cache is None or cache[0] is not config.itow:
-            cache = (config.itow, [config.itow.get(str(i)) for i in range(vocab_size)])   # ids run to len - 2: '-1' is <PAD>
+            lst = [config.itow.get(str(i)) for i in range(vocab_size)]                    # ids run to len - 2: '-1' is <PAD>
+            cache = (config.itow, lst, np.array(lst, dtype=object))
             try:
                 config._itow_list = cache
             except AttributeError:
                 pass
         words_of = cache[1]
+        def lookup(wids):
+            words = [words_of[w] for w in wids]
+            if None in words:                             # the dict lookup of the reference raises here
+                raise KeyError(str(wids[words.index(None)]))
+            return ' '.join(words)
+        if word_len <= 2 and ids.ndim == 2 and ids.shape[1] > 0:
+            # all rows at once (the SCST loop decodes (1 + beam) * batch rows per step): compact the digits of every row
+            # to the left in order, drop one trailing digit of odd rows, combine digit pairs
+            valid = (ids >= 0) & (ids < base)
+            order = np.argsort(~valid, axis=1, kind='stable')
+            comp = np.take_along_axis(np.where(valid, ids, 0).astype(np.int64), order, axis=1)
+            n_words = valid.sum(axis=1) // word_len
+            if word_len == 2:
+                if comp.shape[1] % 2:
+                    comp = np.concatenate([comp, np.zeros((comp.shape[0], 1), np.int64)], axis=1)
+                wid = comp[:, 0::2] * base + comp[:, 1::2]
+            else:
+                wid = comp
+            keep = (np.arange(wid.shape[1])[None, :] < n_words[:, None]) & (wid < vocab_size)
+            flat_ids = wid[keep]                          # row-major: the words of row 0, then row 1, ...
+            flat = cache[2][flat_ids].tolist()
+            if None in flat:                              # the dict lookup of the reference raises here
+                raise KeyError(str(int(flat_ids[flat.index(None)])))
+            ends = np.cumsum(keep.sum(axis=1)).tolist()
+            return [' '.join(flat[a:b]) for a, b in zip([0] + ends[:-1], ends)]
         weights = base ** np.arange(word_len - 1, -1, -1, dtype=np.int64)       # most significant digit first
         for row in ids:
             keep = row[(row >= 0) & (row < base)]
@@ -63,10 +89,7 @@ def id_to_caption(ids, config):
             wid = keep[:n * word_len].reshape(n, word_len).astype(np.int64) @ weights
             if len(keep) > n * word_len:                 # word_len > 2: a short last group decodes as it stands
                 wid = np.append(wid, base_n_to_dec(keep[n * word_len:].tolist(), base))
-            words = [words_of[w] for w in wid[wid < vocab_size].tolist()]
-            if None in words:                             # the dict lookup of the reference raises here
-                raise KeyError(str(int(wid[wid < vocab_size][words.index(None)])))
-            captions.append(' '.join(words))
+            captions.append(lookup(wid[wid < vocab_size].tolist()))
         return captions
     eos = config.wtoi['<EOS>']
     joiner = ' ' if config.token_type == 'word' else ''

@@ -35,7 +35,7 @@ class captionScorer(object):
         if not self._h:
             raise L.ComicHipError('comic_scorer_create failed: %s' % self.lib.comic_last_error())
         self.weights = metric_weights
-        self.n_threads = n_threads or min(8, os.cpu_count() or 1)
+        self.n_threads = n_threads or min(16, os.cpu_count() or 1)     # 16 = the CPU share of one GPU on the boxes measured
 
     def __del__(self):
         try:
@@ -48,7 +48,8 @@ class captionScorer(object):
     def _score(self, hypos, refs_per_hypo):
         n = len(hypos)
         hy = (C.c_char_p * n)(*[h.encode('utf-8') for h in hypos])
-        flat = [r.encode('utf-8') for rl in refs_per_hypo for r in rl]
+        enc = {}                                     # the hypotheses of an image share its references: encode each once
+        flat = [enc.get(r) or enc.setdefault(r, r.encode('utf-8')) for rl in refs_per_hypo for r in rl]
         rf = (C.c_char_p * len(flat))(*flat)
         per = (C.c_int32 * n)(*[len(rl) for rl in refs_per_hypo])
         cider = (C.c_double * n)()
