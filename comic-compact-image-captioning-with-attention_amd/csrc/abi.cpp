@@ -48,38 +48,64 @@ extern "C" int comic_device_count(void) {
 // ------------------------------------------------------------------------------ scorer --
 namespace {
 
-typedef std::unordered_map<std::string, int> Counts;
+// N-grams are identified by a 64-bit order-sensitive hash of their words (FNV-1a per word, mixed with the position):
+// no strings are allocated per n-gram, the tables are flat vectors sorted by key (sums run in key order:
+// deterministic), and the scoring threads stop contending for the allocator.  A collision of two different n-grams
+// has probability ~2^-64 per pair.
+typedef uint64_t Key;
+typedef std::vector<std::pair<Key, int>> Counts;        // sorted by key, keys unique
+typedef std::vector<std::pair<Key, double>> Vec;        // sorted by key
 
-std::vector<std::string> split_ws(const char* s) {
-  std::vector<std::string> out;
+inline uint64_t word_hash(const char* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+  return h;
+}
+inline uint64_t mix(uint64_t h, uint64_t w) {
+  h ^= w + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  return h ^ (h >> 33);
+}
+inline Key ngram_key(const uint64_t* w, int k) {
+  uint64_t h = 0x243f6a8885a308d3ull + (uint64_t)k;
+  for (int j = 0; j < k; ++j) h = mix(h, w[j]);
+  return h;
+}
+
+// words of a sentence (split on ASCII white space, as str.split()) as hashes
+std::vector<uint64_t> split_ws(const char* s) {
+  std::vector<uint64_t> out;
   const char* p = s;
   while (*p) {
     while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
     if (!*p) break;
     const char* q = p;
     while (*q && !(*q == ' ' || *q == '\t' || *q == '\n' || *q == '\r' || *q == '\f' || *q == '\v')) ++q;
-    out.emplace_back(p, q - p);
+    out.push_back(word_hash(p, (size_t)(q - p)));
     p = q;
   }
   return out;
 }
 
-// n-gram counts per order; key = words joined by ' '
-void precook(const std::vector<std::string>& w, Counts cnt[4]) {
+// n-gram counts per order
+void precook(const std::vector<uint64_t>& w, Counts cnt[4]) {
   for (int k = 1; k <= 4; ++k) {
-    for (size_t i = 0; i + k <= w.size(); ++i) {
-      std::string key = w[i];
-      for (int j = 1; j < k; ++j) {
-        key.push_back(' ');
-        key += w[i + j];
-      }
-      ++cnt[k - 1][key];
+    Counts& c = cnt[k - 1];
+    c.clear();
+    std::vector<Key> keys;
+    for (size_t i = 0; i + k <= w.size(); ++i) keys.push_back(ngram_key(w.data() + i, k));
+    std::sort(keys.begin(), keys.end());
+    for (size_t i = 0; i < keys.size();) {
+      size_t j = i;
+      while (j < keys.size() && keys[j] == keys[i]) ++j;
+      c.emplace_back(keys[i], (int)(j - i));
+      i = j;
     }
   }
 }
 
 struct TfIdf {
-  std::unordered_map<std::string, double> vec[4];
+  Vec vec[4];
   double norm[4];
   int length;
 };
@@ -164,7 +190,7 @@ class ScorerPool {
 };
 
 struct comic_scorer {
-  std::unordered_map<std::string, double> df;
+  std::unordered_map<Key, double> df;
   double log_ref_len;
   mutable std::mutex pool_mutex;                 // one scoring call at a time uses the pool
   mutable std::unique_ptr<ScorerPool> pool;
@@ -173,11 +199,12 @@ struct comic_scorer {
     t.length = 0;
     for (int k = 0; k < 4; ++k) {
       double nrm = 0.0;
+      t.vec[k].clear();
       for (const auto& kv : cnt[k]) {
         auto it = df.find(kv.first);
         const double d = log(std::max(1.0, it == df.end() ? 0.0 : it->second));
         const double v = (double)kv.second * (log_ref_len - d);
-        t.vec[k][kv.first] = v;
+        t.vec[k].emplace_back(kv.first, v);
         nrm += v * v;
         if (k == 1) t.length += kv.second;  // reference quirk: "length" counts bigrams
       }
@@ -192,7 +219,7 @@ struct comic_scorer {
     int words;
   };
   void cook_ref(const char* text, CookedRef& c) const {
-    const std::vector<std::string> w = split_ws(text);
+    const std::vector<uint64_t> w = split_ws(text);
     c.words = (int)w.size();
     precook(w, c.cnt);
     to_vec(c.cnt, c.tv);
@@ -207,10 +234,19 @@ struct comic_scorer {
       const double delta = (double)(h.length - rv.length);
       for (int k = 0; k < 4; ++k) {
         double val = 0.0;
-        for (const auto& kv : h.vec[k]) {
-          auto it = rv.vec[k].find(kv.first);
-          const double rr = it == rv.vec[k].end() ? 0.0 : it->second;
-          val += std::min(kv.second, rr) * rr;
+        // n-grams present in both (an n-gram missing from the reference contributes min(h, 0) * 0 = 0)
+        size_t i = 0, j = 0;
+        const Vec &hv = h.vec[k], &rr = rv.vec[k];
+        while (i < hv.size() && j < rr.size()) {
+          if (hv[i].first < rr[j].first) {
+            ++i;
+          } else if (rr[j].first < hv[i].first) {
+            ++j;
+          } else {
+            val += std::min(hv[i].second, rr[j].second) * rr[j].second;
+            ++i;
+            ++j;
+          }
         }
         if (h.norm[k] != 0 && rv.norm[k] != 0) val /= (h.norm[k] * rv.norm[k]);
         val *= pow(M_E, -(delta * delta) / (2 * 6.0 * 6.0));
@@ -225,16 +261,8 @@ struct comic_scorer {
 
   static void bleu_one(int testlen, const Counts hc[4], const std::vector<const CookedRef*>& refs, double out[4]) {
     const double small = 1e-9, tiny = 1e-15;
-    Counts maxc[4];
     std::vector<int> reflens;
-    for (const CookedRef* rp : refs) {
-      reflens.push_back(rp->words);
-      for (int k = 0; k < 4; ++k)
-        for (const auto& kv : rp->cnt[k]) {
-          int& m = maxc[k][kv.first];
-          m = std::max(m, kv.second);
-        }
-    }
+    for (const CookedRef* rp : refs) reflens.push_back(rp->words);
     // 'closest': min over (|l - testlen|, l)
     int best_d = 1 << 30, reflen = 0;
     for (int l : reflens) {
@@ -246,10 +274,17 @@ struct comic_scorer {
     }
     double bleu = 1.0;
     for (int k = 0; k < 4; ++k) {
+      // clipped matches: for every n-gram of the hypothesis, min(its count, the largest count in any reference)
       int correct = 0;
       for (const auto& kv : hc[k]) {
-        auto it = maxc[k].find(kv.first);
-        correct += std::min(it == maxc[k].end() ? 0 : it->second, kv.second);
+        int mx = 0;
+        for (const CookedRef* rp : refs) {
+          const Counts& rc = rp->cnt[k];
+          auto it = std::lower_bound(rc.begin(), rc.end(), std::make_pair(kv.first, 0),
+                                     [](const std::pair<Key, int>& x, const std::pair<Key, int>& y) { return x.first < y.first; });
+          if (it != rc.end() && it->first == kv.first) mx = std::max(mx, it->second);
+        }
+        correct += std::min(mx, kv.second);
       }
       const int guess = std::max(0, testlen - (k + 1) + 1);
       bleu *= ((double)correct + tiny) / ((double)guess + small);
@@ -273,7 +308,8 @@ extern "C" comic_scorer* comic_scorer_create(const char* ngrams_host, const doub
   const char* p = ngrams_host;
   for (int64_t i = 0; i < n_entries; ++i) {
     const size_t len = strlen(p);
-    s->df.emplace(std::string(p, len), counts_host[i]);
+    const std::vector<uint64_t> w = split_ws(p);        // "w1 w2 w3": the words of the n-gram
+    if (!w.empty() && w.size() <= 4) s->df.emplace(ngram_key(w.data(), (int)w.size()), counts_host[i]);
     p += len + 1;
   }
   return s;
@@ -318,7 +354,7 @@ extern "C" int comic_scorer_score(const comic_scorer* s, const char* const* hypo
   auto run = [&](int count, const std::function<void(int)>& fn) { s->pool->run(count, fn); };
   run((int)uniq_text.size(), [&](int u) { s->cook_ref(uniq_text[(size_t)u], cooked[(size_t)u]); });
   run(n, [&](int i) {
-    const std::vector<std::string> hyp = split_ws(hypos_host[i]);
+    const std::vector<uint64_t> hyp = split_ws(hypos_host[i]);
     Counts hc[4];
     precook(hyp, hc);
     std::vector<const comic_scorer::CookedRef*> refs;
@@ -326,6 +362,8 @@ extern "C" int comic_scorer_score(const comic_scorer* s, const char* const* hypo
     if (out_cider_host) out_cider_host[i] = s->cider_one(hc, refs);
     if (out_bleu_host) comic_scorer::bleu_one((int)hyp.size(), hc, refs, out_bleu_host + (size_t)i * 4);
   });
+  // free the cooked references on the workers too: ~100k string-keyed map nodes, 2-3 ms when one thread frees them
+  run((int)cooked.size(), [&](int u) { cooked[(size_t)u] = comic_scorer::CookedRef(); });
   return 0;
 }
 
