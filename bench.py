@@ -592,6 +592,8 @@ def main():
                 out['extras'] = extras(device, tr.encoder, cnn_params, plan)
             except Exception as e:          # secondary figures must never break the headline line
                 out['extras'] = {'error': repr(e)}
+            if isinstance(out['extras'].get('cnn_frac_at_batch64'), dict):   # the same definition at 64 images per forward
+                out['roofline']['frac_at_batch64'] = out['extras']['cnn_frac_at_batch64']['frac']
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         else:
