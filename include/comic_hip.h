@@ -374,7 +374,11 @@ int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int
  *   masks (may be NULL when the keeps are 1): init_in [B,E+A], in [Tp,B,E+A],
  *   out [Tp,B,D], alpha [Tp,B,H,M].
  * Outputs: logits [T,B,V] (time-major), ids [T,B], attn history [Tp,B,H,M], loss_rows [T*B],
- *   map_loss (1 float), grads (no L2), dfm [B,M,C] / dim_embed [B,Cg] (may be NULL). */
+ *   map_loss (1 float), grads (no L2), dfm [B,M,C] / dim_embed [B,Cg] (may be NULL).
+ * The forward and the backward time loop each run as ONE persistent launch per 64 batch rows when the shape allows
+ * (D = 512, B <= 256, no context layer; backward: tied keys/values, softmax, M <= 28; a device with >= 256 CUs), as
+ * per-step launches otherwise: same results to fp32 summation order (comic_decoder_train_path tells which).  If a
+ * bounded wait inside a persistent loop ever expires, map_loss (and with it the loss) is NaN. */
 int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_params* p,
                              const comic_decoder_params* grads, const float* fm,
                              const float* im_embed, const int32_t* inputs_bt,
