@@ -107,6 +107,7 @@ _SIGS = {
     'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
     'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_path': (c_int, []),
+    'comic_decoder_greedy_path': (c_int, []),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
                                          P, P, P, P, P, c_int64, P]),

@@ -600,6 +600,8 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
 
 thread_local int g_train_path = 0;
 extern "C" int comic_decoder_train_path(void) { return g_train_path; }
+thread_local int g_greedy_path = 0;
+extern "C" int comic_decoder_greedy_path(void) { return g_greedy_path; }
 
 extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, int B, int T) {
   if (!d) return -1;
@@ -998,7 +1000,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
 
 extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int max_steps) {
   if (!d) return -1;
-  (void)max_steps;
   Bump w(nullptr, 0);
   const long D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, Wd = E + A + D, R = rows;
   w.take<float>(R * M * d->C); w.take<float>(R * d->Cg);           // tiled fm, im_embed
@@ -1016,6 +1017,11 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<char>(kSplitKBytes);                                      // split-K partials
   w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
   w.take<float>(D * ((V + 3) / 4 * 4));                            // W_o with 16-byte aligned rows
+  if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
+    const long S = std::max(1, max_steps);
+    w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
+    w.take<unsigned>(kPersistSyncWords);
+  }
   return (int64_t)w.off;
 }
 
@@ -1026,9 +1032,11 @@ struct InferBufs {
   StepBufs sb;
   float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad;
   int32_t *ids, *parents;
+  float *p_xh = nullptr, *p_y = nullptr, *p_q = nullptr, *p_argp = nullptr;   // persistent greedy loop (rows <= 64)
+  unsigned* p_sync = nullptr;
   bool ok;
 };
-InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t bytes) {
+InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t bytes, int max_steps = 0) {
   Bump w(ws, (size_t)bytes);
   const long D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv, Wd = E + A + D, R = rows;
   InferBufs b;
@@ -1048,6 +1056,12 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   g_splitk_ws = w.take<char>(kSplitKBytes);
   b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
   b.wo_pad = w.take<float>(D * ((V + 3) / 4 * 4));
+  if (rows <= 64 && max_steps > 0) {
+    const long S = max_steps;
+    b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);
+    b.p_argp = w.take<float>(S * R * 132);
+    b.p_sync = w.take<unsigned>(kPersistSyncWords);
+  }
   b.ok = w.ok;
   return b;
 }
@@ -1079,7 +1093,7 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   COMIC_REQUIRE(B > 0 && max_steps > 0, "greedy: bad shape");
   COMIC_REQUIRE(workspace_bytes >= comic_decoder_infer_workspace(d, B, max_steps), "greedy: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  InferBufs ws = carve_infer(d, B, workspace, workspace_bytes);
+  InferBufs ws = carve_infer(d, B, workspace, workspace_bytes, max_steps);
   COMIC_REQUIRE(ws.ok, "greedy: workspace overflow");
   const int D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H, Cv = d->Cv;
   const comic_attn_desc ad = attn_desc(d, B);
@@ -1094,6 +1108,43 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   COMIC_LAUNCH_CHECK("greedy init");
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
   if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
+  // the whole loop as one persistent launch (decoder_persist.hip, GREEDY) when the shape allows it
+  g_greedy_path = 0;
+  if (fused && persist_enabled() && ws.p_xh &&
+      comic_persist_greedy_supported(B, D, E, A, M, H, Cv, V, d->method, d->context_layer, ad.tied) &&
+      comic_persist_fits_device(B)) {
+    const int Wd = E + A + D;
+    ComicPersistRanges pr{};
+    pr.p[0] = ws.p_xh; pr.n[0] = (long)max_steps * B * Wd;
+    pr.p[1] = ws.p_y; pr.n[1] = (long)max_steps * B * D;
+    pr.p[2] = ws.p_q; pr.n[2] = (long)max_steps * B * D;
+    pr.p[3] = ws.p_argp; pr.n[3] = (long)max_steps * B * 132;
+    RC(comic_persist_prepare(pr, ws.p_sync, st));
+    // step 0 operand: att = 0, h = h0 (the x third comes from the embedding table inside the loop)
+    {
+      const long n = (long)B * A + (long)B * D;
+      hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb,
+                         (const int32_t*)nullptr, (int32_t*)nullptr, (const float*)nullptr, 1.f, ws.p_xh, ws.att[0], ws.h[0],
+                         0, B, 0, E, A, D, V);
+      COMIC_LAUNCH_CHECK("greedy step0");
+    }
+    ComicPersistFwdArgs pa{};
+    pa.K_panel = ws.kpanel; pa.bias = p->b; pa.W_q = p->W_q; pa.keys = ws.keys; pa.values = values;
+    pa.ln_g = p->ln_g; pa.ln_b = p->ln_b; pa.v = p->v; pa.tau = p->tau;
+    pa.keep_in = pa.keep_out = pa.keep_alpha = 1.f;
+    pa.xh_all = ws.p_xh; pa.y_all = ws.p_y; pa.q_all = ws.p_q; pa.cs = ws.c[0]; pa.hs = ws.h[0];
+    pa.attn_hist = attn_hist; pa.sync = ws.p_sync;
+    pa.B = B; pa.D = D; pa.E = E; pa.Wd = Wd; pa.M = M; pa.H = H; pa.Tp = max_steps;
+    pa.method = d->method; pa.prob = d->prob; pa.tied = ad.tied;
+    pa.grp0 = 0; pa.n_groups = (B + 15) / 16;
+    pa.greedy = 1; pa.emb = p->emb; pa.W_o = p->W_o; pa.b_o = p->b_o; pa.V = V; pa.ld_wo = V;
+    pa.start_id = d->start_id; pa.end_id = d->end_id;
+    pa.argp = ws.p_argp; pa.ids_tb = ids_tb; pa.first_eos = first_eos; pa.logits_tb = logits_tb;
+    RC(comic_persist_fwd_launch(pa, st));
+    RC(comic_persist_check_greedy(ws.p_sync, first_eos, st));
+    g_greedy_path = 1;
+    return 0;
+  }
   int ld_wo = V;
   const float* w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
   struct StopScope {          // whatever way this call returns, no later launch sees the flag

@@ -34,9 +34,19 @@ struct ComicPersistFwdArgs {
   int B, D, E, Wd, M, H, Tp;
   int method, prob, tied;
   int grp0, n_groups;     // this launch serves the 16-row groups [grp0, grp0 + n_groups) of the batch (n_groups <= 4)
+  // greedy decode (GREEDY instantiation): no teacher forcing / masks / lens / saved activations
+  int greedy;
+  const float* emb;       // [V][E]
+  const float* W_o;       // [D][ld_wo] output projection (columns < V)
+  const float* b_o;       // [V]
+  int V, ld_wo, start_id, end_id;
+  float* argp;            // [Tp][B][132] per row 64 partial (value, column) maxima of the logits + the group's stop word; sentinel-filled
+  int32_t* ids_tb;        // [Tp][B] token ids (out)
+  int32_t* first_eos;     // [B] step of the first EOS (out; pre-filled with Tp)
+  float* logits_tb;       // [Tp][B][V] or null
 };
 
-constexpr int kPersistSyncWords = 32;       // the error word on a 128-byte line of its own
+constexpr int kPersistSyncWords = 64;       // the error word, and from word 32 one "all my rows emitted EOS" word per group (greedy)
 // "not written yet" pattern of the handed-off buffers (xh_all, y_all, q_all): comic_persist_prepare fills them
 #define COMIC_PERSIST_SENTINEL 0xFFFFDEADu
 
@@ -49,6 +59,9 @@ struct ComicPersistRanges {
   long n[8];
 };
 int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st);
+bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, int Cv, int V, int method,
+                                    int context_layer, int tied);
+int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStream_t st);
 bool comic_persist_fits_device(int B);   // CUs of the current device >= workgroups of the launch
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
 // poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)

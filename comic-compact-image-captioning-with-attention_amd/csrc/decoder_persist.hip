@@ -55,7 +55,11 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
 
 // A wave's k16-blocks of the operand row [x ; att ; h]: NX of the x third (block wave + 8 i), then four of the att third
 // and four of the h third (pairs of adjacent blocks: the two loads of a row share a 128-B line).
-template <int NX, bool WQ_LDS>
+// GREEDY: the same loop as the greedy decode of rnn_decoder_search (common/ops_rnn.py:115-180; GreedyEmbeddingHelper): no
+// teacher forcing, no dropout, no finished-row select; the Q phase also forms this workgroup's columns of the logits
+// y W_o + b_o and their row maxima, every workgroup reduces the 64 partial maxima of its rows to the step's token ids
+// and the x third of the next operand row is read straight from the embedding table.
+template <int NX, bool WQ_LDS, bool GREEDY>
 __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicPersistFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = kD;
@@ -73,10 +77,14 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   float* q_l = (float*)(red + kWaves * 2 * 64);                // [D]      q row of the attention phase
   float* sc_l = q_l + D;                                       // [<= 4 heads][64]
   float* wq_l = sc_l + 4 * 64;                                 // [D][8] + 4 floats per 16 rows: eight W_q columns
+  float* wo_l = wq_l + (WQ_LDS ? 8 * D + (D / 16) * 4 : 0);     // GREEDY: [D][8] + pad, this workgroup's logit columns of W_o
+  int* ids_l = (int*)(wo_l + 8 * D + (D / 16) * 4);            // GREEDY: [16] token ids of the group's rows, [16] first-EOS steps
 
   const __amdgpu_buffer_rsrc_t xh_r = make_rsrc(a.xh_all, (long)a.Tp * B * Wd * 4);
   const __amdgpu_buffer_rsrc_t y_r = make_rsrc(a.y_all, (long)a.Tp * B * D * 4);
   const __amdgpu_buffer_rsrc_t q_r = make_rsrc(a.q_all, (long)a.Tp * B * D * 4);
+  const __amdgpu_buffer_rsrc_t ap_r = make_rsrc(a.argp, GREEDY ? (long)a.Tp * B * kArgRow * 4 : 0);
+  const int ncol = GREEDY ? (a.V + kGroupWgs - 1) / kGroupWgs : 0;   // logit columns per workgroup (<= 8)
 
   // ---- attention-phase identity: batch row + channel quarter --------------------------------------------------------
   const int ab = row0 + (wi & 15), aq = wi >> 4;
@@ -97,6 +105,17 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         *(float4*)dst = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi);
         *(float4*)(dst + 4) = *(const float4*)(a.W_q + (size_t)k * D + 8 * wi + 4);
       }
+    }
+    if constexpr (GREEDY) {   // W_o[k][ncol wi + c] for c < ncol (0 past V), same padded layout as the W_q columns
+      for (int i = tid; i < D * 8; i += kThreads) {
+        const int k = i >> 3, c = i & 7, col = ncol * wi + c;
+        wo_l[8 * k + 4 * (k >> 4) + c] = (c < ncol && col < a.V) ? a.W_o[(size_t)k * a.ld_wo + col] : 0.f;
+      }
+      if (tid < 16) {
+        ids_l[tid] = a.start_id;
+        ids_l[16 + tid] = a.Tp;
+      }
+      if (tid == 0) ids_l[32] = ids_l[33] = 0;
     }
   }
 
@@ -128,13 +147,13 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
     e_c = a.cs[(size_t)e_row * D + e_d];
     e_h = a.hs[(size_t)e_row * D + e_d];
     e_b[0] = a.bias[e_d]; e_b[1] = a.bias[D + e_d]; e_b[2] = a.bias[2 * D + e_d]; e_b[3] = a.bias[3 * D + e_d];
-    e_len = a.lens[e_row];
+    e_len = GREEDY ? 0x7fffffff : a.lens[e_row];
   }
   const int l_row = min(row0 + r16, B - 1);                    // operand row of this lane (clamped: results unused)
   // attention epilogue threads (tid < D/4): previous attention state of (row, channel)
   const int a_c = cq0 + tid;
   float att_prev = 0.f;
-  const int a_len = a_live ? a.lens[ab] : 0;
+  const int a_len = GREEDY ? 0x7fffffff : (a_live ? a.lens[ab] : 0);
   float lnp[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // gamma, beta, v of this lane's two quarter channels
   if (a.method == 0) {
     const int c = cq0 + 2 * lane;
@@ -152,12 +171,18 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
     const unsigned xo = (unsigned)((((size_t)t * B + l_row) * Wd + 4 * kq) * 4);
     float4 xa[N];
     unsigned off[N];
+    if constexpr (GREEDY && I0 == 0) {    // x third: the embedding row of the token this row emitted (plain loads: a table)
+      const float* er = a.emb + (size_t)ids_l[r16] * E + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      off[i] = kb_off[I0 + i];
-      xa[i] = load16_sc1(xh_r, xo + off[i]);
+      for (int i = 0; i < N; ++i) xa[i] = *(const float4*)(er + kb_off[I0 + i] / 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        off[i] = kb_off[I0 + i];
+        xa[i] = load16_sc1(xh_r, xo + off[i]);
+      }
+      wait_written<N>(xa, xh_r, xo, off, (1u << N) - 1u, wt);
     }
-    wait_written<N>(xa, xh_r, xo, off, (1u << N) - 1u, wt);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
           store16_sc1(xh_r, (unsigned)((((size_t)(t + 1) * B + e_row) * Wd + EA + 8 * wi + 4 * wave) * 4),
                       make_float4(h4[0], h4[1], h4[2], h4[3]));
       }
-      if (e_lane) {
+      if (!GREEDY && e_lane) {      // saved for the backward loop
         float* ga = a.gates_all + ((size_t)t * B + e_row) * 4 * D;
         ga[e_d] = si; ga[D + e_d] = tj; ga[2 * D + e_d] = sf; ga[3 * D + e_d] = so;
         a.cnew_all[e_i] = c2;
@@ -277,11 +302,118 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         store16_sc1(q_r, qo, make_float4(q8[0], q8[1], q8[2], q8[3]));
         store16_sc1(q_r, qo + 16, make_float4(q8[4], q8[5], q8[6], q8[7]));
       }
+      if constexpr (GREEDY) {       // this workgroup's columns of the logits, and their maximum per row
+        float l8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ys[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k = 16 * part + 4 * i + e;
+            const float* src = wo_l + 8 * k + 4 * part;
+            const float4 w0 = *(const float4*)src, w1 = *(const float4*)(src + 4);
+            l8[0] = fmaf(ys[e], w0.x, l8[0]); l8[1] = fmaf(ys[e], w0.y, l8[1]);
+            l8[2] = fmaf(ys[e], w0.z, l8[2]); l8[3] = fmaf(ys[e], w0.w, l8[3]);
+            l8[4] = fmaf(ys[e], w1.x, l8[4]); l8[5] = fmaf(ys[e], w1.y, l8[5]);
+            l8[6] = fmaf(ys[e], w1.z, l8[6]); l8[7] = fmaf(ys[e], w1.w, l8[7]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          l8[e] = group_sum_dpp(l8[e], 16);
+          l8[e] += __shfl_xor(l8[e], 16, 64);
+        }
+        // Leaving the loop: workgroup 0 of the group decides and publishes the decision with its partial of this step
+        // (word 128 of the group's first row), so that all 64 workgroups leave after the SAME step.  It says "stop"
+        // once its rows had all emitted EOS before this step and it has seen the same word of every other group of
+        // the launch: no row stops before the step the host trims to; a late sighting costs a step.
+        if (wi == 0 && tid == 0) {
+          bool every = true;
+          for (int r = 0; r < kGroupRows && row0 + r < B; ++r) every &= ids_l[16 + r] < t;
+          for (int g = a.grp0; every && g < a.grp0 + a.n_groups; ++g)
+            every = g == grp || __hip_atomic_load(a.sync + 32 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+          store4_sc1(ap_r, (unsigned)((((size_t)t * B + row0) * kArgRow + 128) * 4), every ? 1.f : 0.f);
+        }
+        if (part == 0 && row0 + rl < B) {
+          float best = -INFINITY;
+          int bi = 0x7fffffff;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int col = ncol * wi + e;
+            if (e < ncol && col < a.V) {
+              const float v = l8[e] + a.b_o[col];
+              if (a.logits_tb) a.logits_tb[((size_t)t * B + row0 + rl) * a.V + col] = v;
+              if (v > best) {                                   // first maximum: lowest column wins a tie
+                best = v;
+                bi = col;
+              }
+            }
+          }
+          // (value, column) of this workgroup for the row; a workgroup without columns publishes (-inf, INT_MAX)
+          const unsigned po = (unsigned)((((size_t)t * B + row0 + rl) * kArgRow + 2 * wi) * 4);
+          store4_sc1(ap_r, po, best);
+          store4_sc1(ap_r, po + 4, __int_as_float(bi));
+        }
+      }
     }
     stamp(a.stamps, t, 3);
     // ============================================ next step's x and h thirds, under the q hand-off ====================
     acc[0] = acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (t + 1 < a.Tp) {
+    if constexpr (GREEDY) {
+      if (t + 1 < a.Tp) lstm_part(t + 1, ca, ch);              // h third first: the ids are still on their way
+      __syncthreads();                                          // ids_l of the previous step is no longer read
+      // the step's token ids: 64 partial (value, column) maxima per row, two per thread
+      {
+        const int rl = tid >> 5, j = tid & 31;
+        const int row = min(row0 + rl, B - 1);
+        const unsigned po = (unsigned)((((size_t)t * B + row) * kArgRow + 4 * j) * 4);
+        const unsigned zoff[1] = {0u};
+        float4 pv[1] = {load16_sc1(ap_r, po)};
+        wait_written<1>(pv, ap_r, po, zoff, 1u, wt);
+        float bv = pv[0].x;
+        int bi = __float_as_int(pv[0].y);
+        if (pv[0].z > bv) {                                     // columns grow with the workgroup index: ties keep the lower
+          bv = pv[0].z;
+          bi = __float_as_int(pv[0].w);
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        if (j == 0) {
+          ids_l[rl] = bi;
+          if (bi == a.end_id && ids_l[16 + rl] > t) ids_l[16 + rl] = t;
+          if (wi == 0 && row0 + rl < B) {
+            a.ids_tb[(size_t)t * B + row0 + rl] = bi;
+            if (ids_l[16 + rl] == t) a.first_eos[row0 + rl] = t;
+          }
+        }
+        if (tid == 0) {                                         // workgroup 0's "stop after this step"
+          const unsigned fo = (unsigned)((((size_t)t * B + row0) * kArgRow + 128) * 4);
+          const unsigned z4[1] = {0u};
+          float4 fv[1] = {load16_sc1(ap_r, fo)};                // words 128..131 of the row: only 128 is written
+          unsigned spins = 0;
+          while (__float_as_uint(fv[0].x) == kSentinel && !wt.spin(spins)) fv[0] = load16_sc1(ap_r, fo);
+          (void)z4;
+          ids_l[32] = fv[0].x == 1.f ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (wi == 0 && tid == 0 && ids_l[33] == 0) {              // all rows of this group have emitted EOS: say so, once
+        bool mine = true;
+        for (int r = 0; r < kGroupRows && row0 + r < B; ++r) mine &= ids_l[16 + r] <= t;
+        if (mine) {
+          __hip_atomic_store(a.sync + 32 + grp, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ids_l[33] = 1;
+        }
+      }
+      if (t + 1 < a.Tp) lstm_part(t + 1, c0, cx);              // x third from the embedding table
+    } else if (t + 1 < a.Tp) {
       lstm_part(t + 1, c0, cx);
       lstm_part(t + 1, ca, ch);
     }
@@ -382,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
           al = sg / wave_sum(sg);
         }
         if (lane < M) {
-          a.alpha_all[go + lane] = al;
+          if (!GREEDY) a.alpha_all[go + lane] = al;
           const float ad = a.mask_alpha ? (al / a.keep_alpha) * m_al : al;
           a.attn_hist[go + lane] = ad;
           srow[lane] = ad;
@@ -401,10 +533,10 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         }
         for (; m < M; ++m) c4[0] = fmaf(al[m], vp[m * D], c4[0]);
         const float cx = (c4[0] + c4[1]) + (c4[2] + c4[3]);
-        a.ctx_all[((size_t)t * B + ab) * D + a_c] = cx;
+        if (!GREEDY) a.ctx_all[((size_t)t * B + ab) * D + a_c] = cx;
         const bool fin = t >= a_len;
         att_prev = fin ? att_prev : cx;
-        a.att_all[((size_t)(t + 1) * B + ab) * D + a_c] = att_prev;
+        if (!GREEDY) a.att_all[((size_t)(t + 1) * B + ab) * D + a_c] = att_prev;
         if (t + 1 < a.Tp) {
           const float xv = a.mask_in ? (att_prev / a.keep_in) * m_in : att_prev;
           const float x1 = __shfl_down(xv, 1, 64), x2 = __shfl_down(xv, 2, 64), x3 = __shfl_down(xv, 3, 64);
@@ -415,6 +547,9 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
       __syncthreads();   // as after the cell epilogue: poll the next operand only once our own att stores are issued
     }
     stamp(a.stamps, t, 7);
+    if constexpr (GREEDY) {
+      if (ids_l[32]) break;       // the same word in all 64 workgroups of the group (read in the ids gather of this step)
+    }
   }
 }
 
@@ -437,16 +572,17 @@ __global__ void persist_check_kernel(const unsigned* err, float* loss) {
   if (err[0] != 0u) loss[0] = __int_as_float(0x7fc00000);
 }
 
-int64_t lds_bytes(int M, int tied, bool wq_lds) {
-  return (int64_t)(tied ? 1 : 2) * M * kD * 4 + kWaves * 2 * 64 * 16 + kD * 4 + 4 * 64 * 4 +
-         (wq_lds ? kD * 32 + (kD / 16) * 16 : 0);
+int64_t lds_bytes(int M, int tied, bool wq_lds, bool greedy = false) {
+  const int64_t cols = kD * 32 + (kD / 16) * 16;               // eight padded columns of a [D][D'] matrix
+  return (int64_t)(tied ? 1 : 2) * M * kD * 4 + kWaves * 2 * 64 * 16 + kD * 4 + 4 * 64 * 4 + (wq_lds ? cols : 0) +
+         (greedy ? cols + 64 * 4 : 0);
 }
 constexpr int64_t kLdsMax = 160 * 1024;
 constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at most one workgroup per CU
 
-template <int NX, bool WQ_LDS>
+template <int NX, bool WQ_LDS, bool GREEDY = false>
 int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st) {
-  auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS>;
+  auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS, GREEDY>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess) {
@@ -513,8 +649,13 @@ unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st) {
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   ComicPersistFwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(0, a.Tp, st) : nullptr;
-  const bool wq_lds = lds_bytes(a.M, a.tied, true) <= kLdsMax;
-  int64_t lds = lds_bytes(a.M, a.tied, wq_lds);
+  const bool greedy = a.greedy != 0;
+  const bool wq_lds = lds_bytes(a.M, a.tied, true, greedy) <= kLdsMax;
+  int64_t lds = lds_bytes(a.M, a.tied, wq_lds, greedy);
+  if (lds > kLdsMax) {
+    comic_set_error("persistent decoder: %lld bytes of LDS needed", (long long)lds);
+    return 2;
+  }
   if (lds < kLdsMin) lds = kLdsMin;
   const int groups = a.n_groups;
   if (groups < 1 || groups > kMaxGroups || (a.grp0 + groups - 1) * kGroupRows >= a.B) {
@@ -523,11 +664,35 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   }
   const int nx = (a.E / 16 + kWaves - 1) / kWaves;                // x blocks per wave
   int rc = 2;
+  if (greedy) {
+    if (nx <= 1) rc = wq_lds ? launch<1, true, true>(a, groups, lds, st) : launch<1, false, true>(a, groups, lds, st);
+    else if (nx == 2) rc = wq_lds ? launch<2, true, true>(a, groups, lds, st) : launch<2, false, true>(a, groups, lds, st);
+    else if (nx <= 4) rc = wq_lds ? launch<4, true, true>(a, groups, lds, st) : launch<4, false, true>(a, groups, lds, st);
+    else comic_set_error("persistent decoder: word size %d not supported", a.E);
+    return rc;
+  }
   if (nx <= 1) rc = wq_lds ? launch<1, true>(a, groups, lds, st) : launch<1, false>(a, groups, lds, st);
   else if (nx == 2) rc = wq_lds ? launch<2, true>(a, groups, lds, st) : launch<2, false>(a, groups, lds, st);
   else if (nx <= 4) rc = wq_lds ? launch<4, true>(a, groups, lds, st) : launch<4, false>(a, groups, lds, st);
   else comic_set_error("persistent decoder: word size %d not supported", a.E);
   return rc;
+}
+
+// greedy decode: as the training loop, plus the logit columns in LDS (V <= 512: radix / char vocabularies), one launch
+bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, int Cv, int V, int method,
+                                    int context_layer, int tied) {
+  if (B > kMaxGroups * kGroupRows || V < 2 || V > 8 * kGroupWgs) return false;
+  if (!comic_persist_fwd_supported(B, D, E, A, M, H, Cv, method, context_layer, tied)) return false;
+  return lds_bytes(M, tied, false, true) <= kLdsMax;
+}
+
+__global__ void persist_check_greedy_kernel(const unsigned* err, int32_t* first_eos) {
+  if (err[0] != 0u) first_eos[0] = -1;
+}
+int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStream_t st) {
+  hipLaunchKernelGGL(persist_check_greedy_kernel, dim3(1), dim3(1), 0, st, sync, first_eos);
+  COMIC_LAUNCH_CHECK("persistent decoder check");
+  return 0;
 }
 
 int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st) {

@@ -14,6 +14,7 @@ constexpr int kMaxGroups = 4;         // groups of one launch (256 CUs); larger 
 constexpr int kMaxLaunches = 4;       // ... up to this many (beyond, the per-step kernels are better filled)
 constexpr int kD = 512;                // = 8 units per workgroup x 64 workgroups
 constexpr unsigned kSpinLimit = 1u << 20;
+constexpr int kArgRow = 132;           // greedy: floats per row of the partial-argmax hand-off: 64 x (value, column) + stop word
 constexpr int kSc1 = 16;               // cache-policy bit of raw buffer loads / stores: sc1
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;

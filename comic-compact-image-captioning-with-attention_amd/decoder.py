@@ -512,6 +512,8 @@ class Decoder:
                                                   ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()), 'decoder_greedy')
         self._run_infer(ctx, launch, use_graph)
         fe = ctx.first_eos.cpu().numpy()
+        if fe.min() < 0:                                  # comic_persist_check_greedy: a bounded wait of the loop expired
+            raise L.ComicHipError('greedy: the persistent decode loop did not complete (a wait on another workgroup timed out)')
         t_exec = int(min(max_steps, fe.max() + 1))       # loop ends when every row has emitted EOS
         out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
         hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()

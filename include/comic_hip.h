@@ -394,6 +394,9 @@ int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_pa
  * (csrc/decoder_persist_bwd.hip); 0 = per-step launches.  The choice depends on the shape (D = 512, B <= 64, ...), the
  * device (one workgroup per CU must be resident) and the COMIC_PERSIST / COMIC_PERSIST_BWD switches. */
 int comic_decoder_train_path(void);
+/* 1 when the LAST comic_decoder_greedy of this thread ran its loop as one persistent launch (D = 512, B <= 64,
+ * V <= 512, no context layer, a device with enough CUs, COMIC_PERSIST != 0), 0 for per-step launches. */
+int comic_decoder_greedy_path(void);
 
 /* Greedy decode (rnn_decoder_search, ops_rnn.py:115-180): runs `max_steps` steps on the
  * device without host sync; ids [max_steps,B], attn [max_steps,B,H,M]; finished-at step per

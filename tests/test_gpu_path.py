@@ -689,6 +689,39 @@ def test_greedy_and_beam_match_oracle(kw):
         assert_close(res['attn_hist'], hist, F32_RTOL, 'beam alignment history')
 
 
+@pytest.mark.parametrize('kw,B', [(dict(D=512, E=256), 5), (dict(D=512, E=128, method='dot', H=4, M=7), 37),
+                                  (dict(D=512, E=64, fm_projection='independent', prob='sigmoid', H=16), 64)])
+def test_persistent_greedy_loop_matches_oracle(kw, B, monkeypatch):
+    """Greedy decoding as ONE persistent launch (decoder_persist.hip, GREEDY: logit columns and their maxima in the
+    query phase, ids reduced by every workgroup, x third from the embedding table) against the oracle and against the
+    per-step launches: ids bit-exact, logits / attention maps at 1e-3; with a strong EOS bias the loop leaves early in
+    every group at the same step and the executed prefix is the oracle's; eager, captured and replayed."""
+    spec, cfg = _spec_and_cfg(**kw)
+    p = _rand_params(cfg, 5)
+    p['b_o'][spec.end_id] = 1.5
+    fm, im, _ = _batch(spec, B, 6, 21)
+    max_steps = 12
+    for eos_bias in (1.5, 9.0):
+        pe = dict(p); pe['b_o'] = p['b_o'].copy(); pe['b_o'][spec.end_id] = eos_bias
+        g_ids, g_logits, g_map = beam_ref.greedy_decode(pe, cfg, fm, im, max_steps)
+        if eos_bias == 9.0:
+            assert g_ids.shape[1] < max_steps, 'the early-exit case did not exit early'
+        dec = cdec.Decoder(spec, pe, DEV)
+        for _ in range(3):
+            ids, amap, logits = dec.greedy(dev(fm), dev(im), max_steps, want_logits=True)
+            np.testing.assert_array_equal(ids, g_ids)
+            assert_close(logits.cpu().numpy(), g_logits, F32_RTOL, 'greedy logits')
+            assert_close(amap.cpu().numpy(), g_map, F32_RTOL, 'greedy attention maps')
+        dec.greedy(dev(fm), dev(im), max_steps, use_graph=False)
+        assert dec.lib.comic_decoder_greedy_path() == 1            # the persistent loop really ran
+        monkeypatch.setenv('COMIC_PERSIST', '0')
+        ids0, amap0, logits0 = cdec.Decoder(spec, pe, DEV).greedy(dev(fm), dev(im), max_steps, want_logits=True)
+        monkeypatch.delenv('COMIC_PERSIST')
+        np.testing.assert_array_equal(ids0, ids)
+        assert_close(logits.cpu().numpy(), logits0.cpu().numpy(), 2e-5, 'persistent vs per-step logits')
+        assert_close(amap.cpu().numpy(), amap0.cpu().numpy(), 2e-5, 'persistent vs per-step attention maps')
+
+
 def test_train_step_full_batch_properties():
     """Full bench geometry (B=64, COMIC-256 on a 5x5x2048 map, T=29): (i) deterministic
     across two runs, (ii) rows are independent -- the per-row losses of a 64-batch equal
