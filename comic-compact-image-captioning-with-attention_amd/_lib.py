@@ -15,7 +15,7 @@ c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
 class CnnOp(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'kind', 'src', 'dst', 'src_coff', 'dst_coff', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'SH', 'SW',
-        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group', 'flags')]
+        'PT', 'PL', 'Ho', 'Wo', 'weight', 'relu', 'out_f32', 'src_f32', 'lane', 'tile', 'group', 'flags', 'min_lds')]
 
 
 class ImageDesc(C.Structure):           # struct comic_image_desc
@@ -35,7 +35,26 @@ class DecoderDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'D', 'E', 'A', 'V', 'C', 'Cg', 'H', 'M', 'Cv', 'fm_projection', 'method', 'prob', 'context_layer',
         'init_method', 'start_id', 'end_id')] + [(n, c_float) for n in (
-            'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')]
+            'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')] + [('flags', C.c_uint32)]
+
+
+# comic_decoder_desc.flags (include/comic_hip.h COMIC_DEC_*).  The library reads no environment: the A/B switches of
+# the decoder executors are environment variables of the PYTHON side, read at every call (tests flip them inside one
+# process) by decoder_flags_from_env() and handed over in the descriptor.
+DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS = (
+    1, 2, 4, 8, 16, 32, 64)
+_DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
+            ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
+            ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
+            ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS))
+
+
+def decoder_flags_from_env():
+    f = 0
+    for name, val, bit in _DEC_ENV:
+        if os.environ.get(name, '')[:1] == val:
+            f |= bit
+    return f
 
 
 CONV_TILES = 54          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
@@ -66,7 +85,6 @@ _SIGS = {
     'comic_pack_conv_weights': (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     'comic_fold_bn': (c_int, [P, P, P, c_float, P, P, c_int, P]),
     'comic_cnn_forward': (c_int, [P, c_int, P, P, P, c_int, c_int, P]),
-    'comic_conv_set_min_lds': (c_int, [c_int]),
     'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
     'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
     'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),
@@ -107,6 +125,7 @@ _SIGS = {
     'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
     'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_path': (c_int, []),
+    'comic_debug_inject_persist_timeout': (c_int, []),
     'comic_decoder_greedy_path': (c_int, []),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,

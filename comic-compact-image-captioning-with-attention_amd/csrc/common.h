@@ -97,3 +97,19 @@ __device__ __forceinline__ float group_sum_dpp(float v, int n) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// One-time-per-DEVICE latch (hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device's copy of a
+// kernel): slot() is the current device's flag; when the device cannot be told the flag reads false every time, i.e.
+// the attribute is set again before every launch.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool never = false;
+  bool& slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      never = false;
+      return never;
+    }
+    return done[dev];
+  }
+};

@@ -1005,20 +1005,19 @@ __global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_gr
     conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, false>(a, bm, bn);
 }
 
-// Lower bound on the dynamic LDS a DMA conv workgroup requests (comic_conv_set_min_lds).  84 KiB
-// admits one workgroup per CU instead of 2-3: a forward that runs on a second stream UNDER the
-// decoder step then leaves wave slots, registers and LDS for the latency-bound decoder kernels
-// (measured: forward alone 1.44 -> 1.79 ms, overlapped training step 3.67 -> 3.53 ms).
-static int g_conv_min_lds = 0;
-int conv_min_lds() { return g_conv_min_lds; }
+// comic_cnn_op::min_lds: lower bound on the dynamic LDS a DMA conv workgroup requests.  84 KiB admits one
+// workgroup per CU instead of 2-3: a forward that runs on a second stream UNDER the decoder step then leaves
+// wave slots, registers and LDS for the latency-bound decoder kernels (measured: forward alone 1.44 -> 1.79 ms,
+// overlapped training step 3.67 -> 3.53 ms).  Carried per op (ConvArgs::min_lds), no process state.
 
 #include "conv_patch.inc"
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
+int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st) {
   constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
-  const int lds = std::max(lds0, conv_min_lds());
-  static bool attr_set = false;
+  const int lds = std::max(lds0, min_lds);
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_igemm_dma_grouped_kernel<BM, BN, WM, WN, NSTAGE>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -1036,9 +1035,10 @@ template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
   static_assert(ring_stages(NSTAGE) >= 2 && ring_stages(NSTAGE) <= 4, "pipeline depth");
   constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
-  const int lds = std::max(lds0, conv_min_lds());
+  const int lds = std::max(lds0, a.min_lds);
   static_assert(lds0 <= 160 * 1024, "LDS");
-  static bool attr_set = false;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<BM, BN, WM, WN, NSTAGE, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -1144,42 +1144,42 @@ inline int im2col_tile_threads(int t) { return (t >= 29 && t <= 31) || t >= 35 ?
 inline int tile_bm(int t) { return t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
 inline int tile_bn(int t) { return t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
 
-int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total_blocks, hipStream_t st) {
+int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st) {
   switch (tile) {
-    case 26: return launch_dma_grouped<128, 128, 2, 2, 2>(args_dev, n, total_blocks, st);
-    case 27: return launch_dma_grouped<128, 192, 2, 2, 2>(args_dev, n, total_blocks, st);
-    case 28: return launch_dma_grouped<192, 128, 2, 2, 2>(args_dev, n, total_blocks, st);
-    case 29: return launch_dma_grouped<256, 128, 4, 2, 2>(args_dev, n, total_blocks, st);
-    case 30: return launch_dma_grouped<256, 192, 2, 4, 2>(args_dev, n, total_blocks, st);
-    case 31: return launch_dma_grouped<256, 256, 2, 4, 2>(args_dev, n, total_blocks, st);
-    case 32: return launch_dma_grouped<128, 160, 2, 2, 2>(args_dev, n, total_blocks, st);
-    case 33: return launch_dma_grouped<256, 64, 4, 1, 2>(args_dev, n, total_blocks, st);
-    case 34: return launch_dma_grouped<192, 96, 2, 2, 2>(args_dev, n, total_blocks, st);
-    case 35: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 36: return launch_dma_grouped<128, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 37: return launch_dma_grouped<128, 256, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 38: return launch_dma_grouped<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 39: return launch_dma_grouped<128, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 40: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 2>(args_dev, n, total_blocks, st);
-    case 41: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, st);
-    case 42: return launch_dma_grouped<160, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 43: return launch_dma_grouped<192, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 44: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 45: return launch_dma_grouped<64, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 46: return launch_dma_grouped<128, 64, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, st);
-    case 47: return launch_dma_grouped<64, 64, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, st);
-    case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
-    case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
-    case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, st);
-    case 4: return launch_dma_grouped<32, 64, 1, 4, 3>(args_dev, n, total_blocks, st);
-    case 5: return launch_dma_grouped<128, 32, 4, 1, 3>(args_dev, n, total_blocks, st);
-    case 6: return launch_dma_grouped<64, 128, 2, 2, 3>(args_dev, n, total_blocks, st);
-    case 7: return launch_dma_grouped<256, 64, 4, 1, 3>(args_dev, n, total_blocks, st);
-    case 8: return launch_dma_grouped<128, 64, 2, 2, 4>(args_dev, n, total_blocks, st);
-    case 9: return launch_dma_grouped<64, 64, 2, 2, 4>(args_dev, n, total_blocks, st);
-    case 10: return launch_dma_grouped<32, 64, 1, 4, 4>(args_dev, n, total_blocks, st);
-    case 11: return launch_dma_grouped<64, 128, 2, 2, 4>(args_dev, n, total_blocks, st);
-    case 12: return launch_dma_grouped<128, 32, 4, 1, 4>(args_dev, n, total_blocks, st);
+    case 26: return launch_dma_grouped<128, 128, 2, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 27: return launch_dma_grouped<128, 192, 2, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 28: return launch_dma_grouped<192, 128, 2, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 29: return launch_dma_grouped<256, 128, 4, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 30: return launch_dma_grouped<256, 192, 2, 4, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 31: return launch_dma_grouped<256, 256, 2, 4, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 32: return launch_dma_grouped<128, 160, 2, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 33: return launch_dma_grouped<256, 64, 4, 1, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 34: return launch_dma_grouped<192, 96, 2, 2, 2>(args_dev, n, total_blocks, min_lds, st);
+    case 35: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 36: return launch_dma_grouped<128, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 37: return launch_dma_grouped<128, 256, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 38: return launch_dma_grouped<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 39: return launch_dma_grouped<128, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 40: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 2>(args_dev, n, total_blocks, min_lds, st);
+    case 41: return launch_dma_grouped<128, 192, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, min_lds, st);
+    case 42: return launch_dma_grouped<160, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 43: return launch_dma_grouped<192, 160, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 44: return launch_dma_grouped<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 45: return launch_dma_grouped<64, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 46: return launch_dma_grouped<128, 64, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 47: return launch_dma_grouped<64, 64, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, min_lds, st);
+    case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 4: return launch_dma_grouped<32, 64, 1, 4, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 5: return launch_dma_grouped<128, 32, 4, 1, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 6: return launch_dma_grouped<64, 128, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 7: return launch_dma_grouped<256, 64, 4, 1, 3>(args_dev, n, total_blocks, min_lds, st);
+    case 8: return launch_dma_grouped<128, 64, 2, 2, 4>(args_dev, n, total_blocks, min_lds, st);
+    case 9: return launch_dma_grouped<64, 64, 2, 2, 4>(args_dev, n, total_blocks, min_lds, st);
+    case 10: return launch_dma_grouped<32, 64, 1, 4, 4>(args_dev, n, total_blocks, min_lds, st);
+    case 11: return launch_dma_grouped<64, 128, 2, 2, 4>(args_dev, n, total_blocks, min_lds, st);
+    case 12: return launch_dma_grouped<128, 32, 4, 1, 4>(args_dev, n, total_blocks, min_lds, st);
     default:
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
@@ -1355,15 +1355,6 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-int xcd_remap_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("COMIC_XCD_MAP");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
 int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels, void* y, int y_channels,
               const comic_conv_weight* wt, int batch) {
   a.x = x;
@@ -1387,7 +1378,8 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.tiles_m = 0;
   a.accum = 0;
   a.member_kind = 0;
-  a.remap = xcd_remap_enabled();
+  a.min_lds = std::min(std::max(op->min_lds, 0), 160 * 1024);
+  a.remap = 1;
   return 0;
 }
 
@@ -1697,8 +1689,8 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       }
       COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
       if (!is_im2col_tile(tile)) {
-        if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, lds_max, main_st)) return rc;
-      } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, main_st)) {
+        if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, std::max(lds_max, op->min_lds), main_st)) return rc;
+      } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, op->min_lds, main_st)) {
         return rc;
       }
       COMIC_LAUNCH_CHECK("grouped conv");
@@ -1744,12 +1736,6 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
                                   buf_channels[op->dst], wt, batch, dtype, (void*)st);
     if (rc) return rc;
   }
-  return 0;
-}
-
-extern "C" int comic_conv_set_min_lds(int bytes) {
-  COMIC_REQUIRE(bytes >= 0 && bytes <= 160 * 1024, "conv_set_min_lds: 0..163840 bytes");
-  g_conv_min_lds = bytes;
   return 0;
 }
 
@@ -2279,15 +2265,8 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
 }
 
 // workgroups per backward-weight launch that the pixel split aims for (every split adds one fp32
-// atomic pass over the filter; tunable for experiments with COMIC_WGRAD_BLOCKS)
-int wgrad_blocks_target() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("COMIC_WGRAD_BLOCKS");
-    v = e ? std::max(1, atoi(e)) : 1024;
-  }
-  return v;
-}
+// atomic pass over the filter; fewer splits measured slower)
+int wgrad_blocks_target() { return 1024; }
 
 template <typename T>
 int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,

@@ -315,7 +315,8 @@ int comic_stem_stream_launch(const ComicStemArgs& a, hipStream_t st) {
     return 2;
   }
   constexpr int lds = kTableFloats * 4 + 2 * kRing * kRowB;
-  static bool attr_set = false;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_stem_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {

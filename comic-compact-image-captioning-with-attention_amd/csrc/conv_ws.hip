@@ -272,7 +272,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ComicWsArgs a) {
 template <int KS, int NT>
 int launch_ws(const ComicWsArgs& a, hipStream_t st) {
   constexpr int lds = kWsTableBytes + 2 * ((KS + 1) / 2) * kWsRows * 128;
-  static bool attr_set = false;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_ws_kernel<KS, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {

@@ -12,6 +12,7 @@
 // (embedding lookup for all steps, output projection + cross-entropy as one batched GEMM,
 // all weight-gradient GEMMs batched over time), states are kept per step for the backward
 // pass instead of TF's TensorArray stack, and dropout masks are explicit inputs.
+#include <atomic>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -76,43 +77,31 @@ int comic_input_grad_fused(const float* dg, const float* K, const float* mask, f
 
 namespace {
 
-// COMIC_FUSED_STEP=0 keeps the split-K GEMM + element-wise kernel chain (A/B switch for profiling)
-// COMIC_SPLIT_ATTN_BWD=0 keeps one attention-backward workgroup per batch row (A/B measurements)
-bool split_attn_bwd_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("COMIC_SPLIT_ATTN_BWD");
-    v = (e && e[0] == '0') ? 0 : 1;
+// Executor switches come with the call (comic_decoder_desc::flags, COMIC_DEC_*): the library reads no environment.
+// The entry points latch them for the calling thread; the helpers below are what the executors consult.
+thread_local uint32_t g_dec_flags = 0;
+struct FlagScope {
+  explicit FlagScope(const comic_decoder_desc* d) {
+    g_dec_flags = d ? d->flags : 0u;
+    comic_persist_set_stamps((g_dec_flags & COMIC_DEC_STAMPS) != 0);
   }
-  return v == 1;
-}
-
-bool fused_step_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("COMIC_FUSED_STEP");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
-}
-
-// read at every call (tests flip it inside one process): COMIC_PERSIST=0 keeps the per-step launch chain
-bool persist_enabled() {
-  const char* e = getenv("COMIC_PERSIST");
-  return !(e && e[0] == '0');
-}
+  ~FlagScope() { comic_persist_set_stamps(false); }
+};
+bool split_attn_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_SPLIT_ATTN_BWD); }
+bool fused_step_enabled() { return !(g_dec_flags & COMIC_DEC_NO_FUSED_STEP); }
+bool persist_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST); }
+bool persist_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST_BWD); }
 
 // A second stream inside the training executor: the weight-gradient products after the backward loop are independent
 // chains of mid-sized GEMMs and small reductions; two lanes fill each other's tails and launch gaps
-// (COMIC_GRAD_LANES=0: one stream).  Fork / join with events, so a hipGraph capture of the step takes both lanes.
+// (COMIC_DEC_ONE_LANE: one stream).  Fork / join with events, so a hipGraph capture of the step takes both lanes.
 struct SideLane {
   hipStream_t s = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
 };
 SideLane* side_lane() {
   static SideLane lanes[64];
-  const char* e = getenv("COMIC_GRAD_LANES");
-  if (e && e[0] == '0') return nullptr;
+  if (g_dec_flags & COMIC_DEC_ONE_LANE) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideLane* L = &lanes[dev];
@@ -125,11 +114,6 @@ SideLane* side_lane() {
     }
   }
   return L;
-}
-
-bool persist_bwd_enabled() {
-  const char* e = getenv("COMIC_PERSIST_BWD");
-  return !(e && e[0] == '0');
 }
 
 #define RC(x)               \
@@ -477,14 +461,10 @@ inline int gemm(const float* A, const float* B, float* C, const float* bias, int
 
 // The time-batched products (hundreds of rows: keys, logits, d logits * W_o^T, every weight gradient) go
 // to the bf16 matrix cores with hi/lo-split operands (comic_gemm_f32_split3, product error ~2^-15); the
-// per-step products keep exact fp32 MFMAs.  COMIC_SPLIT3=0 selects the exact kernels everywhere.
+// per-step products keep exact fp32 MFMAs.  COMIC_DEC_EXACT_GEMM selects the exact kernels everywhere.
 inline int gemm_big(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                     int ldc, int ta, int tb, float beta, hipStream_t st) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("COMIC_SPLIT3");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
+  const bool on = !(g_dec_flags & COMIC_DEC_EXACT_GEMM);
   if (!on || (long)M * N < 64 * 256 || K < 64)
     return gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, beta, st);
   return comic_gemm_bf16x3_impl(A, B, C, bias, M, N, K, lda, ldb, ldc, ta, tb, 1.0f, beta, g_splitk_ws,
@@ -600,6 +580,10 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
 
 thread_local int g_train_path = 0;
 extern "C" int comic_decoder_train_path(void) { return g_train_path; }
+// fault injection for the tests of the end-of-step gate: the next comic_decoder_train_step that runs a persistent loop
+// behaves as if one of its bounded waits had expired (one shot)
+static std::atomic<int> g_inject_timeout{0};
+extern "C" int comic_debug_inject_persist_timeout(void) { g_inject_timeout.store(1); return 0; }
 thread_local int g_greedy_path = 0;
 extern "C" int comic_decoder_greedy_path(void) { return g_greedy_path; }
 
@@ -647,6 +631,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                                         float* loss_rows, float* map_loss, float* dfm, float* dim_embed,
                                         void* workspace, int64_t workspace_bytes, void* stream) {
   RC(check_desc(d));
+  FlagScope flag_scope__(d);
   COMIC_REQUIRE(p && gr && fm && im_embed && inputs_bt && targets_bt && wmask_bt && coef_bt && lens,
                 "train_step: null input");
   COMIC_REQUIRE(logits_tb && ids_tb && attn_hist && loss_rows && map_loss && workspace, "train_step: null output");
@@ -847,7 +832,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                        map_loss);
     COMIC_LAUNCH_CHECK("maploss");
   }
-  if (persist && !persist_b) RC(comic_persist_check(persist_sync, map_loss, st));
 
   // ------------------------------------------------------------------ backward -----------
   const bool use_map = d->map_loss_scale > 0.f;
@@ -882,7 +866,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       pb.n_groups = std::min(4, n_grp - g0);
       RC(comic_persist_bwd_launch(pb, st));
     }
-    RC(comic_persist_check(persist_sync, map_loss, st));
   } else if (attn_bwd_mode == 2) {
     RC(fill(dq_all, 0.f, (long)Tp * B * D, st));
     RC(fill(pgrad, 0.f, (long)Tp * B * (3 * D + 1), st));
@@ -994,6 +977,26 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   if (L)
     COMIC_REQUIRE(hipEventRecord(L->join, sb) == hipSuccess && hipStreamWaitEvent(st, L->join, 0) == hipSuccess,
                   "train_step: cannot join the gradient lane");
+  if (persist) {
+    // a persistent loop that timed out leaves garbage everywhere: NaN losses and zero gradients (no host check needed
+    // for the optimiser step that follows to be harmless; the host raises at its next look at the loss)
+    ComicGateRanges gr_{};
+    int k = 0;
+    auto add = [&](float* ptr, long n) {
+      if (ptr && n > 0 && k < 16) { gr_.p[k] = ptr; gr_.n[k] = n; ++k; }
+    };
+    add(gr->W_init, (long)d->Cg * n_init); add(gr->K, (long)Wd * 4 * D); add(gr->b, 4L * D);
+    add(gr->W_m, (long)d->C * D);
+    if (d->fm_projection == 1) add(gr->W_v, (long)d->C * D);
+    add(gr->W_q, (long)D * D);
+    if (d->method == 0) { add(gr->v, D); add(gr->ln_g, D); add(gr->ln_b, D); add(gr->tau, 1); }
+    if (d->context_layer) add(gr->W_a, (long)Cv * D);
+    add(gr->W_o, (long)D * V); add(gr->b_o, V); add(gr->emb, (long)V * E);
+    add(dfm, (long)B * M * d->C); add(dim_embed, (long)B * d->Cg);
+    if (g_inject_timeout.exchange(0) != 0)       // comic_debug_inject_persist_timeout: raise the error word by hand
+      COMIC_REQUIRE(hipMemsetAsync(persist_sync, 0xFF, sizeof(unsigned), st) == hipSuccess, "train_step: memset");
+    RC(comic_persist_gate(persist_sync, loss_rows, map_loss, gr_, st));
+  }
   COMIC_LAUNCH_CHECK("train_step");
   return 0;
 }
@@ -1089,6 +1092,7 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
                                     float* attn_hist, int32_t* first_eos, void* workspace, int64_t workspace_bytes,
                                     void* stream) {
   RC(check_desc(d));
+  FlagScope flag_scope__(d);
   COMIC_REQUIRE(p && fm && im_embed && ids_tb && attn_hist && first_eos && workspace, "greedy: null pointer");
   COMIC_REQUIRE(B > 0 && max_steps > 0, "greedy: bad shape");
   COMIC_REQUIRE(workspace_bytes >= comic_decoder_infer_workspace(d, B, max_steps), "greedy: workspace too small");
@@ -1190,6 +1194,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
                                   float* attn_hist, int32_t* steps_executed, void* workspace, int64_t workspace_bytes,
                                   void* stream) {
   RC(check_desc(d));
+  FlagScope flag_scope__(d);
   COMIC_REQUIRE(p && fm && im_embed && step_ids && parent_ids && scores && lengths && finished && attn_hist &&
                     steps_executed && workspace,
                 "beam: null pointer");

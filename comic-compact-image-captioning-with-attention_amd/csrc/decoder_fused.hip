@@ -613,17 +613,8 @@ int comic_lstm_step_fused(const float* xh, int ld_xh, const float* K, const floa
   a.stop_t = g_comic_stop.t;
   // rows per workgroup: 16 keeps the most workgroups in flight and measured fastest at 64 rows (training)
   // and at 150-224 rows (beam search); 32 / 64 stay selectable for experiments
-  static int mt_env = -1;
-  if (mt_env < 0) {
-    const char* e = getenv("COMIC_LSTM_MT");
-    mt_env = e ? atoi(e) : 0;
-  }
-  const int mt = mt_env > 0 ? mt_env : 1;
-  static int nt_env = -1;
-  if (nt_env < 0) {
-    const char* e = getenv("COMIC_LSTM_NT");
-    nt_env = e ? atoi(e) : 2;   // 2 adjacent unit tiles per workgroup measured fastest (training and beam search)
-  }
+  constexpr int mt = 1;
+  constexpr int nt_env = 2;     // 2 adjacent unit tiles per workgroup measured fastest (training and beam search)
   if (nt_env == 4) {
     hipLaunchKernelGGL(lstm_step_fused_wide_kernel<4>, dim3(cdiv(D / 4, 4), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);
   } else if (nt_env == 2) {
@@ -645,11 +636,7 @@ int comic_input_grad_fused(const float* dg, const float* K, const float* mask, f
   COMIC_REQUIRE(D % 4 == 0 && ((uintptr_t)dg & 15) == 0 && ((uintptr_t)K & 15) == 0,
                 "input_grad_fused: D must be a multiple of 4 and the operands 16-byte aligned");
   InputGradArgs a{dg, K, mask, keep, demb, datt, dh, lens, t, carry, B, E, A, D};
-  static int nt = -1;
-  if (nt < 0) {
-    const char* e = getenv("COMIC_IGRAD_NT");
-    nt = e ? atoi(e) : 2;
-  }
+  constexpr int nt = 2;
   const int tiles = cdiv(E + A + D, 16);
   if (nt == 4)
     hipLaunchKernelGGL(input_grad_fused_wide_kernel<4>, dim3(cdiv(tiles, 4), cdiv(B, 16)), dim3(kFusedThreads), 0, st, a);

@@ -64,8 +64,16 @@ bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, in
 int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStream_t st);
 bool comic_persist_fits_device(int B);   // CUs of the current device >= workgroups of the launch
 int comic_persist_fwd_launch(const ComicPersistFwdArgs& a, hipStream_t st);
-// poisons loss[0] with NaN when a bounded spin of the last launch expired (its outputs are then garbage)
-int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st);
+// End-of-step gate: when a bounded spin of one of the step's persistent launches expired (the error word of `sync`
+// is set: the step's activations and gradients are garbage), loss_rows[0] and map_loss[0] become NaN -- so both the
+// sequence loss the host reduces from loss_rows and the map loss read NaN -- and every range of `r` (the gradient
+// views, dfm, dim_embed) is zero-filled, so an optimiser step that follows without a host check applies no gradient.
+// A healthy step costs one launch whose workgroups read the error word and return.
+struct ComicGateRanges {
+  float* p[16];
+  long n[16];
+};
+int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, hipStream_t st);
 
 // ---- backward loop (decoder_persist_bwd.hip) ---------------------------------------------------------------------------
 struct ComicPersistBwdArgs {
@@ -108,5 +116,6 @@ struct ComicPersistBwdArgs {
 bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,
                                  int context_layer, int tied);
 unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st);
+void comic_persist_set_stamps(bool on);   // diagnostic phase clocks for this thread's launches (COMIC_DEC_STAMPS)
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a, hipStream_t st);
 int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st);

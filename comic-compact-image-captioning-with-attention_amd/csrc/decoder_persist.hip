@@ -35,7 +35,7 @@
 // 24.7 us step three times over (measured, profiles/r02_persist_phases.txt); a validated load costs one more round
 // trip only when the data is late.  Data that only later kernels read (saved gates, alpha, ...) uses plain stores.
 // Every spin is bounded: a wave that polls more than kSpinLimit times raises the error word, every wave that sees it
-// stops waiting, and comic_persist_check poisons the step's loss with NaN so that the host sees it.  One workgroup
+// stops waiting, and comic_persist_gate (end of the step) turns the step's losses into NaN and its gradients into zeros.  One workgroup
 // per CU (the launch reserves more than half of the LDS): with 256 CUs all workgroups of a launch are resident.
 #include <stdio.h>
 #include <stdlib.h>
@@ -568,8 +568,17 @@ __global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync) {
   }
 }
 
-__global__ void persist_check_kernel(const unsigned* err, float* loss) {
-  if (err[0] != 0u) loss[0] = __int_as_float(0x7fc00000);
+__global__ __launch_bounds__(256) void persist_gate_kernel(const unsigned* err, float* loss_rows, float* map_loss,
+                                                           ComicGateRanges r) {
+  if (err[0] == 0u) return;                       // uniform over the launch: a healthy step ends here
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    loss_rows[0] = __int_as_float(0x7fc00000);
+    map_loss[0] = __int_as_float(0x7fc00000);
+  }
+  const long stride = (long)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (int k = 0; k < 16; ++k)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n[k]; i += stride) r.p[k][i] = 0.f;
 }
 
 int64_t lds_bytes(int M, int tied, bool wq_lds, bool greedy = false) {
@@ -583,7 +592,8 @@ constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at mos
 template <int NX, bool WQ_LDS, bool GREEDY = false>
 int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st) {
   auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS, GREEDY>;
-  static bool attr_set = false;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax) != hipSuccess) {
       comic_set_error("persistent decoder: cannot reserve LDS");
@@ -608,19 +618,17 @@ bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int C
   return lds_bytes(M, tied, false) <= kLdsMax;
 }
 
-// COMIC_PERSIST_STAMPS=1: print the previous launch's mean phase times (a host synchronisation per launch: diagnostic).
+// COMIC_DEC_STAMPS (comic_decoder_desc::flags; Python: COMIC_PERSIST_STAMPS=1): print the previous launch's mean phase times (a host synchronisation per launch: diagnostic).
 // which = 0 forward loop, 1 backward loop; workgroup 0 stores eight 100 MHz clock values per step.
+static thread_local bool g_stamps_on = false;
+void comic_persist_set_stamps(bool on) { g_stamps_on = on; }
 unsigned long long* comic_persist_stamps(int which, int Tp, hipStream_t st) {
-  static int on = -1;
+  const bool on = g_stamps_on;
   static unsigned long long* dev[2] = {nullptr, nullptr};
   static int prev_tp[2] = {0, 0};
   static const char* names[2][8] = {
       {"att-wait+L", "L-epi", "y-wait+Q", "L-xh+q-wait", "scores", "prob", "ctx", "(masks)"},
       {"A'", "dq-sum", "dq-gather+dyq", "cell", "dg-stores", "sync", "dg-wait+I", "I-epi"}};
-  if (on < 0) {
-    const char* e = getenv("COMIC_PERSIST_STAMPS");
-    on = (e && e[0] == '1') ? 1 : 0;
-  }
   if (!on) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // the read-back synchronises: never inside a graph capture
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
@@ -722,8 +730,8 @@ bool comic_persist_fits_device(int B) {
   return cus[dev] >= (groups < kMaxGroups ? groups : kMaxGroups) * kGroupWgs;
 }
 
-int comic_persist_check(const unsigned* sync, float* loss, hipStream_t st) {
-  hipLaunchKernelGGL(persist_check_kernel, dim3(1), dim3(1), 0, st, sync, loss);
-  COMIC_LAUNCH_CHECK("persistent decoder check");
+int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, hipStream_t st) {
+  hipLaunchKernelGGL(persist_gate_kernel, dim3(128), dim3(256), 0, st, sync, loss_rows, map_loss, r);
+  COMIC_LAUNCH_CHECK("persistent decoder gate");
   return 0;
 }

@@ -534,7 +534,8 @@ int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(1, a.Tp, st) : nullptr;
   int64_t lds = bwd_lds_bytes(a.M);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
-  static bool attr_set = false;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)decoder_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {

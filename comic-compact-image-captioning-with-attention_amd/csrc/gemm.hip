@@ -695,11 +695,8 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
   a.stop = g_comic_stop.p;
   a.stop_t = g_comic_stop.t;
   const long blocks128 = (long)cdiv(M, 128) * cdiv(N, 128);
-  static int big_min = -1;     // COMIC_X3_BIG_MIN: 128-row tiles from this many 128 x 128 output blocks on
-  if (big_min < 0) {
-    const char* e = getenv("COMIC_X3_BIG_MIN");
-    big_min = e ? atoi(e) : 40;      // measured on the decoder step's products: 314 -> 288 us per step against 200
-  }
+  constexpr int big_min = 40;  // 128-row tiles from this many 128 x 128 output blocks on (measured on the decoder step's
+                               // products: 314 -> 288 us per step against 200)
   const bool big = blocks128 >= big_min;
   const long tiles = big ? blocks128 : (long)cdiv(M, 64) * cdiv(N, 128);
   int S = 1;

@@ -118,6 +118,7 @@ class DecoderSpec:
         d.keep_out = 1.0 - self.dropout_rnn_out if training else 1.0
         d.keep_alpha = self.attn_keep_prob if training else 1.0
         d.map_loss_scale = self.map_loss_scale
+        d.flags = L.decoder_flags_from_env()
         return d
 
 
@@ -337,6 +338,7 @@ class Decoder:
         BT = B * T
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()
+        ctx.desc.flags = L.decoder_flags_from_env()
         L.check(self.lib.comic_decoder_train_step(
             C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm_in.data_ptr(), ctx.im_in.data_ptr(),
             i32.data_ptr(), i32.data_ptr() + 4 * BT, f32.data_ptr(), f32.data_ptr() + 4 * BT,
@@ -506,6 +508,7 @@ class Decoder:
         ctx = self._infer_ctx('greedy', B, 1, max_steps, want_logits, fm, im_embed)
 
         def launch():
+            ctx.desc.flags = L.decoder_flags_from_env()
             L.check(self.lib.comic_decoder_greedy(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(),
                                                   ctx.im.data_ptr(), B, max_steps, ctx.ids.data_ptr(),
                                                   L.ptr(ctx.logits), ctx.hist.data_ptr(), ctx.first_eos.data_ptr(),
@@ -529,6 +532,7 @@ class Decoder:
         ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed)
 
         def launch():
+            ctx.desc.flags = L.decoder_flags_from_env()
             L.check(self.lib.comic_decoder_beam(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(),
                                                 ctx.im.data_ptr(), B, W, max_steps, ctx.step_ids.data_ptr(),
                                                 ctx.parent_ids.data_ptr(), ctx.scores.data_ptr(),

@@ -603,10 +603,25 @@ class CnnEncoder:
         self._build_group_args()
         self._graph = None
         self._calls = 0
-        # > 0: conv workgroups request at least this much LDS (1 per CU at 84) -- for forwards that run on a
-        # second stream under other kernels (CaptionTrainer's overlapped encoder); set before the graph capture
-        self.polite_lds_kb = 0
+        self._polite_lds_kb = 0
         self._fm_f32 = None
+
+    @property
+    def polite_lds_kb(self):
+        """> 0: conv workgroups request at least this much LDS (1 per CU at 84) -- for forwards that run on a
+        second stream under other kernels (CaptionTrainer's overlapped encoder).  Written into every op record
+        (comic_cnn_op.min_lds); a captured graph is dropped because its launches hold the old value."""
+        return self._polite_lds_kb
+
+    @polite_lds_kb.setter
+    def polite_lds_kb(self, kb):
+        kb = int(kb)
+        if kb == self._polite_lds_kb:
+            return
+        self._polite_lds_kb = kb
+        for i in range(len(self.plan.ops)):
+            self._ops[i].min_lds = kb * 1024
+        self._graph, self._calls = None, 0
 
     def load_params(self, params):
         """(Re)load every CNN variable from {slim name: array} into the flat masters IN PLACE (all
@@ -790,16 +805,6 @@ class CnnEncoder:
         torch.cuda.synchronize()
 
     def _run(self):
-        if self.polite_lds_kb:
-            L.check(self.lib.comic_conv_set_min_lds(self.polite_lds_kb * 1024), 'conv_set_min_lds')
-            try:
-                self._run_plan()
-            finally:
-                L.check(self.lib.comic_conv_set_min_lds(0), 'conv_set_min_lds')
-        else:
-            self._run_plan()
-
-    def _run_plan(self):
         if self._group_args is not None:
             L.check(self.lib.comic_cnn_forward_grouped(self._ops, len(self.plan.ops), self._bufptr, self._bufch,
                                                        self._wt, self.batch, self.dcode,
@@ -868,12 +873,7 @@ class CnnEncoder:
                     self._build_group_args()
                 self._graph, self._calls = None, 0
                 return {i: (None, t) for i, t in enumerate(tiles)}
-        if self.polite_lds_kb:        # tune under the occupancy the forward will run with
-            L.check(self.lib.comic_conv_set_min_lds(self.polite_lds_kb * 1024), 'conv_set_min_lds')
-        try:
-            chosen = self._autotune(reps, verbose, torch, st)
-        finally:
-            L.check(self.lib.comic_conv_set_min_lds(0), 'conv_set_min_lds')
+        chosen = self._autotune(reps, verbose, torch, st)      # op.min_lds: tuned under the occupancy the forward runs with
         if cache:
             db = json.load(open(cache)) if os.path.isfile(cache) else {}
             db[self._tune_key()] = [int(self._ops[i].tile) for i in range(len(self.plan.ops))]

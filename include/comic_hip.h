@@ -99,6 +99,9 @@ typedef struct comic_cnn_op {
                         them as one launch */
   int32_t flags;     /* bit 0 (COMIC_OP_RAW), conv: store the raw product (no BatchNorm, no ReLU);
                         the epilogue is applied by a later kind-7 op */
+  int32_t min_lds;   /* conv, bf16 plans: lower bound (bytes, 0 = off) on the dynamic LDS the op's workgroups request --
+                        an occupancy knob for forwards that share the GPU with other kernels (84 KiB = one conv
+                        workgroup per CU).  A grouped launch takes the value of its first member. */
 } comic_cnn_op;
 #define COMIC_OP_RAW 1
 #define COMIC_OP_POOLED_SRC 2   /* bit 1, 1x1 conv of a bf16 plan: the conv reads its source through a 3x3 / stride-2 VALID
@@ -117,11 +120,6 @@ typedef struct comic_conv_weight {
 int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
                       int dtype, void* stream);
-
-/* Occupancy knob for forwards that share the GPU with other work: lower bound (bytes, 0 = off) on the
- * LDS a bf16 conv workgroup requests; 84 KiB = one conv workgroup per CU.  Process-wide; launches
- * captured in a hipGraph keep the value they were captured with. */
-int comic_conv_set_min_lds(int bytes);
 
 /* Grouped execution of the same plan (bf16 plans): every run of ops with the same non-zero
  * `group` becomes ONE launch whose workgroups are spread over all member convolutions (a
@@ -356,7 +354,16 @@ typedef struct comic_decoder_desc {
   int32_t start_id, end_id;
   float keep_in, keep_out, keep_alpha; /* 1.0 disables the dropout */
   float map_loss_scale;
+  uint32_t flags;                      /* COMIC_DEC_* executor switches, 0 = every fast path on (A/B measurements and tests;
+                                          results agree to fp32 summation order).  The library reads no environment. */
 } comic_decoder_desc;
+#define COMIC_DEC_NO_PERSIST 1u         /* time loops as per-step launches (forward and backward; greedy too) */
+#define COMIC_DEC_NO_PERSIST_BWD 2u     /* backward time loop as per-step launches */
+#define COMIC_DEC_NO_FUSED_STEP 4u      /* split-K GEMM + element-wise kernel chain instead of the fused step kernels */
+#define COMIC_DEC_NO_SPLIT_ATTN_BWD 8u  /* one attention-backward workgroup per batch row */
+#define COMIC_DEC_ONE_LANE 16u          /* no second stream inside the training executor */
+#define COMIC_DEC_EXACT_GEMM 32u        /* exact-fp32 MFMA for the time-batched products (no hi/lo-split bf16) */
+#define COMIC_DEC_STAMPS 64u            /* diagnostic phase clocks of the persistent loops (host sync per launch) */
 
 /* Parameter (or gradient) table; every pointer is a view into one flat fp32 buffer. */
 typedef struct comic_decoder_params {
@@ -378,7 +385,9 @@ int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int
  * The forward and the backward time loop each run as ONE persistent launch per 64 batch rows when the shape allows
  * (D = 512, B <= 256, no context layer; backward: tied keys/values, softmax, M <= 28; a device with >= 256 CUs), as
  * per-step launches otherwise: same results to fp32 summation order (comic_decoder_train_path tells which).  If a
- * bounded wait inside a persistent loop ever expires, map_loss (and with it the loss) is NaN. */
+ * bounded wait inside a persistent loop ever expires, the step's results are void and the call says so in its
+ * outputs: loss_rows[0] and map_loss[0] are NaN (the sequence loss reduced from loss_rows is then NaN too) and every
+ * gradient (grads, dfm, dim_embed) is zero, so an optimiser step issued without a host check applies no gradient. */
 int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_params* p,
                              const comic_decoder_params* grads, const float* fm,
                              const float* im_embed, const int32_t* inputs_bt,
@@ -394,6 +403,9 @@ int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_pa
  * (csrc/decoder_persist_bwd.hip); 0 = per-step launches.  The choice depends on the shape (D = 512, B <= 64, ...), the
  * device (one workgroup per CU must be resident) and the COMIC_PERSIST / COMIC_PERSIST_BWD switches. */
 int comic_decoder_train_path(void);
+/* Test hook (fault injection): the next comic_decoder_train_step that runs a persistent loop reports a loop timeout
+ * (NaN loss_rows[0] / map_loss, zero gradients) although its kernels completed.  One shot. */
+int comic_debug_inject_persist_timeout(void);
 /* 1 when the LAST comic_decoder_greedy of this thread ran its loop as one persistent launch (D = 512, B <= 64,
  * V <= 512, no context layer, a device with enough CUs, COMIC_PERSIST != 0), 0 for per-step launches. */
 int comic_decoder_greedy_path(void);

@@ -31,10 +31,26 @@ def rel_err(got, ref):
     return float(np.abs(got - ref).max() / denom)
 
 
-def assert_close(got, ref, tol=F32_RTOL, name=''):
+def elementwise_excess(got, ref, tol):
+    """Element-wise criterion beside the max-norm one: |a - b| <= tol*|b| + tol*rms(b) for EVERY element.  (With
+    max|b| as the absolute term the bound would be implied by the max-norm check; the root mean square is the typical
+    magnitude of the tensor, so an element may not hide behind one large outlier of its tensor.)  Returns the largest
+    |a - b| / (tol*|b| + tol*rms(b)); <= 1 passes."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    if not got.size:
+        return 0.0
+    bound = tol * np.abs(ref) + tol * (np.sqrt(np.mean(ref * ref)) + 1e-30)
+    return float((np.abs(got - ref) / bound).max())
+
+
+def assert_close(got, ref, tol=F32_RTOL, name='', elementwise=True):
     e = rel_err(got, ref)
     assert np.isfinite(np.asarray(got, np.float64)).all(), '%s: non-finite values' % name
     assert e <= tol, '%s: rel err %.3e > %.1e (max|ref| %.3e)' % (name, e, tol, np.abs(ref).max())
+    if elementwise:
+        x = elementwise_excess(got, ref, tol)
+        assert x <= 1.0, '%s: element-wise |a-b| is %.2f x (tol*|b| + tol*rms(b)), tol %.1e' % (name, x, tol)
     return e
 
 

@@ -458,6 +458,64 @@ def test_persistent_time_loop_equals_step_launches(B, monkeypatch):
             assert abs(g['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
 
 
+@pytest.mark.parametrize('B', [64, 224])
+def test_persistent_loops_match_oracle_at_bench_geometry(B):
+    """The persistent forward and backward time loops against the ORACLE (not against the per-step launches) at the
+    geometry bench.py times -- COMIC-256: D = 512, E = 256, C = 2048, M = 25, 8 heads, tied, T' = 29, every dropout on
+    with injected masks -- at batch 64 (four 16-row groups in one launch) and at the SCST step's 224 hypotheses (four
+    consecutive launches).  Same 1e-3 bar as the small cases, max-norm and element-wise."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    Lc = 31                                               # row 0 has the longest caption: T' = Lc - 2 = 29
+    p = _rand_params(cfg, 13)
+    fm, im, caps = _batch(spec, B, Lc, 17)
+    _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+    assert int(lens.max()) == 29
+    masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, 19)
+    cfg.l2_decay = 0.0
+    out = dr.train_forward(p, cfg, fm, im, caps, masks, None)
+    grads, dfm, dim = dr.train_backward(p, cfg, out)
+    dec = cdec.Decoder(spec, p, DEV)
+    res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+    sync()
+    assert dec.lib.comic_decoder_train_path() == 3        # both loops ran as persistent launches
+    assert_close(res['logits'].cpu().numpy(), out['logits'], F32_RTOL, 'logits')
+    assert_close(res['attn_maps'].cpu().numpy(), out['attn_maps'], F32_RTOL, 'attn_maps')
+    assert abs(float(res['loss']) - float(out['xe'])) <= F32_RTOL * abs(float(out['xe']))
+    assert abs(float(res['map_loss']) - float(out['map_loss'])) <= F32_RTOL * abs(float(out['map_loss'])) + 1e-7
+    g = dec.grads.to_numpy()
+    for k in grads:
+        assert_close(g[k], grads[k], F32_RTOL, 'grad ' + k)
+    assert_close(res['dfm'].cpu().numpy(), dfm, F32_RTOL, 'dfm')
+    assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
+
+
+def test_persistent_loop_timeout_voids_the_step():
+    """A bounded wait of a persistent loop that expires must not train on garbage: the executor's last
+    launch turns the step's losses into NaN and every gradient into zeros (comic_persist_gate), so the fused Adam that
+    follows without a host check applies no gradient, and the host sees NaN at its next look at the loss.  The timeout
+    is injected (comic_debug_inject_persist_timeout); the step before and the step after are healthy."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    B, Lc = 32, 12
+    dec = cdec.Decoder(spec, _rand_params(cfg, 6), DEV)
+    fm, im, caps = _batch(spec, B, Lc, 43)
+    _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+    masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, 43)
+    good = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+    sync()
+    assert dec.lib.comic_decoder_train_path() == 3
+    want = (float(good['loss']), dec.grads.data.clone(), good['dfm'].clone())
+    assert np.isfinite(want[0]) and float(want[1].abs().max()) > 0
+    assert dec.lib.comic_debug_inject_persist_timeout() == 0
+    bad = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+    sync()
+    assert np.isnan(float(bad['loss'])) and np.isnan(float(bad['map_loss']))
+    assert float(dec.grads.data.abs().max()) == 0.0
+    assert float(bad['dfm'].abs().max()) == 0.0 and float(bad['dim_embed'].abs().max()) == 0.0
+    again = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)   # one shot
+    sync()
+    assert float(again['loss']) == want[0] and torch.equal(dec.grads.data, want[1]) and torch.equal(again['dfm'], want[2])
+
+
 @pytest.mark.parametrize('kw,B,Lc', [
     (dict(E=64, H=4, M=1), 1, 4),                                  # one row, one memory row, one x block per wave
     (dict(E=512, H=16, M=28), 17, 9),                              # second group holds a single row; widest x third

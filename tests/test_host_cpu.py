@@ -34,11 +34,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.comic_abi_version() == 1
 
 
+def test_library_reads_no_environment():
+    """no hidden process state behind the boundary -- the executors' A/B switches travel in
+    comic_decoder_desc.flags / comic_cnn_op.min_lds, and libcomic_hip.so imports no getenv."""
+    import subprocess
+    und = subprocess.run(['nm', '-D', '--undefined-only', L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'getenv' not in und, [l for l in und.splitlines() if 'getenv' in l]
+
+
+def test_decoder_flags_follow_the_python_environment(monkeypatch):
+    for k in ('COMIC_PERSIST', 'COMIC_PERSIST_BWD', 'COMIC_FUSED_STEP', 'COMIC_SPLIT_ATTN_BWD', 'COMIC_GRAD_LANES',
+              'COMIC_SPLIT3', 'COMIC_PERSIST_STAMPS'):
+        monkeypatch.delenv(k, raising=False)
+    assert L.decoder_flags_from_env() == 0
+    monkeypatch.setenv('COMIC_PERSIST', '0')
+    monkeypatch.setenv('COMIC_SPLIT3', '0')
+    assert L.decoder_flags_from_env() == L.DEC_NO_PERSIST | L.DEC_EXACT_GEMM
+    monkeypatch.setenv('COMIC_PERSIST', '1')
+    monkeypatch.setenv('COMIC_PERSIST_STAMPS', '1')
+    assert L.decoder_flags_from_env() == L.DEC_EXACT_GEMM | L.DEC_STAMPS
+    header = open(os.path.join(ROOT, 'include', 'comic_hip.h')).read()
+    for name, val in (('NO_PERSIST', L.DEC_NO_PERSIST), ('NO_PERSIST_BWD', L.DEC_NO_PERSIST_BWD),
+                      ('NO_FUSED_STEP', L.DEC_NO_FUSED_STEP), ('NO_SPLIT_ATTN_BWD', L.DEC_NO_SPLIT_ATTN_BWD),
+                      ('ONE_LANE', L.DEC_ONE_LANE), ('EXACT_GEMM', L.DEC_EXACT_GEMM), ('STAMPS', L.DEC_STAMPS)):
+        assert int(re.search(r'#define COMIC_DEC_%s (\d+)u' % name, header).group(1)) == val
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
-    assert C.sizeof(L.CnnOp) == 25 * 4
+    assert C.sizeof(L.CnnOp) == 26 * 4                    # ... flags, min_lds
     assert C.sizeof(L.AttnDesc) == 8 * 4
-    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4
+    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4  # ... map_loss_scale, flags
     assert C.sizeof(L.DecoderParams) == 14 * 8
     assert C.sizeof(L.ConvWeight) == 3 * 8
 
