@@ -337,10 +337,17 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
                          '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    # COMIC_DIST_BACKEND=gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (gloo moves CUDA tensors through the
+    # host; ranks share the visible devices round-robin).  The driver's scaling runs use the default: nccl = RCCL.
+    backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
+    local_rank %= max(1, torch.cuda.device_count()) if backend != 'nccl' else (local_rank + 1)
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     from comic_amd import decoder as cdec, nets, trainer
     dp = trainer.DataParallel(dist if world > 1 else None)

@@ -344,7 +344,10 @@ class CaptionModel(ModelBase):
         if getattr(self, '_pipe', None) is None:
             from .trainer import EncoderPipeline
             import collections
-            group = max(1, int(getattr(self._config, 'encoder_group', 1)))
+            group = int(getattr(self._config, 'encoder_group', 1) or 0)
+            if group <= 0:                 # --encoder_group 0: auto
+                group = auto_encoder_group(self._batch_size)
+                group = max(1, min(group, int(getattr(self._config, 'max_step', group)) - int(self.global_step)))
             enc = self._encoder_for(self._batch_size * group)
             enc.polite_lds_kb = int(getattr(self._config, 'encoder_polite_lds_kb', 84))   # see CaptionTrainer.enable_overlap
             self._pipe = EncoderPipeline(enc, self._batch_size, group, self.device)
@@ -405,6 +408,14 @@ class CaptionModel(ModelBase):
         ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
         self.infer_output = [ids, attn]
         return self.infer_output
+
+
+def auto_encoder_group(batch_size, images_per_forward=1280, cap=64):
+    """Steps per encoder forward when `--encoder_group 0` (auto): enough images per forward to fill the conv tiles
+    (the InceptionV3 forward runs at twice the MFMA rate at 1280 images than at 64 -- DESIGN.md section 5), capped so
+    that the activation buffers of one forward stay around 16 GB.  bench.py's pick_encoder_group applies the same size
+    to its timed step count."""
+    return max(1, min(cap, images_per_forward // max(1, int(batch_size))))
 
 
 class CaptionModel_SCST(ModelBase):

@@ -79,6 +79,7 @@ def _train_loop(inputs_man, device, dp):
             speed = (step + 1 - start_step) * c.batch_size_train / t
             print('   Training speed: {:7.2f} examples/sec.'.format(speed))
         elif (step + 1) % n_steps_log == 0:
+            _check_loss(ppl, global_step)
             logstr = 'Epoch {:2d} ~~ {:6.2f} %  ~  '.format(epoch, ((step % num_batches) + 1) / num_batches * 100)
             logstr += 'Perplexity {:8.4f} ~ LR {:5.3e} ~ '.format(float(np.exp(float(ppl))), m_train.lr)
             logstr += 'Step {}'.format(global_step)
@@ -167,6 +168,7 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
             logstr += '\n   top beam: \t\t`{}`\n'.format(hypos[0][0])
             print(logstr)
         elif (step + 1) % n_steps_log == 0:
+            _check_loss(ppl, global_step)
             logstr = '   Epoch {:2d} ~~ {:6.2f} %  ~  '.format(epoch, ((step % num_batches) + 1) / num_batches * 100)
             logstr += 'Greedy score {:8.4f} ~ Loss {:8.4f} ~ LR {:5.3e} ~ Step {}'.format(
                 np.mean(sc_greedy), float(ppl), m_train.lr, global_step)
@@ -195,6 +197,17 @@ def _lr_reduce_check(config, epoch, learning_rate):
         if learning_rate < config.lr_end:
             learning_rate = config.lr_end
     return learning_rate
+
+
+def _check_loss(loss, step):
+    """Log points are where the host looks at the loss (one device sync per `num_logs_per_epoch`-th of an epoch): a NaN
+    there is either a diverged run or a step the device voided -- comic_decoder_train_step turns its losses into NaN
+    and its gradients into zeros when a bounded wait of a persistent time loop expired (include/comic_hip.h), so nothing
+    was trained on garbage.  Either way the run stops here; try_to_train writes the error file."""
+    v = float(loss)
+    if not np.isfinite(v):
+        raise RuntimeError('step {}: the training loss is {} -- diverged, or a persistent decoder loop timed out and the '
+                           'device voided the step (retry with COMIC_PERSIST=0 to run the per-step kernels)'.format(step, v))
 
 
 def _run_eval_loop(c, m, global_step):

@@ -73,6 +73,9 @@ def create_parser():
     a('--checkpoint_format', type=str, default='npz', choices=['npz', 'tf'],
       help='Container of saved checkpoints: .npz or the TF checkpoint-V2 tensor bundle (both restore).')
     a('--log_root', type=str, default='', help='Root of the experiments directory (default: ../experiments).')
+    a('--encoder_group', type=int, default=0,
+      help='Frozen-CNN modes: training steps served by ONE encoder forward (group x batch images per forward, on a '
+           'second stream under the decoder steps). 0 = auto (about 1280 images per forward), 1 = one forward per step.')
     a('--loader_processes', type=int, default=0,
       help='JPEG decode in this many worker processes (shared-memory staging); 0 = decode threads in this process.')
     return p
@@ -166,11 +169,18 @@ def main(argv=None):
     from comic_amd.trainer import DataParallel
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', kwargs['gpu'].split(',')[0] if world == 1 else '0'))
+    # COMIC_DIST_BACKEND=gloo: data-parallel rehearsal on fewer GPUs than ranks (the ranks share the visible devices)
+    backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     dp = None
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
         dp = DataParallel(dist)
         # rand_seed stays the SAME on every rank: it seeds the parameter initialisers and the common shuffle; the
         # input managers shard the shuffled list by rank (config.dp_world / dp_rank)

@@ -128,7 +128,8 @@ def test_run_train_step_pipelined_equals_serial(tmp_path):
     runs = []
 
     def probe(config):
-        for pipe, group in ((False, 1), (True, 1), (True, 2)):
+        assert config.encoder_group == 0                 # the CLI default: auto (train.py --encoder_group)
+        for pipe, group in ((False, 1), (True, 1), (True, 2), (True, 0)):
             mdl.reset_default_graph()
             config.pipeline_encoder, config.encoder_group = pipe, group
             man = train._manager(config)
@@ -142,11 +143,13 @@ def test_run_train_step_pipelined_equals_serial(tmp_path):
             finally:
                 man.close()
     train.try_to_train(train_fn=probe, try_block=False, overwrite=overwrite, **kwargs)
-    (l0, p0), (l1, p1), (l2, p2) = runs
+    (l0, p0), (l1, p1), (l2, p2), (l3, p3) = runs
     assert len(set(round(v, 6) for v in l0)) == len(l0)        # the steps see different batches
-    assert l1 == l0 and l2 == l0
+    assert l1 == l0 and l2 == l0 and l3 == l0                  # l3: auto group (16 steps per forward at this size)
     np.testing.assert_array_equal(p1, p0)
     np.testing.assert_array_equal(p2, p0)
+    np.testing.assert_array_equal(p3, p0)
+    assert mdl.auto_encoder_group(64) == 20 and mdl.auto_encoder_group(32) == 40 and mdl.auto_encoder_group(4096) == 1
 
 
 def test_model_autotunes_encoder_and_caches_variants(tmp_path):
