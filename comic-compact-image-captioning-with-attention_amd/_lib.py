@@ -24,7 +24,7 @@ class ImageDesc(C.Structure):           # struct comic_image_desc
 
 
 class ConvWeight(C.Structure):
-    _fields_ = [('w', c_void_p), ('scale', c_void_p), ('shift', c_void_p)]
+    _fields_ = [('w', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('w_frag', c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -57,8 +57,9 @@ def decoder_flags_from_env():
     return f
 
 
-CONV_TILES = 54          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
+CONV_TILES = 55          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants
 WS_TILE = 54             # weight-stationary 1x1 groups (csrc/conv_ws.hip)
+IMG_TILE = 55            # image-resident stride-1 convs on 25x25 / 12x12 / 5x5 maps (csrc/conv_img.hip)
 OP_RAW, OP_POOLED_SRC = 1, 2
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
@@ -92,6 +93,7 @@ _SIGS = {
     'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P]),
     'comic_cnn_pack_bwd_filters': (c_int, [P, c_int, P, c_int, P]),
     'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
+    'comic_cnn_pack_frag_weights': (c_int, [P, P, P, c_int, c_int64, P]),
     'comic_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),
     'comic_conv2d_bn_relu': (c_int, [P, P, c_int, P, c_int, P, c_int, c_int, P]),
     'comic_gemm_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -17,6 +17,7 @@
 #include "conv_common.h"
 #include "conv_ws.h"
 #include "conv_stem.h"
+#include "conv_img.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -1064,6 +1065,43 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// Image-resident kernel (conv_img.hip): n convs of ONE shape (same source geometry, Cin, Cout) as one launch.
+int img_config(const ConvArgs& a) {
+  if (!a.w_frag || a.accum || a.x_cs % 8 != 0 || a.x_co % 8 != 0) return -1;
+  return comic_img_config(a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.SH, a.SW, a.Ho, a.Wo);
+}
+bool img_same_shape(const ConvArgs& p, const ConvArgs& q) {
+  return p.H == q.H && p.W == q.W && p.Cin == q.Cin && p.Cout == q.Cout && p.B == q.B;
+}
+int launch_img_convs(const ConvArgs* a, int n, hipStream_t st) {
+  const int cfg = img_config(a[0]);
+  if (cfg < 0 || n < 1 || n > kImgMaxMembers) {
+    comic_set_error("conv: layer not eligible for the image-resident kernel (%dx%d, %dx%d, Cin %d, Cout %d%s)", a[0].H, a[0].W,
+                    a[0].KH, a[0].KW, a[0].Cin, a[0].Cout, a[0].w_frag ? "" : ", no fragment-order weights");
+    return 3;
+  }
+  ComicImgArgs ia;
+  memset(&ia, 0, sizeof(ia));
+  ia.n_members = n;
+  ia.B = a[0].B; ia.H = a[0].H; ia.W = a[0].W; ia.Cin = a[0].Cin; ia.Cout = a[0].Cout;
+  ia.G = comic_img_images_per_group(cfg);
+  ia.groups = cdiv(ia.B, ia.G);
+  const int pxb = a[0].Cin * 2;
+  ia.PXBp = pxb + ((pxb % 64 == 0) ? 32 : 0);
+  ia.KS32 = a[0].Kpad / 32;
+  for (int j = 0; j < n; ++j) {
+    if (img_config(a[j]) != cfg || !img_same_shape(a[j], a[0])) {
+      comic_set_error("conv: the members of an image-resident launch must have one shape");
+      return 3;
+    }
+    ComicImgMember& m = ia.m[j];
+    m.x = (const bf16_t*)a[j].x; m.wf = (const bf16_t*)a[j].w_frag; m.scale = a[j].scale; m.shift = a[j].shift; m.y = a[j].y;
+    m.x_cs = a[j].x_cs; m.x_co = a[j].x_co; m.y_cs = a[j].y_cs; m.y_co = a[j].y_co;
+    m.KH = a[j].KH; m.KW = a[j].KW; m.PT = a[j].PT; m.PL = a[j].PL; m.relu = a[j].relu; m.out_f32 = a[j].out_f32;
+  }
+  return comic_img_launch(cfg, ia, st);
+}
+
 // explicit tile selection (comic_cnn_op.tile, filled by the host-side autotuner)
 constexpr int kNumConvTiles = 12;
 // ids 26..28: two-stage wide im2col tiles.  The L2 -> LDS fill (about 30 B/clk/CU) bounds the im2col kernel: a k-tile
@@ -1129,6 +1167,7 @@ int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
     case 51: return launch_patch<2, 6, 4, 1, kLoaderWaves + 3>(a, st);   // 128 px x 96 ch
     case 52: return launch_patch<4, 6, 2, 2, kLoaderWaves + 3>(a, st);   // 128 px x 192 ch
     case 53: return launch_patch<4, 4, 2, 2, kLoaderWaves + 3>(a, st);   // 128 px x 128 ch
+    case COMIC_IMG_TILE: return launch_img_convs(&a, 1, st);             // image-resident (conv_img.hip)
     default:
       comic_set_error("conv: unknown tile id %d", tile);
       return 2;
@@ -1263,6 +1302,7 @@ bool ws_group_selected(const comic_cnn_op* ops, int n, int batch) {
 }
 
 int group_tile(const comic_cnn_op* ops, int n, int batch) {
+  if (ops[0].tile == COMIC_IMG_TILE) return COMIC_IMG_TILE;
   if (ops[0].tile > 0 && ops[0].tile < COMIC_WS_TILE) return ops[0].tile;
   bool all128 = true;
   for (int i = 0; i < n; ++i) all128 = all128 && ops[i].Cout % 128 == 0;
@@ -1378,6 +1418,7 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.tiles_m = 0;
   a.accum = 0;
   a.member_kind = 0;
+  a.w_frag = wt ? wt->w_frag : nullptr;
   a.min_lds = std::min(std::max(op->min_lds, 0), 160 * 1024);
   a.remap = 1;
   return 0;
@@ -1549,6 +1590,12 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
     }
     COMIC_REQUIRE(ops[i].tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
     const int tile = group_tile(ops + i, n, batch);
+    if (tile == COMIC_IMG_TILE) {                       // conv_img.hip takes its arguments by value, too
+      memset(out, 0, sizeof(ConvArgs) * n);
+      out += n;
+      i += n;
+      continue;
+    }
     int blk = 0;
     for (int j = 0; j < n; ++j) {
       const comic_cnn_op* op = ops + i + j;
@@ -1674,6 +1721,33 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       }
       COMIC_REQUIRE(op->tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
       const int tile = group_tile(op, n, batch);
+      if (tile == COMIC_IMG_TILE) {
+        // members of one shape share a launch; a member of another shape (7x1 128 -> 192 beside 1x7 128 -> 128) gets its own
+        COMIC_REQUIRE(n <= kImgMaxMembers, "grouped launch: too many members for the image-resident kernel");
+        ConvArgs ma[kImgMaxMembers];
+        bool done[kImgMaxMembers] = {false, false, false, false};
+        for (int j = 0; j < n; ++j) {
+          COMIC_REQUIRE(op[j].kind == 0, "grouped launch: the image-resident kernel takes convolutions only");
+          if (int rc = validate_grouped_conv(op + j, buf_channels[op[j].src], buf_channels[op[j].dst], weights + op[j].weight, batch)) return rc;
+          fill_args(ma[j], op + j, buffers[op[j].src], buf_channels[op[j].src], buffers[op[j].dst], buf_channels[op[j].dst],
+                    weights + op[j].weight, batch);
+        }
+        for (int j = 0; j < n; ++j) {
+          if (done[j]) continue;
+          ConvArgs run[kImgMaxMembers];
+          int nr = 0;
+          for (int q = j; q < n; ++q)
+            if (!done[q] && img_same_shape(ma[q], ma[j])) {
+              run[nr++] = ma[q];
+              done[q] = true;
+            }
+          if (int rc = launch_img_convs(run, nr, main_st)) return rc;
+        }
+        COMIC_LAUNCH_CHECK("image-resident conv group");
+        gargs += n;
+        i += n - 1;
+        continue;
+      }
       long blocks = 0;
       int lds_max = 0;
       for (int j = 0; j < n; ++j) {

@@ -1,0 +1,28 @@
+// Internal interface between conv.hip (plan executor) and conv_img.hip (image-resident convolutions).
+#pragma once
+#include "conv_common.h"
+
+constexpr int kImgMaxMembers = 4;
+
+struct ComicImgMember {
+  const bf16_t* x;       // source activation buffer (NHWC bf16)
+  const bf16_t* wf;      // weights in MFMA-fragment order (comic_cnn_pack_frag_weights)
+  const float* scale;    // null: raw product (no BatchNorm)
+  const float* shift;
+  void* y;
+  int x_cs, x_co, y_cs, y_co;
+  int KH, KW, PT, PL, relu, out_f32;
+};
+struct ComicImgArgs {
+  ComicImgMember m[kImgMaxMembers];
+  int n_members;
+  int B, H, W, Cin, Cout;   // common to all members: stride-1 SAME convolutions over H x W maps
+  int G, groups;            // images per workgroup, workgroups per member = ceil(B / G)
+  int PXBp;                 // bytes per resident pixel (Cin * 2, padded to an odd multiple of 32)
+  int KS32;                 // 32-deep k-steps per 16-channel tile in the packed weights (= Kpad / 32)
+};
+
+// config id (>= 0) of the kernel instantiation that serves this shape, -1: not eligible
+int comic_img_config(int H, int W, int Cin, int Cout, int KH, int KW, int SH, int SW, int Ho, int Wo);
+int comic_img_images_per_group(int cfg);
+int comic_img_launch(int cfg, const ComicImgArgs& a, hipStream_t st);

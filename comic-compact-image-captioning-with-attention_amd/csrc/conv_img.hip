@@ -1,0 +1,247 @@
+// Image-resident implicit GEMM for the stride-1 SAME convolutions on SMALL feature maps (bf16): the 1x7 / 7x1 chains
+// of Mixed_6 (12x12), the 3x3 convs of Mixed_5 (25x25) and the 3x3 / 1x3 / 3x1 convs of Mixed_7 (5x5)
+// (common/nets/inception_v3.py:124-413).
+//
+// What bounds the im2col kernels (conv.hip) on these layers is the L2 -> LDS fill: every k-tile moves (BM + BN) * 128
+// bytes for BM * BN / 32 MFMA cycles and the fill path delivers about 30 B/clk/CU (the committed
+// counters show the matrix pipe 29-45 % busy).  Here a workgroup keeps G WHOLE images resident in the LDS:
+//   * pixels    [P = G*H*W][Cin] bf16, pixel stride padded to an odd multiple of 32 B (the 16 pixels x 2 chunks of a
+//               ds_read_b128 lane group fall into 16 distinct 16-byte bank groups), NO halo: a filter tap that leaves
+//               the image reads a zero page instead (one validity bit per pixel and tap, computed once);
+//   * weights   never touch the LDS: they are pre-packed in MFMA-fragment order ([16-channel tile][k32-step][lane][8])
+//               so that a wave's A operand of one k-step is ONE contiguous KiB, and stream global -> VGPR one step ahead
+//               (buffer loads with a scalar offset: no address arithmetic on the vector unit);
+//   * no barrier in the main loop: after the patch fill the WM x WN waves are independent; two waves per SIMD cover
+//     each other's LDS latency.
+// Per 32-deep k-step a wave reads TM pixel fragments for TM * TN MFMAs; a k-step lies inside one filter tap
+// (Cin % 32 == 0), so the tap's per-lane addresses are formed once per tap and the channel steps are ds_read immediates.
+// Fill bytes per MFMA cycle fall from (BM + BN) * 128 / (BM * BN / 32) to the weight stream alone, shared through L1/L2
+// by the waves of a CU: 14 B/clk/CU at 288 pixels x 192 channels.
+//
+// Same operands and the same k order per accumulator as conv_igemm_dma_body: results are bit-identical.
+#include <algorithm>
+
+#include "conv_img.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned img_u32x4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t img_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+
+template <int TM, int TN, int WM, int WN, int CS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CPP = CS * 4;            // 16-byte chunks per pixel (Cin = 32 * CS)
+  constexpr int PMAX = TM * WM * 16;     // pixel slots of the workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int mi = blockIdx.x % a.n_members, grp = blockIdx.x / a.n_members;
+  const ComicImgMember& m = a.m[mi];
+  const int HW = a.H * a.W, W = a.W, H = a.H;
+  const int img0 = grp * a.G;
+  const int P = min(a.G, a.B - img0) * HW;            // resident pixels of this workgroup
+  const int PXBp = a.PXBp;
+  const uint32_t zoff = PMAX * PXBp;                  // 1 KiB of zeros behind the pixels
+
+  // ---- patch fill: the G images are consecutive pixels of the NHWC source ------------------------------------------
+  {
+    const bf16_t* __restrict__ xg = m.x + (size_t)img0 * HW * m.x_cs + m.x_co;
+    const int x_cs = m.x_cs;
+    const int total = P * CPP;
+    for (int base = 0; base < total; base += NT * 4) {
+      uint4 v[4];
+      int dst[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * NT + tid;
+        const bool ok = idx < total;
+        const int p = ok ? idx / CPP : 0;
+        const int c = ok ? idx - p * CPP : 0;
+        dst[u] = ok ? p * PXBp + c * 16 : -1;
+        v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
+    }
+    if (tid < 64) *(uint4*)(smem + zoff + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  // ---- per-lane pixel state ------------------------------------------------------------------------------------------
+  const int fr = lane & 15, fg = lane >> 4;
+  const int KH = m.KH, KW = m.KW, PT = m.PT, PL = m.PL;
+  const int taps = KH * KW;
+  uint32_t pixaddr[TM], mask[TM];
+  int mrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int p = (wm * TM + j) * 16 + fr;
+    const bool pv = p < P;
+    const int pp = pv ? p : 0;
+    const int img = pp / HW;
+    const int r = pp - img * HW;
+    const int h = r / W, w = r - (r / W) * W;
+    pixaddr[j] = (uint32_t)(pp * PXBp + fg * 16);
+    uint32_t mk = 0;
+    int t = 0;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw, ++t) {
+        const bool ok = pv & ((unsigned)(h + kh - PT) < (unsigned)H) & ((unsigned)(w + kw - PL) < (unsigned)W);
+        mk |= ok ? (1u << t) : 0u;
+      }
+    mask[j] = mk;
+    mrow[j] = pv ? img0 * HW + pp : -1;
+  }
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- weight stream: tile (wn*TN + i), step s at byte ((tile * KS32 + s) * 64 + lane) * 16 ---------------------------
+  const __amdgpu_buffer_rsrc_t wr = img_rsrc(m.wf, (uint32_t)(a.Cout / 16) * (uint32_t)a.KS32 * 1024u);
+  const int wv = lane * 16;
+  const int tile_stride = a.KS32 * 1024;
+  const int wbase = wn * TN * tile_stride;
+  const int nsteps = taps * CS;
+  img_u32x4 wcur[TN], wnext[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) wcur[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + i * tile_stride, 0);
+
+  __syncthreads();                       // the patch is complete (the only barrier of the kernel)
+
+  int kh = 0, kw = 0, s = 0;
+  for (int t = 0; t < taps; ++t) {
+    const int tapoff = ((kh - PT) * W + (kw - PL)) * PXBp;
+    uint32_t addr[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) addr[j] = ((mask[j] >> t) & 1u) ? pixaddr[j] + (uint32_t)tapoff : zoff + (uint32_t)(fg * 16);
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) {
+      ++s;
+      const int so = wbase + min(s, nsteps - 1) * 1024;          // the last prefetch re-reads the last step
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wnext[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + i * tile_stride, 0);
+      uint4 xf[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) xf[j] = *(const uint4*)(smem + addr[j] + cs * 64);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wcur[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wcur[i] = wnext[i];
+    }
+    if (++kw == KW) {
+      kw = 0;
+      ++kh;
+    }
+  }
+
+  // ---- epilogue: BatchNorm + ReLU + store, shared with the other bf16 conv kernels ----------------------------------
+  ConvArgs ca;
+  ca.scale = m.scale; ca.shift = m.shift; ca.y = m.y; ca.y_cs = m.y_cs; ca.y_co = m.y_co; ca.Cout = a.Cout;
+  ca.relu = m.relu; ca.out_f32 = m.out_f32; ca.accum = 0;
+  conv_store_tiles<TN, TM>(ca, acc, wn * TN * 16, fg * 4, mrow);
+}
+
+// [Cout][Kpad] bf16 -> fragment order, for every conv weight of a flat plan buffer in one launch.  table: per weight
+// {element offset, Cout, Kpad} (int64 x 3), sorted by offset; stem / ineligible records carry Kpad 0 and are copied.
+__global__ void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const long* __restrict__ table,
+                                 int n, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte chunk per thread
+  if (idx * 8 >= total) return;
+  const long e0 = idx * 8;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[3 * mid] <= e0) lo = mid; else hi = mid - 1;
+  }
+  const long off = table[3 * lo], cout = table[3 * lo + 1], kpad = table[3 * lo + 2];
+  const long local = e0 - off;
+  long s_el = e0;                                                   // source element of this chunk (alignment gaps: copied)
+  if (kpad > 0 && local < cout * kpad) {
+    const long ks32 = kpad / 32;
+    const long lane = (local / 8) % 64, s = (local / 512) % ks32, nt = local / (512 * ks32);
+    s_el = off + (nt * 16 + (lane & 15)) * kpad + s * 32 + (lane >> 4) * 8;
+  }
+  *(uint4*)(dst + e0) = *(const uint4*)(src + s_el);
+}
+
+struct ImgCfg { int HW, Cin, Cout, G; };
+// instantiations: (TM, TN, WM, WN, CS)
+constexpr ImgCfg kCfg[] = {
+    {144, 128, 192, 2}, {144, 160, 192, 2}, {144, 192, 192, 2},      // 0-2: 9,3,2,4,{4,5,6}
+    {144, 128, 128, 2},                                                // 3:   9,2,2,4,4
+    {144, 160, 160, 2},                                                // 4:   9,2,2,5,5
+    {625, 64, 96, 1},  {625, 96, 96, 1},                               // 5-6: 10,3,4,2,{2,3}
+    {25, 384, 384, 6}, {25, 448, 384, 6},                              // 7-8: 5,6,2,4,{12,14}
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
+template <int TM, int TN, int WM, int WN, int CS>
+int launch_img(const ComicImgArgs& a, hipStream_t st) {
+  const int lds = TM * WM * 16 * a.PXBp + 1024;
+  if (lds > 160 * 1024) {
+    comic_set_error("conv_img: %d bytes of LDS", lds);
+    return 2;
+  }
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_img_kernel<TM, TN, WM, WN, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      comic_set_error("conv_img: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_img_kernel<TM, TN, WM, WN, CS>), dim3(a.groups * a.n_members), dim3(64 * WM * WN), lds, st, a);
+  return 0;
+}
+
+}  // namespace
+
+int comic_img_config(int H, int W, int Cin, int Cout, int KH, int KW, int SH, int SW, int Ho, int Wo) {
+  if (SH != 1 || SW != 1 || Ho != H || Wo != W || KH * KW > 32 || KH * KW < 2) return -1;
+  for (int c = 0; c < kNumCfg; ++c)
+    if (kCfg[c].HW == H * W && kCfg[c].Cin == Cin && kCfg[c].Cout == Cout) return c;
+  return -1;
+}
+
+int comic_img_images_per_group(int cfg) { return (cfg >= 0 && cfg < kNumCfg) ? kCfg[cfg].G : 0; }
+
+int comic_img_launch(int cfg, const ComicImgArgs& a, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_img<9, 3, 2, 4, 4>(a, st);
+    case 1: return launch_img<9, 3, 2, 4, 5>(a, st);
+    case 2: return launch_img<9, 3, 2, 4, 6>(a, st);
+    case 3: return launch_img<9, 2, 2, 4, 4>(a, st);
+    case 4: return launch_img<9, 2, 2, 5, 5>(a, st);
+    case 5: return launch_img<10, 3, 4, 2, 2>(a, st);
+    case 6: return launch_img<10, 3, 4, 2, 3>(a, st);
+    case 7: return launch_img<5, 6, 2, 4, 12>(a, st);
+    case 8: return launch_img<5, 6, 2, 4, 14>(a, st);
+    default:
+      comic_set_error("conv_img: unknown configuration %d", cfg);
+      return 2;
+  }
+}
+
+extern "C" int comic_cnn_pack_frag_weights(const void* w_plan, void* w_frag, const int64_t* table_dev, int n_weights,
+                                           int64_t total_elems, void* stream) {
+  COMIC_REQUIRE(w_plan && w_frag && table_dev && n_weights > 0 && total_elems % 8 == 0, "pack_frag_weights: bad arguments");
+  const long chunks = total_elems / 8;
+  hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)w_plan, (bf16_t*)w_frag, (const long*)table_dev, n_weights, (long)total_elems);
+  COMIC_LAUNCH_CHECK("pack_frag_weights");
+  return 0;
+}

@@ -566,6 +566,7 @@ class CnnEncoder:
             assert o.plan.weights == plan.weights and o.dtype == dtype
             self.w_master, self.beta, self.mean, self.scale, self.shift = o.w_master, o.beta, o.mean, o.scale, o.shift
             self.w_plan, wt = o.w_plan, o._wt
+            self.w_frag, self._frag_table = o.w_frag, o._frag_table
         else:
             wshapes, bshapes = flat_layout(plan)
             self.w_master = FlatParams(wshapes, device)
@@ -574,6 +575,19 @@ class CnnEncoder:
             self.scale.data.fill_(1.0)
             self.w_plan = self.w_master.data if self.dcode == 0 else torch.zeros(self.w_master.numel, dtype=tdt,
                                                                                   device=device)
+            # bf16 plans: a second copy of the weights in MFMA-fragment order for the image-resident kernel
+            # (csrc/conv_img.hip), refreshed with the plan copy; table = {element offset, Cout, Kpad} per weight
+            self.w_frag, self._frag_table = None, None
+            if self.dcode == 1:
+                self.w_frag = torch.zeros(self.w_master.numel, dtype=tdt, device=device)
+                tab = []
+                for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+                    cin_p, cout_p = plan.wphys[i]
+                    kpad = (kh * kw * cin_p + 63) // 64 * 64
+                    tab.append((self.w_master.offsets['w%d' % i], cout_p, 0 if stem else kpad))
+                order = sorted(range(len(tab)), key=lambda i: tab[i][0])
+                assert all(tab[i][0] % 8 == 0 for i in order), 'weight records must start on 16-byte boundaries'
+                self._frag_table = torch.tensor([tab[i] for i in order], dtype=torch.int64, device=device)
             wt = (L.ConvWeight * len(plan.weights))()
             for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
                 bk = 'b%d' % i
@@ -582,6 +596,8 @@ class CnnEncoder:
                 wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
                 wt[i].scale = self.scale.view(bk).data_ptr()
                 wt[i].shift = self.shift.view(bk).data_ptr()
+                if self.w_frag is not None and not stem:
+                    wt[i].w_frag = self.w_frag.data_ptr() + 2 * self.w_master.offsets['w%d' % i]
             self.load_params(params)
         self._train = None
         torch.cuda.synchronize()
@@ -664,6 +680,10 @@ class CnnEncoder:
                                                    self.beta.data.data_ptr(), self.mean.data.data_ptr(),
                                                    self.scale.data.data_ptr(), self.shift.data.data_ptr(),
                                                    self.beta.numel, L.stream_ptr()), 'cnn_refresh_weights')
+        if self.w_frag is not None:
+            L.check(self.lib.comic_cnn_pack_frag_weights(self.w_plan.data_ptr(), self.w_frag.data_ptr(),
+                                                         self._frag_table.data_ptr(), self._frag_table.shape[0],
+                                                         self.w_master.numel, L.stream_ptr()), 'cnn_pack_frag_weights')
         # masters changed: version stamp shared by every encoder aliasing them
         self.w_master.__dict__['_ver'] = self.w_master.__dict__.get('_ver', 0) + 1
         t = getattr(self, '_train', None)

@@ -32,8 +32,9 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 54
+#define COMIC_CONV_TILES 55
 #define COMIC_WS_TILE 54     /* weight-stationary 1x1 group kernel (csrc/conv_ws.hip) */
+#define COMIC_IMG_TILE 55    /* image-resident kernel for stride-1 SAME convs on small maps (csrc/conv_img.hip) */
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -91,8 +92,10 @@ typedef struct comic_cnn_op {
                         loader waves.  Id 54 (COMIC_WS_TILE): weight-stationary kernel for 1x1 convs / groups of 1x1 convs
                         over one source with Cin <= 288 and <= 256 output channels in total (all weights in registers,
                         persistent workgroups, activation tiles streamed once).  An ineligible layer returns an error
-                        for ids 13..25 and 48..54.  In a group the
-                        id of the first member applies to all members.  Every variant gives identical bits. */
+                        for ids 13..25 and 48..55.  Id 55 (COMIC_IMG_TILE): image-resident kernel for the stride-1 SAME
+                        convs of Mixed_5 / Mixed_6 / Mixed_7 (whole 25x25 / 12x12 / 5x5 images in the LDS without halo,
+                        weights streamed global -> VGPR in fragment order: needs comic_conv_weight::w_frag).  In a group
+                        the id of the first member applies to all members.  Every variant gives identical bits. */
   int32_t group;     /* conv, bf16 plans: 0 = own launch; ops that are ADJACENT in the table and
                         share a non-zero id are mutually independent (the same-depth convs of
                         the parallel Inception branches) and comic_cnn_forward_grouped runs
@@ -112,6 +115,8 @@ typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */
   const float* scale;  /* [Cout] */
   const float* shift;  /* [Cout] */
+  const void* w_frag;  /* bf16 plans, optional (NULL: tile id 55 is not eligible): the same weights in MFMA-fragment
+                          order [Cout / 16][Kpad / 32][64 lanes][8] (comic_cnn_pack_frag_weights) */
 } comic_conv_weight;
 
 /* Run a whole forward plan on `stream`.  buffers[i] has buf_channels[i] channels per
@@ -120,6 +125,13 @@ typedef struct comic_conv_weight {
 int comic_cnn_forward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, int batch,
                       int dtype, void* stream);
+
+/* w_plan: the flat bf16 weight buffer of a plan ([Cout][Kpad] records); w_frag: same size, receives every record in
+ * MFMA-fragment order (lane l of k32-step s of 16-channel tile t holds W[16 t + (l & 15)][32 s + 8 (l >> 4) .. + 8]).
+ * table_dev: n_weights x {element offset, Cout, Kpad} as int64 in device memory, ascending offsets; Kpad 0 = copy the
+ * record unchanged up to the next offset (the fp32 stem filter). */
+int comic_cnn_pack_frag_weights(const void* w_plan, void* w_frag, const int64_t* table_dev, int n_weights,
+                                int64_t total_elems, void* stream);
 
 /* Grouped execution of the same plan (bf16 plans): every run of ops with the same non-zero
  * `group` becomes ONE launch whose workgroups are spread over all member convolutions (a

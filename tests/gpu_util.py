@@ -44,7 +44,12 @@ def elementwise_excess(got, ref, tol):
     return float((np.abs(got - ref) / bound).max())
 
 
-def assert_close(got, ref, tol=F32_RTOL, name='', elementwise=True):
+def assert_close(got, ref, tol=F32_RTOL, name='', elementwise=None):
+    """Max-norm bound at `tol`; comparisons at the north star's fp32 bar (tol == F32_RTOL) are also held to the
+    element-wise criterion (elementwise=None).  The bf16 plans (3e-2 bounds) and the self-comparisons at 1e-5 keep the
+    max-norm form: their tolerances were set for it."""
+    if elementwise is None:
+        elementwise = tol == F32_RTOL
     e = rel_err(got, ref)
     assert np.isfinite(np.asarray(got, np.float64)).all(), '%s: non-finite values' % name
     assert e <= tol, '%s: rel err %.3e > %.1e (max|ref| %.3e)' % (name, e, tol, np.abs(ref).max())

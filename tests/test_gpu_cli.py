@@ -145,10 +145,14 @@ def test_run_train_step_pipelined_equals_serial(tmp_path):
     train.try_to_train(train_fn=probe, try_block=False, overwrite=overwrite, **kwargs)
     (l0, p0), (l1, p1), (l2, p2), (l3, p3) = runs
     assert len(set(round(v, 6) for v in l0)) == len(l0)        # the steps see different batches
-    assert l1 == l0 and l2 == l0 and l3 == l0                  # l3: auto group (16 steps per forward at this size)
+    assert l1 == l0 and l2 == l0
     np.testing.assert_array_equal(p1, p0)
     np.testing.assert_array_equal(p2, p0)
-    np.testing.assert_array_equal(p3, p0)
+    # auto group: 16 steps (64 images) per forward.  At that many pixels the plan executor switches two launches to
+    # forms with another fp32 summation order (row-walking pool + BN + ReLU, weight-stationary 1x1 groups), so this
+    # run agrees to rounding, not bit for bit
+    np.testing.assert_allclose(l3, l0, rtol=2e-4)
+    assert np.abs(p3 - p0).max() <= 2e-3 * np.abs(p0).max()
     assert mdl.auto_encoder_group(64) == 20 and mdl.auto_encoder_group(32) == 40 and mdl.auto_encoder_group(4096) == 1
 
 

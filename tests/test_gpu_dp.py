@@ -31,7 +31,10 @@ def _launch(script_args, nproc=2, timeout=900, extra_env=None):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
            '--master-addr', '127.0.0.1', '--master-port', str(_port())] + script_args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    if r.returncode != 0:                    # pytest shows the captured output of a failing test in full
+        print(r.stdout[-6000:])
+        print(r.stderr[-12000:])
+    assert r.returncode == 0, 'torch.distributed.run exited with %d (output above)' % r.returncode
     return r
 
 

@@ -246,6 +246,63 @@ def test_conv_patch_random_sweep():
     assert n_ok > 300
 
 
+IMG_CASES = [   # (H, W, Cin, Cout, taps): every shape csrc/conv_img.hip is instantiated for
+    (12, 12, 128, 192, (7, 1)), (12, 12, 128, 192, (1, 7)), (12, 12, 160, 192, (7, 1)), (12, 12, 192, 192, (1, 7)),
+    (12, 12, 192, 192, (7, 1)), (12, 12, 128, 128, (1, 7)), (12, 12, 128, 128, (7, 1)), (12, 12, 160, 160, (1, 7)),
+    (12, 12, 160, 160, (7, 1)), (25, 25, 64, 96, (3, 3)), (25, 25, 96, 96, (3, 3)), (5, 5, 448, 384, (3, 3)),
+    (5, 5, 384, 384, (1, 3)), (5, 5, 384, 384, (3, 1))]
+
+
+def _frag_weights(w, Cout, Kpad):
+    """comic_cnn_pack_frag_weights on one [Cout][Kpad] bf16 record."""
+    out = torch.zeros_like(w)
+    table = torch.tensor([[0, Cout, Kpad]], dtype=torch.int64, device=DEV)
+    L.check(lib().comic_cnn_pack_frag_weights(w.data_ptr(), out.data_ptr(), table.data_ptr(), 1, w.numel(), stream()), 'pack')
+    return out
+
+
+@pytest.mark.parametrize('case', IMG_CASES)
+def test_conv_image_resident_identical_bits(case):
+    """The image-resident kernel (tile id 55: whole images in the LDS without halo, out-of-image taps read a zero page,
+    weights streamed in fragment order) against the im2col kernel: same operands, same k order per accumulator ->
+    identical bits.  Batch sizes that leave the last workgroup with fewer images than it has room for, source and
+    destination channel slices, with and without ReLU; one launch with two members (a grouped launch's form) too."""
+    H, W, Cin, Cout, (kh, kw) = case
+    rng = np.random.default_rng(H * 131 + Cin + Cout + 7 * kh + kw)
+    K = kh * kw * Cin
+    Kpad = (K + 63) // 64 * 64
+    pt, pl = (kh - 1) // 2, (kw - 1) // 2
+    for B, xc, xo, yc, yo, relu in ((1, Cin, 0, Cout, 0, 1), (5, Cin + 64, 8, Cout + 48, 16, 1), (13, Cin, 0, Cout + 16, 4, 0)):
+        x = torch.randn(B, H, W, xc, device=DEV).to(torch.bfloat16)
+        wf = torch.randn(Cout, Kpad, device=DEV) / K ** 0.5
+        wf[:, K:] = 0
+        w = wf.to(torch.bfloat16).contiguous()
+        frag = _frag_weights(w, Cout, Kpad)
+        # the packing itself: lane l of step s of tile t holds W[16 t + (l & 15)][32 s + 8 (l >> 4) .. + 8]
+        f = frag.view(Cout // 16, Kpad // 32, 64, 8)
+        for t, s_, l in ((0, 0, 0), (Cout // 16 - 1, Kpad // 32 - 1, 63), (1, 3, 37)):
+            assert torch.equal(f[t, s_, l], w[16 * t + (l & 15), 32 * s_ + 8 * (l >> 4):32 * s_ + 8 * (l >> 4) + 8])
+        scale, shift = torch.rand(Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV) * 0.1
+        wt = L.ConvWeight(w.data_ptr(), scale.data_ptr(), shift.data_ptr(), frag.data_ptr())
+        ys = {}
+        for tile in (3, L.IMG_TILE):
+            y = torch.full((B, H, W, yc), -7.0, dtype=torch.bfloat16, device=DEV)
+            op = L.CnnOp(kind=0, src=0, dst=1, src_coff=xo, dst_coff=yo, H=H, W=W, Cin=Cin, Cout=Cout, KH=kh, KW=kw, SH=1,
+                         SW=1, PT=pt, PL=pl, Ho=H, Wo=W, weight=0, relu=relu, out_f32=0, tile=tile)
+            L.check(lib().comic_conv2d_bn_relu(C.byref(op), x.data_ptr(), xc, y.data_ptr(), yc, C.byref(wt), B, 1, stream()),
+                    'conv tile %d' % tile)
+            sync()
+            ys[tile] = y
+        assert torch.equal(ys[L.IMG_TILE], ys[3]), (case, B)
+        assert bool((ys[3][..., yo:yo + Cout].float().abs().max() > 0.1))
+    # without fragment-order weights the id is refused, like a patch id on an ineligible layer
+    wt0 = L.ConvWeight(w.data_ptr(), scale.data_ptr(), shift.data_ptr())
+    op = L.CnnOp(kind=0, src=0, dst=1, H=H, W=W, Cin=Cin, Cout=Cout, KH=kh, KW=kw, SH=1, SW=1, PT=pt, PL=pl, Ho=H, Wo=W,
+                 weight=0, relu=1, tile=L.IMG_TILE)
+    assert lib().comic_conv2d_bn_relu(C.byref(op), x.data_ptr(), xc, y.data_ptr(), yc, C.byref(wt0), B, 1, stream()) != 0
+    assert b'not eligible' in lib().comic_last_error()
+
+
 def test_conv_patch_rejects_strided():
     x = np.zeros((1, 9, 9, 32), np.float32)
     w = np.zeros((3, 3, 32, 32), np.float32)

@@ -465,7 +465,7 @@ def test_persistent_loops_match_oracle_at_bench_geometry(B):
     with injected masks -- at batch 64 (four 16-row groups in one launch) and at the SCST step's 224 hypotheses (four
     consecutive launches).  Same 1e-3 bar as the small cases, max-norm and element-wise."""
     spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
-    Lc = 31                                               # row 0 has the longest caption: T' = Lc - 2 = 29
+    Lc = 30                                               # row 0 has the longest caption: T' = Lc - 1 = 29
     p = _rand_params(cfg, 13)
     fm, im, caps = _batch(spec, B, Lc, 17)
     _, _, _, lens = dr.process_inputs(caps, cfg.token_type)

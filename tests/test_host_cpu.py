@@ -66,7 +66,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.AttnDesc) == 8 * 4
     assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4  # ... map_loss_scale, flags
     assert C.sizeof(L.DecoderParams) == 14 * 8
-    assert C.sizeof(L.ConvWeight) == 3 * 8
+    assert C.sizeof(L.ConvWeight) == 4 * 8                # w, scale, shift, w_frag
 
 
 def test_conv_variant_ids_match_header():
@@ -77,8 +77,9 @@ def test_conv_variant_ids_match_header():
     im2col = [t for t in range(1, L.CONV_TILES + 1) if L.is_im2col_tile(t)]
     patch = [t for t in range(1, L.CONV_TILES + 1) if not L.is_im2col_tile(t)]
     assert im2col == list(range(1, 13)) + list(range(26, 48))
-    assert patch == list(range(13, 26)) + list(range(48, 54)) + [L.WS_TILE]     # may-refuse ids (incl. the 1x1 weight-stationary kernel)
+    assert patch == list(range(13, 26)) + list(range(48, 54)) + [L.WS_TILE, L.IMG_TILE]   # may-refuse ids (incl. the weight-stationary and image-resident kernels)
     assert int(re.search(r'#define COMIC_WS_TILE (\d+)', header).group(1)) == L.WS_TILE
+    assert int(re.search(r'#define COMIC_IMG_TILE (\d+)', header).group(1)) == L.IMG_TILE
     assert int(re.search(r'#define COMIC_OP_POOLED_SRC (\d+)', header).group(1)) == L.OP_POOLED_SRC
 
 
