@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libcomic_hip.so')
+# COMIC_HIP_LIB: another build of the same library (A/B timing of two kernel versions on one box, tools/ only)
+LIB_PATH = os.environ.get('COMIC_HIP_LIB') or os.path.join(_HERE, 'lib', 'libcomic_hip.so')
 
 c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_char_p, c_uint64 = (
     C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_char_p, C.c_uint64)

@@ -22,7 +22,7 @@ struct ConvArgs {
   int grp_nt;        // remap 2: out-channel tiles of all members together; blk0 = those of the members before this one
   int accum;         // 1: y += result (backward-data accumulation into a gradient buffer)
   // patch-resident kernel (conv_patch.inc): tile geometry, filled by apply_geometry()
-  int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB;
+  int p_TC, p_TR, p_ncol, p_PW, p_PXBp, p_CPP, p_CPPp, p_cmagic, p_NR, p_Hp, p_rowB, p_gapB;
   int member_kind;   // grouped launch: 0 conv tile, 1 pool + BN + ReLU (kind 7) work items
   int min_lds;       // host only: lower bound on the dynamic LDS of the launch (comic_cnn_op::min_lds)
   const void* w_frag; // host only: the weights in MFMA-fragment order (comic_conv_weight::w_frag), or null

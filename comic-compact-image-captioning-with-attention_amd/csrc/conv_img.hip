@@ -48,27 +48,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   const int PXBp = a.PXBp;
   const uint32_t zoff = PMAX * PXBp;                  // 1 KiB of zeros behind the pixels
 
-  // ---- patch fill: the G images are consecutive pixels of the NHWC source ------------------------------------------
+  // ---- patch fill: the G images are consecutive pixels of the NHWC source; every load of a thread is in flight before
+  // its first LDS write (one memory latency for the whole patch, not one per pass) ----------------------------------------
   {
+    constexpr int U = (PMAX * CPP + NT - 1) / NT;
     const bf16_t* __restrict__ xg = m.x + (size_t)img0 * HW * m.x_cs + m.x_co;
     const int x_cs = m.x_cs;
     const int total = P * CPP;
-    for (int base = 0; base < total; base += NT * 4) {
-      uint4 v[4];
-      int dst[4];
+    uint4 v[U];
+    int dst[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + u * NT + tid;
-        const bool ok = idx < total;
-        const int p = ok ? idx / CPP : 0;
-        const int c = ok ? idx - p * CPP : 0;
-        dst[u] = ok ? p * PXBp + c * 16 : -1;
-        v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * NT + tid;
+      const bool ok = idx < total;
+      const int p = ok ? idx / CPP : 0;
+      const int c = ok ? idx - p * CPP : 0;
+      dst[u] = ok ? p * PXBp + c * 16 : -1;
+      v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
     if (tid < 64) *(uint4*)(smem + zoff + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 
@@ -78,24 +78,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   const int taps = KH * KW;
   uint32_t pixaddr[TM], mask[TM];
   int mrow[TM];
+  {
+    const float rHW = 1.0f / (float)HW, rW = 1.0f / (float)W;
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int p = (wm * TM + j) * 16 + fr;
-    const bool pv = p < P;
-    const int pp = pv ? p : 0;
-    const int img = pp / HW;
-    const int r = pp - img * HW;
-    const int h = r / W, w = r - (r / W) * W;
-    pixaddr[j] = (uint32_t)(pp * PXBp + fg * 16);
-    uint32_t mk = 0;
-    int t = 0;
-    for (int kh = 0; kh < KH; ++kh)
-      for (int kw = 0; kw < KW; ++kw, ++t) {
-        const bool ok = pv & ((unsigned)(h + kh - PT) < (unsigned)H) & ((unsigned)(w + kw - PL) < (unsigned)W);
-        mk |= ok ? (1u << t) : 0u;
-      }
-    mask[j] = mk;
-    mrow[j] = pv ? img0 * HW + pp : -1;
+    for (int j = 0; j < TM; ++j) {
+      const int p = (wm * TM + j) * 16 + fr;
+      const bool pv = p < P;
+      const int pp = pv ? p : 0;
+      const int img = (int)(((float)pp + 0.5f) * rHW);        // exact for these sizes (pp < 2^16)
+      const int r = pp - img * HW;
+      const int h = (int)(((float)r + 0.5f) * rW), w = r - h * W;
+      pixaddr[j] = (uint32_t)(pp * PXBp + fg * 16);
+      // taps (kh, kw) inside the image: kh in [klo, khi], kw in [wlo, whi]; bit kh*KW + kw
+      const int klo = max(0, PT - h), khi = min(KH - 1, H - 1 - h + PT);
+      const int wlo = max(0, PL - w), whi = min(KW - 1, W - 1 - w + PL);
+      const uint32_t rowbits = ((2u << whi) - 1u) & ~((1u << wlo) - 1u);
+      uint32_t mk = 0;
+      for (int kh = klo; kh <= khi; ++kh) mk |= rowbits << (kh * KW);
+      mask[j] = pv ? mk : 0u;
+      mrow[j] = pv ? img0 * HW + pp : -1;
+    }
   }
 
   f32x4_t acc[TN][TM];
@@ -110,9 +112,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   const int tile_stride = a.KS32 * 1024;
   const int wbase = wn * TN * tile_stride;
   const int nsteps = taps * CS;
-  img_u32x4 wcur[TN], wnext[TN];
+  // software pipeline of depth 2: w0 = this step's fragments, w1 = the next step's, w2 = the loads issued now for the
+  // step after that.  The sched_barrier pins the loads at the top of the step (left alone, the scheduler sinks them
+  // behind the last MFMA that reads the register they overwrite and their latency is exposed).
+  img_u32x4 w0[TN], w1[TN], w2[TN];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) wcur[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + i * tile_stride, 0);
+  for (int i = 0; i < TN; ++i) {
+    w0[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + i * tile_stride, 0);
+    w1[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + min(1, nsteps - 1) * 1024 + i * tile_stride, 0);
+  }
 
   __syncthreads();                       // the patch is complete (the only barrier of the kernel)
 
@@ -124,21 +132,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
     for (int j = 0; j < TM; ++j) addr[j] = ((mask[j] >> t) & 1u) ? pixaddr[j] + (uint32_t)tapoff : zoff + (uint32_t)(fg * 16);
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
+      const int so = wbase + min(s + 2, nsteps - 1) * 1024;      // the last prefetches re-read the last step
       ++s;
-      const int so = wbase + min(s, nsteps - 1) * 1024;          // the last prefetch re-reads the last step
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wnext[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + i * tile_stride, 0);
+      for (int i = 0; i < TN; ++i) w2[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + i * tile_stride, 0);
       uint4 xf[TM];
 #pragma unroll
       for (int j = 0; j < TM; ++j) xf[j] = *(const uint4*)(smem + addr[j] + cs * 64);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wcur[i]),
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w0[i]),
                                                               __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wcur[i] = wnext[i];
+      for (int i = 0; i < TN; ++i) {
+        w0[i] = w1[i];
+        w1[i] = w2[i];
+      }
     }
     if (++kw == KW) {
       kw = 0;
