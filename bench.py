@@ -139,11 +139,9 @@ def extras(device, enc, cnn_params, plan):
     for _ in range(n):
         res = scst_step()
     torch.cuda.synchronize()
-    out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
-    out['scst_conv_mfma_frac'] = round(out['scst_images_per_sec'] * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
-    out['scst_config'] = ('COMIC-256, batch 32, greedy + beam-7 rollouts (40 steps max), C++ CIDEr-D+BLEU-4 reward, 224-hypothesis '
-                          'step (encoder once, features tiled); random weights with an EOS bias of +2: the rollouts END AFTER %d '
-                          'STEP(S) (device-side early exit) -- the lower bound of the step' % int(res['Tp']))
+    out['scst_one_step'] = {'images_per_sec': round(Bs * n / (time.perf_counter() - t0), 1), 'time_steps': int(res['Tp']),
+                            'config': 'random weights with an EOS bias of +2: every rollout ends after its first step '
+                                      '(device-side early exit) -- the LOWER bracket of the SCST step'}
     # the upper bound: EOS never emitted, every rollout and the training step run all 40 time steps
     dec.params.view('b_o')[257] = -30.0
     for _ in range(2):
@@ -157,6 +155,45 @@ def extras(device, enc, cnn_params, plan):
                                'config': 'the same step with EOS suppressed: greedy + beam-7 run all 40 steps, the 224-hypothesis '
                                          'training step has T\' = %d (persistent loops in four launches: path %d)'
                                          % (int(res['Tp']), int(dec.lib.comic_decoder_train_path()))}
+    # the figure reported as scst_images_per_sec: caption lengths as on MS-COCO (N ~ U{8..14} words =
+    # 16..28 radix digits + EOS).  Random weights cannot be made to stop there by themselves, so EOS stays suppressed, the
+    # rollouts run 29 steps (the length of the longest caption of a batch: dynamic_decode stops when EVERY row has ended)
+    # and each sampled hypothesis is cut at its own drawn length before it is scored and trained on.
+    real_iters = 29
+    len_rng = np.random.default_rng(11)
+
+    def cut(ids2d):
+        ids2d = np.array(ids2d, copy=True)
+        for r in range(ids2d.shape[0]):
+            L = 2 * int(len_rng.integers(8, 15))
+            ids2d[r, L:] = 257
+        return ids2d
+
+    def scst_step_realistic():
+        im, fm = enc_s.forward(imgs, use_graph=True)
+        greedy, _, _ = dec.greedy(fm, im, real_iters)
+        beam = dec.beam_search(fm, im, W, real_iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
+        cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]
+        cap_greedy = [[c] for c in id_to_caption(cut(greedy), cfg)]
+        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
+        ids = captions_to_batched_ids(hypos, cfg, table)
+        im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
+        res = dec.train_step(fm, im, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True)
+        opt.step(dec.grads, 1e-3)
+        return res
+    for _ in range(2):
+        res = scst_step_realistic()
+    torch.cuda.synchronize()
+    n, t0 = 5, time.perf_counter()
+    for _ in range(n):
+        res = scst_step_realistic()
+    torch.cuda.synchronize()
+    out['scst_images_per_sec'] = round(Bs * n / (time.perf_counter() - t0), 1)
+    out['scst_conv_mfma_frac'] = round(out['scst_images_per_sec'] * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
+    out['scst_config'] = ('COMIC-256, batch 32, greedy + beam-7 rollouts of %d steps (the longest caption of a batch), every '
+                          'hypothesis cut at its own length N ~ U{8..14} words (16..28 radix digits + EOS), C++ CIDEr-D+BLEU-4 '
+                          'reward, 224-hypothesis training step with T\' = %d (encoder once, features tiled); brackets: '
+                          'scst_one_step (rollouts end at once) and scst_full_length (40 steps)' % (real_iters, int(res['Tp'])))
     del enc_s, dec, opt
     torch.cuda.empty_cache()
     # ---- cnn_finetune step (configs[2]: CNN + decoder trainable, batch 32) ---------------------
@@ -210,6 +247,96 @@ def extras(device, enc, cnn_params, plan):
                      'cnn_forward_ms': round(fwd_ms, 3), 'flop_per_image': flop299,
                      'cnn_mfma_frac': round(flop299 * BATCH / (fwd_ms * 1e-3) / PEAK_BF16_MFMA, 5), 'loss': round(float(res['loss']), 4)}
     del tr
+    torch.cuda.empty_cache()
+    # ---- the fp32 plan (the one that meets the north star's 1e-3 against the oracle): its throughput, and what the
+    # benchmarked bf16 plan deviates from it on ONE XE step of the same batch (same weights, dropout off) -------------------
+    plan_f32 = nets.CnnPlan('inception_v3', (IMG, IMG))
+    spec0 = cdec.DecoderSpec()
+    tr32 = trainer.CaptionTrainer(cnn_params, spec0, None, BATCH, (IMG, IMG), 'f32', device, seed=8, plan=plan_f32)
+    p_same = tr32.decoder.params.to_numpy()
+    tr16 = trainer.CaptionTrainer(cnn_params, spec0, p_same, BATCH, (IMG, IMG), 'bf16', device, seed=8, plan=plan)
+    if tune:
+        tr16.encoder.autotune()
+    imgs = torch.from_numpy(rng.uniform(-1, 1, (BATCH, IMG, IMG, 3)).astype(np.float32)).to(device)
+    caps = synth_captions(rng, BATCH)
+    dev_rel = {}
+    got = {}
+    for name, t in (('f32', tr32), ('bf16', tr16)):
+        im_e, fm_e = t.encoder.forward(imgs, use_graph=False)
+        r = t.decoder.train_step(fm_e, im_e, caps, training=False)
+        torch.cuda.synchronize()
+        got[name] = dict(fm=fm_e.float().cpu().numpy(), logits=r['logits'].cpu().numpy(), loss=float(r['loss']),
+                         grads=t.decoder.grads.to_numpy())
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    dev_rel['feature_map'] = rel(got['bf16']['fm'], got['f32']['fm'])
+    dev_rel['logits'] = rel(got['bf16']['logits'], got['f32']['logits'])
+    dev_rel['loss'] = abs(got['bf16']['loss'] - got['f32']['loss']) / abs(got['f32']['loss'])
+    gk = {k: rel(got['bf16']['grads'][k], got['f32']['grads'][k]) for k in got['f32']['grads']}
+    dev_rel['grad_max'] = max(gk.values())
+    dev_rel['grad_worst'] = max(gk, key=gk.get)
+    for _ in range(3):
+        tr32.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    n, t0 = 8, time.perf_counter()
+    for _ in range(n):
+        res = tr32.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        tr32.encoder.forward(imgs, use_graph=True)
+    e1.record(); e1.synchronize()
+    f32_ms = e0.elapsed_time(e1) / 3
+    out['xe_f32'] = {'images_per_sec': round(BATCH / dt, 1), 'ms_per_step': round(dt * 1e3, 3),
+                     'config': 'the same step with the exact-fp32 CNN plan (v_mfma_f32_16x16x4_f32, plain op order: the plan the '
+                               '1e-3 parity tests run), batch 64, one forward per step, no overlap',
+                     'cnn_forward_ms': round(f32_ms, 3),
+                     'cnn_f32_mfma_frac': round(FLOP_PER_IMAGE_CNN * BATCH / (f32_ms * 1e-3) / 157.3e12, 5),
+                     'bf16_plan_vs_f32_plan': {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev_rel.items()},
+                     'note': 'bf16_plan_vs_f32_plan: max|a-b| / max|b| per tensor between the benchmarked bf16 plan and the fp32 plan '
+                             'on one XE step of the same batch and weights, dropout off -- the price of the benchmarked precision'}
+    del tr32, tr16, got
+    torch.cuda.empty_cache()
+    # ---- the reference CLI's DEFAULT backbone: Inception-V1, attention over Mixed_4f = 14x14x832 (M = 196), batch 64 ------
+    plan_v1 = nets.CnnPlan('inception_v1', (IMG, IMG))
+    v1_params = plan_v1.init_params(seed=0)
+    Hf, Wf, Cf = plan_v1.fm_dims()
+    spec_v1 = cdec.DecoderSpec(M=Hf * Wf, C=Cf, Cg=1024)
+    trv = trainer.CaptionTrainer(v1_params, spec_v1, None, BATCH, (IMG, IMG), 'bf16', device, seed=9, plan=plan_v1)
+    if tune:
+        trv.encoder.autotune()
+    for _ in range(3):
+        trv.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    n, t0 = 10, time.perf_counter()
+    for _ in range(n):
+        res = trv.xe_step(imgs, caps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        trv.encoder.forward(imgs, use_graph=True)
+    e1.record(); e1.synchronize()
+    v1_ms = e0.elapsed_time(e1) / 5
+    flop_v1 = 2 * plan_v1.macs
+    v1_path = int(trv.decoder.lib.comic_decoder_train_path())
+    # attention bytes per time step (tied): B*M*D keys + B*(2D + H*M) small vectors, fp32
+    att_bytes = 4 * (BATCH * spec_v1.M * spec_v1.D + BATCH * (2 * spec_v1.D + spec_v1.H * spec_v1.M))
+    out['xe_v1'] = {'images_per_sec': round(BATCH / dt, 1), 'ms_per_step': round(dt * 1e3, 3),
+                    'config': 'reference default (train.py:56,65): Inception-V1, Mixed_4f %dx%dx%d (M = %d), COMIC-256, batch 64, '
+                              '224x224x3, one forward per step' % (Hf, Wf, Cf, Hf * Wf),
+                    'cnn_forward_ms': round(v1_ms, 3), 'flop_per_image': flop_v1,
+                    'cnn_mfma_frac': round(flop_v1 * BATCH / (v1_ms * 1e-3) / PEAK_BF16_MFMA, 5),
+                    'decoder_ms': round(dt * 1e3 - v1_ms, 3), 'decoder_time_loops': {0: 'per-step launches', 1: 'persistent forward', 3: 'persistent forward + backward'}.get(v1_path, str(v1_path)),
+                    'attention_roofline': {'bound': 'hbm', 'bytes_per_time_step': att_bytes, 'unit': 'GB/s', 'peak': 8000.0,
+                                           'note': 'keys of a batch row are 401 KB fp32 at M = 196: more than a CU\'s LDS, so the '
+                                                   'persistent loops (M <= 64 forward, M <= 28 backward) do not cover this geometry'},
+                    'loss': round(float(res['loss']), 4)}
+    del trv
     torch.cuda.empty_cache()
     # ---- the 224 x 224 encoder at 64 images per forward (no grouping): the same roofline definition as `roofline.frac` --
     enc64 = nets.CnnEncoder(plan, cnn_params, BATCH, 'bf16', device)

@@ -123,6 +123,20 @@ def adam_to_tf(dec_spec, m, v, t, beta1=0.9, beta2=0.999):
     return out
 
 
+def momentum_to_tf(dec_spec, accum):
+    """tf.train.MomentumOptimizer keeps ONE slot per variable, named `<scope>/<var>/Momentum`, and no power accumulators."""
+    names = decoder_var_names(dec_spec)
+    return {ADAM_SCOPE + n + '/Momentum': np.asarray(accum[k], np.float32) for k, n in names.items()}
+
+
+def momentum_from_tf(dec_spec, arrays):
+    """Inverse of momentum_to_tf: -> accum dict keyed like the decoder parameters, or None."""
+    names = decoder_var_names(dec_spec)
+    if not all(ADAM_SCOPE + n + '/Momentum' in arrays for n in names.values()):
+        return None
+    return {k: arrays[ADAM_SCOPE + n + '/Momentum'] for k, n in names.items()}
+
+
 def adam_from_tf(dec_spec, arrays):
     """Inverse of adam_to_tf: -> (m, v) dicts keyed like the decoder parameters, or None."""
     names = decoder_var_names(dec_spec)

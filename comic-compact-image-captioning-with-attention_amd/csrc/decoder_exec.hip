@@ -116,6 +116,42 @@ SideLane* side_lane() {
   return L;
 }
 
+thread_local void* g_splitk_ws = nullptr;   // split-K scratch of the GEMM helpers below (one per lane)
+
+// Fork / join of the side lane as a scope: whatever path leaves the scope (every RC(...) can return early), the lane
+// is joined back into the caller's stream and the split-K scratch pointer is restored -- a capture of the step is
+// never left with an unjoined stream, and a later step is never ordered behind the stragglers of a failed one.
+struct LaneScope {
+  SideLane* L;
+  hipStream_t st;
+  void* saved_ws;
+  bool forked = false;
+  int rc = 0;
+  LaneScope(SideLane* lane, hipStream_t main, void* lane_ws) : L(lane), st(main), saved_ws(g_splitk_ws) {
+    if (!L) return;
+    if (hipEventRecord(L->fork, st) != hipSuccess || hipStreamWaitEvent(L->s, L->fork, 0) != hipSuccess) {
+      comic_set_error("train_step: cannot fork the side lane");
+      rc = 2;
+      return;
+    }
+    forked = true;
+    g_splitk_ws = lane_ws;
+  }
+  hipStream_t lane() const { return forked ? L->s : st; }
+  void main_ws() { g_splitk_ws = saved_ws; }      // launches on the caller's stream from here on
+  int join() {
+    g_splitk_ws = saved_ws;
+    if (!forked) return 0;
+    forked = false;
+    if (hipEventRecord(L->join, L->s) != hipSuccess || hipStreamWaitEvent(st, L->join, 0) != hipSuccess) {
+      comic_set_error("train_step: cannot join the side lane");
+      return 2;
+    }
+    return 0;
+  }
+  ~LaneScope() { (void)join(); }
+};
+
 #define RC(x)               \
   do {                      \
     int rc__ = (x);         \
@@ -451,7 +487,6 @@ inline int fill(float* p, float v, long n, hipStream_t st) {
 }
 // split-K scratch of the running executor call (carved from the caller's workspace)
 constexpr int64_t kSplitKBytes = 32ll << 20;
-thread_local void* g_splitk_ws = nullptr;
 
 inline int gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int ta, int tb, float beta, hipStream_t st) {
@@ -723,25 +758,19 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // ------------------------------------------------------------------ forward ------------
   // the rnn init state (a chain of small products) on the side lane, beside the memory projections
   SideLane* L = side_lane();
-  void* const ws_a = g_splitk_ws;
-  if (L) {
-    COMIC_REQUIRE(hipEventRecord(L->fork, st) == hipSuccess && hipStreamWaitEvent(L->s, L->fork, 0) == hipSuccess,
-                  "train_step: cannot fork the side lane");
-    g_splitk_ws = splitk_ws_b;
-  }
   {
-    hipStream_t sl = L ? L->s : st;
+    LaneScope lane(L, st, splitk_ws_b);
+    RC(lane.rc);
+    hipStream_t sl = lane.lane();
     // weight panels of the fused step kernels (the persistent backward reads K and W_q in place): needed by the time
     // loop only, so they are packed on the side lane too
     if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, sl));
     if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, sl));
     RC(rnn_init_fwd(d, p, im_embed, B, drop_in ? mask_init_in : nullptr, ib, cs, hs, sl));
+    lane.main_ws();
+    RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
+    RC(lane.join());
   }
-  g_splitk_ws = ws_a;
-  RC(memory_projections(d, p, fm, B, keys, values_buf, &values, st));
-  if (L)
-    COMIC_REQUIRE(hipEventRecord(L->join, L->s) == hipSuccess && hipStreamWaitEvent(st, L->join, 0) == hipSuccess,
-                  "train_step: cannot join the side lane");
   // operand rows before the loop: the x part of every step (embedding lookup + input dropout, hoisted) and step 0's
   // att part (zero: dropout of 0 is 0) and h part (h0)
   {
@@ -920,13 +949,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     }
   }
   // ---- gradients that do not feed the recurrence, on two lanes (side_lane) ------------------------------------------
-  hipStream_t sb = st;
-  if (L) {
-    COMIC_REQUIRE(hipEventRecord(L->fork, st) == hipSuccess && hipStreamWaitEvent(L->s, L->fork, 0) == hipSuccess,
-                  "train_step: cannot fork the gradient lane");
-    sb = L->s;
-    g_splitk_ws = splitk_ws_b;
-  }
+  LaneScope glane(L, st, splitk_ws_b);
+  RC(glane.rc);
+  hipStream_t sb = glane.lane();
   // lane B: output projection, embedding, query layer, memory projections, attention parameters
   RC(gemm_big(y_all, dlogits, gr->W_o, nullptr, D, V, Tp * B, D, V, V, 1, 0, 0.f, sb));
   if (persist_b) {   // the embedding third of d gates * K^T, all steps at once, and its input dropout
@@ -952,7 +977,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     else RC(comic_colsum_ws(pgrad, tmp, Tp * B, 3 * D + 1, 0.f, (float*)g_splitk_ws, sb));
     hipLaunchKernelGGL(scatter_pgrad_kernel, dim3(cdiv(D, 256)), dim3(256), 0, sb, tmp, gr->v, gr->ln_g, gr->ln_b, gr->tau, D);
   }
-  g_splitk_ws = ws_a;
+  glane.main_ws();
   // lane A: output bias, LSTM kernel and bias, then the rnn init (which accumulates into both)
   RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
   RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
@@ -974,9 +999,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   }
   RC(gemm_big(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
   if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
-  if (L)
-    COMIC_REQUIRE(hipEventRecord(L->join, sb) == hipSuccess && hipStreamWaitEvent(st, L->join, 0) == hipSuccess,
-                  "train_step: cannot join the gradient lane");
+  RC(glane.join());
   if (persist) {
     // a persistent loop that timed out leaves garbage everywhere: NaN losses and zero gradients (no host check needed
     // for the optimiser step that follows to be harmless; the host raises at its next look at the loss)

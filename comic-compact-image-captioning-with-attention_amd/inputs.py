@@ -160,7 +160,7 @@ class DecodePool(object):
     def decode_batch(self, paths):
         """-> (block, [(offset, h, w)], bytes spanned); waits for the pixels."""
         blk, off, res = self.decode_batch_async(paths)
-        return blk, self.geometry(paths, res), off
+        return blk, self.geometry(paths, res, blk), off
 
     def decode_batch_async(self, paths):
         """-> (block, bytes spanned, async result).  Every image gets a fixed slot of `slot_bytes` in a free staging
@@ -177,9 +177,20 @@ class DecodePool(object):
                                                    for i, p in enumerate(paths)])
         return blk, n * self.slot_bytes, res
 
-    def geometry(self, paths, res):
+    def geometry(self, paths, res, blk=None, timeout=120.0):
+        """Waits for the workers of one batch.  multiprocessing.Pool silently replaces a worker that dies (out of
+        memory, a crash inside libjpeg on a corrupt file) and the task it held never completes: the wait is bounded,
+        the staging block goes back to the free list and the batch fails with the file names instead of hanging."""
+        import multiprocessing as mp
+        try:
+            sizes = res.get(timeout=timeout)
+        except mp.TimeoutError:
+            if blk is not None:
+                self.release(blk)
+            raise RuntimeError('JPEG decode workers did not return within %.0f s (a worker process died?) for: %s'
+                               % (timeout, ', '.join(str(p) for p in paths[:4]) + (' ...' if len(paths) > 4 else '')))
         out = []
-        for i, (p, (h, w)) in enumerate(zip(paths, res.get())):
+        for i, (p, (h, w)) in enumerate(zip(paths, sizes)):
             if h < 0:
                 raise ValueError('%s decodes to %dx%d: larger than the loader slot of %d bytes (config.loader_slot_bytes)'
                                  % (p, -h, -w, self.slot_bytes))

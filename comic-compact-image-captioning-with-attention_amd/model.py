@@ -212,9 +212,12 @@ class ModelBase(object):
                 o.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v']))
             else:
                 slots = ckpt.adam_from_tf(self.spec, extra)        # TF bundle: per-variable Adam / Adam_1
-                if slots:
+                accum = ckpt.momentum_from_tf(self.spec, extra)    # ... or MomentumOptimizer's single `Momentum` slot
+                if slots and not isinstance(o, optim.MomentumTF):
                     o.m.load(slots[0])
                     o.v.load(slots[1])
+                elif accum and isinstance(o, optim.MomentumTF):
+                    o.m.load(accum)
             if 'optimise/caption/head_adam_m' in extra and 'opt_head' in self._share:
                 oh = self._share['opt_head']
                 oh.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/head_adam_m']))
@@ -265,7 +268,9 @@ class ModelBase(object):
         fmt = getattr(self._config, 'checkpoint_format', 'npz')
         if not compact and 'opt' in self._share:
             o = self._share['opt']
-            if fmt == 'tf':
+            if fmt == 'tf' and isinstance(o, optim.MomentumTF):     # `--optimiser sgd`: <var>/Momentum, no beta powers
+                extra = ckpt.momentum_to_tf(self.spec, o.m.to_numpy())
+            elif fmt == 'tf':
                 extra = ckpt.adam_to_tf(self.spec, o.m.to_numpy(), o.v.to_numpy(), o.t, o.beta1, o.beta2)
             else:
                 extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(),

@@ -491,6 +491,14 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
     assert 'model-7"' not in state and 'model-8"' not in state and 'model-9"' in state and 'model-10"' in state
     assert not os.path.isfile(str(tmp_path / 'model-8.index')) and os.path.isfile(str(tmp_path / 'model-10.index'))
     assert ckpt.latest_checkpoint(str(tmp_path), 'model').endswith('model-10')
+    # `--optimiser sgd`: tf.train.MomentumOptimizer's layout -- one `<var>/Momentum` slot, no beta power accumulators
+    mom = ckpt.momentum_to_tf(spec, m)
+    assert not any(k.endswith('/Adam') or 'beta1_power' in k for k in mom)
+    assert any(k.endswith('basic_lstm_cell/kernel/Momentum') for k in mom)
+    p2 = ckpt.save(str(tmp_path / 'sgd'), 3, cnn, spec, dec, mom, fmt='tf')
+    _, _, ex2 = ckpt.restore(p2, list(cnn), spec, resume_training=True)
+    acc = ckpt.momentum_from_tf(spec, ex2)
+    assert acc is not None and all(np.array_equal(acc[k], m[k]) for k in dec) and ckpt.adam_from_tf(spec, ex2) is None
 
 
 def test_cli_refuses_options_it_does_not_implement(tmp_path):
