@@ -233,7 +233,9 @@ def _dp_barrier():
 def try_to_train(train_fn, try_block=True, overwrite=False, **kargs):
     """Wrapper for the main training function."""
     config = conf.Config(**kargs)
-    config.overwrite_safety_check(overwrite)
+    if int(kargs.get('dp_rank', 0) or 0) == 0:         # data parallel: rank 0 alone checks / creates the run directory
+        config.overwrite_safety_check(overwrite)
+    _dp_barrier()
     if config.resume_training:
         print('INFO: Resuming training from checkpoint.')
         config = conf.load_config(pjoin(config.log_path, 'config.pkl'))

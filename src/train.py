@@ -162,25 +162,30 @@ def check_supported(kw):
 
 def main(argv=None):
     args = create_parser().parse_args(argv)
-    kwargs, train_fn_name, overwrite = build_kwargs(args)
     import torch
     import torch.distributed as dist
-    from comic_amd import train_fn as train
-    from comic_amd.trainer import DataParallel
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', kwargs['gpu'].split(',')[0] if world == 1 else '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(args.gpu).split(',')[0] if world == 1 else '0'))
     # COMIC_DIST_BACKEND=gloo: data-parallel rehearsal on fewer GPUs than ranks (the ranks share the visible devices)
     backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
     if backend != 'nccl':
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
-    dp = None
     if world > 1:
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
             dist.init_process_group(backend)
+    # every rank decides "new run or resume" from the SAME state of the experiments directory: the decision is taken
+    # (build_kwargs looks at log_path) before any rank may create it (try_to_train, behind this barrier)
+    kwargs, train_fn_name, overwrite = build_kwargs(args)
+    if world > 1:
+        dist.barrier()
+    from comic_amd import train_fn as train
+    from comic_amd.trainer import DataParallel
+    dp = None
+    if world > 1:
         dp = DataParallel(dist)
         # rand_seed stays the SAME on every rank: it seeds the parameter initialisers and the common shuffle; the
         # input managers shard the shuffled list by rank (config.dp_world / dp_rank)

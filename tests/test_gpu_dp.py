@@ -52,7 +52,7 @@ def test_two_ranks_through_train_fn_end_with_equal_parameters(tmp_path):
     assert not glob.glob(os.path.join(logs, 'mscoco', 'error__*')), open(glob.glob(os.path.join(logs, 'mscoco', 'error__*'))[0]).read()
     p0, p1 = (np.load(os.path.join(out, 'params_rank%d.npy' % r)) for r in (0, 1))
     s0, s1 = (int(np.load(os.path.join(out, 'step_rank%d.npy' % r))[0]) for r in (0, 1))
-    assert s0 == s1 == 3                                   # 24 images / (2 ranks x 4): three GLOBAL batches
+    assert s0 == s1 == 15                                  # 24 images x 5 captions / (2 ranks x 4): GLOBAL batches of one epoch
     assert np.isfinite(p0).all() and np.array_equal(p0, p1)
     run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01')
     assert os.path.isfile(os.path.join(run_dir, 'config.pkl')) and glob.glob(os.path.join(run_dir, 'model_compact-*.npz'))
