@@ -214,6 +214,10 @@ struct AttnArgs {
   int pgrad_overwrite;      // backward: 1 = store this step's parameter-gradient row instead of adding to it
   const int32_t* stop;      // decode loops: see comic_stopped (common.h)
   int stop_t;
+  // large memories (M >= kAttnSplitMinM, executor only): a batch row is served by gridDim.y workgroups; the scaled scores
+  // (forward and backward) and d alpha_d (backward) of all memory rows pass through these [B][H][M] scratch arrays
+  float* ws_s;
+  float* ws_d;
 };
 
 template <int EPL>
@@ -381,6 +385,179 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ---- large memories: gridDim.y workgroups per batch row ------------------------------------------------------------------
+// At M = 196 (Inception-V1 Mixed_4f, the reference CLI's default feature map) a batch row's keys are 401 KB and the
+// one-workgroup-per-row kernels above leave 192 of the 256 CUs idle at batch 64 (47 us forward, 59 us backward per time
+// step).  Split form: kernel 1 -- each of the S workgroups of a row scores its share of the memory rows (LayerNorm +
+// tanh: the VALU-heavy part) into a [B][H][M] scratch; kernel 2 -- every workgroup redoes the cheap probability fn of
+// the whole row from the scratch (workgroup 0 of the row writes alpha / alpha_d) and forms the context of ITS share of
+// the channels.  Same formulas; the context is summed over m in kCtxGroups interleaved chains instead of one.
+constexpr int kAttnSplitMinM = 49;
+
+template <int EPL>
+__global__ __launch_bounds__(kAttnThreads) void attn_scores_kernel(AttnArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
+  const int M = a.d.M, D = a.d.D, H = a.d.H;
+  const int b = blockIdx.x, S = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (M + S - 1) / S, m0 = (int)blockIdx.y * per, m1 = min(M, m0 + per);
+  const int dh = D / H, lph = dh / EPL;
+  const int k0 = lane * EPL, head = k0 / dh;
+  float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
+  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
+  for (int s = 1; s < a.q_parts; ++s) {
+    float qs[EPL];
+    load_row<EPL>(a.q + ((size_t)s * a.d.B + b) * D + k0, qs);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) qv[i] += qs[i];
+  }
+  if (a.q_out && wave == 0 && blockIdx.y == 0) {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) a.q_out[(size_t)b * D + k0 + i] = qv[i];
+  }
+  if (a.d.method == 0) {
+    load_row<EPL>(a.ln_g + k0, gv);
+    load_row<EPL>(a.ln_b + k0, bv);
+    load_row<EPL>(a.v + k0, vv);
+  }
+  const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
+  for (int m = m0 + wave; m < m1; m += kAttnWaves) {
+    float kr[EPL], rstd;
+    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
+    if ((lane % lph) == 0) a.ws_s[((size_t)b * H + head) * M + m] = raw / scale;
+  }
+}
+
+__global__ __launch_bounds__(kAttnThreads) void attn_ctx_kernel(AttnArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int M = a.d.M, H = a.d.H, Cv = a.d.Cv;
+  float* sc = sm;                 // [H][M]
+  float* red = sm + H * M;        // [kAttnThreads] partial context sums
+  const int b = blockIdx.x, S = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool writer = blockIdx.y == 0;
+  for (int i = tid; i < H * M; i += kAttnThreads) sc[i] = a.ws_s[(size_t)b * H * M + i];
+  __syncthreads();
+  for (int h = wave; h < H; h += kAttnWaves) {
+    float* row = sc + h * M;
+    const size_t go = ((size_t)b * H + h) * M;
+    if (a.d.prob == 0) {
+      float mx = -INFINITY;
+      for (int m = lane; m < M; m += 64) mx = fmaxf(mx, row[m]);
+      mx = wave_max(mx);
+      float s = 0.f;
+      for (int m = lane; m < M; m += 64) s += expf(row[m] - mx);
+      s = wave_sum(s);
+      for (int m = lane; m < M; m += 64) {
+        const float al = expf(row[m] - mx) / s;
+        const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go + m] : al;
+        if (writer) {
+          a.alpha[go + m] = al;
+          a.alpha_d[go + m] = ad;
+        }
+        row[m] = ad;
+      }
+    } else {
+      float s = 0.f;
+      for (int m = lane; m < M; m += 64) s += sigmoidf_(row[m]);
+      s = wave_sum(s);
+      for (int m = lane; m < M; m += 64) {
+        const float al = sigmoidf_(row[m]) / s;
+        const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go + m] : al;
+        if (writer) {
+          a.alpha[go + m] = al;
+          a.alpha_d[go + m] = ad;
+        }
+        row[m] = ad;
+      }
+    }
+  }
+  __syncthreads();
+  // context of the channels [c_lo, c_hi) of this workgroup: G chains over m per channel, then a fixed-order sum
+  const int dv = Cv / H;
+  const int CW = (Cv + S - 1) / S, c_lo = (int)blockIdx.y * CW, c_hi = min(Cv, c_lo + CW);
+  const int G = max(1, kAttnThreads / CW);
+  const int g = tid / CW, cl = tid - g * CW, c = c_lo + cl;
+  float acc = 0.f;
+  if (g < G && c < c_hi) {
+    const float* al = sc + (c / dv) * M;
+    const float* vp = a.values + (size_t)b * M * Cv + c;
+    for (int m = g; m < M; m += G) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid < CW && c_lo + tid < c_hi) {
+    float sum = 0.f;
+    for (int k = 0; k < G; ++k) sum += red[k * CW + tid];
+    const int cc = c_lo + tid;
+    a.ctx[(size_t)b * Cv + cc] = sum;
+    if (a.att_next) {  // impute_finished select + next step's (dropped) LSTM input
+      const bool fin = a.lens && a.t >= a.lens[b];
+      const float av = fin ? a.att_prev[(size_t)b * Cv + cc] : sum;
+      a.att_next[(size_t)b * Cv + cc] = av;
+      if (a.xh_next) {
+        float xv = av;
+        if (a.mask_next) xv = (xv / a.keep_in) * a.mask_next[(size_t)b * a.mask_ld + cc];
+        a.xh_next[(size_t)b * a.xh_ld + cc] = xv;
+      }
+    }
+  }
+}
+
+// Backward, kernel 1 of the split form: the recomputed scaled scores and d alpha_d of this workgroup's memory rows
+// (one pass over its key rows; d values of its rows when values are not tied).
+template <int EPL>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_scores_kernel(AttnArgs a) {
+  const int M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
+  const int b = blockIdx.x, S = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (M + S - 1) / S, m0 = (int)blockIdx.y * per, m1 = min(M, m0 + per);
+  const int dh = D / H, lph = dh / EPL;
+  const int k0 = lane * EPL, head = k0 / dh;
+  float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
+  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
+  if (a.d.method == 0) {
+    load_row<EPL>(a.ln_g + k0, gv);
+    load_row<EPL>(a.ln_b + k0, bv);
+    load_row<EPL>(a.v + k0, vv);
+  }
+  const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
+  const int dv = Cv / H, eplv = Cv / 64, lphv = dv / eplv;
+  const int c0 = lane * eplv, headv = c0 / dv;
+  const float* dctx = a.dctx + (size_t)b * Cv;
+  const float live = (a.lens && a.t >= a.lens[b]) ? 0.f : 1.f;
+  const bool tied = a.d.tied != 0;
+  float dcl[EPL];
+  if (tied) {
+    load_row<EPL>(dctx + k0, dcl);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) dcl[i] *= live;
+  }
+  for (int m = m0 + wave; m < m1; m += kAttnWaves) {
+    float kr[EPL], rstd;
+    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
+    if ((lane % lph) == 0) a.ws_s[((size_t)b * H + head) * M + m] = raw / scale;
+    float part = 0.f;
+    if (tied) {
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) part = fmaf(dcl[i], kr[i], part);
+    } else {
+      const size_t go = ((size_t)b * H + headv) * M + m;
+      const float al = a.alpha_in[go];
+      const float ad = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go] : al;
+      const float* vr = a.values + ((size_t)b * M + m) * Cv + c0;
+      float* dvr = a.dvalues + ((size_t)b * M + m) * Cv + c0;
+      for (int i = 0; i < eplv; ++i) {
+        const float dc = dctx[c0 + i] * live;
+        part = fmaf(dc, vr[i], part);
+        dvr[i] += ad * dc;
+      }
+    }
+    part = head_sum(part, lphv);
+    if ((lane % lphv) == 0) a.ws_d[((size_t)b * H + headv) * M + m] = part + (a.dmap ? a.dmap[(size_t)b * M + m] : 0.f);
+  }
+}
+
 template <int EPL>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -413,9 +590,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
   // ALL rows (the probability backward needs the full sum).  d q and the parameter-gradient row are then sums of two
   // contributions, added atomically into zero-filled buffers: with exactly two addends the result does not depend
   // on their order.
-  const bool split = gridDim.y == 2;
-  const int m0 = split ? (int)blockIdx.y * ((M + 1) >> 1) : 0;
-  const int m1 = split ? min(M, m0 + ((M + 1) >> 1)) : M;
+  // gridDim.y > 2 (large memories): phase A ran as attn_bwd_scores_kernel (a.ws_s / a.ws_d hold s and d alpha_d of ALL
+  // rows); the S contributions to d q and to the parameter-gradient row are added atomically (for S > 2 the sum of
+  // the partials depends on their arrival order in the last bits: the step is no longer bit-reproducible there)
+  const bool split = gridDim.y >= 2;
+  const int S_ = (int)gridDim.y, per_ = (M + S_ - 1) / S_;
+  const int m0 = split ? (int)blockIdx.y * per_ : 0;
+  const int m1 = split ? min(M, m0 + per_) : M;
+  const bool pre = a.ws_s != nullptr;
 
   // ---- phase A: scores (recomputed) and d alpha_d; d values accumulation ----------------
   // tied values: the value row IS the key row (one load), and the alpha_d * dctx term of
@@ -427,7 +609,16 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) dcl[i] *= live;
   }
-  for (int m = wave; m < M; m += kAttnWaves) {
+  if (pre) {
+    for (int i = tid; i < H * M; i += kAttnThreads) {
+      const size_t go = (size_t)b * H * M + i;
+      ss[i] = a.ws_s[go];
+      sd[i] = a.ws_d[go];
+      const float al = a.alpha_in[go];
+      sa[i] = a.mask_alpha ? (al / a.keep_alpha) * a.mask_alpha[go] : al;
+    }
+  }
+  for (int m = wave; m < (pre ? 0 : M); m += kAttnWaves) {
     float kr[EPL], rstd;
     load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
     const size_t go = ((size_t)b * H + headv) * M + m;
@@ -917,12 +1108,13 @@ int comic_lstm_gates_bwd_ex(const float* gates_act, const float* c_prev, const f
   return 0;
 }
 
+int comic_attn_splits(int B, int M);
 // executor-internal forms (fused state plumbing); the public ops pass no extras
 int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, int q_parts, float* q_out, hipStream_t st) {
+                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && alpha_d && ctx, "attn_fwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_fwd: add_LN needs ln_g/ln_b/v/tau");
@@ -934,6 +1126,17 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in; a.q_parts = q_parts; a.q_out = q_out;
   a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
   const size_t lds = (size_t)d->H * d->M * sizeof(float);
+  const int S = scores_ws ? comic_attn_splits(d->B, d->M) : 1;
+  if (S > 1) {        // large memory: S workgroups per batch row, scores and probability / context as two launches
+    a.ws_s = scores_ws;
+    int rc = attn_dispatch(d->D, [&](auto epl) {
+      hipLaunchKernelGGL((attn_scores_kernel<decltype(epl)::value>), dim3(d->B, S), dim3(kAttnThreads), 0, st, a);
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_ctx_kernel, dim3(d->B, S), dim3(kAttnThreads), lds + kAttnThreads * sizeof(float), st, a);
+    COMIC_LAUNCH_CHECK("attn_fwd (split)");
+    return 0;
+  }
   int rc = attn_dispatch(d->D, [&](auto epl) {
     hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
   });
@@ -942,11 +1145,19 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   return 0;
 }
 
+// workgroups per batch row of the attention kernels when a scratch for the split form is available: enough to put a
+// workgroup on every CU (batch 64 -> 4), 1 for the memories the one-workgroup kernels are built for
+int comic_attn_splits(int B, int M) {
+  if (M < kAttnSplitMinM || B < 1) return 1;
+  const int S = std::min(8, (256 + B - 1) / B);
+  return S >= 2 ? S : 1;
+}
+
 int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
                       const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
                       float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st,
-                      int pgrad_overwrite) {
+                      int pgrad_overwrite, float* ws_s, float* ws_d) {
   if (int rc = attn_check(d)) return rc;
   COMIC_REQUIRE(keys && values && q && alpha && dctx && dq && dkeys && dvalues, "attn_bwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_bwd: add_LN needs ln_g/ln_b/v/tau");
@@ -958,10 +1169,20 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.pgrad_overwrite = pgrad_overwrite;
   COMIC_REQUIRE(pgrad_overwrite != 2 || d->prob == 0, "attn_bwd: the split form needs the softmax probability fn");
   const size_t lds = ((size_t)d->H * d->M * 3 + kAttnWaves * 512 + kAttnWaves + 16) * sizeof(float);
+  // pgrad_overwrite == 2: split mode -- the caller zero-filled dq and the pgrad rows; two workgroups per batch row, or,
+  // with scratch for the scores and a large memory, comic_attn_splits workgroups behind attn_bwd_scores_kernel
+  const bool split = pgrad_overwrite == 2;
+  const int S = (split && ws_s && ws_d) ? comic_attn_splits(d->B, d->M) : 1;
+  if (S > 2) {
+    a.ws_s = ws_s;
+    a.ws_d = ws_d;
+    int rc0 = attn_dispatch(d->D, [&](auto epl) {
+      hipLaunchKernelGGL((attn_bwd_scores_kernel<decltype(epl)::value>), dim3(d->B, S), dim3(kAttnThreads), 0, st, a);
+    });
+    if (rc0) return rc0;
+  }
   int rc = attn_dispatch(d->D, [&](auto epl) {
-    // pgrad_overwrite == 2: split mode -- two workgroups per batch row; the caller zero-filled dq and the pgrad rows
-    const bool split = pgrad_overwrite == 2;
-    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B, split ? 2 : 1), dim3(kAttnThreads), lds, st, a);
+    hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B, S > 2 ? S : (split ? 2 : 1)), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_bwd");
@@ -973,7 +1194,7 @@ extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, 
                                    const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
                                    void* stream) {
   return comic_attn_fwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, mask_alpha, keep_alpha, alpha, alpha_d, ctx, nullptr,
-                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, 1, nullptr, (hipStream_t)stream);
+                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, 1, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,
@@ -982,7 +1203,7 @@ extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, 
                                    const float* dmap, float* dq, float* dkeys, float* dvalues, float* pgrad,
                                    void* stream) {
   return comic_attn_bwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, alpha, mask_alpha, keep_alpha, dctx, dmap, dq,
-                           dkeys, dvalues, pgrad, nullptr, 0, (hipStream_t)stream, 0);
+                           dkeys, dvalues, pgrad, nullptr, 0, (hipStream_t)stream, 0, nullptr, nullptr);
 }
 
 // t_rows time steps of logits are processed; the [B, t_stride] tables are indexed b*t_stride + t

@@ -33,7 +33,8 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, int q_parts, float* q_out, hipStream_t st);
+                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st);
+int comic_attn_splits(int B, int M);
 int comic_colsum_ws(const float* in, float* out, int rows, int cols, float beta, float* ws, hipStream_t st);
 int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int trans_b,
                            void* ws, int64_t ws_bytes, int* S_out, hipStream_t st);
@@ -44,7 +45,7 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* alpha,
                       const float* mask_alpha, float keep_alpha, const float* dctx, const float* dmap, float* dq,
                       float* dkeys, float* dvalues, float* pgrad, const int32_t* lens, int t, hipStream_t st,
-                      int pgrad_overwrite);
+                      int pgrad_overwrite, float* ws_s = nullptr, float* ws_d = nullptr);
 int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_prev, float* gates_act, float* c_new,
                             float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
@@ -604,7 +605,7 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
   float* part = (float*)g_splitk_ws;
   RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
   RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha, alpha_d_out,
-                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, st));
+                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, nullptr, st));
   if (d->context_layer) {
     RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
   }
@@ -741,6 +742,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const bool persist_b = persist && persist_bwd_enabled() &&
                          comic_persist_bwd_supported(B, D, E, A, M, H, Cv, d->method, d->prob, d->context_layer, ad.tied);
   g_train_path = (persist ? 1 : 0) | (persist_b ? 2 : 0);
+  // scratch of the split attention kernels (large memories: comic_attn_splits workgroups per batch row): the d q
+  // partials of the persistent backward loop, free whenever the per-step kernels run ([Tp][B][4][D] >= 2 x [B][H][M])
+  float* attn_ws = (!persist_b && comic_attn_splits(B, M) > 1 && (long)T * 4 * D >= 2L * H * M) ? dq_part : nullptr;
   if (persist) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
     ComicPersistRanges pr{};
     const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
@@ -829,11 +833,11 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (!d->context_layer) {
       RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
                            alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, lens, t,
-                           att_prev, att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, S2, q_t, st));
+                           att_prev, att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, S2, q_t, attn_ws, st));
     } else {
       RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, mal, d->keep_alpha,
                            alpha_all + (size_t)t * B * H * M, attn_hist + (size_t)t * B * H * M, ctx_t, nullptr, 0,
-                           nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S2, q_t, st));
+                           nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S2, q_t, attn_ws, st));
       RC(gemm(ctx_t, p->W_a, att_new, nullptr, B, D, Cv, Cv, D, D, 0, 0, 0.f, st));
       hipLaunchKernelGGL(select_att_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, att_prev, att_new, lens, t,
                          att_next, xh_n ? xh_n + E : nullptr, Wd, mask_n, EA, d->keep_in, B, A);
@@ -909,7 +913,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, datt,
                            use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
-                           pgrad + (size_t)t * B * (3 * D + 1), lens, t, st, attn_bwd_mode));
+                           pgrad + (size_t)t * B * (3 * D + 1), lens, t, st, attn_bwd_mode, attn_ws,
+                           attn_ws ? attn_ws + (size_t)B * H * M : nullptr));
       carry = 1;
     } else {
       hipLaunchKernelGGL(split_live_kernel, dim3(cdiv(B * A, 256)), dim3(256), 0, st, datt, datt_live, lens, t, B, A);
@@ -919,7 +924,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(comic_attn_bwd_ex(&ad, keys, values, q_all + (size_t)t * B * D, p->ln_g, p->ln_b, p->v, p->tau,
                            alpha_all + (size_t)t * B * H * M, mal, d->keep_alpha, dctx,
                            use_map ? dmap + (size_t)t * B * M : nullptr, dq_t, dkeys, dvalues,
-                           pgrad + (size_t)t * B * (3 * D + 1), nullptr, 0, st, attn_bwd_mode));
+                           pgrad + (size_t)t * B * (3 * D + 1), nullptr, 0, st, attn_bwd_mode, attn_ws,
+                           attn_ws ? attn_ws + (size_t)B * H * M : nullptr));
       carry = 0;
     }
     float* dy_t = dy_all + (size_t)t * B * D;

@@ -386,6 +386,10 @@ TRAIN_VARIANTS = [
     # persistent time loop (decoder_persist.hip; D = 512 only): the other memory / alignment / probability forms
     dict(D=512, E=256, fm_projection='independent', prob='sigmoid', H=4),
     dict(D=512, E=128, method='dot', H=16, M=64),                               # W_q columns from L2 (keys fill the LDS)
+    # the reference CLI's default geometry (train.py:56,65): Inception-V1 Mixed_4f, 14 x 14 x 832 -> M = 196; the
+    # attention kernels run in their split form (several workgroups per batch row, decoder.hip)
+    dict(D=512, E=256, C=832, Cg=1024, M=196),
+    dict(D=512, E=256, C=832, Cg=1024, M=196, fm_projection='independent', prob='sigmoid'),
 ]
 
 
