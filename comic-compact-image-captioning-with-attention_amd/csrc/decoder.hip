@@ -1149,7 +1149,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
 // workgroup on every CU (batch 64 -> 4), 1 for the memories the one-workgroup kernels are built for
 int comic_attn_splits(int B, int M) {
   if (M < kAttnSplitMinM || B < 1) return 1;
-  const int S = std::min(8, (256 + B - 1) / B);
+  const int S = std::min(8, (256 + B - 1) / B);      // 8 per row at batch 64 measured slower (4.13 vs 3.68 ms per step)
   return S >= 2 ? S : 1;
 }
 
