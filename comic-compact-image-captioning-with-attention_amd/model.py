@@ -294,8 +294,11 @@ class ModelBase(object):
 
     # ---- decode (model_base.py:692-757, :272-314) ----------------------------------------
     def _decode(self, images, beam_size, max_length, top_beam=True, want_attention=True):
-        c = self._config
         im_embed, fm = self._encode(images)
+        return self._decode_features(im_embed, fm, beam_size, max_length, top_beam, want_attention)
+
+    def _decode_features(self, im_embed, fm, beam_size, max_length, top_beam=True, want_attention=True):
+        c = self._config
         iters = self.decoder.max_iterations(max_length, len(c.wtoi))
         if beam_size > 1:
             r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention)
@@ -407,10 +410,53 @@ class CaptionModel(ModelBase):
         return res['loss']
 
     def infer(self, batch=None):
-        """== sess.run(m_infer.infer_output) -> [dec_preds (B,T), attention_maps (B,H,T,M)]."""
+        """== sess.run(m_infer.infer_output) -> [dec_preds (B,T), attention_maps (B,H,T,M)].
+        Batches drawn from the input pipeline are decoded with the encoder forward of the NEXT batch already running on
+        a second stream (the decode steps are small launches that leave most of the GPU idle; config.pipeline_encoder,
+        default on): the same kernels on the same rows, so the captions equal the serial order's."""
         c = self._config
-        images = batch[0] if isinstance(batch, (tuple, list)) else (batch if batch is not None else next(self.batch_ops)[0])
-        ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+        if batch is not None or not (getattr(c, 'pipeline_encoder', True) and str(self.device).startswith('cuda')
+                                     and os.environ.get('COMIC_PIPELINE_INFER', '1') == '1'):
+            images = batch[0] if isinstance(batch, (tuple, list)) else (batch if batch is not None else next(self.batch_ops)[0])
+            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+            self.infer_output = [ids, attn]
+            return self.infer_output
+        torch = self.torch
+
+        def next_images():
+            try:
+                b = next(self.batch_ops)
+            except StopIteration:
+                return None
+            im = b[0] if isinstance(b, (tuple, list)) else b
+            return im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im, np.float32)).to(self.device)
+        if getattr(self, '_infer_tail', None) is not None:           # a batch of another size: served serially
+            images, self._infer_tail = self._infer_tail, None
+            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+            self.infer_output = [ids, attn]
+            return self.infer_output
+        if getattr(self, '_ipipe', None) is None:
+            from .trainer import EncoderPipeline
+            first = next_images()
+            self._ipipe = EncoderPipeline(self._encoder_for(int(first.shape[0])), int(first.shape[0]), 1, self.device)
+            self._ipipe.submit(first)
+        if self._ipipe.steps_ready == 0:                              # nothing in flight (the previous call hit a ragged batch)
+            nxt = next_images()
+            if nxt is None:
+                raise StopIteration('infer(): the input pipeline is exhausted')
+            if int(nxt.shape[0]) != self._ipipe.batch:
+                self._infer_tail = nxt
+                return self.infer()
+            self._ipipe.submit(nxt)
+        im_embed, fm, release = self._ipipe.take()
+        im_embed, fm = self._embed(im_embed).clone(), fm.clone()     # the staging copy goes back to the pipeline at once
+        release()
+        nxt = next_images()
+        if nxt is not None and int(nxt.shape[0]) == self._ipipe.batch:
+            self._ipipe.submit(nxt)                                   # runs under this batch's decode steps
+        elif nxt is not None:                                         # a ragged batch: served serially by the next call
+            self._infer_tail = nxt
+        ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True)
         self.infer_output = [ids, attn]
         return self.infer_output
 

@@ -42,7 +42,7 @@ def test_train_infer_scst_cli(tmp_path):
     assert os.path.isfile(os.path.join(run_dir, 'model_size.txt'))
     # ---- inference ----
     _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
-                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--infer_set', 'test', '--batch_size_infer', '2',
                                                  '--annotations_file', 'captions_test_annotations.json'])
     out_dir = os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0')
     caps = glob.glob(os.path.join(out_dir, 'captions___*.json'))
@@ -54,6 +54,16 @@ def test_train_infer_scst_cli(tmp_path):
     scores = open(os.path.join(out_dir, 'metric_scores.txt')).read()
     assert all(m in scores for m in ('Bleu_1', 'Bleu_4', 'ROUGE_L', 'CIDEr')) and 'METEOR' not in scores
     assert len(open(os.path.join(out_dir, 'metric_scores.csv')).read().strip().split(',')) == 7
+    # the inference loop runs the encoder of batch i + 1 under the decode of batch i: the serial loop writes the same captions
+    os.rename(caps[0], caps[0] + '.pipelined')
+    os.environ['COMIC_PIPELINE_INFER'] = '0'
+    try:
+        _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                     '--infer_set', 'test', '--batch_size_infer', '2',
+                                                     '--get_metric_score', ''])
+    finally:
+        del os.environ['COMIC_PIPELINE_INFER']
+    assert json.load(open(caps[0])) == json.load(open(caps[0] + '.pipelined'))
     # ---- CNN fine-tune: restores the decoder run, trains CNN + decoder, saves both ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '8',
                                                           '--max_epoch', '1', '--checkpoint_format', 'tf'])
