@@ -218,6 +218,8 @@ struct AttnArgs {
   // (forward and backward) and d alpha_d (backward) of all memory rows pass through these [B][H][M] scratch arrays
   float* ws_s;
   float* ws_d;
+  float* ws_parts;          // backward, gridDim.y > 2: [gridDim.y][B][4D + 4] partial d q | d v | d ln_g | d ln_b | d tau rows,
+                            // summed in a fixed order by attn_bwd_reduce_kernel (no float atomics: bit-reproducible)
 };
 
 template <int EPL>
@@ -761,6 +763,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
       }
     }
   };
+  if (a.ws_parts) {     // more than two workgroups per row: partial rows, reduced in a fixed order by the next launch
+    float* pr = a.ws_parts + ((size_t)blockIdx.y * a.d.B + b) * (4 * D + 4);
+    reduce_store(dq_acc, pr, 0);
+    if (a.d.method == 0 && a.pgrad) {
+      reduce_store(dv_acc, pr + D, 0);
+      reduce_store(dg_acc, pr + 2 * D, 0);
+      reduce_store(db_acc, pr + 3 * D, 0);
+      if (tid == 0) {
+        float dt = 0.f;
+        for (int w = 0; w < kAttnWaves; ++w) dt += misc[w];
+        pr[4 * D] = dt / a.tau[0];
+      }
+    }
+    return;
+  }
   reduce_store(dq_acc, a.dq + (size_t)b * D, split ? 2 : 0);
   if (a.d.method == 0 && a.pgrad) {
     float* pg = a.pgrad + (size_t)b * (3 * D + 1);
@@ -778,6 +795,23 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_kernel(AttnArgs a) {
         pg[3 * D] = (mode == 1 ? pg[3 * D] : 0.f) + dt / a.tau[0];
     }
   }
+}
+
+// d q [B][D] and the parameter-gradient row [B][3D + 1] of a step from the S partial rows of the split backward kernel
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __restrict__ parts, float* __restrict__ dq,
+                                                              float* __restrict__ pgrad, int B, int D, int S, int n) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float v[8];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) v[y] = y < S ? parts[((size_t)y * B + b) * (4 * D + 4) + k] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) s += v[y];                 // fixed order; the absent partials add exact zeros
+  if (k < D)
+    dq[(size_t)b * D + k] = s;
+  else
+    pgrad[(size_t)b * (3 * D + 1) + (k - D)] = s;
 }
 
 // ------------------------------------------------------------------ cross-entropy -----
@@ -1176,6 +1210,7 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   if (S > 2) {
     a.ws_s = ws_s;
     a.ws_d = ws_d;
+    a.ws_parts = ws_d + (size_t)d->B * d->H * d->M;        // the caller's scratch holds all three (comic_attn_bwd_scratch)
     int rc0 = attn_dispatch(d->D, [&](auto epl) {
       hipLaunchKernelGGL((attn_bwd_scores_kernel<decltype(epl)::value>), dim3(d->B, S), dim3(kAttnThreads), 0, st, a);
     });
@@ -1185,8 +1220,18 @@ int comic_attn_bwd_ex(const comic_attn_desc* d, const float* keys, const float* 
     hipLaunchKernelGGL((attn_bwd_kernel<decltype(epl)::value>), dim3(d->B, S > 2 ? S : (split ? 2 : 1)), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
+  if (S > 2) {
+    const int n = (d->method == 0 && pgrad) ? 4 * d->D + 1 : d->D;
+    hipLaunchKernelGGL(attn_bwd_reduce_kernel, dim3((n + 255) / 256, d->B), dim3(256), 0, st, a.ws_parts, dq, pgrad, d->B,
+                       d->D, S, n);
+  }
   COMIC_LAUNCH_CHECK("attn_bwd");
   return 0;
+}
+
+// floats of scratch the split backward needs behind ws_s: d alpha_d [B][H][M] + the partial rows
+long comic_attn_bwd_scratch(int B, int H, int M, int D) {
+  return (long)B * H * M + (long)comic_attn_splits(B, M) * B * (4 * D + 4);
 }
 
 extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,

@@ -35,6 +35,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
                       int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st);
 int comic_attn_splits(int B, int M);
+long comic_attn_bwd_scratch(int B, int H, int M, int D);
 int comic_colsum_ws(const float* in, float* out, int rows, int cols, float beta, float* ws, hipStream_t st);
 int comic_gemm_f32_partial(const float* A, const float* B, int M, int N, int K, int lda, int ldb, int trans_b,
                            void* ws, int64_t ws_bytes, int* S_out, hipStream_t st);
@@ -604,8 +605,11 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
   int S = 1;
   float* part = (float*)g_splitk_ws;
   RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
+  // large memories (Inception-V1 Mixed_4f: M = 196): the attention step in its split form; its [rows][H][M] scratch is the
+  // pre-activation gate buffer, which the fused LSTM step above never materialises
+  float* attn_ws = ((long)d->H * d->M <= 4L * D) ? sb.g : nullptr;
   RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha, alpha_d_out,
-                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, nullptr, st));
+                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, attn_ws, st));
   if (d->context_layer) {
     RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
   }
@@ -744,7 +748,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   g_train_path = (persist ? 1 : 0) | (persist_b ? 2 : 0);
   // scratch of the split attention kernels (large memories: comic_attn_splits workgroups per batch row): the d q
   // partials of the persistent backward loop, free whenever the per-step kernels run ([Tp][B][4][D] >= 2 x [B][H][M])
-  float* attn_ws = (!persist_b && comic_attn_splits(B, M) > 1 && (long)T * 4 * D >= 2L * H * M) ? dq_part : nullptr;
+  float* attn_ws = (!persist_b && comic_attn_splits(B, M) > 1 &&
+                    TB * 4 * D >= (long)B * H * M + comic_attn_bwd_scratch(B, H, M, D)) ? dq_part : nullptr;
   if (persist) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
     ComicPersistRanges pr{};
     const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;

@@ -707,7 +707,9 @@ def test_known_answer_param_count_on_device():
                                             init_method='project_hidden', start_id=298, end_id=299),
                                 # large vocabulary: the beam step runs split over several workgroups per entry
                                 dict(fm_projection=None, H=1, token_type='word', V=9000,
-                                     init_method='project_hidden', start_id=8998, end_id=8999)])
+                                     init_method='project_hidden', start_id=8998, end_id=8999),
+                                # Inception-V1 Mixed_4f (M = 196): the attention step in its split form
+                                dict(C=832, Cg=1024, M=196)])
 def test_greedy_and_beam_match_oracle(kw):
     spec, cfg = _spec_and_cfg(**kw)
     p = _rand_params(cfg, 5)
