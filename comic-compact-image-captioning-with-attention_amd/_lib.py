@@ -42,12 +42,12 @@ class DecoderDesc(C.Structure):
 # comic_decoder_desc.flags (include/comic_hip.h COMIC_DEC_*).  The library reads no environment: the A/B switches of
 # the decoder executors are environment variables of the PYTHON side, read at every call (tests flip them inside one
 # process) by decoder_flags_from_env() and handed over in the descriptor.
-DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS = (
-    1, 2, 4, 8, 16, 32, 64)
+(DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS,
+ DEC_NO_BEAM_LOGITS) = (1, 2, 4, 8, 16, 32, 64, 128)
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
-            ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS))
+            ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS), ('COMIC_BEAM_LOGITS', '0', DEC_NO_BEAM_LOGITS))
 
 
 def decoder_flags_from_env():
@@ -130,6 +130,7 @@ _SIGS = {
     'comic_decoder_train_path': (c_int, []),
     'comic_debug_inject_persist_timeout': (c_int, []),
     'comic_decoder_greedy_path': (c_int, []),
+    'comic_decoder_beam_path': (c_int, []),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
                                          P, P, P, P, P, c_int64, P]),

@@ -1,0 +1,516 @@
+// Beam-search step at a large vocabulary (word tokens: V = 25 599, rows = batch x beam = 150): the vocabulary projection
+// and the first half of the top-k as ONE streaming launch, the second half as a merge launch.
+//
+// Replaces, inside comic_decoder_beam (rnn_decoder_beam_search, common/ops_rnn.py:49-112; tf.contrib.seq2seq
+// _beam_search_step [TF-1.9]): logits = y W_o + b_o, log_softmax, _mask_probs, top_k over the flattened beam * V axis.
+// Round 2 ran it as four launches -- a hi/lo-split GEMM that wrote the [rows][V] logits (43.7 us: W_o streamed at
+// 1.2 TB/s), a statistics pass and a per-chunk top-k pass that read them back (8.0 + 14.8 us) and a merge (6.6 us).
+//
+// Here a workgroup owns a CHUNK of 128 vocabulary columns for ALL rows:
+//   * W_o is pre-packed once per decode call (beam_pack_wo_kernel): per chunk and 32-deep k-step the eight 16-column
+//     tiles as bf16 hi and lo halves in MFMA-fragment order -- a chunk's K-quarter is 64 contiguous KB that go
+//     global -> LDS by LDS-DMA (two quarters in flight), the 52 MB stream is read exactly once per step;
+//   * the eight waves split the ROWS (16-row tiles); a wave converts only its own rows of y to hi / lo and reads the
+//     weight fragments from the LDS: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (the arithmetic of
+//     comic_gemm_f32_split3, product error about 2^-16);
+//   * D[v][row] orientation: a lane holds 4 consecutive columns of ONE row per tile, so the per-row work of the chunk is
+//     lane-local plus two cross-lane steps (lanes r, r+16, r+32, r+48): the chunk's maximum and sum of exponentials
+//     (the log-softmax partials) and its top-W columns BY LOGIT -- inside one beam the order by logit is the order by
+//     total score, so the global top-W of an entry lies in the union of its (beam, chunk) top-W lists;
+//   * the logits never reach memory: per row and chunk 2 + 2W words instead of 128.
+// The merge launch (one workgroup per entry) combines the partials in chunk order into the log-softmax constants,
+// scores the candidates, applies _mask_probs to finished beams (their candidates are synthesised: EOS and the lowest
+// columns) and selects the top W under the total order (score descending, flat index ascending) with the same
+// bookkeeping as beam_merge_kernel.
+#include <float.h>
+
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kChunkCols = 128;         // vocabulary columns per workgroup (eight 16-column tiles)
+constexpr int kQuarterBytes = 64 * 1024;
+
+struct BLVal {
+  float v;
+  int i;
+};
+__device__ __forceinline__ bool bl_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// ---- W_o [D][ld] fp32 -> per chunk / k32-step / tile / {hi, lo} / lane: 8 bf16 ---------------------------------------
+// (+ b_o padded with zeros to whole chunks, behind the fragments)
+__global__ __launch_bounds__(256) void beam_pack_wo_kernel(const float* __restrict__ W_o, const float* __restrict__ b_o, int ld,
+                                                           uint4* __restrict__ out, int D, int V, long units) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) {
+    float* bias = (float*)(out + units);
+    const long v = u - units;
+    if (v < (long)((V + kChunkCols - 1) / kChunkCols) * kChunkCols) bias[v] = v < V ? b_o[v] : 0.f;
+    return;
+  }
+  const int KS = D / 32;
+  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1), vt = (int)((u >> 7) & 7);
+  const long t = u >> 10;
+  const int s = (int)(t % KS);
+  const long c = t / KS;
+  const int fr = lane & 15, fg = lane >> 4;
+  const long v = c * kChunkCols + vt * 16 + fr;
+  const int k0 = s * 32 + fg * 8;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) x[e] = v < V ? W_o[(size_t)(k0 + 2 * j + e) * ld + v] : 0.f;
+    const uint32_t h = pack_bf16x2(x[0], x[1]);
+    w[j] = hl == 0 ? h : pack_bf16x2(x[0] - __uint_as_float(h << 16), x[1] - __uint_as_float(h & 0xFFFF0000u));
+  }
+  out[u] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct BeamLogitsArgs {
+  const uint4* y_frag;     // beam_pack_y_kernel: the step's decoder outputs as bf16 hi / lo fragments
+  const uint4* wo_frag;    // beam_pack_wo_kernel
+  const float* bias_pad;   // [chunks * 128] b_o, zero padded (beam_pack_wo_kernel)
+  float* pmax;             // [R][chunks]
+  float* psum;             // [R][chunks]
+  float* cand_v;           // [R][chunks][W]
+  int32_t* cand_i;         // [R][chunks][W]   column index, -1: no such candidate
+  int R, D, V, W, chunks;
+  const int32_t* stop;
+  int stop_t;
+};
+
+// y [R][D] fp32 -> per 16-row tile / k32-step / {hi, lo} / lane: 8 bf16 (the B operand of the products, split once per
+// step instead of once per workgroup)
+__global__ __launch_bounds__(256) void beam_pack_y_kernel(const float* __restrict__ y, uint4* __restrict__ out, int R, int D,
+                                                          long units, const int32_t* __restrict__ stop, int stop_t) {
+  if (comic_stopped(stop, stop_t)) return;
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int KS = D / 32;
+  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1);
+  const long t = u >> 7;
+  const int s = (int)(t % KS), tile = (int)(t / KS);
+  const int row = tile * 16 + (lane & 15), k0 = s * 32 + (lane >> 4) * 8;
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (row < R) {
+    const float4 a = *(const float4*)(y + (size_t)row * D + k0), b = *(const float4*)(y + (size_t)row * D + k0 + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t h = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+    w[j] = hl == 0 ? h : pack_bf16x2(x[2 * j] - __uint_as_float(h << 16), x[2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
+  }
+  out[u] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// One wave's share: NT (0, 1 or 2) of the 16-row tiles wave, wave + 8.  Every wave takes part in the LDS-DMA of every
+// quarter and in every barrier whatever its NT.
+//   registers (NT = 2): 64 accumulators, 64 of y fragments (one K-quarter, refilled step by step for the next quarter as
+//   soon as a step's products have issued: a rolling four-step prefetch), 2 x 32 of weight fragments (half a k-step is
+//   read from the LDS while the half before it multiplies).
+template <int NT>
+__device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsigned char* smem, int wave, int lane, int tid) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int c = blockIdx.x, D = a.D, KS = D / 32, NQ = D / 128;
+  const unsigned char* wsrc = (const unsigned char*)a.wo_frag + (size_t)c * KS * 16 * 1024;
+  constexpr int NR = NT > 0 ? NT : 1;
+
+  auto issue = [&](int q, int buf) {     // 64 KB: eight rounds of 512 lanes x 16 B
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      dma16(wsrc + (size_t)q * kQuarterBytes + i * 8192 + tid * 16, smem + buf * kQuarterBytes + i * 8192 + wave * 1024);
+  };
+  int row[NR];
+  const uint4* ysrc[NR];
+#pragma unroll
+  for (int m = 0; m < NR; ++m) {
+    const int r = (wave + 8 * m) * 16 + fr;
+    row[m] = r < a.R ? r : -1;
+    ysrc[m] = a.y_frag + (size_t)(wave + 8 * m) * KS * 128 + lane;
+  }
+  uint4 yf[NR][4][2];                     // [tile][k-step of the quarter][hi, lo]
+  auto load_y = [&](int q, int s) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      yf[m][s][0] = ysrc[m][(size_t)(q * 4 + s) * 128];
+      yf[m][s][1] = ysrc[m][(size_t)(q * 4 + s) * 128 + 64];
+    }
+  };
+  f32x4_t acc[NR][8];
+#pragma unroll
+  for (int m = 0; m < NR; ++m)
+#pragma unroll
+    for (int vt = 0; vt < 8; ++vt) acc[m][vt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (wave == 0 && lane < 32) dma16(a.bias_pad + c * kChunkCols + lane * 4, smem + 2 * kQuarterBytes);   // the chunk's bias
+  issue(0, 0);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) load_y(0, s);
+  for (int q = 0; q < NQ; ++q) {
+    const int buf = q & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of quarter q (and its y fragments) have landed
+    __builtin_amdgcn_s_barrier();                          // ... everybody's; the other buffer is no longer read
+    if (q + 1 < NQ) issue(q + 1, buf ^ 1);
+    if constexpr (NT > 0) {
+      const uint4* wl = (const uint4*)(smem + buf * kQuarterBytes) + lane;
+      uint4 wa[2][8];                                      // [ring][4 tiles x {hi, lo}] of one half k-step
+      auto load_half = [&](int h, uint4 (&dst)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = wl[(h * 8 + j) * 64];
+      };
+      load_half(0, wa[0]);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        if (h + 1 < 8) load_half(h + 1, wa[(h + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);                 // the next half's LDS reads are in flight before these products
+        const int s = h >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int vt = (h & 1) * 4 + j;
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, wa[h & 1][2 * j]);
+          const bf16x8_t al = __builtin_bit_cast(bf16x8_t, wa[h & 1][2 * j + 1]);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, yf[m][s][0]), acc[m][vt], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, yf[m][s][1]), acc[m][vt], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, yf[m][s][0]), acc[m][vt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if ((h & 1) && q + 1 < NQ) load_y(q + 1, s);       // this step's y registers refill for the next quarter
+      }
+    }
+  }
+  if constexpr (NT == 0) return;
+
+  // ---- per row: the chunk's log-softmax partials and its top-W columns by logit ------------------------------------------
+  // lane (fr, fg) holds columns v = 128 c + 16 vt + 4 fg + i (i < 4) of row `row[m]`
+  const int v_base = c * kChunkCols + 4 * fg;
+  float4 bias[8];
+#pragma unroll
+  for (int vt = 0; vt < 8; ++vt) bias[vt] = *(const float4*)(smem + 2 * kQuarterBytes + (16 * vt + 4 * fg) * 4);
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    float x[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int vt = 0; vt < 8; ++vt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = v_base + 16 * vt + i;
+        const float bb = i == 0 ? bias[vt].x : i == 1 ? bias[vt].y : i == 2 ? bias[vt].z : bias[vt].w;
+        const float val = v < a.V ? acc[m][vt][i] + bb : -INFINITY;
+        x[vt * 4 + i] = val;
+        mx = fmaxf(mx, val);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) se += x[e] == -INFINITY ? 0.f : expf(x[e] - mx);
+    // the four lane groups' partial sums in a fixed order
+    const float s0 = __shfl(se, fr, 64), s1 = __shfl(se, fr + 16, 64), s2 = __shfl(se, fr + 32, 64), s3 = __shfl(se, fr + 48, 64);
+    const float stot = ((s0 + s1) + s2) + s3;
+    const size_t ro = (size_t)(row[m] < 0 ? 0 : row[m]) * a.chunks + c;
+    if (fg == 0 && row[m] >= 0) {
+      a.pmax[ro] = mx;
+      a.psum[ro] = stot;
+    }
+    unsigned taken = 0u;
+    for (int k = 0; k < a.W; ++k) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const int v = v_base + 16 * (e >> 2) + (e & 3);
+        const bool ok = !((taken >> e) & 1u) && v < a.V;
+        if (ok && bl_better(x[e], v, bv, bi)) {
+          bv = x[e];
+          bi = v;
+        }
+      }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (bl_better(ov, oi, bv, bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      // the lane that holds the winner retires it: its element index is (bi - v_base) folded to 4 per 16 columns
+      const int d = bi - v_base;
+      if (bi != 0x7fffffff && d >= 0 && (d & 15) < 4 && d < 128) taken |= 1u << (((d >> 4) << 2) | (d & 3));
+      if (fg == 0 && row[m] >= 0) {
+        a.cand_v[ro * a.W + k] = bv;
+        a.cand_i[ro * a.W + k] = bi == 0x7fffffff ? -1 : bi;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void beam_logits_kernel(BeamLogitsArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = (a.R + 15) >> 4;
+  const int nt = (wave < tiles ? 1 : 0) + (wave + 8 < tiles ? 1 : 0);        // wave-uniform (scalar)
+  if (nt == 2) beam_logits_wave<2>(a, smem, wave, lane, tid);
+  else if (nt == 1) beam_logits_wave<1>(a, smem, wave, lane, tid);
+  else beam_logits_wave<0>(a, smem, wave, lane, tid);
+}
+
+// ---- merge: one workgroup per batch entry -----------------------------------------------------------------------------
+__device__ __forceinline__ BLVal bl_block_argmax(float v, int i, BLVal* sh) {
+  const int tid = threadIdx.x;
+  sh[tid].v = v;
+  sh[tid].i = i;
+  __syncthreads();
+  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (tid < s && bl_better(sh[tid + s].v, sh[tid + s].i, sh[tid].v, sh[tid].i)) sh[tid] = sh[tid + s];
+    __syncthreads();
+  }
+  const BLVal r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                          const float* __restrict__ cand_v, const int32_t* __restrict__ cand_i,
+                                                          float* __restrict__ log_probs, int32_t* __restrict__ finished,
+                                                          int64_t* __restrict__ lengths, int32_t* __restrict__ word_ids,
+                                                          int32_t* __restrict__ parent_ids, float* __restrict__ scores,
+                                                          int W, int V, int chunks, int end_id,
+                                                          unsigned long long* __restrict__ done_cnt,
+                                                          int32_t* __restrict__ steps_executed, int t, int max_steps,
+                                                          const int32_t* __restrict__ stop, int stop_t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  __shared__ BLVal sh[256];
+  __shared__ float s_max[64], s_logsum[64], s_lp[64], s_selv[64];
+  __shared__ int s_fin[64], s_sel[64], s_alldone;
+  __shared__ long long s_len[64];
+  if (comic_stopped(stop, stop_t)) return;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = chunks * W, n = W * per;
+  float* c_tot = (float*)dyn;                  // candidate scores / flat indices of this entry (0x7fffffff: no candidate)
+  int* c_f = (int*)(c_tot + n);
+  for (int w = tid; w < W; w += 256) {
+    s_lp[w] = log_probs[b * W + w];
+    s_fin[w] = finished[b * W + w];
+    s_len[w] = lengths[b * W + w];
+  }
+  if (tid == 0) s_alldone = 1;
+  // log-softmax constants of every beam from the per-chunk partials (a wave per beam; every lane walks its chunks in
+  // ascending order, the wave reduction is a fixed tree: the same bits on every launch)
+  for (int w = wave; w < W; w += 4) {
+    const size_t ro = (size_t)(b * W + w) * chunks;
+    float mx = -INFINITY;
+    for (int k = lane; k < chunks; k += 64) mx = fmaxf(mx, pmax[ro + k]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < chunks; k += 64) s += psum[ro + k] * expf(pmax[ro + k] - mx);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s_max[w] = mx;
+      s_logsum[w] = logf(s);
+    }
+  }
+  __syncthreads();
+  // candidate slots: beam w, slot k < chunks * W.  A live beam's slot is the k-th (chunk, rank) entry of its lists; a
+  // finished beam (_mask_probs: 0 at EOS, float32 min elsewhere) has W + 1 synthetic ones: EOS and the W lowest other
+  // columns, which is all a top-W selection can ever take from it.
+  for (int j0 = tid; j0 < n; j0 += 256 * 4) {
+    int vv[4];
+    float xx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 256;
+      vv[u] = -1;
+      xx[u] = 0.f;
+      if (j < n) {
+        vv[u] = cand_i[(size_t)b * n + j];
+        xx[u] = cand_v[(size_t)b * n + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 256;
+      if (j >= n) continue;
+      const int w = j / per, k = j - w * per;
+      int f = 0x7fffffff;
+      float tot = -INFINITY;
+      if (s_fin[w]) {
+        if (k <= W) {
+          int v = end_id;
+          if (k > 0) {
+            v = k - 1;
+            if (v >= end_id) ++v;                 // the (k-1)-th column that is not EOS
+          }
+          if (v < V) {
+            tot = s_lp[w] + ((v == end_id) ? 0.f : -FLT_MAX);
+            f = w * V + v;
+          }
+        }
+      } else if (vv[u] >= 0) {
+        const float step = (xx[u] - s_max[w]) - s_logsum[w];
+        tot = s_lp[w] + step;
+        f = w * V + vv[u];
+      }
+      c_tot[j] = tot;
+      c_f[j] = f;
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < W; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff, bj = -1;
+    for (int j = tid; j < n; j += 256) {
+      const int f = c_f[j];
+      if (f == 0x7fffffff) continue;
+      const float tot = c_tot[j];
+      if (bl_better(tot, f, bv, bi)) {
+        bv = tot;
+        bi = f;
+        bj = j;
+      }
+    }
+    const BLVal best = bl_block_argmax(bv, bi, sh);
+    if (best.i != 0x7fffffff && bi == best.i) c_f[bj] = 0x7fffffff;       // flat indices are unique: one thread retires it
+    if (tid == 0) {
+      int sel = best.i;
+      if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
+        sel = 0;
+        bool again = true;
+        while (again) {
+          again = false;
+          for (int q = 0; q < r; ++q)
+            if (s_sel[q] == sel) {
+              ++sel;
+              again = true;
+            }
+        }
+      }
+      s_sel[r] = sel;
+      s_selv[r] = best.v;
+    }
+    __syncthreads();
+  }
+  if (tid < W) {
+    const int f = s_sel[tid];
+    const int parent = f / V, word = f - parent * V;
+    const int prev_fin = s_fin[parent];
+    const int fin = (prev_fin || word == end_id) ? 1 : 0;
+    word_ids[b * W + tid] = word;
+    parent_ids[b * W + tid] = parent;
+    scores[b * W + tid] = s_selv[tid];
+    log_probs[b * W + tid] = s_selv[tid];
+    finished[b * W + tid] = fin;
+    lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
+    if (!fin) s_alldone = 0;
+  }
+  __syncthreads();
+  // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
+  // arrive at the step's counter sees how many entries are done
+  if (tid == 0) {
+    const unsigned long long add = ((unsigned long long)(s_alldone ? 1 : 0) << 32) | 1ull;
+    const unsigned long long old = atomicAdd(done_cnt, add);
+    if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {
+      const unsigned done = (unsigned)(old >> 32) + (s_alldone ? 1u : 0u);
+      if (done == gridDim.x && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
+    }
+  }
+}
+
+}  // namespace
+
+// The fused form serves large vocabularies on decoders whose output size is a multiple of 128, up to 256 rows and 8 beams.
+bool comic_beam_logits_supported(int D, int V, int R, int W) {
+  return D % 128 == 0 && D >= 128 && D <= 1024 && V >= 4096 && R >= 1 && R <= 256 && W >= 1 && W <= 8 &&
+         (long)W * V < (1L << 31) && (long)W * W * ((V + kChunkCols - 1) / kChunkCols) * 8 <= 144 * 1024;
+}
+int comic_beam_logits_chunks(int V) { return (V + kChunkCols - 1) / kChunkCols; }
+// bytes of the packed W_o and of the per-step partial arrays
+int64_t comic_beam_logits_pack_bytes(int D, int V) { return (int64_t)comic_beam_logits_chunks(V) * kChunkCols * (D + 1) * 4; }
+// floats of the per-step partial arrays plus the per-step completion counters (8 bytes each)
+// (and the step's y as hi / lo fragments: 4 bytes per element of the 16-row tiles)
+int64_t comic_beam_logits_partial_floats(int D, int V, int R, int W, int max_steps) {
+  return (int64_t)R * comic_beam_logits_chunks(V) * (2 + 2 * W) + 2 * (int64_t)max_steps + 4 + (int64_t)((R + 15) / 16 * 16) * D;
+}
+
+int comic_beam_pack_wo(const float* W_o, const float* b_o, int ld, void* wo_frag, int D, int V, hipStream_t st) {
+  const long units = (long)comic_beam_logits_chunks(V) * (D / 32) * 8 * 2 * 64;
+  const long total = units + (long)comic_beam_logits_chunks(V) * kChunkCols;
+  hipLaunchKernelGGL(beam_pack_wo_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, W_o, b_o, ld, (uint4*)wo_frag,
+                     D, V, units);
+  COMIC_LAUNCH_CHECK("beam_pack_wo");
+  return 0;
+}
+
+// zero the completion counters (once per decode call, before step 0; a kernel, so that a captured decode replays it)
+__global__ void beam_zero_kernel(uint32_t* p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps, hipStream_t st) {
+  const int R = B * W;
+  float* cnt = partials + (size_t)R * comic_beam_logits_chunks(V) * (2 + 2 * W);
+  hipLaunchKernelGGL(beam_zero_kernel, dim3((unsigned)cdiv64(2L * max_steps, 256)), dim3(256), 0, st, (uint32_t*)cnt,
+                     2L * max_steps);
+  COMIC_LAUNCH_CHECK("beam_logits_begin");
+  return 0;
+}
+
+int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials, float* log_probs,
+                           int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
+                           int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
+                           hipStream_t st) {
+  const int R = B * W, chunks = comic_beam_logits_chunks(V);
+  COMIC_REQUIRE(comic_beam_logits_supported(D, V, R, W), "beam_logits: unsupported shape (D %d, V %d, rows %d, beam %d)", D, V, R, W);
+  BeamLogitsArgs a;
+  a.wo_frag = (const uint4*)wo_frag;
+  a.bias_pad = (const float*)((const uint4*)wo_frag + (size_t)chunks * (D / 32) * 8 * 2 * 64);
+  a.pmax = partials;
+  a.psum = a.pmax + (size_t)R * chunks;
+  a.cand_v = a.psum + (size_t)R * chunks;
+  a.cand_i = (int32_t*)(a.cand_v + (size_t)R * chunks * W);
+  unsigned long long* cnt = (unsigned long long*)(a.cand_i + (size_t)R * chunks * W);
+  uint4* y_frag = (uint4*)(((uintptr_t)(cnt + max_steps) + 15) & ~(uintptr_t)15);
+  a.y_frag = y_frag;
+  a.R = R; a.D = D; a.V = V; a.W = W; a.chunks = chunks;
+  a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
+  {
+    const long units = (long)((R + 15) / 16) * (D / 32) * 2 * 64;
+    hipLaunchKernelGGL(beam_pack_y_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, y, y_frag, R, D, units,
+                       g_comic_stop.p, g_comic_stop.t);
+  }
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)beam_logits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      comic_set_error("beam_logits: cannot reserve the LDS");
+      return 1;
+    }
+    if (hipFuncSetAttribute((const void*)beam_merge2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess) {
+      comic_set_error("beam_logits: cannot reserve the merge LDS");
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks), dim3(512), 2 * kQuarterBytes + 512, st, a);   // row tiles w, w + 8 per wave
+  const size_t merge_lds = (size_t)W * chunks * W * 8;
+  hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(256), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
+                     (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,
+                     scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, g_comic_stop.p, g_comic_stop.t);
+  COMIC_LAUNCH_CHECK("beam_logits_step");
+  return 0;
+}

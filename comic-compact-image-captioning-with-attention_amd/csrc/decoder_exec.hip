@@ -57,6 +57,15 @@ int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float
                            int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws,
                            int64_t ws_bytes, hipStream_t st);
 // decode.hip
+bool comic_beam_logits_supported(int D, int V, int R, int W);
+int64_t comic_beam_logits_pack_bytes(int D, int V);
+int64_t comic_beam_logits_partial_floats(int D, int V, int R, int W, int max_steps);
+int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps, hipStream_t st);
+int comic_beam_pack_wo(const float* W_o, const float* b_o, int ld, void* wo_frag, int D, int V, hipStream_t st);
+int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials, float* log_probs,
+                           int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
+                           int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
+                           hipStream_t st);
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
                        hipStream_t st);
@@ -93,6 +102,7 @@ bool split_attn_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_SPLIT_ATTN_B
 bool fused_step_enabled() { return !(g_dec_flags & COMIC_DEC_NO_FUSED_STEP); }
 bool persist_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST); }
 bool persist_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST_BWD); }
+bool beam_logits_enabled() { return !(g_dec_flags & COMIC_DEC_NO_BEAM_LOGITS); }
 
 // A second stream inside the training executor: the weight-gradient products after the backward loop are independent
 // chains of mid-sized GEMMs and small reductions; two lanes fill each other's tails and launch gaps
@@ -626,6 +636,8 @@ static std::atomic<int> g_inject_timeout{0};
 extern "C" int comic_debug_inject_persist_timeout(void) { g_inject_timeout.store(1); return 0; }
 thread_local int g_greedy_path = 0;
 extern "C" int comic_decoder_greedy_path(void) { return g_greedy_path; }
+thread_local int g_beam_path = 0;
+extern "C" int comic_decoder_beam_path(void) { return g_beam_path; }
 
 extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, int B, int T) {
   if (!d) return -1;
@@ -1053,7 +1065,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>(R * (2 * D + A));                                  // gather temp
   w.take<char>(kSplitKBytes);                                      // split-K partials
   w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
-  w.take<float>(D * ((V + 3) / 4 * 4));                            // W_o with 16-byte aligned rows
+  w.take<float>((D + 1) * ((V + 127) / 128 * 128));                // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
   if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
     const long S = std::max(1, max_steps);
     w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
@@ -1092,7 +1104,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.gtmp = w.take<float>(R * (2 * D + A));
   g_splitk_ws = w.take<char>(kSplitKBytes);
   b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
-  b.wo_pad = w.take<float>(D * ((V + 3) / 4 * 4));
+  b.wo_pad = w.take<float>((D + 1) * ((V + 127) / 128 * 128));
   if (rows <= 64 && max_steps > 0) {
     const long S = max_steps;
     b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);
@@ -1260,8 +1272,18 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   COMIC_LAUNCH_CHECK("beam init");
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
   if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
+  // large vocabularies: projection + per-chunk top-k as one streaming launch over a packed W_o (beam_logits.hip)
+  const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
+                             comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128) * 4 &&
+                             comic_beam_logits_partial_floats(D, V, R, W, max_steps) <= (int64_t)R * V;
   int ld_wo = V;
-  const float* w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
+  const float* w_o = nullptr;
+  if (stream_logits) {
+    RC(comic_beam_pack_wo(p->W_o, p->b_o, V, ws.wo_pad, D, V, st));
+    RC(comic_beam_logits_begin(ws.logits, B, W, V, max_steps, st));
+  }
+  else w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
+  g_beam_path = stream_logits ? 1 : 0;
   int cur = 0;
   struct StopScope {          // whatever way this call returns, no later launch sees the flag
     ~StopScope() { g_comic_stop = ComicStop(); }
@@ -1289,9 +1311,14 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
       RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
                           sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st));
-      RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
-      RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
-                            d->end_id, g_splitk_ws, kSplitKBytes, st));
+      if (stream_logits) {
+        RC(comic_beam_logits_step(sb.y, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
+                                  scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id, st));
+      } else {
+        RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
+        RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                              d->end_id, g_splitk_ws, kSplitKBytes, st));
+      }
     } else {
       if (t > 0) (void)hipMemcpyAsync(ws.ids, step_ids + (size_t)(t - 1) * R, sizeof(int32_t) * R,
                                       hipMemcpyDeviceToDevice, st);
@@ -1311,8 +1338,10 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
       RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));
     }
-    hipLaunchKernelGGL(all_finished_kernel, dim3(1), dim3(256), 0, st, finished, steps_executed, t, R, max_steps);
-    COMIC_LAUNCH_CHECK("all_finished");
+    if (!stream_logits) {       // (the streaming step's merge launch keeps steps_executed itself)
+      hipLaunchKernelGGL(all_finished_kernel, dim3(1), dim3(256), 0, st, finished, steps_executed, t, R, max_steps);
+      COMIC_LAUNCH_CHECK("all_finished");
+    }
     cur = nxt;
   }
   return 0;

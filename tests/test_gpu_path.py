@@ -753,6 +753,44 @@ def test_greedy_and_beam_match_oracle(kw):
         assert_close(res['attn_hist'], hist, F32_RTOL, 'beam alignment history')
 
 
+@pytest.mark.parametrize('B,W,V,D', [(5, 3, 9000, 128), (50, 3, 8962, 128), (32, 8, 4300, 256), (7, 5, 25599, 512)])
+def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
+    """Large-vocabulary beam step as the streaming projection + per-chunk top-k launch and its merge
+    (csrc/beam_logits.hip) against the oracle and against the GEMM + statistics + top-k launches: ids, parents and
+    lengths bit-exact, scores at 1e-4.  Row counts on one and on two 16-row tiles per wave, a last chunk with fewer
+    live columns than the beam width (V = 8962 = 70 * 128 + 2), beam 8, and the bench vocabulary at D = 512."""
+    spec, cfg = _spec_and_cfg(fm_projection=None, H=1, token_type='word', V=V, D=D, init_method='project_hidden',
+                              start_id=V - 2, end_id=V - 1)
+    p = _rand_params(cfg, 9)
+    fm, im, _ = _batch(spec, B, 6, 23)
+    max_steps = 10
+    for eos_bias in (1.5, 9.0):
+        pe = dict(p); pe['b_o'] = p['b_o'].copy(); pe['b_o'][spec.end_id] = eos_bias
+        dec = cdec.Decoder(spec, pe, DEV)
+        res = None
+        for _ in range(3):                                # eager, captured, replayed
+            res = dec.beam_search(dev(fm), dev(im), W, max_steps)
+        dec.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
+        assert dec.lib.comic_decoder_beam_path() == 1     # the streaming launch really ran
+        monkeypatch.setenv('COMIC_BEAM_LOGITS', '0')
+        dec0 = cdec.Decoder(spec, pe, DEV)
+        res0 = dec0.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
+        assert dec0.lib.comic_decoder_beam_path() == 0
+        monkeypatch.delenv('COMIC_BEAM_LOGITS')
+        for k in ('step_ids', 'parent_ids', 'predicted_ids', 'lengths'):
+            np.testing.assert_array_equal(res[k], res0[k], err_msg=k)
+        fin = np.isfinite(res0['scores'])
+        assert_close(np.where(fin, res['scores'], 0), np.where(fin, res0['scores'], 0), 1e-4, 'beam scores vs the GEMM path')
+        if B * W * V * max_steps <= 150 * 9000 * 10:
+            pred, scores, hist, dbg = beam_ref.beam_search_decode(pe, cfg, fm, im, W, max_steps, return_debug=True)
+            np.testing.assert_array_equal(res['step_ids'], dbg['step_ids'])
+            np.testing.assert_array_equal(res['parent_ids'], dbg['parent_ids'])
+            np.testing.assert_array_equal(res['predicted_ids'], pred)
+            np.testing.assert_array_equal(res['lengths'], dbg['lengths'])
+            fin = np.isfinite(scores)
+            assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'beam scores')
+
+
 @pytest.mark.parametrize('kw,B', [(dict(D=512, E=256), 5), (dict(D=512, E=128, method='dot', H=4, M=7), 37),
                                   (dict(D=512, E=64, fm_projection='independent', prob='sigmoid', H=16), 64)])
 def test_persistent_greedy_loop_matches_oracle(kw, B, monkeypatch):
