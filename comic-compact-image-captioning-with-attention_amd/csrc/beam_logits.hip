@@ -200,6 +200,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
   for (int vt = 0; vt < 8; ++vt) bias[vt] = *(const float4*)(smem + 2 * kQuarterBytes + (16 * vt + 4 * fg) * 4);
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
+    // branch-free: dead columns are -inf (exp -> 0, never the strict maximum of a scan)
     float x[32];
     float mx = -INFINITY;
 #pragma unroll
@@ -216,40 +217,39 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float se = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) se += x[e] == -INFINITY ? 0.f : expf(x[e] - mx);
-    // the four lane groups' partial sums in a fixed order
-    const float s0 = __shfl(se, fr, 64), s1 = __shfl(se, fr + 16, 64), s2 = __shfl(se, fr + 32, 64), s3 = __shfl(se, fr + 48, 64);
-    const float stot = ((s0 + s1) + s2) + s3;
+    for (int e = 0; e < 32; ++e) se += __expf(x[e] - mx);
+    // the four lane groups' partial sums: (s_r + s_r^16) + (s_r^32 + s_r^48), the same bits in all four lanes
+    se += __shfl_xor(se, 16, 64);
+    se += __shfl_xor(se, 32, 64);
     const size_t ro = (size_t)(row[m] < 0 ? 0 : row[m]) * a.chunks + c;
     if (fg == 0 && row[m] >= 0) {
       a.pmax[ro] = mx;
-      a.psum[ro] = stot;
+      a.psum[ro] = se;
     }
-    unsigned taken = 0u;
     for (int k = 0; k < a.W; ++k) {
+      // lane-local strict maximum, first element on ties (elements ascend with the column index)
       float bv = -INFINITY;
-      int bi = 0x7fffffff;
+      int be = -1;
 #pragma unroll
       for (int e = 0; e < 32; ++e) {
-        const int v = v_base + 16 * (e >> 2) + (e & 3);
-        const bool ok = !((taken >> e) & 1u) && v < a.V;
-        if (ok && bl_better(x[e], v, bv, bi)) {
-          bv = x[e];
-          bi = v;
-        }
+        const bool g = x[e] > bv;
+        bv = g ? x[e] : bv;
+        be = g ? e : be;
       }
+      const int mine = be < 0 ? 0x7fffffff : v_base + 16 * (be >> 2) + (be & 3);
+      int bi = mine;
 #pragma unroll
       for (int o = 16; o < 64; o <<= 1) {
         const float ov = __shfl_xor(bv, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
-        if (bl_better(ov, oi, bv, bi)) {
-          bv = ov;
-          bi = oi;
-        }
+        const bool g = bl_better(ov, oi, bv, bi);
+        bv = g ? ov : bv;
+        bi = g ? oi : bi;
       }
-      // the lane that holds the winner retires it: its element index is (bi - v_base) folded to 4 per 16 columns
-      const int d = bi - v_base;
-      if (bi != 0x7fffffff && d >= 0 && (d & 15) < 4 && d < 128) taken |= 1u << (((d >> 4) << 2) | (d & 3));
+      // the lane that holds the winner retires it
+      const int gone = (bi == mine) ? be : -1;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) x[e] = (e == gone) ? -INFINITY : x[e];
       if (fg == 0 && row[m] >= 0) {
         a.cand_v[ro * a.W + k] = bv;
         a.cand_i[ro * a.W + k] = bi == 0x7fffffff ? -1 : bi;
