@@ -43,11 +43,12 @@ class DecoderDesc(C.Structure):
 # the decoder executors are environment variables of the PYTHON side, read at every call (tests flip them inside one
 # process) by decoder_flags_from_env() and handed over in the descriptor.
 (DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS,
- DEC_NO_BEAM_LOGITS) = (1, 2, 4, 8, 16, 32, 64, 128)
+ DEC_NO_BEAM_LOGITS, DEC_NO_LSTM_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256)
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
-            ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS), ('COMIC_BEAM_LOGITS', '0', DEC_NO_BEAM_LOGITS))
+            ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS), ('COMIC_BEAM_LOGITS', '0', DEC_NO_BEAM_LOGITS),
+            ('COMIC_LSTM_STREAM', '0', DEC_NO_LSTM_STREAM))
 
 
 def decoder_flags_from_env():

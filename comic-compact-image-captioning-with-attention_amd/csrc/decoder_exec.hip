@@ -66,6 +66,15 @@ int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials,
                            int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
                            int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
                            hipStream_t st);
+bool comic_lstm_stream_supported(int D, int E, int A, int R);
+int64_t comic_lstm_stream_kfrag_floats(int D, int Wd);
+int64_t comic_lstm_stream_xfrag_floats(int R, int Wd);
+int64_t comic_lstm_stream_part_bytes(int D, int Wd, int R);
+int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st);
+int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
+                           const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
+                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y, int R, int E,
+                           int A, int D, int V, hipStream_t st);
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
                        hipStream_t st);
@@ -103,6 +112,7 @@ bool fused_step_enabled() { return !(g_dec_flags & COMIC_DEC_NO_FUSED_STEP); }
 bool persist_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST); }
 bool persist_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST_BWD); }
 bool beam_logits_enabled() { return !(g_dec_flags & COMIC_DEC_NO_BEAM_LOGITS); }
+bool lstm_stream_enabled() { return !(g_dec_flags & COMIC_DEC_NO_LSTM_STREAM); }
 
 // A second stream inside the training executor: the weight-gradient products after the backward loop are independent
 // chains of mid-sized GEMMs and small reductions; two lanes fill each other's tails and launch gaps
@@ -602,16 +612,20 @@ int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const
 int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
                      const float* keys, const float* values, const float* kpanel, const int32_t* ids,
                      const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
-                     StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st) {
+                     StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st,
+                     const void* kfrag = nullptr, void* xfrag = nullptr) {
   const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
-  {
+  if (kfrag) {      // many rows: the kernel streamed once for all of them (lstm_stream.hip)
+    RC(comic_lstm_stream_step(p->emb, ids, parent, W, att_src, h_src, c_src, kfrag, p->b, xfrag, c_in, (float*)g_splitk_ws,
+                              kSplitKBytes, sb.c2, sb.h2, sb.y, rows, E, A, D, d->V, st));
+  } else {
     const long n = (long)rows * (Wd + D);
     hipLaunchKernelGGL(infer_prep_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, ids, parent, W,
                        att_src, h_src, c_src, sb.xh, c_in, rows, E, A, D, d->V, g_comic_stop.p, g_comic_stop.t);
     COMIC_LAUNCH_CHECK("infer_prep");
+    RC(comic_lstm_step_fused(sb.xh, Wd, kpanel, p->b, c_in, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0,
+                             sb.c2, sb.h2, nullptr, 0, rows, D, Wd, st));
   }
-  RC(comic_lstm_step_fused(sb.xh, Wd, kpanel, p->b, c_in, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0,
-                           sb.c2, sb.h2, nullptr, 0, rows, D, Wd, st));
   int S = 1;
   float* part = (float*)g_splitk_ws;
   RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
@@ -1066,6 +1080,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<char>(kSplitKBytes);                                      // split-K partials
   w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
   w.take<float>((D + 1) * ((V + 127) / 128 * 128));                // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
+  w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));  // streaming LSTM step
   if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
     const long S = std::max(1, max_steps);
     w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
@@ -1079,7 +1094,7 @@ struct InferBufs {
   float *fm_t, *im_t, *keys, *values_buf;
   InitBufs ib;
   StepBufs sb;
-  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad;
+  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad, *kfrag, *xfrag;
   int32_t *ids, *parents;
   float *p_xh = nullptr, *p_y = nullptr, *p_q = nullptr, *p_argp = nullptr;   // persistent greedy loop (rows <= 64)
   unsigned* p_sync = nullptr;
@@ -1105,6 +1120,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   g_splitk_ws = w.take<char>(kSplitKBytes);
   b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
   b.wo_pad = w.take<float>((D + 1) * ((V + 127) / 128 * 128));
+  b.kfrag = w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); b.xfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));
   if (rows <= 64 && max_steps > 0) {
     const long S = max_steps;
     b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);
@@ -1271,7 +1287,10 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps_executed, max_steps, 1L);
   COMIC_LAUNCH_CHECK("beam init");
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
-  if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
+  const bool stream_lstm = fused && lstm_stream_enabled() && comic_lstm_stream_supported(D, E, A, R) &&
+                           comic_lstm_stream_part_bytes(D, E + A + D, R) <= kSplitKBytes;
+  if (stream_lstm) RC(comic_lstm_stream_pack(p->K, ws.kfrag, D, E + A + D, st));
+  else if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   // large vocabularies: projection + per-chunk top-k as one streaming launch over a packed W_o (beam_logits.hip)
   const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
                              comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128) * 4 &&
@@ -1283,7 +1302,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
     RC(comic_beam_logits_begin(ws.logits, B, W, V, max_steps, st));
   }
   else w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
-  g_beam_path = stream_logits ? 1 : 0;
+  g_beam_path = (stream_logits ? 1 : 0) | (stream_lstm ? 2 : 0);
   int cur = 0;
   struct StopScope {          // whatever way this call returns, no later launch sees the flag
     ~StopScope() { g_comic_stop = ComicStop(); }
@@ -1310,7 +1329,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
       RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
-                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st));
+                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st, stream_lstm ? ws.kfrag : nullptr, ws.xfrag));
       if (stream_logits) {
         RC(comic_beam_logits_step(sb.y, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
                                   scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id, st));

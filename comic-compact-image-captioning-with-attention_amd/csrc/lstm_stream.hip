@@ -1,0 +1,301 @@
+// LSTM step of the decode loops at many rows (beam search: rows = batch x beam = 150 ... 224): the gate product as ONE
+// streaming pass over the [Wd][4D] kernel, then the cell as an element-wise reduction of its K-slices.
+//
+// Replaces, inside infer_step_fused (decoder_exec.hip; BasicLSTMCell of rnn_decoder_*search, common/ops_rnn.py:49-180):
+// comic_lstm_step_fused, whose grid (unit tiles x 16-row tiles) re-reads the kernel once per row tile -- at 150 rows
+// and Wd = 2816 (word baseline: E 256 + A 2048 + D 512) ten passes over 23 MB out of the L2, 42.7 us per step.
+//
+// Here the kernel is packed once per decode call (lstm_pack_k_kernel) as bf16 hi / lo halves in MFMA-fragment order,
+// per CHUNK of 16 hidden units (4 gates x 16 units = 64 columns) and 32-deep k-step: 8 KB.  A workgroup (chunk, K-slice)
+// pulls its slice (<= 16 k-steps, <= 128 KB) into the LDS by LDS-DMA in one go, multiplies ALL rows by it
+// (hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16, the arithmetic of comic_gemm_f32_split3, product error ~2^-16;
+// the waves split the 16-row tiles, the operand rows arrive as pre-split fragments written by the step's gather kernel)
+// and stores its partial gate sums; D[col][row] orientation puts the four gates of a unit into one lane.  The kernel is
+// read from HBM exactly once per step.  lstm_cell_kernel adds the slices in slice order (deterministic), the bias and
+// the forget bias, and applies the cell -- c2, h2, y as comic_lstm_step_fused writes them.
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int kStepBytes = 8 * 1024;     // one chunk, one k32-step: 4 gate tiles x {hi, lo} x 64 lanes x 16 B
+constexpr int kMaxSliceSteps = 16;       // 128 KB of LDS
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// K [Wd][4D] fp32 -> [chunk][k-step][gate][hi, lo][lane]: 8 bf16, lane (fr, fg) <-> K[32 s + 8 fg + j][gate D + 16 chunk + fr]
+__global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restrict__ K, uint4* __restrict__ out, int D, int Wd,
+                                                          int KS, long units) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1), g = (int)((u >> 7) & 3);
+  const long t = u >> 9;
+  const int s = (int)(t % KS);
+  const int c = (int)(t / KS);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int col = g * D + c * 16 + fr, k0 = s * 32 + fg * 8;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = k0 + 2 * j + e;
+      x[e] = k < Wd ? K[(size_t)k * 4 * D + col] : 0.f;
+    }
+    const uint32_t h = pack_bf16x2(x[0], x[1]);
+    w[j] = hl == 0 ? h : pack_bf16x2(x[0] - __uint_as_float(h << 16), x[1] - __uint_as_float(h & 0xFFFF0000u));
+  }
+  out[u] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// The step's operand gather (infer_prep_kernel: embedding of the last word | attention state and hidden state through
+// the parent beams) written straight as hi / lo fragments [16-row tile][k-step][hi, lo][lane], plus the gathered cell
+// state.  One thread per (row, 8 consecutive features): E, A and D are multiples of 8, so a segment has one source.
+__global__ __launch_bounds__(256) void lstm_prep_frag_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                                             const int32_t* __restrict__ parent, int W,
+                                                             const float* __restrict__ att, const float* __restrict__ h,
+                                                             const float* __restrict__ c, uint4* __restrict__ x_frag,
+                                                             float* __restrict__ c_in, int R, int Rp, int E, int A, int D, int V,
+                                                             int KS, const int32_t* __restrict__ stop, int stop_t) {
+  if (comic_stopped(stop, stop_t)) return;
+  const int Wd = E + A + D, segs = KS * 4 + D / 8;            // operand segments (zero padded to 32 KS) | cell segments
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Rp * segs) return;
+  const int r = (int)(i / segs), sg = (int)(i % segs);
+  const bool live = r < R;
+  const int src = !live ? 0 : parent ? (r / W) * W + min(max(parent[r], 0), W - 1) : r;
+  if (sg >= KS * 4) {
+    if (!live) return;
+    const int k = (sg - KS * 4) * 8;
+    const float4* p = (const float4*)(c + (size_t)src * D + k);
+    float4* q = (float4*)(c_in + (size_t)r * D + k);
+    q[0] = p[0];
+    q[1] = p[1];
+    return;
+  }
+  const int k = sg * 8;
+  float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
+  if (live && k < Wd) {
+    const float* p = nullptr;
+    if (k < E) {
+      const int id = ids[r];
+      if (id >= 0 && id < V) p = table + (size_t)id * E + k;
+    } else if (k < E + A) {
+      p = att + (size_t)src * A + (k - E);
+    } else {
+      p = h + (size_t)src * D + (k - E - A);
+    }
+    if (p) {
+      lo4 = *(const float4*)p;
+      hi4 = *(const float4*)(p + 4);
+    }
+  }
+  const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+  uint32_t wh[4], wl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    wh[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+    wl[j] = pack_bf16x2(x[2 * j] - __uint_as_float(wh[j] << 16), x[2 * j + 1] - __uint_as_float(wh[j] & 0xFFFF0000u));
+  }
+  // element (row r, k-step s = sg / 4, chunk fg = sg % 4) of tile r / 16 is lane (fr = r % 16, fg)
+  const int tile = r >> 4, fr = r & 15, s = sg >> 2, fg = sg & 3;
+  uint4* o = x_frag + ((size_t)tile * KS + s) * 128 + fg * 16 + fr;
+  o[0] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+  o[64] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+}
+
+struct LstmStreamArgs {
+  const uint4* k_frag;
+  const uint4* x_frag;
+  float* part;             // [S][R][4D] partial gate sums
+  int R, D, KS, ksteps;
+  const int32_t* stop;
+  int stop_t;
+};
+
+template <int NT>
+__device__ __forceinline__ void lstm_stream_wave(const LstmStreamArgs& a, unsigned char* smem, int wave, int lane, int tid) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int c = blockIdx.x, sl = blockIdx.y, KS = a.KS;
+  const int s0 = sl * a.ksteps, n = min(a.ksteps, KS - s0);
+  const unsigned char* wsrc = (const unsigned char*)(a.k_frag + ((size_t)c * KS + s0) * 512);
+  for (int i = 0; i < n; ++i) dma16(wsrc + (size_t)i * kStepBytes + tid * 16, smem + i * kStepBytes + wave * 1024);
+  constexpr int NR = NT > 0 ? NT : 1;
+  int row[NR];
+  const uint4* ysrc[NR];
+#pragma unroll
+  for (int m = 0; m < NR; ++m) {
+    const int r = (wave + 8 * m) * 16 + fr;
+    row[m] = r < a.R ? r : -1;
+    ysrc[m] = a.x_frag + ((size_t)(wave + 8 * m) * KS + s0) * 128 + lane;
+  }
+  uint4 yf[NR][4][2];
+  auto load_y = [&](int s, int slot) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      yf[m][slot][0] = ysrc[m][(size_t)s * 128];
+      yf[m][slot][1] = ysrc[m][(size_t)s * 128 + 64];
+    }
+  };
+  f32x4_t acc[NR][4];
+#pragma unroll
+  for (int m = 0; m < NR; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (u < n) load_y(u, u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // the whole slice of the kernel is in the LDS
+  if constexpr (NT == 0) return;
+  const uint4* wl = (const uint4*)smem + lane;
+  for (int g0 = 0; g0 < n; g0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = g0 + u;
+      if (s < n) {                                   // wave-uniform
+        uint4 wa[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wa[j] = wl[(s * 8 + j) * 64];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, wa[2 * g]);
+          const bf16x8_t al = __builtin_bit_cast(bf16x8_t, wa[2 * g + 1]);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, yf[m][u][0]), acc[m][g], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(bf16x8_t, yf[m][u][1]), acc[m][g], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+            acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, yf[m][u][0]), acc[m][g], 0, 0, 0);
+        }
+        if (s + 4 < n) load_y(s + 4, u);             // this step's registers refill four steps ahead
+      }
+    }
+  }
+  // lane (fr, fg) holds, of row `row[m]`, units 16 c + 4 fg + i of gate g in acc[m][g][i]
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    if (row[m] < 0) continue;
+    float* o = a.part + ((size_t)sl * a.R + row[m]) * 4 * a.D + c * 16 + 4 * fg;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(float4*)(o + (size_t)g * a.D) = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_stream_kernel(LstmStreamArgs a) {
+  if (comic_stopped(a.stop, a.stop_t)) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = (a.R + 15) >> 4;
+  const int nt = (wave < tiles ? 1 : 0) + (wave + 8 < tiles ? 1 : 0);
+  if (nt == 2) lstm_stream_wave<2>(a, smem, wave, lane, tid);
+  else if (nt == 1) lstm_stream_wave<1>(a, smem, wave, lane, tid);
+  else lstm_stream_wave<0>(a, smem, wave, lane, tid);
+}
+
+// gates = sum of the K-slices (slice order) + bias; i, j, f, o -> c2 = c sigma(f + 1) + sigma(i) tanh(j), h2 = tanh(c2) sigma(o)
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias,
+                                                        const float* __restrict__ c_prev, float* __restrict__ c_state,
+                                                        float* __restrict__ h_state, float* __restrict__ y, int R, int D,
+                                                        const int32_t* __restrict__ stop, int stop_t) {
+  if (comic_stopped(stop, stop_t)) return;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)R * D) return;
+  const int r = (int)(t / D), d = (int)(t % D);
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float* p = part + ((size_t)s * R + r) * 4 * D + d;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] += p[(size_t)q * D];
+  }
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] += bias[q * D + d];
+  }
+  const float si = sigmoid_(g[0]), tj = tanhf(g[1]);
+  const float sf = sigmoid_(g[2] + 1.0f), so = sigmoid_(g[3]);   // forget_bias = 1
+  const float c2 = c_prev[t] * sf + si * tj;
+  const float h2 = tanhf(c2) * so;
+  c_state[t] = c2;
+  h_state[t] = h2;
+  y[t] = h2;
+}
+
+}  // namespace
+
+// Shapes the streaming step serves: hidden size a multiple of 16, operand thirds multiples of 8, 33 ... 256 rows.
+bool comic_lstm_stream_supported(int D, int E, int A, int R) {
+  return D % 16 == 0 && D >= 16 && E % 8 == 0 && A % 8 == 0 && D % 8 == 0 && R > 32 && R <= 256;
+}
+static inline int lstm_ks(int Wd) { return (Wd + 31) / 32; }
+// K-slices: as many as fill the device (chunks x S ~ 256 workgroups), at most 16 k-steps each
+static void lstm_slices(int D, int Wd, int* ksteps, int* S) {
+  const int KS = lstm_ks(Wd), chunks = D / 16;
+  int s = std::min(16, std::max(1, 256 / chunks));
+  int n = (KS + s - 1) / s;
+  if (n > kMaxSliceSteps) n = kMaxSliceSteps;
+  *ksteps = n;
+  *S = (KS + n - 1) / n;
+}
+int64_t comic_lstm_stream_kfrag_floats(int D, int Wd) { return (int64_t)4 * D * lstm_ks(Wd) * 32; }
+int64_t comic_lstm_stream_xfrag_floats(int R, int Wd) { return (int64_t)((R + 15) / 16 * 16) * lstm_ks(Wd) * 32; }
+int64_t comic_lstm_stream_part_bytes(int D, int Wd, int R) {
+  int n, S;
+  lstm_slices(D, Wd, &n, &S);
+  return (int64_t)S * R * 4 * D * 4;
+}
+
+int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st) {
+  const int KS = lstm_ks(Wd);
+  const long units = (long)(D / 16) * KS * 512;
+  hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, K, (uint4*)k_frag, D, Wd, KS,
+                     units);
+  COMIC_LAUNCH_CHECK("lstm_stream_pack");
+  return 0;
+}
+
+// One decode step: gather + split the operand rows, stream the kernel, apply the cell.
+int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
+                           const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
+                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y, int R, int E,
+                           int A, int D, int V, hipStream_t st) {
+  const int Wd = E + A + D, KS = lstm_ks(Wd);
+  COMIC_REQUIRE(comic_lstm_stream_supported(D, E, A, R), "lstm_stream: unsupported shape (D %d, E %d, A %d, rows %d)", D, E, A, R);
+  int ksteps, S;
+  lstm_slices(D, Wd, &ksteps, &S);
+  COMIC_REQUIRE(part_bytes >= (int64_t)S * R * 4 * D * 4, "lstm_stream: partial buffer too small");
+  const int Rp = (R + 15) / 16 * 16;
+  {
+    const long n = (long)Rp * (KS * 4 + D / 8);
+    hipLaunchKernelGGL(lstm_prep_frag_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, table, ids, parent, W, att_src,
+                       h_src, c_src, (uint4*)x_frag, c_in, R, Rp, E, A, D, V, KS, g_comic_stop.p, g_comic_stop.t);
+  }
+  LstmStreamArgs a;
+  a.k_frag = (const uint4*)k_frag; a.x_frag = (const uint4*)x_frag; a.part = part;
+  a.R = R; a.D = D; a.KS = KS; a.ksteps = ksteps;
+  a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)lstm_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+      comic_set_error("lstm_stream: cannot reserve the LDS");
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_stream_kernel, dim3(D / 16, S), dim3(512), (size_t)ksteps * kStepBytes, st, a);
+  {
+    const long n = (long)R * D;
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const float*)part, S, bias,
+                       (const float*)c_in, c_state, h_state, y, R, D, g_comic_stop.p, g_comic_stop.t);
+  }
+  COMIC_LAUNCH_CHECK("lstm_stream_step");
+  return 0;
+}

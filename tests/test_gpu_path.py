@@ -756,8 +756,9 @@ def test_greedy_and_beam_match_oracle(kw):
 @pytest.mark.parametrize('B,W,V,D', [(5, 3, 9000, 128), (50, 3, 8962, 128), (32, 8, 4300, 256), (7, 5, 25599, 512)])
 def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
     """Large-vocabulary beam step as the streaming projection + per-chunk top-k launch and its merge
-    (csrc/beam_logits.hip) against the oracle and against the GEMM + statistics + top-k launches: ids, parents and
-    lengths bit-exact, scores at 1e-4.  Row counts on one and on two 16-row tiles per wave, a last chunk with fewer
+    (csrc/beam_logits.hip) and, above 32 rows, the LSTM step as one streaming pass over the packed kernel
+    (csrc/lstm_stream.hip), against the oracle and against the GEMM + statistics + top-k launches with the
+    per-row-tile LSTM kernel: ids, parents and lengths bit-exact, scores at 1e-4.  Row counts on one and on two 16-row tiles per wave, a last chunk with fewer
     live columns than the beam width (V = 8962 = 70 * 128 + 2), beam 8, and the bench vocabulary at D = 512."""
     spec, cfg = _spec_and_cfg(fm_projection=None, H=1, token_type='word', V=V, D=D, init_method='project_hidden',
                               start_id=V - 2, end_id=V - 1)
@@ -771,12 +772,15 @@ def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
         for _ in range(3):                                # eager, captured, replayed
             res = dec.beam_search(dev(fm), dev(im), W, max_steps)
         dec.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
-        assert dec.lib.comic_decoder_beam_path() == 1     # the streaming launch really ran
+        # the streaming launches really ran: bit 0 the logits step, bit 1 the LSTM step (more than 32 rows)
+        assert dec.lib.comic_decoder_beam_path() == (3 if B * W > 32 else 1)
         monkeypatch.setenv('COMIC_BEAM_LOGITS', '0')
+        monkeypatch.setenv('COMIC_LSTM_STREAM', '0')
         dec0 = cdec.Decoder(spec, pe, DEV)
         res0 = dec0.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
         assert dec0.lib.comic_decoder_beam_path() == 0
         monkeypatch.delenv('COMIC_BEAM_LOGITS')
+        monkeypatch.delenv('COMIC_LSTM_STREAM')
         for k in ('step_ids', 'parent_ids', 'predicted_ids', 'lengths'):
             np.testing.assert_array_equal(res[k], res0[k], err_msg=k)
         fin = np.isfinite(res0['scores'])
