@@ -271,18 +271,21 @@ __global__ __launch_bounds__(512) void beam_logits_kernel(BeamLogitsArgs a) {
 }
 
 // ---- merge: one workgroup per batch entry -----------------------------------------------------------------------------
-__device__ __forceinline__ BLVal bl_block_argmax(float v, int i, BLVal* sh) {
-  const int tid = threadIdx.x;
-  sh[tid].v = v;
-  sh[tid].i = i;
-  __syncthreads();
-  for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-    if (tid < s && bl_better(sh[tid + s].v, sh[tid + s].i, sh[tid].v, sh[tid].i)) sh[tid] = sh[tid + s];
-    __syncthreads();
-  }
-  const BLVal r = sh[0];
-  __syncthreads();
-  return r;
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// wave-wide best of one (score, flat index) pair per lane under the total order (score descending, index ascending);
+// 0x7fffffff: no candidate.  Two DPP reductions: the maximum score, then the lowest index that carries it.
+__device__ __forceinline__ BLVal wave_best(float v, int i) {
+  const float mx = wave_max(i == 0x7fffffff ? -INFINITY : v);
+  const int gi = wave_min_i32((i != 0x7fffffff && v == mx) ? i : 0x7fffffff);
+  return BLVal{mx, gi};
 }
 
 __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
@@ -295,30 +298,63 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
                                                           int32_t* __restrict__ steps_executed, int t, int max_steps,
                                                           const int32_t* __restrict__ stop, int stop_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  __shared__ BLVal sh[256];
-  __shared__ float s_max[64], s_logsum[64], s_lp[64], s_selv[64];
-  __shared__ int s_fin[64], s_sel[64], s_alldone;
-  __shared__ long long s_len[64];
+  __shared__ float s_max[8], s_logsum[8], s_lp[8], s_selv[8], s_fv[64];
+  __shared__ int s_fin[8], s_sel[8], s_fi[64], s_alldone;
+  __shared__ long long s_len[8];
   if (comic_stopped(stop, stop_t)) return;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = chunks * W, n = W * per;
   float* c_tot = (float*)dyn;                  // candidate scores / flat indices of this entry (0x7fffffff: no candidate)
   int* c_f = (int*)(c_tot + n);
-  for (int w = tid; w < W; w += 256) {
-    s_lp[w] = log_probs[b * W + w];
-    s_fin[w] = finished[b * W + w];
-    s_len[w] = lengths[b * W + w];
+  // every global load the kernel can issue without a dependence goes out first: the beam state, the chunk partials
+  // of this wave's first beam (<= 8 per lane) and the first 8 candidates per thread
+  constexpr int CP = 8, CQ = 8;
+  const bool pre = wave < W && chunks <= 64 * CP;
+  float pm[CP], ps[CP];
+  if (pre) {
+    const size_t ro = (size_t)(b * W + wave) * chunks;
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      const int k = lane + 64 * u;
+      pm[u] = k < chunks ? pmax[ro + k] : -INFINITY;
+      ps[u] = k < chunks ? psum[ro + k] : 0.f;
+    }
+  }
+  int vv0[CQ];
+  float xx0[CQ];
+#pragma unroll
+  for (int u = 0; u < CQ; ++u) {
+    const int j = tid + u * 256;
+    vv0[u] = -1;
+    xx0[u] = 0.f;
+    if (j < n) {
+      vv0[u] = cand_i[(size_t)b * n + j];
+      xx0[u] = cand_v[(size_t)b * n + j];
+    }
+  }
+  if (tid < W) {
+    s_lp[tid] = log_probs[b * W + tid];
+    s_fin[tid] = finished[b * W + tid];
+    s_len[tid] = lengths[b * W + tid];
   }
   if (tid == 0) s_alldone = 1;
   // log-softmax constants of every beam from the per-chunk partials (a wave per beam; every lane walks its chunks in
   // ascending order, the wave reduction is a fixed tree: the same bits on every launch)
   for (int w = wave; w < W; w += 4) {
     const size_t ro = (size_t)(b * W + w) * chunks;
-    float mx = -INFINITY;
-    for (int k = lane; k < chunks; k += 64) mx = fmaxf(mx, pmax[ro + k]);
-    mx = wave_max(mx);
-    float s = 0.f;
-    for (int k = lane; k < chunks; k += 64) s += psum[ro + k] * expf(pmax[ro + k] - mx);
+    float mx = -INFINITY, s = 0.f;
+    if (pre && w == wave) {
+#pragma unroll
+      for (int u = 0; u < CP; ++u) mx = fmaxf(mx, pm[u]);
+      mx = wave_max(mx);
+#pragma unroll
+      for (int u = 0; u < CP; ++u)
+        if (lane + 64 * u < chunks) s += ps[u] * expf(pm[u] - mx);
+    } else {
+      for (int k = lane; k < chunks; k += 64) mx = fmaxf(mx, pmax[ro + k]);
+      mx = wave_max(mx);
+      for (int k = lane; k < chunks; k += 64) s += psum[ro + k] * expf(pmax[ro + k] - mx);
+    }
     s = wave_sum(s);
     if (lane == 0) {
       s_max[w] = mx;
@@ -329,7 +365,36 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   // candidate slots: beam w, slot k < chunks * W.  A live beam's slot is the k-th (chunk, rank) entry of its lists; a
   // finished beam (_mask_probs: 0 at EOS, float32 min elsewhere) has W + 1 synthetic ones: EOS and the W lowest other
   // columns, which is all a top-W selection can ever take from it.
-  for (int j0 = tid; j0 < n; j0 += 256 * 4) {
+  auto place = [&](int j, int v_in, float x_in) {
+    const int w = j / per, k = j - w * per;
+    int f = 0x7fffffff;
+    float tot = -INFINITY;
+    if (s_fin[w]) {
+      if (k <= W) {
+        int v = end_id;
+        if (k > 0) {
+          v = k - 1;
+          if (v >= end_id) ++v;                 // the (k-1)-th column that is not EOS
+        }
+        if (v < V) {
+          tot = s_lp[w] + ((v == end_id) ? 0.f : -FLT_MAX);
+          f = w * V + v;
+        }
+      }
+    } else if (v_in >= 0) {
+      const float step = (x_in - s_max[w]) - s_logsum[w];
+      tot = s_lp[w] + step;
+      f = w * V + v_in;
+    }
+    c_tot[j] = tot;
+    c_f[j] = f;
+  };
+#pragma unroll
+  for (int u = 0; u < CQ; ++u) {
+    const int j = tid + u * 256;
+    if (j < n) place(j, vv0[u], xx0[u]);
+  }
+  for (int j0 = tid + 256 * CQ; j0 < n; j0 += 256 * 4) {
     int vv[4];
     float xx[4];
 #pragma unroll
@@ -345,66 +410,90 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = j0 + u * 256;
-      if (j >= n) continue;
-      const int w = j / per, k = j - w * per;
-      int f = 0x7fffffff;
-      float tot = -INFINITY;
-      if (s_fin[w]) {
-        if (k <= W) {
-          int v = end_id;
-          if (k > 0) {
-            v = k - 1;
-            if (v >= end_id) ++v;                 // the (k-1)-th column that is not EOS
-          }
-          if (v < V) {
-            tot = s_lp[w] + ((v == end_id) ? 0.f : -FLT_MAX);
-            f = w * V + v;
-          }
-        }
-      } else if (vv[u] >= 0) {
-        const float step = (xx[u] - s_max[w]) - s_logsum[w];
-        tot = s_lp[w] + step;
-        f = w * V + vv[u];
-      }
-      c_tot[j] = tot;
-      c_f[j] = f;
+      if (j < n) place(j, vv[u], xx[u]);
     }
   }
   __syncthreads();
-  for (int r = 0; r < W; ++r) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff, bj = -1;
-    for (int j = tid; j < n; j += 256) {
-      const int f = c_f[j];
-      if (f == 0x7fffffff) continue;
-      const float tot = c_tot[j];
-      if (bl_better(tot, f, bv, bi)) {
-        bv = tot;
-        bi = f;
-        bj = j;
+  // the W best of every beam (a wave per beam): W x W finalists
+  constexpr int CL = 16;
+  for (int w = wave; w < W; w += 4) {
+    if (per <= 64 * CL) {         // the beam's candidates in registers: one LDS pass, W branch-free rounds
+      float rt[CL];
+      int rf[CL];
+#pragma unroll
+      for (int u = 0; u < CL; ++u) {
+        const int j = lane + 64 * u;
+        rf[u] = j < per ? c_f[w * per + j] : 0x7fffffff;
+        rt[u] = j < per ? c_tot[w * per + j] : -INFINITY;
       }
-    }
-    const BLVal best = bl_block_argmax(bv, bi, sh);
-    if (best.i != 0x7fffffff && bi == best.i) c_f[bj] = 0x7fffffff;       // flat indices are unique: one thread retires it
-    if (tid == 0) {
-      int sel = best.i;
-      if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
-        sel = 0;
-        bool again = true;
-        while (again) {
-          again = false;
-          for (int q = 0; q < r; ++q)
-            if (s_sel[q] == sel) {
-              ++sel;
-              again = true;
-            }
+      for (int r = 0; r < W; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < CL; ++u) {
+          const bool g = rf[u] != 0x7fffffff && bl_better(rt[u], rf[u], bv, bi);
+          bv = g ? rt[u] : bv;
+          bi = g ? rf[u] : bi;
+        }
+        const BLVal best = wave_best(bv, bi);
+#pragma unroll
+        for (int u = 0; u < CL; ++u) rf[u] = rf[u] == best.i ? 0x7fffffff : rf[u];
+        if (lane == 0) {
+          s_fv[w * W + r] = best.v;
+          s_fi[w * W + r] = best.i;
         }
       }
-      s_sel[r] = sel;
-      s_selv[r] = best.v;
+      continue;
     }
-    __syncthreads();
+    for (int r = 0; r < W; ++r) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff, bj = -1;
+      for (int j = w * per + lane; j < (w + 1) * per; j += 64) {
+        const int f = c_f[j];
+        if (f == 0x7fffffff) continue;
+        const float tot = c_tot[j];
+        if (bl_better(tot, f, bv, bi)) {
+          bv = tot;
+          bi = f;
+          bj = j;
+        }
+      }
+      const BLVal best = wave_best(bv, bi);
+      if (best.i != 0x7fffffff && bi == best.i) c_f[bj] = 0x7fffffff;     // flat indices are unique: one lane retires it
+      if (lane == 0) {
+        s_fv[w * W + r] = best.v;
+        s_fi[w * W + r] = best.i;
+      }
+    }
   }
+  __syncthreads();
+  // the W best of the finalists (wave 0, one finalist per lane)
+  if (wave == 0) {
+    float fv = lane < W * W ? s_fv[lane] : -INFINITY;
+    int fi = lane < W * W ? s_fi[lane] : 0x7fffffff;
+    for (int r = 0; r < W; ++r) {
+      const BLVal best = wave_best(fv, fi);
+      if (best.i != 0x7fffffff && fi == best.i) fi = 0x7fffffff;
+      if (lane == 0) {
+        int sel = best.i;
+        if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
+          sel = 0;
+          bool again = true;
+          while (again) {
+            again = false;
+            for (int q = 0; q < r; ++q)
+              if (s_sel[q] == sel) {
+                ++sel;
+                again = true;
+              }
+          }
+        }
+        s_sel[r] = sel;
+        s_selv[r] = best.v;
+      }
+    }
+  }
+  __syncthreads();
   if (tid < W) {
     const int f = s_sel[tid];
     const int parent = f / V, word = f - parent * V;
@@ -470,7 +559,8 @@ int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps,
   return 0;
 }
 
-int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials, float* log_probs,
+// y_frag_in: the step's decoder outputs already as fragments (lstm_cell_kernel), or null: split from y here
+int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
                            int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
                            int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
                            hipStream_t st) {
@@ -485,10 +575,10 @@ int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials,
   a.cand_i = (int32_t*)(a.cand_v + (size_t)R * chunks * W);
   unsigned long long* cnt = (unsigned long long*)(a.cand_i + (size_t)R * chunks * W);
   uint4* y_frag = (uint4*)(((uintptr_t)(cnt + max_steps) + 15) & ~(uintptr_t)15);
-  a.y_frag = y_frag;
+  a.y_frag = y_frag_in ? (const uint4*)y_frag_in : y_frag;
   a.R = R; a.D = D; a.V = V; a.W = W; a.chunks = chunks;
   a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
-  {
+  if (!y_frag_in) {
     const long units = (long)((R + 15) / 16) * (D / 32) * 2 * 64;
     hipLaunchKernelGGL(beam_pack_y_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, y, y_frag, R, D, units,
                        g_comic_stop.p, g_comic_stop.t);

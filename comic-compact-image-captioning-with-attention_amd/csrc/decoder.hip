@@ -210,6 +210,8 @@ struct AttnArgs {
   int mask_ld;
   float keep_in;
   int q_parts;              // > 1: q is [q_parts][B][D] split-K partials; the reduced row goes to q_out
+  int mem_div;              // > 1 (forward only): batch row b attends to memory row b / mem_div (beam search: the beams
+                            // of an entry share its keys / values, which are then held once per entry)
   float* q_out;
   int pgrad_overwrite;      // backward: 1 = store this step's parameter-gradient row instead of adding to it
   const int32_t* stop;      // decode loops: see comic_stopped (common.h)
@@ -299,24 +301,49 @@ __device__ __forceinline__ float score_row(const AttnArgs& a, const float* kr, c
 constexpr int kAttnWaves = 16;   // waves per workgroup: each wave owns <= 2 memory rows at M=25 (8 waves measured: isolated step +0.15 ms, overlapped equal)
 constexpr int kAttnThreads = kAttnWaves * 64;
 
+// q row from its split-K partials [parts][B][D], added in slice order; the loads of four slices travel together
+template <int EPL>
+__device__ __forceinline__ void sum_q_parts(const float* q, int parts, size_t stride, float (&qv)[EPL]) {
+  load_row<EPL>(q, qv);
+  int s = 1;
+  for (; s + 4 <= parts; s += 4) {
+    float t[4][EPL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_row<EPL>(q + (size_t)(s + u) * stride, t[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) qv[i] += t[u][i];
+  }
+  for (; s < parts; ++s) {
+    float qs[EPL];
+    load_row<EPL>(q + (size_t)s * stride, qs);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) qv[i] += qs[i];
+  }
+}
+
 template <int EPL>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   if (comic_stopped(a.stop, a.stop_t)) return;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int B = a.d.B, M = a.d.M, D = a.d.D, H = a.d.H, Cv = a.d.Cv;
-  (void)B;
   float* sc = sm;  // [H][M]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  if (a.mem_div > 1) {
+    // shared memories: workgroups x, x + 8, x + 16, ... are the beams of ONE entry -- consecutive workgroup ids go
+    // round the 8 XCDs, so the beams of an entry run on one XCD at the same time and its keys / values leave the HBM once
+    const int W = a.mem_div, wg = blockIdx.x;
+    const int e = (wg / (8 * W)) * 8 + (wg & 7), w = (wg >> 3) % W;
+    if (e * W >= B) return;
+    b = e * W + w;
+  }
+  const int bm = a.mem_div > 1 ? b / a.mem_div : b;
   const int dh = D / H, lph = dh / EPL;
   const int k0 = lane * EPL, head = k0 / dh;
   float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
-  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
-  for (int s = 1; s < a.q_parts; ++s) {
-    float qs[EPL];
-    load_row<EPL>(a.q + ((size_t)s * a.d.B + b) * D + k0, qs);
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) qv[i] += qs[i];
-  }
+  sum_q_parts<EPL>(a.q + (size_t)b * D + k0, a.q_parts, (size_t)a.d.B * D, qv);
   if (a.q_out && wave == 0) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) a.q_out[(size_t)b * D + k0 + i] = qv[i];
@@ -329,7 +356,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
   for (int m = wave; m < M; m += kAttnWaves) {
     float kr[EPL], rstd;
-    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    load_row<EPL>(a.keys + ((size_t)bm * M + m) * D + k0, kr);
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
     if ((lane % lph) == 0) sc[head * M + m] = raw / scale;
   }
@@ -370,7 +397,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   const int dv = Cv / H;
   for (int c = tid; c < Cv; c += kAttnThreads) {
     const float* al = sc + (c / dv) * M;
-    const float* vp = a.values + (size_t)b * M * Cv + c;
+    const float* vp = a.values + (size_t)bm * M * Cv + c;
     float acc = 0.f;
     for (int m = 0; m < M; ++m) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
     a.ctx[(size_t)b * Cv + c] = acc;
@@ -405,13 +432,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_scores_kernel(AttnArgs a) {
   const int dh = D / H, lph = dh / EPL;
   const int k0 = lane * EPL, head = k0 / dh;
   float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
-  load_row<EPL>(a.q + (size_t)b * D + k0, qv);
-  for (int s = 1; s < a.q_parts; ++s) {
-    float qs[EPL];
-    load_row<EPL>(a.q + ((size_t)s * a.d.B + b) * D + k0, qs);
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) qv[i] += qs[i];
-  }
+  sum_q_parts<EPL>(a.q + (size_t)b * D + k0, a.q_parts, (size_t)a.d.B * D, qv);
   if (a.q_out && wave == 0 && blockIdx.y == 0) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) a.q_out[(size_t)b * D + k0 + i] = qv[i];
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_scores_kernel(AttnArgs a) {
   const float scale = a.d.method == 0 ? a.tau[0] : sqrtf((float)D / (float)H);
   for (int m = m0 + wave; m < m1; m += kAttnWaves) {
     float kr[EPL], rstd;
-    load_row<EPL>(a.keys + ((size_t)b * M + m) * D + k0, kr);
+    load_row<EPL>(a.keys + ((size_t)(a.mem_div > 1 ? b / a.mem_div : b) * M + m) * D + k0, kr);
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
     if ((lane % lph) == 0) a.ws_s[((size_t)b * H + head) * M + m] = raw / scale;
   }
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_ctx_kernel(AttnArgs a) {
   float acc = 0.f;
   if (g < G && c < c_hi) {
     const float* al = sc + (c / dv) * M;
-    const float* vp = a.values + (size_t)b * M * Cv + c;
+    const float* vp = a.values + (size_t)(a.mem_div > 1 ? b / a.mem_div : b) * M * Cv + c;
     for (int m = g; m < M; m += G) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
   }
   red[tid] = acc;
@@ -1148,8 +1169,9 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st) {
+                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st, int mem_div) {
   if (int rc = attn_check(d)) return rc;
+  COMIC_REQUIRE(mem_div >= 1 && d->B % mem_div == 0, "attn_fwd: the batch must be a multiple of the rows per shared memory");
   COMIC_REQUIRE(keys && values && q && alpha && alpha_d && ctx, "attn_fwd: null pointer");
   COMIC_REQUIRE(d->method != 0 || (ln_g && ln_b && v && tau), "attn_fwd: add_LN needs ln_g/ln_b/v/tau");
   AttnArgs a{};
@@ -1158,6 +1180,7 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
   a.mask_alpha = mask_alpha; a.keep_alpha = keep_alpha; a.alpha = alpha; a.alpha_d = alpha_d; a.ctx = ctx;
   a.lens = lens; a.t = t; a.att_prev = att_prev; a.att_next = att_next; a.xh_next = xh_next; a.xh_ld = xh_ld;
   a.mask_next = mask_next; a.mask_ld = mask_ld; a.keep_in = keep_in; a.q_parts = q_parts; a.q_out = q_out;
+  a.mem_div = mem_div;
   a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
   const size_t lds = (size_t)d->H * d->M * sizeof(float);
   const int S = scores_ws ? comic_attn_splits(d->B, d->M) : 1;
@@ -1172,7 +1195,8 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
     return 0;
   }
   int rc = attn_dispatch(d->D, [&](auto epl) {
-    hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(d->B), dim3(kAttnThreads), lds, st, a);
+    const int grid = mem_div > 1 ? ((d->B / mem_div + 7) / 8) * 8 * mem_div : d->B;
+    hipLaunchKernelGGL((attn_fwd_kernel<decltype(epl)::value>), dim3(grid), dim3(kAttnThreads), lds, st, a);
   });
   if (rc) return rc;
   COMIC_LAUNCH_CHECK("attn_fwd");
@@ -1239,7 +1263,7 @@ extern "C" int comic_attn_step_fwd(const comic_attn_desc* d, const float* keys, 
                                    const float* mask_alpha, float keep_alpha, float* alpha, float* alpha_d, float* ctx,
                                    void* stream) {
   return comic_attn_fwd_ex(d, keys, values, q, ln_g, ln_b, v, tau, mask_alpha, keep_alpha, alpha, alpha_d, ctx, nullptr,
-                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, 1, nullptr, nullptr, (hipStream_t)stream);
+                           0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, 1, nullptr, nullptr, (hipStream_t)stream, 1);
 }
 
 extern "C" int comic_attn_step_bwd(const comic_attn_desc* d, const float* keys, const float* values, const float* q,

@@ -33,7 +33,8 @@ int comic_attn_fwd_ex(const comic_attn_desc* d, const float* keys, const float* 
                       const float* ln_g, const float* ln_b, const float* v, const float* tau, const float* mask_alpha,
                       float keep_alpha, float* alpha, float* alpha_d, float* ctx, const int32_t* lens, int t,
                       const float* att_prev, float* att_next, float* xh_next, int xh_ld, const float* mask_next,
-                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st);
+                      int mask_ld, float keep_in, int q_parts, float* q_out, float* scores_ws, hipStream_t st,
+                      int mem_div = 1);
 int comic_attn_splits(int B, int M);
 long comic_attn_bwd_scratch(int B, int H, int M, int D);
 int comic_colsum_ws(const float* in, float* out, int rows, int cols, float beta, float* ws, hipStream_t st);
@@ -62,7 +63,7 @@ int64_t comic_beam_logits_pack_bytes(int D, int V);
 int64_t comic_beam_logits_partial_floats(int D, int V, int R, int W, int max_steps);
 int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps, hipStream_t st);
 int comic_beam_pack_wo(const float* W_o, const float* b_o, int ld, void* wo_frag, int D, int V, hipStream_t st);
-int comic_beam_logits_step(const float* y, const void* wo_frag, float* partials, float* log_probs,
+int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
                            int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
                            int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
                            hipStream_t st);
@@ -73,8 +74,14 @@ int64_t comic_lstm_stream_part_bytes(int D, int Wd, int R);
 int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st);
 int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
                            const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
-                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y, int R, int E,
-                           int A, int D, int V, hipStream_t st);
+                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y,
+                           void* y_frag, int R, int E, int A, int D, int V, hipStream_t st);
+bool comic_stream_gemm_supported(int Kin, int N, int R);
+int64_t comic_stream_gemm_wfrag_floats(int Kin, int N);
+int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R);
+int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st);
+int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
+                      hipStream_t st);
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
                        hipStream_t st);
@@ -609,15 +616,23 @@ int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const
 // The same wrapper step on the fused kernels: operand prep (embedding + parent gather + concat),
 // LSTM product + gates, query product left as split-K partials for the attention kernel.
 // Reads the previous step's raw outputs (c_src, h_src, att_src) through `parent`.
+// operands of the streaming step kernels (lstm_stream.hip): packed LSTM kernel, the step's operand rows and outputs as
+// hi / lo fragments, packed W_q (null: exact split-K product)
+struct StreamBufs {
+  const void* kfrag;
+  void* xfrag;
+  void* yfrag;
+  const void* wqfrag;
+};
 int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
                      const float* keys, const float* values, const float* kpanel, const int32_t* ids,
                      const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
                      StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st,
-                     const void* kfrag = nullptr, void* xfrag = nullptr) {
+                     const StreamBufs* sm = nullptr, int mem_div = 1) {
   const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
-  if (kfrag) {      // many rows: the kernel streamed once for all of them (lstm_stream.hip)
-    RC(comic_lstm_stream_step(p->emb, ids, parent, W, att_src, h_src, c_src, kfrag, p->b, xfrag, c_in, (float*)g_splitk_ws,
-                              kSplitKBytes, sb.c2, sb.h2, sb.y, rows, E, A, D, d->V, st));
+  if (sm) {         // many rows: the kernel streamed once for all of them (lstm_stream.hip)
+    RC(comic_lstm_stream_step(p->emb, ids, parent, W, att_src, h_src, c_src, sm->kfrag, p->b, sm->xfrag, c_in,
+                              (float*)g_splitk_ws, kSplitKBytes, sb.c2, sb.h2, sb.y, sm->yfrag, rows, E, A, D, d->V, st));
   } else {
     const long n = (long)rows * (Wd + D);
     hipLaunchKernelGGL(infer_prep_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, ids, parent, W,
@@ -628,12 +643,13 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
   }
   int S = 1;
   float* part = (float*)g_splitk_ws;
-  RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
+  if (sm && sm->wqfrag) RC(comic_stream_gemm(sm->yfrag, sm->wqfrag, part, kSplitKBytes, rows, D, D, &S, st));
+  else RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
   // large memories (Inception-V1 Mixed_4f: M = 196): the attention step in its split form; its [rows][H][M] scratch is the
   // pre-activation gate buffer, which the fused LSTM step above never materialises
   float* attn_ws = ((long)d->H * d->M <= 4L * D) ? sb.g : nullptr;
   RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha, alpha_d_out,
-                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, attn_ws, st));
+                       sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, attn_ws, st, mem_div));
   if (d->context_layer) {
     RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
   }
@@ -1081,6 +1097,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
   w.take<float>((D + 1) * ((V + 127) / 128 * 128));                // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
   w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));  // streaming LSTM step
+  w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));     // ... W_q, y fragments
   if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
     const long S = std::max(1, max_steps);
     w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
@@ -1094,7 +1111,7 @@ struct InferBufs {
   float *fm_t, *im_t, *keys, *values_buf;
   InitBufs ib;
   StepBufs sb;
-  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad, *kfrag, *xfrag;
+  float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad, *kfrag, *xfrag, *wqfrag, *yfrag;
   int32_t *ids, *parents;
   float *p_xh = nullptr, *p_y = nullptr, *p_q = nullptr, *p_argp = nullptr;   // persistent greedy loop (rows <= 64)
   unsigned* p_sync = nullptr;
@@ -1121,6 +1138,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
   b.wo_pad = w.take<float>((D + 1) * ((V + 127) / 128 * 128));
   b.kfrag = w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); b.xfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));
+  b.wqfrag = w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); b.yfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));
   if (rows <= 64 && max_steps > 0) {
     const long S = max_steps;
     b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);
@@ -1267,18 +1285,23 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   InferBufs ws = carve_infer(d, R, workspace, workspace_bytes);
   COMIC_REQUIRE(ws.ok, "beam: workspace overflow");
   const int D = d->D, E = d->E, A = d->A, V = d->V, M = d->M, H = d->H;
-  // tile_batch BEFORE keys are computed (model_base.py:127-131)
+  // tile_batch BEFORE keys are computed (model_base.py:127-131).  The beams of an entry attend to the same memory: the
+  // fused step's attention kernel reads row b / W of keys / values held ONCE per entry (same values as the tiled copy's)
+  const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
+  const int mem_div = fused ? W : 1;
   {
     const long n1 = (long)R * M * d->C, n2 = (long)R * d->Cg;
-    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)cdiv64(n1, 256)), dim3(256), 0, st, fm, ws.fm_t, n1, W,
-                       M * d->C);
+    if (mem_div == 1)
+      hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)cdiv64(n1, 256)), dim3(256), 0, st, fm, ws.fm_t, n1, W,
+                         M * d->C);
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)cdiv64(n2, 256)), dim3(256), 0, st, im_embed, ws.im_t, n2, W,
                        d->Cg);
     COMIC_LAUNCH_CHECK("tile_rows");
   }
   const comic_attn_desc ad = attn_desc(d, R);
   const float* values = nullptr;
-  RC(memory_projections(d, p, ws.fm_t, R, ws.keys, ws.values_buf, &values, st));
+  if (mem_div == 1) RC(memory_projections(d, p, ws.fm_t, R, ws.keys, ws.values_buf, &values, st));
+  else RC(memory_projections(d, p, fm, B, ws.keys, ws.values_buf, &values, st));
   RC(rnn_init_fwd(d, p, ws.im_t, R, nullptr, ws.ib, ws.c[0], ws.h[0], st));
   RC(fill(ws.att[0], 0.f, (long)R * A, st));
   // initial beam state: log_probs [0,-inf,...], finished [0,1,...], lengths 0
@@ -1286,11 +1309,16 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   hipLaunchKernelGGL(fill_i32_kernel, dim3(cdiv(R, 256)), dim3(256), 0, st, ws.ids, d->start_id, (long)R);
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps_executed, max_steps, 1L);
   COMIC_LAUNCH_CHECK("beam init");
-  const bool fused = fused_step_enabled() && comic_fused_step_supported(D, E + A + D);
   const bool stream_lstm = fused && lstm_stream_enabled() && comic_lstm_stream_supported(D, E, A, R) &&
                            comic_lstm_stream_part_bytes(D, E + A + D, R) <= kSplitKBytes;
-  if (stream_lstm) RC(comic_lstm_stream_pack(p->K, ws.kfrag, D, E + A + D, st));
-  else if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
+  StreamBufs sm{ws.kfrag, ws.xfrag, ws.yfrag, nullptr};
+  if (stream_lstm) {
+    RC(comic_lstm_stream_pack(p->K, ws.kfrag, D, E + A + D, st));
+    if (comic_stream_gemm_supported(D, D, R) && comic_stream_gemm_part_bytes(D, D, R) <= kSplitKBytes) {
+      RC(comic_stream_gemm_pack(p->W_q, ws.wqfrag, D, D, st));
+      sm.wqfrag = ws.wqfrag;
+    }
+  } else if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   // large vocabularies: projection + per-chunk top-k as one streaming launch over a packed W_o (beam_logits.hip)
   const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
                              comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128) * 4 &&
@@ -1329,9 +1357,9 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
       RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
-                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st, stream_lstm ? ws.kfrag : nullptr, ws.xfrag));
+                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st, stream_lstm ? &sm : nullptr, mem_div));
       if (stream_logits) {
-        RC(comic_beam_logits_step(sb.y, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
+        RC(comic_beam_logits_step(sb.y, stream_lstm ? ws.yfrag : nullptr, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
                                   scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id, st));
       } else {
         RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));

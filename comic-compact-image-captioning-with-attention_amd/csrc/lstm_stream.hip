@@ -17,6 +17,12 @@
 
 #include "conv_common.h"
 
+#define RC(x)      \
+  do {             \
+    int rc_ = (x); \
+    if (rc_) return rc_; \
+  } while (0)
+
 namespace {
 
 constexpr int kStepBytes = 8 * 1024;     // one chunk, one k32-step: 4 gate tiles x {hi, lo} x 64 lanes x 16 B
@@ -24,9 +30,11 @@ constexpr int kMaxSliceSteps = 16;       // 128 KB of LDS
 
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// K [Wd][4D] fp32 -> [chunk][k-step][gate][hi, lo][lane]: 8 bf16, lane (fr, fg) <-> K[32 s + 8 fg + j][gate D + 16 chunk + fr]
-__global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restrict__ K, uint4* __restrict__ out, int D, int Wd,
-                                                          int KS, long units) {
+// K [Wd][N] fp32 -> [chunk][k-step][tile g][hi, lo][lane]: 8 bf16, lane (fr, fg) <-> K[32 s + 8 fg + j][g gstride + chunk cstride + fr]
+// (LSTM kernel, N = 4D: tile g = gate g of 16 units, gstride D, cstride 16; plain matrix: four adjacent 16-column tiles,
+// gstride 16, cstride 64)
+__global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restrict__ K, uint4* __restrict__ out, int N, int Wd,
+                                                          int KS, int gstride, int cstride, long units) {
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1), g = (int)((u >> 7) & 3);
@@ -34,7 +42,7 @@ __global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restric
   const int s = (int)(t % KS);
   const int c = (int)(t / KS);
   const int fr = lane & 15, fg = lane >> 4;
-  const int col = g * D + c * 16 + fr, k0 = s * 32 + fg * 8;
+  const int col = g * gstride + c * cstride + fr, k0 = s * 32 + fg * 8;
   uint32_t w[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -42,7 +50,7 @@ __global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int k = k0 + 2 * j + e;
-      x[e] = k < Wd ? K[(size_t)k * 4 * D + col] : 0.f;
+      x[e] = k < Wd ? K[(size_t)k * N + col] : 0.f;
     }
     const uint32_t h = pack_bf16x2(x[0], x[1]);
     w[j] = hl == 0 ? h : pack_bf16x2(x[0] - __uint_as_float(h << 16), x[1] - __uint_as_float(h & 0xFFFF0000u));
@@ -109,8 +117,8 @@ __global__ __launch_bounds__(256) void lstm_prep_frag_kernel(const float* __rest
 struct LstmStreamArgs {
   const uint4* k_frag;
   const uint4* x_frag;
-  float* part;             // [S][R][4D] partial gate sums
-  int R, D, KS, ksteps;
+  float* part;             // [S][R][N] partial sums
+  int R, N, KS, ksteps, gstride, cstride;
   const int32_t* stop;
   int stop_t;
 };
@@ -177,14 +185,14 @@ __device__ __forceinline__ void lstm_stream_wave(const LstmStreamArgs& a, unsign
       }
     }
   }
-  // lane (fr, fg) holds, of row `row[m]`, units 16 c + 4 fg + i of gate g in acc[m][g][i]
+  // lane (fr, fg) holds, of row `row[m]`, columns g gstride + c cstride + 4 fg + i in acc[m][g][i]
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
     if (row[m] < 0) continue;
-    float* o = a.part + ((size_t)sl * a.R + row[m]) * 4 * a.D + c * 16 + 4 * fg;
+    float* o = a.part + ((size_t)sl * a.R + row[m]) * a.N + c * a.cstride + 4 * fg;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      *(float4*)(o + (size_t)g * a.D) = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+      *(float4*)(o + (size_t)g * a.gstride) = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
   }
 }
 
@@ -203,29 +211,53 @@ __global__ __launch_bounds__(512) void lstm_stream_kernel(LstmStreamArgs a) {
 // gates = sum of the K-slices (slice order) + bias; i, j, f, o -> c2 = c sigma(f + 1) + sigma(i) tanh(j), h2 = tanh(c2) sigma(o)
 __global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ part, int S, const float* __restrict__ bias,
                                                         const float* __restrict__ c_prev, float* __restrict__ c_state,
-                                                        float* __restrict__ h_state, float* __restrict__ y, int R, int D,
+                                                        float* __restrict__ h_state, float* __restrict__ y,
+                                                        uint4* __restrict__ y_frag, int R, int D,
                                                         const int32_t* __restrict__ stop, int stop_t) {
+  __shared__ float sy[256];
   if (comic_stopped(stop, stop_t)) return;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)R * D) return;
-  const int r = (int)(t / D), d = (int)(t % D);
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) {
-    const float* p = part + ((size_t)s * R + r) * 4 * D + d;
+  const long t0 = (long)blockIdx.x * blockDim.x, t = t0 + threadIdx.x;
+  float h2 = 0.f;
+  if (t < (long)R * D) {
+    const int r = (int)(t / D), d = (int)(t % D);
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const float* p = part + ((size_t)s * R + r) * 4 * D + d;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[q] += p[(size_t)q * D];
-  }
-  if (bias) {
+      for (int q = 0; q < 4; ++q) g[q] += p[(size_t)q * D];
+    }
+    if (bias) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) g[q] += bias[q * D + d];
+      for (int q = 0; q < 4; ++q) g[q] += bias[q * D + d];
+    }
+    const float si = sigmoid_(g[0]), tj = tanhf(g[1]);
+    const float sf = sigmoid_(g[2] + 1.0f), so = sigmoid_(g[3]);   // forget_bias = 1
+    const float c2 = c_prev[t] * sf + si * tj;
+    h2 = tanhf(c2) * so;
+    c_state[t] = c2;
+    h_state[t] = h2;
+    y[t] = h2;
   }
-  const float si = sigmoid_(g[0]), tj = tanhf(g[1]);
-  const float sf = sigmoid_(g[2] + 1.0f), so = sigmoid_(g[3]);   // forget_bias = 1
-  const float c2 = c_prev[t] * sf + si * tj;
-  const float h2 = tanhf(c2) * so;
-  c_state[t] = c2;
-  h_state[t] = h2;
-  y[t] = h2;
+  if (!y_frag) return;
+  // y also as hi / lo fragments [16-row tile][k-step][hi, lo][lane] for the products that consume it (query
+  // projection, vocabulary projection): a segment of 8 units is one lane's 16 bytes (D % 8 == 0)
+  sy[threadIdx.x] = h2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int seg = threadIdx.x >> 1, hl = threadIdx.x & 1;
+    const long e = t0 + seg * 8;
+    if (e < (long)R * D) {
+      const int r = (int)(e / D), d = (int)(e % D), KS = (D + 31) / 32;
+      const float* x = sy + seg * 8;
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t hh = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+        w[j] = hl == 0 ? hh : pack_bf16x2(x[2 * j] - __uint_as_float(hh << 16), x[2 * j + 1] - __uint_as_float(hh & 0xFFFF0000u));
+      }
+      y_frag[((size_t)(r >> 4) * KS + (d >> 5)) * 128 + hl * 64 + ((d >> 3) & 3) * 16 + (r & 15)] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
 }
 
 }  // namespace
@@ -236,9 +268,9 @@ bool comic_lstm_stream_supported(int D, int E, int A, int R) {
 }
 static inline int lstm_ks(int Wd) { return (Wd + 31) / 32; }
 // K-slices: as many as fill the device (chunks x S ~ 256 workgroups), at most 16 k-steps each
-static void lstm_slices(int D, int Wd, int* ksteps, int* S) {
-  const int KS = lstm_ks(Wd), chunks = D / 16;
-  int s = std::min(16, std::max(1, 256 / chunks));
+static void lstm_slices(int N, int Wd, int* ksteps, int* S) {
+  const int KS = lstm_ks(Wd), chunks = N / 64;
+  int s = std::min(8, std::max(1, 256 / chunks));     // (more slices: more partial rows for the consumer to add)
   int n = (KS + s - 1) / s;
   if (n > kMaxSliceSteps) n = kMaxSliceSteps;
   *ksteps = n;
@@ -248,38 +280,17 @@ int64_t comic_lstm_stream_kfrag_floats(int D, int Wd) { return (int64_t)4 * D * 
 int64_t comic_lstm_stream_xfrag_floats(int R, int Wd) { return (int64_t)((R + 15) / 16 * 16) * lstm_ks(Wd) * 32; }
 int64_t comic_lstm_stream_part_bytes(int D, int Wd, int R) {
   int n, S;
-  lstm_slices(D, Wd, &n, &S);
+  lstm_slices(4 * D, Wd, &n, &S);
   return (int64_t)S * R * 4 * D * 4;
 }
 
-int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st) {
-  const int KS = lstm_ks(Wd);
-  const long units = (long)(D / 16) * KS * 512;
-  hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, K, (uint4*)k_frag, D, Wd, KS,
-                     units);
-  COMIC_LAUNCH_CHECK("lstm_stream_pack");
-  return 0;
-}
-
-// One decode step: gather + split the operand rows, stream the kernel, apply the cell.
-int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
-                           const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
-                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y, int R, int E,
-                           int A, int D, int V, hipStream_t st) {
-  const int Wd = E + A + D, KS = lstm_ks(Wd);
-  COMIC_REQUIRE(comic_lstm_stream_supported(D, E, A, R), "lstm_stream: unsupported shape (D %d, E %d, A %d, rows %d)", D, E, A, R);
+static int stream_launch(const void* k_frag, const void* x_frag, float* part, int R, int N, int Kin, int gstride, int cstride,
+                         int* S_out, hipStream_t st) {
   int ksteps, S;
-  lstm_slices(D, Wd, &ksteps, &S);
-  COMIC_REQUIRE(part_bytes >= (int64_t)S * R * 4 * D * 4, "lstm_stream: partial buffer too small");
-  const int Rp = (R + 15) / 16 * 16;
-  {
-    const long n = (long)Rp * (KS * 4 + D / 8);
-    hipLaunchKernelGGL(lstm_prep_frag_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, table, ids, parent, W, att_src,
-                       h_src, c_src, (uint4*)x_frag, c_in, R, Rp, E, A, D, V, KS, g_comic_stop.p, g_comic_stop.t);
-  }
+  lstm_slices(N, Kin, &ksteps, &S);
   LstmStreamArgs a;
   a.k_frag = (const uint4*)k_frag; a.x_frag = (const uint4*)x_frag; a.part = part;
-  a.R = R; a.D = D; a.KS = KS; a.ksteps = ksteps;
+  a.R = R; a.N = N; a.KS = lstm_ks(Kin); a.ksteps = ksteps; a.gstride = gstride; a.cstride = cstride;
   a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();
@@ -290,11 +301,67 @@ int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(lstm_stream_kernel, dim3(D / 16, S), dim3(512), (size_t)ksteps * kStepBytes, st, a);
+  hipLaunchKernelGGL(lstm_stream_kernel, dim3(N / 64, S), dim3(512), (size_t)ksteps * kStepBytes, st, a);
+  *S_out = S;
+  return 0;
+}
+
+int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st) {
+  const int KS = lstm_ks(Wd);
+  const long units = (long)(D / 16) * KS * 512;
+  hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, K, (uint4*)k_frag, 4 * D, Wd, KS,
+                     D, 16, units);
+  COMIC_LAUNCH_CHECK("lstm_stream_pack");
+  return 0;
+}
+
+// ---- plain skinny product out[R][N] = x[R][Kin] W[Kin][N] through the same streaming kernel (query projection) -----------
+// x arrives as fragments (lstm_cell_kernel's y_frag), the result leaves as S K-slice partials [S][R][N] that the consumer
+// sums in slice order (comic_attn_fwd_ex takes them as they are).
+bool comic_stream_gemm_supported(int Kin, int N, int R) { return N % 64 == 0 && Kin % 8 == 0 && R > 32 && R <= 256; }
+int64_t comic_stream_gemm_wfrag_floats(int Kin, int N) { return (int64_t)N * lstm_ks(Kin) * 32; }
+int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R) {
+  int n, S;
+  lstm_slices(N, Kin, &n, &S);
+  return (int64_t)S * R * N * 4;
+}
+int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st) {
+  const int KS = lstm_ks(Kin);
+  const long units = (long)(N / 64) * KS * 512;
+  hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, Wm, (uint4*)w_frag, N, Kin, KS,
+                     16, 64, units);
+  COMIC_LAUNCH_CHECK("stream_gemm_pack");
+  return 0;
+}
+int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
+                      hipStream_t st) {
+  COMIC_REQUIRE(comic_stream_gemm_supported(Kin, N, R), "stream_gemm: unsupported shape (K %d, N %d, rows %d)", Kin, N, R);
+  COMIC_REQUIRE(part_bytes >= comic_stream_gemm_part_bytes(Kin, N, R), "stream_gemm: partial buffer too small");
+  RC(stream_launch(w_frag, x_frag, part, R, N, Kin, 16, 64, S, st));
+  COMIC_LAUNCH_CHECK("stream_gemm");
+  return 0;
+}
+
+// One decode step: gather + split the operand rows, stream the kernel, apply the cell.
+int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
+                           const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
+                           float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y,
+                           void* y_frag, int R, int E, int A, int D, int V, hipStream_t st) {
+  const int Wd = E + A + D, KS = lstm_ks(Wd);
+  COMIC_REQUIRE(comic_lstm_stream_supported(D, E, A, R), "lstm_stream: unsupported shape (D %d, E %d, A %d, rows %d)", D, E, A, R);
+  COMIC_REQUIRE(part_bytes >= comic_lstm_stream_part_bytes(D, Wd, R), "lstm_stream: partial buffer too small");
+  const int Rp = (R + 15) / 16 * 16;
+  {
+    const long n = (long)Rp * (KS * 4 + D / 8);
+    hipLaunchKernelGGL(lstm_prep_frag_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, table, ids, parent, W, att_src,
+                       h_src, c_src, (uint4*)x_frag, c_in, R, Rp, E, A, D, V, KS, g_comic_stop.p, g_comic_stop.t);
+  }
+  int S = 1;
+  RC(stream_launch(k_frag, x_frag, part, R, 4 * D, Wd, D, 16, &S, st));
   {
     const long n = (long)R * D;
     hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const float*)part, S, bias,
-                       (const float*)c_in, c_state, h_state, y, R, D, g_comic_stop.p, g_comic_stop.t);
+                       (const float*)c_in, c_state, h_state, y, (uint4*)y_frag, R, D, g_comic_stop.p, g_comic_stop.t);
   }
   COMIC_LAUNCH_CHECK("lstm_stream_step");
   return 0;

@@ -20,3 +20,12 @@ names = ['start', 'bar q0', 'bar q1', 'bar q2', 'bar q3', 'loop end', 'epi end']
 for w in (0, 1, 2, 4, 7):
     print('wave', w, ' '.join('%s %.2f/%.2f' % (names[i], np.median(us[:, w, i]), us[:, w, i].max()) for i in range(7) if not (w >= 2 and False)))
 print('last end over WGs: %.2f us; start spread %.2f' % (us[:, :, 5:7].max(), us[:, :, 0].max()))
+
+buf2 = np.zeros(256 * 8 * 8, np.int64)
+dec.lib.comic_debug_bm_stamps(C.c_void_p(buf2.ctypes.data))
+st2 = buf2.reshape(256, 8, 8)[:50, :4].astype(np.float64)
+t0 = st2[:, :, 0].min()
+us2 = (st2 - t0) / 100.0
+names2 = ['start', 'consts', 'fill', 'per-beam', 'final', 'end']
+for w in (0, 1, 3):
+    print('merge wave', w, ' '.join('%s %.2f/%.2f' % (names2[i], np.median(us2[:, w, i]), us2[:, w, i].max()) for i in range(6)))
