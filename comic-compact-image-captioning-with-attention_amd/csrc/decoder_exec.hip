@@ -624,11 +624,10 @@ struct StreamBufs {
   void* yfrag;
   const void* wqfrag;
 };
-int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
-                     const float* keys, const float* values, const float* kpanel, const int32_t* ids,
-                     const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
-                     StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st,
-                     const StreamBufs* sm = nullptr, int mem_div = 1) {
+// first half: operand prep + LSTM product + cell -> c2, h2, y (and y as fragments on the streaming path)
+int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, const float* kpanel, const int32_t* ids,
+                    const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
+                    StepBufs& sb, float* c_in, int rows, hipStream_t st, const StreamBufs* sm) {
   const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
   if (sm) {         // many rows: the kernel streamed once for all of them (lstm_stream.hip)
     RC(comic_lstm_stream_step(p->emb, ids, parent, W, att_src, h_src, c_src, sm->kfrag, p->b, sm->xfrag, c_in,
@@ -641,12 +640,20 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
     RC(comic_lstm_step_fused(sb.xh, Wd, kpanel, p->b, c_in, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0,
                              sb.c2, sb.h2, nullptr, 0, rows, D, Wd, st));
   }
+  return 0;
+}
+// second half: query projection (split-K partials in g_splitk_ws) + attention -> alpha, context (the next step's
+// attention state); reads y, writes nothing the vocabulary projection of the step looks at
+int infer_step_attend(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
+                      const float* keys, const float* values, StepBufs& sb, float* alpha_d_out, int rows, hipStream_t st,
+                      const StreamBufs* sm, int mem_div) {
+  const int D = d->D;
   int S = 1;
   float* part = (float*)g_splitk_ws;
   if (sm && sm->wqfrag) RC(comic_stream_gemm(sm->yfrag, sm->wqfrag, part, kSplitKBytes, rows, D, D, &S, st));
   else RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
   // large memories (Inception-V1 Mixed_4f: M = 196): the attention step in its split form; its [rows][H][M] scratch is the
-  // pre-activation gate buffer, which the fused LSTM step above never materialises
+  // pre-activation gate buffer, which the fused LSTM step never materialises
   float* attn_ws = ((long)d->H * d->M <= 4L * D) ? sb.g : nullptr;
   RC(comic_attn_fwd_ex(&ad, keys, values, part, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha, alpha_d_out,
                        sb.ctx, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 1.f, S, nullptr, attn_ws, st, mem_div));
@@ -654,6 +661,14 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
     RC(gemm(sb.ctx, p->W_a, sb.att2, nullptr, rows, D, d->Cv, d->Cv, D, D, 0, 0, 0.f, st));
   }
   return 0;
+}
+int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
+                     const float* keys, const float* values, const float* kpanel, const int32_t* ids,
+                     const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
+                     StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st,
+                     const StreamBufs* sm = nullptr, int mem_div = 1) {
+  RC(infer_step_lstm(d, p, kpanel, ids, parent, W, c_src, h_src, att_src, sb, c_in, rows, st, sm));
+  return infer_step_attend(d, p, ad, keys, values, sb, alpha_d_out, rows, st, sm, mem_div);
 }
 
 }  // namespace
@@ -1356,8 +1371,12 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       else sb.att2 = ws.att[nxt];
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
-      RC(infer_step_fused(d, p, ad, ws.keys, values, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur],
-                          sb, ws.gtmp, attn_hist + (size_t)t * R * H * M, R, st, stream_lstm ? &sm : nullptr, mem_div));
+      const StreamBufs* smp = stream_lstm ? &sm : nullptr;
+      RC(infer_step_lstm(d, p, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur], sb, ws.gtmp, R, st, smp));
+      // (the two chains that hang off y -- query projection + attention, vocabulary projection + top-k -- measured
+      // slower on two lanes than back to back: 98.5 vs 94.8 us per step, the fork / join of a 20 us branch costs more
+      // than the overlap returns)
+      RC(infer_step_attend(d, p, ad, ws.keys, values, sb, attn_hist + (size_t)t * R * H * M, R, st, smp, mem_div));
       if (stream_logits) {
         RC(comic_beam_logits_step(sb.y, stream_lstm ? ws.yfrag : nullptr, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
                                   scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id, st));
