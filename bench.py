@@ -111,7 +111,7 @@ def extras(device, enc, cnn_params, plan):
     out['beam3_roofline'] = {'bound': 'hbm', 'bytes_per_step': bytes_step, 'us_per_step': round(us_step, 1),
                              'achieved': round(bytes_step / us_step / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(bytes_step / us_step / 1e3 / 8000.0, 4),
-                             'note': 'whole decode step (LSTM, attention, logits GEMM, chunked top-k) over the logits bytes'}
+                             'note': 'whole decode step (streaming LSTM, attention, streaming logits + top-k, merge) over the bytes of W_o and of a full logits write'}
     del dec, enc50
     # ---- SCST step, COMIC-256 -------------------------------------------------------------
     Bs, W = 32, 7

@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "conv_common.h"
+#include "lstm_prep.h"
 
 namespace {
 
@@ -296,8 +297,9 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
                                                           int W, int V, int chunks, int end_id,
                                                           unsigned long long* __restrict__ done_cnt,
                                                           int32_t* __restrict__ steps_executed, int t, int max_steps,
-                                                          const int32_t* __restrict__ stop, int stop_t) {
+                                                          LstmPrepArgs prep, const int32_t* __restrict__ stop, int stop_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+  __shared__ int s_word[8], s_par[8];
   __shared__ float s_max[8], s_logsum[8], s_lp[8], s_selv[8], s_fv[64];
   __shared__ int s_fin[8], s_sel[8], s_fi[64], s_alldone;
   __shared__ long long s_len[8];
@@ -506,8 +508,34 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
     finished[b * W + tid] = fin;
     lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
     if (!fin) s_alldone = 0;
+    s_word[tid] = word;
+    s_par[tid] = parent;
   }
   __syncthreads();
+  // the NEXT step's LSTM operand rows of this entry (lstm_prep.h): embedding of the new words, attention / hidden / cell
+  // state of the parents -- what lstm_prep_frag_kernel would gather through the ids this workgroup has just chosen
+  if (prep.x_frag) {
+    const int segs = prep.KS * 4 + prep.D / 8;
+    for (int i0 = tid; i0 < W * segs; i0 += 256 * 6) {
+      float4 la[6], lb[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < W * segs) {
+          const int w = i / segs;
+          lstm_prep_load(prep, b * W + s_par[w], s_word[w], true, i - w * segs, la[u], lb[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < W * segs) {
+          const int w = i / segs;
+          lstm_prep_store(prep, b * W + w, true, i - w * segs, la[u], lb[u]);
+        }
+      }
+    }
+  }
   // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
   // arrive at the step's counter sees how many entries are done
   if (tid == 0) {
@@ -563,7 +591,7 @@ int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps,
 int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
                            int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
                            int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
-                           hipStream_t st) {
+                           const LstmPrepArgs* prep, hipStream_t st) {
   const int R = B * W, chunks = comic_beam_logits_chunks(V);
   COMIC_REQUIRE(comic_beam_logits_supported(D, V, R, W), "beam_logits: unsupported shape (D %d, V %d, rows %d, beam %d)", D, V, R, W);
   BeamLogitsArgs a;
@@ -600,7 +628,7 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
   const size_t merge_lds = (size_t)W * chunks * W * 8;
   hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(256), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
                      (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,
-                     scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, g_comic_stop.p, g_comic_stop.t);
+                     scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_logits_step");
   return 0;
 }

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "decoder_persist.h"
+#include "lstm_prep.h"
 
 // internal cross-file entries (gemm.hip, decoder.hip)
 int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -66,7 +67,7 @@ int comic_beam_pack_wo(const float* W_o, const float* b_o, int ld, void* wo_frag
 int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
                            int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
                            int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
-                           hipStream_t st);
+                           const LstmPrepArgs* prep, hipStream_t st);
 bool comic_lstm_stream_supported(int D, int E, int A, int R);
 int64_t comic_lstm_stream_kfrag_floats(int D, int Wd);
 int64_t comic_lstm_stream_xfrag_floats(int R, int Wd);
@@ -75,7 +76,7 @@ int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStrea
 int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
                            const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
                            float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y,
-                           void* y_frag, int R, int E, int A, int D, int V, hipStream_t st);
+                           void* y_frag, int R, int E, int A, int D, int V, int skip_prep, hipStream_t st);
 bool comic_stream_gemm_supported(int Kin, int N, int R);
 int64_t comic_stream_gemm_wfrag_floats(int Kin, int N);
 int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R);
@@ -623,6 +624,7 @@ struct StreamBufs {
   void* xfrag;
   void* yfrag;
   const void* wqfrag;
+  int skip_prep = 0;       // the operand rows of this step were prepared by the previous step's beam merge
 };
 // first half: operand prep + LSTM product + cell -> c2, h2, y (and y as fragments on the streaming path)
 int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, const float* kpanel, const int32_t* ids,
@@ -631,7 +633,7 @@ int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, 
   const int D = d->D, E = d->E, A = d->A, Wd = E + A + D;
   if (sm) {         // many rows: the kernel streamed once for all of them (lstm_stream.hip)
     RC(comic_lstm_stream_step(p->emb, ids, parent, W, att_src, h_src, c_src, sm->kfrag, p->b, sm->xfrag, c_in,
-                              (float*)g_splitk_ws, kSplitKBytes, sb.c2, sb.h2, sb.y, sm->yfrag, rows, E, A, D, d->V, st));
+                              (float*)g_splitk_ws, kSplitKBytes, sb.c2, sb.h2, sb.y, sm->yfrag, rows, E, A, D, d->V, sm->skip_prep, st));
   } else {
     const long n = (long)rows * (Wd + D);
     hipLaunchKernelGGL(infer_prep_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, ids, parent, W,
@@ -1371,6 +1373,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       else sb.att2 = ws.att[nxt];
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
+      sm.skip_prep = (stream_lstm && stream_logits && t > 0) ? 1 : 0;
       const StreamBufs* smp = stream_lstm ? &sm : nullptr;
       RC(infer_step_lstm(d, p, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur], sb, ws.gtmp, R, st, smp));
       // (the two chains that hang off y -- query projection + attention, vocabulary projection + top-k -- measured
@@ -1378,8 +1381,13 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       // than the overlap returns)
       RC(infer_step_attend(d, p, ad, ws.keys, values, sb, attn_hist + (size_t)t * R * H * M, R, st, smp, mem_div));
       if (stream_logits) {
+        // (with the streaming LSTM step the merge also gathers the next step's operand rows: raw c / h / attention
+        // outputs of this step through the parents it has just chosen)
+        const float* att_new = d->context_layer ? sb.att2 : sb.ctx;
+        LstmPrepArgs prep{p->emb, att_new, sb.h2, sb.c2, (uint4*)ws.xfrag, ws.gtmp, E, A, D, V, (E + A + D + 31) / 32};
         RC(comic_beam_logits_step(sb.y, stream_lstm ? ws.yfrag : nullptr, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
-                                  scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id, st));
+                                  scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id,
+                                  stream_lstm ? &prep : nullptr, st));
       } else {
         RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
         RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,

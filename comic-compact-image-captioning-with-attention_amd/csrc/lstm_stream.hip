@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "conv_common.h"
+#include "lstm_prep.h"
 
 #define RC(x)      \
   do {             \
@@ -59,59 +60,19 @@ __global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restric
 }
 
 // The step's operand gather (infer_prep_kernel: embedding of the last word | attention state and hidden state through
-// the parent beams) written straight as hi / lo fragments [16-row tile][k-step][hi, lo][lane], plus the gathered cell
-// state.  One thread per (row, 8 consecutive features): E, A and D are multiples of 8, so a segment has one source.
-__global__ __launch_bounds__(256) void lstm_prep_frag_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
-                                                             const int32_t* __restrict__ parent, int W,
-                                                             const float* __restrict__ att, const float* __restrict__ h,
-                                                             const float* __restrict__ c, uint4* __restrict__ x_frag,
-                                                             float* __restrict__ c_in, int R, int Rp, int E, int A, int D, int V,
-                                                             int KS, const int32_t* __restrict__ stop, int stop_t) {
+// the parent beams) written straight as hi / lo fragments, plus the gathered cell state (lstm_prep.h).  One thread per
+// (row, segment); rows R .. Rp - 1 of the last tile are zero filled.
+__global__ __launch_bounds__(256) void lstm_prep_frag_kernel(LstmPrepArgs p, const int32_t* __restrict__ ids,
+                                                             const int32_t* __restrict__ parent, int W, int R, int Rp,
+                                                             const int32_t* __restrict__ stop, int stop_t) {
   if (comic_stopped(stop, stop_t)) return;
-  const int Wd = E + A + D, segs = KS * 4 + D / 8;            // operand segments (zero padded to 32 KS) | cell segments
+  const int segs = p.KS * 4 + p.D / 8;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Rp * segs) return;
   const int r = (int)(i / segs), sg = (int)(i % segs);
   const bool live = r < R;
   const int src = !live ? 0 : parent ? (r / W) * W + min(max(parent[r], 0), W - 1) : r;
-  if (sg >= KS * 4) {
-    if (!live) return;
-    const int k = (sg - KS * 4) * 8;
-    const float4* p = (const float4*)(c + (size_t)src * D + k);
-    float4* q = (float4*)(c_in + (size_t)r * D + k);
-    q[0] = p[0];
-    q[1] = p[1];
-    return;
-  }
-  const int k = sg * 8;
-  float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f), hi4 = lo4;
-  if (live && k < Wd) {
-    const float* p = nullptr;
-    if (k < E) {
-      const int id = ids[r];
-      if (id >= 0 && id < V) p = table + (size_t)id * E + k;
-    } else if (k < E + A) {
-      p = att + (size_t)src * A + (k - E);
-    } else {
-      p = h + (size_t)src * D + (k - E - A);
-    }
-    if (p) {
-      lo4 = *(const float4*)p;
-      hi4 = *(const float4*)(p + 4);
-    }
-  }
-  const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
-  uint32_t wh[4], wl[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    wh[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
-    wl[j] = pack_bf16x2(x[2 * j] - __uint_as_float(wh[j] << 16), x[2 * j + 1] - __uint_as_float(wh[j] & 0xFFFF0000u));
-  }
-  // element (row r, k-step s = sg / 4, chunk fg = sg % 4) of tile r / 16 is lane (fr = r % 16, fg)
-  const int tile = r >> 4, fr = r & 15, s = sg >> 2, fg = sg & 3;
-  uint4* o = x_frag + ((size_t)tile * KS + s) * 128 + fg * 16 + fr;
-  o[0] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
-  o[64] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+  lstm_prep_segment(p, r, src, live ? ids[r] : -1, live, sg);
 }
 
 struct LstmStreamArgs {
@@ -342,19 +303,21 @@ int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64
   return 0;
 }
 
-// One decode step: gather + split the operand rows, stream the kernel, apply the cell.
+// One decode step: gather + split the operand rows (skip_prep: the previous step's beam merge already did), stream the
+// kernel, apply the cell.
 int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t* parent, int W, const float* att_src,
                            const float* h_src, const float* c_src, const void* k_frag, const float* bias, void* x_frag,
                            float* c_in, float* part, int64_t part_bytes, float* c_state, float* h_state, float* y,
-                           void* y_frag, int R, int E, int A, int D, int V, hipStream_t st) {
+                           void* y_frag, int R, int E, int A, int D, int V, int skip_prep, hipStream_t st) {
   const int Wd = E + A + D, KS = lstm_ks(Wd);
   COMIC_REQUIRE(comic_lstm_stream_supported(D, E, A, R), "lstm_stream: unsupported shape (D %d, E %d, A %d, rows %d)", D, E, A, R);
   COMIC_REQUIRE(part_bytes >= comic_lstm_stream_part_bytes(D, Wd, R), "lstm_stream: partial buffer too small");
   const int Rp = (R + 15) / 16 * 16;
-  {
+  if (!skip_prep) {
     const long n = (long)Rp * (KS * 4 + D / 8);
-    hipLaunchKernelGGL(lstm_prep_frag_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, table, ids, parent, W, att_src,
-                       h_src, c_src, (uint4*)x_frag, c_in, R, Rp, E, A, D, V, KS, g_comic_stop.p, g_comic_stop.t);
+    LstmPrepArgs pa{table, att_src, h_src, c_src, (uint4*)x_frag, c_in, E, A, D, V, KS};
+    hipLaunchKernelGGL(lstm_prep_frag_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, pa, ids, parent, W, R, Rp,
+                       g_comic_stop.p, g_comic_stop.t);
   }
   int S = 1;
   RC(stream_launch(k_frag, x_frag, part, R, 4 * D, Wd, D, 16, &S, st));
