@@ -730,12 +730,12 @@ def main():
             'frac': round(dec_bytes / (dec_ms * 1e-3) / 8e12, 5), 'loops_persistent': dec_path,
             'note': 'the chain is latency-bound, not bandwidth-bound: 2 x T\' dependent phases of three to four '
                     'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
-        tfile = os.path.join(ROOT, 'profiles', 'r02_cnn_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r03_cnn_hbm_traffic.json')
         if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
             tj = json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH))
             if tj:
                 out['roofline']['traffic'] = tj['per_forward']['conv_only_bytes_corrected']
-                out['roofline']['traffic_source'] = ('profiles/r02_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
+                out['roofline']['traffic_source'] = ('profiles/r03_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
                                                      'images, conv kernels)' % ENC_BATCH)
         if not args.no_extras and world == 1:
             try:
