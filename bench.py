@@ -484,6 +484,11 @@ def main():
     # host; ranks share the visible devices round-robin).  The driver's scaling runs use the default: nccl = RCCL.
     backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
     local_rank %= max(1, torch.cuda.device_count()) if backend != 'nccl' else (local_rank + 1)
+    if backend != 'nccl' and int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) > torch.cuda.device_count():
+        # ranks SHARING a GPU: the persistent time loops need all their workgroups resident at once (one per CU), which two
+        # processes on one device cannot both have -- the bounded waits expire and the end-of-step gate voids the step
+        # (NaN loss; observed).  The rehearsal runs the loops as per-step launches.
+        os.environ.setdefault('COMIC_PERSIST', '0')
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     if world > 1:

@@ -170,6 +170,9 @@ def main(argv=None):
     backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
     if backend != 'nccl':
         local_rank %= max(1, torch.cuda.device_count())
+        if int(os.environ.get('LOCAL_WORLD_SIZE', str(world))) > torch.cuda.device_count():
+            # ranks sharing a GPU cannot both keep a persistent loop's workgroups resident: per-step launches (bench.py)
+            os.environ.setdefault('COMIC_PERSIST', '0')
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     if world > 1:
