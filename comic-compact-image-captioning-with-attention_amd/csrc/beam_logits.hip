@@ -110,22 +110,49 @@ __global__ __launch_bounds__(256) void beam_pack_y_kernel(const float* __restric
   out[u] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Loads the compiler must not count (cdna_hip_programming.md, section 5.7 item 1): beside a builtin LDS-DMA hipcc waits
+// vmcnt(0) before every ds_read and at every use of an ordinary load, which serialises the quarter's stream behind the
+// quarter's products (measured: 4.3 us per quarter = 2.3 us of load latency + 2.0 us of products).  Both load kinds of the
+// main loop are therefore inline asm and the waits are counted by hand.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bl_lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// 16 bytes per lane global -> LDS (lds_dst: the wave's base address, lane l lands at + 16 l); M0 saved and restored
+__device__ __forceinline__ void bl_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ u32x4_t bl_load16(const void* p) {
+  u32x4_t r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void bl_wait(u32x4_t& a, u32x4_t& b) {      // vmcnt(N), and a / b are not read above it
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
+
 // One wave's share: NT (0, 1 or 2) of the 16-row tiles wave, wave + 8.  Every wave takes part in the LDS-DMA of every
 // quarter and in every barrier whatever its NT.
 //   registers (NT = 2): 64 accumulators, 64 of y fragments (one K-quarter, refilled step by step for the next quarter as
 //   soon as a step's products have issued: a rolling four-step prefetch), 2 x 32 of weight fragments (half a k-step is
 //   read from the LDS while the half before it multiplies).
+//   per quarter q: drain (DMA(q) and Y(q, 0..3) have landed), barrier, issue DMA(q + 1), multiply quarter q while
+//   Y(q + 1, s) is requested behind the products of step s.
 template <int NT>
 __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsigned char* smem, int wave, int lane, int tid) {
   const int fr = lane & 15, fg = lane >> 4;
   const int c = blockIdx.x, D = a.D, KS = D / 32, NQ = D / 128;
   const unsigned char* wsrc = (const unsigned char*)a.wo_frag + (size_t)c * KS * 16 * 1024;
   constexpr int NR = NT > 0 ? NT : 1;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(bl_lds_addr(smem)) + wave * 1024;
 
   auto issue = [&](int q, int buf) {     // 64 KB: eight rounds of 512 lanes x 16 B
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      dma16(wsrc + (size_t)q * kQuarterBytes + i * 8192 + tid * 16, smem + buf * kQuarterBytes + i * 8192 + wave * 1024);
+      bl_dma16(wsrc + (size_t)q * kQuarterBytes + i * 8192 + tid * 16, lds0 + buf * kQuarterBytes + i * 8192);
   };
   int row[NR];
   const uint4* ysrc[NR];
@@ -135,12 +162,12 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
     row[m] = r < a.R ? r : -1;
     ysrc[m] = a.y_frag + (size_t)(wave + 8 * m) * KS * 128 + lane;
   }
-  uint4 yf[NR][4][2];                     // [tile][k-step of the quarter][hi, lo]
+  u32x4_t yf[NR][4][2];                   // [tile][k-step of the quarter][hi, lo]
   auto load_y = [&](int q, int s) {
 #pragma unroll
     for (int m = 0; m < NT; ++m) {
-      yf[m][s][0] = ysrc[m][(size_t)(q * 4 + s) * 128];
-      yf[m][s][1] = ysrc[m][(size_t)(q * 4 + s) * 128 + 64];
+      yf[m][s][0] = bl_load16(ysrc[m] + (size_t)(q * 4 + s) * 128);
+      yf[m][s][1] = bl_load16(ysrc[m] + (size_t)(q * 4 + s) * 128 + 64);
     }
   };
   f32x4_t acc[NR][8];
@@ -149,15 +176,20 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
 #pragma unroll
     for (int vt = 0; vt < 8; ++vt) acc[m][vt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  if (wave == 0 && lane < 32) dma16(a.bias_pad + c * kChunkCols + lane * 4, smem + 2 * kQuarterBytes);   // the chunk's bias
+  if (wave == 0 && lane < 32) bl_dma16(a.bias_pad + c * kChunkCols + lane * 4, lds0 + 2 * kQuarterBytes);   // the chunk's bias
   issue(0, 0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) load_y(0, s);
   for (int q = 0; q < NQ; ++q) {
     const int buf = q & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of quarter q (and its y fragments) have landed
+    const bool more = q + 1 < NQ;
+    // this wave's pieces of quarter q and its row fragments have landed.  (A counted wait that left the younger row-fragment
+    // loads in flight -- vmcnt(8 NT) -- read stale weights in about one workgroup per launch whenever the row loads were
+    // L2 hits and the LDS-DMA was not: the two kinds do not retire in issue order against each other.  Nothing below
+    // relies on their relative order: everything is drained here, the next quarter's DMA and row loads are issued behind it.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // ... everybody's; the other buffer is no longer read
-    if (q + 1 < NQ) issue(q + 1, buf ^ 1);
+    if (more) issue(q + 1, buf ^ 1);
     if constexpr (NT > 0) {
       const uint4* wl = (const uint4*)(smem + buf * kQuarterBytes) + lane;
       uint4 wa[2][8];                                      // [ring][4 tiles x {hi, lo}] of one half k-step
@@ -171,6 +203,11 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
         if (h + 1 < 8) load_half(h + 1, wa[(h + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);                 // the next half's LDS reads are in flight before these products
         const int s = h >> 1;
+        if ((h & 1) == 0) {                                // first use of the step's row fragments: landed since the top
+#pragma unroll                                              // of the quarter; the statement keeps their readers below it
+          for (int m = 0; m < NT; ++m) bl_wait<63>(yf[m][s][0], yf[m][s][1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int vt = (h & 1) * 4 + j;
@@ -187,7 +224,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
             acc[m][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(bf16x8_t, yf[m][s][0]), acc[m][vt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if ((h & 1) && q + 1 < NQ) load_y(q + 1, s);       // this step's y registers refill for the next quarter
+        if ((h & 1) && more) load_y(q + 1, s);             // this step's y registers refill for the next quarter
       }
     }
   }
@@ -285,7 +322,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // 0x7fffffff: no candidate.  Two DPP reductions: the maximum score, then the lowest index that carries it.
 __device__ __forceinline__ BLVal wave_best(float v, int i) {
   const float mx = wave_max(i == 0x7fffffff ? -INFINITY : v);
-  const int gi = wave_min_i32((i != 0x7fffffff && v == mx) ? i : 0x7fffffff);
+  const int gi = wave_min_i32(((i != 0x7fffffff) & (v == mx)) ? i : 0x7fffffff);
   return BLVal{mx, gi};
 }
 
@@ -350,12 +387,11 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
       for (int u = 0; u < CP; ++u) mx = fmaxf(mx, pm[u]);
       mx = wave_max(mx);
 #pragma unroll
-      for (int u = 0; u < CP; ++u)
-        if (lane + 64 * u < chunks) s += ps[u] * expf(pm[u] - mx);
+      for (int u = 0; u < CP; ++u) s += ps[u] * __expf(pm[u] - mx);      // (absent chunks: 0 * exp(-inf) = 0)
     } else {
       for (int k = lane; k < chunks; k += 64) mx = fmaxf(mx, pmax[ro + k]);
       mx = wave_max(mx);
-      for (int k = lane; k < chunks; k += 64) s += psum[ro + k] * expf(pmax[ro + k] - mx);
+      for (int k = lane; k < chunks; k += 64) s += psum[ro + k] * __expf(pmax[ro + k] - mx);
     }
     s = wave_sum(s);
     if (lane == 0) {
@@ -367,29 +403,16 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   // candidate slots: beam w, slot k < chunks * W.  A live beam's slot is the k-th (chunk, rank) entry of its lists; a
   // finished beam (_mask_probs: 0 at EOS, float32 min elsewhere) has W + 1 synthetic ones: EOS and the W lowest other
   // columns, which is all a top-W selection can ever take from it.
-  auto place = [&](int j, int v_in, float x_in) {
-    const int w = j / per, k = j - w * per;
-    int f = 0x7fffffff;
-    float tot = -INFINITY;
-    if (s_fin[w]) {
-      if (k <= W) {
-        int v = end_id;
-        if (k > 0) {
-          v = k - 1;
-          if (v >= end_id) ++v;                 // the (k-1)-th column that is not EOS
-        }
-        if (v < V) {
-          tot = s_lp[w] + ((v == end_id) ? 0.f : -FLT_MAX);
-          f = w * V + v;
-        }
-      }
-    } else if (v_in >= 0) {
-      const float step = (x_in - s_max[w]) - s_logsum[w];
-      tot = s_lp[w] + step;
-      f = w * V + v_in;
-    }
-    c_tot[j] = tot;
-    c_f[j] = f;
+  const float inv_per = 1.0f / (float)per;
+  auto place = [&](int j, int v_in, float x_in) {          // selects only: no branches
+    const int w = (int)(((float)j + 0.5f) * inv_per), k = j - w * per;     // j / per (exact: j < 2^16, margin 0.5 / per)
+    const bool fin = s_fin[w] != 0;
+    const int vs = (k == 0) ? end_id : (k - 1 + ((k - 1 >= end_id) ? 1 : 0));     // EOS, then the (k-1)-th column that is not EOS
+    const bool ok = fin ? ((k <= W) & (vs < V)) : (v_in >= 0);
+    const float step = fin ? ((vs == end_id) ? 0.f : -FLT_MAX) : ((x_in - s_max[w]) - s_logsum[w]);
+    const int v = fin ? vs : v_in;
+    c_tot[j] = ok ? s_lp[w] + step : -INFINITY;
+    c_f[j] = ok ? w * V + v : 0x7fffffff;
   };
 #pragma unroll
   for (int u = 0; u < CQ; ++u) {
@@ -423,17 +446,19 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
       float rt[CL];
       int rf[CL];
 #pragma unroll
-      for (int u = 0; u < CL; ++u) {
-        const int j = lane + 64 * u;
-        rf[u] = j < per ? c_f[w * per + j] : 0x7fffffff;
-        rt[u] = j < per ? c_tot[w * per + j] : -INFINITY;
+      for (int u = 0; u < CL; ++u) {                       // (clamped index + select, bitwise conditions: no branches)
+        const int j = lane + 64 * u, jc = min(j, per - 1);
+        const int f = c_f[w * per + jc];
+        const float tt = c_tot[w * per + jc];
+        rf[u] = j < per ? f : 0x7fffffff;
+        rt[u] = j < per ? tt : -INFINITY;
       }
       for (int r = 0; r < W; ++r) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int u = 0; u < CL; ++u) {
-          const bool g = rf[u] != 0x7fffffff && bl_better(rt[u], rf[u], bv, bi);
+          const bool g = (rf[u] != 0x7fffffff) & ((rt[u] > bv) | ((rt[u] == bv) & (rf[u] < bi)));
           bv = g ? rt[u] : bv;
           bi = g ? rf[u] : bi;
         }
@@ -512,6 +537,16 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
     s_par[tid] = parent;
   }
   __syncthreads();
+  // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
+  // arrive at the step's counter sees how many entries are done
+  if (tid == 0) {
+    const unsigned long long add = ((unsigned long long)(s_alldone ? 1 : 0) << 32) | 1ull;
+    const unsigned long long old = atomicAdd(done_cnt, add);
+    if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {
+      const unsigned done = (unsigned)(old >> 32) + (s_alldone ? 1u : 0u);
+      if (done == gridDim.x && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
+    }
+  }
   // the NEXT step's LSTM operand rows of this entry (lstm_prep.h): embedding of the new words, attention / hidden / cell
   // state of the parents -- what lstm_prep_frag_kernel would gather through the ids this workgroup has just chosen
   if (prep.x_frag) {
@@ -534,16 +569,6 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
           lstm_prep_store(prep, b * W + w, true, i - w * segs, la[u], lb[u]);
         }
       }
-    }
-  }
-  // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
-  // arrive at the step's counter sees how many entries are done
-  if (tid == 0) {
-    const unsigned long long add = ((unsigned long long)(s_alldone ? 1 : 0) << 32) | 1ull;
-    const unsigned long long old = atomicAdd(done_cnt, add);
-    if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {
-      const unsigned done = (unsigned)(old >> 32) + (s_alldone ? 1u : 0u);
-      if (done == gridDim.x && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
     }
   }
 }

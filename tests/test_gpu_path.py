@@ -753,13 +753,16 @@ def test_greedy_and_beam_match_oracle(kw):
         assert_close(res['attn_hist'], hist, F32_RTOL, 'beam alignment history')
 
 
-@pytest.mark.parametrize('B,W,V,D', [(5, 3, 9000, 128), (50, 3, 8962, 128), (32, 8, 4300, 256), (7, 5, 25599, 512)])
+@pytest.mark.parametrize('B,W,V,D', [(5, 3, 9000, 128), (50, 3, 8962, 128), (32, 8, 4300, 256), (7, 5, 25599, 512),
+                                     (20, 3, 25599, 512)])
 def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
     """Large-vocabulary beam step as the streaming projection + per-chunk top-k launch and its merge
     (csrc/beam_logits.hip) and, above 32 rows, the LSTM step as one streaming pass over the packed kernel
     (csrc/lstm_stream.hip), against the oracle and against the GEMM + statistics + top-k launches with the
     per-row-tile LSTM kernel: ids, parents and lengths bit-exact, scores at 1e-4.  Row counts on one and on two 16-row tiles per wave, a last chunk with fewer
-    live columns than the beam width (V = 8962 = 70 * 128 + 2), beam 8, and the bench vocabulary at D = 512."""
+    live columns than the beam width (V = 8962 = 70 * 128 + 2), beam 8, and the bench vocabulary at D = 512 with
+    waves that only feed the LDS ring (35 and 60 rows: a counted wait that trusted LDS-DMA and register loads to retire in
+    issue order gave about one wrong workgroup per launch exactly there)."""
     spec, cfg = _spec_and_cfg(fm_projection=None, H=1, token_type='word', V=V, D=D, init_method='project_hidden',
                               start_id=V - 2, end_id=V - 1)
     p = _rand_params(cfg, 9)

@@ -5,7 +5,7 @@ cd /root/repo/comic-compact-image-captioning-with-attention_amd/csrc
 python - <<'PY'
 s=open('beam_logits.hip').read()
 s=s.replace("namespace {\n\nconstexpr int kChunkCols","#undef STAMP\n__device__ long long g_bl_stamps[256 * 8 * 8];\n#define STAMP(i) do { if (lane == 0) g_bl_stamps[(blockIdx.x * 8 + wave) * 8 + (i)] = wall_clock64(); } while (0)\nextern \"C\" int comic_debug_bl_stamps(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bl_stamps), sizeof(long long) * 256 * 8 * 8); }\nnamespace {\n\nconstexpr int kChunkCols",1)
-s=s.replace("  if (wave == 0 && lane < 32) dma16(a.bias_pad","  STAMP(0);\n  if (wave == 0 && lane < 32) dma16(a.bias_pad")
+s=s.replace("  if (wave == 0 && lane < 32) bl_dma16(a.bias_pad","  STAMP(0);\n  if (wave == 0 && lane < 32) bl_dma16(a.bias_pad")
 s=s.replace("    __builtin_amdgcn_s_barrier();                          // ... everybody's; the other buffer is no longer read\n","    __builtin_amdgcn_s_barrier();                          // ... everybody's; the other buffer is no longer read\n    if (q < 4) STAMP(1 + q);\n")
 s=s.replace("  if constexpr (NT == 0) return;","  STAMP(5);\n  if constexpr (NT == 0) return;")
 s=s.replace("        a.cand_i[ro * a.W + k] = bi == 0x7fffffff ? -1 : bi;\n      }\n    }\n  }\n}","        a.cand_i[ro * a.W + k] = bi == 0x7fffffff ? -1 : bi;\n      }\n    }\n  }\n  STAMP(6);\n}")
