@@ -326,6 +326,105 @@ __device__ __forceinline__ BLVal wave_best(float v, int i) {
   return BLVal{mx, gi};
 }
 
+// Shared state of an entry's workgroup between the candidate phases and the tail of the step
+struct BeamEntryShared {
+  float max[8], logsum[8], lp[8], selv[8], fv[64];
+  int fin[8], sel[8], fi[64], alldone, word[8], par[8];
+  long long len[8];
+};
+
+// Tail of a beam step, common to the large- and the small-vocabulary kernels: the W best of the W x W finalists in
+// sh.fv / sh.fi (wave 0, one finalist per lane), bookkeeping, the step's completion counter (done_cnt may be null: the
+// caller keeps steps_executed by other means) and the NEXT step's LSTM operand rows (prep.x_frag may be null).  Enter
+// behind a barrier that made the finalists and sh.alldone = 1 visible.
+__device__ __forceinline__ void beam_entry_tail(BeamEntryShared& sh, int b, int W, int V, int end_id,
+                                                float* __restrict__ log_probs, int32_t* __restrict__ finished,
+                                                int64_t* __restrict__ lengths, int32_t* __restrict__ word_ids,
+                                                int32_t* __restrict__ parent_ids, float* __restrict__ scores,
+                                                unsigned long long* __restrict__ done_cnt,
+                                                int32_t* __restrict__ steps_executed, int t, int max_steps,
+                                                const LstmPrepArgs& prep) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the W best of the finalists (wave 0, one finalist per lane)
+  if (wave == 0) {
+    float fv = lane < W * W ? sh.fv[lane] : -INFINITY;
+    int fi = lane < W * W ? sh.fi[lane] : 0x7fffffff;
+    for (int r = 0; r < W; ++r) {
+      const BLVal best = wave_best(fv, fi);
+      if (best.i != 0x7fffffff && fi == best.i) fi = 0x7fffffff;
+      if (lane == 0) {
+        int sel = best.i;
+        if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
+          sel = 0;
+          bool again = true;
+          while (again) {
+            again = false;
+            for (int q = 0; q < r; ++q)
+              if (sh.sel[q] == sel) {
+                ++sel;
+                again = true;
+              }
+          }
+        }
+        sh.sel[r] = sel;
+        sh.selv[r] = best.v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < W) {
+    const int f = sh.sel[tid];
+    const int parent = f / V, word = f - parent * V;
+    const int prev_fin = sh.fin[parent];
+    const int fin = (prev_fin || word == end_id) ? 1 : 0;
+    word_ids[b * W + tid] = word;
+    parent_ids[b * W + tid] = parent;
+    scores[b * W + tid] = sh.selv[tid];
+    log_probs[b * W + tid] = sh.selv[tid];
+    finished[b * W + tid] = fin;
+    lengths[b * W + tid] = sh.len[parent] + (prev_fin ? 0 : 1);
+    if (!fin) sh.alldone = 0;
+    sh.word[tid] = word;
+    sh.par[tid] = parent;
+  }
+  __syncthreads();
+  // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
+  // arrive at the step's counter sees how many entries are done
+  if (tid == 0 && done_cnt) {
+    const unsigned long long add = ((unsigned long long)(sh.alldone ? 1 : 0) << 32) | 1ull;
+    const unsigned long long old = atomicAdd(done_cnt, add);
+    if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {
+      const unsigned done = (unsigned)(old >> 32) + (sh.alldone ? 1u : 0u);
+      if (done == gridDim.x && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
+    }
+  }
+  // the NEXT step's LSTM operand rows of this entry (lstm_prep.h): embedding of the new words, attention / hidden / cell
+  // state of the parents -- what lstm_prep_frag_kernel would gather through the ids this workgroup has just chosen
+  if (prep.x_frag) {
+    const int segs = prep.KS * 4 + prep.D / 8;
+    const int nt = blockDim.x;
+    for (int i0 = tid; i0 < W * segs; i0 += nt * 6) {
+      float4 la[6], lb[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + nt * u;
+        if (i < W * segs) {
+          const int w = i / segs;
+          lstm_prep_load(prep, b * W + sh.par[w], sh.word[w], true, i - w * segs, la[u], lb[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = i0 + nt * u;
+        if (i < W * segs) {
+          const int w = i / segs;
+          lstm_prep_store(prep, b * W + w, true, i - w * segs, la[u], lb[u]);
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                           const float* __restrict__ cand_v, const int32_t* __restrict__ cand_i,
                                                           float* __restrict__ log_probs, int32_t* __restrict__ finished,
@@ -336,10 +435,7 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
                                                           int32_t* __restrict__ steps_executed, int t, int max_steps,
                                                           LstmPrepArgs prep, const int32_t* __restrict__ stop, int stop_t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-  __shared__ int s_word[8], s_par[8];
-  __shared__ float s_max[8], s_logsum[8], s_lp[8], s_selv[8], s_fv[64];
-  __shared__ int s_fin[8], s_sel[8], s_fi[64], s_alldone;
-  __shared__ long long s_len[8];
+  __shared__ BeamEntryShared sh;
   if (comic_stopped(stop, stop_t)) return;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = chunks * W, n = W * per;
@@ -372,11 +468,11 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
     }
   }
   if (tid < W) {
-    s_lp[tid] = log_probs[b * W + tid];
-    s_fin[tid] = finished[b * W + tid];
-    s_len[tid] = lengths[b * W + tid];
+    sh.lp[tid] = log_probs[b * W + tid];
+    sh.fin[tid] = finished[b * W + tid];
+    sh.len[tid] = lengths[b * W + tid];
   }
-  if (tid == 0) s_alldone = 1;
+  if (tid == 0) sh.alldone = 1;
   // log-softmax constants of every beam from the per-chunk partials (a wave per beam; every lane walks its chunks in
   // ascending order, the wave reduction is a fixed tree: the same bits on every launch)
   for (int w = wave; w < W; w += 4) {
@@ -395,8 +491,8 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
     }
     s = wave_sum(s);
     if (lane == 0) {
-      s_max[w] = mx;
-      s_logsum[w] = logf(s);
+      sh.max[w] = mx;
+      sh.logsum[w] = logf(s);
     }
   }
   __syncthreads();
@@ -406,12 +502,12 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   const float inv_per = 1.0f / (float)per;
   auto place = [&](int j, int v_in, float x_in) {          // selects only: no branches
     const int w = (int)(((float)j + 0.5f) * inv_per), k = j - w * per;     // j / per (exact: j < 2^16, margin 0.5 / per)
-    const bool fin = s_fin[w] != 0;
+    const bool fin = sh.fin[w] != 0;
     const int vs = (k == 0) ? end_id : (k - 1 + ((k - 1 >= end_id) ? 1 : 0));     // EOS, then the (k-1)-th column that is not EOS
     const bool ok = fin ? ((k <= W) & (vs < V)) : (v_in >= 0);
-    const float step = fin ? ((vs == end_id) ? 0.f : -FLT_MAX) : ((x_in - s_max[w]) - s_logsum[w]);
+    const float step = fin ? ((vs == end_id) ? 0.f : -FLT_MAX) : ((x_in - sh.max[w]) - sh.logsum[w]);
     const int v = fin ? vs : v_in;
-    c_tot[j] = ok ? s_lp[w] + step : -INFINITY;
+    c_tot[j] = ok ? sh.lp[w] + step : -INFINITY;
     c_f[j] = ok ? w * V + v : 0x7fffffff;
   };
 #pragma unroll
@@ -466,8 +562,8 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < CL; ++u) rf[u] = rf[u] == best.i ? 0x7fffffff : rf[u];
         if (lane == 0) {
-          s_fv[w * W + r] = best.v;
-          s_fi[w * W + r] = best.i;
+          sh.fv[w * W + r] = best.v;
+          sh.fi[w * W + r] = best.i;
         }
       }
       continue;
@@ -488,89 +584,104 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
       const BLVal best = wave_best(bv, bi);
       if (best.i != 0x7fffffff && bi == best.i) c_f[bj] = 0x7fffffff;     // flat indices are unique: one lane retires it
       if (lane == 0) {
-        s_fv[w * W + r] = best.v;
-        s_fi[w * W + r] = best.i;
+        sh.fv[w * W + r] = best.v;
+        sh.fi[w * W + r] = best.i;
       }
     }
   }
   __syncthreads();
-  // the W best of the finalists (wave 0, one finalist per lane)
-  if (wave == 0) {
-    float fv = lane < W * W ? s_fv[lane] : -INFINITY;
-    int fi = lane < W * W ? s_fi[lane] : 0x7fffffff;
-    for (int r = 0; r < W; ++r) {
-      const BLVal best = wave_best(fv, fi);
-      if (best.i != 0x7fffffff && fi == best.i) fi = 0x7fffffff;
-      if (lane == 0) {
-        int sel = best.i;
-        if (sel == 0x7fffffff) {   // all-NaN corner, as in beam_step_kernel: lowest untaken flat index
-          sel = 0;
-          bool again = true;
-          while (again) {
-            again = false;
-            for (int q = 0; q < r; ++q)
-              if (s_sel[q] == sel) {
-                ++sel;
-                again = true;
-              }
-          }
-        }
-        s_sel[r] = sel;
-        s_selv[r] = best.v;
-      }
+  beam_entry_tail(sh, b, W, V, end_id, log_probs, finished, lengths, word_ids, parent_ids, scores, done_cnt, steps_executed, t,
+                  max_steps, prep);
+}
+
+// ---- small vocabularies (radix-256: V = 258): the whole step of an entry in one workgroup -------------------------------
+// Replaces beam_step_kernel (decode.hip) inside comic_decoder_beam: that kernel scans the W V candidates of an entry
+// W + 2 times from memory with a division per candidate and an 8-level block reduction per round (35.6 us at beam 7,
+// V = 258: a third of the SCST rollout step).  Here a wave keeps a beam's logits in registers (V <= 1024): log-softmax
+// constants, scores, and the beam's own top-W by W branch-free rounds + two DPP reductions each; then the common tail.
+// Same arithmetic (expf / logf, sums in the same order) and the same total order as beam_step_kernel.
+template <int CL>
+__global__ __launch_bounds__(512) void beam_step_small_kernel(const float* __restrict__ logits, float* __restrict__ log_probs,
+                                                              int32_t* __restrict__ finished, int64_t* __restrict__ lengths,
+                                                              int32_t* __restrict__ word_ids, int32_t* __restrict__ parent_ids,
+                                                              float* __restrict__ scores, int W, int V, int end_id,
+                                                              const float* __restrict__ bias, int S, int ld, long slice_stride,
+                                                              unsigned long long* __restrict__ done_cnt,
+                                                              int32_t* __restrict__ steps_executed, int t, int max_steps,
+                                                              LstmPrepArgs prep, const int32_t* __restrict__ stop, int stop_t) {
+  __shared__ BeamEntryShared sh;
+  if (comic_stopped(stop, stop_t)) return;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (eight waves: a beam each up to beam 8; CL = logits per lane: 5 serves V <= 320, 16 V <= 1024)
+  // this wave's first beam: its logits are requested before the beam state is known
+  // logits: [B W][ld] rows, or S K-slice partials of them slice_stride floats apart (comic_stream_gemm) + bias
+  float x[CL];
+  auto load_row = [&](int w) {
+    const float* row = logits + (size_t)(b * W + w) * ld;
+#pragma unroll
+    for (int u = 0; u < CL; ++u) x[u] = row[min(lane + 64 * u, V - 1)];
+    for (int sl = 1; sl < S; ++sl) {
+#pragma unroll
+      for (int u = 0; u < CL; ++u) x[u] += row[(size_t)sl * slice_stride + min(lane + 64 * u, V - 1)];
     }
-  }
-  __syncthreads();
+    if (bias) {
+#pragma unroll
+      for (int u = 0; u < CL; ++u) x[u] += bias[min(lane + 64 * u, V - 1)];
+    }
+  };
+  load_row(min(wave, W - 1));
   if (tid < W) {
-    const int f = s_sel[tid];
-    const int parent = f / V, word = f - parent * V;
-    const int prev_fin = s_fin[parent];
-    const int fin = (prev_fin || word == end_id) ? 1 : 0;
-    word_ids[b * W + tid] = word;
-    parent_ids[b * W + tid] = parent;
-    scores[b * W + tid] = s_selv[tid];
-    log_probs[b * W + tid] = s_selv[tid];
-    finished[b * W + tid] = fin;
-    lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
-    if (!fin) s_alldone = 0;
-    s_word[tid] = word;
-    s_par[tid] = parent;
+    sh.lp[tid] = log_probs[b * W + tid];
+    sh.fin[tid] = finished[b * W + tid];
+    sh.len[tid] = lengths[b * W + tid];
+  }
+  if (tid == 0) sh.alldone = 1;
+  __syncthreads();
+  for (int w = wave; w < W; w += 8) {
+    if (w != wave) load_row(w);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < CL; ++u) {
+      x[u] = lane + 64 * u < V ? x[u] : -INFINITY;
+      mx = fmaxf(mx, x[u]);
+    }
+    mx = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int u = 0; u < CL; ++u) se += lane + 64 * u < V ? expf(x[u] - mx) : 0.f;
+    const float logsum = logf(wave_sum(se));
+    const bool fin = sh.fin[w] != 0;
+    const float lp = sh.lp[w];
+    float rt[CL];
+    int rf[CL];
+#pragma unroll
+    for (int u = 0; u < CL; ++u) {
+      const int v = lane + 64 * u;
+      const float step = fin ? ((v == end_id) ? 0.f : -FLT_MAX) : ((x[u] - mx) - logsum);     // _mask_probs: dtype.min
+      rt[u] = v < V ? lp + step : -INFINITY;
+      rf[u] = v < V ? w * V + v : 0x7fffffff;
+    }
+    for (int r = 0; r < W; ++r) {
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int u = 0; u < CL; ++u) {
+        const bool g = (rf[u] != 0x7fffffff) & ((rt[u] > bv) | ((rt[u] == bv) & (rf[u] < bi)));
+        bv = g ? rt[u] : bv;
+        bi = g ? rf[u] : bi;
+      }
+      const BLVal best = wave_best(bv, bi);
+#pragma unroll
+      for (int u = 0; u < CL; ++u) rf[u] = rf[u] == best.i ? 0x7fffffff : rf[u];
+      if (lane == 0) {
+        sh.fv[w * W + r] = best.v;
+        sh.fi[w * W + r] = best.i;
+      }
+    }
   }
   __syncthreads();
-  // steps_executed = t + 1 at the first step after which every beam of every entry is finished: the last entry to
-  // arrive at the step's counter sees how many entries are done
-  if (tid == 0) {
-    const unsigned long long add = ((unsigned long long)(s_alldone ? 1 : 0) << 32) | 1ull;
-    const unsigned long long old = atomicAdd(done_cnt, add);
-    if ((unsigned)(old & 0xffffffffull) == gridDim.x - 1) {
-      const unsigned done = (unsigned)(old >> 32) + (s_alldone ? 1u : 0u);
-      if (done == gridDim.x && steps_executed[0] == max_steps) steps_executed[0] = t + 1;
-    }
-  }
-  // the NEXT step's LSTM operand rows of this entry (lstm_prep.h): embedding of the new words, attention / hidden / cell
-  // state of the parents -- what lstm_prep_frag_kernel would gather through the ids this workgroup has just chosen
-  if (prep.x_frag) {
-    const int segs = prep.KS * 4 + prep.D / 8;
-    for (int i0 = tid; i0 < W * segs; i0 += 256 * 6) {
-      float4 la[6], lb[6];
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int i = i0 + 256 * u;
-        if (i < W * segs) {
-          const int w = i / segs;
-          lstm_prep_load(prep, b * W + s_par[w], s_word[w], true, i - w * segs, la[u], lb[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        const int i = i0 + 256 * u;
-        if (i < W * segs) {
-          const int w = i / segs;
-          lstm_prep_store(prep, b * W + w, true, i - w * segs, la[u], lb[u]);
-        }
-      }
-    }
-  }
+  beam_entry_tail(sh, b, W, V, end_id, log_probs, finished, lengths, word_ids, parent_ids, scores, done_cnt, steps_executed, t,
+                  max_steps, prep);
 }
 
 }  // namespace
@@ -655,5 +766,33 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
                      (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,
                      scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_logits_step");
+  return 0;
+}
+
+// ---- small vocabularies ------------------------------------------------------------------------------------------------------
+bool comic_beam_step_small_supported(int V, int W) { return V >= 1 && V <= 1024 && W >= 1 && W <= 8 && (long)W * V < (1L << 31); }
+// zero n 8-byte completion counters (once per decode call)
+int comic_beam_counters_zero(void* cnt, int n, hipStream_t st) {
+  hipLaunchKernelGGL(beam_zero_kernel, dim3((unsigned)cdiv64(2L * n, 256)), dim3(256), 0, st, (uint32_t*)cnt, 2L * n);
+  COMIC_LAUNCH_CHECK("beam_counters_zero");
+  return 0;
+}
+// One beam step from [B * W][V] logits.  cnt: this step's completion counter (zeroed before step 0) or null (the caller keeps
+// steps_executed with its own launch); prep: gather the next step's LSTM operand rows, or null.
+// logits: [B W][ld]; S > 1: K-slice partials slice_stride floats apart (comic_stream_gemm), summed in slice order, + bias
+int comic_beam_step_small(const float* logits, const float* bias, int S, int ld, long slice_stride, float* log_probs,
+                          int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores, int B,
+                          int W, int V, int end_id, void* cnt, int32_t* steps_executed, int t, int max_steps,
+                          const LstmPrepArgs* prep, hipStream_t st) {
+  COMIC_REQUIRE(comic_beam_step_small_supported(V, W), "beam_step_small: unsupported shape (V %d, beam %d)", V, W);
+  if (V <= 320)
+    hipLaunchKernelGGL(beam_step_small_kernel<5>, dim3(B), dim3(512), 0, st, logits, log_probs, finished, lengths, word_ids,
+                       parent_ids, scores, W, V, end_id, bias, S, ld, slice_stride, (unsigned long long*)cnt, steps_executed, t,
+                       max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
+  else
+    hipLaunchKernelGGL(beam_step_small_kernel<16>, dim3(B), dim3(512), 0, st, logits, log_probs, finished, lengths, word_ids,
+                       parent_ids, scores, W, V, end_id, bias, S, ld, slice_stride, (unsigned long long*)cnt, steps_executed, t,
+                       max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
+  COMIC_LAUNCH_CHECK("beam_step_small");
   return 0;
 }

@@ -83,6 +83,12 @@ int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R);
 int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st);
 int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
                       hipStream_t st);
+bool comic_beam_step_small_supported(int V, int W);
+int comic_beam_counters_zero(void* cnt, int n, hipStream_t st);
+int comic_beam_step_small(const float* logits, const float* bias, int S, int ld, long slice_stride, float* log_probs,
+                          int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores, int B,
+                          int W, int V, int end_id, void* cnt, int32_t* steps_executed, int t, int max_steps,
+                          const LstmPrepArgs* prep, hipStream_t st);
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
                        hipStream_t st);
@@ -1094,6 +1100,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   return 0;
 }
 
+constexpr int kBeamCntSteps = 4096;       // decode steps the in-kernel completion counters of the beam step cover
+
 extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int max_steps) {
   if (!d) return -1;
   Bump w(nullptr, 0);
@@ -1115,6 +1123,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>((D + 1) * ((V + 127) / 128 * 128));                // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
   w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));  // streaming LSTM step
   w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));     // ... W_q, y fragments
+  w.take<unsigned long long>(kBeamCntSteps);                       // beam search: per-step completion counters
   if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
     const long S = std::max(1, max_steps);
     w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
@@ -1129,6 +1138,7 @@ struct InferBufs {
   InitBufs ib;
   StepBufs sb;
   float *c[2], *h[2], *att[2], *x, *logits, *log_probs, *gtmp, *kpanel, *wo_pad, *kfrag, *xfrag, *wqfrag, *yfrag;
+  unsigned long long* beam_cnt = nullptr;
   int32_t *ids, *parents;
   float *p_xh = nullptr, *p_y = nullptr, *p_q = nullptr, *p_argp = nullptr;   // persistent greedy loop (rows <= 64)
   unsigned* p_sync = nullptr;
@@ -1156,6 +1166,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.wo_pad = w.take<float>((D + 1) * ((V + 127) / 128 * 128));
   b.kfrag = w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); b.xfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));
   b.wqfrag = w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); b.yfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));
+  b.beam_cnt = w.take<unsigned long long>(kBeamCntSteps);
   if (rows <= 64 && max_steps > 0) {
     const long S = max_steps;
     b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);
@@ -1340,14 +1351,25 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
                              comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128) * 4 &&
                              comic_beam_logits_partial_floats(D, V, R, W, max_steps) <= (int64_t)R * V;
+  // small vocabularies (radix-256): the entry's beam step with a beam's logits in a wave's registers; with the step's y at
+  // hand as fragments (streaming LSTM step) the projection goes through the streaming kernel too
+  const bool small_step = fused && !stream_logits && beam_logits_enabled() && comic_beam_step_small_supported(V, W) &&
+                          max_steps <= kBeamCntSteps;
+  const bool stream_wo = small_step && stream_lstm && comic_stream_gemm_supported(D, V, R) &&
+                         comic_stream_gemm_part_bytes(D, V, R) <= kSplitKBytes &&
+                         comic_stream_gemm_wfrag_floats(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128);
   int ld_wo = V;
   const float* w_o = nullptr;
   if (stream_logits) {
     RC(comic_beam_pack_wo(p->W_o, p->b_o, V, ws.wo_pad, D, V, st));
     RC(comic_beam_logits_begin(ws.logits, B, W, V, max_steps, st));
+  } else if (stream_wo) {
+    RC(comic_stream_gemm_pack(p->W_o, ws.wo_pad, D, V, st));
+  } else {
+    w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
   }
-  else w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
-  g_beam_path = (stream_logits ? 1 : 0) | (stream_lstm ? 2 : 0);
+  if (small_step) RC(comic_beam_counters_zero(ws.beam_cnt, max_steps, st));
+  g_beam_path = (stream_logits ? 1 : 0) | (stream_lstm ? 2 : 0) | (small_step ? 4 : 0);
   int cur = 0;
   struct StopScope {          // whatever way this call returns, no later launch sees the flag
     ~StopScope() { g_comic_stop = ComicStop(); }
@@ -1373,7 +1395,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       else sb.att2 = ws.att[nxt];
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
-      sm.skip_prep = (stream_lstm && stream_logits && t > 0) ? 1 : 0;
+      sm.skip_prep = (stream_lstm && (stream_logits || small_step) && t > 0) ? 1 : 0;
       const StreamBufs* smp = stream_lstm ? &sm : nullptr;
       RC(infer_step_lstm(d, p, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur], sb, ws.gtmp, R, st, smp));
       // (the two chains that hang off y -- query projection + attention, vocabulary projection + top-k -- measured
@@ -1388,6 +1410,24 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
         RC(comic_beam_logits_step(sb.y, stream_lstm ? ws.yfrag : nullptr, ws.wo_pad, ws.logits, ws.log_probs, finished, lengths, word, parent,
                                   scores + (size_t)t * R, steps_executed, t, max_steps, B, W, D, V, d->end_id,
                                   stream_lstm ? &prep : nullptr, st));
+      } else if (small_step) {
+        // small vocabulary: the entry's whole step in one workgroup, which also keeps steps_executed and (with the
+        // streaming LSTM step) gathers the next step's operand rows
+        const float* att_new = d->context_layer ? sb.att2 : sb.ctx;
+        LstmPrepArgs prep{p->emb, att_new, sb.h2, sb.c2, (uint4*)ws.xfrag, ws.gtmp, E, A, D, V, (E + A + D + 31) / 32};
+        if (stream_wo) {     // vocabulary projection through the streaming kernel: K-slice partials, summed by the step kernel
+          int S = 1;
+          const int ldp = (V + 63) / 64 * 64;
+          RC(comic_stream_gemm(ws.yfrag, ws.wo_pad, (float*)g_splitk_ws, kSplitKBytes, R, D, V, &S, st));
+          RC(comic_beam_step_small((const float*)g_splitk_ws, p->b_o, S, ldp, (long)R * ldp, ws.log_probs, finished, lengths,
+                                   word, parent, scores + (size_t)t * R, B, W, V, d->end_id, ws.beam_cnt + t, steps_executed,
+                                   t, max_steps, &prep, st));
+        } else {
+          RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
+          RC(comic_beam_step_small(ws.logits, nullptr, 1, V, 0, ws.log_probs, finished, lengths, word, parent,
+                                   scores + (size_t)t * R, B, W, V, d->end_id, ws.beam_cnt + t, steps_executed, t, max_steps,
+                                   stream_lstm ? &prep : nullptr, st));
+        }
       } else {
         RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
         RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
@@ -1412,7 +1452,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
       RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));
     }
-    if (!stream_logits) {       // (the streaming step's merge launch keeps steps_executed itself)
+    if (!stream_logits && !small_step) {       // (the streaming step's merge / the small step keep steps_executed themselves)
       hipLaunchKernelGGL(all_finished_kernel, dim3(1), dim3(256), 0, st, finished, steps_executed, t, R, max_steps);
       COMIC_LAUNCH_CHECK("all_finished");
     }

@@ -35,7 +35,7 @@ __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(
 // (LSTM kernel, N = 4D: tile g = gate g of 16 units, gstride D, cstride 16; plain matrix: four adjacent 16-column tiles,
 // gstride 16, cstride 64)
 __global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restrict__ K, uint4* __restrict__ out, int N, int Wd,
-                                                          int KS, int gstride, int cstride, long units) {
+                                                          int KS, int gstride, int cstride, long units) {   // N: row stride AND column count of K (columns >= N pack as zeros)
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
   const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1), g = (int)((u >> 7) & 3);
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void lstm_pack_k_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int k = k0 + 2 * j + e;
-      x[e] = k < Wd ? K[(size_t)k * N + col] : 0.f;
+      x[e] = (k < Wd && col < N) ? K[(size_t)k * N + col] : 0.f;
     }
     const uint32_t h = pack_bf16x2(x[0], x[1]);
     w[j] = hl == 0 ? h : pack_bf16x2(x[0] - __uint_as_float(h << 16), x[1] - __uint_as_float(h & 0xFFFF0000u));
@@ -279,16 +279,18 @@ int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStrea
 // ---- plain skinny product out[R][N] = x[R][Kin] W[Kin][N] through the same streaming kernel (query projection) -----------
 // x arrives as fragments (lstm_cell_kernel's y_frag), the result leaves as S K-slice partials [S][R][N] that the consumer
 // sums in slice order (comic_attn_fwd_ex takes them as they are).
-bool comic_stream_gemm_supported(int Kin, int N, int R) { return N % 64 == 0 && Kin % 8 == 0 && R > 32 && R <= 256; }
-int64_t comic_stream_gemm_wfrag_floats(int Kin, int N) { return (int64_t)N * lstm_ks(Kin) * 32; }
+// (N need not be a multiple of 64: the packed matrix and the partial rows are padded to Np = ceil64(N) columns of zeros)
+bool comic_stream_gemm_supported(int Kin, int N, int R) { return N >= 1 && Kin % 8 == 0 && R > 32 && R <= 256; }
+static inline int np64(int N) { return (N + 63) / 64 * 64; }
+int64_t comic_stream_gemm_wfrag_floats(int Kin, int N) { return (int64_t)np64(N) * lstm_ks(Kin) * 32; }
 int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R) {
   int n, S;
-  lstm_slices(N, Kin, &n, &S);
-  return (int64_t)S * R * N * 4;
+  lstm_slices(np64(N), Kin, &n, &S);
+  return (int64_t)S * R * np64(N) * 4;
 }
 int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st) {
   const int KS = lstm_ks(Kin);
-  const long units = (long)(N / 64) * KS * 512;
+  const long units = (long)(np64(N) / 64) * KS * 512;
   hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, Wm, (uint4*)w_frag, N, Kin, KS,
                      16, 64, units);
   COMIC_LAUNCH_CHECK("stream_gemm_pack");
@@ -298,7 +300,7 @@ int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64
                       hipStream_t st) {
   COMIC_REQUIRE(comic_stream_gemm_supported(Kin, N, R), "stream_gemm: unsupported shape (K %d, N %d, rows %d)", Kin, N, R);
   COMIC_REQUIRE(part_bytes >= comic_stream_gemm_part_bytes(Kin, N, R), "stream_gemm: partial buffer too small");
-  RC(stream_launch(w_frag, x_frag, part, R, N, Kin, 16, 64, S, st));
+  RC(stream_launch(w_frag, x_frag, part, R, np64(N), Kin, 16, 64, S, st));     // partial rows of np64(N) floats
   COMIC_LAUNCH_CHECK("stream_gemm");
   return 0;
 }

@@ -377,7 +377,8 @@ typedef struct comic_decoder_desc {
 #define COMIC_DEC_EXACT_GEMM 32u        /* exact-fp32 MFMA for the time-batched products (no hi/lo-split bf16) */
 #define COMIC_DEC_STAMPS 64u            /* diagnostic phase clocks of the persistent loops (host sync per launch) */
 #define COMIC_DEC_NO_LSTM_STREAM 256u   /* decode steps at > 32 rows with the per-row-tile fused LSTM kernel instead of the streaming one */
-#define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge instead of the streaming logits/top-k launch */
+#define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge (large V) / comic_beam_step's kernel (small V)
+                                           instead of the streaming logits + top-k launch / the register-resident small step */
 
 /* Parameter (or gradient) table; every pointer is a view into one flat fp32 buffer. */
 typedef struct comic_decoder_params {
@@ -426,7 +427,9 @@ int comic_decoder_greedy_path(void);
 /* Paths of the LAST comic_decoder_beam of this thread, a bit mask: 1 = projection + top-k as the streaming launch over
  * a packed W_o (csrc/beam_logits.hip: D % 128 == 0, V >= 4096, batch * beam <= 256, beam <= 8, fused step available)
  * instead of the GEMM + statistics + top-k launches; 2 = the LSTM step as one streaming pass over the packed kernel
- * (csrc/lstm_stream.hip: 33 ... 256 rows) instead of the per-row-tile fused kernel. */
+ * (csrc/lstm_stream.hip: 33 ... 256 rows) instead of the per-row-tile fused kernel; 4 = small vocabulary (V <= 1024, beam
+ * <= 8): the entry's beam step with a beam's logits held in a wave's registers (beam_step_small_kernel) instead of
+ * comic_beam_step's kernel + the all-finished launch. */
 int comic_decoder_beam_path(void);
 
 /* Greedy decode (rnn_decoder_search, ops_rnn.py:115-180): runs `max_steps` steps on the

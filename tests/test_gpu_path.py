@@ -798,6 +798,35 @@ def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
             assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'beam scores')
 
 
+@pytest.mark.parametrize('B,W,kw', [(32, 7, dict(D=512, E=256, C=2048, Cg=2048)), (5, 8, dict()), (9, 4, dict(V=1000, H=4))])
+def test_beam_small_vocabulary_step_matches_launch_chain(B, W, kw, monkeypatch):
+    """Small-vocabulary beam step with a beam's logits in a wave's registers (beam_step_small_kernel: radix-256, the SCST
+    rollout geometry 32 x 7 at COMIC-256 size; beam 8; V = 1000) against comic_beam_step's kernel + the all-finished
+    launch: ids, parents, lengths bit-exact, scores at 1e-5; early exit at the same step; eager, captured, replayed.
+    (The oracle comparison of this path is test_greedy_and_beam_match_oracle.)"""
+    spec, cfg = _spec_and_cfg(**kw)
+    p = _rand_params(cfg, 11)
+    fm, im, _ = _batch(spec, B, 6, 29)
+    max_steps = 12
+    for eos_bias in (1.5, 9.0):
+        pe = dict(p); pe['b_o'] = p['b_o'].copy(); pe['b_o'][spec.end_id] = eos_bias
+        dec = cdec.Decoder(spec, pe, DEV)
+        for _ in range(3):
+            res = dec.beam_search(dev(fm), dev(im), W, max_steps)
+        dec.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
+        assert dec.lib.comic_decoder_beam_path() & 4
+        monkeypatch.setenv('COMIC_BEAM_LOGITS', '0')
+        dec0 = cdec.Decoder(spec, pe, DEV)
+        res0 = dec0.beam_search(dev(fm), dev(im), W, max_steps, use_graph=False)
+        assert not dec0.lib.comic_decoder_beam_path() & 4
+        monkeypatch.delenv('COMIC_BEAM_LOGITS')
+        for k in ('step_ids', 'parent_ids', 'predicted_ids', 'lengths'):
+            np.testing.assert_array_equal(res[k], res0[k], err_msg=k)
+        fin = np.isfinite(res0['scores'])
+        assert_close(np.where(fin, res['scores'], 0), np.where(fin, res0['scores'], 0), 1e-5, 'beam scores vs comic_beam_step')
+        assert_close(res['attn_hist'], res0['attn_hist'], 1e-5, 'alignment history')
+
+
 @pytest.mark.parametrize('kw,B', [(dict(D=512, E=256), 5), (dict(D=512, E=128, method='dot', H=4, M=7), 37),
                                   (dict(D=512, E=64, fm_projection='independent', prob='sigmoid', H=16), 64)])
 def test_persistent_greedy_loop_matches_oracle(kw, B, monkeypatch):

@@ -6,8 +6,11 @@ import numpy as np, torch
 from comic_amd import decoder as cdec
 dev = 'cuda:0'
 B, V, W = int(os.environ.get('B', '50')), 25599, int(os.environ.get('W', '3'))
-spec = cdec.DecoderSpec(V=V, H=1, fm_projection=None, token_type='word', start_id=V - 2, end_id=V - 1)
+spec = (cdec.DecoderSpec() if os.environ.get('SPEC') == 'radix' else
+        cdec.DecoderSpec(V=V, H=1, fm_projection=None, token_type='word', start_id=V - 2, end_id=V - 1))   # SPEC=radix: COMIC-256 (SCST rollouts: B=32 W=7)
 dec = cdec.Decoder(spec, None, dev, seed=3)
+if os.environ.get('SPEC') == 'radix':
+    dec.params.view('b_o')[spec.end_id] = -9.0      # rollouts run all steps
 fm = torch.randn(B, spec.M, spec.C, device=dev)
 im = torch.randn(B, spec.Cg, device=dev)
 graph = os.environ.get('GRAPH', '1') == '1'
