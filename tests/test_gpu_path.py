@@ -798,6 +798,32 @@ def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
             assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'beam scores')
 
 
+@pytest.mark.parametrize('B,W,V', [(20, 3, 25599), (7, 5, 25599), (50, 3, 25599), (32, 7, 258)])
+def test_beam_streaming_step_race_screen(B, W, V, monkeypatch):
+    """Race screen of the hand-synchronised streaming kernels (LDS-DMA rings with counted / drained waits, cross-workgroup
+    completion counters): 40 decodes of one input, eager and replayed, must all equal the round-2 launch chain's result.
+    A wait that is one request short shows as a rare wrong workgroup (about 1 of 200 per launch when it existed), which
+    a single comparison passes most of the time."""
+    if V == 258:
+        spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    else:
+        spec, cfg = _spec_and_cfg(fm_projection=None, H=1, token_type='word', V=V, D=512, init_method='project_hidden',
+                                  start_id=V - 2, end_id=V - 1)
+    p = _rand_params(cfg, 9)
+    p['b_o'][spec.end_id] = 1.5
+    fm, im, _ = _batch(spec, B, 6, 23)
+    monkeypatch.setenv('COMIC_BEAM_LOGITS', '0')
+    monkeypatch.setenv('COMIC_LSTM_STREAM', '0')
+    ref = cdec.Decoder(spec, p, DEV).beam_search(dev(fm), dev(im), W, 8, use_graph=False, want_attention=False)
+    monkeypatch.delenv('COMIC_BEAM_LOGITS')
+    monkeypatch.delenv('COMIC_LSTM_STREAM')
+    dec = cdec.Decoder(spec, p, DEV)
+    for i in range(40):
+        res = dec.beam_search(dev(fm), dev(im), W, 8, use_graph=(i % 4 != 0), want_attention=False)
+        for k in ('step_ids', 'parent_ids', 'lengths'):
+            np.testing.assert_array_equal(res[k], ref[k], err_msg='%s, call %d' % (k, i))
+
+
 @pytest.mark.parametrize('B,W,kw', [(32, 7, dict(D=512, E=256, C=2048, Cg=2048)), (5, 8, dict()), (9, 4, dict(V=1000, H=4))])
 def test_beam_small_vocabulary_step_matches_launch_chain(B, W, kw, monkeypatch):
     """Small-vocabulary beam step with a beam's logits in a wave's registers (beam_step_small_kernel: radix-256, the SCST
