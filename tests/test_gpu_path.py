@@ -709,7 +709,10 @@ def test_known_answer_param_count_on_device():
                                 dict(fm_projection=None, H=1, token_type='word', V=9000,
                                      init_method='project_hidden', start_id=8998, end_id=8999),
                                 # Inception-V1 Mixed_4f (M = 196): the attention step in its split form
-                                dict(C=832, Cg=1024, M=196)])
+                                dict(C=832, Cg=1024, M=196),
+                                # context layer (attention state = W_a ctx), independent value projection, sigmoid
+                                dict(fm_projection='independent', context_layer=True, prob='sigmoid', H=4),
+                                dict(fm_projection=None, context_layer=True, method='dot', H=4)])
 def test_greedy_and_beam_match_oracle(kw):
     spec, cfg = _spec_and_cfg(**kw)
     p = _rand_params(cfg, 5)
