@@ -488,8 +488,9 @@ class CaptionModel_SCST(ModelBase):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
         infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
         c = self._config
-        greedy, _ = self._decode(imgs, 1, 20, want_attention=False)
-        beam, _ = self._decode(imgs, c.scst_beam_size, 20, top_beam=False, want_attention=False)
+        im_embed, fm = self._encode(imgs)          # ONE encoder forward serves both rollouts
+        greedy, _ = self._decode_features(im_embed, fm, 1, 20, want_attention=False)
+        beam, _ = self._decode_features(im_embed, fm, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
 
     def run_train_scst(self, imgs, captions, rewards, tile=1):
