@@ -83,6 +83,8 @@ int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R);
 int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st);
 int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
                       hipStream_t st);
+int comic_stream_gemm2(const void* x_frag, const void* w_a, float* part_a, int N_a, int* S_a, const void* w_b, float* part_b,
+                       int N_b, int* S_b, int64_t part_bytes_each, int R, int Kin, hipStream_t st);
 bool comic_beam_step_small_supported(int V, int W);
 int comic_beam_counters_zero(void* cnt, int n, hipStream_t st);
 int comic_beam_step_small(const float* logits, const float* bias, int S, int ld, long slice_stride, float* log_probs,
@@ -631,6 +633,11 @@ struct StreamBufs {
   void* yfrag;
   const void* wqfrag;
   int skip_prep = 0;       // the operand rows of this step were prepared by the previous step's beam merge
+  // a second product over the same y, launched with the query projection (vocabulary projection at a small V):
+  const void* wofrag = nullptr;   // packed W_o, or null
+  int wo_N = 0;
+  float* wo_part = nullptr;       // out: its K-slice partials (second half of the split-K scratch)
+  int wo_S = 0;                   // out: their count
 };
 // first half: operand prep + LSTM product + cell -> c2, h2, y (and y as fragments on the streaming path)
 int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, const float* kpanel, const int32_t* ids,
@@ -654,11 +661,15 @@ int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, 
 // attention state); reads y, writes nothing the vocabulary projection of the step looks at
 int infer_step_attend(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
                       const float* keys, const float* values, StepBufs& sb, float* alpha_d_out, int rows, hipStream_t st,
-                      const StreamBufs* sm, int mem_div) {
+                      StreamBufs* sm, int mem_div) {
   const int D = d->D;
   int S = 1;
   float* part = (float*)g_splitk_ws;
-  if (sm && sm->wqfrag) RC(comic_stream_gemm(sm->yfrag, sm->wqfrag, part, kSplitKBytes, rows, D, D, &S, st));
+  if (sm && sm->wqfrag && sm->wofrag) {
+    sm->wo_part = (float*)((char*)g_splitk_ws + kSplitKBytes / 2);
+    RC(comic_stream_gemm2(sm->yfrag, sm->wqfrag, part, D, &S, sm->wofrag, sm->wo_part, sm->wo_N, &sm->wo_S, kSplitKBytes / 2,
+                          rows, D, st));
+  } else if (sm && sm->wqfrag) RC(comic_stream_gemm(sm->yfrag, sm->wqfrag, part, kSplitKBytes, rows, D, D, &S, st));
   else RC(comic_gemm_f32_partial(sb.y, p->W_q, rows, D, D, D, D, 0, part, kSplitKBytes, &S, st));
   // large memories (Inception-V1 Mixed_4f: M = 196): the attention step in its split form; its [rows][H][M] scratch is the
   // pre-activation gate buffer, which the fused LSTM step never materialises
@@ -674,7 +685,7 @@ int infer_step_fused(const comic_decoder_desc* d, const comic_decoder_params* p,
                      const float* keys, const float* values, const float* kpanel, const int32_t* ids,
                      const int32_t* parent, int W, const float* c_src, const float* h_src, const float* att_src,
                      StepBufs& sb, float* c_in, float* alpha_d_out, int rows, hipStream_t st,
-                     const StreamBufs* sm = nullptr, int mem_div = 1) {
+                     StreamBufs* sm = nullptr, int mem_div = 1) {
   RC(infer_step_lstm(d, p, kpanel, ids, parent, W, c_src, h_src, att_src, sb, c_in, rows, st, sm));
   return infer_step_attend(d, p, ad, keys, values, sb, alpha_d_out, rows, st, sm, mem_div);
 }
@@ -1365,6 +1376,12 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
     RC(comic_beam_logits_begin(ws.logits, B, W, V, max_steps, st));
   } else if (stream_wo) {
     RC(comic_stream_gemm_pack(p->W_o, ws.wo_pad, D, V, st));
+    // (not with the context layer: its product after the attention may use the whole split-K scratch)
+    if (sm.wqfrag && !d->context_layer && comic_stream_gemm_part_bytes(D, D, R) <= kSplitKBytes / 2 &&
+        comic_stream_gemm_part_bytes(D, V, R) <= kSplitKBytes / 2) {
+      sm.wofrag = ws.wo_pad;       // one launch for the query and the vocabulary projection
+      sm.wo_N = V;
+    }
   } else {
     w_o = aligned_w_o(d, p, ws.wo_pad, &ld_wo, st);
   }
@@ -1396,7 +1413,8 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       const int32_t* ids_in = t == 0 ? ws.ids : step_ids + (size_t)(t - 1) * R;
       const int32_t* par_in = t == 0 ? nullptr : parent_ids + (size_t)(t - 1) * R;
       sm.skip_prep = (stream_lstm && (stream_logits || small_step) && t > 0) ? 1 : 0;
-      const StreamBufs* smp = stream_lstm ? &sm : nullptr;
+      sm.wo_part = nullptr;
+      StreamBufs* smp = stream_lstm ? &sm : nullptr;
       RC(infer_step_lstm(d, p, ws.kpanel, ids_in, par_in, W, ws.c[cur], ws.h[cur], ws.att[cur], sb, ws.gtmp, R, st, smp));
       // (the two chains that hang off y -- query projection + attention, vocabulary projection + top-k -- measured
       // slower on two lanes than back to back: 98.5 vs 94.8 us per step, the fork / join of a 20 us branch costs more
@@ -1416,10 +1434,14 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
         const float* att_new = d->context_layer ? sb.att2 : sb.ctx;
         LstmPrepArgs prep{p->emb, att_new, sb.h2, sb.c2, (uint4*)ws.xfrag, ws.gtmp, E, A, D, V, (E + A + D + 31) / 32};
         if (stream_wo) {     // vocabulary projection through the streaming kernel: K-slice partials, summed by the step kernel
-          int S = 1;
+          int S = sm.wo_S;
           const int ldp = (V + 63) / 64 * 64;
-          RC(comic_stream_gemm(ws.yfrag, ws.wo_pad, (float*)g_splitk_ws, kSplitKBytes, R, D, V, &S, st));
-          RC(comic_beam_step_small((const float*)g_splitk_ws, p->b_o, S, ldp, (long)R * ldp, ws.log_probs, finished, lengths,
+          const float* lp_part = sm.wo_part;               // launched together with the query projection ...
+          if (!lp_part) {                                  // ... or on its own
+            RC(comic_stream_gemm(ws.yfrag, ws.wo_pad, (float*)g_splitk_ws, kSplitKBytes, R, D, V, &S, st));
+            lp_part = (const float*)g_splitk_ws;
+          }
+          RC(comic_beam_step_small(lp_part, p->b_o, S, ldp, (long)R * ldp, ws.log_probs, finished, lengths,
                                    word, parent, scores + (size_t)t * R, B, W, V, d->end_id, ws.beam_cnt + t, steps_executed,
                                    t, max_steps, &prep, st));
         } else {

@@ -85,9 +85,10 @@ struct LstmStreamArgs {
 };
 
 template <int NT>
-__device__ __forceinline__ void lstm_stream_wave(const LstmStreamArgs& a, unsigned char* smem, int wave, int lane, int tid) {
+__device__ __forceinline__ void lstm_stream_wave(const LstmStreamArgs& a, unsigned char* smem, int wave, int lane, int tid,
+                                                 int bid) {
   const int fr = lane & 15, fg = lane >> 4;
-  const int c = blockIdx.x, sl = blockIdx.y, KS = a.KS;
+  const int chunks = a.N / 64, c = bid % chunks, sl = bid / chunks, KS = a.KS;
   const int s0 = sl * a.ksteps, n = min(a.ksteps, KS - s0);
   const unsigned char* wsrc = (const unsigned char*)(a.k_frag + ((size_t)c * KS + s0) * 512);
   for (int i = 0; i < n; ++i) dma16(wsrc + (size_t)i * kStepBytes + tid * 16, smem + i * kStepBytes + wave * 1024);
@@ -157,16 +158,21 @@ __device__ __forceinline__ void lstm_stream_wave(const LstmStreamArgs& a, unsign
   }
 }
 
-__global__ __launch_bounds__(512) void lstm_stream_kernel(LstmStreamArgs a) {
+// One launch serves one product or two that read the same operand rows (query projection + vocabulary projection of a
+// decode step): workgroups [0, n_a) belong to a, the rest to b; within a product, workgroup id = slice * chunks + chunk.
+__global__ __launch_bounds__(512) void lstm_stream_kernel(LstmStreamArgs a, LstmStreamArgs b, int n_a) {
   if (comic_stopped(a.stop, a.stop_t)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles = (a.R + 15) >> 4;
+  const bool second = (int)blockIdx.x >= n_a;
+  const LstmStreamArgs& p = second ? b : a;
+  const int bid = second ? blockIdx.x - n_a : blockIdx.x;
+  const int tiles = (p.R + 15) >> 4;
   const int nt = (wave < tiles ? 1 : 0) + (wave + 8 < tiles ? 1 : 0);
-  if (nt == 2) lstm_stream_wave<2>(a, smem, wave, lane, tid);
-  else if (nt == 1) lstm_stream_wave<1>(a, smem, wave, lane, tid);
-  else lstm_stream_wave<0>(a, smem, wave, lane, tid);
+  if (nt == 2) lstm_stream_wave<2>(p, smem, wave, lane, tid, bid);
+  else if (nt == 1) lstm_stream_wave<1>(p, smem, wave, lane, tid, bid);
+  else lstm_stream_wave<0>(p, smem, wave, lane, tid, bid);
 }
 
 // gates = sum of the K-slices (slice order) + bias; i, j, f, o -> c2 = c sigma(f + 1) + sigma(i) tanh(j), h2 = tanh(c2) sigma(o)
@@ -245,14 +251,18 @@ int64_t comic_lstm_stream_part_bytes(int D, int Wd, int R) {
   return (int64_t)S * R * 4 * D * 4;
 }
 
-static int stream_launch(const void* k_frag, const void* x_frag, float* part, int R, int N, int Kin, int gstride, int cstride,
-                         int* S_out, hipStream_t st) {
+static LstmStreamArgs stream_args(const void* k_frag, const void* x_frag, float* part, int R, int N, int Kin, int gstride,
+                                  int cstride, int* S_out) {
   int ksteps, S;
   lstm_slices(N, Kin, &ksteps, &S);
   LstmStreamArgs a;
   a.k_frag = (const uint4*)k_frag; a.x_frag = (const uint4*)x_frag; a.part = part;
   a.R = R; a.N = N; a.KS = lstm_ks(Kin); a.ksteps = ksteps; a.gstride = gstride; a.cstride = cstride;
   a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
+  *S_out = S;
+  return a;
+}
+static int stream_launch2(const LstmStreamArgs& a, int Sa, const LstmStreamArgs* b, int Sb, hipStream_t st) {
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();
   if (!attr_set) {
@@ -262,9 +272,15 @@ static int stream_launch(const void* k_frag, const void* x_frag, float* part, in
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(lstm_stream_kernel, dim3(N / 64, S), dim3(512), (size_t)ksteps * kStepBytes, st, a);
-  *S_out = S;
+  const int n_a = (a.N / 64) * Sa, n_b = b ? (b->N / 64) * Sb : 0;
+  const int ksteps = std::max(a.ksteps, b ? b->ksteps : 0);
+  hipLaunchKernelGGL(lstm_stream_kernel, dim3(n_a + n_b), dim3(512), (size_t)ksteps * kStepBytes, st, a, b ? *b : a, n_a);
   return 0;
+}
+static int stream_launch(const void* k_frag, const void* x_frag, float* part, int R, int N, int Kin, int gstride, int cstride,
+                         int* S_out, hipStream_t st) {
+  const LstmStreamArgs a = stream_args(k_frag, x_frag, part, R, N, Kin, gstride, cstride, S_out);
+  return stream_launch2(a, *S_out, nullptr, 0, st);
 }
 
 int comic_lstm_stream_pack(const float* K, void* k_frag, int D, int Wd, hipStream_t st) {
@@ -294,6 +310,18 @@ int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStr
   hipLaunchKernelGGL(lstm_pack_k_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, Wm, (uint4*)w_frag, N, Kin, KS,
                      16, 64, units);
   COMIC_LAUNCH_CHECK("stream_gemm_pack");
+  return 0;
+}
+// Two products over the same operand rows in one launch (outputs apart: part_a, part_b)
+int comic_stream_gemm2(const void* x_frag, const void* w_a, float* part_a, int N_a, int* S_a, const void* w_b, float* part_b,
+                       int N_b, int* S_b, int64_t part_bytes_each, int R, int Kin, hipStream_t st) {
+  COMIC_REQUIRE(comic_stream_gemm_supported(Kin, N_a, R) && comic_stream_gemm_supported(Kin, N_b, R), "stream_gemm2: unsupported shape");
+  COMIC_REQUIRE(part_bytes_each >= comic_stream_gemm_part_bytes(Kin, N_a, R) && part_bytes_each >= comic_stream_gemm_part_bytes(Kin, N_b, R),
+                "stream_gemm2: partial buffer too small");
+  const LstmStreamArgs a = stream_args(w_a, x_frag, part_a, R, np64(N_a), Kin, 16, 64, S_a);
+  const LstmStreamArgs b = stream_args(w_b, x_frag, part_b, R, np64(N_b), Kin, 16, 64, S_b);
+  RC(stream_launch2(a, *S_a, &b, *S_b, st));
+  COMIC_LAUNCH_CHECK("stream_gemm2");
   return 0;
 }
 int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
