@@ -411,9 +411,10 @@ class CaptionModel(ModelBase):
 
     def infer(self, batch=None):
         """== sess.run(m_infer.infer_output) -> [dec_preds (B,T), attention_maps (B,H,T,M)].
-        Batches drawn from the input pipeline are decoded with the encoder forward of the NEXT batch already running on
-        a second stream (the decode steps are small launches that leave most of the GPU idle; config.pipeline_encoder,
-        default on): the same kernels on the same rows, so the captions equal the serial order's."""
+        Batches drawn from the input pipeline are decoded with the encoder forward of the NEXT group of batches already
+        running on a second stream (the decode steps are small launches that leave most of the GPU idle;
+        config.pipeline_encoder, default on; config.pipeline_encoder_group batches per forward, 0 = auto).  Same
+        arithmetic per image; a forward over more images may pick other conv tiles, i.e. another fp32 summation order."""
         c = self._config
         if batch is not None or not (getattr(c, 'pipeline_encoder', True) and str(self.device).startswith('cuda')
                                      and os.environ.get('COMIC_PIPELINE_INFER', '1') == '1'):
@@ -430,32 +431,59 @@ class CaptionModel(ModelBase):
                 return None
             im = b[0] if isinstance(b, (tuple, list)) else b
             return im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im, np.float32)).to(self.device)
-        if getattr(self, '_infer_tail', None) is not None:           # a batch of another size: served serially
-            images, self._infer_tail = self._infer_tail, None
+
+        def next_group(G, B):
+            """up to G batches of B images in input order; stops at the end of the input or behind a ragged batch"""
+            out = []
+            while len(out) < G:
+                im = next_images()
+                if im is None:
+                    break
+                out.append(im)
+                if int(im.shape[0]) != B:
+                    break
+            return out
+
+        def serial(images):
             ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
             self.infer_output = [ids, attn]
             return self.infer_output
-        if getattr(self, '_ipipe', None) is None:
-            from .trainer import EncoderPipeline
-            first = next_images()
-            self._ipipe = EncoderPipeline(self._encoder_for(int(first.shape[0])), int(first.shape[0]), 1, self.device)
-            self._ipipe.submit(first)
-        if self._ipipe.steps_ready == 0:                              # nothing in flight (the previous call hit a ragged batch)
-            nxt = next_images()
-            if nxt is None:
+
+        # ONE encoder forward covers the next G batches (config.pipeline_encoder_group, 0 = auto: about 200 images -- the
+        # forward at 200 images runs at 1.6x the MFMA rate of 50); batches that do not fill a group (the end of the input,
+        # a ragged last batch) are decoded serially, in input order
+        tail = self.__dict__.setdefault('_infer_tail', [])
+        pipe = getattr(self, '_ipipe', None)
+        if pipe is None or pipe.steps_ready == 0:
+            if tail:
+                return serial(tail.pop(0))
+            first = next_images() if pipe is None else None
+            if pipe is None:
+                if first is None:
+                    raise StopIteration('infer(): the input pipeline is exhausted')
+                B = int(first.shape[0])
+                G = int(getattr(c, 'pipeline_encoder_group', 0)) or max(1, min(8, 200 // max(1, B)))
+                grp = [first] + next_group(G - 1, B)
+            else:
+                B, G = pipe.batch, pipe.group
+                grp = next_group(G, B)
+            if not grp:
                 raise StopIteration('infer(): the input pipeline is exhausted')
-            if int(nxt.shape[0]) != self._ipipe.batch:
-                self._infer_tail = nxt
-                return self.infer()
-            self._ipipe.submit(nxt)
-        im_embed, fm, release = self._ipipe.take()
+            if len(grp) < G or any(int(g.shape[0]) != B for g in grp):
+                tail.extend(grp)
+                return serial(tail.pop(0))
+            if pipe is None:
+                from .trainer import EncoderPipeline
+                pipe = self._ipipe = EncoderPipeline(self._encoder_for(G * B), B, G, self.device)
+            pipe.submit(torch.cat(grp, 0) if G > 1 else grp[0])
+        im_embed, fm, release = pipe.take()
         im_embed, fm = self._embed(im_embed).clone(), fm.clone()     # the staging copy goes back to the pipeline at once
-        release()
-        nxt = next_images()
-        if nxt is not None and int(nxt.shape[0]) == self._ipipe.batch:
-            self._ipipe.submit(nxt)                                   # runs under this batch's decode steps
-        elif nxt is not None:                                         # a ragged batch: served serially by the next call
-            self._infer_tail = nxt
+        if release():                                                 # first batch of its group: the next group's forward
+            grp = next_group(pipe.group, pipe.batch)                  # runs under this group's decode steps
+            if len(grp) == pipe.group and all(int(g.shape[0]) == pipe.batch for g in grp):
+                pipe.submit(torch.cat(grp, 0) if pipe.group > 1 else grp[0])
+            else:
+                tail.extend(grp)                                      # served once the group in flight is consumed
         ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True)
         self.infer_output = [ids, attn]
         return self.infer_output
