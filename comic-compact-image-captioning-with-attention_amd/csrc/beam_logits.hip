@@ -620,7 +620,19 @@ __global__ __launch_bounds__(512) void beam_step_small_kernel(const float* __res
     const float* row = logits + (size_t)(b * W + w) * ld;
 #pragma unroll
     for (int u = 0; u < CL; ++u) x[u] = row[min(lane + 64 * u, V - 1)];
-    for (int sl = 1; sl < S; ++sl) {
+    int sl = 1;
+    for (; sl + 3 <= S; sl += 3) {        // three slices' loads travel together; added in slice order
+      float v[3][CL];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int u = 0; u < CL; ++u) v[q][u] = row[(size_t)(sl + q) * slice_stride + min(lane + 64 * u, V - 1)];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int u = 0; u < CL; ++u) x[u] += v[q][u];
+    }
+    for (; sl < S; ++sl) {
 #pragma unroll
       for (int u = 0; u < CL; ++u) x[u] += row[(size_t)sl * slice_stride + min(lane + 64 * u, V - 1)];
     }
