@@ -516,7 +516,10 @@ class CaptionModel_SCST(ModelBase):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
         infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
         c = self._config
-        im_embed, fm = self._encode(imgs)          # ONE encoder forward serves both rollouts
+        im_embed, fm = self._encode(imgs)          # ONE encoder forward serves both rollouts ...
+        # ... and the training step on the same images that follows (train_fn_scst: the CNN is frozen in SCST mode, so
+        # run_train_scst takes these features instead of a second forward)
+        self._share['scst_features'] = ((id(imgs), tuple(np.shape(imgs))), im_embed.clone(), fm.clone())
         greedy, _ = self._decode_features(im_embed, fm, 1, 20, want_attention=False)
         beam, _ = self._decode_features(im_embed, fm, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
@@ -525,7 +528,11 @@ class CaptionModel_SCST(ModelBase):
         """One reward-weighted update on `tile` hypotheses per image.  imgs: the batch tiled `tile`
         times (tile=1, the reference's feed) or the untiled batch with tile=beam: the frozen encoder
         then runs once and (im_embed, fm) are tiled -- same values, 1/tile of the CNN work."""
-        im_embed, fm = self._encode(imgs)
+        kept = self._share.pop('scst_features', None)
+        if kept is not None and kept[0] == (id(imgs), tuple(np.shape(imgs))) and 'opt_cnn' not in self._share:
+            im_embed, fm = kept[1], kept[2]          # the sampling pass's features of these very images
+        else:
+            im_embed, fm = self._encode(imgs)
         if tile > 1:
             im_embed, fm = im_embed.repeat(tile, 1), fm.repeat(tile, 1, 1)
         lr = self.lr
