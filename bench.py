@@ -149,10 +149,25 @@ def extras(device, enc, cnn_params, plan):
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bs, IMG, IMG, 3)).astype(np.float32)).to(device)
     iters = 40                                   # infer_max_length 20 x 2 radix digits
 
-    def scst_step():
+    ahead = {}
+
+    def encode_now():
+        # as train_fn's SCST loop runs it: the encoder forward of the NEXT step is enqueued as soon as this step's
+        # rollouts are back, so it runs on the device while the host scores them; one forward per step either way
+        if 'f' in ahead:
+            return ahead.pop('f')
         im, fm = enc_s.forward(imgs, use_graph=True)
+        return im.clone(), fm.clone()
+
+    def encode_ahead():
+        im, fm = enc_s.forward(imgs, use_graph=True)
+        ahead['f'] = (im.clone(), fm.clone())
+
+    def scst_step():
+        im, fm = encode_now()
         greedy, _, _ = dec.greedy(fm, im, iters)
         beam = dec.beam_search(fm, im, W, iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
+        encode_ahead()
         cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
         cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
@@ -199,9 +214,10 @@ def extras(device, enc, cnn_params, plan):
         return ids2d
 
     def scst_step_realistic():
-        im, fm = enc_s.forward(imgs, use_graph=True)
+        im, fm = encode_now()
         greedy, _, _ = dec.greedy(fm, im, real_iters)
         beam = dec.beam_search(fm, im, W, real_iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
+        encode_ahead()
         cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]
         cap_greedy = [[c] for c in id_to_caption(cut(greedy), cfg)]
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)

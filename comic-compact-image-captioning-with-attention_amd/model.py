@@ -516,13 +516,27 @@ class CaptionModel_SCST(ModelBase):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
         infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
         c = self._config
-        im_embed, fm = self._encode(imgs)          # ONE encoder forward serves both rollouts ...
+        key = (id(imgs), tuple(np.shape(imgs)))
+        pf = self._share.pop('scst_prefetch', None)
+        if pf is not None and pf[0] == key:
+            im_embed, fm = pf[1], pf[2]            # forward enqueued during the previous step's reward computation
+        else:
+            im_embed, fm = self._encode(imgs)      # ONE encoder forward serves both rollouts ...
         # ... and the training step on the same images that follows (train_fn_scst: the CNN is frozen in SCST mode, so
         # run_train_scst takes these features instead of a second forward)
-        self._share['scst_features'] = ((id(imgs), tuple(np.shape(imgs))), im_embed.clone(), fm.clone())
+        self._share['scst_features'] = (key, im_embed.clone(), fm.clone())
         greedy, _ = self._decode_features(im_embed, fm, 1, 20, want_attention=False)
         beam, _ = self._decode_features(im_embed, fm, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
+
+    def prefetch_features(self, imgs):
+        """Enqueue the encoder forward of the NEXT step's images now: the device is idle while the host scores this
+        step's rollouts (text, CIDEr-D / BLEU, ids), and the frozen CNN does not depend on the update in between.
+        sample(imgs) on the same object picks the features up."""
+        if 'opt_cnn' in self._share:
+            return
+        im_embed, fm = self._encode(imgs)
+        self._share['scst_prefetch'] = ((id(imgs), tuple(np.shape(imgs))), im_embed.clone(), fm.clone())
 
     def run_train_scst(self, imgs, captions, rewards, tile=1):
         """One reward-weighted update on `tile` hypotheses per image.  imgs: the batch tiled `tile`

@@ -140,12 +140,17 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
     print('INFO: Graph constructed. SCST training begins now.')
     start_epoch = time.time()
     greedy_high_sc = 0
+    ahead = None
     for step in range(start_step, c.max_step):
         epoch = int(step / num_batches) + 1
-        imgs, refs = next(inputs_man.batch_train)
+        imgs, refs = ahead if ahead is not None else next(inputs_man.batch_train)
         # `cap_beam` is (beam_size, batch_size, time) -> (beam_size * batch_size, time):
         # [[im0_hypo0], ..., [imN_hypo0], [im0_hypo1], ..., [imN_hypo1]]   (train_fn.py:226-238)
         cap_beam, cap_greedy = m_sample.sample(imgs)
+        # the next batch's encoder forward runs on the device while the host scores this batch's rollouts
+        ahead = next(inputs_man.batch_train) if step + 1 < c.max_step else None
+        if ahead is not None:
+            m_sample.prefetch_features(ahead[0])
         cap_beam = np.reshape(cap_beam, [-1, cap_beam.shape[-1]])
         cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
         cap_greedy = [[s] for s in id_to_caption(cap_greedy, c)]
