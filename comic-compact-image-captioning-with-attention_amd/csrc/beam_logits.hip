@@ -10,9 +10,10 @@
 //   * W_o is pre-packed once per decode call (beam_pack_wo_kernel): per chunk and 32-deep k-step the eight 16-column
 //     tiles as bf16 hi and lo halves in MFMA-fragment order -- a chunk's K-quarter is 64 contiguous KB that go
 //     global -> LDS by LDS-DMA (two quarters in flight), the 52 MB stream is read exactly once per step;
-//   * the eight waves split the ROWS (16-row tiles); a wave converts only its own rows of y to hi / lo and reads the
-//     weight fragments from the LDS: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (the arithmetic of
-//     comic_gemm_f32_split3, product error about 2^-16);
+//   * the eight waves split the ROWS (16-row tiles); the rows of y arrive pre-split as hi / lo fragments (from the LSTM
+//     cell kernel, or beam_pack_y_kernel) and go to registers with a rolling four-step prefetch, the weight fragments
+//     come from the LDS: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (the arithmetic of comic_gemm_f32_split3,
+//     product error about 2^-16);
 //   * D[v][row] orientation: a lane holds 4 consecutive columns of ONE row per tile, so the per-row work of the chunk is
 //     lane-local plus two cross-lane steps (lanes r, r+16, r+32, r+48): the chunk's maximum and sum of exponentials
 //     (the log-softmax partials) and its top-W columns BY LOGIT -- inside one beam the order by logit is the order by
@@ -20,8 +21,11 @@
 //   * the logits never reach memory: per row and chunk 2 + 2W words instead of 128.
 // The merge launch (one workgroup per entry) combines the partials in chunk order into the log-softmax constants,
 // scores the candidates, applies _mask_probs to finished beams (their candidates are synthesised: EOS and the lowest
-// columns) and selects the top W under the total order (score descending, flat index ascending) with the same
-// bookkeeping as beam_merge_kernel.
+// columns), selects the top W under the total order (score descending, flat index ascending) with the bookkeeping of
+// beam_step_kernel, counts the step's finished entries (the last one to arrive writes steps_executed) and gathers the
+// next step's LSTM operand rows through the parents it has chosen (lstm_prep.h).
+// Small vocabularies (V <= 1024: radix-256) take beam_step_small_kernel below: a beam's logits in a wave's registers,
+// the same tail.
 #include <float.h>
 
 #include <algorithm>

@@ -12,7 +12,9 @@
 // the waves split the 16-row tiles, the operand rows arrive as pre-split fragments written by the step's gather kernel)
 // and stores its partial gate sums; D[col][row] orientation puts the four gates of a unit into one lane.  The kernel is
 // read from HBM exactly once per step.  lstm_cell_kernel adds the slices in slice order (deterministic), the bias and
-// the forget bias, and applies the cell -- c2, h2, y as comic_lstm_step_fused writes them.
+// the forget bias, and applies the cell -- c2, h2, y as comic_lstm_step_fused writes them, plus y as hi / lo fragments
+// for the products that consume it.  The same streaming kernel serves plain skinny products out = x W over the step's
+// fragments (comic_stream_gemm: query projection; vocabulary projection at a small V; two of them in one launch).
 #include <algorithm>
 
 #include "conv_common.h"
