@@ -344,6 +344,20 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   const int k0 = lane * EPL, head = k0 / dh;
   float qv[EPL], gv[EPL], bv[EPL], vv[EPL];
   sum_q_parts<EPL>(a.q + (size_t)b * D + k0, a.q_parts, (size_t)a.d.B * D, qv);
+  // small memories (M <= 28 rows of 2 x 1024 value channels: the 5 x 5 x 2048 map): the thread's two value channels of
+  // every row are requested HERE, before the scores -- 205 KB per workgroup arrive at the CU's fill rate (4.4 us, phase
+  // clocks) under the scoring and the probability function instead of behind them.  The two barriers of this path are raw
+  // s_barriers behind an lgkmcnt wait: the fence of the library barrier would drain the loads (it waits vmcnt(0)).
+  constexpr int kPre = 28;      // (32 rows spill at 8 elements per lane: 1024 threads leave 128 VGPRs)
+  // (the tied 512-wide values of COMIC-256 measured no gain from the same treatment: 51 KB per row is not fill-bound)
+  const bool fast = M <= kPre && Cv == 2 * kAttnThreads && ((Cv / H) & 1) == 0;
+  float2 vpre[kPre];
+  if (fast) {
+    const float2* vp2 = (const float2*)(a.values + (size_t)bm * M * Cv) + tid;
+#pragma unroll
+    for (int m = 0; m < kPre; ++m)
+      if (m < M) vpre[m] = vp2[(size_t)m * (Cv / 2)];
+  }
   if (a.q_out && wave == 0) {
 #pragma unroll
     for (int i = 0; i < EPL; ++i) a.q_out[(size_t)b * D + k0 + i] = qv[i];
@@ -360,7 +374,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
     const float raw = score_row<EPL>(a, kr, qv, gv, bv, vv, lph, nullptr, nullptr, rstd);
     if ((lane % lph) == 0) sc[head * M + m] = raw / scale;
   }
-  __syncthreads();
+  if (fast) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
   // probability fn per head (wave per head), then dropout; sc <- alpha_d
   for (int h = wave; h < H; h += kAttnWaves) {
     float* row = sc + h * M;
@@ -392,14 +411,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
       }
     }
   }
-  __syncthreads();
+  if (fast) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
   // context: ctx[c] = sum_m alpha_d[head(c)][m] * values[m][c]   (coalesced over c)
   const int dv = Cv / H;
-  for (int c = tid; c < Cv; c += kAttnThreads) {
-    const float* al = sc + (c / dv) * M;
-    const float* vp = a.values + (size_t)bm * M * Cv + c;
-    float acc = 0.f;
-    for (int m = 0; m < M; ++m) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
+  auto finish = [&](int c, float acc) {
     a.ctx[(size_t)b * Cv + c] = acc;
     if (a.att_next) {  // impute_finished select + next step's (dropped) LSTM input
       const bool fin = a.lens && a.t >= a.lens[b];
@@ -411,6 +431,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
         a.xh_next[(size_t)b * a.xh_ld + c] = xv;
       }
     }
+  };
+  if (fast) {
+    const float* al = sc + ((2 * tid) / dv) * M;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < kPre; ++m)
+      if (m < M) {
+        a0 = fmaf(al[m], vpre[m].x, a0);
+        a1 = fmaf(al[m], vpre[m].y, a1);
+      }
+    finish(2 * tid, a0);
+    finish(2 * tid + 1, a1);
+    return;
+  }
+  for (int c = tid; c < Cv; c += kAttnThreads) {
+    const float* al = sc + (c / dv) * M;
+    const float* vp = a.values + (size_t)bm * M * Cv + c;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(al[m], vp[(size_t)m * Cv], acc);
+    finish(c, acc);
   }
 }
 
