@@ -35,8 +35,14 @@
 
 namespace {
 
-constexpr int kChunkCols = 128;         // vocabulary columns per workgroup (eight 16-column tiles)
-constexpr int kQuarterBytes = 64 * 1024;
+#ifndef BL_VT
+#define BL_VT 7
+#endif
+// 16-column tiles per workgroup: 7 -> 112-column chunks, 229 workgroups at V = 25 599 (8 -> 200 of the 256 CUs)
+constexpr int kVT = BL_VT;
+constexpr int kChunkCols = 16 * kVT;    // vocabulary columns per workgroup
+constexpr int kQuarterBytes = 4 * kVT * 2 * 1024;     // four k-steps of kVT tiles x {hi, lo} x 1 KB
+constexpr int kBiasBytes = 512;
 
 struct BLVal {
   float v;
@@ -56,8 +62,10 @@ __global__ __launch_bounds__(256) void beam_pack_wo_kernel(const float* __restri
     return;
   }
   const int KS = D / 32;
-  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1), vt = (int)((u >> 7) & 7);
-  const long t = u >> 10;
+  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1);
+  const long t1 = u >> 7;
+  const int vt = (int)(t1 % kVT);
+  const long t = t1 / kVT;
   const int s = (int)(t % KS);
   const long c = t / KS;
   const int fr = lane & 15, fg = lane >> 4;
@@ -149,13 +157,13 @@ template <int NT>
 __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsigned char* smem, int wave, int lane, int tid) {
   const int fr = lane & 15, fg = lane >> 4;
   const int c = blockIdx.x, D = a.D, KS = D / 32, NQ = D / 128;
-  const unsigned char* wsrc = (const unsigned char*)a.wo_frag + (size_t)c * KS * 16 * 1024;
+  const unsigned char* wsrc = (const unsigned char*)a.wo_frag + (size_t)c * KS * kVT * 2 * 1024;
   constexpr int NR = NT > 0 ? NT : 1;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(bl_lds_addr(smem)) + wave * 1024;
 
-  auto issue = [&](int q, int buf) {     // 64 KB: eight rounds of 512 lanes x 16 B
+  auto issue = [&](int q, int buf) {     // a K-quarter: kVT rounds of 512 lanes x 16 B
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < kVT; ++i)
       bl_dma16(wsrc + (size_t)q * kQuarterBytes + i * 8192 + tid * 16, lds0 + buf * kQuarterBytes + i * 8192);
   };
   int row[NR];
@@ -174,13 +182,13 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
       yf[m][s][1] = bl_load16(ysrc[m] + (size_t)(q * 4 + s) * 128 + 64);
     }
   };
-  f32x4_t acc[NR][8];
+  f32x4_t acc[NR][kVT];
 #pragma unroll
   for (int m = 0; m < NR; ++m)
 #pragma unroll
-    for (int vt = 0; vt < 8; ++vt) acc[m][vt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int vt = 0; vt < kVT; ++vt) acc[m][vt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  if (wave == 0 && lane < 32) bl_dma16(a.bias_pad + c * kChunkCols + lane * 4, lds0 + 2 * kQuarterBytes);   // the chunk's bias
+  if (wave == 0 && lane < kChunkCols / 4) bl_dma16(a.bias_pad + c * kChunkCols + lane * 4, lds0 + 2 * kQuarterBytes);   // the chunk's bias
   issue(0, 0);
 #pragma unroll
   for (int s = 0; s < 4; ++s) load_y(0, s);
@@ -197,9 +205,10 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
     if constexpr (NT > 0) {
       const uint4* wl = (const uint4*)(smem + buf * kQuarterBytes) + lane;
       uint4 wa[2][8];                                      // [ring][4 tiles x {hi, lo}] of one half k-step
-      auto load_half = [&](int h, uint4 (&dst)[8]) {
+      auto load_half = [&](int h, uint4 (&dst)[8]) {       // half h of k-step h / 2: tiles 4 (h & 1) .. of its kVT
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = wl[(h * 8 + j) * 64];
+        for (int j = 0; j < 8; ++j)
+          if ((h & 1) * 4 + (j >> 1) < kVT) dst[j] = wl[(((h >> 1) * kVT + (h & 1) * 4) * 2 + j) * 64];
       };
       load_half(0, wa[0]);
 #pragma unroll
@@ -215,6 +224,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int vt = (h & 1) * 4 + j;
+          if (vt >= kVT) continue;
           const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, wa[h & 1][2 * j]);
           const bf16x8_t al = __builtin_bit_cast(bf16x8_t, wa[h & 1][2 * j + 1]);
 #pragma unroll
@@ -235,18 +245,18 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
   if constexpr (NT == 0) return;
 
   // ---- per row: the chunk's log-softmax partials and its top-W columns by logit ------------------------------------------
-  // lane (fr, fg) holds columns v = 128 c + 16 vt + 4 fg + i (i < 4) of row `row[m]`
+  // lane (fr, fg) holds columns v = kChunkCols c + 16 vt + 4 fg + i (i < 4) of row `row[m]`
   const int v_base = c * kChunkCols + 4 * fg;
-  float4 bias[8];
+  float4 bias[kVT];
 #pragma unroll
-  for (int vt = 0; vt < 8; ++vt) bias[vt] = *(const float4*)(smem + 2 * kQuarterBytes + (16 * vt + 4 * fg) * 4);
+  for (int vt = 0; vt < kVT; ++vt) bias[vt] = *(const float4*)(smem + 2 * kQuarterBytes + (16 * vt + 4 * fg) * 4);
 #pragma unroll
   for (int m = 0; m < NT; ++m) {
     // branch-free: dead columns are -inf (exp -> 0, never the strict maximum of a scan)
-    float x[32];
+    float x[4 * kVT];
     float mx = -INFINITY;
 #pragma unroll
-    for (int vt = 0; vt < 8; ++vt)
+    for (int vt = 0; vt < kVT; ++vt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int v = v_base + 16 * vt + i;
@@ -259,7 +269,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float se = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) se += __expf(x[e] - mx);
+    for (int e = 0; e < 4 * kVT; ++e) se += __expf(x[e] - mx);
     // the four lane groups' partial sums: (s_r + s_r^16) + (s_r^32 + s_r^48), the same bits in all four lanes
     se += __shfl_xor(se, 16, 64);
     se += __shfl_xor(se, 32, 64);
@@ -273,7 +283,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
       float bv = -INFINITY;
       int be = -1;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) {
+      for (int e = 0; e < 4 * kVT; ++e) {
         const bool g = x[e] > bv;
         bv = g ? x[e] : bv;
         be = g ? e : be;
@@ -291,7 +301,7 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
       // the lane that holds the winner retires it
       const int gone = (bi == mine) ? be : -1;
 #pragma unroll
-      for (int e = 0; e < 32; ++e) x[e] = (e == gone) ? -INFINITY : x[e];
+      for (int e = 0; e < 4 * kVT; ++e) x[e] = (e == gone) ? -INFINITY : x[e];
       if (fg == 0 && row[m] >= 0) {
         a.cand_v[ro * a.W + k] = bv;
         a.cand_i[ro * a.W + k] = bi == 0x7fffffff ? -1 : bi;
@@ -717,7 +727,7 @@ int64_t comic_beam_logits_partial_floats(int D, int V, int R, int W, int max_ste
 }
 
 int comic_beam_pack_wo(const float* W_o, const float* b_o, int ld, void* wo_frag, int D, int V, hipStream_t st) {
-  const long units = (long)comic_beam_logits_chunks(V) * (D / 32) * 8 * 2 * 64;
+  const long units = (long)comic_beam_logits_chunks(V) * (D / 32) * kVT * 2 * 64;
   const long total = units + (long)comic_beam_logits_chunks(V) * kChunkCols;
   hipLaunchKernelGGL(beam_pack_wo_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, W_o, b_o, ld, (uint4*)wo_frag,
                      D, V, units);
@@ -748,7 +758,7 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
   COMIC_REQUIRE(comic_beam_logits_supported(D, V, R, W), "beam_logits: unsupported shape (D %d, V %d, rows %d, beam %d)", D, V, R, W);
   BeamLogitsArgs a;
   a.wo_frag = (const uint4*)wo_frag;
-  a.bias_pad = (const float*)((const uint4*)wo_frag + (size_t)chunks * (D / 32) * 8 * 2 * 64);
+  a.bias_pad = (const float*)((const uint4*)wo_frag + (size_t)chunks * (D / 32) * kVT * 2 * 64);
   a.pmax = partials;
   a.psum = a.pmax + (size_t)R * chunks;
   a.cand_v = a.psum + (size_t)R * chunks;
@@ -776,7 +786,7 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks), dim3(512), 2 * kQuarterBytes + 512, st, a);   // row tiles w, w + 8 per wave
+  hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks), dim3(512), 2 * kQuarterBytes + kBiasBytes, st, a);   // row tiles w, w + 8 per wave
   const size_t merge_lds = (size_t)W * chunks * W * 8;
   hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(256), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
                      (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,

@@ -1111,6 +1111,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   return 0;
 }
 
+// columns of the W_o scratch: V rounded up to whole chunks of any of its packed forms (128, 112 or 64 columns)
+static inline long wo_pad_cols(long V) { return (V + 127) / 128 * 128 + 128; }
 constexpr int kBeamCntSteps = 4096;       // decode steps the in-kernel completion counters of the beam step cover
 
 extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int max_steps) {
@@ -1131,7 +1133,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>(R * (2 * D + A));                                  // gather temp
   w.take<char>(kSplitKBytes);                                      // split-K partials
   w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));  // LSTM kernel panel (fused step)
-  w.take<float>((D + 1) * ((V + 127) / 128 * 128));                // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
+  w.take<float>((D + 1) * wo_pad_cols(V));                         // W_o with 16-byte aligned rows / packed hi-lo fragments + bias
   w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));  // streaming LSTM step
   w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));     // ... W_q, y fragments
   w.take<unsigned long long>(kBeamCntSteps);                       // beam search: per-step completion counters
@@ -1174,7 +1176,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.gtmp = w.take<float>(R * (2 * D + A));
   g_splitk_ws = w.take<char>(kSplitKBytes);
   b.kpanel = w.take<float>(comic_lstm_panel_floats(d->D, d->E + d->A + d->D, 0));
-  b.wo_pad = w.take<float>((D + 1) * ((V + 127) / 128 * 128));
+  b.wo_pad = w.take<float>((D + 1) * wo_pad_cols(V));
   b.kfrag = w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); b.xfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));
   b.wqfrag = w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); b.yfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));
   b.beam_cnt = w.take<unsigned long long>(kBeamCntSteps);
@@ -1360,7 +1362,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
   } else if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   // large vocabularies: projection + per-chunk top-k as one streaming launch over a packed W_o (beam_logits.hip)
   const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
-                             comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128) * 4 &&
+                             comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * wo_pad_cols(V) * 4 &&
                              comic_beam_logits_partial_floats(D, V, R, W, max_steps) <= (int64_t)R * V;
   // small vocabularies (radix-256): the entry's beam step with a beam's logits in a wave's registers; with the step's y at
   // hand as fragments (streaming LSTM step) the projection goes through the streaming kernel too
@@ -1368,7 +1370,7 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
                           max_steps <= kBeamCntSteps;
   const bool stream_wo = small_step && stream_lstm && comic_stream_gemm_supported(D, V, R) &&
                          comic_stream_gemm_part_bytes(D, V, R) <= kSplitKBytes &&
-                         comic_stream_gemm_wfrag_floats(D, V) <= (int64_t)(D + 1) * ((V + 127) / 128 * 128);
+                         comic_stream_gemm_wfrag_floats(D, V) <= (int64_t)(D + 1) * wo_pad_cols(V);
   int ld_wo = V;
   const float* w_o = nullptr;
   if (stream_logits) {
