@@ -439,7 +439,8 @@ __device__ __forceinline__ void beam_entry_tail(BeamEntryShared& sh, int b, int 
   }
 }
 
-__global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+constexpr int kMergeThreads = 512;      // eight waves: a beam each up to beam 8, twice the threads for the fill and the gather
+__global__ __launch_bounds__(512) void beam_merge2_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                           const float* __restrict__ cand_v, const int32_t* __restrict__ cand_i,
                                                           float* __restrict__ log_probs, int32_t* __restrict__ finished,
                                                           int64_t* __restrict__ lengths, int32_t* __restrict__ word_ids,
@@ -456,8 +457,8 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   float* c_tot = (float*)dyn;                  // candidate scores / flat indices of this entry (0x7fffffff: no candidate)
   int* c_f = (int*)(c_tot + n);
   // every global load the kernel can issue without a dependence goes out first: the beam state, the chunk partials
-  // of this wave's first beam (<= 8 per lane) and the first 8 candidates per thread
-  constexpr int CP = 8, CQ = 8;
+  // of this wave's first beam (<= 8 per lane) and the first 4 candidates per thread
+  constexpr int CP = 8, CQ = 4;
   const bool pre = wave < W && chunks <= 64 * CP;
   float pm[CP], ps[CP];
   if (pre) {
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   float xx0[CQ];
 #pragma unroll
   for (int u = 0; u < CQ; ++u) {
-    const int j = tid + u * 256;
+    const int j = tid + u * kMergeThreads;
     vv0[u] = -1;
     xx0[u] = 0.f;
     if (j < n) {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   if (tid == 0) sh.alldone = 1;
   // log-softmax constants of every beam from the per-chunk partials (a wave per beam; every lane walks its chunks in
   // ascending order, the wave reduction is a fixed tree: the same bits on every launch)
-  for (int w = wave; w < W; w += 4) {
+  for (int w = wave; w < W; w += kMergeThreads / 64) {
     const size_t ro = (size_t)(b * W + w) * chunks;
     float mx = -INFINITY, s = 0.f;
     if (pre && w == wave) {
@@ -526,15 +527,15 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
   };
 #pragma unroll
   for (int u = 0; u < CQ; ++u) {
-    const int j = tid + u * 256;
+    const int j = tid + u * kMergeThreads;
     if (j < n) place(j, vv0[u], xx0[u]);
   }
-  for (int j0 = tid + 256 * CQ; j0 < n; j0 += 256 * 4) {
+  for (int j0 = tid + kMergeThreads * CQ; j0 < n; j0 += kMergeThreads * 4) {
     int vv[4];
     float xx[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * 256;
+      const int j = j0 + u * kMergeThreads;
       vv[u] = -1;
       xx[u] = 0.f;
       if (j < n) {
@@ -544,14 +545,14 @@ __global__ __launch_bounds__(256) void beam_merge2_kernel(const float* __restric
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * 256;
+      const int j = j0 + u * kMergeThreads;
       if (j < n) place(j, vv[u], xx[u]);
     }
   }
   __syncthreads();
   // the W best of every beam (a wave per beam): W x W finalists
   constexpr int CL = 16;
-  for (int w = wave; w < W; w += 4) {
+  for (int w = wave; w < W; w += kMergeThreads / 64) {
     if (per <= 64 * CL) {         // the beam's candidates in registers: one LDS pass, W branch-free rounds
       float rt[CL];
       int rf[CL];
@@ -788,7 +789,7 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
   }
   hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks), dim3(512), 2 * kQuarterBytes + kBiasBytes, st, a);   // row tiles w, w + 8 per wave
   const size_t merge_lds = (size_t)W * chunks * W * 8;
-  hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(256), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
+  hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(kMergeThreads), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
                      (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,
                      scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_logits_step");
