@@ -32,6 +32,13 @@
 
 #include "conv_common.h"
 #include "lstm_prep.h"
+#include "lstm_stream_dev.h"
+
+#define RC(x)      \
+  do {             \
+    int rc_ = (x); \
+    if (rc_) return rc_; \
+  } while (0)
 
 namespace {
 
@@ -310,11 +317,18 @@ __device__ __forceinline__ void beam_logits_wave(const BeamLogitsArgs& a, unsign
   }
 }
 
-__global__ __launch_bounds__(512) void beam_logits_kernel(BeamLogitsArgs a) {
+// The last n_q workgroups of the launch are not chunks of W_o: they run the query projection q = y W_q of the same step
+// (lstm_stream_dev.h) on the CUs the 229 chunks leave idle -- it reads the same y fragments and its 7 us no longer stand
+// in front of the attention step as a launch of their own.
+__global__ __launch_bounds__(512) void beam_logits_kernel(BeamLogitsArgs a, LstmStreamArgs q, int n_q) {
   if (comic_stopped(a.stop, a.stop_t)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= (int)gridDim.x - n_q) {
+    lstm_stream_block(q, smem, wave, lane, tid, (int)blockIdx.x - ((int)gridDim.x - n_q));
+    return;
+  }
   const int tiles = (a.R + 15) >> 4;
   const int nt = (wave < tiles ? 1 : 0) + (wave + 8 < tiles ? 1 : 0);        // wave-uniform (scalar)
   if (nt == 2) beam_logits_wave<2>(a, smem, wave, lane, tid);
@@ -750,30 +764,21 @@ int comic_beam_logits_begin(float* partials, int B, int W, int V, int max_steps,
   return 0;
 }
 
-// y_frag_in: the step's decoder outputs already as fragments (lstm_cell_kernel), or null: split from y here
-int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
-                           int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
-                           int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
-                           const LstmPrepArgs* prep, hipStream_t st) {
-  const int R = B * W, chunks = comic_beam_logits_chunks(V);
-  COMIC_REQUIRE(comic_beam_logits_supported(D, V, R, W), "beam_logits: unsupported shape (D %d, V %d, rows %d, beam %d)", D, V, R, W);
-  BeamLogitsArgs a;
-  a.wo_frag = (const uint4*)wo_frag;
-  a.bias_pad = (const float*)((const uint4*)wo_frag + (size_t)chunks * (D / 32) * kVT * 2 * 64);
+// The step in two launches (a caller may put the attention step between them: the merge gathers the attention output
+// for the next step's operand rows).
+// y_frag_in: the step's decoder outputs already as fragments (lstm_cell_kernel), or null: split from y here.
+// q / n_q / q_lds: an optional streaming product (comic_stream_gemm_args: the query projection) whose n_q workgroups ride
+// at the end of the projection launch.
+static void beam_logits_layout(BeamLogitsArgs& a, float* partials, int R, int W, int chunks, int max_steps,
+                               unsigned long long** cnt, uint4** y_frag) {
   a.pmax = partials;
   a.psum = a.pmax + (size_t)R * chunks;
   a.cand_v = a.psum + (size_t)R * chunks;
   a.cand_i = (int32_t*)(a.cand_v + (size_t)R * chunks * W);
-  unsigned long long* cnt = (unsigned long long*)(a.cand_i + (size_t)R * chunks * W);
-  uint4* y_frag = (uint4*)(((uintptr_t)(cnt + max_steps) + 15) & ~(uintptr_t)15);
-  a.y_frag = y_frag_in ? (const uint4*)y_frag_in : y_frag;
-  a.R = R; a.D = D; a.V = V; a.W = W; a.chunks = chunks;
-  a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
-  if (!y_frag_in) {
-    const long units = (long)((R + 15) / 16) * (D / 32) * 2 * 64;
-    hipLaunchKernelGGL(beam_pack_y_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, y, y_frag, R, D, units,
-                       g_comic_stop.p, g_comic_stop.t);
-  }
+  *cnt = (unsigned long long*)(a.cand_i + (size_t)R * chunks * W);
+  *y_frag = (uint4*)(((uintptr_t)(*cnt + max_steps) + 15) & ~(uintptr_t)15);
+}
+static int beam_logits_attrs() {
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();
   if (!attr_set) {
@@ -787,13 +792,58 @@ int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks), dim3(512), 2 * kQuarterBytes + kBiasBytes, st, a);   // row tiles w, w + 8 per wave
+  return 0;
+}
+int comic_beam_logits_launch(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, int max_steps, int B,
+                             int W, int D, int V, const LstmStreamArgs* q, int n_q, int q_lds, hipStream_t st) {
+  const int R = B * W, chunks = comic_beam_logits_chunks(V);
+  COMIC_REQUIRE(comic_beam_logits_supported(D, V, R, W), "beam_logits: unsupported shape (D %d, V %d, rows %d, beam %d)", D, V, R, W);
+  BeamLogitsArgs a;
+  a.wo_frag = (const uint4*)wo_frag;
+  a.bias_pad = (const float*)((const uint4*)wo_frag + (size_t)chunks * (D / 32) * kVT * 2 * 64);
+  unsigned long long* cnt;
+  uint4* y_frag;
+  beam_logits_layout(a, partials, R, W, chunks, max_steps, &cnt, &y_frag);
+  a.y_frag = y_frag_in ? (const uint4*)y_frag_in : y_frag;
+  a.R = R; a.D = D; a.V = V; a.W = W; a.chunks = chunks;
+  a.stop = g_comic_stop.p; a.stop_t = g_comic_stop.t;
+  if (!y_frag_in) {
+    const long units = (long)((R + 15) / 16) * (D / 32) * 2 * 64;
+    hipLaunchKernelGGL(beam_pack_y_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, y, y_frag, R, D, units,
+                       g_comic_stop.p, g_comic_stop.t);
+  }
+  RC(beam_logits_attrs());
+  const int lds = std::max(2 * kQuarterBytes + kBiasBytes, q && n_q > 0 ? q_lds : 0);
+  LstmStreamArgs qa{};
+  if (q && n_q > 0) qa = *q;
+  else n_q = 0;
+  hipLaunchKernelGGL(beam_logits_kernel, dim3(chunks + n_q), dim3(512), lds, st, a, qa, n_q);   // row tiles w, w + 8 per wave
+  COMIC_LAUNCH_CHECK("beam_logits_launch");
+  return 0;
+}
+int comic_beam_merge_launch(float* partials, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                            int32_t* parent_ids, float* scores, int32_t* steps_executed, int t, int max_steps, int B, int W,
+                            int V, int end_id, const LstmPrepArgs* prep, hipStream_t st) {
+  const int R = B * W, chunks = comic_beam_logits_chunks(V);
+  BeamLogitsArgs a;
+  unsigned long long* cnt;
+  uint4* y_frag;
+  beam_logits_layout(a, partials, R, W, chunks, max_steps, &cnt, &y_frag);
+  RC(beam_logits_attrs());
   const size_t merge_lds = (size_t)W * chunks * W * 8;
   hipLaunchKernelGGL(beam_merge2_kernel, dim3(B), dim3(kMergeThreads), merge_lds, st, (const float*)a.pmax, (const float*)a.psum,
                      (const float*)a.cand_v, (const int32_t*)a.cand_i, log_probs, finished, lengths, word_ids, parent_ids,
                      scores, W, V, chunks, end_id, cnt + t, steps_executed, t, max_steps, prep ? *prep : LstmPrepArgs{}, g_comic_stop.p, g_comic_stop.t);
-  COMIC_LAUNCH_CHECK("beam_logits_step");
+  COMIC_LAUNCH_CHECK("beam_merge_launch");
   return 0;
+}
+int comic_beam_logits_step(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, float* log_probs,
+                           int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores,
+                           int32_t* steps_executed, int t, int max_steps, int B, int W, int D, int V, int end_id,
+                           const LstmPrepArgs* prep, hipStream_t st) {
+  RC(comic_beam_logits_launch(y, y_frag_in, wo_frag, partials, max_steps, B, W, D, V, nullptr, 0, 0, st));
+  return comic_beam_merge_launch(partials, log_probs, finished, lengths, word_ids, parent_ids, scores, steps_executed, t,
+                                 max_steps, B, W, V, end_id, prep, st);
 }
 
 // ---- small vocabularies ------------------------------------------------------------------------------------------------------

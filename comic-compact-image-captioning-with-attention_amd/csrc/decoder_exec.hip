@@ -21,6 +21,7 @@
 #include "common.h"
 #include "decoder_persist.h"
 #include "lstm_prep.h"
+#include "lstm_stream_dev.h"
 
 // internal cross-file entries (gemm.hip, decoder.hip)
 int comic_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -83,6 +84,14 @@ int64_t comic_stream_gemm_part_bytes(int Kin, int N, int R);
 int comic_stream_gemm_pack(const float* Wm, void* w_frag, int Kin, int N, hipStream_t st);
 int comic_stream_gemm(const void* x_frag, const void* w_frag, float* part, int64_t part_bytes, int R, int Kin, int N, int* S,
                       hipStream_t st);
+LstmStreamArgs comic_stream_gemm_args(const void* x_frag, const void* w_frag, float* part, int R, int Kin, int N, int* S,
+                                      int* n_wg, int* lds_bytes, int max_wg);
+int comic_beam_logits_chunks(int V);
+int comic_beam_logits_launch(const float* y, const void* y_frag_in, const void* wo_frag, float* partials, int max_steps, int B,
+                             int W, int D, int V, const LstmStreamArgs* q, int n_q, int q_lds, hipStream_t st);
+int comic_beam_merge_launch(float* partials, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                            int32_t* parent_ids, float* scores, int32_t* steps_executed, int t, int max_steps, int B, int W,
+                            int V, int end_id, const LstmPrepArgs* prep, hipStream_t st);
 int comic_stream_gemm2(const void* x_frag, const void* w_a, float* part_a, int N_a, int* S_a, const void* w_b, float* part_b,
                        int N_b, int* S_b, int64_t part_bytes_each, int R, int Kin, hipStream_t st);
 bool comic_beam_step_small_supported(int V, int W);
@@ -638,6 +647,7 @@ struct StreamBufs {
   int wo_N = 0;
   float* wo_part = nullptr;       // out: its K-slice partials (second half of the split-K scratch)
   int wo_S = 0;                   // out: their count
+  int q_S = 0;                    // > 0: the query partials are already in the split-K scratch (they rode another launch)
 };
 // first half: operand prep + LSTM product + cell -> c2, h2, y (and y as fragments on the streaming path)
 int infer_step_lstm(const comic_decoder_desc* d, const comic_decoder_params* p, const float* kpanel, const int32_t* ids,
@@ -665,7 +675,9 @@ int infer_step_attend(const comic_decoder_desc* d, const comic_decoder_params* p
   const int D = d->D;
   int S = 1;
   float* part = (float*)g_splitk_ws;
-  if (sm && sm->wqfrag && sm->wofrag) {
+  if (sm && sm->q_S > 0) {
+    S = sm->q_S;
+  } else if (sm && sm->wqfrag && sm->wofrag) {
     sm->wo_part = (float*)((char*)g_splitk_ws + kSplitKBytes / 2);
     RC(comic_stream_gemm2(sm->yfrag, sm->wqfrag, part, D, &S, sm->wofrag, sm->wo_part, sm->wo_N, &sm->wo_S, kSplitKBytes / 2,
                           rows, D, st));
@@ -1421,6 +1433,21 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       // (the two chains that hang off y -- query projection + attention, vocabulary projection + top-k -- measured
       // slower on two lanes than back to back: 98.5 vs 94.8 us per step, the fork / join of a 20 us branch costs more
       // than the overlap returns)
+      if (stream_logits && stream_lstm && sm.wqfrag) {
+        // projection launch first, with the query projection's workgroups riding on the CUs its chunks leave idle; the
+        // attention step (which needs q) and the merge (which gathers the attention output) follow
+        const float* att_new = d->context_layer ? sb.att2 : sb.ctx;
+        LstmPrepArgs prep{p->emb, att_new, sb.h2, sb.c2, (uint4*)ws.xfrag, ws.gtmp, E, A, D, V, (E + A + D + 31) / 32};
+        int n_q = 0, q_lds = 0;
+        const LstmStreamArgs qa = comic_stream_gemm_args(ws.yfrag, ws.wqfrag, (float*)g_splitk_ws, R, D, D, &sm.q_S, &n_q, &q_lds,
+                                                         std::max(8, 256 - comic_beam_logits_chunks(V)));
+        RC(comic_beam_logits_launch(sb.y, ws.yfrag, ws.wo_pad, ws.logits, max_steps, B, W, D, V, &qa, n_q, q_lds, st));
+        RC(infer_step_attend(d, p, ad, ws.keys, values, sb, attn_hist + (size_t)t * R * H * M, R, st, smp, mem_div));
+        RC(comic_beam_merge_launch(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R,
+                                   steps_executed, t, max_steps, B, W, V, d->end_id, &prep, st));
+        cur = nxt;
+        continue;
+      }
       RC(infer_step_attend(d, p, ad, ws.keys, values, sb, attn_hist + (size_t)t * R * H * M, R, st, smp, mem_div));
       if (stream_logits) {
         // (with the streaming LSTM step the merge also gathers the next step's operand rows: raw c / h / attention
