@@ -36,7 +36,8 @@ class DecoderDesc(C.Structure):
     _fields_ = [(n, c_int32) for n in (
         'D', 'E', 'A', 'V', 'C', 'Cg', 'H', 'M', 'Cv', 'fm_projection', 'method', 'prob', 'context_layer',
         'init_method', 'start_id', 'end_id')] + [(n, c_float) for n in (
-            'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')] + [('flags', C.c_uint32)]
+            'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')] + [('flags', C.c_uint32),
+                                                                       ('length_penalty_weight', c_float)]
 
 
 # comic_decoder_desc.flags (include/comic_hip.h COMIC_DEC_*).  The library reads no environment: the A/B switches of

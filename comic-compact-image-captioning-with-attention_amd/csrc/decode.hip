@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
                                                         int32_t* __restrict__ finished, int64_t* __restrict__ lengths,
                                                         int32_t* __restrict__ word_ids, int32_t* __restrict__ parent_ids,
                                                         float* __restrict__ scores, int W, int V, int end_id,
-                                                        const int32_t* __restrict__ stop, int stop_t) {
+                                                        float lpw, const int32_t* __restrict__ stop, int stop_t) {
+  // lpw: length_penalty_weight of BeamSearchDecoder ([TF-1.9] _get_scores): candidates are ranked by
+  // total / ((5 + length) / 6)^lpw with length = the beam's + 1 unless the beam is finished or the candidate is EOS;
+  // the beam state keeps the unpenalised total, the step's `scores` output the penalised one.  0: no penalty.
   __shared__ ValIdx sh[256];
   __shared__ float s_max[64], s_logsum[64], s_lp[64];
   __shared__ int s_fin[64], s_sel[64];
@@ -127,7 +130,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
         step = (v == end_id) ? 0.f : -FLT_MAX;  // dtype.min
       else
         step = (lg[f] - s_max[w]) - s_logsum[w];
-      const float tot = s_lp[w] + step;
+      float tot = s_lp[w] + step;
+      if (lpw != 0.f) {
+        const long long len = s_len[w] + ((s_fin[w] || v == end_id) ? 0 : 1);
+        tot = tot / powf((5.f + (float)len) / 6.f, lpw);
+      }
       if (better(tot, f, bv, bi)) {
         bv = tot;
         bi = f;
@@ -161,7 +168,12 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     word_ids[b * W + tid] = word;
     parent_ids[b * W + tid] = parent;
     scores[b * W + tid] = s_selv[tid];
-    log_probs[b * W + tid] = s_selv[tid];
+    float total = s_selv[tid];
+    if (lpw != 0.f) {      // the state carries the unpenalised total log probability of the chosen candidate
+      const float step = prev_fin ? ((word == end_id) ? 0.f : -FLT_MAX) : ((lg[f] - s_max[parent]) - s_logsum[parent]);
+      total = s_lp[parent] + step;
+    }
+    log_probs[b * W + tid] = total;
     finished[b * W + tid] = (prev_fin || word == end_id) ? 1 : 0;
     lengths[b * W + tid] = s_len[parent] + (prev_fin ? 0 : 1);
   }
@@ -432,17 +444,23 @@ extern "C" int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, 
   return 0;
 }
 
-extern "C" int comic_beam_step(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths,
-                               int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int V, int end_id,
-                               void* stream) {
+// executor-internal: the step with BeamSearchDecoder's length penalty (length_penalty_weight; 0 = none)
+int comic_beam_step_lp(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                       int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, float lpw, hipStream_t st) {
   COMIC_REQUIRE(logits && log_probs && finished && lengths && word_ids && parent_ids && scores,
                 "beam_step: null pointer");
   COMIC_REQUIRE(W >= 1 && W <= 64, "beam_step: beam width must be in [1,64] (got %d)", W);
   COMIC_REQUIRE((long)W * V < (1L << 31) && W <= V, "beam_step: beam*V too large or beam > V");
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, log_probs, finished,
-                     lengths, word_ids, parent_ids, scores, W, V, end_id, g_comic_stop.p, g_comic_stop.t);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, st, logits, log_probs, finished, lengths, word_ids,
+                     parent_ids, scores, W, V, end_id, lpw, g_comic_stop.p, g_comic_stop.t);
   COMIC_LAUNCH_CHECK("beam_step");
   return 0;
+}
+extern "C" int comic_beam_step(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths,
+                               int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int V, int end_id,
+                               void* stream) {
+  return comic_beam_step_lp(logits, log_probs, finished, lengths, word_ids, parent_ids, scores, B, W, V, end_id, 0.f,
+                            (hipStream_t)stream);
 }
 
 // executor-internal: with a workspace and a large vocabulary the step is split over several

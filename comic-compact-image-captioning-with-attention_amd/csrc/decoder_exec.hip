@@ -100,6 +100,8 @@ int comic_beam_step_small(const float* logits, const float* bias, int S, int ld,
                           int32_t* finished, int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores, int B,
                           int W, int V, int end_id, void* cnt, int32_t* steps_executed, int t, int max_steps,
                           const LstmPrepArgs* prep, hipStream_t st);
+int comic_beam_step_lp(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
+                       int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, float lpw, hipStream_t st);
 int comic_beam_step_ws(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths, int32_t* word_ids,
                        int32_t* parent_ids, float* scores, int B, int W, int V, int end_id, void* ws, int64_t ws_bytes,
                        hipStream_t st);
@@ -1373,12 +1375,14 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
     }
   } else if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   // large vocabularies: projection + per-chunk top-k as one streaming launch over a packed W_o (beam_logits.hip)
-  const bool stream_logits = fused && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
+  // (a length penalty ranks by score, not by log probability: its step runs the one-workgroup-per-entry kernel)
+  const float lpw = d->length_penalty_weight;
+  const bool stream_logits = fused && lpw == 0.f && beam_logits_enabled() && comic_beam_logits_supported(D, V, R, W) &&
                              comic_beam_logits_pack_bytes(D, V) <= (int64_t)(D + 1) * wo_pad_cols(V) * 4 &&
                              comic_beam_logits_partial_floats(D, V, R, W, max_steps) <= (int64_t)R * V;
   // small vocabularies (radix-256): the entry's beam step with a beam's logits in a wave's registers; with the step's y at
   // hand as fragments (streaming LSTM step) the projection goes through the streaming kernel too
-  const bool small_step = fused && !stream_logits && beam_logits_enabled() && comic_beam_step_small_supported(V, W) &&
+  const bool small_step = fused && lpw == 0.f && !stream_logits && beam_logits_enabled() && comic_beam_step_small_supported(V, W) &&
                           max_steps <= kBeamCntSteps;
   const bool stream_wo = small_step && stream_lstm && comic_stream_gemm_supported(D, V, R) &&
                          comic_stream_gemm_part_bytes(D, V, R) <= kSplitKBytes &&
@@ -1481,8 +1485,12 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
         }
       } else {
         RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
-        RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
-                              d->end_id, g_splitk_ws, kSplitKBytes, st));
+        if (lpw != 0.f)
+          RC(comic_beam_step_lp(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                                d->end_id, lpw, st));
+        else
+          RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                                d->end_id, g_splitk_ws, kSplitKBytes, st));
       }
     } else {
       if (t > 0) (void)hipMemcpyAsync(ws.ids, step_ids + (size_t)(t - 1) * R, sizeof(int32_t) * R,
@@ -1497,8 +1505,12 @@ extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decod
       RC(infer_step(d, p, ad, ws.keys, values, ws.x, ws.c[cur], ws.h[cur], ws.att[cur], sb,
                     attn_hist + (size_t)t * R * H * M, R, st));
       RC(gemm_big(sb.y, w_o, ws.logits, p->b_o, R, V, D, D, ld_wo, V, 0, 0, 0.f, st));
-      RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
-                            d->end_id, g_splitk_ws, kSplitKBytes, st));
+      if (lpw != 0.f)
+        RC(comic_beam_step_lp(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                              d->end_id, lpw, st));
+      else
+        RC(comic_beam_step_ws(ws.logits, ws.log_probs, finished, lengths, word, parent, scores + (size_t)t * R, B, W, V,
+                              d->end_id, g_splitk_ws, kSplitKBytes, st));
       RC(comic_gather_rows(sb.c2, parent, ws.c[nxt], R, W, D, (void*)st));
       RC(comic_gather_rows(sb.h2, parent, ws.h[nxt], R, W, D, (void*)st));
       RC(comic_gather_rows(att_new, parent, ws.att[nxt], R, W, A, (void*)st));

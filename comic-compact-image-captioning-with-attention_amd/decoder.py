@@ -522,14 +522,18 @@ class Decoder:
         hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
         return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
 
-    def beam_search(self, fm, im_embed, beam, max_steps, want_attention=True, use_graph=True):
+    def beam_search(self, fm, im_embed, beam, max_steps, want_attention=True, use_graph=True, length_penalty_weight=0.0):
         """rnn_decoder_beam_search (ops_rnn.py:49-112).  Returns predicted_ids [T,B,W] (after
-        gather_tree), scores [T,B,W], the raw step/parent ids and, unless want_attention=False, the
+        gather_tree), scores [T,B,W] (with length_penalty_weight != 0: the penalised scores the beams were ranked by,
+        BeamSearchDecoder's `scores` output), the raw step/parent ids and, unless want_attention=False, the
         beam-sorted alignment history [T,B*W,H*M] (numpy; BeamSearchDecoderMultiHead,
         ops_rnn.py:807-845 -- host post-processing that only visualisation needs)."""
         torch, s = self.torch, self.spec
         B, W = fm.shape[0], beam
-        ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed)
+        # (a non-zero length penalty is another captured graph: the weight is baked into the step kernel's arguments)
+        ctx = self._infer_ctx('beam' if not length_penalty_weight else 'beam_lp%r' % float(length_penalty_weight), B, W,
+                              max_steps, False, fm, im_embed)
+        ctx.desc.length_penalty_weight = float(length_penalty_weight)
 
         def launch():
             ctx.desc.flags = L.decoder_flags_from_env()

@@ -293,15 +293,17 @@ class ModelBase(object):
                          self.decoder.params.to_numpy(), extra, max_to_keep, fmt=fmt)
 
     # ---- decode (model_base.py:692-757, :272-314) ----------------------------------------
-    def _decode(self, images, beam_size, max_length, top_beam=True, want_attention=True):
+    def _decode(self, images, beam_size, max_length, top_beam=True, want_attention=True, length_penalty_weight=0.0):
         im_embed, fm = self._encode(images)
-        return self._decode_features(im_embed, fm, beam_size, max_length, top_beam, want_attention)
+        return self._decode_features(im_embed, fm, beam_size, max_length, top_beam, want_attention, length_penalty_weight)
 
-    def _decode_features(self, im_embed, fm, beam_size, max_length, top_beam=True, want_attention=True):
+    def _decode_features(self, im_embed, fm, beam_size, max_length, top_beam=True, want_attention=True,
+                         length_penalty_weight=0.0):
         c = self._config
         iters = self.decoder.max_iterations(max_length, len(c.wtoi))
         if beam_size > 1:
-            r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention)
+            r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention,
+                                         length_penalty_weight=length_penalty_weight)
             pred = r['predicted_ids']                                  # (T, B, W)
             T = pred.shape[0]
             attn = None
@@ -419,7 +421,8 @@ class CaptionModel(ModelBase):
         if batch is not None or not (getattr(c, 'pipeline_encoder', True) and str(self.device).startswith('cuda')
                                      and os.environ.get('COMIC_PIPELINE_INFER', '1') == '1'):
             images = batch[0] if isinstance(batch, (tuple, list)) else (batch if batch is not None else next(self.batch_ops)[0])
-            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True,
+                                     length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
             self.infer_output = [ids, attn]
             return self.infer_output
         torch = self.torch
@@ -445,7 +448,8 @@ class CaptionModel(ModelBase):
             return out
 
         def serial(images):
-            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True)
+            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True,
+                                     length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
             self.infer_output = [ids, attn]
             return self.infer_output
 
@@ -484,7 +488,8 @@ class CaptionModel(ModelBase):
                 pipe.submit(torch.cat(grp, 0) if pipe.group > 1 else grp[0])
             else:
                 tail.extend(grp)                                      # served once the group in flight is consumed
-        ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True)
+        ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True,
+                                          length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
         self.infer_output = [ids, attn]
         return self.infer_output
 

@@ -368,6 +368,8 @@ typedef struct comic_decoder_desc {
   float map_loss_scale;
   uint32_t flags;                      /* COMIC_DEC_* executor switches, 0 = every fast path on (A/B measurements and tests;
                                           results agree to fp32 summation order).  The library reads no environment. */
+  float length_penalty_weight;         /* comic_decoder_beam only: BeamSearchDecoder(length_penalty_weight) -- candidates
+                                          are ranked by total / ((5 + length) / 6)^w (ops_rnn.py:96, infer.py:65); 0 = none */
 } comic_decoder_desc;
 #define COMIC_DEC_NO_PERSIST 1u         /* time loops as per-step launches (forward and backward; greedy too) */
 #define COMIC_DEC_NO_PERSIST_BWD 2u     /* backward time loop as per-step launches */

@@ -98,9 +98,13 @@ def gather_tree_from_array(t, parent_ids, sequence_length):
     return src[ti, bi, sorted_ids].reshape(np.asarray(t).shape)
 
 
-def beam_search_decode(p, cfg, fm, im_embed, beam, max_iters, return_debug=False):
+def beam_search_decode(p, cfg, fm, im_embed, beam, max_iters, return_debug=False, length_penalty_weight=0.0):
     """-> predicted_ids [T,B,W] (after gather_tree), scores [T,B,W], attn history
-    [T, B*W, H*M] beam-sorted, plus raw step/parent ids when return_debug."""
+    [T, B*W, H*M] beam-sorted, plus raw step/parent ids when return_debug.
+    length_penalty_weight (ops_rnn.py:96, infer.py:65) [TF-1.9 _beam_search_step / _get_scores]: candidates are ranked by
+    total / ((5 + length) / 6)^w, length = the beam's + 1 unless the beam is finished or the candidate is EOS
+    (lengths_to_add = one_hot(EOS, on 0, off 1) * not finished); the beam state keeps the unpenalised totals,
+    `scores` are the penalised ones."""
     B, M, C = fm.shape
     W, V, H = beam, cfg.softmax_size, cfg.attn_num_heads
     dt = fm.dtype
@@ -125,16 +129,24 @@ def beam_search_decode(p, cfg, fm, im_embed, beam, max_iters, return_debug=False
         fin_row = np.full(V, F32_MIN, dt); fin_row[cfg.end_id] = 0
         step_lp = np.where(finished[:, :, None], fin_row[None, None, :], step_lp)
         total = log_probs[:, :, None] + step_lp
-        flat = total.reshape(B, W * V)
+        flat_total = total.reshape(B, W * V)
+        if length_penalty_weight != 0:
+            add = np.ones(V, np.int64); add[cfg.end_id] = 0
+            new_len = lengths[:, :, None] + add[None, None, :] * (~finished)[:, :, None]
+            pen = (((np.float32(5.) + new_len.astype(dt)) / np.float32(6.)) ** np.float32(length_penalty_weight)).astype(dt)
+            flat = (total / pen).reshape(B, W * V)
+        else:
+            flat = flat_total
         # top_k: descending value, lower flat index first among equals
         order = np.argsort(-flat, axis=1, kind='stable')[:, :W]
         next_scores = np.take_along_axis(flat, order, axis=1)
+        next_totals = np.take_along_axis(flat_total, order, axis=1)
         word = (order % V).astype(np.int32)
         parent = (order // V).astype(np.int32)
         prev_fin = finished[bidx, parent]
         next_fin = prev_fin | (word == cfg.end_id)
         lengths = lengths[bidx, parent] + (~prev_fin).astype(np.int64)
-        log_probs = next_scores.astype(dt)
+        log_probs = next_totals.astype(dt)
         finished = next_fin
         gidx = (bidx * W + parent).reshape(-1)
         c, h, att = c[gidx], h[gidx], att[gidx]

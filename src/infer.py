@@ -56,8 +56,6 @@ def main(argv=None):
             raise ValueError('`infer_checkpoints` must be either `all` or a list of comma-separated checkpoint numbers.')
     c = conf.load_config(pjoin(args.infer_checkpoints_dir, 'config.pkl'))
     c.__dict__.update(args.__dict__)
-    if c.infer_length_penalty_weight != 0:
-        raise NotImplementedError('length penalty != 0 is not used by the reference runs and not implemented')
     save_name = 'beam_{}_lpen_{}'.format(c.infer_beam_size, c.infer_length_penalty_weight)
     save_name = {'test': 'infer_test_', 'valid': 'infer_valid_', 'coco_test': 'infer_cocoTest_',
                  'coco_valid': 'infer_cocoValid_'}[c.infer_set] + save_name

@@ -801,6 +801,38 @@ def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
             assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'beam scores')
 
 
+@pytest.mark.parametrize('kw,w', [(dict(), 0.7), (dict(fm_projection=None, H=1, token_type='word', V=300,
+                                                     init_method='project_hidden', start_id=298, end_id=299), 1.0),
+                                  (dict(C=832, Cg=1024, M=196), -0.5)])
+def test_beam_length_penalty_matches_oracle(kw, w):
+    """rnn_decoder_beam_search with length_penalty_weight != 0 (ops_rnn.py:96, infer.py:65): candidates ranked by
+    total / ((5 + length) / 6)^w, EOS and finished beams do not grow; ids / parents / lengths bit-exact against the
+    oracle, penalised scores at 1e-4; and a different result than without the penalty (the option does something)."""
+    spec, cfg = _spec_and_cfg(**kw)
+    p = _rand_params(cfg, 5)
+    p['b_o'][spec.end_id] = 3.0                 # EOS competitive from the first steps: beams of different lengths
+    B, max_steps = 5, 14
+    fm, im, _ = _batch(spec, B, 6, 21)
+    dec = cdec.Decoder(spec, p, DEV)
+    plain = dec.beam_search(dev(fm), dev(im), 3, max_steps)
+    differs = False
+    for W in (3, 7):
+        pred, scores, hist, dbg = beam_ref.beam_search_decode(p, cfg, fm, im, W, max_steps, return_debug=True,
+                                                              length_penalty_weight=w)
+        for _ in range(3):
+            res = dec.beam_search(dev(fm), dev(im), W, max_steps, length_penalty_weight=w)
+        np.testing.assert_array_equal(res['step_ids'], dbg['step_ids'])
+        np.testing.assert_array_equal(res['parent_ids'], dbg['parent_ids'])
+        np.testing.assert_array_equal(res['predicted_ids'], pred)
+        np.testing.assert_array_equal(res['lengths'], dbg['lengths'])
+        fin = np.isfinite(scores) & (np.abs(scores) < 1e30)
+        assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'penalised beam scores')
+        if W == 3:
+            differs = res['step_ids'].shape != plain['step_ids'].shape or (res['step_ids'] != plain['step_ids']).any() \
+                or not np.allclose(res['scores'], plain['scores'])
+    assert differs, 'the length penalty changed nothing'
+
+
 @pytest.mark.parametrize('B,W,V', [(20, 3, 25599), (7, 5, 25599), (50, 3, 25599), (32, 7, 258)])
 def test_beam_streaming_step_race_screen(B, W, V, monkeypatch):
     """Race screen of the hand-synchronised streaming kernels (LDS-DMA rings with counted / drained waits, cross-workgroup

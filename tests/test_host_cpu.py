@@ -64,7 +64,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(L.CnnOp) == 26 * 4                    # ... flags, min_lds
     assert C.sizeof(L.AttnDesc) == 8 * 4
-    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4  # ... map_loss_scale, flags
+    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4 + 4  # ... map_loss_scale, flags
     assert C.sizeof(L.DecoderParams) == 14 * 8
     assert C.sizeof(L.ConvWeight) == 4 * 8                # w, scale, shift, w_frag
 
