@@ -55,6 +55,8 @@ class DecoderSpec:
     attn_keep_prob: float = 0.9
     map_loss_scale: float = 1.0
     l2_decay: float = 1e-5
+    recurrent_dropout: bool = False      # DropoutWrapper(variational_recurrent=True): ONE input / output mask row
+                                         # for all batch rows and time steps of a run [TF-1.9: noise shape [1, size]]
 
     @property
     def A(self):                     # model_base.py:611-615
@@ -83,7 +85,7 @@ class DecoderSpec:
                    init_method=c.rnn_init_method, token_type=c.token_type, start_id=start, end_id=end,
                    dropout_rnn_in=getattr(c, 'dropout_rnn_in', 0.35), dropout_rnn_out=getattr(c, 'dropout_rnn_out', 0.35),
                    attn_keep_prob=c.attn_keep_prob, map_loss_scale=getattr(c, 'rnn_map_loss_scale', 1.0),
-                   l2_decay=getattr(c, 'l2_decay', 1e-5))
+                   l2_decay=getattr(c, 'l2_decay', 1e-5), recurrent_dropout=bool(getattr(c, 'rnn_recurr_dropout', False)))
 
     def param_shapes(self):
         D, E, A, V, C_, Cg = self.D, self.E, self.A, self.V, self.C, self.Cg
@@ -335,6 +337,16 @@ class Decoder:
         if training and gen_masks:
             L.check(self.lib.comic_dropout_masks4_dev(ctx.mask_buf.data_ptr(), ctx.mask_n4, ctx.mask_keep4,
                                                       ctx.seed.data_ptr(), st), 'dropout_masks4')
+            if s.recurrent_dropout:
+                # variational recurrent dropout (model_base.py:645; [TF-1.9] DropoutWrapper draws its input / output
+                # noise once per run with a batch dimension of 1): the first row of the drawn masks serves every batch
+                # row and time step, the init call through the same wrapper included; the attention dropout is not
+                # part of the wrapper and stays per step
+                row_in = m['inp'][0, 0].clone()
+                row_out = m['out'][0, 0].clone()
+                m['inp'].copy_(row_in.expand_as(m['inp']))
+                m['init_in'].copy_(row_in.expand_as(m['init_in']))
+                m['out'].copy_(row_out.expand_as(m['out']))
         BT = B * T
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()

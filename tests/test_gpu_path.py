@@ -801,6 +801,38 @@ def test_beam_streaming_logits_step_matches_oracle(B, W, V, D, monkeypatch):
             assert_close(np.where(fin, res['scores'], 0), np.where(fin, scores, 0), 1e-4, 'beam scores')
 
 
+def test_variational_recurrent_dropout_masks():
+    """--rnn_recurr_dropout (model_base.py:645; DropoutWrapper(variational_recurrent=True), [TF-1.9] noise of shape
+    [1, size]): the generated input / output masks are ONE row for every batch row and time step, the init call uses the
+    input row, the attention dropout stays per step; two steps draw different rows; the step itself is the one the
+    injected-mask oracle tests cover (loss and gradients finite, equal to a re-run with the same masks injected)."""
+    spec, cfg = _spec_and_cfg(D=128, E=64)
+    spec.recurrent_dropout = True
+    B = 6
+    fm, im, caps = _batch(spec, B, 9, 4)
+    dec = cdec.Decoder(spec, _rand_params(cfg, 2), DEV)
+    r1 = dec.train_step(dev(fm), dev(im), caps, training=True, use_graph=False)
+    ctx = [c for c in dec._ctx.values() if c.masks is not None][0]
+    m = {k: v.clone() for k, v in ctx.masks.items()}
+    for k in ('inp', 'out'):
+        row = m[k][0, 0]
+        assert bool((m[k] == row).all()), k
+        assert 0 < float((row == 0).float().mean()) < 1          # a real Bernoulli row
+    assert bool((m['init_in'] == m['inp'][0, 0]).all())
+    assert not bool((m['alpha'] == m['alpha'][0, 0]).all())
+    g1 = dec.grads.data.clone()
+    r2 = dec.train_step(dev(fm), dev(im), caps, masks={k: v for k, v in m.items()}, training=True, use_graph=False)
+    assert abs(r1['loss'] - r2['loss']) <= 1e-6 * abs(r2['loss']) and bool(torch.equal(g1, dec.grads.data))
+    dec.train_step(dev(fm), dev(im), caps, training=True, use_graph=False)
+    assert not bool((ctx.masks['inp'][0, 0] == m['inp'][0, 0]).all())
+    for _ in range(3):                                             # captured and replayed: the broadcast is part of the graph
+        r3 = dec.train_step(dev(fm), dev(im), caps, training=True, use_graph=True)
+        assert np.isfinite(float(r3['loss']))
+        ctxg = [c for c in dec._ctx.values() if c.masks is not None][0]
+        assert bool((ctxg.masks['out'] == ctxg.masks['out'][0, 0]).all())
+        assert bool((ctxg.masks['init_in'] == ctxg.masks['inp'][0, 0]).all())
+
+
 @pytest.mark.parametrize('kw,w', [(dict(), 0.7), (dict(fm_projection=None, H=1, token_type='word', V=300,
                                                      init_method='project_hidden', start_id=298, end_id=299), 1.0),
                                   (dict(C=832, Cg=1024, M=196), -0.5)])

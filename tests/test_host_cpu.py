@@ -502,22 +502,23 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
 
 
 def test_cli_refuses_options_it_does_not_implement(tmp_path):
-    """LN_LSTM / GRU cells, variational recurrent dropout and gradient clipping fail at argument time instead of
-    training a different model; sgd, every --initialiser value (all Xavier-uniform in the reference, model_base.py:
-    823-831) and --legacy build."""
+    """LN_LSTM / GRU cells and gradient clipping fail at argument time instead of training a different model; sgd, every
+    --initialiser value (all Xavier-uniform in the reference, model_base.py:823-831), --legacy and variational recurrent
+    dropout (built in round 3) build."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('train_cli2', os.path.join(ROOT, 'src', 'train.py'))
     train = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(train)
     base = ['--log_root', str(tmp_path)]
-    for bad in (['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM'], ['--rnn_recurr_dropout', 'True']):
+    for bad in (['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM']):
         with pytest.raises(NotImplementedError):
             train.build_kwargs(train.create_parser().parse_args(base + bad))
     kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base))
     kw['clip_gradient_norm'] = 5.0
     with pytest.raises(NotImplementedError):
         train.check_supported(kw)
-    for ok in (['--optimiser', 'sgd'], ['--initialiser', 'he'], ['--initialiser', 'none'], ['--legacy', 'True']):
+    for ok in (['--optimiser', 'sgd'], ['--initialiser', 'he'], ['--initialiser', 'none'], ['--rnn_recurr_dropout', 'True'],
+               ['--legacy', 'True']):
         kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base + ok))
     assert kw['legacy'] and kw['cnn_name'] == 'inception_v1' and kw['adam_epsilon'] == 1e-6
 
