@@ -521,15 +521,15 @@ class CaptionModel_SCST(ModelBase):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
         infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
         c = self._config
-        key = (id(imgs), tuple(np.shape(imgs)))
+        # (the caches below hold the image object itself: `is` on a live object cannot be fooled by a recycled id())
         pf = self._share.pop('scst_prefetch', None)
-        if pf is not None and pf[0] == key:
+        if pf is not None and pf[0] is imgs:
             im_embed, fm = pf[1], pf[2]            # forward enqueued during the previous step's reward computation
         else:
             im_embed, fm = self._encode(imgs)      # ONE encoder forward serves both rollouts ...
         # ... and the training step on the same images that follows (train_fn_scst: the CNN is frozen in SCST mode, so
         # run_train_scst takes these features instead of a second forward)
-        self._share['scst_features'] = (key, im_embed.clone(), fm.clone())
+        self._share['scst_features'] = (imgs, im_embed.clone(), fm.clone())
         greedy, _ = self._decode_features(im_embed, fm, 1, 20, want_attention=False)
         beam, _ = self._decode_features(im_embed, fm, c.scst_beam_size, 20, top_beam=False, want_attention=False)
         return beam, greedy
@@ -541,14 +541,14 @@ class CaptionModel_SCST(ModelBase):
         if 'opt_cnn' in self._share:
             return
         im_embed, fm = self._encode(imgs)
-        self._share['scst_prefetch'] = ((id(imgs), tuple(np.shape(imgs))), im_embed.clone(), fm.clone())
+        self._share['scst_prefetch'] = (imgs, im_embed.clone(), fm.clone())
 
     def run_train_scst(self, imgs, captions, rewards, tile=1):
         """One reward-weighted update on `tile` hypotheses per image.  imgs: the batch tiled `tile`
         times (tile=1, the reference's feed) or the untiled batch with tile=beam: the frozen encoder
         then runs once and (im_embed, fm) are tiled -- same values, 1/tile of the CNN work."""
         kept = self._share.pop('scst_features', None)
-        if kept is not None and kept[0] == (id(imgs), tuple(np.shape(imgs))) and 'opt_cnn' not in self._share:
+        if kept is not None and kept[0] is imgs and 'opt_cnn' not in self._share:
             im_embed, fm = kept[1], kept[2]          # the sampling pass's features of these very images
         else:
             im_embed, fm = self._encode(imgs)
