@@ -302,3 +302,69 @@ int comic_lstm_stream_step(const float* table, const int32_t* ids, const int32_t
   COMIC_LAUNCH_CHECK("lstm_stream_step");
   return 0;
 }
+
+// ---- the streaming product as an operator of its own (C-ABI): out[R][N] = x[R][Kin] W[Kin][N] + bias ------------------------------
+// What the decode executors do per step with resident packed weights, end to end in one call: pack W and the rows,
+// stream, add the K-slices in slice order.  33 ... 256 rows, Kin a multiple of 8, any N.
+namespace {
+__global__ __launch_bounds__(256) void stream_pack_x_kernel(const float* __restrict__ x, uint4* __restrict__ out, int R, int Kin,
+                                                            int KS, long units) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const int lane = (int)(u & 63), hl = (int)((u >> 6) & 1);
+  const long t = u >> 7;
+  const int s = (int)(t % KS), tile = (int)(t / KS);
+  const int row = tile * 16 + (lane & 15), k0 = s * 32 + (lane >> 4) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (row < R && k0 + j < Kin) ? x[(size_t)row * Kin + k0 + j] : 0.f;
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t h = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+    w[j] = hl == 0 ? h : pack_bf16x2(v[2 * j] - __uint_as_float(h << 16), v[2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
+  }
+  out[u] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__global__ __launch_bounds__(256) void stream_sum_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int S, int R, int N, int Np) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)R * N) return;
+  const int r = (int)(t / N), n = (int)(t % N);
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += part[((size_t)s * R + r) * Np + n];
+  out[t] = acc + (bias ? bias[n] : 0.f);
+}
+}  // namespace
+
+extern "C" int64_t comic_gemm_f32_stream_workspace(int R, int Kin, int N) {
+  return (comic_stream_gemm_wfrag_floats(Kin, N) + comic_lstm_stream_xfrag_floats(R, Kin)) * 4 +
+         comic_stream_gemm_part_bytes(Kin, N, R) + 1024;
+}
+extern "C" int comic_gemm_f32_stream(const float* x, const float* W, const float* bias, float* out, int R, int Kin, int N,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+  COMIC_REQUIRE(x && W && out && workspace, "gemm_stream: null pointer");
+  COMIC_REQUIRE(comic_stream_gemm_supported(Kin, N, R), "gemm_stream: 33 ... 256 rows, K a multiple of 8 (got rows %d, K %d)", R, Kin);
+  COMIC_REQUIRE(workspace_bytes >= comic_gemm_f32_stream_workspace(R, Kin, N), "gemm_stream: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  void* w_frag = w;
+  w += (comic_stream_gemm_wfrag_floats(Kin, N) * 4 + 255) / 256 * 256;
+  void* x_frag = w;
+  w += (comic_lstm_stream_xfrag_floats(R, Kin) * 4 + 255) / 256 * 256;
+  float* part = (float*)w;
+  RC(comic_stream_gemm_pack(W, w_frag, Kin, N, st));
+  {
+    const int KS = lstm_ks(Kin);
+    const long units = (long)((R + 15) / 16) * KS * 2 * 64;
+    hipLaunchKernelGGL(stream_pack_x_kernel, dim3((unsigned)cdiv64(units, 256)), dim3(256), 0, st, x, (uint4*)x_frag, R, Kin, KS,
+                       units);
+  }
+  int S = 1;
+  RC(comic_stream_gemm(x_frag, w_frag, part, comic_stream_gemm_part_bytes(Kin, N, R), R, Kin, N, &S, st));
+  const long n = (long)R * N;
+  hipLaunchKernelGGL(stream_sum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, (const float*)part, bias, out, S, R, N,
+                     np64(N));
+  COMIC_LAUNCH_CHECK("gemm_stream");
+  return 0;
+}

@@ -228,6 +228,17 @@ int comic_gemm_f32_split3(const float* A, const float* B, float* C, const float*
                           float beta, void* workspace /* may be NULL: no split-K */,
                           int64_t workspace_bytes, void* stream);
 
+/* Skinny product for the decode steps: out[R][N] = x[R][Kin] W[Kin][N] + bias for 33 ... 256 rows (batch x beam), Kin a
+ * multiple of 8, any N -- the [TF-1.9] dense layers inside rnn_decoder_beam_search's step (BasicLSTMCell's gate product
+ * model_base.py:618-621, the query layer ops_rnn.py:440-447, the output projection model_base.py:531-594) when the
+ * weight matrix dwarfs the rows: W is packed to bf16 hi / lo halves in MFMA-fragment order and read from HBM exactly
+ * once for all rows through an LDS-DMA stream (csrc/lstm_stream.hip), products hi*hi + hi*lo + lo*hi as
+ * comic_gemm_f32_split3.  This entry packs, streams and sums in one call (the decode executors keep the packed weights
+ * across the steps of a decode).  bias may be NULL. */
+int64_t comic_gemm_f32_stream_workspace(int R, int Kin, int N);
+int comic_gemm_f32_stream(const float* x, const float* W, const float* bias, float* out, int R, int Kin, int N,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Same product; a caller-provided workspace lets skinny problems (M <= 2048, no trans_a)
  * split K over extra workgroups (deterministic slab reduction). */
 int comic_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N,

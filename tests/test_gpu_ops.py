@@ -42,6 +42,36 @@ def test_gemm_f32(M, N, K, ta, tb):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('R,K,N', [(150, 512, 512), (33, 96, 70), (256, 1000, 258), (64, 2816, 2048), (224, 512, 258),
+                                   (100, 40, 1), (35, 520, 130)])
+def test_gemm_f32_stream(R, K, N):
+    """Weight-streaming skinny product of the decode steps (csrc/lstm_stream.hip through its C-ABI entry): rows on one and
+    two 16-row tiles per wave and with idle waves, K not a multiple of the 32-deep step, N not a multiple of the
+    64-column chunk, the LSTM gate product's shape; bf16 hi/lo split products, bound 5e-5 of the result's max-norm."""
+    rng = np.random.default_rng(R + K + N)
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ W.astype(np.float64) + b
+    nb = int(lib().comic_gemm_f32_stream_workspace(R, K, N))
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dx, dW, db = dev(x), dev(W), dev(b)
+    out = torch.full((R, N), float('nan'), dtype=torch.float32, device=DEV)
+    for _ in range(3):
+        L.check(lib().comic_gemm_f32_stream(dx.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr(), R, K, N,
+                                            ws.data_ptr(), nb, stream()))
+    sync()
+    assert_close(out.cpu().numpy(), ref, 5e-5, 'gemm stream')
+    out2 = torch.empty_like(out)
+    L.check(lib().comic_gemm_f32_stream(dx.data_ptr(), dW.data_ptr(), None, out2.data_ptr(), R, K, N, ws.data_ptr(), nb,
+                                        stream()))
+    sync()
+    assert_close(out2.cpu().numpy(), ref - b, 5e-5, 'gemm stream, no bias')
+    with pytest.raises(L.ComicHipError):
+        L.check(lib().comic_gemm_f32_stream(dx.data_ptr(), dW.data_ptr(), None, out2.data_ptr(), 16, K, N, ws.data_ptr(), nb,
+                                            stream()))
+
+
 @pytest.mark.parametrize('M,N,K,ta,tb', [
     (1600, 512, 2048, 0, 0), (1856, 258, 512, 0, 0), (1856, 512, 258, 0, 1), (1280, 2048, 1856, 1, 0),
     (512, 258, 1856, 1, 0), (2048, 512, 1600, 1, 0), (33, 70, 19, 1, 1), (130, 131, 45, 0, 1), (257, 129, 64, 0, 0),
