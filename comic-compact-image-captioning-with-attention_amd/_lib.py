@@ -133,6 +133,8 @@ _SIGS = {
     'comic_debug_inject_persist_timeout': (c_int, []),
     'comic_decoder_greedy_path': (c_int, []),
     'comic_decoder_beam_path': (c_int, []),
+    'comic_beam_step_dense_workspace': (c_int64, [c_int, c_int, c_int, c_int]),
+    'comic_beam_step_dense': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'comic_gemm_f32_stream_workspace': (c_int64, [c_int, c_int, c_int]),
     'comic_gemm_f32_stream': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     'comic_decoder_infer_workspace': (c_int64, [P, c_int, c_int]),

@@ -1323,6 +1323,52 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   return 0;
 }
 
+// ---- one beam step from the decoder outputs, as an operator (C-ABI) -----------------------------------------------------
+// logits = y W_o + b_o, log_softmax, _mask_probs, top-k over beam x V, bookkeeping ([TF-1.9] _beam_search_step as used by
+// rnn_decoder_beam_search, ops_rnn.py:49-112) with the kernels comic_decoder_beam picks for the shape: the streaming
+// projection + per-chunk top-k + merge (V >= 4096, D % 128 == 0), the register-resident small step (V <= 1024), the GEMM +
+// comic_beam_step chain otherwise.  The same state arrays as comic_beam_step.
+static int64_t beam_dense_region(int B, int W, int D, int V) {        // floats: logits / partials
+  const int64_t R = (int64_t)B * W;
+  return std::max<int64_t>(R * V, comic_beam_logits_supported(D, V, (int)R, W) ? comic_beam_logits_partial_floats(D, V, (int)R, W, 1) : 0) + 64;
+}
+extern "C" int64_t comic_beam_step_dense_workspace(int B, int W, int D, int V) {
+  if (B <= 0 || W <= 0 || D <= 0 || V <= 0) return -1;
+  return ((int64_t)(D + 1) * wo_pad_cols(V) + beam_dense_region(B, W, D, V)) * 4 + kSplitKBytes + 4096;
+}
+extern "C" int comic_beam_step_dense(const float* y, const float* W_o, const float* b_o, float* log_probs, int32_t* finished,
+                                     int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W,
+                                     int D, int V, int end_id, void* workspace, int64_t workspace_bytes, void* stream) {
+  COMIC_REQUIRE(y && W_o && b_o && log_probs && finished && lengths && word_ids && parent_ids && scores && workspace,
+                "beam_step_dense: null pointer");
+  COMIC_REQUIRE(B > 0 && W > 0 && W <= 64 && D > 0 && V >= W, "beam_step_dense: bad shape");
+  COMIC_REQUIRE(workspace_bytes >= comic_beam_step_dense_workspace(B, W, D, V), "beam_step_dense: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  Bump w(workspace, (size_t)workspace_bytes);
+  float* wo = w.take<float>((D + 1) * wo_pad_cols(V));
+  float* region = w.take<float>(beam_dense_region(B, W, D, V));
+  void* splitk = w.take<char>(kSplitKBytes);
+  int32_t* steps = w.take<int32_t>(16);
+  unsigned long long* cnt = (unsigned long long*)w.take<int64_t>(16);
+  COMIC_REQUIRE(w.ok, "beam_step_dense: workspace overflow");
+  const int R = B * W;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, st, steps, 1, 1L);
+  if (comic_beam_logits_supported(D, V, R, W)) {
+    RC(comic_beam_pack_wo(W_o, b_o, V, wo, D, V, st));
+    RC(comic_beam_logits_begin(region, B, W, V, 1, st));
+    return comic_beam_logits_step(y, nullptr, wo, region, log_probs, finished, lengths, word_ids, parent_ids, scores, steps, 0, 1,
+                                  B, W, D, V, end_id, nullptr, st);
+  }
+  RC(comic_gemm_bf16x3_impl(y, W_o, region, b_o, R, V, D, D, V, V, 0, 0, 1.f, 0.f, splitk, kSplitKBytes, st));
+  if (comic_beam_step_small_supported(V, W)) {
+    RC(comic_beam_counters_zero(cnt, 1, st));
+    return comic_beam_step_small(region, nullptr, 1, V, 0, log_probs, finished, lengths, word_ids, parent_ids, scores, B, W, V,
+                                 end_id, cnt, steps, 0, 1, nullptr, st);
+  }
+  return comic_beam_step_ws(region, log_probs, finished, lengths, word_ids, parent_ids, scores, B, W, V, end_id, splitk,
+                            kSplitKBytes, st);
+}
+
 extern "C" int comic_decoder_beam(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
                                   const float* im_embed, int B, int W, int max_steps, int32_t* step_ids,
                                   int32_t* parent_ids, float* scores, int64_t* lengths, int32_t* finished,

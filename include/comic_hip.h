@@ -332,6 +332,17 @@ int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, void* strea
 int comic_beam_step(const float* logits, float* log_probs, int32_t* finished, int64_t* lengths,
                     int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int V,
                     int end_id, void* stream);
+
+/* The same step from the decoder outputs y [B*W][D]: logits = y W_o + b_o (W_o [D][V], TensorFlow layout), then as
+ * comic_beam_step -- with the kernels comic_decoder_beam picks for the shape: from V = 4096 (D % 128 == 0, <= 256 rows,
+ * beam <= 8) the projection, log-softmax and top-k are one streaming launch over packed hi/lo W_o fragments plus a merge and
+ * the logits are never written (csrc/beam_logits.hip); up to V = 1024 a beam's logits stay in a wave's registers;
+ * otherwise GEMM + comic_beam_step.  Total order (score descending, flat index ascending), _mask_probs, lengths and
+ * finished flags as there. */
+int64_t comic_beam_step_dense_workspace(int B, int W, int D, int V);
+int comic_beam_step_dense(const float* y, const float* W_o, const float* b_o, float* log_probs, int32_t* finished,
+                          int64_t* lengths, int32_t* word_ids, int32_t* parent_ids, float* scores, int B, int W, int D,
+                          int V, int end_id, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[r,:] = in[(r/W)*W + parent[r], :]   (state re-ordering by parent beam) */
 int comic_gather_rows(const float* in, const int32_t* parent, float* out, int rows, int W, int cols,
                       void* stream);

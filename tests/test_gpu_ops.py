@@ -654,6 +654,69 @@ def test_beam_step_vs_oracle_step():
     assert word.cpu().numpy()[0, 0] == 5 and word.cpu().numpy()[0, 1] == 9
 
 
+@pytest.mark.parametrize('B,W,V,D', [(4, 3, 258, 128), (5, 8, 9000, 128), (6, 3, 8962, 256), (3, 5, 1000, 64), (4, 3, 2500, 96)])
+def test_beam_step_dense_vs_oracle_step(B, W, V, D):
+    """One beam step from the decoder outputs through the kernels the decode loop uses for the shape (streaming projection
+    + chunk top-k + merge; register-resident small step; GEMM + comic_beam_step) against the [TF-1.9] step restated in
+    numpy: exact ties between duplicate vocabulary columns (lower flat index first, also across chunks and beams), a
+    finished beam, an entry whose other beams are at -inf, an entry with every beam finished."""
+    rng = np.random.default_rng(B + W + V)
+    end = V - 1
+    y = rng.standard_normal((B, W, D)).astype(np.float32)
+    Wo = (rng.standard_normal((D, V)) / np.sqrt(D)).astype(np.float32)
+    bo = (0.1 * rng.standard_normal(V)).astype(np.float32)
+    Wo[:, 7] = Wo[:, 3]; bo[7] = bo[3]                          # duplicate columns: exact ties, same chunk
+    Wo[:, V - 5] = Wo[:, 3]; bo[V - 5] = bo[3]                  # ... and in the last chunk
+    Wo[:, 3] *= 3.0; Wo[:, 7] *= 3.0; Wo[:, V - 5] *= 3.0       # make them likely winners for some rows
+    y[0, 1] = y[0, 0]                                           # two beams of entry 0 with identical logits
+    lp = np.tile(np.linspace(0, -2.0, W, dtype=np.float32), (B, 1))
+    lp[0, 1] = lp[0, 0]                                         # ... and equal totals: ties across beams
+    lp[1, 1:] = -np.inf
+    fin = np.zeros((B, W), np.int32); fin[2, 1] = 1; fin[B - 1] = 1
+    lens = rng.integers(0, 5, (B, W)).astype(np.int64)
+    logits = (y.reshape(B * W, D).astype(np.float64) @ Wo.astype(np.float64) + bo).astype(np.float32).reshape(B, W, V)
+    step = dr.log_softmax(logits, -1)
+    row = np.full(V, np.finfo(np.float32).min, np.float32); row[end] = 0
+    step = np.where(fin[:, :, None].astype(bool), row[None, None, :], step)
+    total = (lp[:, :, None] + step).reshape(B, W * V)
+    order = np.argsort(-total, axis=1, kind='stable')[:, :W]
+    d_lp, d_fin, d_len = dev(lp), dev(fin), dev(lens)
+    word = torch.empty((B, W), dtype=torch.int32, device=DEV); par = torch.empty_like(word)
+    sc = torch.empty((B, W), device=DEV)
+    nb = int(lib().comic_beam_step_dense_workspace(B, W, D, V))
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    L.check(lib().comic_beam_step_dense(P(y), P(Wo), P(bo), d_lp.data_ptr(), d_fin.data_ptr(), d_len.data_ptr(),
+                                        word.data_ptr(), par.data_ptr(), sc.data_ptr(), B, W, D, V, end, ws.data_ptr(), nb,
+                                        stream()))
+    sync()
+    ref_sc = np.take_along_axis(total, order, 1)
+    got_w, got_p, got_sc = word.cpu().numpy(), par.cpu().numpy(), sc.cpu().numpy()
+    # device logits carry ~1e-5 of split-product error: where the oracle's neighbours are closer than that the order may
+    # legitimately differ; everything else must agree exactly, and exact ties (duplicate columns, equal beams) must
+    # resolve to the lower flat index
+    fl = got_p.astype(np.int64) * V + got_w
+    for b in range(B):
+        for k in range(W):
+            if fl[b, k] != order[b, k]:
+                assert abs(total[b, fl[b, k]] - ref_sc[b, k]) <= 2e-4 * max(1.0, abs(ref_sc[b, k])), (b, k, fl[b, k], order[b, k])
+        assert len(set(fl[b].tolist())) == W
+    fin_sc = np.isfinite(ref_sc) & (np.abs(ref_sc) < 1e30)
+    assert_close(np.where(fin_sc, got_sc, 0), np.where(fin_sc, ref_sc, 0), 2e-4, 'beam scores')
+    dup = {3, 7, V - 5}
+    for b in range(B):
+        ws_b = [int(x) for x in got_w[b]]
+        for k in range(W - 1):
+            if ws_b[k] in dup and ws_b[k + 1] in dup and got_p[b, k] == got_p[b, k + 1] and got_sc[b, k] == got_sc[b, k + 1]:
+                assert ws_b[k] < ws_b[k + 1], 'tie between duplicate columns must keep the lower index first'
+    bidx = np.arange(B)[:, None]
+    pf = fin[bidx, got_p].astype(bool)
+    np.testing.assert_array_equal(d_fin.cpu().numpy().astype(bool), pf | (got_w == end))
+    np.testing.assert_array_equal(d_len.cpu().numpy(), lens[bidx, got_p] + (~pf))
+    # an entry with every beam finished keeps its beams (EOS at score + 0), in beam order
+    np.testing.assert_array_equal(got_w[B - 1], np.full(W, end))
+    np.testing.assert_array_equal(got_p[B - 1], np.argsort(-lp[B - 1], kind='stable'))
+
+
 def test_gather_tree_matches_oracle():
     rng = np.random.default_rng(6)
     T, B, W, end = 9, 5, 4, 17
