@@ -222,6 +222,16 @@ class ModelBase(object):
                 oh = self._share['opt_head']
                 oh.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/head_adam_m']))
                 oh.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/head_adam_v']))
+            elif 'opt_head' in self._share:            # TF bundle: per-variable slots of the legacy head
+                from .encoder_head import TF_NAMES
+                oh = self._share['opt_head']
+                key = lambda k, slot: ckpt.ADAM_SCOPE + TF_NAMES[k] + slot
+                if isinstance(oh, optim.MomentumTF) and all(key(k, '/Momentum') in extra for k in TF_NAMES):
+                    oh.m.load({k: extra[key(k, '/Momentum')] for k in TF_NAMES})
+                elif not isinstance(oh, optim.MomentumTF) and all(key(k, '/Adam') in extra and key(k, '/Adam_1') in extra
+                                                                   for k in TF_NAMES):
+                    oh.m.load({k: extra[key(k, '/Adam')] for k in TF_NAMES})
+                    oh.v.load({k: extra[key(k, '/Adam_1')] for k in TF_NAMES})
             if 'optimise/caption/cnn_w_adam_m' in extra and 'opt_cnn' in self._share:
                 ow, ob, _ = self._share['opt_cnn']
                 ow.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_m']))
@@ -279,8 +289,18 @@ class ModelBase(object):
             extra.update(self.head.export_params())
             if not compact and 'opt_head' in self._share:
                 oh = self._share['opt_head']
-                extra.update({'optimise/caption/head_adam_m': oh.m.data.cpu().numpy(),
-                              'optimise/caption/head_adam_v': oh.v.data.cpu().numpy()})
+                if fmt == 'tf':         # per-variable slots under the optimiser's scope, like the decoder's
+                    from .encoder_head import TF_NAMES
+                    hm = oh.m.to_numpy()
+                    if isinstance(oh, optim.MomentumTF):
+                        extra.update({ckpt.ADAM_SCOPE + TF_NAMES[k] + '/Momentum': hm[k] for k in TF_NAMES})
+                    else:
+                        hv = oh.v.to_numpy()
+                        extra.update({ckpt.ADAM_SCOPE + TF_NAMES[k] + '/Adam': hm[k] for k in TF_NAMES})
+                        extra.update({ckpt.ADAM_SCOPE + TF_NAMES[k] + '/Adam_1': hv[k] for k in TF_NAMES})
+                else:
+                    extra.update({'optimise/caption/head_adam_m': oh.m.data.cpu().numpy(),
+                                  'optimise/caption/head_adam_v': oh.v.data.cpu().numpy()})
         if 'opt_cnn' in self._share:      # fine-tuned CNN variables back into the checkpoint layout
             self._share['cnn_params'].update(next(iter(self._share['encoders'].values())).export_params())
             if not compact:

@@ -117,6 +117,36 @@ def test_train_infer_cli_default_backbone(tmp_path):
     assert caps and len(json.load(open(caps[0]))) == 4
 
 
+def test_legacy_head_tf_checkpoint_slots_and_resume(tmp_path):
+    """--legacy (model_base.py:80-91: LN_tanh + im_embed head, trained) with --checkpoint_format tf: the head's optimiser
+    slots are written per variable under the optimiser's scope like the decoder's (`optimise/caption/<var>/Adam[_1]`), and a
+    second invocation of the same run resumes from the bundle (step counter and slots restored)."""
+    from tests import tiny_dataset
+    from comic_amd import tf_bundle
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=4, n_test=4)
+    logs = str(tmp_path / 'experiments')
+    args = ['--dataset_dir', ds, '--log_root', logs, '--batch_size_eval', '4', '--rnn_size', '128', '--rnn_word_size', '64',
+            '--train_mode', 'decoder', '--batch_size_train', '4', '--legacy', 'True', '--checkpoint_format', 'tf']
+    _run(os.path.join(ROOT, 'src', 'train.py'), args + ['--max_epoch', '1'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    run_dirs = glob.glob(os.path.join(logs, 'mscoco', '*_run_01'))
+    assert len(run_dirs) == 1
+    full = sorted(glob.glob(os.path.join(run_dirs[0], 'model-*.index')))
+    assert full
+    names = tf_bundle.list_variables(full[-1][:-len('.index')])
+    for v in ('Model/encoder/LN_tanh/beta', 'Model/encoder/LN_tanh/gamma', 'Model/encoder/im_embed/weight'):
+        assert v in names and 'optimise/caption/' + v + '/Adam' in names and 'optimise/caption/' + v + '/Adam_1' in names, v
+    assert not any('head_adam' in n for n in names)
+    step1 = int(tf_bundle.read_bundle(full[-1][:-len('.index')])['global_step'])
+    _run(os.path.join(ROOT, 'src', 'train.py'), args + ['--max_epoch', '2'])      # the run directory exists: resumes
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    full2 = sorted(glob.glob(os.path.join(run_dirs[0], 'model-*.index')), key=lambda f: int(f.split('model-')[-1].split('.')[0]))
+    step2 = int(tf_bundle.read_bundle(full2[-1][:-len('.index')])['global_step'])
+    assert step2 > step1
+
+
 def test_run_train_step_pipelined_equals_serial(tmp_path):
     """CaptionModel.run_train_step (the reference-API entry, == sess.run(m_train.dec_log_ppl)) with the frozen-CNN
     pipelining on -- the encoder forward of the next step(s) on a second stream, `encoder_group` steps per forward --
