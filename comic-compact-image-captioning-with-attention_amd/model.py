@@ -238,6 +238,14 @@ class ModelBase(object):
                 ow.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_w_adam_v']))
                 ob.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_b_adam_m']))
                 ob.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/cnn_b_adam_v']))
+            elif 'opt_cnn' in self._share:             # TF bundle: per-variable slots of the CNN variables
+                ow, ob, _ = self._share['opt_cnn']
+                enc = next(iter(self._share['encoders'].values()))
+                sc = ckpt.ADAM_SCOPE + 'Model/encoder/cnn/'
+                if isinstance(ow, optim.MomentumTF):
+                    enc.import_slots(ow.m, ob.m, extra, 'Momentum', sc)
+                elif enc.import_slots(ow.m, ob.m, extra, 'Adam', sc):
+                    enc.import_slots(ow.v, ob.v, extra, 'Adam_1', sc)
             print('INFO: Resume training from checkpoint: {}'.format(path))
         if not self.is_training():
             return None
@@ -305,10 +313,19 @@ class ModelBase(object):
             self._share['cnn_params'].update(next(iter(self._share['encoders'].values())).export_params())
             if not compact:
                 ow, ob, _ = self._share['opt_cnn']
-                extra.update({'optimise/caption/cnn_w_adam_m': ow.m.data.cpu().numpy(),
-                              'optimise/caption/cnn_w_adam_v': ow.v.data.cpu().numpy(),
-                              'optimise/caption/cnn_b_adam_m': ob.m.data.cpu().numpy(),
-                              'optimise/caption/cnn_b_adam_v': ob.v.data.cpu().numpy()})
+                if fmt == 'tf':       # per-variable slots under the optimiser's scope: <scope>/Model/encoder/cnn/<var>/Adam[_1]
+                    enc = next(iter(self._share['encoders'].values()))
+                    sc = ckpt.ADAM_SCOPE + 'Model/encoder/cnn/'
+                    if isinstance(ow, optim.MomentumTF):
+                        extra.update({sc + k: v for k, v in enc.export_slots(ow.m, ob.m, 'Momentum').items()})
+                    else:
+                        extra.update({sc + k: v for k, v in enc.export_slots(ow.m, ob.m, 'Adam').items()})
+                        extra.update({sc + k: v for k, v in enc.export_slots(ow.v, ob.v, 'Adam_1').items()})
+                else:
+                    extra.update({'optimise/caption/cnn_w_adam_m': ow.m.data.cpu().numpy(),
+                                  'optimise/caption/cnn_w_adam_v': ow.v.data.cpu().numpy(),
+                                  'optimise/caption/cnn_b_adam_m': ob.m.data.cpu().numpy(),
+                                  'optimise/caption/cnn_b_adam_v': ob.v.data.cpu().numpy()})
         return ckpt.save(save_path, self.global_step, self._share['cnn_params'], self.spec,
                          self.decoder.params.to_numpy(), extra, max_to_keep, fmt=fmt)
 

@@ -708,6 +708,43 @@ class CnnEncoder:
         w = w.reshape(kh, kw, cin_p, cout_p)[:, :, :cin, :cout]
         return w.contiguous().cpu().numpy(), flat_b.view('b%d' % i)[:cout].cpu().numpy().copy()
 
+    def _pack_into(self, i, flat_w, flat_b, w_hwio, vec):
+        """Inverse of _unpack: a variable-shaped (HWIO array, per-channel vector) pair into the packed master-layout
+        buffers of weight i (padding channels zero)."""
+        torch = self.torch
+        prefix, kh, kw, cin, cout, stem = self.plan.weights[i]
+        cin_p, cout_p = self.plan.wphys[i]
+        K = kh * kw * cin_p
+        wp = torch.zeros((kh, kw, cin_p, cout_p), dtype=torch.float32, device=self.device)
+        wp[:, :, :cin, :cout] = torch.from_numpy(np.ascontiguousarray(w_hwio, np.float32)).to(self.device)
+        m = flat_w.view('w%d' % i)
+        if stem:
+            m.view(K, cout_p).copy_(wp.reshape(K, cout_p))
+        else:
+            mv = m.view(cout_p, -1)
+            mv.zero_()
+            mv[:, :K].copy_(wp.reshape(K, cout_p).t())
+        b = flat_b.view('b%d' % i)
+        b.zero_()
+        b[:cout].copy_(torch.from_numpy(np.ascontiguousarray(vec, np.float32)).to(self.device))
+
+    def export_slots(self, flat_w, flat_b, suffix):
+        """Optimiser slot buffers with the masters' layout -> {`<variable name>/<suffix>`: array of the variable's shape}."""
+        out = {}
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            w, b = self._unpack(i, flat_w, flat_b)
+            out[prefix + '/weights/' + suffix], out[prefix + '/BatchNorm/beta/' + suffix] = w, b
+        return out
+
+    def import_slots(self, flat_w, flat_b, arrays, suffix, scope=''):
+        """Inverse of export_slots; returns False (and loads nothing) unless every slot is present."""
+        keys = [(scope + p[0] + '/weights/' + suffix, scope + p[0] + '/BatchNorm/beta/' + suffix) for p in self.plan.weights]
+        if not all(a in arrays and b in arrays for a, b in keys):
+            return False
+        for i, (a, b) in enumerate(keys):
+            self._pack_into(i, flat_w, flat_b, arrays[a], arrays[b])
+        return True
+
     def export_params(self):
         """Trainable CNN variables back in the slim checkpoint layout: {name: HWIO weights / beta}."""
         out = {}

@@ -81,6 +81,11 @@ def test_train_infer_scst_cli(tmp_path):
     np.testing.assert_array_equal(a[km], b[km])         # BN statistics stay frozen (model_base.py:76)
     full = tf_bundle.list_variables(sorted(glob.glob(os.path.join(ft_dir, 'model-*.index')))[-1][:-len('.index')])
     assert 'optimise/caption/beta1_power' in full and 'global_step' in full
+    # the CNN variables' optimiser slots: per variable, under the optimiser's scope, of the variable's shape
+    kk = 'optimise/caption/' + k
+    assert kk + '/Adam' in full and kk + '/Adam_1' in full and not any('cnn_w_adam' in n for n in full)
+    slots = tf_bundle.read_bundle(sorted(glob.glob(os.path.join(ft_dir, 'model-*.index')))[-1][:-len('.index')])
+    assert slots[kk + '/Adam'].shape == b[k].shape and float(np.abs(slots[kk + '/Adam_1']).max()) > 0
     # ---- SCST on top of the fine-tuned run (restores the TF bundle) ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'scst', '--max_epoch', '2',
                                                           '--scst_beam_size', '3'])

@@ -265,6 +265,17 @@ def test_inception_v3_backward_224_f32():
     for k in ('InceptionV3/Conv2d_1a_3x3/weights', 'InceptionV3/Mixed_6b/Branch_2/Conv2d_0c_1x7/weights',
               'InceptionV3/Mixed_7a/Branch_0/Conv2d_1a_3x3/BatchNorm/beta'):
         np.testing.assert_array_equal(ex[k], params[k])
+    # optimiser slots travel per variable (TF-format checkpoints): export -> import into cleared buffers -> same buffers
+    tr_ = enc._train
+    slots = {'sc/' + k: v for k, v in enc.export_slots(tr_.dw, tr_.dbeta, 'Adam').items()}
+    assert slots['sc/InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights/Adam'].shape == (1, 1, 2048, 320)
+    w1, b1 = tr_.dw.like(), tr_.dbeta.like()
+    w1.data.fill_(7.0), b1.data.fill_(7.0)
+    assert not enc.import_slots(w1, b1, slots, 'Adam_1', 'sc/')          # absent slots: nothing loaded
+    assert enc.import_slots(w1, b1, slots, 'Adam', 'sc/')
+    for i in range(len(enc.plan.weights)):
+        assert torch.equal(w1.view('w%d' % i), tr_.dw.view('w%d' % i)), i
+        assert torch.equal(b1.view('b%d' % i), tr_.dbeta.view('b%d' % i)), i
 
 
 _CHAIN = [('c', 'c1', 32, (3, 3), 2, 'VALID'), ('c', 'c2', 64, (3, 3), 1, 'SAME'), ('max',),
