@@ -37,7 +37,11 @@ class DecoderDesc(C.Structure):
         'D', 'E', 'A', 'V', 'C', 'Cg', 'H', 'M', 'Cv', 'fm_projection', 'method', 'prob', 'context_layer',
         'init_method', 'start_id', 'end_id')] + [(n, c_float) for n in (
             'keep_in', 'keep_out', 'keep_alpha', 'map_loss_scale')] + [('flags', C.c_uint32),
-                                                                       ('length_penalty_weight', c_float)]
+                                                                       ('length_penalty_weight', c_float),
+                                                                       ('cell', c_int32)]
+
+
+CELLS = {'LSTM': 0, 'LN_LSTM': 1, 'GRU': 2}          # include/comic_hip.h COMIC_CELL_*
 
 
 # comic_decoder_desc.flags (include/comic_hip.h COMIC_DEC_*).  The library reads no environment: the A/B switches of
@@ -70,7 +74,7 @@ IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 laye
 def is_im2col_tile(tile):
     """Every layer is eligible for these ids (a failure is an error); the patch-resident ids may refuse a layer."""
     return tile <= IM2COL_CONV_TILES or 26 <= tile <= 47        # 48..53: patch-resident with loader waves
-PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb')
+PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb', 'cell_ln', 'K_c', 'b_c')
 
 
 class DecoderParams(C.Structure):

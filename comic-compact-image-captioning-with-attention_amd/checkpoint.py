@@ -22,7 +22,7 @@ import re
 import numpy as np
 
 from . import tf_bundle
-from .decoder import TF_NAMES
+from .decoder import TF_NAMES, CELL_SCOPES
 
 DEC_SCOPE = 'Model/decoder/rnn_decoder/'
 CNN_SCOPE = 'Model/encoder/cnn/'
@@ -36,6 +36,10 @@ def decoder_var_names(spec):
             n = n[spec.init_method]
         if spec.method == 'dot':
             n = n.replace('multi_add_attention/', 'MultiHeadDot/')
+        rnn = getattr(spec, 'rnn_name', 'LSTM')
+        if k in ('K', 'b') and rnn != 'LSTM':
+            scope, kn, bn = CELL_SCOPES[rnn]
+            n = 'rnn_init_input/%s/%s' % (scope, kn if k == 'K' else bn)
         out[k] = DEC_SCOPE + n
     return out
 

@@ -122,6 +122,28 @@ int comic_input_grad_fused(const float* dg, const float* K, const float* mask, f
                            float* dh, const int32_t* lens, int t, int carry, int B, int E, int A, int D,
                            hipStream_t st);
 
+// the reference's other recurrent cells (cells.hip)
+int comic_cell_ln_stride(int D);
+int comic_ln_lstm_fwd(const float* g, int S, const float* ln, const float* c_prev, const float* h_prev, float* gates_act,
+                      float* xhat, float* rstd, float* c_new, float* y, const float* mask_out, float keep_out,
+                      const int32_t* lens, int t, float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld,
+                      hipStream_t st);
+int comic_ln_lstm_bwd(const float* gates_act, const float* xhat, const float* rstd, const float* ln, const float* c_prev,
+                      const float* c_new, const float* dy, const float* dy_part, int S, const float* mask_out,
+                      float keep_out, const int32_t* lens, int t, float* dc, float* dh, float* dg, float* pgrad, int B, int D,
+                      hipStream_t st);
+int comic_ln_lstm_scatter(const float* sums, float* cell_ln_grad, int D, float beta, hipStream_t st);
+int comic_gru_gates_fwd(const float* g1, int S, const float* bias, const float* h_prev, const float* xh, int xh_ld, float* ru,
+                        int ld_ru, float* xh2, int xh2_ld, int B, int D, int EA, hipStream_t st);
+int comic_gru_out_fwd(const float* g2, int S, const float* bias, const float* ru, int ld_ru, const float* h_prev,
+                      float* cand, int ld_cand, float* y, const float* mask_out, float keep_out, const int32_t* lens, int t,
+                      float* h_state, float* xh_next, int xh_ld, int B, int D, hipStream_t st);
+int comic_gru_bwd1(const float* dy, const float* dy_part, int S, const float* mask_out, float keep_out, const int32_t* lens,
+                   int t, float* dh_state, const float* ru, int ld_ru, const float* cand, int ld_cand, const float* h_prev,
+                   float* dpre, int ld_dpre, int B, int D, hipStream_t st);
+int comic_gru_bwd2(float* dxh2, int ld, const float* ru, int ld_ru, const float* h_prev, float* dpre, int ld_dpre, int B,
+                   int D, int EA, hipStream_t st);
+
 namespace {
 
 // Executor switches come with the call (comic_decoder_desc::flags, COMIC_DEC_*): the library reads no environment.
@@ -130,6 +152,8 @@ thread_local uint32_t g_dec_flags = 0;
 struct FlagScope {
   explicit FlagScope(const comic_decoder_desc* d) {
     g_dec_flags = d ? d->flags : 0u;
+    // LN_LSTM / GRU run on the per-step launch chain: the fused / streaming / persistent kernels are BasicLSTMCell's
+    if (d && d->cell != COMIC_CELL_LSTM) g_dec_flags |= COMIC_DEC_NO_FUSED_STEP | COMIC_DEC_NO_PERSIST | COMIC_DEC_NO_PERSIST_BWD;
     comic_persist_set_stamps((g_dec_flags & COMIC_DEC_STAMPS) != 0);
   }
   ~FlagScope() { comic_persist_set_stamps(false); }
@@ -563,6 +587,14 @@ int check_desc(const comic_decoder_desc* d) {
   COMIC_REQUIRE(d->Cv == cv, "decoder: Cv must be %d for fm_projection %d", cv, d->fm_projection);
   const int a = (d->fm_projection == 0 && !d->context_layer) ? d->C : d->D;
   COMIC_REQUIRE(d->A == a, "decoder: attention size A must be %d", a);
+  COMIC_REQUIRE(d->cell >= COMIC_CELL_LSTM && d->cell <= COMIC_CELL_GRU, "decoder: unknown cell %d", d->cell);
+  return 0;
+}
+int check_cell_params(const comic_decoder_desc* d, const comic_decoder_params* p) {
+  COMIC_REQUIRE(p && p->K, "decoder: null cell kernel");
+  if (d->cell == COMIC_CELL_LSTM) COMIC_REQUIRE(p->b, "decoder: LSTM needs its bias");
+  if (d->cell == COMIC_CELL_LN_LSTM) COMIC_REQUIRE(p->cell_ln, "decoder: LN_LSTM needs cell_ln");
+  if (d->cell == COMIC_CELL_GRU) COMIC_REQUIRE(p->b && p->K_c && p->b_c, "decoder: GRU needs b, K_c, b_c");
   return 0;
 }
 
@@ -590,6 +622,7 @@ int memory_projections(const comic_decoder_desc* d, const comic_decoder_params* 
 
 struct InitBufs {
   float *x, *xh, *g, *gates, *c_new;
+  float *lnx = nullptr, *lnr = nullptr;      // LN_LSTM, training: normalised rows [rows][5D] and 1/std [rows][8] of the init step
 };
 
 // _get_rnn_init (model_base.py:651-689) -> c0,h0 [rows,D]
@@ -603,7 +636,21 @@ int rnn_init_fwd(const comic_decoder_desc* d, const comic_decoder_params* p, con
   }
   RC(gemm(im_embed, p->W_init, ib.x, nullptr, rows, EA, d->Cg, d->Cg, EA, EA, 0, 0, 0.f, st));
   RC(comic_dropout_apply(ib.x, mask_init, d->keep_in, ib.xh, (int64_t)rows * EA, (void*)st));
-  // zero initial state: only the first E+A rows of the LSTM kernel contribute
+  // zero initial state: only the first E+A rows of the cell's kernel(s) contribute
+  if (d->cell == COMIC_CELL_LN_LSTM) {
+    RC(gemm(ib.xh, p->K, ib.g, nullptr, rows, 4 * D, EA, EA, 4 * D, 4 * D, 0, 0, 0.f, st));
+    return comic_ln_lstm_fwd(ib.g, 1, p->cell_ln, nullptr, nullptr, ib.gates, ib.lnx, ib.lnr, ib.c_new, nullptr, nullptr, 1.f,
+                             nullptr, 0, c0, h0, rows, D, nullptr, 0, st);
+  }
+  if (d->cell == COMIC_CELL_GRU) {           // r*h = 0: the candidate sees [x ; 0]; gates / candidate kept in ib.gates
+    float* g2 = ib.g + (size_t)rows * 2 * D;
+    RC(gemm(ib.xh, p->K, ib.g, nullptr, rows, 2 * D, EA, EA, 2 * D, 2 * D, 0, 0, 0.f, st));
+    RC(comic_gru_gates_fwd(ib.g, 1, p->b, nullptr, ib.xh, EA, ib.gates, 4 * D, nullptr, 0, rows, D, EA, st));
+    RC(gemm(ib.xh, p->K_c, g2, nullptr, rows, D, EA, EA, D, D, 0, 0, 0.f, st));
+    RC(comic_gru_out_fwd(g2, 1, p->b_c, ib.gates, 4 * D, nullptr, ib.gates + 2 * D, 4 * D, nullptr, nullptr, 1.f, nullptr, 0,
+                         h0, nullptr, 0, rows, D, st));
+    return fill(c0, 0.f, (long)rows * D, st);
+  }
   RC(gemm(ib.xh, p->K, ib.g, p->b, rows, 4 * D, EA, EA, 4 * D, 4 * D, 0, 0, 0.f, st));
   RC(comic_lstm_gates_fwd(ib.g, nullptr, nullptr, ib.gates, ib.c_new, nullptr, nullptr, nullptr, 1.f, nullptr, 0, c0,
                           h0, rows, D, (void*)st));
@@ -613,6 +660,7 @@ int rnn_init_fwd(const comic_decoder_desc* d, const comic_decoder_params* p, con
 // one wrapper step without dropout / imputing (inference)
 struct StepBufs {
   float *xh, *g, *y, *q, *alpha, *ctx, *c2, *h2, *att2;
+  float* xh2 = nullptr;                       // GRU: [x ; att ; r*h]
 };
 int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const comic_attn_desc& ad,
                const float* keys, const float* values, const float* x, const float* c, const float* h,
@@ -621,9 +669,23 @@ int infer_step(const comic_decoder_desc* d, const comic_decoder_params* p, const
   hipLaunchKernelGGL(assemble_input_kernel, dim3(cdiv(rows * Wd, 256)), dim3(256), 0, st, x, att, h, nullptr, 1.f,
                      sb.xh, rows, E, A, D);
   COMIC_LAUNCH_CHECK("assemble_input");
-  RC(gemm(sb.xh, p->K, sb.g, p->b, rows, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
-  RC(comic_lstm_gates_fwd(sb.g, c, h, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0, sb.c2, sb.h2, rows,
-                          D, (void*)st));
+  if (d->cell == COMIC_CELL_LN_LSTM) {
+    RC(gemm(sb.xh, p->K, sb.g, nullptr, rows, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
+    RC(comic_ln_lstm_fwd(sb.g, 1, p->cell_ln, c, h, nullptr, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0, sb.c2,
+                         sb.h2, rows, D, nullptr, 0, st));
+  } else if (d->cell == COMIC_CELL_GRU) {
+    float* ru = sb.g + (size_t)rows * 2 * D;             // sb.g: [rows][2D] product, then [rows][2D] r | u
+    RC(gemm(sb.xh, p->K, sb.g, nullptr, rows, 2 * D, Wd, Wd, 2 * D, 2 * D, 0, 0, 0.f, st));
+    RC(comic_gru_gates_fwd(sb.g, 1, p->b, h, sb.xh, Wd, ru, 2 * D, sb.xh2, Wd, rows, D, E + A, st));
+    RC(gemm(sb.xh2, p->K_c, sb.q, nullptr, rows, D, Wd, Wd, D, D, 0, 0, 0.f, st));      // sb.q: free until the query product
+    RC(comic_gru_out_fwd(sb.q, 1, p->b_c, ru, 2 * D, h, nullptr, 0, sb.y, nullptr, 1.f, nullptr, 0, sb.h2, nullptr, 0, rows, D,
+                         st));
+    RC(fill(sb.c2, 0.f, (long)rows * D, st));            // the state is h alone; c rides along as zeros
+  } else {
+    RC(gemm(sb.xh, p->K, sb.g, p->b, rows, 4 * D, Wd, Wd, 4 * D, 4 * D, 0, 0, 0.f, st));
+    RC(comic_lstm_gates_fwd(sb.g, c, h, nullptr, nullptr, nullptr, sb.y, nullptr, 1.f, nullptr, 0, sb.c2, sb.h2, rows,
+                            D, (void*)st));
+  }
   RC(gemm(sb.y, p->W_q, sb.q, nullptr, rows, D, D, D, D, D, 0, 0, 0.f, st));
   RC(comic_attn_step_fwd(&ad, keys, values, sb.q, p->ln_g, p->ln_b, p->v, p->tau, nullptr, 1.f, sb.alpha,
                          alpha_d_out, sb.ctx, (void*)st));
@@ -749,6 +811,11 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>((long)T * ((B + 15) / 16) * 16 * D);                                  // summed d q (blocked)
   w.take<float>(TB * 2 * D);                                                   // d att | d h
   w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
+  if (d->cell == COMIC_CELL_LN_LSTM) {           // normalised rows, 1/std and LayerNorm gradient rows of every step + the init step
+    w.take<float>((TB + B) * 5 * D); w.take<float>((TB + B) * 8); w.take<float>((TB + B) * 10 * D); w.take<float>(10 * D);
+  } else if (d->cell == COMIC_CELL_GRU) {        // [x ; att ; r*h] of every step, the two d-operand products of a step, bias sums
+    w.take<float>(TB * Wd); w.take<float>(2 * B * Wd); w.take<float>(4 * D);
+  }
   return (int64_t)w.off;
 }
 
@@ -823,7 +890,17 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dq_sum = w.take<float>(TB16 * D);
   float* dstate = w.take<float>(TB * 2 * D);
   float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
+  const int cell = d->cell;
+  float *lnx_all = nullptr, *lnr_all = nullptr, *lnpg = nullptr, *cell_tmp = nullptr, *xh2_all = nullptr, *gru_dxh = nullptr;
+  if (cell == COMIC_CELL_LN_LSTM) {
+    lnx_all = w.take<float>((TB + B) * 5 * D); lnr_all = w.take<float>((TB + B) * 8);
+    lnpg = w.take<float>((TB + B) * 10 * D); cell_tmp = w.take<float>(10L * D);
+    ib.lnx = lnx_all + TB * 5 * D; ib.lnr = lnr_all + TB * 8;      // the init step's rows sit behind the time steps'
+  } else if (cell == COMIC_CELL_GRU) {
+    xh2_all = w.take<float>(TB * Wd); gru_dxh = w.take<float>(2L * B * Wd); cell_tmp = w.take<float>(4L * D);
+  }
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
+  RC(check_cell_params(d, p));
 
   const comic_attn_desc ad = attn_desc(d, B);
   const float* values = nullptr;
@@ -913,6 +990,21 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                                cnew_all + (size_t)t * B * D, y_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
                                d->keep_out, lens, t, cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D,
                                xh_n ? xh_n + EA : nullptr, Wd, B, D, Wd, st));
+    } else if (cell == COMIC_CELL_LN_LSTM) {
+      RC(comic_gemm_f32_partial(xh_t, p->K, B, 4 * D, Wd, Wd, 4 * D, 0, part, kSplitKBytes, &S1, st));
+      RC(comic_ln_lstm_fwd(part, S1, p->cell_ln, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
+                           lnx_all + (size_t)t * B * 5 * D, lnr_all + (size_t)t * B * 8, cnew_all + (size_t)t * B * D, y_t,
+                           drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t,
+                           cs + (size_t)(t + 1) * B * D, hs + (size_t)(t + 1) * B * D, B, D, xh_n ? xh_n + EA : nullptr, Wd, st));
+    } else if (cell == COMIC_CELL_GRU) {         // gates_all[t]: r | u | candidate | -
+      float* ga = gates_all + (size_t)t * B * 4 * D;
+      float* xh2_t = xh2_all + (size_t)t * B * Wd;
+      RC(comic_gemm_f32_partial(xh_t, p->K, B, 2 * D, Wd, Wd, 2 * D, 0, part, kSplitKBytes, &S1, st));
+      RC(comic_gru_gates_fwd(part, S1, p->b, h_prev, xh_t, Wd, ga, 4 * D, xh2_t, Wd, B, D, EA, st));
+      RC(comic_gemm_f32_partial(xh2_t, p->K_c, B, D, Wd, Wd, D, 0, part, kSplitKBytes, &S1, st));
+      RC(comic_gru_out_fwd(part, S1, p->b_c, ga, 4 * D, h_prev, ga + 2 * D, 4 * D, y_t,
+                           drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t,
+                           hs + (size_t)(t + 1) * B * D, xh_n ? xh_n + EA : nullptr, Wd, B, D, st));
     } else {
       RC(comic_gemm_f32_partial(xh_t, p->K, B, 4 * D, Wd, Wd, 4 * D, 0, part, kSplitKBytes, &S1, st));
       RC(comic_lstm_gates_fwd_ex(part, c_prev, h_prev, gates_all + (size_t)t * B * 4 * D,
@@ -1031,6 +1123,27 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       RC(comic_lstm_grad_fused(dq_t, wq_panel, gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
                                cnew_all + (size_t)t * B * D, dy_t, drop_out ? mask_out + (size_t)t * B * D : nullptr,
                                d->keep_out, lens, t, dc, dh, dg_t, B, D, st));
+    } else if (cell == COMIC_CELL_LN_LSTM) {
+      RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
+      RC(comic_ln_lstm_bwd(gates_all + (size_t)t * B * 4 * D, lnx_all + (size_t)t * B * 5 * D, lnr_all + (size_t)t * B * 8,
+                           p->cell_ln, cs + (size_t)t * B * D, cnew_all + (size_t)t * B * D, dy_t, part, S3,
+                           drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dc, dh, dg_t,
+                           lnpg + (size_t)t * B * 10 * D, B, D, st));
+    } else if (cell == COMIC_CELL_GRU) {         // dg_t: d r_pre | d u_pre | d candidate_pre | -
+      const float* ga = gates_all + (size_t)t * B * 4 * D;
+      const float* h_prev = hs + (size_t)t * B * D;
+      float* slice1 = gru_dxh + (size_t)B * Wd;
+      RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
+      RC(comic_gru_bwd1(dy_t, part, S3, drop_out ? mask_out + (size_t)t * B * D : nullptr, d->keep_out, lens, t, dh, ga, 4 * D,
+                        ga + 2 * D, 4 * D, h_prev, dg_t, 4 * D, B, D, st));
+      RC(gemm(dg_t + 2 * D, p->K_c, slice1, nullptr, B, Wd, D, 4 * D, D, Wd, 0, 1, 0.f, st));
+      RC(comic_gru_bwd2(slice1, Wd, ga, 4 * D, h_prev, dg_t, 4 * D, B, D, EA, st));
+      RC(gemm(dg_t, p->K, gru_dxh, nullptr, B, Wd, 2 * D, 4 * D, 2 * D, Wd, 0, 1, 0.f, st));
+      hipLaunchKernelGGL(input_bwd_kernel, dim3(cdiv(B * Wd, 256)), dim3(256), 0, st, gru_dxh,
+                         drop_in ? mask_in + (size_t)t * B * EA : nullptr, d->keep_in, demb + (size_t)t * B * E,
+                         datt, dh, lens, t, carry, B, E, A, D, 2);
+      COMIC_LAUNCH_CHECK("input_bwd");
+      continue;
     } else {
       RC(comic_gemm_f32_partial(dq_t, p->W_q, B, D, D, D, D, 1, part, kSplitKBytes, &S3, st));
       RC(comic_lstm_gates_bwd_ex(gates_all + (size_t)t * B * 4 * D, cs + (size_t)t * B * D,
@@ -1081,13 +1194,44 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   glane.main_ws();
   // lane A: output bias, LSTM kernel and bias, then the rnn init (which accumulates into both)
   RC(comic_colsum_ws(dlogits, gr->b_o, Tp * B, V, 0.f, (float*)g_splitk_ws, st));
-  RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
-  RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
+  if (cell == COMIC_CELL_GRU) {
+    RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 2 * D, Tp * B, Wd, 4 * D, 2 * D, 1, 0, 0.f, st));
+    RC(gemm_big(xh2_all, dg_all + 2 * D, gr->K_c, nullptr, Wd, D, Tp * B, Wd, 4 * D, D, 1, 0, 0.f, st));
+    RC(comic_colsum_ws(dg_all, cell_tmp, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
+    COMIC_REQUIRE(hipMemcpyAsync(gr->b, cell_tmp, sizeof(float) * 2 * D, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                      hipMemcpyAsync(gr->b_c, cell_tmp + 2 * D, sizeof(float) * D, hipMemcpyDeviceToDevice, st) == hipSuccess,
+                  "train_step: bias gradient copy");
+  } else {
+    RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
+    if (cell == COMIC_CELL_LSTM) RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
+  }
   float* dx_im = nullptr;  // gradient w.r.t. (im_embed * W_init)
   int n_init = 0;
   if (d->init_method == 1) {
     dx_im = dh;
     n_init = D;
+  } else if (cell == COMIC_CELL_LN_LSTM) {
+    RC(comic_ln_lstm_bwd(ib.gates, ib.lnx, ib.lnr, p->cell_ln, nullptr, ib.c_new, nullptr, nullptr, 0, nullptr, 1.f, nullptr, 0,
+                         dc, dh, ib.g, lnpg + (size_t)Tp * B * 10 * D, B, D, st));
+    RC(gemm(ib.xh, ib.g, gr->K, nullptr, EA, 4 * D, B, EA, 4 * D, 4 * D, 1, 0, 1.f, st));
+    RC(gemm(ib.g, p->K, dx_init, nullptr, B, EA, 4 * D, 4 * D, 4 * D, EA, 0, 1, 0.f, st));
+    if (drop_in) RC(comic_dropout_apply(dx_init, mask_init_in, d->keep_in, dx_init, (int64_t)B * EA, (void*)st));
+    dx_im = dx_init;
+    n_init = EA;
+  } else if (cell == COMIC_CELL_GRU) {        // zero state: d r_pre = 0
+    RC(fill(ib.g, 0.f, (long)B * 4 * D, st));
+    RC(comic_gru_bwd1(nullptr, nullptr, 0, nullptr, 1.f, nullptr, 0, dh, ib.gates, 4 * D, ib.gates + 2 * D, 4 * D, nullptr,
+                      ib.g, 4 * D, B, D, st));
+    RC(gemm(ib.xh, ib.g, gr->K, nullptr, EA, 2 * D, B, EA, 4 * D, 2 * D, 1, 0, 1.f, st));
+    RC(gemm(ib.xh, ib.g + 2 * D, gr->K_c, nullptr, EA, D, B, EA, 4 * D, D, 1, 0, 1.f, st));
+    RC(comic_colsum(ib.g, cell_tmp, B, 4 * D, 0.f, (void*)st));
+    RC(comic_axpy(gr->b, cell_tmp, 1.f, 2 * D, (void*)st));
+    RC(comic_axpy(gr->b_c, cell_tmp + 2 * D, 1.f, D, (void*)st));
+    RC(gemm(ib.g, p->K, dx_init, nullptr, B, EA, 2 * D, 4 * D, 2 * D, EA, 0, 1, 0.f, st));
+    RC(gemm(ib.g + 2 * D, p->K_c, dx_init, nullptr, B, EA, D, 4 * D, D, EA, 0, 1, 1.f, st));
+    if (drop_in) RC(comic_dropout_apply(dx_init, mask_init_in, d->keep_in, dx_init, (int64_t)B * EA, (void*)st));
+    dx_im = dx_init;
+    n_init = EA;
   } else {
     RC(comic_lstm_gates_bwd(ib.gates, nullptr, ib.c_new, nullptr, nullptr, 1.f, nullptr, 0, dc, dh, ib.g, B, D,
                             (void*)st));
@@ -1097,6 +1241,11 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (drop_in) RC(comic_dropout_apply(dx_init, mask_init_in, d->keep_in, dx_init, (int64_t)B * EA, (void*)st));
     dx_im = dx_init;
     n_init = EA;
+  }
+  if (cell == COMIC_CELL_LN_LSTM) {           // LayerNorm gains / shifts: column sums of the per-row gradient rows
+    const int rows = Tp * B + (d->init_method == 1 ? 0 : B);      // (the init step wrote its rows behind step Tp - 1's)
+    RC(comic_colsum_ws(lnpg, cell_tmp, rows, 10 * D, 0.f, (float*)g_splitk_ws, st));
+    RC(comic_ln_lstm_scatter(cell_tmp, gr->cell_ln, D, 0.f, st));
   }
   RC(gemm_big(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
   if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
@@ -1109,7 +1258,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     auto add = [&](float* ptr, long n) {
       if (ptr && n > 0 && k < 16) { gr_.p[k] = ptr; gr_.n[k] = n; ++k; }
     };
-    add(gr->W_init, (long)d->Cg * n_init); add(gr->K, (long)Wd * 4 * D); add(gr->b, 4L * D);
+    add(gr->W_init, (long)d->Cg * n_init); add(gr->K, (long)Wd * 4 * D); add(gr->b, 4L * D);      // (LSTM only: persist)
     add(gr->W_m, (long)d->C * D);
     if (d->fm_projection == 1) add(gr->W_v, (long)d->C * D);
     add(gr->W_q, (long)D * D);
@@ -1151,6 +1300,7 @@ extern "C" int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));  // streaming LSTM step
   w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));     // ... W_q, y fragments
   w.take<unsigned long long>(kBeamCntSteps);                       // beam search: per-step completion counters
+  if (d->cell == COMIC_CELL_GRU) w.take<float>(R * Wd);            // GRU: [x ; att ; r*h]
   if (rows <= 64) {                                                // persistent greedy loop: hand-off buffers of all steps
     const long S = std::max(1, max_steps);
     w.take<float>(S * R * Wd); w.take<float>(S * R * D); w.take<float>(S * R * D); w.take<float>(S * R * 132);
@@ -1194,6 +1344,7 @@ InferBufs carve_infer(const comic_decoder_desc* d, int rows, void* ws, int64_t b
   b.kfrag = w.take<float>(comic_lstm_stream_kfrag_floats(d->D, (int)Wd)); b.xfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, (int)Wd));
   b.wqfrag = w.take<float>(comic_stream_gemm_wfrag_floats(d->D, d->D)); b.yfrag = w.take<float>(comic_lstm_stream_xfrag_floats(rows, d->D));
   b.beam_cnt = w.take<unsigned long long>(kBeamCntSteps);
+  if (d->cell == COMIC_CELL_GRU) b.sb.xh2 = w.take<float>(R * Wd);
   if (rows <= 64 && max_steps > 0) {
     const long S = max_steps;
     b.p_xh = w.take<float>(S * R * Wd); b.p_y = w.take<float>(S * R * D); b.p_q = w.take<float>(S * R * D);

@@ -29,7 +29,17 @@ TF_NAMES = {
     'ln_g': 'multi_add_attention/LN_tanh/gamma', 'ln_b': 'multi_add_attention/LN_tanh/beta',
     'tau': 'softmax_temperature', 'W_a': 'a_layer/kernel',
     'W_o': 'output_projection/kernel', 'b_o': 'output_projection/bias', 'emb': 'embedding_map',
+    # --rnn_name GRU: tf.contrib.rnn.GRUCell's candidate pair (its gates pair takes K / b)
+    'K_c': 'rnn_init_input/gru_cell/candidate/kernel', 'b_c': 'rnn_init_input/gru_cell/candidate/bias',
 }
+# per cell: TF scope of the cell's variables and the names of K / b inside it (model_base.py:606-632)
+CELL_SCOPES = {'LSTM': ('basic_lstm_cell', 'kernel', 'bias'), 'LN_LSTM': ('layer_norm_basic_lstm_cell', 'kernel', None),
+               'GRU': ('gru_cell', 'gates/kernel', 'gates/bias')}
+# --rnn_name LN_LSTM: LayerNormBasicLSTMCell's five layer_norm scopes, in the order of comic_decoder_params::cell_ln
+LN_LSTM_NORMS = (('i', 'input'), ('j', 'transform'), ('f', 'forget'), ('o', 'output'), ('c', 'state'))
+for _k, _scope in LN_LSTM_NORMS:
+    TF_NAMES['cln_%sg' % _k] = 'rnn_init_input/layer_norm_basic_lstm_cell/%s/gamma' % _scope
+    TF_NAMES['cln_%sb' % _k] = 'rnn_init_input/layer_norm_basic_lstm_cell/%s/beta' % _scope
 
 
 @dataclass
@@ -57,6 +67,8 @@ class DecoderSpec:
     l2_decay: float = 1e-5
     recurrent_dropout: bool = False      # DropoutWrapper(variational_recurrent=True): ONE input / output mask row
                                          # for all batch rows and time steps of a run [TF-1.9: noise shape [1, size]]
+    rnn_name: str = 'LSTM'               # 'LSTM' | 'LN_LSTM' | 'GRU' (model_base.py:606-632); the persistent / fused /
+                                         # streaming kernels are BasicLSTMCell's, the other two run per-step launches
 
     @property
     def A(self):                     # model_base.py:611-615
@@ -69,8 +81,8 @@ class DecoderSpec:
     @classmethod
     def from_config(cls, c, fm_shape, im_embed_size):
         """c: reference-style Config (token_type, radix_base, rnn_size, ... itow/wtoi)."""
-        if c.rnn_name != 'LSTM':
-            raise NotImplementedError('only rnn_name=LSTM is on the MI355X hot path')
+        if c.rnn_name not in L.CELLS:
+            raise ValueError('Only `LSTM`, `LN_LSTM` and `GRU` are accepted.')      # model_base.py:631
         if c.attn_alignment_method not in ('add_LN', 'dot'):
             raise ValueError('Invalid alignment method.')          # model_base.py:133-138
         if c.attn_probability_fn not in ('softmax', 'sigmoid'):
@@ -85,14 +97,23 @@ class DecoderSpec:
                    init_method=c.rnn_init_method, token_type=c.token_type, start_id=start, end_id=end,
                    dropout_rnn_in=getattr(c, 'dropout_rnn_in', 0.35), dropout_rnn_out=getattr(c, 'dropout_rnn_out', 0.35),
                    attn_keep_prob=c.attn_keep_prob, map_loss_scale=getattr(c, 'rnn_map_loss_scale', 1.0),
-                   l2_decay=getattr(c, 'l2_decay', 1e-5), recurrent_dropout=bool(getattr(c, 'rnn_recurr_dropout', False)))
+                   l2_decay=getattr(c, 'l2_decay', 1e-5), recurrent_dropout=bool(getattr(c, 'rnn_recurr_dropout', False)),
+                   rnn_name=c.rnn_name)
 
     def param_shapes(self):
         D, E, A, V, C_, Cg = self.D, self.E, self.A, self.V, self.C, self.Cg
         s = {}
         s['W_init'] = (Cg, E + A) if self.init_method == 'first_input' else (Cg, D)
-        s['K'] = (E + A + D, 4 * D)
-        s['b'] = (4 * D,)
+        if self.rnn_name == 'GRU':
+            s['K'] = (E + A + D, 2 * D); s['b'] = (2 * D,)
+            s['K_c'] = (E + A + D, D); s['b_c'] = (D,)
+        elif self.rnn_name == 'LN_LSTM':       # no bias; the ten LayerNorm vectors are consecutive views (cell_ln)
+            s['K'] = (E + A + D, 4 * D)
+            for k, _ in LN_LSTM_NORMS:
+                s['cln_%sg' % k] = (D,); s['cln_%sb' % k] = (D,)
+        else:
+            s['K'] = (E + A + D, 4 * D)
+            s['b'] = (4 * D,)
         s['W_m'] = (C_, D)
         if self.fm_projection == 'independent':
             s['W_v'] = (C_, D)
@@ -121,6 +142,7 @@ class DecoderSpec:
         d.keep_alpha = self.attn_keep_prob if training else 1.0
         d.map_loss_scale = self.map_loss_scale
         d.flags = L.decoder_flags_from_env()
+        d.cell = L.CELLS[self.rnn_name]
         return d
 
 
@@ -138,9 +160,11 @@ def init_params(spec: DecoderSpec, seed=0):
     rng = np.random.default_rng(seed)
     p = {}
     for k, shp in spec.param_shapes().items():
-        if k in ('b', 'b_o', 'ln_b'):
+        if k == 'b' and spec.rnn_name == 'GRU':
+            p[k] = np.ones(shp, np.float32)                        # [TF-1.9] GRUCell: gates bias starts at 1.0
+        elif k in ('b', 'b_o', 'ln_b', 'b_c') or (k.startswith('cln_') and k.endswith('b')):
             p[k] = np.zeros(shp, np.float32)
-        elif k == 'ln_g':
+        elif k == 'ln_g' or (k.startswith('cln_') and k.endswith('g')):
             p[k] = np.ones(shp, np.float32)
         elif k == 'tau':
             p[k] = np.array(5.0, np.float32)                       # ops_rnn.py:559
@@ -192,6 +216,8 @@ class FlatParams:
         base = self.data.data_ptr()
         for k in L.PARAM_NAMES:
             setattr(t, k, base + 4 * self.offsets[k] if k in self.offsets else None)
+        if 'cln_ig' in self.offsets:          # LN_LSTM: the ten vectors are consecutive views, ALIGN-padded (= the C stride)
+            t.cell_ln = base + 4 * self.offsets['cln_ig']
         return t
 
     def n_params(self):

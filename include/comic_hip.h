@@ -392,7 +392,11 @@ typedef struct comic_decoder_desc {
                                           results agree to fp32 summation order).  The library reads no environment. */
   float length_penalty_weight;         /* comic_decoder_beam only: BeamSearchDecoder(length_penalty_weight) -- candidates
                                           are ranked by total / ((5 + length) / 6)^w (ops_rnn.py:96, infer.py:65); 0 = none */
+  int32_t cell;                        /* COMIC_CELL_*: --rnn_name (src/model_base.py:606-632) */
 } comic_decoder_desc;
+#define COMIC_CELL_LSTM 0               /* tf.contrib.rnn.BasicLSTMCell: K [E+A+D][4D], b [4D] */
+#define COMIC_CELL_LN_LSTM 1            /* tf.contrib.rnn.LayerNormBasicLSTMCell: K [E+A+D][4D], no bias, cell_ln */
+#define COMIC_CELL_GRU 2                /* tf.contrib.rnn.GRUCell: K [E+A+D][2D] + b [2D] (gates), K_c [E+A+D][D] + b_c [D] (candidate) */
 #define COMIC_DEC_NO_PERSIST 1u         /* time loops as per-step launches (forward and backward; greedy too) */
 #define COMIC_DEC_NO_PERSIST_BWD 2u     /* backward time loop as per-step launches */
 #define COMIC_DEC_NO_FUSED_STEP 4u      /* split-K GEMM + element-wise kernel chain instead of the fused step kernels */
@@ -407,6 +411,9 @@ typedef struct comic_decoder_desc {
 /* Parameter (or gradient) table; every pointer is a view into one flat fp32 buffer. */
 typedef struct comic_decoder_params {
   float *W_init, *K, *b, *W_m, *W_v, *W_q, *v, *ln_g, *ln_b, *tau, *W_a, *W_o, *b_o, *emb;
+  float* cell_ln;   /* LN_LSTM: ten [D] vectors gamma, beta of the scopes input, transform, forget, output, state, in that
+                       order, (D + 63) / 64 * 64 floats apart; NULL otherwise */
+  float *K_c, *b_c; /* GRU: candidate kernel and bias; NULL otherwise */
 } comic_decoder_params;
 
 /* Workspace size in bytes for a training step at (B, T, M) / a decode at rows=B*W. */

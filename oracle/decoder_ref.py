@@ -22,6 +22,9 @@ Reference anchors
 Short parameter keys -> reference variable (scope Model/decoder/rnn_decoder/):
   W_init  rnn_init_input/projection/weight | rnn_initial_state/weight
   K, b    .../basic_lstm_cell/{kernel,bias}
+          rnn_name LN_LSTM: .../layer_norm_basic_lstm_cell/kernel (no bias) and cln_{i,j,f,o,c}{g,b} =
+          .../layer_norm_basic_lstm_cell/{input,transform,forget,output,state}/{gamma,beta}
+          rnn_name GRU: K, b = .../gru_cell/gates/{kernel,bias}; K_c, b_c = .../gru_cell/candidate/{kernel,bias}
   W_m     memory_layer/kernel        W_v  value_layer/kernel (independent only)
   W_q     query_layer/kernel         v    attention_v
   ln_g, ln_b  LN_tanh/{gamma,beta}   tau  softmax_temperature
@@ -36,6 +39,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 LN_EPS = 1e-12  # tf.contrib.layers.layer_norm variance_epsilon
+LN_LSTM_NORMS = ('i', 'j', 'f', 'o', 'c')     # input, transform, forget, output, state
 
 
 @dataclass
@@ -60,6 +64,7 @@ class DecoderConfig:
     l2_decay: float = 1e-5
     start_id: int = 256
     end_id: int = 257
+    rnn_name: str = 'LSTM'         # 'LSTM' | 'LN_LSTM' | 'GRU'   (model_base.py:606-632)
 
     @property
     def attn_size(self):           # A   (model_base.py:611-615)
@@ -91,8 +96,19 @@ def init_params(cfg: DecoderConfig, seed=0, dtype=np.float32):
         p['W_init'] = xavier_uniform(rng, (Cg, E + A), dtype)
     else:
         p['W_init'] = xavier_uniform(rng, (Cg, D), dtype)
-    p['K'] = xavier_uniform(rng, (E + A + D, 4 * D), dtype)
-    p['b'] = np.zeros(4 * D, dtype)
+    if cfg.rnn_name == 'GRU':       # [TF-1.9] GRUCell: gates bias starts at 1.0, candidate bias at 0
+        p['K'] = xavier_uniform(rng, (E + A + D, 2 * D), dtype)
+        p['b'] = np.ones(2 * D, dtype)
+        p['K_c'] = xavier_uniform(rng, (E + A + D, D), dtype)
+        p['b_c'] = np.zeros(D, dtype)
+    elif cfg.rnn_name == 'LN_LSTM':  # [TF-1.9] LayerNormBasicLSTMCell(layer_norm=True): no bias, gain 1 / shift 0
+        p['K'] = xavier_uniform(rng, (E + A + D, 4 * D), dtype)
+        for n in LN_LSTM_NORMS:
+            p['cln_%sg' % n] = np.ones(D, dtype)
+            p['cln_%sb' % n] = np.zeros(D, dtype)
+    else:
+        p['K'] = xavier_uniform(rng, (E + A + D, 4 * D), dtype)
+        p['b'] = np.zeros(4 * D, dtype)
     p['W_m'] = xavier_uniform(rng, (C, D), dtype)
     if cfg.cnn_fm_projection == 'independent':
         p['W_v'] = xavier_uniform(rng, (C, D), dtype)
@@ -191,6 +207,41 @@ def lstm_cell(p, xin, c, h):
     return c2, h2, (si, tj, sf, so, tc)
 
 
+def ln_lstm_cell(p, xin, c, h):
+    """tf.contrib.rnn.LayerNormBasicLSTMCell(num_units) [TF-1.9 contrib/rnn/python/ops/rnn_cell.py]: layer_norm=True,
+    forget_bias 1.0, norm_gain 1 / norm_shift 0 initialisers, dropout_keep_prob 1: concat = [x,h] K (NO bias);
+    i, j, f, o each through layers.layer_norm (scopes input / transform / forget / output); new_c =
+    c*sigmoid(f + 1) + sigmoid(i)*tanh(j), then LN (scope state) -- the NORMALISED value is the new cell state --
+    new_h = tanh(new_c) * sigmoid(o)."""
+    D = c.shape[-1]
+    g = np.concatenate([xin, h], axis=1) @ p['K']
+    pre, xh, rs = [], [], []
+    for k, n in enumerate('ijfo'):
+        z = g[:, k * D:(k + 1) * D]
+        y, mean, rstd = layer_norm_tf(z, p['cln_%sg' % n], p['cln_%sb' % n])
+        pre.append(y); xh.append((z - mean) * rstd); rs.append(rstd)
+    si, tj, sf, so = sigmoid(pre[0]), np.tanh(pre[1]), sigmoid(pre[2] + 1.0), sigmoid(pre[3])
+    craw = c * sf + si * tj
+    c2, mean, rstd = layer_norm_tf(craw, p['cln_cg'], p['cln_cb'])
+    xh.append((craw - mean) * rstd); rs.append(rstd)
+    tc = np.tanh(c2)
+    return c2, tc * so, (si, tj, sf, so, tc, xh, rs)
+
+
+def gru_cell(p, xin, c, h):
+    """tf.contrib.rnn.GRUCell [TF-1.9 rnn_cell_impl.GRUCell.call]: [r,u] = sigmoid([x,h] W_g + b_g);
+    cand = tanh([x, r*h] W_c + b_c); new_h = u*h + (1-u)*cand.  The state is h alone; `c` rides along untouched."""
+    D = h.shape[-1]
+    ru = sigmoid(np.concatenate([xin, h], axis=1) @ p['K'] + p['b'])
+    r, u = ru[:, :D], ru[:, D:]
+    cand = np.tanh(np.concatenate([xin, r * h], axis=1) @ p['K_c'] + p['b_c'])
+    return c, u * h + (1 - u) * cand, (r, u, cand)
+
+
+def rnn_cell(p, cfg, xin, c, h):
+    return {'LSTM': lstm_cell, 'LN_LSTM': ln_lstm_cell, 'GRU': gru_cell}[cfg.rnn_name](p, xin, c, h)
+
+
 def layer_norm_tf(z, g, b):
     """tf.contrib.layers.layer_norm [TF-1.9]: moments over the last axis (biased var),
     nn.batch_normalization(x, mean, var, beta, gamma, 1e-12) = x*inv + (beta - mean*inv),
@@ -252,7 +303,7 @@ def rnn_init(p, cfg, im_embed, mask_in=None):
     else:
         x = im_embed @ p['W_init']
         u = dropout(x, mask_in, 1.0 - cfg.dropout_rnn_in)
-        c0, h0, gc = lstm_cell(p, u, np.zeros((B, D), dt), np.zeros((B, D), dt))
+        c0, h0, gc = rnn_cell(p, cfg, u, np.zeros((B, D), dt), np.zeros((B, D), dt))
         cache.update(u=u, gates=gc)
     return c0, h0, cache
 
@@ -263,7 +314,7 @@ def decoder_step(p, cfg, keys, values, x_t, c, h, att, masks=None):
     m = masks or {}
     xin = np.concatenate([x_t, att], axis=1)
     u = dropout(xin, m.get('in'), 1.0 - cfg.dropout_rnn_in)
-    c2, h2, gc = lstm_cell(p, u, c, h)
+    c2, h2, gc = rnn_cell(p, cfg, u, c, h)
     y = dropout(h2, m.get('out'), 1.0 - cfg.dropout_rnn_out)
     q = y @ p['W_q']
     alpha, ac = attention_scores(p, cfg, keys, q)
@@ -380,6 +431,55 @@ def _lstm_backward(p, cache_gates, c_prev, dc2, dh2, D):
     return dg, dc_prev
 
 
+def _ln_backward(dy, xhat, rstd, gamma):
+    """y = xhat*gamma + beta -> (dz, dgamma, dbeta), rows independent."""
+    dxh = dy * gamma
+    dz = rstd * (dxh - dxh.mean(axis=-1, keepdims=True) - xhat * (dxh * xhat).mean(axis=-1, keepdims=True))
+    return dz, (dy * xhat).sum(axis=0), dy.sum(axis=0)
+
+
+def _cell_backward(p, cfg, grads, cache_gates, xh_rows, h_prev, c_prev, dc2, dh2):
+    """Backward of one cell call: accumulates the cell's parameter gradients, returns
+    (d [x ; h] of the cell input rows `xh_rows` = [u ; h_prev], d c_prev)."""
+    D = h_prev.shape[-1]
+    EA = xh_rows.shape[1] - D
+    if cfg.rnn_name == 'LSTM':
+        dg, dc_prev = _lstm_backward(p, cache_gates, c_prev, dc2, dh2, D)
+        grads['K'] += xh_rows.T @ dg
+        grads['b'] += dg.sum(axis=0)
+        return dg @ p['K'].T, dc_prev
+    if cfg.rnn_name == 'LN_LSTM':
+        si, tj, sf, so, tc, xh, rs = cache_gates
+        dso = dh2 * tc
+        dcn = dc2 + dh2 * so * (1 - tc * tc)                       # d (normalised new c)
+        dcraw, gg, gb = _ln_backward(dcn, xh[4], rs[4], p['cln_cg'])
+        grads['cln_cg'] += gg; grads['cln_cb'] += gb
+        dpre = [dcraw * tj * si * (1 - si), dcraw * si * (1 - tj * tj), dcraw * c_prev * sf * (1 - sf),
+                dso * so * (1 - so)]
+        dz = []
+        for k, n in enumerate('ijfo'):
+            z, gg, gb = _ln_backward(dpre[k], xh[k], rs[k], p['cln_%sg' % n])
+            grads['cln_%sg' % n] += gg; grads['cln_%sb' % n] += gb
+            dz.append(z)
+        dg = np.concatenate(dz, axis=1)
+        grads['K'] += xh_rows.T @ dg
+        return dg @ p['K'].T, dcraw * sf
+    r, u, cand = cache_gates                                       # GRU
+    dpc = dh2 * (1 - u) * (1 - cand * cand)
+    xh2 = np.concatenate([xh_rows[:, :EA], r * h_prev], axis=1)
+    grads['K_c'] += xh2.T @ dpc
+    grads['b_c'] += dpc.sum(axis=0)
+    dxh2 = dpc @ p['K_c'].T
+    drh = dxh2[:, EA:]
+    dpg = np.concatenate([drh * h_prev * r * (1 - r), dh2 * (h_prev - cand) * u * (1 - u)], axis=1)
+    grads['K'] += xh_rows.T @ dpg
+    grads['b'] += dpg.sum(axis=0)
+    dxh = dpg @ p['K'].T
+    dxh[:, :EA] += dxh2[:, :EA]
+    dxh[:, EA:] += drh * r + dh2 * u
+    return dxh, dc2
+
+
 def _attention_backward(p, cfg, keys, q, ac, alpha, dalpha, grads):
     """-> (dkeys, dq); accumulates d(v, ln_g, ln_b, tau) into grads."""
     B, M, D = keys.shape
@@ -482,10 +582,8 @@ def train_backward(p, cfg, out):
             dh2 = dh2 + (dy / dt.type(1 - cfg.dropout_rnn_out)) * masks['out'][t]
         else:
             dh2 = dh2 + dy
-        dg, dc_prev = _lstm_backward(p, st['gates'], st['c_prev'], dc2, dh2, D)
-        grads['K'] += np.concatenate([st['u'], st['h_prev']], axis=1).T @ dg
-        grads['b'] += dg.sum(axis=0)
-        dxh = dg @ p['K'].T
+        dxh, dc_prev = _cell_backward(p, cfg, grads, st['gates'], np.concatenate([st['u'], st['h_prev']], axis=1),
+                                      st['h_prev'], st['c_prev'], dc2, dh2)
         du, dh_prev = dxh[:, :E + A], dxh[:, E + A:]
         if masks is not None:
             dxin = (du / dt.type(1 - cfg.dropout_rnn_in)) * masks['inp'][t]
@@ -507,10 +605,8 @@ def train_backward(p, cfg, out):
     else:
         ic = cc['init']
         zeros = np.zeros((B, D), dt)
-        dg, _ = _lstm_backward(p, ic['gates'], zeros, dc, dh, D)
-        grads['K'] += np.concatenate([ic['u'], zeros], axis=1).T @ dg
-        grads['b'] += dg.sum(axis=0)
-        du = (dg @ p['K'].T)[:, :E + A]
+        dxh, _ = _cell_backward(p, cfg, grads, ic['gates'], np.concatenate([ic['u'], zeros], axis=1), zeros, zeros, dc, dh)
+        du = dxh[:, :E + A]
         if masks is not None:
             dx = (du / dt.type(1 - cfg.dropout_rnn_in)) * masks['init_in']
         else:

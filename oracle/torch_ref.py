@@ -109,6 +109,15 @@ def torch_forward(p, cfg, fm, im, caps, masks, rewards=None, dtype=None):
     Cv = values.shape[-1]
 
     def lstm(xin, c, h):
+        if cfg.rnn_name == 'GRU':
+            r, u = torch.sigmoid(torch.cat([xin, h], 1) @ tp['K'] + tp['b']).chunk(2, dim=1)
+            cand = torch.tanh(torch.cat([xin, r * h], 1) @ tp['K_c'] + tp['b_c'])
+            return c, u * h + (1 - u) * cand
+        if cfg.rnn_name == 'LN_LSTM':
+            ln = lambda z, n: F.layer_norm(z, (D,), tp['cln_%sg' % n], tp['cln_%sb' % n], eps=1e-12)
+            i, j, f, o = (torch.cat([xin, h], 1) @ tp['K']).chunk(4, dim=1)
+            c2 = ln(c * torch.sigmoid(ln(f, 'f') + 1.0) + torch.sigmoid(ln(i, 'i')) * torch.tanh(ln(j, 'j')), 'c')
+            return c2, torch.tanh(c2) * torch.sigmoid(ln(o, 'o'))
         g = torch.cat([xin, h], 1) @ tp['K'] + tp['b']
         i, j, f, o = g.chunk(4, dim=1)
         c2 = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)

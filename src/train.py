@@ -145,10 +145,9 @@ def build_kwargs(args):
 
 def check_supported(kw):
     """Options of the reference that this hot path does not implement fail HERE instead of silently training a different
-    model (model_base.py:622-629 LN_LSTM / GRU, :394-401 gradient clipping)."""
+    model (model_base.py:394-401 gradient clipping).  --rnn_name LN_LSTM / GRU (model_base.py:622-629) build: their
+    cells run on the per-step launch chain."""
     bad = []
-    if kw.get('rnn_name', 'LSTM') != 'LSTM':
-        bad.append('--rnn_name %s (only LSTM)' % kw['rnn_name'])
     if kw.get('clip_gradient_norm'):
         bad.append('clip_gradient_norm != 0')
     # --initialiser: `he` / `none` select TensorFlow's default initialiser in the reference (model_base.py:823-831:

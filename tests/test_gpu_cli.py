@@ -122,6 +122,40 @@ def test_train_infer_cli_default_backbone(tmp_path):
     assert caps and len(json.load(open(caps[0]))) == 4
 
 
+@pytest.mark.parametrize('rnn,var', [('LN_LSTM', 'layer_norm_basic_lstm_cell/state/gamma'), ('GRU', 'gru_cell/candidate/kernel')])
+def test_train_infer_cli_other_cells(tmp_path, rnn, var):
+    """--rnn_name LN_LSTM / GRU (train.py:73-75, model_base.py:622-629): one decoder-mode epoch, the cell's variables under
+    their TensorFlow names in the checkpoint, beam-3 inference from it."""
+    from tests import tiny_dataset
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=4, n_test=4)
+    logs = str(tmp_path / 'experiments')
+    _run(os.path.join(ROOT, 'src', 'train.py'), ['--dataset_dir', ds, '--log_root', logs, '--batch_size_eval', '4',
+                                                 '--cnn_name', 'inception_v3', '--cnn_fm_attention', 'Mixed_7c',
+                                                 '--cnn_input_size', '139,139', '--rnn_name', rnn, '--name', rnn.lower(),
+                                                 '--rnn_size', '128', '--rnn_word_size', '64', '--train_mode', 'decoder',
+                                                 '--batch_size_train', '4', '--max_epoch', '2'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_%s_run_01' % rnn.lower())
+    ck = sorted(glob.glob(os.path.join(run_dir, 'model_compact-*.npz')))
+    assert ck, os.listdir(os.path.join(logs, 'mscoco'))
+    z = np.load(ck[-1])
+    names = [n for n in z.files if n.startswith('Model/decoder/rnn_decoder/rnn_init_input/')]
+    assert 'Model/decoder/rnn_decoder/rnn_init_input/' + var in names, names
+    assert not any('basic_lstm_cell/' in n and 'layer_norm' not in n for n in names), names
+    if rnn == 'GRU':
+        assert z['Model/decoder/rnn_decoder/rnn_init_input/gru_cell/gates/kernel'].shape == (64 + 128 + 128, 256)
+        assert z['Model/decoder/rnn_decoder/rnn_init_input/gru_cell/gates/bias'].shape == (256,)
+    else:
+        assert z['Model/decoder/rnn_decoder/rnn_init_input/layer_norm_basic_lstm_cell/kernel'].shape == (320, 512)
+        assert not any(n.endswith('layer_norm_basic_lstm_cell/bias') for n in names)
+    _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--get_metric_score', ''])
+    caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
+    assert caps and len(json.load(open(caps[0]))) == 4
+
+
 def test_legacy_head_tf_checkpoint_slots_and_resume(tmp_path):
     """--legacy (model_base.py:80-91: LN_tanh + im_embed head, trained) with --checkpoint_format tf: the head's optimiser
     slots are written per variable under the optimiser's scope like the decoder's (`optimise/caption/<var>/Adam[_1]`), and a

@@ -358,7 +358,8 @@ def _spec_and_cfg(**kw):
                            cnn_fm_projection=spec.fm_projection, attn_alignment_method=spec.method,
                            attn_probability_fn=spec.prob, attn_context_layer=spec.context_layer,
                            rnn_init_method=spec.init_method, token_type=spec.token_type, softmax_size=spec.V,
-                           fm_channels=spec.C, im_embed_size=spec.Cg, start_id=spec.start_id, end_id=spec.end_id)
+                           fm_channels=spec.C, im_embed_size=spec.Cg, start_id=spec.start_id, end_id=spec.end_id,
+                           rnn_name=spec.rnn_name)
     return spec, cfg
 
 
@@ -383,6 +384,11 @@ def _rand_params(cfg, seed):
             p[k] = (0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
     if 'ln_g' in p:
         p['ln_g'] = (1 + 0.1 * rng.standard_normal(p['ln_g'].shape)).astype(np.float32)
+    for k in p:                                                    # --rnn_name LN_LSTM / GRU
+        if k == 'b_c' or (k.startswith('cln_') and k.endswith('b')):
+            p[k] = (0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+        if k.startswith('cln_') and k.endswith('g'):
+            p[k] = (1 + 0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
     return p
 
 
@@ -401,6 +407,11 @@ TRAIN_VARIANTS = [
     # attention kernels run in their split form (several workgroups per batch row, decoder.hip)
     dict(D=512, E=256, C=832, Cg=1024, M=196),
     dict(D=512, E=256, C=832, Cg=1024, M=196, fm_projection='independent', prob='sigmoid'),
+    # --rnn_name LN_LSTM / GRU (model_base.py:622-629; cells.hip), both state initialisations
+    dict(rnn_name='LN_LSTM'),
+    dict(rnn_name='LN_LSTM', D=512, E=256, init_method='project_hidden', fm_projection='independent'),
+    dict(rnn_name='GRU'),
+    dict(rnn_name='GRU', D=512, E=256, init_method='project_hidden', method='dot', H=2),
 ]
 
 
@@ -723,7 +734,10 @@ def test_known_answer_param_count_on_device():
                                 dict(C=832, Cg=1024, M=196),
                                 # context layer (attention state = W_a ctx), independent value projection, sigmoid
                                 dict(fm_projection='independent', context_layer=True, prob='sigmoid', H=4),
-                                dict(fm_projection=None, context_layer=True, method='dot', H=4)])
+                                dict(fm_projection=None, context_layer=True, method='dot', H=4),
+                                # --rnn_name LN_LSTM / GRU
+                                dict(rnn_name='LN_LSTM'), dict(rnn_name='GRU'),
+                                dict(rnn_name='GRU', init_method='project_hidden', context_layer=True)])
 def test_greedy_and_beam_match_oracle(kw):
     spec, cfg = _spec_and_cfg(**kw)
     p = _rand_params(cfg, 5)

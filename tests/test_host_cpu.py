@@ -64,8 +64,8 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(L.CnnOp) == 26 * 4                    # ... flags, min_lds
     assert C.sizeof(L.AttnDesc) == 8 * 4
-    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4 + 4  # ... map_loss_scale, flags
-    assert C.sizeof(L.DecoderParams) == 14 * 8
+    assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4 + 4 + 4  # ... map_loss_scale, flags, length_penalty_weight, cell
+    assert C.sizeof(L.DecoderParams) == 17 * 8               # ... emb, cell_ln, K_c, b_c
     assert C.sizeof(L.ConvWeight) == 4 * 8                # w, scale, shift, w_frag
 
 
@@ -502,23 +502,20 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
 
 
 def test_cli_refuses_options_it_does_not_implement(tmp_path):
-    """LN_LSTM / GRU cells and gradient clipping fail at argument time instead of training a different model; sgd, every
-    --initialiser value (all Xavier-uniform in the reference, model_base.py:823-831), --legacy and variational recurrent
-    dropout (built in round 3) build."""
+    """Gradient clipping fails at argument time instead of training a different model; sgd, every --initialiser value (all
+    Xavier-uniform in the reference, model_base.py:823-831), --legacy, variational recurrent dropout and the LN_LSTM / GRU
+    cells (built in round 3) build."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('train_cli2', os.path.join(ROOT, 'src', 'train.py'))
     train = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(train)
     base = ['--log_root', str(tmp_path)]
-    for bad in (['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM']):
-        with pytest.raises(NotImplementedError):
-            train.build_kwargs(train.create_parser().parse_args(base + bad))
     kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base))
     kw['clip_gradient_norm'] = 5.0
     with pytest.raises(NotImplementedError):
         train.check_supported(kw)
     for ok in (['--optimiser', 'sgd'], ['--initialiser', 'he'], ['--initialiser', 'none'], ['--rnn_recurr_dropout', 'True'],
-               ['--legacy', 'True']):
+               ['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM'], ['--legacy', 'True']):
         kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base + ok))
     assert kw['legacy'] and kw['cnn_name'] == 'inception_v1' and kw['adam_epsilon'] == 1e-6
 

@@ -43,6 +43,10 @@ VARIANTS = [
     dict(cnn_fm_projection=None, attn_num_heads=1, token_type='word', rnn_init_method='project_hidden'),
     dict(cnn_fm_projection=None, attn_context_layer=True, attn_alignment_method='dot'),
     dict(attn_alignment_method='dot', attn_num_heads=2),
+    dict(rnn_name='LN_LSTM'),
+    dict(rnn_name='LN_LSTM', rnn_init_method='project_hidden', cnn_fm_projection='independent'),
+    dict(rnn_name='GRU'),
+    dict(rnn_name='GRU', rnn_init_method='project_hidden', attn_alignment_method='dot', attn_num_heads=2),
 ]
 
 
@@ -52,11 +56,11 @@ def test_forward_and_grads_match_torch_autograd(kw, use_dropout):
     cfg = small_cfg(**kw)
     p = dr.init_params(cfg, seed=3, dtype=np.float64)
     rng = np.random.default_rng(5)
-    for k in ('b', 'b_o', 'ln_b'):
-        if k in p:
-            p[k] = 0.1 * rng.standard_normal(p[k].shape)
-    if 'ln_g' in p:
-        p['ln_g'] = 1 + 0.1 * rng.standard_normal(p['ln_g'].shape)
+    for k in p:
+        if k in ('b', 'b_o', 'ln_b', 'b_c') or (k.startswith('cln_') and k.endswith('b')):
+            p[k] = p[k] + 0.1 * rng.standard_normal(p[k].shape)
+        if k == 'ln_g' or (k.startswith('cln_') and k.endswith('g')):
+            p[k] = 1 + 0.1 * rng.standard_normal(p[k].shape)
     fm, im, caps = make_batch(cfg)
     _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
     masks = dr.make_dropout_masks(cfg, fm.shape[0], int(lens.max()), fm.shape[1], 11, np.float64) \
