@@ -421,6 +421,155 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
   }
 }
 
+// The same product for stems with a LARGE filter and padding (Inception-V1's Conv2d_1a_7x7: 7x7 / stride 2, SAME, 3 -> 64,
+// common/nets/inception_v1.py:59-60; K = 147).  The direct kernel above spent 4.3 ms on 640 images (47 % of the
+// Inception-V1 forward).  bf16 plans only.
+//   * a workgroup owns kStemRows output rows of one image; the input rows they need are staged ONCE in LDS as fp32 with
+//     zeroed halo columns / rows (SAME padding costs no per-element test);
+//   * k is re-indexed as k' = 24 kh + j, j = kw * Cin + ci < KW * Cin <= 24 (weights of the pad positions are zero): the
+//     eight k' of an MFMA operand lane then lie inside ONE filter row, i.e. they are eight consecutive floats of a staged
+//     input row -- four ds_read_b64 instead of eight bounds-checked gathers;
+//   * every 32-deep chunk runs as hi*hi + hi*lo + lo*hi of bf16 halves; the whole filter lives in registers
+//     (KC x NT hi / lo fragment pairs).
+constexpr int kStemRows = 2;          // output rows per workgroup
+constexpr int kStemKRow = 24;         // k' per filter row
+constexpr int kStemFetch = 12;        // float2 a thread moves per staged unit: (rows with weights) * W * Cin / 2 <= 12 * 256
+template <int NT, int KC>
+__global__ __launch_bounds__(256) void conv_stem_wide_kernel(ConvArgs a, int lrow, int blocks_per_image, int total_units) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];      // two buffers of [(kStemRows - 1) * SH + 8][lrow]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const float* __restrict__ wg = (const float*)a.w;      // [K][Cout]
+  auto split8 = [](const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+      l[e] = pack_bf16x2(v[2 * e] - __uint_as_float(h[e] << 16), v[2 * e + 1] - __uint_as_float(h[e] & 0xFFFF0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+  };
+  const int nrows = (kStemRows - 1) * a.SH + 8;           // staged rows (filter rows >= KH carry zero weights: never loaded)
+  const int lrows = (kStemRows - 1) * a.SH + a.KH;        // ... of which these are loaded
+  const int jw = a.KW * a.Cin;                            // floats of one filter row
+  const int half = a.W * a.x_cs / 2;                      // float2 per image row (x_cs == Cin: dense NHWC image)
+  const float* __restrict__ xg = (const float*)a.x + a.x_co;
+  // a unit = kStemRows output rows of one image.  Staged row r = image row ho0*SH - PT + r behind PL*Cin zero floats; rows
+  // outside the image are written as zeros, the halo columns are zeroed once and never written again.
+  auto fetch = [&](int u, float2 (&v)[kStemFetch]) {
+    const int b = u / blocks_per_image, ho0 = (u - b * blocks_per_image) * kStemRows;
+#pragma unroll
+    for (int q = 0; q < kStemFetch; ++q) {
+      const int i = threadIdx.x + 256 * q;
+      const int r = i / half, c2 = i - r * half;
+      const int hi = ho0 * a.SH - a.PT + r;
+      v[q] = make_float2(0.f, 0.f);
+      if (r < lrows && (unsigned)hi < (unsigned)a.H) v[q] = *(const float2*)(xg + ((size_t)(b * a.H + hi) * a.W) * a.x_cs + 2 * c2);
+    }
+  };
+  auto stash = [&](float* buf, const float2 (&v)[kStemFetch]) {
+#pragma unroll
+    for (int q = 0; q < kStemFetch; ++q) {
+      const int i = threadIdx.x + 256 * q;
+      const int r = i / half, c2 = i - r * half;
+      if (r < lrows) *(float2*)(buf + r * lrow + a.PL * a.Cin + 2 * c2) = v[q];
+    }
+  };
+  for (int i = threadIdx.x; i < 2 * nrows * lrow; i += 256) xs[i] = 0.f;
+  // ---- the filter as fragments: lane holds k' = 32 c + 8 fg + s of chunk c ------------------------------------------------
+  bf16x8_t wh[KC][NT], wl[KC][NT];
+  int off[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k0 = 32 * c + 8 * fg;
+    const int kh = k0 / kStemKRow, j0 = k0 - kh * kStemKRow;
+    off[c] = kh * lrow + j0;
+    float wf[NT][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bool kv = kh < a.KH && j0 + s < jw;
+      const int k = kv ? kh * jw + j0 + s : 0;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i][s] = kv ? wg[k * a.Cout + i * 16 + fr] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) split8(wf[i], wh[c][i], wl[c][i]);
+  }
+  // ---- this wave's pixel tiles: tile = wave + 4 t over the kStemRows * Wo pixels of a unit --------------------------------
+  const int npix = kStemRows * a.Wo;
+  int xbase[4], prow[4], pcol[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int p = (wave + 4 * t) * 16 + fr;
+    const int r = p / a.Wo, wo = p - r * a.Wo;
+    const bool ok = p < npix;
+    xbase[t] = ok ? r * a.SH * lrow + wo * a.SW * a.Cin : 0;
+    prow[t] = ok ? r : (1 << 20);
+    pcol[t] = wo;
+  }
+  float2 pre[kStemFetch];
+  __syncthreads();                                        // the zero fill is complete
+  int unit = blockIdx.x;
+  if (unit < total_units) {
+    fetch(unit, pre);
+    stash(xs, pre);
+  }
+  __syncthreads();
+  for (int it = 0; unit < total_units; unit += gridDim.x, ++it) {
+    const float* buf = xs + (it & 1) * nrows * lrow;
+    const int next = unit + gridDim.x;
+    if (next < total_units) fetch(next, pre);             // in flight under this unit's matrix work
+    const int b = unit / blocks_per_image, ho0 = (unit - b * blocks_per_image) * kStemRows;
+    f32x4_t acc[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      bf16x8_t xh[4], xl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float2* sp = (const float2*)(buf + xbase[t] + off[c]);      // even float offset: 8-byte aligned
+        const float2 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+        const float xv[8] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y};
+        split8(xv, xh[t], xl[t]);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c][i], xh[t], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c][i], xl[t], acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[c][i], xh[t], acc[i][t], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds channels i*16 + fg*4 .. +3 of its pixel of tile t
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n0 = i * 16 + fg * 4;
+      const float4 sc = *(const float4*)(a.scale + n0), sh = *(const float4*)(a.shift + n0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v0 = fmaf(acc[i][t][0], sc.x, sh.x), v1 = fmaf(acc[i][t][1], sc.y, sh.y);
+        float v2 = fmaf(acc[i][t][2], sc.z, sh.z), v3 = fmaf(acc[i][t][3], sc.w, sh.w);
+        if (a.relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        if (ho0 + prow[t] >= a.Ho) continue;
+        const size_t o = ((size_t)(b * a.Ho + ho0 + prow[t]) * a.Wo + pcol[t]) * a.y_cs + a.y_co + n0;
+        if (a.out_f32)
+          *(float4*)((float*)a.y + o) = make_float4(v0, v1, v2, v3);
+        else
+          *(uint2*)((bf16_t*)a.y + o) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+    if (next < total_units) stash(xs + ((it + 1) & 1) * nrows * lrow, pre);
+    __syncthreads();                                      // the other buffer is complete; this one is free
+  }
+}
+
 // ---- pooling ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void load_vec(const T* p, float* v);
@@ -1465,6 +1614,21 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       if (a.K <= 32 && a.Cout == 32 && a.PT == 0 && a.PL == 0 && (op->Ho - 1) * op->SH + op->KH <= op->H &&
           (op->Wo - 1) * op->SW + op->KW <= op->W && op->tile != 1)
         hipLaunchKernelGGL((conv_stem_mfma_kernel<T, 2>), dim3(cdiv(a.M, 1024)), dim3(256), 0, st, a);   // VALID 3x3x3
+      else if (const int lrow = ((op->PL + op->W + op->KW) * op->Cin + kStemKRow + 1) / 2 * 2;   // staged row, floats
+               sizeof(T) == 2 && op->tile != 1 && a.Cout == 64 && op->KW * op->Cin <= kStemKRow && op->KH <= 8 &&
+               xc == op->Cin && op->src_coff == 0 && (op->W * op->Cin) % 2 == 0 && (op->PL * op->Cin) % 2 == 0 &&
+               (op->SW * op->Cin) % 2 == 0 && kStemRows * op->Wo <= 256 &&
+               (op->Wo - 1) * op->SW * op->Cin + kStemKRow <= lrow &&          // the last pixel's widest operand read
+               ((kStemRows - 1) * op->SH + op->KH) * (op->W * op->Cin / 2) <= kStemFetch * 256 &&
+               2 * lrow * ((kStemRows - 1) * op->SH + 8) * 4 <= 64 * 1024) {
+        // Inception-V1 Conv2d_1a_7x7 (7x7 / 2, SAME) -- conv_stem_wide_kernel, persistent workgroups (one per CU: the
+        // filter fragments take most of the register file)
+        const int bpi = cdiv(op->Ho, kStemRows), total = batch * bpi;
+        const int lds_w = 2 * lrow * ((kStemRows - 1) * op->SH + 8) * 4;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL((conv_stem_wide_kernel<4, 6>), dim3(std::min(total, cus)), dim3(256), lds_w, st, a, lrow, bpi, total);
+      }
       else
         hipLaunchKernelGGL((conv_stem_kernel<T>), dim3(cdiv(a.M, 256)), dim3(256), lds, st, a);
       break;
