@@ -923,6 +923,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pr.p[0] = xh_all; pr.n[0] = (long)Tp * B * Wd;
     pr.p[1] = y_all; pr.n[1] = (long)Tp * B * D;
     pr.p[2] = q_all; pr.n[2] = (long)Tp * B * D;
+    if (M > 64) {                      // the quarters' partial LayerNorm sums (decoder_persist.hip, BIGM): [Tp][B][4][M/2][4]
+      pr.p[3] = dq_part; pr.n[3] = (long)Tp * B * 8 * M;      // (dq_part: the backward loop does not cover this M)
+    }
     if (persist_b) {
       pr.p[3] = dq_part; pr.n[3] = (long)Tp * B * 4 * D;
       pr.p[4] = dg_blk; pr.n[4] = 4 * n16;
@@ -965,6 +968,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pa.xh_all = xh_all; pa.gates_all = gates_all; pa.cnew_all = cnew_all; pa.y_all = y_all; pa.q_all = q_all;
     pa.cs = cs; pa.hs = hs; pa.att_all = att_all; pa.alpha_all = alpha_all; pa.attn_hist = attn_hist;
     pa.ctx_all = ctx_all; pa.sync = persist_sync;
+    pa.statp = (M > 64 && !persist_b && (long)8 * M <= 4L * D) ? dq_part : nullptr;
     pa.B = B; pa.D = D; pa.E = E; pa.Wd = Wd; pa.M = M; pa.H = H; pa.Tp = Tp;
     pa.method = d->method; pa.prob = d->prob; pa.tied = ad.tied;
     const int n_grp = (B + 15) / 16;                     // a launch serves up to four 16-row groups (256 CUs)

@@ -29,6 +29,7 @@ struct ComicPersistFwdArgs {
   float* alpha_all;       // [Tp][B][H][M]
   float* attn_hist;       // [Tp][B][H][M]
   float* ctx_all;         // [Tp][B][D]
+  float* statp;           // M > 64: [Tp][B][4][M/2][4] partial LayerNorm sums of the channel quarters; sentinel-filled
   unsigned long long* stamps;   // diagnostic phase clock of workgroup 0 (null = off)
   unsigned* sync;         // kPersistSyncWords words: the error word (comic_persist_prepare clears it)
   int B, D, E, Wd, M, H, Tp;

@@ -59,7 +59,12 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
 // teacher forcing, no dropout, no finished-row select; the Q phase also forms this workgroup's columns of the logits
 // y W_o + b_o and their row maxima, every workgroup reduces the 64 partial maxima of its rows to the step's token ids
 // and the x third of the next operand row is read straight from the embedding table.
-template <int NX, bool WQ_LDS, bool GREEDY>
+// BIGM (64 < M <= 256, tied keys / values; the reference CLI's default map, Inception-V1 Mixed_4f: M = 196): the keys of
+// a batch row (M*D*4 = 401 KB) do not fit a CU, so a workgroup keeps only ITS CHANNEL QUARTER of them ([M][128], 100 KB).
+// The LayerNorm statistics of keys + q run over all D channels: every quarter forms the partial sums (sum z, sum z^2) of
+// its 128 channels for all M rows and the four workgroups of a batch row exchange them through one more sentinel-checked
+// hand-off (M/2 pieces of 16 bytes per quarter); mean and variance come from the combined sums (var = E[z^2] - mean^2).
+template <int NX, bool WQ_LDS, bool GREEDY, bool BIGM = false>
 __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicPersistFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = kD;
@@ -71,12 +76,16 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   Waiter wt{a.sync, false};
 
   // ---- LDS carve-up ---------------------------------------------------------------------------------------------
-  float* keys_l = (float*)smem;                                // [M][D]  keys of this workgroup's attention row
-  float* vals_l = a.tied ? keys_l : keys_l + M * D;            // [M][D]  values (independent projection)
-  float4* red = (float4*)(vals_l + M * D);                     // [8 waves][2 tiles][64 lanes]   cross-wave combine
+  constexpr int KP = BIGM ? D / 4 : D;                         // floats per resident key row (BIGM: the quarter's channels)
+  constexpr int SCP = BIGM ? 256 : 64;                         // floats per head row of the score buffer
+  float* keys_l = (float*)smem;                                // [M][KP] keys of this workgroup's attention row
+  float* vals_l = (a.tied || BIGM) ? keys_l : keys_l + M * D;  // [M][D]  values (independent projection)
+  float4* red = (float4*)(vals_l + M * KP);                    // [8 waves][2 tiles][64 lanes]   cross-wave combine
   float* q_l = (float*)(red + kWaves * 2 * 64);                // [D]      q row of the attention phase
-  float* sc_l = q_l + D;                                       // [<= 4 heads][64]
-  float* wq_l = sc_l + 4 * 64;                                 // [D][8] + 4 floats per 16 rows: eight W_q columns
+  float* sc_l = q_l + D;                                       // [<= 4 heads][SCP]
+  float* st_l = sc_l + 4 * SCP;                                // BIGM: [256][2] mean, 1/std of the rows; [3][128] gamma, beta, v
+  float* lnq_l = st_l + 512;
+  float* wq_l = sc_l + 4 * SCP + (BIGM ? 512 + 3 * (D / 4) : 0);   // [D][8] + 4 floats per 16 rows: eight W_q columns
   float* wo_l = wq_l + (WQ_LDS ? 8 * D + (D / 16) * 4 : 0);     // GREEDY: [D][8] + pad, this workgroup's logit columns of W_o
   int* ids_l = (int*)(wo_l + 8 * D + (D / 16) * 4);            // GREEDY: [16] token ids of the group's rows, [16] first-EOS steps
 
@@ -84,6 +93,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   const __amdgpu_buffer_rsrc_t y_r = make_rsrc(a.y_all, (long)a.Tp * B * D * 4);
   const __amdgpu_buffer_rsrc_t q_r = make_rsrc(a.q_all, (long)a.Tp * B * D * 4);
   const __amdgpu_buffer_rsrc_t ap_r = make_rsrc(a.argp, GREEDY ? (long)a.Tp * B * kArgRow * 4 : 0);
+  const __amdgpu_buffer_rsrc_t sp_r = make_rsrc(a.statp, BIGM ? (long)a.Tp * B * 8 * M * 4 : 0);   // [t][row][quarter][M/2][4]
   const int ncol = GREEDY ? (a.V + kGroupWgs - 1) / kGroupWgs : 0;   // logit columns per workgroup (<= 8)
 
   // ---- attention-phase identity: batch row + channel quarter --------------------------------------------------------
@@ -94,8 +104,17 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   {
     const int arow = a_live ? ab : 0;
     const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
-    for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
-    if (!a.tied) {
+    if constexpr (BIGM) {
+      for (int i = tid; i < M * (KP / 4); i += kThreads)
+        ((float4*)keys_l)[i] = *(const float4*)(a.keys + ((size_t)arow * M + (i >> 5)) * D + (wi >> 4) * (D / 4) + 4 * (i & 31));
+      for (int i = tid; i < 3 * (D / 4); i += kThreads) {
+        const int w = i / (D / 4), c = (wi >> 4) * (D / 4) + i % (D / 4);
+        lnq_l[i] = a.method == 0 ? (w == 0 ? a.ln_g[c] : w == 1 ? a.ln_b[c] : a.v[c]) : 0.f;
+      }
+    } else {
+      for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
+    }
+    if (!a.tied && !BIGM) {
       const float4* vs = (const float4*)(a.values + (size_t)arow * M * D);
       for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)vals_l)[i] = vs[i];
     }
@@ -210,8 +229,16 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
     const size_t e_i = ((size_t)t * B + e_row) * D + e_d;
     if (a.mask_out && e_lane) m_out = a.mask_out[e_i];
     if (a.mask_in && a_live && tid < D / 4 && t + 1 < a.Tp) m_in = a.mask_in[((size_t)(t + 1) * B + ab) * EA + E + a_c];
-    if (a.mask_alpha && a_live && wave < hq && lane < M)
+    float m_al4[4] = {1.f, 1.f, 1.f, 1.f};                     // BIGM: a lane holds rows lane + 64 k
+    if constexpr (BIGM) {
+      if (a.mask_alpha && a_live && wave < hq) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (lane + 64 * k < M) m_al4[k] = a.mask_alpha[(((size_t)t * B + ab) * H + aq * hq + wave) * M + lane + 64 * k];
+      }
+    } else if (a.mask_alpha && a_live && wave < hq && lane < M) {
       m_al = a.mask_alpha[(((size_t)t * B + ab) * H + aq * hq + wave) * M + lane];
+    }
     // =============================================================== L: LSTM cell (att third) ========================
     stamp(a.stamps, t, 0);
     lstm_part(t, cx, ca);
@@ -430,6 +457,89 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
       stamp(a.stamps, t, 4);
       // scores of this quarter's heads; a wave owns memory rows m = wave, wave + 8, ... and takes two per pass (the
       // reductions of the two rows interleave); the phase is VALU-bound (about 150 wave instructions per row)
+      if constexpr (BIGM) {
+        if (a.method == 0) {
+          // (i) partial statistics of this quarter's 128 channels: thread (row tid >> 1, channel half tid & 1); the walk
+          // over the 64 channels starts at a per-thread rotation so that the lanes of a wave hit distinct LDS banks
+          const int pm = tid >> 1, ph = tid & 1;
+          float s1 = 0.f, s2 = 0.f;
+          if (pm < M) {
+            const float* kr = keys_l + pm * KP + 64 * ph;
+            const float* qq = q_l + cq0 + 64 * ph;
+            const int rot = pm + 16 * ph;
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {                      // two channels a read (8-byte LDS reads, 32 distinct pairs)
+              const int c = 2 * ((j + rot) & 31);
+              const float2 kv = *(const float2*)(kr + c), qv = *(const float2*)(qq + c);
+              const float z0 = kv.x + qv.x, z1 = kv.y + qv.y;
+              s1 += z0; t1 += z1;
+              s2 = fmaf(z0, z0, s2); t2 = fmaf(z1, z1, t2);
+            }
+            s1 += t1;
+            s2 += t2;
+          }
+          s1 += dpp_move<0xB1>(0.f, s1);                        // the two halves of a row: adjacent lanes
+          s2 += dpp_move<0xB1>(0.f, s2);
+          const float n1 = __shfl_down(s1, 2, 64), n2 = __shfl_down(s2, 2, 64);   // the next row's sums
+          const unsigned sbase = (unsigned)(((size_t)t * B + ab) * 8 * M * 4);    // bytes; quarter qq at qq * 2M floats
+          if ((tid & 3) == 0 && pm < M) store16_sc1(sp_r, sbase + (unsigned)((aq * 2 * M + 2 * pm) * 4), make_float4(s1, s2, n1, n2));
+          __syncthreads();                                      // poll only after the own stores are on their way
+          // (ii) the four quarters' sums of a row pair -> mean, 1/std (combined in quarter order: the same in all four)
+          if (wave < 2) {
+            const int pr = min(tid, M / 2 - 1);
+            const unsigned po = sbase + (unsigned)(4 * pr * 4);
+            const unsigned qoff[4] = {0u, (unsigned)(2 * M * 4), (unsigned)(4 * M * 4), (unsigned)(6 * M * 4)};
+            float4 pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[k] = load16_sc1(sp_r, po + qoff[k]);
+            wait_written<4>(pv, sp_r, po, qoff, 15u, wt);
+            const float S0 = (pv[0].x + pv[1].x) + (pv[2].x + pv[3].x), Q0 = (pv[0].y + pv[1].y) + (pv[2].y + pv[3].y);
+            const float S1 = (pv[0].z + pv[1].z) + (pv[2].z + pv[3].z), Q1 = (pv[0].w + pv[1].w) + (pv[2].w + pv[3].w);
+            const float mean0 = S0 * (1.0f / (float)D), mean1 = S1 * (1.0f / (float)D);
+            const float var0 = fmaxf(Q0 * (1.0f / (float)D) - mean0 * mean0, 0.f);
+            const float var1 = fmaxf(Q1 * (1.0f / (float)D) - mean1 * mean1, 0.f);
+            if (tid < M / 2)
+              *(float4*)(st_l + 4 * tid) = make_float4(mean0, __frsqrt_rn(var0 + kLnEps), mean1, __frsqrt_rn(var1 + kLnEps));
+          }
+          __syncthreads();
+        }
+        // (iii) scores: one (row, head of the quarter) per thread over the head's dh channels
+        for (int idx = tid; idx < M * hq; idx += kThreads) {
+          const int m = idx / hq, hl = idx - m * hq;
+          const float* kr = keys_l + m * KP + hl * dh;
+          const float* qq = q_l + cq0 + hl * dh;
+          float acc_s = 0.f;
+          if (a.method == 0) {
+            const float mean = st_l[2 * m], rstd = st_l[2 * m + 1];
+            const float* lg = lnq_l + hl * dh;
+            float acc_t = 0.f;
+            // tanh(x) = 1 - 2 / (1 + e^(2x)) on v_exp_f32 / v_rcp_f32: |error| < 2e-7 absolute (what a score, a sum of
+            // tanh * v, needs); M * 128 of them per step make this loop the phase's cost
+            auto th = [](float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); };
+#pragma unroll 4
+            for (int j = 0; j < dh / 2; ++j) {
+              const int c = 2 * ((j + idx) & (dh / 2 - 1));
+              const float2 kv = *(const float2*)(kr + c), qv = *(const float2*)(qq + c);
+              const float2 gv = *(const float2*)(lg + c), bv = *(const float2*)(lg + D / 4 + c), vv = *(const float2*)(lg + 2 * (D / 4) + c);
+              const float i0 = rstd * gv.x, i1 = rstd * gv.y;
+              const float zh0 = (kv.x + qv.x) * i0 + (bv.x - mean * i0);   // tf.nn.batch_normalization form
+              const float zh1 = (kv.y + qv.y) * i1 + (bv.y - mean * i1);
+              acc_s = fmaf(th(zh0), vv.x, acc_s);
+              acc_t = fmaf(th(zh1), vv.y, acc_t);
+            }
+            acc_s += acc_t;
+          } else {
+#pragma unroll 4
+            for (int j = 0; j < dh / 2; ++j) {
+              const int c = 2 * ((j + idx) & (dh / 2 - 1));
+              const float2 kv = *(const float2*)(kr + c), qv = *(const float2*)(qq + c);
+              acc_s = fmaf(kv.x, qv.x, fmaf(kv.y, qv.y, acc_s));
+            }
+          }
+          sc_l[hl * SCP + m] = acc_s * inv_scale;
+        }
+      } else {
       auto score_rows = [&](int m0, auto nr_) {
         constexpr int NR = decltype(nr_)::value;
         const int c = cq0 + 2 * lane;                           // this lane's two channels of the quarter
@@ -496,10 +606,38 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
         if (m0 + kWaves < M) score_rows(m0, integral_constant<int, 2>());
         else score_rows(m0, integral_constant<int, 1>());
       }
+      }
       __syncthreads();
       stamp(a.stamps, t, 5);
       // probability fn per head (a wave per head of the quarter), dropout; sc <- alpha_d
-      if (wave < hq) {
+      if (BIGM && wave < hq) {                                  // a lane holds rows lane + 64 k
+        const int h = aq * hq + wave;
+        float* srow = sc_l + wave * SCP;
+        const size_t go = (((size_t)t * B + ab) * H + h) * M;
+        float sv[4], al[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv[k] = lane + 64 * k < M ? srow[lane + 64 * k] : -INFINITY;
+        if (a.prob == 0) {
+          const float mx = wave_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) al[k] = lane + 64 * k < M ? expf(sv[k] - mx) : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) al[k] = lane + 64 * k < M ? sigmoidf_(sv[k]) : 0.f;
+        }
+        const float tot = wave_sum((al[0] + al[1]) + (al[2] + al[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = lane + 64 * k;
+          if (m < M) {
+            const float av = al[k] / tot;
+            a.alpha_all[go + m] = av;
+            const float ad = a.mask_alpha ? (av / a.keep_alpha) * m_al4[k] : av;
+            a.attn_hist[go + m] = ad;
+            srow[m] = ad;
+          }
+        }
+      } else if (!BIGM && wave < hq) {
         const int h = aq * hq + wave;
         float* srow = sc_l + wave * 64;
         const size_t go = (((size_t)t * B + ab) * H + h) * M;
@@ -522,17 +660,38 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
       }
       __syncthreads();
       stamp(a.stamps, t, 6);
+      if constexpr (BIGM) {      // context: the M rows in four ranges over the eight waves, combined in a fixed order
+        const int ch = tid & 127, part = tid >> 7;
+        const int mq = (M + 3) / 4, me = min(M, (part + 1) * mq);
+        const float* al = sc_l + (ch / dh) * SCP;
+        const float* vp = vals_l + ch;
+        float c4[4] = {0.f, 0.f, 0.f, 0.f};
+        int m = part * mq;
+        for (; m + 4 <= me; m += 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c4[k] = fmaf(al[m + k], vp[(m + k) * KP], c4[k]);
+        }
+        for (; m < me; ++m) c4[0] = fmaf(al[m], vp[m * KP], c4[0]);
+        ((float*)red)[tid] = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        __syncthreads();
+      }
       if (wave < 2) {
-        const float* al = sc_l + (tid / dh) * 64;
+        float cx;
+        if constexpr (BIGM) {
+          const float* rp = (const float*)red;
+          cx = (rp[tid] + rp[128 + tid]) + (rp[256 + tid] + rp[384 + tid]);
+        } else {
+        const float* al = sc_l + (tid / dh) * SCP;
         const float* vp = vals_l + a_c;
         float c4[4] = {0.f, 0.f, 0.f, 0.f};                     // four interleaved partial sums (fixed order)
         int m = 0;
         for (; m + 4 <= M; m += 4) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) c4[k] = fmaf(al[m + k], vp[(m + k) * D], c4[k]);
+          for (int k = 0; k < 4; ++k) c4[k] = fmaf(al[m + k], vp[(m + k) * KP], c4[k]);
         }
-        for (; m < M; ++m) c4[0] = fmaf(al[m], vp[m * D], c4[0]);
-        const float cx = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        for (; m < M; ++m) c4[0] = fmaf(al[m], vp[m * KP], c4[0]);
+        cx = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        }
         if (!GREEDY) a.ctx_all[((size_t)t * B + ab) * D + a_c] = cx;
         const bool fin = t >= a_len;
         att_prev = fin ? att_prev : cx;
@@ -581,17 +740,19 @@ __global__ __launch_bounds__(256) void persist_gate_kernel(const unsigned* err, 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n[k]; i += stride) r.p[k][i] = 0.f;
 }
 
-int64_t lds_bytes(int M, int tied, bool wq_lds, bool greedy = false) {
+int64_t lds_bytes(int M, int tied, bool wq_lds, bool greedy = false, bool bigm = false) {
   const int64_t cols = kD * 32 + (kD / 16) * 16;               // eight padded columns of a [D][D'] matrix
-  return (int64_t)(tied ? 1 : 2) * M * kD * 4 + kWaves * 2 * 64 * 16 + kD * 4 + 4 * 64 * 4 + (wq_lds ? cols : 0) +
-         (greedy ? cols + 64 * 4 : 0);
+  const int64_t keys = bigm ? (int64_t)M * (kD / 4) * 4 : (int64_t)(tied ? 1 : 2) * M * kD * 4;
+  const int64_t sc = bigm ? (4 * 256 + 512 + 3 * (kD / 4)) * 4 : 4 * 64 * 4;
+  return keys + kWaves * 2 * 64 * 16 + kD * 4 + sc + (wq_lds ? cols : 0) + (greedy ? cols + 64 * 4 : 0);
 }
+inline bool big_m(int M) { return M > 64; }
 constexpr int64_t kLdsMax = 160 * 1024;
 constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at most one workgroup per CU
 
-template <int NX, bool WQ_LDS, bool GREEDY = false>
+template <int NX, bool WQ_LDS, bool GREEDY = false, bool BIGM = false>
 int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st) {
-  auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS, GREEDY>;
+  auto kern = decoder_fwd_persistent_kernel<NX, WQ_LDS, GREEDY, BIGM>;
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
@@ -613,8 +774,10 @@ bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int C
   if (context_layer || B < 1 || B > kMaxLaunches * kMaxGroups * kGroupRows) return false;
   if (D != kD || A != D || Cv != D || E < 16 || E % 16 != 0 || E > 512) return false;
   if (H != 4 && H != 8 && H != 16) return false;                  // a channel quarter holds 1, 2 or 4 whole heads
-  if (M < 1 || M > 64) return false;
+  if (M < 1) return false;
   if (method != 0 && method != 1) return false;
+  // larger memories (Inception-V1 Mixed_4f, M = 196): a workgroup holds its channel quarter of the keys (BIGM)
+  if (big_m(M)) return tied && M <= 256 && M % 2 == 0 && lds_bytes(M, tied, false, false, true) <= kLdsMax;
   return lds_bytes(M, tied, false) <= kLdsMax;
 }
 
@@ -658,8 +821,13 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   ComicPersistFwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(0, a.Tp, st) : nullptr;
   const bool greedy = a.greedy != 0;
-  const bool wq_lds = lds_bytes(a.M, a.tied, true, greedy) <= kLdsMax;
-  int64_t lds = lds_bytes(a.M, a.tied, wq_lds, greedy);
+  const bool bigm = big_m(a.M);
+  if (bigm && (greedy || !a.tied || !a.statp)) {
+    comic_set_error("persistent decoder: M = %d needs tied keys / values, the statistics buffer, and is not a greedy loop", a.M);
+    return 2;
+  }
+  const bool wq_lds = lds_bytes(a.M, a.tied, true, greedy, bigm) <= kLdsMax;
+  int64_t lds = lds_bytes(a.M, a.tied, wq_lds, greedy, bigm);
   if (lds > kLdsMax) {
     comic_set_error("persistent decoder: %lld bytes of LDS needed", (long long)lds);
     return 2;
@@ -676,6 +844,13 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
     if (nx <= 1) rc = wq_lds ? launch<1, true, true>(a, groups, lds, st) : launch<1, false, true>(a, groups, lds, st);
     else if (nx == 2) rc = wq_lds ? launch<2, true, true>(a, groups, lds, st) : launch<2, false, true>(a, groups, lds, st);
     else if (nx <= 4) rc = wq_lds ? launch<4, true, true>(a, groups, lds, st) : launch<4, false, true>(a, groups, lds, st);
+    else comic_set_error("persistent decoder: word size %d not supported", a.E);
+    return rc;
+  }
+  if (bigm) {
+    if (nx <= 1) rc = wq_lds ? launch<1, true, false, true>(a, groups, lds, st) : launch<1, false, false, true>(a, groups, lds, st);
+    else if (nx == 2) rc = wq_lds ? launch<2, true, false, true>(a, groups, lds, st) : launch<2, false, false, true>(a, groups, lds, st);
+    else if (nx <= 4) rc = wq_lds ? launch<4, true, false, true>(a, groups, lds, st) : launch<4, false, false, true>(a, groups, lds, st);
     else comic_set_error("persistent decoder: word size %d not supported", a.E);
     return rc;
   }
