@@ -811,6 +811,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>((long)T * ((B + 15) / 16) * 16 * D);                                  // summed d q (blocked)
   w.take<float>(TB * 2 * D);                                                   // d att | d h
   w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
+  w.take<float>(TB * 64);                                                      // ... per-head dot products of the row quarters (M > 28)
   if (d->cell == COMIC_CELL_LN_LSTM) {           // normalised rows, 1/std and LayerNorm gradient rows of every step + the init step
     w.take<float>((TB + B) * 5 * D); w.take<float>((TB + B) * 8); w.take<float>((TB + B) * 10 * D); w.take<float>(10 * D);
   } else if (d->cell == COMIC_CELL_GRU) {        // [x ; att ; r*h] of every step, the two d-operand products of a step, bias sums
@@ -890,6 +891,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dq_sum = w.take<float>(TB16 * D);
   float* dstate = w.take<float>(TB * 2 * D);
   float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
+  float* dotp = w.take<float>(TB * 64);
   const int cell = d->cell;
   float *lnx_all = nullptr, *lnr_all = nullptr, *lnpg = nullptr, *cell_tmp = nullptr, *xh2_all = nullptr, *gru_dxh = nullptr;
   if (cell == COMIC_CELL_LN_LSTM) {
@@ -931,6 +933,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       pr.p[4] = dg_blk; pr.n[4] = 4 * n16;
       pr.p[5] = dstate; pr.n[5] = (long)Tp * B * 2 * D;
       pr.p[6] = dq_sum; pr.n[6] = n16;
+      pr.p[7] = dotp; pr.n[7] = (long)Tp * B * 64;
     }
     RC(comic_persist_prepare(pr, persist_sync, st));
   }
@@ -1082,6 +1085,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pb.q_all = q_all; pb.alpha_all = alpha_all; pb.gates_all = gates_all; pb.cs = cs; pb.cnew_all = cnew_all;
     pb.dy_all = dy_all; pb.dmap = use_map ? dmap : nullptr;
     pb.dq_part = dq_part; pb.dq_sum = dq_sum; pb.dg_blk = dg_blk; pb.dg_all = dg_all; pb.dstate = dstate;
+    pb.dotp = dotp;
     pb.dq_all = dq_all; pb.dc = dc; pb.dh = dh; pb.dkeys = dkeys; pb.pgrad = pgrad4; pb.sync = persist_sync;
     pb.B = B; pb.E = E; pb.M = M; pb.H = H; pb.Tp = Tp; pb.method = d->method;
     const int n_grp = (B + 15) / 16;

@@ -100,6 +100,7 @@ struct ComicPersistBwdArgs {
   float* dq_sum;          // [Tp][groups][32][16][16]      blocked (see decoder_persist_bwd.hip), groups = ceil(B / 16)
   float* dg_blk;          // [Tp][groups][128][16][16]     blocked
   float* dstate;          // [Tp][B][2D]   d att | d h of the step's operand row
+  float* dotp;            // M > 28: [Tp][B][4][16] per-head partial sums of alpha * d alpha of the row quarters; sentinel-filled
   // outputs
   float* dq_all;          // [Tp][B][D]
   float* dg_all;          // [Tp][B][4D]   row-major (operand of the d K / d b / d emb reductions after the loop)

@@ -48,6 +48,12 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
   if (st && blockIdx.x == 0 && threadIdx.x == 0) st[t * 8 + i] = __builtin_amdgcn_s_memrealtime();
 }
 
+// OWN (28 < M <= 64; the 8 x 8 map of 299-pixel inputs): the batch row's whole key matrix no longer fits beside the other
+// residents, so a workgroup keeps only ITS memory rows m = quarter + 4 j (<= 16 of them, two per wave).  d alpha_d is then
+// formed for the own rows only; the softmax backward needs the dot product sum_m alpha * d alpha over ALL rows of a head,
+// which the four workgroups of a batch row assemble from their partial sums through one more sentinel-checked hand-off
+// ([T'][B][4][16] floats).  The own rows' LayerNorm / tanh are recomputed in the last part instead of held in registers.
+template <bool OWN>
 __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicPersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = kD, EPL = 8;
@@ -59,8 +65,8 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   Waiter wt{a.sync, false};
 
   // ---- LDS carve-up ---------------------------------------------------------------------------------------------
-  float* keys_l = (float*)smem;                                // [M][D]   keys (= values) of the attention row
-  float* wq_l = keys_l + M * D;                                // [32 k16-blocks][8 units][4][4]  W_q rows of its units
+  float* keys_l = (float*)smem;                                // [M][D]   keys (= values) of the attention row (OWN: [16 slots][D], slot j = row quarter + 4 j)
+  float* wq_l = keys_l + (OWN ? 16 : M) * D;                   // [32 k16-blocks][8 units][4][4]  W_q rows of its units
   float4* red_i = (float4*)(wq_l + 8 * D);                     // [8 waves][64]  cross-wave combine of the G and I products
   float* red_q = (float*)(red_i + kWaves * 64);                // [8 waves][D]        d q combine (A')
   float* ss = red_q + kWaves * D;                              // [H][32] scaled scores of own rows
@@ -68,6 +74,8 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   float* sa = sd + 16 * 32;                                    // [H][32] alpha_d
   float* lnp_l = sa + 16 * 32;                                 // [3][D]  ln gamma | ln beta | v (read in A' only)
   float* pacc = lnp_l + 3 * D;                                 // [3][8 waves][D]  d v | d ln_g | d ln_b accumulators of the waves
+  float* pd_l = pacc + 3 * kWaves * D;                         // OWN: [16] this workgroup's partial dots, [16] the batch row's dots
+  float* dot_l = pd_l + 16;
 
   // hand-off buffers in BLOCKED layouts: a k16-block of the 16 rows of a group is one contiguous KiB (16 rows x 64
   // bytes), which is exactly what one MFMA-operand load of a wave reads: whole 128-byte lines instead of 16 half lines
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   const int rows_here = min(kGroupRows, B - row0);              // rows of this group that exist
   const int r16c = min(lane & 15, rows_here - 1);               // MFMA-operand row of this lane (clamped: unused rows)
   const __amdgpu_buffer_rsrc_t ds_r = make_rsrc(a.dstate, (long)Tp * B * 2 * D * 4);
+  const __amdgpu_buffer_rsrc_t dot_r = make_rsrc(a.dotp, OWN ? (long)Tp * B * 64 * 4 : 0);   // [t][row][quarter][16 heads]
 
   // ---- A' identity: batch row, owned memory rows ---------------------------------------------------------------------
   const int ab = row0 + (wi & 15), aq = wi >> 4;
@@ -87,11 +96,21 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   const int k0 = lane * EPL, head = k0 / dh;
   const int m_own = aq + 4 * wave;                             // this wave's memory row
   const bool has_own = a_live && m_own < M;
+  const int m_own2 = aq + 4 * (wave + kWaves);                 // OWN: its second row (slot wave + 8)
+  const bool has_own2 = OWN && a_live && m_own2 < M;
   const int a_len = a_live ? a.lens[ab] : 0;
   {
     const int arow = a_live ? ab : 0;
     const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
-    for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
+    if constexpr (OWN) {
+      for (int i = tid; i < 16 * D / 4; i += kThreads) {
+        const int m = aq + 4 * (i / (D / 4));
+        ((float4*)keys_l)[i] = m < M ? ks[(size_t)m * (D / 4) + i % (D / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (tid < 32) pd_l[tid] = 0.f;
+    } else {
+      for (int i = tid; i < M * D / 4; i += kThreads) ((float4*)keys_l)[i] = ks[i];
+    }
     for (int i = tid; i < 8 * D; i += kThreads) {              // W_q[8 wi + u][k] at ((k/16 * 8 + u) * 4 + (k%16)/4) * 4 + k%4
       const int u = i >> 9, k = i & (D - 1);
       wq_l[(((k >> 4) * 8 + u) * 4 + ((k & 15) >> 2)) * 4 + (k & 3)] = a.W_q[(size_t)(8 * wi + u) * D + k];
@@ -103,9 +122,9 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   }
   const float scale = a.method == 0 ? a.tau[0] : sqrtf((float)dh);
   const float inv_scale = 1.0f / scale;
-  float datt_state[EPL], dk_acc[EPL], dtau = 0.f;
+  float datt_state[EPL], dk_acc[EPL], dk_acc2[EPL], dtau = 0.f;
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = 0.f;
+  for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = dk_acc2[i] = 0.f;
   for (int i = tid; i < 3 * kWaves * D; i += kThreads) pacc[i] = 0.f;
   float* pa_v = pacc + wave * D + k0;                          // this lane's slices
   float* pa_g = pa_v + kWaves * D;
@@ -159,6 +178,199 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         bv[i] = lnp_l[D + k0 + i];
         vv[i] = lnp_l[2 * D + k0 + i];
       }
+      if constexpr (OWN) {
+        // the wave's own rows: slot wave (row m_own) and slot wave + 8 (row m_own2)
+        float mean0 = 0.f, rstd0 = 0.f, mean1 = 0.f, rstd1 = 0.f;   // (scalar selects below: no dynamically indexed arrays)
+        // (i) statistics and scaled scores of the own rows (tanh is recomputed in (iii): nothing but two scalars is held)
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+          if (!(r == 0 ? has_own : has_own2)) continue;
+          const int slot = wave + kWaves * r;
+          const float* kr = keys_l + slot * D + k0;
+          const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+          const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+          float part = 0.f;
+          if (a.method == 0) {
+            float z[EPL], s = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              z[i] = kk[i] + qv[i];
+              s += z[i];
+            }
+            const float mean = wave_sum(s) / (float)D;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              const float cc = z[i] - mean;
+              s2 += cc * cc;
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
+            if (r == 0) { mean0 = mean; rstd0 = rstd; } else { mean1 = mean; rstd1 = rstd; }
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              const float inv = rstd * gv[i];
+              part += fast_tanh(z[i] * inv + (bv[i] - mean * inv)) * vv[i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) part += kk[i] * qv[i];
+          }
+          part = head_total(part, lph);
+          if ((lane % lph) == 0) ss[head * 32 + slot] = part * inv_scale;
+        }
+        // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
+        if (t + 1 < Tp) {
+          wait_written<2>(dv2, ds_r, dso, off2, 3u, wt);
+          const float keepf = (t + 1 >= a_len) ? 1.f : 0.f;
+          const float vin[EPL] = {dv2[0].x, dv2[0].y, dv2[0].z, dv2[0].w, dv2[1].x, dv2[1].y, dv2[1].z, dv2[1].w};
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) datt_state[i] = datt_state[i] * keepf + vin[i];
+        }
+        float dcl[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) dcl[i] = datt_state[i] * live;
+        // (ii) d alpha_d of the OWN rows: d ctx . values
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+          if (!(r == 0 ? has_own : has_own2)) continue;
+          const int slot = wave + kWaves * r;
+          const float* kr = keys_l + slot * D + k0;
+          const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+          float part = dcl[0] * ka.x;
+          part = fmaf(dcl[1], ka.y, part); part = fmaf(dcl[2], ka.z, part); part = fmaf(dcl[3], ka.w, part);
+          part = fmaf(dcl[4], kb.x, part); part = fmaf(dcl[5], kb.y, part); part = fmaf(dcl[6], kb.z, part);
+          part = fmaf(dcl[7], kb.w, part);
+          part = head_total(part, lph);
+          if ((lane % lph) == 0)
+            sd[head * 32 + slot] = part + (a.dmap ? a.dmap[((size_t)t * B + ab) * M + aq + 4 * slot] : 0.f);
+        }
+        __syncthreads();
+        // through the dropout; the softmax backward needs sum_m alpha * d alpha over ALL rows of a head: this workgroup's
+        // part of it (lanes = own slots), heads wave and wave + 8
+        float al_[2] = {0.f, 0.f}, da_[2] = {0.f, 0.f}, mk_[2] = {1.f, 1.f};
+        const int mlane = aq + 4 * lane;
+        const bool in = lane < 16 && mlane < M;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int h = wave + kWaves * hh;
+          if (h >= H) continue;
+          const size_t go = (((size_t)t * B + ab) * H + h) * M;
+          al_[hh] = in ? a.alpha_all[go + mlane] : 0.f;
+          mk_[hh] = (in && a.mask_alpha) ? a.mask_alpha[go + mlane] : 1.f;
+          float da = in ? sd[h * 32 + lane] : 0.f;
+          if (a.mask_alpha) da = (da / a.keep_alpha) * mk_[hh];
+          da_[hh] = da;
+          const float pd = wave_sum(al_[hh] * da);
+          if (lane == 0) pd_l[h] = pd;
+        }
+        __syncthreads();
+        const unsigned dbase = (unsigned)((((size_t)t * B + ab) * 64) * 4);
+        if (wave == 0 && lane < 4)
+          store16_sc1(dot_r, dbase + (unsigned)((aq * 16 + 4 * lane) * 4), *(const float4*)(pd_l + 4 * lane));
+        __syncthreads();                                        // poll only after the own stores are on their way
+        if (wave == 0) {                                        // lane l < 4: heads 4 l .. 4 l + 3 of the four quarters, in order
+          const unsigned po = dbase + (unsigned)((4 * (lane & 3)) * 4);
+          const unsigned qoff[4] = {0u, 64u, 128u, 192u};
+          float4 pv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pv[k] = load16_sc1(dot_r, po + qoff[k]);
+          wait_written<4>(pv, dot_r, po, qoff, 15u, wt);
+          if (lane < 4)
+            *(float4*)(dot_l + 4 * lane) = make_float4((pv[0].x + pv[1].x) + (pv[2].x + pv[3].x), (pv[0].y + pv[1].y) + (pv[2].y + pv[3].y),
+                                                       (pv[0].z + pv[1].z) + (pv[2].z + pv[3].z), (pv[0].w + pv[1].w) + (pv[2].w + pv[3].w));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int h = wave + kWaves * hh;
+          if (h >= H) continue;
+          const float dsv = al_[hh] * (da_[hh] - dot_l[h]);      // softmax backward (the launch requires prob == 0)
+          if (in) {
+            dtau -= dsv * ss[h * 32 + lane];
+            sd[h * 32 + lane] = dsv * inv_scale;
+            sa[h * 32 + lane] = a.mask_alpha ? (al_[hh] / a.keep_alpha) * mk_[hh] : al_[hh];
+          }
+        }
+        __syncthreads();
+        // (iii) own rows: through tanh / LayerNorm (or the dot product); d keys and parameter gradients stay on the CU
+        float dqv[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) dqv[i] = 0.f;
+        if (has_own) {
+          // (the accumulators of d v / d ln_g / d ln_b are updated in LDS row by row: no register copy of them is held)
+          auto lds_add8 = [](float* p, const float (&v)[EPL]) {
+            float4 x = *(const float4*)p, y = *(const float4*)(p + 4);
+            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3]; y.x += v[4]; y.y += v[5]; y.z += v[6]; y.w += v[7];
+            *(float4*)p = x;
+            *(float4*)(p + 4) = y;
+          };
+#pragma unroll 1
+          for (int r = 0; r < 2; ++r) {
+            if (!(r == 0 ? has_own : has_own2)) continue;
+            const int slot = wave + kWaves * r;
+            const float* kr = keys_l + slot * D + k0;
+            const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+            const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+            const float draw = sd[head * 32 + slot], adm = sa[head * 32 + slot];
+            float dkr[EPL];
+            if (a.method == 0) {
+              const float mean = r == 0 ? mean0 : mean1, rstd = r == 0 ? rstd0 : rstd1;
+              float dxh[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
+              {
+                float tv[EPL], tg[EPL], tb[EPL];
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) {
+                  const float zz = kk[i] + qv[i];
+                  const float inv = rstd * gv[i];
+                  const float th = fast_tanh(zz * inv + (bv[i] - mean * inv));
+                  xh[i] = (zz - mean) * rstd;
+                  tv[i] = draw * th;
+                  const float dzh = draw * vv[i] * (1.f - th * th);
+                  tg[i] = dzh * xh[i];
+                  tb[i] = dzh;
+                  dxh[i] = dzh * gv[i];
+                  s1 += dxh[i];
+                  s2 += dxh[i] * xh[i];
+                }
+                lds_add8(pa_v, tv);
+                lds_add8(pa_g, tg);
+                lds_add8(pa_b, tb);
+              }
+              const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+              for (int i = 0; i < EPL; ++i) {
+                const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
+                dkr[i] = dz + adm * dcl[i];
+                dqv[i] += dz;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < EPL; ++i) {
+                dkr[i] = draw * qv[i] + adm * dcl[i];
+                dqv[i] += draw * kk[i];
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              if (r == 0) dk_acc[i] += dkr[i];
+              else dk_acc2[i] += dkr[i];
+            }
+          }
+          *(float4*)(red_q + wave * D + k0) = make_float4(dqv[0], dqv[1], dqv[2], dqv[3]);
+          *(float4*)(red_q + wave * D + k0 + 4) = make_float4(dqv[4], dqv[5], dqv[6], dqv[7]);
+        }
+        __syncthreads();
+        if (wave < 2) {                                           // this workgroup's partial of d q_t: 4 channels a thread
+          float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int w = 0; w < kWaves; ++w) {                      // fixed order: deterministic
+            const float4 pp = *(const float4*)(red_q + w * D + 4 * tid);
+            sum.x += pp.x; sum.y += pp.y; sum.z += pp.z; sum.w += pp.w;
+          }
+          store16_sc1(dqp_r, (unsigned)(((((size_t)t * B + ab) * 4 + aq) * D + 4 * tid) * 4), sum);
+        }
+        __syncthreads();   // polls of the next phase start after this workgroup's own stores are on their way
+      } else {
       // (i) own row: LayerNorm / tanh recomputed, scaled scores of every head
       float th[EPL], xh[EPL], kro[EPL], rstd = 0.f;
 #pragma unroll
@@ -292,6 +504,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         store16_sc1(dqp_r, (unsigned)(((((size_t)t * B + ab) * 4 + aq) * D + 4 * tid) * 4), sum);
       }
       __syncthreads();   // polls of the next phase start after this workgroup's own stores are on their way
+      }
     }
     stamp(a.stamps, t, 1);
     // ===================================================================== G: query layer + LSTM cell backward =========
@@ -487,6 +700,11 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
       *(float4*)dk = make_float4(dk_acc[0], dk_acc[1], dk_acc[2], dk_acc[3]);
       *(float4*)(dk + 4) = make_float4(dk_acc[4], dk_acc[5], dk_acc[6], dk_acc[7]);
     }
+    if (has_own2) {
+      float* dk = a.dkeys + ((size_t)ab * M + m_own2) * D + k0;
+      *(float4*)dk = make_float4(dk_acc2[0], dk_acc2[1], dk_acc2[2], dk_acc2[3]);
+      *(float4*)(dk + 4) = make_float4(dk_acc2[4], dk_acc2[5], dk_acc2[6], dk_acc2[7]);
+    }
     // parameter-gradient row of this workgroup: [d v | d ln_g | d ln_b | d tau], summed over its waves in fixed order
     float* pg = a.pgrad + ((size_t)ab * 4 + aq) * (3 * D + 1);
     __syncthreads();
@@ -508,9 +726,11 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   }
 }
 
-int64_t bwd_lds_bytes(int M) {
-  return (int64_t)M * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4 + 3 * kWaves * kD * 4;
+int64_t bwd_lds_bytes(int M, bool own) {
+  return (int64_t)(own ? 16 : M) * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4 +
+         3 * kWaves * kD * 4 + 32 * 4;
 }
+inline bool bwd_own(int M) { return M > 28; }                 // the whole key matrix fits up to M = 28
 
 }  // namespace
 
@@ -518,8 +738,8 @@ bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int C
                                  int context_layer, int tied) {
   if (!comic_persist_fwd_supported(B, D, E, A, M, H, Cv, method, context_layer, tied)) return false;
   if (!tied || prob != 0) return false;                        // d values folded into d keys; softmax probability
-  if (M > 4 * kWaves || E % 16 != 0) return false;             // one owned memory row per wave (4 workgroups a batch row)
-  return bwd_lds_bytes(M) <= 160 * 1024;
+  if (M > 8 * kWaves || E % 16 != 0) return false;             // one or two owned memory rows per wave (4 workgroups a batch row)
+  return bwd_lds_bytes(M, bwd_own(M)) <= 160 * 1024;
 }
 
 int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st) {
@@ -532,13 +752,18 @@ int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int c
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
   ComicPersistBwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(1, a.Tp, st) : nullptr;
-  int64_t lds = bwd_lds_bytes(a.M);
+  const bool own = bwd_own(a.M);
+  if (own && !a.dotp) {
+    comic_set_error("persistent decoder backward: M = %d needs the dot-product hand-off buffer", a.M);
+    return 2;
+  }
+  int64_t lds = bwd_lds_bytes(a.M, own);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
-  static PerDeviceOnce attr_once__;
-  bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
+  static PerDeviceOnce attr_once__[2];
+  bool& attr_set = attr_once__[own ? 1 : 0].slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)decoder_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
+    const void* kern = own ? (const void*)decoder_bwd_persistent_kernel<true> : (const void*)decoder_bwd_persistent_kernel<false>;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       comic_set_error("persistent decoder backward: cannot reserve LDS");
       return 1;
     }
@@ -549,7 +774,8 @@ int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
     comic_set_error("persistent decoder backward: bad group range %d + %d at batch %d", a.grp0, groups, a.B);
     return 2;
   }
-  hipLaunchKernelGGL(decoder_bwd_persistent_kernel, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  if (own) hipLaunchKernelGGL(decoder_bwd_persistent_kernel<true>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  else hipLaunchKernelGGL(decoder_bwd_persistent_kernel<false>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
   COMIC_LAUNCH_CHECK("persistent decoder backward");
   return 0;
 }

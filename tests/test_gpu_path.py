@@ -403,6 +403,7 @@ TRAIN_VARIANTS = [
     # persistent time loop (decoder_persist.hip; D = 512 only): the other memory / alignment / probability forms
     dict(D=512, E=256, fm_projection='independent', prob='sigmoid', H=4),
     dict(D=512, E=128, method='dot', H=16, M=64),                               # W_q columns from L2 (keys fill the LDS)
+    dict(D=512, E=256, M=64),                                                   # 299-pixel map: own-rows backward loop, add_LN
     # the reference CLI's default geometry (train.py:56,65): Inception-V1 Mixed_4f, 14 x 14 x 832 -> M = 196; the
     # attention kernels run in their split form (several workgroups per batch row, decoder.hip)
     dict(D=512, E=256, C=832, Cg=1024, M=196),
@@ -448,7 +449,8 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
 
 
-@pytest.mark.parametrize('B,geo', [(64, {}), (23, {}), (64, dict(C=832, Cg=1024, M=196)), (23, dict(C=832, Cg=1024, M=196))])
+@pytest.mark.parametrize('B,geo', [(64, {}), (23, {}), (64, dict(C=832, Cg=1024, M=196)), (23, dict(C=832, Cg=1024, M=196)),
+                                   (64, dict(M=64)), (23, dict(M=64, H=16))])
 def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
     """The one-launch forward time loop (decoder_persist.hip: 64 workgroups per 16 batch rows, sc1 hand-offs, counter
     barriers) against the per-step launch chain it replaces, at the bench geometry with every dropout on: same saved
@@ -456,7 +458,8 @@ def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
     of the previous launch read in place of this one's) would show in the second."""
     # geo M = 196 (Inception-V1 Mixed_4f, the reference CLI's default map): the forward loop in its large-memory form (a
     # workgroup holds its channel quarter of the keys, the LayerNorm sums cross the four quarters); the backward loop does
-    # not cover it (path 1)
+    # not cover it (path 1).  geo M = 64 (the 8 x 8 map of 299-pixel inputs): the backward loop in its own-rows form (a
+    # workgroup holds its 16 memory rows, the softmax backward's dot products cross the four quarters): path 3
     spec, cfg = _spec_and_cfg(**dict(dict(D=512, E=256, C=2048, Cg=2048), **geo))
     big = spec.M > 64
     Lc = 30
