@@ -812,6 +812,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(TB * 2 * D);                                                   // d att | d h
   w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
   w.take<float>(TB * 64);                                                      // ... per-head dot products of the row quarters (M > 28)
+  if (M > 64) w.take<float>(TB * 8 * M);                                       // forward loop, M > 64: LayerNorm sums of the channel quarters
   if (d->cell == COMIC_CELL_LN_LSTM) {           // normalised rows, 1/std and LayerNorm gradient rows of every step + the init step
     w.take<float>((TB + B) * 5 * D); w.take<float>((TB + B) * 8); w.take<float>((TB + B) * 10 * D); w.take<float>(10 * D);
   } else if (d->cell == COMIC_CELL_GRU) {        // [x ; att ; r*h] of every step, the two d-operand products of a step, bias sums
@@ -892,6 +893,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dstate = w.take<float>(TB * 2 * D);
   float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
   float* dotp = w.take<float>(TB * 64);
+  float* statp = M > 64 ? w.take<float>(TB * 8 * M) : nullptr;
   const int cell = d->cell;
   float *lnx_all = nullptr, *lnr_all = nullptr, *lnpg = nullptr, *cell_tmp = nullptr, *xh2_all = nullptr, *gru_dxh = nullptr;
   if (cell == COMIC_CELL_LN_LSTM) {
@@ -926,7 +928,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pr.p[1] = y_all; pr.n[1] = (long)Tp * B * D;
     pr.p[2] = q_all; pr.n[2] = (long)Tp * B * D;
     if (M > 64) {                      // the quarters' partial LayerNorm sums (decoder_persist.hip, BIGM): [Tp][B][4][M/2][4]
-      pr.p[3] = dq_part; pr.n[3] = (long)Tp * B * 8 * M;      // (dq_part: the backward loop does not cover this M)
+      pr.p[8] = statp; pr.n[8] = (long)Tp * B * 8 * M;
     }
     if (persist_b) {
       pr.p[3] = dq_part; pr.n[3] = (long)Tp * B * 4 * D;
@@ -971,7 +973,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pa.xh_all = xh_all; pa.gates_all = gates_all; pa.cnew_all = cnew_all; pa.y_all = y_all; pa.q_all = q_all;
     pa.cs = cs; pa.hs = hs; pa.att_all = att_all; pa.alpha_all = alpha_all; pa.attn_hist = attn_hist;
     pa.ctx_all = ctx_all; pa.sync = persist_sync;
-    pa.statp = (M > 64 && !persist_b && (long)8 * M <= 4L * D) ? dq_part : nullptr;
+    pa.statp = statp;
     pa.B = B; pa.D = D; pa.E = E; pa.Wd = Wd; pa.M = M; pa.H = H; pa.Tp = Tp;
     pa.method = d->method; pa.prob = d->prob; pa.tied = ad.tied;
     const int n_grp = (B + 15) / 16;                     // a launch serves up to four 16-row groups (256 CUs)
@@ -1076,6 +1078,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // d q / parameter-gradient contributions are added into zero-filled rows (comic_attn_bwd_ex, pgrad_overwrite 2)
   const int attn_bwd_mode = (d->prob == 0 && split_attn_bwd_enabled()) ? 2 : 1;
   if (persist_b) {
+    // M > 64: the loop ADDS its rows' d keys into memory step by step (one writer per address, in step order)
+    if (M > 64) RC(fill(dkeys, 0.f, (long)B * M * D, st));
     ComicPersistBwdArgs pb{};
     pb.K = p->K; pb.W_q = p->W_q; pb.keys = keys;
     pb.ln_g = p->ln_g; pb.ln_b = p->ln_b; pb.v = p->v; pb.tau = p->tau; pb.lens = lens;

@@ -53,11 +53,12 @@ constexpr int kPersistSyncWords = 64;       // the error word, and from word 32 
 
 bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
                                  int tied);
-// fills the hand-off buffers (up to eight ranges of floats, sizes multiples of 4) with the sentinel and clears the
+// fills the hand-off buffers (up to kPersistRanges ranges of floats, sizes multiples of 4) with the sentinel and clears the
 // sync words; call BEFORE the kernels that write the x parts and the step-0 row
+constexpr int kPersistRanges = 10;
 struct ComicPersistRanges {
-  float* p[8];
-  long n[8];
+  float* p[kPersistRanges];
+  long n[kPersistRanges];
 };
 int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st);
 bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, int Cv, int V, int method,

@@ -717,7 +717,7 @@ __global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kPersistSyncWords) sync[i] = 0u;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < kPersistRanges; ++k) {
     const long n4 = r.n[k] >> 2;
     if (i < n4) {
       ((uint4*)r.p[k])[i] = v;
@@ -880,7 +880,7 @@ int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStre
 
 int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st) {
   long n = 0;
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < kPersistRanges; ++k) {
     COMIC_REQUIRE(r.n[k] % 4 == 0 && (r.n[k] == 0 || r.p[k]), "persistent decoder: bad hand-off range %d", k);
     n += r.n[k] / 4;
   }

@@ -53,8 +53,16 @@ __device__ __forceinline__ void stamp(unsigned long long* st, int t, int i) {
 // formed for the own rows only; the softmax backward needs the dot product sum_m alpha * d alpha over ALL rows of a head,
 // which the four workgroups of a batch row assemble from their partial sums through one more sentinel-checked hand-off
 // ([T'][B][4][16] floats).  The own rows' LayerNorm / tanh are recomputed in the last part instead of held in registers.
-template <bool OWN>
+// MODE 2 (64 < M <= 256: the reference CLI's default map, Inception-V1 Mixed_4f, M = 196): the own-rows form with up to
+// eight rows per wave.  Neither eight rows of d keys per wave (registers) nor the per-wave d v / d ln_g / d ln_b accumulators
+// (48 KB of LDS beside 100 KB of keys) fit any more: d keys go to memory with no-return float atomics -- ONE writer per
+// address, adds in step order, so the sums are reproducible -- into a zero-filled buffer, and the three parameter-gradient
+// rows of a step are combined over the waves through the d q combine buffer into three registers per thread.
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicPersistBwdArgs a) {
+  constexpr bool OWN = MODE != 0, BIG = MODE == 2;
+  constexpr int NR = BIG ? 8 : 2;                               // own rows per wave (slots wave + 8 r)
+  constexpr int SP = BIG ? 64 : 32;                             // slots per head row of the score buffers
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = kD, EPL = 8;
   const int M = a.M, H = a.H, E = a.E, EA = a.E + D, B = a.B, Tp = a.Tp, N4 = 4 * D;
@@ -66,16 +74,17 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
 
   // ---- LDS carve-up ---------------------------------------------------------------------------------------------
   float* keys_l = (float*)smem;                                // [M][D]   keys (= values) of the attention row (OWN: [16 slots][D], slot j = row quarter + 4 j)
-  float* wq_l = keys_l + (OWN ? 16 : M) * D;                   // [32 k16-blocks][8 units][4][4]  W_q rows of its units
+  float* wq_l = keys_l + (BIG ? (M + 3) / 4 : OWN ? 16 : M) * D;   // [32 k16-blocks][8 units][4][4]  W_q rows of its units
   float4* red_i = (float4*)(wq_l + 8 * D);                     // [8 waves][64]  cross-wave combine of the G and I products
   float* red_q = (float*)(red_i + kWaves * 64);                // [8 waves][D]        d q combine (A')
-  float* ss = red_q + kWaves * D;                              // [H][32] scaled scores of own rows
-  float* sd = ss + 16 * 32;                                    // [H][32] d alpha_d, then d raw
-  float* sa = sd + 16 * 32;                                    // [H][32] alpha_d
-  float* lnp_l = sa + 16 * 32;                                 // [3][D]  ln gamma | ln beta | v (read in A' only)
-  float* pacc = lnp_l + 3 * D;                                 // [3][8 waves][D]  d v | d ln_g | d ln_b accumulators of the waves
-  float* pd_l = pacc + 3 * kWaves * D;                         // OWN: [16] this workgroup's partial dots, [16] the batch row's dots
+  float* ss = red_q + kWaves * D;                              // [H][SP] scaled scores of own rows
+  float* sd = ss + 16 * SP;                                    // [H][SP] d alpha_d, then d raw
+  float* sa = sd + 16 * SP;                                    // [H][SP] alpha_d
+  float* lnp_l = sa + 16 * SP;                                 // [3][D]  ln gamma | ln beta | v (read in A' only)
+  float* pacc = lnp_l + 3 * D;                                 // [3][8 waves][D]  d v | d ln_g | d ln_b accumulators of the waves (not MODE 2)
+  float* pd_l = pacc + (BIG ? 0 : 3 * kWaves * D);             // OWN: [16] this workgroup's partial dots, [16] the batch row's dots
   float* dot_l = pd_l + 16;
+  float* ms_l = dot_l + 16;                                    // MODE 2: [64 slots][2] mean, 1/std of the own rows at this step
 
   // hand-off buffers in BLOCKED layouts: a k16-block of the 16 rows of a group is one contiguous KiB (16 rows x 64
   // bytes), which is exactly what one MFMA-operand load of a wave reads: whole 128-byte lines instead of 16 half lines
@@ -97,13 +106,13 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   const int m_own = aq + 4 * wave;                             // this wave's memory row
   const bool has_own = a_live && m_own < M;
   const int m_own2 = aq + 4 * (wave + kWaves);                 // OWN: its second row (slot wave + 8)
-  const bool has_own2 = OWN && a_live && m_own2 < M;
+  const bool has_own2 = OWN && a_live && m_own2 < M;           // (MODE 2 walks its rows by slot: row_ok)
   const int a_len = a_live ? a.lens[ab] : 0;
   {
     const int arow = a_live ? ab : 0;
     const float4* ks = (const float4*)(a.keys + (size_t)arow * M * D);
     if constexpr (OWN) {
-      for (int i = tid; i < 16 * D / 4; i += kThreads) {
+      for (int i = tid; i < (BIG ? (M + 3) / 4 : 16) * (D / 4); i += kThreads) {
         const int m = aq + 4 * (i / (D / 4));
         ((float4*)keys_l)[i] = m < M ? ks[(size_t)m * (D / 4) + i % (D / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -125,7 +134,9 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   float datt_state[EPL], dk_acc[EPL], dk_acc2[EPL], dtau = 0.f;
 #pragma unroll
   for (int i = 0; i < EPL; ++i) datt_state[i] = dk_acc[i] = dk_acc2[i] = 0.f;
-  for (int i = tid; i < 3 * kWaves * D; i += kThreads) pacc[i] = 0.f;
+  if constexpr (!BIG)
+    for (int i = tid; i < 3 * kWaves * D; i += kThreads) pacc[i] = 0.f;
+  float pg_v = 0.f, pg_g = 0.f, pg_b = 0.f;                     // MODE 2: d v / d ln_g / d ln_b of channel tid, summed over waves and steps
   float* pa_v = pacc + wave * D + k0;                          // this lane's slices
   float* pa_g = pa_v + kWaves * D;
   float* pa_b = pa_g + kWaves * D;
@@ -179,44 +190,51 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         vv[i] = lnp_l[2 * D + k0 + i];
       }
       if constexpr (OWN) {
-        // the wave's own rows: slot wave (row m_own) and slot wave + 8 (row m_own2)
-        float mean0 = 0.f, rstd0 = 0.f, mean1 = 0.f, rstd1 = 0.f;   // (scalar selects below: no dynamically indexed arrays)
-        // (i) statistics and scaled scores of the own rows (tanh is recomputed in (iii): nothing but two scalars is held)
+        // the wave's own rows: slots wave + 8 r, rows m = quarter + 4 slot
+        auto row_ok = [&](int r) { return a_live && aq + 4 * (wave + kWaves * r) < M; };
+        // one own row's LayerNorm statistics of keys + q over the D channels (8 a lane)
+        auto row_stats = [&](const float (&kk)[EPL], float& mean, float& rstd) {
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) s += kk[i] + qv[i];
+          mean = wave_sum(s) / (float)D;
+          float s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < EPL; ++i) {
+            const float cc = kk[i] + qv[i] - mean;
+            s2 += cc * cc;
+          }
+          rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
+        };
+        // MODE 2 recomputes M / 4 * 512 tanh twice a step: 1 - 2 / (1 + e^(2x)) on v_exp_f32 / v_rcp_f32 (|error| < 2e-7)
+        auto tanh_b = [](float x) {
+          if constexpr (BIG) return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+          else return fast_tanh(x);
+        };
+        // (i) scaled scores of the own rows (a row is recomputed in (iii); MODE 2 keeps its two statistics in LDS)
 #pragma unroll 1
-        for (int r = 0; r < 2; ++r) {
-          if (!(r == 0 ? has_own : has_own2)) continue;
+        for (int r = 0; r < NR; ++r) {
+          if (!row_ok(r)) break;
           const int slot = wave + kWaves * r;
           const float* kr = keys_l + slot * D + k0;
           const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
           const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
           float part = 0.f;
           if (a.method == 0) {
-            float z[EPL], s = 0.f;
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-              z[i] = kk[i] + qv[i];
-              s += z[i];
-            }
-            const float mean = wave_sum(s) / (float)D;
-            float s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-              const float cc = z[i] - mean;
-              s2 += cc * cc;
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)D + kLnEps);
-            if (r == 0) { mean0 = mean; rstd0 = rstd; } else { mean1 = mean; rstd1 = rstd; }
+            float mean, rstd;
+            row_stats(kk, mean, rstd);
+            if (BIG && lane == 0) *(float2*)(ms_l + 2 * slot) = make_float2(mean, rstd);   // (read back by this wave only)
 #pragma unroll
             for (int i = 0; i < EPL; ++i) {
               const float inv = rstd * gv[i];
-              part += fast_tanh(z[i] * inv + (bv[i] - mean * inv)) * vv[i];
+              part += tanh_b((kk[i] + qv[i]) * inv + (bv[i] - mean * inv)) * vv[i];
             }
           } else {
 #pragma unroll
             for (int i = 0; i < EPL; ++i) part += kk[i] * qv[i];
           }
           part = head_total(part, lph);
-          if ((lane % lph) == 0) ss[head * 32 + slot] = part * inv_scale;
+          if ((lane % lph) == 0) ss[head * SP + slot] = part * inv_scale;
         }
         // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
         if (t + 1 < Tp) {
@@ -231,8 +249,8 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
         for (int i = 0; i < EPL; ++i) dcl[i] = datt_state[i] * live;
         // (ii) d alpha_d of the OWN rows: d ctx . values
 #pragma unroll 1
-        for (int r = 0; r < 2; ++r) {
-          if (!(r == 0 ? has_own : has_own2)) continue;
+        for (int r = 0; r < NR; ++r) {
+          if (!row_ok(r)) break;
           const int slot = wave + kWaves * r;
           const float* kr = keys_l + slot * D + k0;
           const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
@@ -242,14 +260,14 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           part = fmaf(dcl[7], kb.w, part);
           part = head_total(part, lph);
           if ((lane % lph) == 0)
-            sd[head * 32 + slot] = part + (a.dmap ? a.dmap[((size_t)t * B + ab) * M + aq + 4 * slot] : 0.f);
+            sd[head * SP + slot] = part + (a.dmap ? a.dmap[((size_t)t * B + ab) * M + aq + 4 * slot] : 0.f);
         }
         __syncthreads();
         // through the dropout; the softmax backward needs sum_m alpha * d alpha over ALL rows of a head: this workgroup's
         // part of it (lanes = own slots), heads wave and wave + 8
         float al_[2] = {0.f, 0.f}, da_[2] = {0.f, 0.f}, mk_[2] = {1.f, 1.f};
         const int mlane = aq + 4 * lane;
-        const bool in = lane < 16 && mlane < M;
+        const bool in = lane < SP && mlane < M;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int h = wave + kWaves * hh;
@@ -257,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           const size_t go = (((size_t)t * B + ab) * H + h) * M;
           al_[hh] = in ? a.alpha_all[go + mlane] : 0.f;
           mk_[hh] = (in && a.mask_alpha) ? a.mask_alpha[go + mlane] : 1.f;
-          float da = in ? sd[h * 32 + lane] : 0.f;
+          float da = in ? sd[h * SP + lane] : 0.f;
           if (a.mask_alpha) da = (da / a.keep_alpha) * mk_[hh];
           da_[hh] = da;
           const float pd = wave_sum(al_[hh] * da);
@@ -286,79 +304,120 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           if (h >= H) continue;
           const float dsv = al_[hh] * (da_[hh] - dot_l[h]);      // softmax backward (the launch requires prob == 0)
           if (in) {
-            dtau -= dsv * ss[h * 32 + lane];
-            sd[h * 32 + lane] = dsv * inv_scale;
-            sa[h * 32 + lane] = a.mask_alpha ? (al_[hh] / a.keep_alpha) * mk_[hh] : al_[hh];
+            dtau -= dsv * ss[h * SP + lane];
+            sd[h * SP + lane] = dsv * inv_scale;
+            sa[h * SP + lane] = a.mask_alpha ? (al_[hh] / a.keep_alpha) * mk_[hh] : al_[hh];
           }
         }
         __syncthreads();
-        // (iii) own rows: through tanh / LayerNorm (or the dot product); d keys and parameter gradients stay on the CU
-        float dqv[EPL];
+        // (iii) own rows: through tanh / LayerNorm (or the dot product)
+        float dqv[EPL], tv[EPL], tg[EPL], tb[EPL];                // d q and (MODE 2) this step's d v / d ln_g / d ln_b of the wave's rows
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) dqv[i] = 0.f;
-        if (has_own) {
-          // (the accumulators of d v / d ln_g / d ln_b are updated in LDS row by row: no register copy of them is held)
-          auto lds_add8 = [](float* p, const float (&v)[EPL]) {
-            float4 x = *(const float4*)p, y = *(const float4*)(p + 4);
-            x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3]; y.x += v[4]; y.y += v[5]; y.z += v[6]; y.w += v[7];
-            *(float4*)p = x;
-            *(float4*)(p + 4) = y;
-          };
+        for (int i = 0; i < EPL; ++i) dqv[i] = tv[i] = tg[i] = tb[i] = 0.f;
+        auto lds_add8 = [](float* p, const float (&v)[EPL]) {
+          float4 x = *(const float4*)p, y = *(const float4*)(p + 4);
+          x.x += v[0]; x.y += v[1]; x.z += v[2]; x.w += v[3]; y.x += v[4]; y.y += v[5]; y.z += v[6]; y.w += v[7];
+          *(float4*)p = x;
+          *(float4*)(p + 4) = y;
+        };
 #pragma unroll 1
-          for (int r = 0; r < 2; ++r) {
-            if (!(r == 0 ? has_own : has_own2)) continue;
-            const int slot = wave + kWaves * r;
-            const float* kr = keys_l + slot * D + k0;
-            const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
-            const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-            const float draw = sd[head * 32 + slot], adm = sa[head * 32 + slot];
-            float dkr[EPL];
-            if (a.method == 0) {
-              const float mean = r == 0 ? mean0 : mean1, rstd = r == 0 ? rstd0 : rstd1;
-              float dxh[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
-              {
-                float tv[EPL], tg[EPL], tb[EPL];
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) {
-                  const float zz = kk[i] + qv[i];
-                  const float inv = rstd * gv[i];
-                  const float th = fast_tanh(zz * inv + (bv[i] - mean * inv));
-                  xh[i] = (zz - mean) * rstd;
-                  tv[i] = draw * th;
-                  const float dzh = draw * vv[i] * (1.f - th * th);
-                  tg[i] = dzh * xh[i];
-                  tb[i] = dzh;
-                  dxh[i] = dzh * gv[i];
-                  s1 += dxh[i];
-                  s2 += dxh[i] * xh[i];
-                }
-                lds_add8(pa_v, tv);
-                lds_add8(pa_g, tg);
-                lds_add8(pa_b, tb);
-              }
-              const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-#pragma unroll
-              for (int i = 0; i < EPL; ++i) {
-                const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
-                dkr[i] = dz + adm * dcl[i];
-                dqv[i] += dz;
-              }
+        for (int r = 0; r < NR; ++r) {
+          if (!row_ok(r)) break;
+          const int slot = wave + kWaves * r;
+          const float* kr = keys_l + slot * D + k0;
+          const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
+          const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+          const float draw = sd[head * SP + slot], adm = sa[head * SP + slot];
+          float dkr[EPL];
+          if (a.method == 0) {
+            float mean, rstd;
+            if constexpr (BIG) {
+              const float2 ms = *(const float2*)(ms_l + 2 * slot);
+              mean = ms.x;
+              rstd = ms.y;
             } else {
+              row_stats(kk, mean, rstd);
+            }
+            float dxh[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
+            {
+              float uv[EPL], ug[EPL], ub[EPL];
 #pragma unroll
               for (int i = 0; i < EPL; ++i) {
-                dkr[i] = draw * qv[i] + adm * dcl[i];
-                dqv[i] += draw * kk[i];
+                const float zz = kk[i] + qv[i];
+                const float inv = rstd * gv[i];
+                const float th = tanh_b(zz * inv + (bv[i] - mean * inv));
+                xh[i] = (zz - mean) * rstd;
+                uv[i] = draw * th;
+                const float dzh = draw * vv[i] * (1.f - th * th);
+                ug[i] = dzh * xh[i];
+                ub[i] = dzh;
+                dxh[i] = dzh * gv[i];
+                s1 += dxh[i];
+                s2 += dxh[i] * xh[i];
+              }
+              if constexpr (BIG) {
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) { tv[i] += uv[i]; tg[i] += ug[i]; tb[i] += ub[i]; }
+              } else {       // the per-wave accumulators live in LDS, updated row by row
+                lds_add8(pa_v, uv);
+                lds_add8(pa_g, ug);
+                lds_add8(pa_b, ub);
               }
             }
+            const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              const float dz = rstd * (dxh[i] - m1 - xh[i] * m2);
+              dkr[i] = dz + adm * dcl[i];
+              dqv[i] += dz;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+              dkr[i] = draw * qv[i] + adm * dcl[i];
+              dqv[i] += draw * kk[i];
+            }
+          }
+          if constexpr (BIG) {       // one writer per address, adds in step order: reproducible sums (zero-filled by the caller)
+            // through the wave's slice of the combine buffer, so that one atomic instruction covers 256 contiguous bytes
+            // (lane = channel 64 i + lane) instead of four dwords in each of the row's sixteen lines
+            float* tr = red_q + wave * D;
+            *(float4*)(tr + k0) = make_float4(dkr[0], dkr[1], dkr[2], dkr[3]);
+            *(float4*)(tr + k0 + 4) = make_float4(dkr[4], dkr[5], dkr[6], dkr[7]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float* dk = a.dkeys + ((size_t)ab * M + aq + 4 * slot) * D + lane;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) unsafeAtomicAdd(dk + 64 * i, tr[64 * i + lane]);
+            __builtin_amdgcn_wave_barrier();
+          } else {
 #pragma unroll
             for (int i = 0; i < EPL; ++i) {
               if (r == 0) dk_acc[i] += dkr[i];
               else dk_acc2[i] += dkr[i];
             }
           }
-          *(float4*)(red_q + wave * D + k0) = make_float4(dqv[0], dqv[1], dqv[2], dqv[3]);
-          *(float4*)(red_q + wave * D + k0 + 4) = make_float4(dqv[4], dqv[5], dqv[6], dqv[7]);
         }
+        if constexpr (BIG) {       // the step's parameter-gradient rows over the eight waves, in wave order, into channel tid
+          if (a.method == 0) {
+            auto over_waves = [&](const float (&src)[EPL], float& acc) {
+              *(float4*)(red_q + wave * D + k0) = make_float4(src[0], src[1], src[2], src[3]);
+              *(float4*)(red_q + wave * D + k0 + 4) = make_float4(src[4], src[5], src[6], src[7]);
+              __syncthreads();
+              float sum = 0.f;
+#pragma unroll
+              for (int w = 0; w < kWaves; ++w) sum += red_q[w * D + tid];
+              acc += sum;
+              __syncthreads();
+            };
+            over_waves(tv, pg_v);
+            over_waves(tg, pg_g);
+            over_waves(tb, pg_b);
+          }
+        }
+        *(float4*)(red_q + wave * D + k0) = make_float4(dqv[0], dqv[1], dqv[2], dqv[3]);
+        *(float4*)(red_q + wave * D + k0 + 4) = make_float4(dqv[4], dqv[5], dqv[6], dqv[7]);
         __syncthreads();
         if (wave < 2) {                                           // this workgroup's partial of d q_t: 4 channels a thread
           float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -695,12 +754,12 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
     }
   }
   if (a_live) {
-    if (has_own) {
+    if (has_own && !BIG) {
       float* dk = a.dkeys + ((size_t)ab * M + m_own) * D + k0;
       *(float4*)dk = make_float4(dk_acc[0], dk_acc[1], dk_acc[2], dk_acc[3]);
       *(float4*)(dk + 4) = make_float4(dk_acc[4], dk_acc[5], dk_acc[6], dk_acc[7]);
     }
-    if (has_own2) {
+    if (has_own2 && !BIG) {
       float* dk = a.dkeys + ((size_t)ab * M + m_own2) * D + k0;
       *(float4*)dk = make_float4(dk_acc2[0], dk_acc2[1], dk_acc2[2], dk_acc2[3]);
       *(float4*)(dk + 4) = make_float4(dk_acc2[4], dk_acc2[5], dk_acc2[6], dk_acc2[7]);
@@ -710,8 +769,12 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
     __syncthreads();
     for (int k = 0; k < 3; ++k) {
       float sum = 0.f;
+      if constexpr (BIG) {
+        sum = k == 0 ? pg_v : k == 1 ? pg_g : pg_b;
+      } else {
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) sum += pacc[(k * kWaves + w) * D + tid];   // fixed order: deterministic
+        for (int w = 0; w < kWaves; ++w) sum += pacc[(k * kWaves + w) * D + tid];   // fixed order: deterministic
+      }
       pg[k * D + tid] = sum;
     }
     __syncthreads();
@@ -726,11 +789,13 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   }
 }
 
-int64_t bwd_lds_bytes(int M, bool own) {
-  return (int64_t)(own ? 16 : M) * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * 32 * 4 + 3 * kD * 4 +
-         3 * kWaves * kD * 4 + 32 * 4;
+inline int bwd_mode(int M) { return M <= 28 ? 0 : M <= 64 ? 1 : 2; }   // the whole key matrix fits up to M = 28
+int64_t bwd_lds_bytes(int M) {
+  const int mode = bwd_mode(M);
+  const int64_t key_rows = mode == 0 ? M : mode == 1 ? 16 : (M + 3) / 4;
+  return key_rows * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * (mode == 2 ? 64 : 32) * 4 + 3 * kD * 4 +
+         (mode == 2 ? 0 : 3 * kWaves * kD * 4) + 32 * 4 + (mode == 2 ? 128 * 4 : 0);
 }
-inline bool bwd_own(int M) { return M > 28; }                 // the whole key matrix fits up to M = 28
 
 }  // namespace
 
@@ -738,8 +803,8 @@ bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int C
                                  int context_layer, int tied) {
   if (!comic_persist_fwd_supported(B, D, E, A, M, H, Cv, method, context_layer, tied)) return false;
   if (!tied || prob != 0) return false;                        // d values folded into d keys; softmax probability
-  if (M > 8 * kWaves || E % 16 != 0) return false;             // one or two owned memory rows per wave (4 workgroups a batch row)
-  return bwd_lds_bytes(M, bwd_own(M)) <= 160 * 1024;
+  if (M > 4 * 8 * kWaves || E % 16 != 0) return false;         // up to eight owned memory rows per wave (4 workgroups a batch row)
+  return bwd_lds_bytes(M) <= 160 * 1024;
 }
 
 int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int cols, int ld, hipStream_t st) {
@@ -752,17 +817,18 @@ int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int c
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
   ComicPersistBwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(1, a.Tp, st) : nullptr;
-  const bool own = bwd_own(a.M);
-  if (own && !a.dotp) {
+  const int mode = bwd_mode(a.M);
+  if (mode != 0 && !a.dotp) {
     comic_set_error("persistent decoder backward: M = %d needs the dot-product hand-off buffer", a.M);
     return 2;
   }
-  int64_t lds = bwd_lds_bytes(a.M, own);
+  int64_t lds = bwd_lds_bytes(a.M);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
-  static PerDeviceOnce attr_once__[2];
-  bool& attr_set = attr_once__[own ? 1 : 0].slot();   // hipFuncSetAttribute holds per device
+  static PerDeviceOnce attr_once__[3];
+  bool& attr_set = attr_once__[mode].slot();   // hipFuncSetAttribute holds per device
+  const void* kern = mode == 0 ? (const void*)decoder_bwd_persistent_kernel<0>
+                   : mode == 1 ? (const void*)decoder_bwd_persistent_kernel<1> : (const void*)decoder_bwd_persistent_kernel<2>;
   if (!attr_set) {
-    const void* kern = own ? (const void*)decoder_bwd_persistent_kernel<true> : (const void*)decoder_bwd_persistent_kernel<false>;
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       comic_set_error("persistent decoder backward: cannot reserve LDS");
       return 1;
@@ -774,8 +840,9 @@ int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
     comic_set_error("persistent decoder backward: bad group range %d + %d at batch %d", a.grp0, groups, a.B);
     return 2;
   }
-  if (own) hipLaunchKernelGGL(decoder_bwd_persistent_kernel<true>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
-  else hipLaunchKernelGGL(decoder_bwd_persistent_kernel<false>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  if (mode == 0) hipLaunchKernelGGL(decoder_bwd_persistent_kernel<0>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  else if (mode == 1) hipLaunchKernelGGL(decoder_bwd_persistent_kernel<1>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
+  else hipLaunchKernelGGL(decoder_bwd_persistent_kernel<2>, dim3(groups * kGroupWgs), dim3(kThreads), (size_t)lds, st, a);
   COMIC_LAUNCH_CHECK("persistent decoder backward");
   return 0;
 }

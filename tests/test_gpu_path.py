@@ -457,11 +457,11 @@ def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
     activations up to fp32 summation order.  Two different batches through the same buffers: a stale hand-off (a byte
     of the previous launch read in place of this one's) would show in the second."""
     # geo M = 196 (Inception-V1 Mixed_4f, the reference CLI's default map): the forward loop in its large-memory form (a
-    # workgroup holds its channel quarter of the keys, the LayerNorm sums cross the four quarters); the backward loop does
-    # not cover it (path 1).  geo M = 64 (the 8 x 8 map of 299-pixel inputs): the backward loop in its own-rows form (a
-    # workgroup holds its 16 memory rows, the softmax backward's dot products cross the four quarters): path 3
+    # workgroup holds its channel quarter of the keys, the LayerNorm sums cross the four quarters), the backward loop in its
+    # own-rows form with up to eight rows a wave (d keys added to memory step by step).  geo M = 64 (the 8 x 8 map of
+    # 299-pixel inputs): the backward loop in its own-rows form (a workgroup holds its 16 memory rows, the softmax
+    # backward's dot products cross the four quarters).  Path 3 everywhere.
     spec, cfg = _spec_and_cfg(**dict(dict(D=512, E=256, C=2048, Cg=2048), **geo))
-    big = spec.M > 64
     Lc = 30
     dec = cdec.Decoder(spec, _rand_params(cfg, 5), DEV)
     for seed in (31, 32):
@@ -474,7 +474,7 @@ def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
             monkeypatch.setenv('COMIC_PERSIST_BWD', mode[1])
             res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
             sync()
-            assert dec.lib.comic_decoder_train_path() == {'11': 1 if big else 3, '10': 1, '00': 0}[mode]   # the loops really ran
+            assert dec.lib.comic_decoder_train_path() == {'11': 3, '10': 1, '00': 0}[mode]   # the loops really ran
             got[mode] = dict(logits=res['logits'].cpu().numpy(), maps=res['attn_maps'].cpu().numpy(),
                              loss=float(res['loss']), map_loss=float(res['map_loss']), dfm=res['dfm'].cpu().numpy(),
                              dim=res['dim_embed'].cpu().numpy(), g=dec.grads.to_numpy())
