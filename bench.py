@@ -391,8 +391,8 @@ def extras(device, enc, cnn_params, plan):
                     'decoder_ms': round(dt * 1e3 - v1_ms, 3), 'decoder_time_loops': {0: 'per-step launches', 1: 'persistent forward', 3: 'persistent forward + backward'}.get(v1_path, str(v1_path)),
                     'attention_roofline': {'bound': 'hbm', 'bytes_per_time_step': att_bytes, 'unit': 'GB/s', 'peak': 8000.0,
                                            'note': 'keys of a batch row are 401 KB fp32 at M = 196: more than a CU\'s LDS.  The persistent '
-                                                   'forward loop holds a channel quarter per workgroup (path 1); the backward loop '
-                                                   '(M <= 64) does not cover this geometry and runs per-step launches'},
+                                                   'forward loop holds a channel quarter of them per workgroup, the backward loop its own '
+                                                   'memory rows (round 3); round 2 ran both as per-step launches'},
                     'loss': round(float(res['loss']), 4)}
     del trv, imgs_g
     torch.cuda.empty_cache()

@@ -430,7 +430,7 @@ int64_t comic_decoder_infer_workspace(const comic_decoder_desc* d, int rows, int
  *   map_loss (1 float), grads (no L2), dfm [B,M,C] / dim_embed [B,Cg] (may be NULL).
  * The forward and the backward time loop each run as ONE persistent launch per 64 batch rows when the shape allows
  * (D = 512, B <= 256, no context layer, M <= 64 or tied keys/values and M <= 256; backward: tied keys/values, softmax,
- * M <= 64; a device with >= 256 CUs), as
+ * M <= 256; a device with >= 256 CUs), as
  * per-step launches otherwise: same results to fp32 summation order (comic_decoder_train_path tells which).  If a
  * bounded wait inside a persistent loop ever expires, the step's results are void and the call says so in its
  * outputs: loss_rows[0] and map_loss[0] are NaN (the sequence loss reduced from loss_rows is then NaN too) and every

@@ -436,6 +436,9 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     res = dec.train_step(dev(fm), dev(im), caps, masks=masks, rewards=rewards, training=use_dropout,
                          want_input_grads=True)
     sync()
+    if kw in (dict(D=512, E=256, C=832, Cg=1024, M=196), dict(D=512, E=256, M=64), dict(D=512, E=256, C=2048, Cg=2048)):
+        # these geometries meet the oracle THROUGH both persistent time loops (Inception-V1 Mixed_4f, the 299-pixel map, COMIC-256)
+        assert dec.lib.comic_decoder_train_path() == 3
     assert_close(res['logits'].cpu().numpy(), out['logits'], F32_RTOL, 'logits')
     assert_close(res['attn_maps'].cpu().numpy(), out['attn_maps'], F32_RTOL, 'attn_maps')
     assert abs(float(res['loss']) - float(out['xe'])) <= F32_RTOL * abs(float(out['xe'])) + 1e-6
