@@ -84,7 +84,6 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
   float* pacc = lnp_l + 3 * D;                                 // [3][8 waves][D]  d v | d ln_g | d ln_b accumulators of the waves (not MODE 2)
   float* pd_l = pacc + (BIG ? 0 : 3 * kWaves * D);             // OWN: [16] this workgroup's partial dots, [16] the batch row's dots
   float* dot_l = pd_l + 16;
-  float* ms_l = dot_l + 16;                                    // MODE 2: [64 slots][2] mean, 1/std of the own rows at this step
 
   // hand-off buffers in BLOCKED layouts: a k16-block of the 16 rows of a group is one contiguous KiB (16 rows x 64
   // bytes), which is exactly what one MFMA-operand load of a wave reads: whole 128-byte lines instead of 16 half lines
@@ -211,31 +210,9 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           if constexpr (BIG) return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
           else return fast_tanh(x);
         };
-        // (i) scaled scores of the own rows (a row is recomputed in (iii); MODE 2 keeps its two statistics in LDS)
-#pragma unroll 1
-        for (int r = 0; r < NR; ++r) {
-          if (!row_ok(r)) break;
-          const int slot = wave + kWaves * r;
-          const float* kr = keys_l + slot * D + k0;
-          const float4 ka = *(const float4*)kr, kb = *(const float4*)(kr + 4);
-          const float kk[EPL] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-          float part = 0.f;
-          if (a.method == 0) {
-            float mean, rstd;
-            row_stats(kk, mean, rstd);
-            if (BIG && lane == 0) *(float2*)(ms_l + 2 * slot) = make_float2(mean, rstd);   // (read back by this wave only)
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-              const float inv = rstd * gv[i];
-              part += tanh_b((kk[i] + qv[i]) * inv + (bv[i] - mean * inv)) * vv[i];
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) part += kk[i] * qv[i];
-          }
-          part = head_total(part, lph);
-          if ((lane % lph) == 0) ss[head * SP + slot] = part * inv_scale;
-        }
+        // (i) -- none: the forward's scaled scores s enter the backward only through d tau = -(sum_m ds_m s_m) / tau, and
+        // with alpha = softmax(s), s_m = log alpha_m + c, sum_m ds_m = 0: the sum is sum_m ds_m log alpha_m, taken from the
+        // SAVED probabilities below.  The rows' LayerNorm / tanh are computed once per step, in (iii).
         // d att state of step t: (finished at t+1 ? carried : 0) + d att of step t+1's operand
         if (t + 1 < Tp) {
           wait_written<2>(dv2, ds_r, dso, off2, 3u, wt);
@@ -304,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           if (h >= H) continue;
           const float dsv = al_[hh] * (da_[hh] - dot_l[h]);      // softmax backward (the launch requires prob == 0)
           if (in) {
-            dtau -= dsv * ss[h * SP + lane];
+            dtau -= dsv * (al_[hh] > 0.f ? logf(al_[hh]) : 0.f);
             sd[h * SP + lane] = dsv * inv_scale;
             sa[h * SP + lane] = a.mask_alpha ? (al_[hh] / a.keep_alpha) * mk_[hh] : al_[hh];
           }
@@ -331,13 +308,7 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
           float dkr[EPL];
           if (a.method == 0) {
             float mean, rstd;
-            if constexpr (BIG) {
-              const float2 ms = *(const float2*)(ms_l + 2 * slot);
-              mean = ms.x;
-              rstd = ms.y;
-            } else {
-              row_stats(kk, mean, rstd);
-            }
+            row_stats(kk, mean, rstd);
             float dxh[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
             {
               float uv[EPL], ug[EPL], ub[EPL];
@@ -794,7 +765,7 @@ int64_t bwd_lds_bytes(int M) {
   const int mode = bwd_mode(M);
   const int64_t key_rows = mode == 0 ? M : mode == 1 ? 16 : (M + 3) / 4;
   return key_rows * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * (mode == 2 ? 64 : 32) * 4 + 3 * kD * 4 +
-         (mode == 2 ? 0 : 3 * kWaves * kD * 4) + 32 * 4 + (mode == 2 ? 128 * 4 : 0);
+         (mode == 2 ? 0 : 3 * kWaves * kD * 4) + 32 * 4;
 }
 
 }  // namespace
