@@ -453,7 +453,8 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
 
 
 @pytest.mark.parametrize('B,geo', [(64, {}), (23, {}), (64, dict(C=832, Cg=1024, M=196)), (23, dict(C=832, Cg=1024, M=196)),
-                                   (64, dict(M=64)), (23, dict(M=64, H=16))])
+                                   (64, dict(M=64)), (23, dict(M=64, H=16)),
+                                   (80, dict(C=832, Cg=1024, M=196))])          # five groups: two launches each way
 def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
     """The one-launch forward time loop (decoder_persist.hip: 64 workgroups per 16 batch rows, sc1 hand-offs, counter
     barriers) against the per-step launch chain it replaces, at the bench geometry with every dropout on: same saved
