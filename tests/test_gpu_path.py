@@ -183,6 +183,19 @@ def test_inception_v1_forward_224(dtype, tol):
         assert_close(got[..., :ep[name].shape[-1]], ep[name], tol, '%s %s' % (name, dtype))
     assert_close(fm.cpu().numpy().reshape(B, 14, 14, 832), ep['Mixed_4f'], tol, 'Mixed_4f ' + dtype)
     assert_close(im.cpu().numpy(), net_ref.reshape(B, -1), tol, 'net ' + dtype)
+    # the row-walking stride-1 max-pool (default only at large batches): the same bits as the per-pixel kernel
+    keep = {n: enc.end_point(n).clone() for n in ('Mixed_3b', 'Mixed_4c', 'Mixed_5c')}
+    n_forced = 0
+    for i, o in enumerate(plan.ops):
+        if o['kind'] == 2 and o['SH'] == 1:
+            enc._ops[i].tile = 1
+            n_forced += 1
+    assert n_forced == 9
+    im2, fm2 = enc.forward(dev(x))
+    sync()
+    assert torch.equal(fm2, fm) and torch.equal(im2, im)
+    for n, v in keep.items():
+        assert torch.equal(enc.end_point(n), v), n
 
 
 def test_inception_v1_backward_224_f32():
