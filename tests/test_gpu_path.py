@@ -417,6 +417,9 @@ TRAIN_VARIANTS = [
     dict(D=512, E=256, fm_projection='independent', prob='sigmoid', H=4),
     dict(D=512, E=128, method='dot', H=16, M=64),                               # W_q columns from L2 (keys fill the LDS)
     dict(D=512, E=256, M=64),                                                   # 299-pixel map: own-rows backward loop, add_LN
+    dict(D=512, E=256, C=832, Cg=1024, M=196, H=4),                             # large-memory loops, 1 / 4 heads a channel quarter
+    dict(D=512, E=128, C=832, Cg=1024, M=196, H=16, method='dot'),
+    dict(D=512, E=256, C=832, Cg=1024, M=130, H=16),                            # M not a multiple of 4: ragged own-row quarters
     # the reference CLI's default geometry (train.py:56,65): Inception-V1 Mixed_4f, 14 x 14 x 832 -> M = 196; the
     # attention kernels run in their split form (several workgroups per batch row, decoder.hip)
     dict(D=512, E=256, C=832, Cg=1024, M=196),
