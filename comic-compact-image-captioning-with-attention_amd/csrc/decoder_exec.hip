@@ -812,7 +812,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(TB * 2 * D);                                                   // d att | d h
   w.take<float>(4 * B * (3 * D + 1));                                          // its parameter-gradient rows
   w.take<float>(TB * 64);                                                      // ... per-head dot products of the row quarters (M > 28)
-  if (M > 64) w.take<float>(TB * 8 * M);                                       // forward loop, M > 64: LayerNorm sums of the channel quarters
+  if (comic_persist_fwd_bigm((int)M, d->fm_projection == 2)) w.take<float>(TB * 8 * M);   // forward loop, channel-quarter form: LayerNorm sums of the quarters
   if (d->cell == COMIC_CELL_LN_LSTM) {           // normalised rows, 1/std and LayerNorm gradient rows of every step + the init step
     w.take<float>((TB + B) * 5 * D); w.take<float>((TB + B) * 8); w.take<float>((TB + B) * 10 * D); w.take<float>(10 * D);
   } else if (d->cell == COMIC_CELL_GRU) {        // [x ; att ; r*h] of every step, the two d-operand products of a step, bias sums
@@ -893,7 +893,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dstate = w.take<float>(TB * 2 * D);
   float* pgrad4 = w.take<float>((long)4 * B * (3 * D + 1));
   float* dotp = w.take<float>(TB * 64);
-  float* statp = M > 64 ? w.take<float>(TB * 8 * M) : nullptr;
+  float* statp = comic_persist_fwd_bigm(M, d->fm_projection == 2) ? w.take<float>(TB * 8 * M) : nullptr;
   const int cell = d->cell;
   float *lnx_all = nullptr, *lnr_all = nullptr, *lnpg = nullptr, *cell_tmp = nullptr, *xh2_all = nullptr, *gru_dxh = nullptr;
   if (cell == COMIC_CELL_LN_LSTM) {
@@ -927,7 +927,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     pr.p[0] = xh_all; pr.n[0] = (long)Tp * B * Wd;
     pr.p[1] = y_all; pr.n[1] = (long)Tp * B * D;
     pr.p[2] = q_all; pr.n[2] = (long)Tp * B * D;
-    if (M > 64) {                      // the quarters' partial LayerNorm sums (decoder_persist.hip, BIGM): [Tp][B][4][M/2][4]
+    if (statp) {                       // the quarters' partial LayerNorm sums (decoder_persist.hip, BIGM): [Tp][B][4][M/2][4]
       pr.p[8] = statp; pr.n[8] = (long)Tp * B * 8 * M;
     }
     if (persist_b) {

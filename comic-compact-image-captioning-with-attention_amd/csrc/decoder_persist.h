@@ -53,6 +53,7 @@ constexpr int kPersistSyncWords = 64;       // the error word, and from word 32 
 
 bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int context_layer,
                                  int tied);
+bool comic_persist_fwd_bigm(int M, int tied);   // the forward loop runs in its channel-quarter form: it needs ComicPersistFwdArgs::statp
 // fills the hand-off buffers (up to kPersistRanges ranges of floats, sizes multiples of 4) with the sentinel and clears the
 // sync words; call BEFORE the kernels that write the x parts and the step-0 row
 constexpr int kPersistRanges = 10;

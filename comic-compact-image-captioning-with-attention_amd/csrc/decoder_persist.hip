@@ -740,15 +740,20 @@ __global__ __launch_bounds__(256) void persist_gate_kernel(const unsigned* err, 
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < r.n[k]; i += stride) r.p[k][i] = 0.f;
 }
 
+constexpr int64_t kLdsMax = 160 * 1024;
+constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at most one workgroup per CU
 int64_t lds_bytes(int M, int tied, bool wq_lds, bool greedy = false, bool bigm = false) {
   const int64_t cols = kD * 32 + (kD / 16) * 16;               // eight padded columns of a [D][D'] matrix
   const int64_t keys = bigm ? (int64_t)M * (kD / 4) * 4 : (int64_t)(tied ? 1 : 2) * M * kD * 4;
   const int64_t sc = bigm ? (4 * 256 + 512 + 3 * (kD / 4)) * 4 : 4 * 64 * 4;
   return keys + kWaves * 2 * 64 * 16 + kD * 4 + sc + (wq_lds ? cols : 0) + (greedy ? cols + 64 * 4 : 0);
 }
-inline bool big_m(int M) { return M > 64; }
-constexpr int64_t kLdsMax = 160 * 1024;
-constexpr int64_t kLdsMin = 96 * 1024;   // more than half of a CU's LDS: at most one workgroup per CU
+// the channel-quarter form: memories that do not fit a CU whole (M > 64) and, among those that do, the ones that leave no
+// room for the W_q columns beside them (tied M = 64: the query product read W_q from L2 every step, 8.7 us against 2.5)
+inline bool big_m(int M, int tied) {
+  if (!tied || M % 2 != 0 || M > 256) return false;
+  return M > 64 || lds_bytes(M, tied, true) > kLdsMax;
+}
 
 template <int NX, bool WQ_LDS, bool GREEDY = false, bool BIGM = false>
 int launch(const ComicPersistFwdArgs& a, int groups, int64_t lds, hipStream_t st) {
@@ -777,9 +782,11 @@ bool comic_persist_fwd_supported(int B, int D, int E, int A, int M, int H, int C
   if (M < 1) return false;
   if (method != 0 && method != 1) return false;
   // larger memories (Inception-V1 Mixed_4f, M = 196): a workgroup holds its channel quarter of the keys (BIGM)
-  if (big_m(M)) return tied && M <= 256 && M % 2 == 0 && lds_bytes(M, tied, false, false, true) <= kLdsMax;
+  if (big_m(M, tied)) return lds_bytes(M, tied, false, false, true) <= kLdsMax;
+  if (M > 64) return false;
   return lds_bytes(M, tied, false) <= kLdsMax;
 }
+bool comic_persist_fwd_bigm(int M, int tied) { return big_m(M, tied); }
 
 // COMIC_DEC_STAMPS (comic_decoder_desc::flags; Python: COMIC_PERSIST_STAMPS=1): print the previous launch's mean phase times (a host synchronisation per launch: diagnostic).
 // which = 0 forward loop, 1 backward loop; workgroup 0 stores eight 100 MHz clock values per step.
@@ -821,8 +828,8 @@ int comic_persist_fwd_launch(const ComicPersistFwdArgs& a_in, hipStream_t st) {
   ComicPersistFwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(0, a.Tp, st) : nullptr;
   const bool greedy = a.greedy != 0;
-  const bool bigm = big_m(a.M);
-  if (bigm && (greedy || !a.tied || !a.statp)) {
+  const bool bigm = !greedy && big_m(a.M, a.tied);
+  if (bigm && !a.statp) {
     comic_set_error("persistent decoder: M = %d needs tied keys / values, the statistics buffer, and is not a greedy loop", a.M);
     return 2;
   }
