@@ -170,10 +170,12 @@ def extras(device, enc, cnn_params, plan):
         encode_ahead()
         cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
         cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
-        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
-        ids = captions_to_batched_ids(hypos, cfg, table)
+        # as train_fn's SCST loop: the update's forward pass (no reward enters it) is enqueued before the host scores the rollouts
+        ids = captions_to_batched_ids(cap_beam, cfg, table)
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)     # = encoder(imgs tiled W times): frozen CNN, run once
-        res = dec.train_step(fm, im, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True)
+        dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
+        res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
         opt.step(dec.grads, 1e-3)
         return res
     for _ in range(2):
@@ -220,10 +222,11 @@ def extras(device, enc, cnn_params, plan):
         encode_ahead()
         cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]
         cap_greedy = [[c] for c in id_to_caption(cut(greedy), cfg)]
-        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
-        ids = captions_to_batched_ids(hypos, cfg, table)
+        ids = captions_to_batched_ids(cap_beam, cfg, table)
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
-        res = dec.train_step(fm, im, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True)
+        dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
+        res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
         opt.step(dec.grads, 1e-3)
         return res
     for _ in range(2):

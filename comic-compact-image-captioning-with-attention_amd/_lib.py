@@ -49,6 +49,7 @@ CELLS = {'LSTM': 0, 'LN_LSTM': 1, 'GRU': 2}          # include/comic_hip.h COMIC
 # process) by decoder_flags_from_env() and handed over in the descriptor.
 (DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS,
  DEC_NO_BEAM_LOGITS, DEC_NO_LSTM_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256)
+DEC_PHASE_FWD, DEC_PHASE_BWD = 512, 1024       # comic_decoder_train_step in two calls (Decoder.train_step(phase=...))
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),

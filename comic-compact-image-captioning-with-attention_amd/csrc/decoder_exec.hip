@@ -905,9 +905,13 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   }
   COMIC_REQUIRE(w.ok, "train_step: workspace overflow");
   RC(check_cell_params(d, p));
+  // COMIC_DEC_PHASE_FWD / _BWD: the step in two calls over the same workspace -- everything up to the logits (no loss
+  // coefficient enters it), then loss + backward.  The SCST step runs the first under the host's reward computation.
+  const bool do_fwd = !(d->flags & COMIC_DEC_PHASE_BWD), do_bwd = !(d->flags & COMIC_DEC_PHASE_FWD);
+  COMIC_REQUIRE(do_fwd || do_bwd, "train_step: both phase flags set");
 
   const comic_attn_desc ad = attn_desc(d, B);
-  const float* values = nullptr;
+  const float* values = d->fm_projection == 2 ? keys : d->fm_projection == 1 ? values_buf : fm;   // (= what memory_projections reports)
   const bool fused = fused_step_enabled() && comic_fused_step_supported(D, Wd);
   const bool fused_q = fused && D % 16 == 0;
   // the time loops as persistent launches (decoder_persist.hip, decoder_persist_bwd.hip) when the shape allows it
@@ -921,7 +925,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // partials of the persistent backward loop, free whenever the per-step kernels run ([Tp][B][4][D] >= 2 x [B][H][M])
   float* attn_ws = (!persist_b && comic_attn_splits(B, M) > 1 &&
                     TB * 4 * D >= (long)B * H * M + comic_attn_bwd_scratch(B, H, M, D)) ? dq_part : nullptr;
-  if (persist) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
+  if (persist && do_fwd) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
     ComicPersistRanges pr{};
     const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
     pr.p[0] = xh_all; pr.n[0] = (long)Tp * B * Wd;
@@ -942,6 +946,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // ------------------------------------------------------------------ forward ------------
   // the rnn init state (a chain of small products) on the side lane, beside the memory projections
   SideLane* L = side_lane();
+  if (do_fwd) {
   {
     LaneScope lane(L, st, splitk_ws_b);
     RC(lane.rc);
@@ -1042,6 +1047,11 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   }
   // output projection for all executed steps, loss, d logits
   RC(gemm_big(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
+  }   // do_fwd
+  if (!do_bwd) {
+    COMIC_LAUNCH_CHECK("train_step (forward phase)");
+    return 0;
+  }
   RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
   for (int t = Tp; t < T; ++t) {  // ops_rnn.py:235-241: pad by copying the last executed step
     (void)hipMemcpyAsync(logits_tb + (size_t)t * B * V, logits_tb + (size_t)(Tp - 1) * B * V, sizeof(float) * B * V,

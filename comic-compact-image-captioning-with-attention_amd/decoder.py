@@ -354,13 +354,14 @@ class Decoder:
         x ^= x >> 31
         self._dropout_base = (x * 0x94D049BB133111EB) & 0x3FFFFFFFFFFFFFFF
 
-    def _train_device(self, ctx):
-        """Device-only part of a training step (no host sync, no host memcpy): capturable."""
+    def _train_device(self, ctx, phase=None):
+        """Device-only part of a training step (no host sync, no host memcpy): capturable.
+        phase 'fwd' / 'bwd': the forward to the logits / the loss and the backward (COMIC_DEC_PHASE_*)."""
         torch, s = self.torch, self.spec
         B, T, Tp, training, gen_masks, _ = ctx.key
         st = L.stream_ptr()
         m = ctx.masks or {}
-        if training and gen_masks:
+        if training and gen_masks and phase != 'bwd':
             L.check(self.lib.comic_dropout_masks4_dev(ctx.mask_buf.data_ptr(), ctx.mask_n4, ctx.mask_keep4,
                                                       ctx.seed.data_ptr(), st), 'dropout_masks4')
             if s.recurrent_dropout:
@@ -376,7 +377,7 @@ class Decoder:
         BT = B * T
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()
-        ctx.desc.flags = L.decoder_flags_from_env()
+        ctx.desc.flags = L.decoder_flags_from_env() | {None: 0, 'fwd': L.DEC_PHASE_FWD, 'bwd': L.DEC_PHASE_BWD}[phase]
         L.check(self.lib.comic_decoder_train_step(
             C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm_in.data_ptr(), ctx.im_in.data_ptr(),
             i32.data_ptr(), i32.data_ptr() + 4 * BT, f32.data_ptr(), f32.data_ptr() + 4 * BT,
@@ -385,14 +386,19 @@ class Decoder:
             ctx.logits.data_ptr(), ctx.ids.data_ptr(), ctx.hist.data_ptr(), ctx.loss_rows.data_ptr(),
             ctx.map_loss.data_ptr(), L.ptr(ctx.dfm), L.ptr(ctx.dim), ctx.ws.data_ptr(), ctx.nbytes, st),
             'decoder_train_step')
+        if phase == 'fwd':
+            return
         # sequence_loss reduction (model_base.py:337-347): rows carry xent*w; rs = 1/denominator (* reward/B)
         L.check(self.lib.comic_weighted_sum_tb(ctx.loss_rows.data_ptr(), f32.data_ptr() + 4 * 2 * BT, T, B,
                                                ctx.loss.data_ptr(), st), 'weighted_sum_tb')
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
                    want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None, dp=None,
-                   copy_inputs=True):
+                   copy_inputs=True, phase=None):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
+        phase: None = the whole step.  'fwd' = everything no loss coefficient enters (forward to the logits; `rewards` is
+        ignored) and 'bwd' = the rest, with the SAME captions and now the rewards: the SCST step enqueues 'fwd' as soon as
+        the rollouts are back and scores them on the host while it runs (the same kernels in the same order: same bits).
         masks: None -> generated on device when training; dict(init_in, inp, out, alpha) of
         device tensors or numpy arrays -> injected (parity tests).  rewards [B] -> SCST loss
         mean_b(xent_b * reward_b) (model_base.py:342-347).
@@ -426,6 +432,18 @@ class Decoder:
         use_masks = bool(training or masks is not None)
         ctx = self._train_ctx(B, T, Tp, use_masks, gen_masks, want_input_grads)
         BT = B * T
+        if phase == 'bwd':          # second call of a split step: only the coefficients are new
+            assert getattr(ctx, 'split_open', False), 'train_step(phase="bwd") without its phase="fwd" call'
+            ctx.split_open = False
+            slot = ctx.stage[(ctx.calls - 1) % 2]                 # the slot its forward call staged: same inputs
+            slot.copied.synchronize()
+            fh = slot.f32.numpy()
+            fh[BT:2 * BT] = coef.reshape(-1); fh[2 * BT:] = rs.reshape(-1)
+            ctx.stage_dev.copy_(slot.buf, non_blocking=True)
+            slot.copied.record(torch.cuda.current_stream())
+            self._run_train_phase(ctx, 'bwd', use_graph)
+            return dict(loss=ctx.loss[0], map_loss=ctx.map_loss[0], logits=ctx.logits.permute(1, 0, 2), ids=ctx.ids.t(),
+                        attn_maps=ctx.hist.permute(1, 2, 0, 3), dfm=ctx.dfm, dim_embed=ctx.dim, Tp=Tp)
         slot = ctx.stage[ctx.calls % 2]
         if slot.copied is not None:
             slot.copied.synchronize()
@@ -460,6 +478,13 @@ class Decoder:
             ctx.fm_in, ctx.im_in = ctx.fm, ctx.im
             if on_inputs_consumed is not None:      # the encoder buffers may be overwritten from here on
                 on_inputs_consumed()
+        if phase == 'fwd':
+            ctx.split_open = True
+            self._run_train_phase(ctx, 'fwd', use_graph)
+            if direct and on_inputs_consumed is not None:
+                on_inputs_consumed()
+            ctx.calls += 1
+            return None
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -474,6 +499,22 @@ class Decoder:
         ctx.calls += 1
         return dict(loss=ctx.loss[0], map_loss=ctx.map_loss[0], logits=ctx.logits.permute(1, 0, 2), ids=ctx.ids.t(),
                     attn_maps=ctx.hist.permute(1, 2, 0, 3), dfm=ctx.dfm, dim_embed=ctx.dim, Tp=Tp)
+
+    def _run_train_phase(self, ctx, phase, use_graph):
+        """One half of a split step, eagerly or from its own hipGraph (captured at the second use of the shape)."""
+        torch = self.torch
+        graphs = ctx.__dict__.setdefault('phase_graphs', {})
+        used = ctx.__dict__.setdefault('phase_calls', {})
+        used[phase] = used.get(phase, 0) + 1
+        if use_graph and phase not in graphs and used[phase] >= 2:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._train_device(ctx, phase)
+            graphs[phase] = g
+        if use_graph and phase in graphs:
+            graphs[phase].replay()
+        else:
+            self._train_device(ctx, phase)
 
     # ------------------------------------------------------------------ decoding -------
     def max_iterations(self, infer_max_length, vocab_len):

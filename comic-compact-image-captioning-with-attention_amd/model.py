@@ -591,9 +591,28 @@ class CaptionModel_SCST(ModelBase):
             im_embed, fm = self._encode(imgs)
         if tile > 1:
             im_embed, fm = im_embed.repeat(tile, 1), fm.repeat(tile, 1, 1)
+        if rewards is None:           # begin_train_scst: the forward is enqueued, the rewards come with finish_train_scst
+            self.decoder.train_step(fm, im_embed, np.asarray(captions), training=True, use_graph=True, phase='fwd')
+            self._share['scst_open'] = np.asarray(captions)
+            return None
         lr = self.lr
         res = self.decoder.train_step(fm, im_embed, np.asarray(captions), rewards=np.asarray(rewards, np.float32),
                                       training=True, use_graph=True)
+        scale = self.dp.average_(self.decoder.grads.data)
+        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        return res['loss']
+
+    def begin_train_scst(self, imgs, captions, tile=1):
+        """The part of run_train_scst that needs no reward -- encoder features, teacher-forced forward to the logits -- enqueued
+        on the device; the caller computes the rewards meanwhile and hands them to finish_train_scst."""
+        return self.run_train_scst(imgs, captions, None, tile=tile)
+
+    def finish_train_scst(self, rewards):
+        """Loss, backward and update of the step begin_train_scst started (same kernels in the same order as run_train_scst)."""
+        captions = self._share.pop('scst_open')
+        lr = self.lr
+        res = self.decoder.train_step(None, None, captions, rewards=np.asarray(rewards, np.float32), training=True,
+                                      use_graph=True, phase='bwd')
         scale = self.dp.average_(self.decoder.grads.data)
         self.opt.step(self.decoder.grads, lr, grad_scale=scale)
         return res['loss']

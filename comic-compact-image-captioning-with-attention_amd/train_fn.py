@@ -154,14 +154,17 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
         cap_beam = np.reshape(cap_beam, [-1, cap_beam.shape[-1]])
         cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
         cap_greedy = [[s] for s in id_to_caption(cap_greedy, c)]
+        # every sampled hypothesis is trained on (get_hypo_scores returns `sample` itself), so the update's forward pass --
+        # which no reward enters -- is enqueued BEFORE the host scores the rollouts and runs on the device meanwhile.
+        # The reference feeds the images tiled by the beam size (train_fn.py:251-253); the CNN is frozen and
+        # deterministic, so the encoder runs once and its two outputs are tiled instead
+        hypos_idx = inputs_man.captions_to_batched_ids(cap_beam)
+        m_train.begin_train_scst(imgs, hypos_idx, tile=c.scst_beam_size)
         hypos, sc_sample, sc_greedy = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         rewards = sc_sample - sc_greedy
         greedy_high_sc = max(greedy_high_sc, np.amax(sc_greedy))
-        hypos_idx = inputs_man.captions_to_batched_ids(hypos)
-        assert hypos_idx.shape[0] == sc_sample.shape[0]
-        # the reference feeds the images tiled by the beam size (train_fn.py:251-253); the CNN is frozen
-        # and deterministic, so the encoder runs once and its two outputs are tiled instead
-        ppl = m_train.run_train_scst(imgs, hypos_idx, rewards, tile=c.scst_beam_size)
+        assert hypos is cap_beam and hypos_idx.shape[0] == sc_sample.shape[0]
+        ppl = m_train.finish_train_scst(rewards)
         global_step = m_train.global_step
         if (step + 1) % (n_steps_log * 5) == 0:
             t = time.time() - start_epoch

@@ -404,6 +404,8 @@ typedef struct comic_decoder_desc {
 #define COMIC_DEC_ONE_LANE 16u          /* no second stream inside the training executor */
 #define COMIC_DEC_EXACT_GEMM 32u        /* exact-fp32 MFMA for the time-batched products (no hi/lo-split bf16) */
 #define COMIC_DEC_STAMPS 64u            /* diagnostic phase clocks of the persistent loops (host sync per launch) */
+#define COMIC_DEC_PHASE_FWD 512u        /* comic_decoder_train_step: only the part that needs no loss coefficient (forward to the logits) */
+#define COMIC_DEC_PHASE_BWD 1024u       /* ... only the rest (loss, backward), over the SAME workspace and arguments as the forward call */
 #define COMIC_DEC_NO_LSTM_STREAM 256u   /* decode steps at > 32 rows with the per-row-tile fused LSTM kernel instead of the streaming one */
 #define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge (large V) / comic_beam_step's kernel (small V)
                                            instead of the streaming logits + top-k launch / the register-resident small step */

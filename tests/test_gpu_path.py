@@ -468,6 +468,27 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
 
 
+def test_split_train_step_equals_whole_step():
+    """SCST: the update's forward pass is enqueued before the rewards exist (Decoder.train_step(phase='fwd'), then phase='bwd'
+    with the rewards; COMIC_DEC_PHASE_FWD / _BWD over one workspace).  Same kernels in the same order: the same bits as the
+    one-call step, eagerly and replayed from the two phase graphs, with the dropout masks generated on the device."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    B, Lc = 40, 24
+    p = _rand_params(cfg, 5)
+    fm, im, caps = _batch(spec, B, Lc, 41)
+    rewards = np.random.default_rng(3).standard_normal(B).astype(np.float32)
+    whole, split = cdec.Decoder(spec, p, DEV, seed=7), cdec.Decoder(spec, p, DEV, seed=7)
+    for it in range(3):                                   # call 1 eager, call 2 captures, call 3 replays
+        a = whole.train_step(dev(fm), dev(im), caps, rewards=rewards, training=True, seed=100 + it, use_graph=True)
+        assert split.train_step(dev(fm), dev(im), caps, training=True, seed=100 + it, use_graph=True, phase='fwd') is None
+        b = split.train_step(None, None, caps, rewards=rewards, training=True, use_graph=True, phase='bwd')
+        sync()
+        assert whole.lib.comic_decoder_train_path() == 3
+        assert float(a['loss']) == float(b['loss']) and float(a['map_loss']) == float(b['map_loss']), it
+        assert torch.equal(whole.grads.data, split.grads.data), it
+        assert torch.equal(a['logits'], b['logits']), it
+
+
 @pytest.mark.parametrize('B,geo', [(64, {}), (23, {}), (64, dict(C=832, Cg=1024, M=196)), (23, dict(C=832, Cg=1024, M=196)),
                                    (64, dict(M=64)), (23, dict(M=64, H=16)),
                                    (80, dict(C=832, Cg=1024, M=196))])          # five groups: two launches each way
