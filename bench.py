@@ -165,15 +165,17 @@ def extras(device, enc, cnn_params, plan):
 
     def scst_step():
         im, fm = encode_now()
-        greedy, _, _ = dec.greedy(fm, im, iters)
-        beam = dec.beam_search(fm, im, W, iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
-        encode_ahead()
+        # as train_fn's SCST loop: the greedy rollout runs on the device while the host turns the beam rollouts into text
+        # and ids; the update's forward pass (no reward enters it) and the next step's encoder forward while it scores them
+        fetch_beam = dec.beam_search_ids(fm, im, W, iters)
+        fetch_greedy = dec.greedy(fm, im, iters, defer=True)
+        beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
         cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
-        cap_greedy = [[c] for c in id_to_caption(greedy, cfg)]
-        # as train_fn's SCST loop: the update's forward pass (no reward enters it) is enqueued before the host scores the rollouts
         ids = captions_to_batched_ids(cap_beam, cfg, table)
+        cap_greedy = [[c] for c in id_to_caption(fetch_greedy()[0], cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)     # = encoder(imgs tiled W times): frozen CNN, run once
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        encode_ahead()
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
         opt.step(dec.grads, 1e-3)
@@ -217,14 +219,15 @@ def extras(device, enc, cnn_params, plan):
 
     def scst_step_realistic():
         im, fm = encode_now()
-        greedy, _, _ = dec.greedy(fm, im, real_iters)
-        beam = dec.beam_search(fm, im, W, real_iters, want_attention=False)['predicted_ids'].transpose(2, 1, 0)   # (W,B,T)
-        encode_ahead()
+        fetch_beam = dec.beam_search_ids(fm, im, W, real_iters)
+        fetch_greedy = dec.greedy(fm, im, real_iters, defer=True)
+        beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
         cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]
-        cap_greedy = [[c] for c in id_to_caption(cut(greedy), cfg)]
         ids = captions_to_batched_ids(cap_beam, cfg, table)
+        cap_greedy = [[c] for c in id_to_caption(cut(fetch_greedy()[0]), cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        encode_ahead()
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
         opt.step(dec.grads, 1e-3)

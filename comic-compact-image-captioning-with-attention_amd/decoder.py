@@ -579,9 +579,11 @@ class Decoder:
             launch()
         ctx.calls += 1
 
-    def greedy(self, fm, im_embed, max_steps, want_logits=False, use_graph=True):
+    def greedy(self, fm, im_embed, max_steps, want_logits=False, use_graph=True, defer=False):
         """rnn_decoder_search(greedy) (ops_rnn.py:115-180).  -> ids [B,T_exec] (numpy int32),
-        attn_maps [B,H,T_exec,M] (device), logits [B,T_exec,V] or None."""
+        attn_maps [B,H,T_exec,M] (device), logits [B,T_exec,V] or None.
+        defer: only enqueue the loop and return a function that fetches the result (the SCST step converts the beam
+        rollouts to text on the host while this loop runs)."""
         s = self.spec
         B = fm.shape[0]
         ctx = self._infer_ctx('greedy', B, 1, max_steps, want_logits, fm, im_embed)
@@ -593,13 +595,54 @@ class Decoder:
                                                   L.ptr(ctx.logits), ctx.hist.data_ptr(), ctx.first_eos.data_ptr(),
                                                   ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()), 'decoder_greedy')
         self._run_infer(ctx, launch, use_graph)
-        fe = ctx.first_eos.cpu().numpy()
-        if fe.min() < 0:                                  # comic_persist_check_greedy: a bounded wait of the loop expired
-            raise L.ComicHipError('greedy: the persistent decode loop did not complete (a wait on another workgroup timed out)')
-        t_exec = int(min(max_steps, fe.max() + 1))       # loop ends when every row has emitted EOS
-        out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
-        hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
-        return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
+
+        def fetch():
+            fe = ctx.first_eos.cpu().numpy()
+            if fe.min() < 0:                              # comic_persist_check_greedy: a bounded wait of the loop expired
+                raise L.ComicHipError('greedy: the persistent decode loop did not complete (a wait on another workgroup timed out)')
+            t_exec = int(min(max_steps, fe.max() + 1))   # loop ends when every row has emitted EOS
+            out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
+            hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
+            return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
+        return fetch if defer else fetch()
+
+    def beam_search_ids(self, fm, im_embed, beam, max_steps, use_graph=True):
+        """Beam search for its predicted ids alone, fetched WITHOUT draining the stream: the loop, gather_tree over all
+        max_steps rows (rows past the executed steps come out as end_id) and the copies to pinned memory are enqueued, an
+        event marks their end, and the returned function waits for that event only -- work enqueued behind it (the greedy
+        rollout of the SCST step) keeps running while the host turns these ids into text.  -> fetch() -> [T,B,W] int32,
+        the same values as beam_search()['predicted_ids']."""
+        torch, s = self.torch, self.spec
+        B, W = fm.shape[0], beam
+        ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed)
+        ctx.desc.length_penalty_weight = 0.0
+
+        def launch():
+            ctx.desc.flags = L.decoder_flags_from_env()
+            L.check(self.lib.comic_decoder_beam(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(),
+                                                ctx.im.data_ptr(), B, W, max_steps, ctx.step_ids.data_ptr(),
+                                                ctx.parent_ids.data_ptr(), ctx.scores.data_ptr(),
+                                                ctx.lengths.data_ptr(), ctx.finished.data_ptr(), ctx.hist.data_ptr(),
+                                                ctx.steps.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()),
+                    'decoder_beam')
+        self._run_infer(ctx, launch, use_graph)
+        if getattr(ctx, 'pred', None) is None:
+            ctx.pred = torch.empty((max_steps, B, W), dtype=torch.int32, device=self.device)
+            ctx.pred_host = torch.empty((max_steps, B, W), dtype=torch.int32).pin_memory()
+            ctx.steps_host = torch.empty(1, dtype=torch.int32).pin_memory()
+            ctx.fetched = torch.cuda.Event()
+        max_len = ctx.lengths.max(dim=1).values.to(torch.int32).contiguous()
+        L.check(self.lib.comic_gather_tree(ctx.step_ids.data_ptr(), ctx.parent_ids.data_ptr(), max_len.data_ptr(),
+                                           ctx.pred.data_ptr(), max_steps, B, W, s.end_id, L.stream_ptr()), 'gather_tree')
+        ctx.pred_host.copy_(ctx.pred, non_blocking=True)
+        ctx.steps_host.copy_(ctx.steps, non_blocking=True)
+        ctx.fetched.record(torch.cuda.current_stream())
+        ctx.keep = max_len                                # (alive until the copies have run)
+
+        def fetch():
+            ctx.fetched.synchronize()
+            return ctx.pred_host[:int(ctx.steps_host[0])].numpy().copy()
+        return fetch
 
     def beam_search(self, fm, im_embed, beam, max_steps, want_attention=True, use_graph=True, length_penalty_weight=0.0):
         """rnn_decoder_beam_search (ops_rnn.py:49-112).  Returns predicted_ids [T,B,W] (after

@@ -554,9 +554,12 @@ class CaptionModel_SCST(ModelBase):
             self._create_optimiser()
         print('INFO: Model `{}` initialisation complete.'.format(scst_mode))
 
-    def sample(self, imgs):
+    def sample(self, imgs, defer_greedy=False):
         """-> (dec_preds_beam (beam,B,T), dec_preds_greedy (B,T)); beam search with
-        infer_max_length=20, length penalty 0 (model_base.py:208-215)."""
+        infer_max_length=20, length penalty 0 (model_base.py:208-215).
+        defer_greedy: the beam rollouts are enqueued first and fetched without draining the stream, the greedy rollout is
+        enqueued behind them and the second return value is a function that fetches it: the caller turns the beam ids into
+        text meanwhile (same parameters, same features: the order of the two rollouts changes nothing)."""
         c = self._config
         # (the caches below hold the image object itself: `is` on a live object cannot be fooled by a recycled id())
         pf = self._share.pop('scst_prefetch', None)
@@ -567,9 +570,15 @@ class CaptionModel_SCST(ModelBase):
         # ... and the training step on the same images that follows (train_fn_scst: the CNN is frozen in SCST mode, so
         # run_train_scst takes these features instead of a second forward)
         self._share['scst_features'] = (imgs, im_embed.clone(), fm.clone())
+        if defer_greedy and c.scst_beam_size > 1:
+            iters = self.decoder.max_iterations(20, len(c.wtoi))
+            fetch_beam = self.decoder.beam_search_ids(fm, im_embed, c.scst_beam_size, iters)
+            fetch_greedy = self.decoder.greedy(fm, im_embed, iters, defer=True)
+            beam = fetch_beam().transpose(2, 1, 0).copy()                 # (W, B, T)
+            return beam, (lambda: fetch_greedy()[0])
         greedy, _ = self._decode_features(im_embed, fm, 1, 20, want_attention=False)
         beam, _ = self._decode_features(im_embed, fm, c.scst_beam_size, 20, top_beam=False, want_attention=False)
-        return beam, greedy
+        return beam, ((lambda: greedy) if defer_greedy else greedy)
 
     def prefetch_features(self, imgs):
         """Enqueue the encoder forward of the NEXT step's images now: the device is idle while the host scores this

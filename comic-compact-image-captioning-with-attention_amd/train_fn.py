@@ -146,20 +146,21 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
         imgs, refs = ahead if ahead is not None else next(inputs_man.batch_train)
         # `cap_beam` is (beam_size, batch_size, time) -> (beam_size * batch_size, time):
         # [[im0_hypo0], ..., [imN_hypo0], [im0_hypo1], ..., [imN_hypo1]]   (train_fn.py:226-238)
-        cap_beam, cap_greedy = m_sample.sample(imgs)
-        # the next batch's encoder forward runs on the device while the host scores this batch's rollouts
-        ahead = next(inputs_man.batch_train) if step + 1 < c.max_step else None
-        if ahead is not None:
-            m_sample.prefetch_features(ahead[0])
+        # (the greedy rollout runs on the device while the host turns the beam rollouts into text and ids)
+        cap_beam, fetch_greedy = m_sample.sample(imgs, defer_greedy=True)
         cap_beam = np.reshape(cap_beam, [-1, cap_beam.shape[-1]])
         cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
-        cap_greedy = [[s] for s in id_to_caption(cap_greedy, c)]
         # every sampled hypothesis is trained on (get_hypo_scores returns `sample` itself), so the update's forward pass --
         # which no reward enters -- is enqueued BEFORE the host scores the rollouts and runs on the device meanwhile.
         # The reference feeds the images tiled by the beam size (train_fn.py:251-253); the CNN is frozen and
         # deterministic, so the encoder runs once and its two outputs are tiled instead
         hypos_idx = inputs_man.captions_to_batched_ids(cap_beam)
+        cap_greedy = [[s] for s in id_to_caption(fetch_greedy(), c)]
         m_train.begin_train_scst(imgs, hypos_idx, tile=c.scst_beam_size)
+        # the next batch's encoder forward joins the update's forward pass on the device while the host scores
+        ahead = next(inputs_man.batch_train) if step + 1 < c.max_step else None
+        if ahead is not None:
+            m_sample.prefetch_features(ahead[0])
         hypos, sc_sample, sc_greedy = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         rewards = sc_sample - sc_greedy
         greedy_high_sc = max(greedy_high_sc, np.amax(sc_greedy))

@@ -810,6 +810,11 @@ def test_greedy_and_beam_match_oracle(kw):
         np.testing.assert_array_equal(ids2, e_ids)
         assert_close(logits2.cpu().numpy(), e_logits, F32_RTOL, 'greedy logits (early exit)')
         assert_close(amap2.cpu().numpy(), e_map, F32_RTOL, 'greedy attention maps (early exit)')
+    # the SCST step's non-draining fetch of the beam ids, with the greedy loop enqueued behind it and fetched later
+    fb = dec.beam_search_ids(dev(fm), dev(im), 3, max_steps)
+    fg = dec.greedy(dev(fm), dev(im), max_steps, defer=True)
+    np.testing.assert_array_equal(fb(), dec.beam_search(dev(fm), dev(im), 3, max_steps, want_attention=False)['predicted_ids'])
+    np.testing.assert_array_equal(fg()[0], g_ids)
     for W, eos_bias in ((3, 1.5), (7, 1.5), (3, 9.0)):
         if eos_bias != 1.5:
             # every beam ends within a few steps: the remaining launches of the fixed-length loop return at once
