@@ -468,6 +468,24 @@ def test_decoder_train_step_matches_oracle(kw, use_dropout, scst):
     assert_close(res['dim_embed'].cpu().numpy(), dim, F32_RTOL, 'dim_embed')
 
 
+@pytest.mark.parametrize('geo', [dict(C=832, Cg=1024, M=196), dict(M=64)])
+def test_large_memory_loops_graph_replay_equals_eager(geo):
+    """The large-memory forms of the persistent loops under hipGraph capture / replay, on a second decoder with the same
+    seed: the same bits as eager launches -- also says that the backward loop's d keys, added to memory with float atomics
+    by ONE writer per address in step order, come out the same in every run."""
+    spec, cfg = _spec_and_cfg(**dict(dict(D=512, E=256, C=2048, Cg=2048), **geo))
+    p = _rand_params(cfg, 5)
+    a, b = cdec.Decoder(spec, p, DEV, seed=3), cdec.Decoder(spec, p, DEV, seed=3)
+    fm, im, caps = _batch(spec, 64, 20, 51)
+    for it in range(3):                                   # call 1 eager, call 2 captures, call 3 replays
+        ra = a.train_step(dev(fm), dev(im), caps, training=True, seed=50 + it, use_graph=False)
+        rb = b.train_step(dev(fm), dev(im), caps, training=True, seed=50 + it, use_graph=True)
+        sync()
+        assert a.lib.comic_decoder_train_path() == 3
+        assert float(ra['loss']) == float(rb['loss']), it
+        assert torch.equal(a.grads.data, b.grads.data), it
+
+
 def test_split_train_step_equals_whole_step():
     """SCST: the update's forward pass is enqueued before the rewards exist (Decoder.train_step(phase='fwd'), then phase='bwd'
     with the rewards; COMIC_DEC_PHASE_FWD / _BWD over one workspace).  Same kernels in the same order: the same bits as the
