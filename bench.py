@@ -73,7 +73,7 @@ def extras(device, enc, cnn_params, plan):
     max_steps = 30
     for _ in range(2):
         im, fm = enc50.forward(imgs, use_graph=True)
-        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+        r = {'predicted_ids': dec.beam_search_ids(fm, im, 3, max_steps)()}
     torch.cuda.synchronize()
     # as CaptionModel.infer runs it: ONE encoder forward covers the next G = 4 batches (200 images: 1.6x the MFMA rate of
     # a 50-image forward) and runs on a second stream under the decode steps of the current group
@@ -91,7 +91,7 @@ def extras(device, enc, cnn_params, plan):
         im, fm = im_s.clone(), fm_s.clone()
         if rel():
             pipe.submit(imgsG)
-        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+        r = {'predicted_ids': dec.beam_search_ids(fm, im, 3, max_steps)()}
     torch.cuda.synchronize()
     n, t0 = 8, time.perf_counter()
     for _ in range(n):
@@ -99,7 +99,7 @@ def extras(device, enc, cnn_params, plan):
         im, fm = im_s.clone(), fm_s.clone()
         if rel():
             pipe.submit(imgsG)
-        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+        r = {'predicted_ids': dec.beam_search_ids(fm, im, 3, max_steps)()}
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     out['beam3_captions_per_sec'] = round(B / dt, 1)
@@ -109,14 +109,14 @@ def extras(device, enc, cnn_params, plan):
     t0 = time.perf_counter()
     for _ in range(3):
         im, fm = enc50.forward(imgs, use_graph=True)
-        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+        r = {'predicted_ids': dec.beam_search_ids(fm, im, 3, max_steps)()}
     torch.cuda.synchronize()
     out['beam3_serial_captions_per_sec'] = round(B * 3 / (time.perf_counter() - t0), 1)
     # decode loop alone against the HBM roofline of the vocabulary projection (per step D*V*s bytes of
     # W_o + rows*V*4 bytes of logits; s = 4: the decoder is fp32)
     t0 = time.perf_counter()
     for _ in range(n):
-        r = dec.beam_search(fm, im, 3, max_steps, want_attention=False)
+        r = {'predicted_ids': dec.beam_search_ids(fm, im, 3, max_steps)()}
     torch.cuda.synchronize()
     steps_ex = int(r['predicted_ids'].shape[0])
     us_step = (time.perf_counter() - t0) / n / steps_ex * 1e6

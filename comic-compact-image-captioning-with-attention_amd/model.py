@@ -339,8 +339,12 @@ class ModelBase(object):
         c = self._config
         iters = self.decoder.max_iterations(max_length, len(c.wtoi))
         if beam_size > 1:
-            r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention,
-                                         length_penalty_weight=length_penalty_weight)
+            if not want_attention and not length_penalty_weight:
+                # captions alone: the ids come back through pinned memory behind one event (no stream drain per array)
+                r = {'predicted_ids': self.decoder.beam_search_ids(fm, im_embed, beam_size, iters)()}
+            else:
+                r = self.decoder.beam_search(fm, im_embed, beam_size, iters, want_attention=want_attention,
+                                             length_penalty_weight=length_penalty_weight)
             pred = r['predicted_ids']                                  # (T, B, W)
             T = pred.shape[0]
             attn = None
