@@ -50,11 +50,12 @@ CELLS = {'LSTM': 0, 'LN_LSTM': 1, 'GRU': 2}          # include/comic_hip.h COMIC
 (DEC_NO_PERSIST, DEC_NO_PERSIST_BWD, DEC_NO_FUSED_STEP, DEC_NO_SPLIT_ATTN_BWD, DEC_ONE_LANE, DEC_EXACT_GEMM, DEC_STAMPS,
  DEC_NO_BEAM_LOGITS, DEC_NO_LSTM_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256)
 DEC_PHASE_FWD, DEC_PHASE_BWD = 512, 1024       # comic_decoder_train_step in two calls (Decoder.train_step(phase=...))
+DEC_NO_GROUP_GEMM = 2048
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
             ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS), ('COMIC_BEAM_LOGITS', '0', DEC_NO_BEAM_LOGITS),
-            ('COMIC_LSTM_STREAM', '0', DEC_NO_LSTM_STREAM))
+            ('COMIC_LSTM_STREAM', '0', DEC_NO_LSTM_STREAM), ('COMIC_GROUP_GEMM', '0', DEC_NO_GROUP_GEMM))
 
 
 def decoder_flags_from_env():
@@ -80,6 +81,12 @@ PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'ta
 
 class DecoderParams(C.Structure):
     _fields_ = [(n, c_void_p) for n in PARAM_NAMES]
+
+
+class GemmProb(C.Structure):         # struct comic_gemm_prob
+    _fields_ = [(n, c_void_p) for n in ('A', 'B', 'C', 'bias', 'mask')] + [(n, c_int32) for n in (
+        'M', 'N', 'K', 'lda', 'ldb', 'ldc', 'ld_mask')] + [(n, c_float) for n in ('alpha', 'beta', 'keep')] + [
+        ('type', c_int32), ('ones_a', c_int32)]
 
 
 class ConvGrad(C.Structure):         # struct comic_conv_grad
@@ -110,6 +117,9 @@ _SIGS = {
                                       c_float, P, c_int64, P]),
     'comic_gemm_f32_splitk': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_float, P, c_int64, P]),
+    'comic_gemm_group_workspace': (c_int64, [P, c_int]),
+    'comic_gemm_group': (c_int, [P, c_int, P, c_int64, P]),
+    'comic_debug_gemm_group_tuning': (c_int, [c_int, c_int]),
     'comic_embed_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_embed_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),

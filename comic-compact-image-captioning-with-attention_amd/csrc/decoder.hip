@@ -25,6 +25,7 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t*
 }
 
 // one block per vocabulary row: deterministic sum over the rows that reference it
+template <bool SET>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids,
                                                         const float* __restrict__ dout,
                                                         float* __restrict__ dtable, int rows, int E) {
@@ -53,7 +54,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
     __syncthreads();
   }
   const int n = min(total, 2048);
-  if (n == 0) return;
+  if (n == 0) {                      // SET: the table row is written, not accumulated into (no zero fill before the launch)
+    if (SET)
+      for (int e = tid; e < E; e += 256) dtable[(size_t)v * E + e] = 0.f;
+    return;
+  }
   for (int e = tid; e < E; e += 256) {
     float acc = 0.f;
     for (int i = 0; i < n; ++i) acc += dout[(size_t)list[i] * E + e];
@@ -61,7 +66,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restric
     if (total > 2048)
       for (int r = list[2047] + 1; r < rows; ++r)
         if (ids[r] == v) acc += dout[(size_t)r * E + e];
-    dtable[(size_t)v * E + e] += acc;
+    if (SET) dtable[(size_t)v * E + e] = acc;
+    else dtable[(size_t)v * E + e] += acc;
   }
 }
 
@@ -1103,8 +1109,14 @@ extern "C" int comic_embed_fwd(const float* table, const int32_t* ids, float* ou
 
 extern "C" int comic_embed_bwd(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V,
                                void* stream) {
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, rows, E);
+  hipLaunchKernelGGL(embed_bwd_kernel<false>, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, rows, E);
   COMIC_LAUNCH_CHECK("embed_bwd");
+  return 0;
+}
+// dtable = (not +=) the scattered sums: every table row is written, so no zero fill precedes it
+int comic_embed_bwd_set(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V, hipStream_t st) {
+  hipLaunchKernelGGL(embed_bwd_kernel<true>, dim3(V), dim3(256), 0, st, ids, dout, dtable, rows, E);
+  COMIC_LAUNCH_CHECK("embed_bwd_set");
   return 0;
 }
 

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "decoder_persist.h"
+#include "gemm_group.h"
 #include "lstm_prep.h"
 #include "lstm_stream_dev.h"
 
@@ -55,6 +56,7 @@ int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
                             const float* bias, hipStream_t st);
 
+int comic_embed_bwd_set(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V, hipStream_t st);
 // gemm.hip
 int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                            int ldb, int ldc, int trans_a, int trans_b, float alpha, float beta, void* ws,
@@ -164,6 +166,7 @@ bool persist_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST); }
 bool persist_bwd_enabled() { return !(g_dec_flags & COMIC_DEC_NO_PERSIST_BWD); }
 bool beam_logits_enabled() { return !(g_dec_flags & COMIC_DEC_NO_BEAM_LOGITS); }
 bool lstm_stream_enabled() { return !(g_dec_flags & COMIC_DEC_NO_LSTM_STREAM); }
+bool group_gemm_enabled() { return !(g_dec_flags & (COMIC_DEC_NO_GROUP_GEMM | COMIC_DEC_EXACT_GEMM)); }
 
 // A second stream inside the training executor: the weight-gradient products after the backward loop are independent
 // chains of mid-sized GEMMs and small reductions; two lanes fill each other's tails and launch gaps
@@ -285,7 +288,7 @@ __global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_
 __global__ void embed_step0_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids_bt,
                                    int32_t* __restrict__ ids_tb, const float* __restrict__ mask, float keep,
                                    float* __restrict__ xh, float* __restrict__ att0, const float* __restrict__ h0, int Tp,
-                                   int B, int T, int E, int A, int D, int V) {
+                                   int B, int T, int E, int A, int D, int V, float* __restrict__ xh_init) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n_x = (long)Tp * B * E;
   const int EA = E + A, Wd = E + A + D;
@@ -304,6 +307,9 @@ __global__ void embed_step0_kernel(const float* __restrict__ table, const int32_
   } else if (i < n_x + (long)B * A + (long)B * D) {
     const long j = i - n_x - (long)B * A;
     xh[(size_t)(j / D) * Wd + EA + (j % D)] = h0[j];
+  } else if (xh_init && i < n_x + (long)B * A + 2L * B * D) {   // zero state of the init step: the h third of its operand rows
+    const long j = i - n_x - (long)B * A - (long)B * D;
+    xh_init[(size_t)(j / D) * Wd + EA + (j % D)] = 0.f;
   }
 }
 
@@ -579,6 +585,45 @@ inline int gemm_big(const float* A, const float* B, float* C, const float* bias,
                                 g_splitk_ws ? kSplitKBytes : 0, st);
 }
 
+// The products of a training step that do not feed the recurrence, as ONE grouped launch (gemm_group.hip): problems are
+// collected here and run together; `slab` / `tickets` come from the step's workspace (kGroupTickets counters, zeroed at
+// the top of the step and left zero by every launch).
+constexpr int kGroupTickets = 4096;
+struct GemmGroupRun {
+  ComicGemmGroup g{};
+  ComicGemmProb* add(int type, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc) {
+    if (g.n >= kGemmGroupMax) return nullptr;
+    ComicGemmProb& p = g.p[g.n++];
+    p = ComicGemmProb{};
+    p.type = type; p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = 1.f; p.beta = 0.f; p.keep = 1.f;
+    return &p;
+  }
+  // column sums of B [K][N] (ldb) -> C [N]
+  ComicGemmProb* add_colsum(const float* B, float* C, int N, int K, int ldb) {
+    ComicGemmProb* p = add(COMIC_GG_TN, nullptr, B, C, 1, N, K, 1, ldb, N);
+    if (p) p->ones_a = 1;
+    return p;
+  }
+  int run(void* slab, int64_t slab_cap, unsigned* tickets, hipStream_t st) {
+    if (g.n == 0) return 0;
+    int target = comic_gemm_group_debug_target(480);
+    for (;;) {
+      int64_t need = 0;
+      int nt = 0;
+      const int wg = comic_gemm_group_plan(g, target, &need, &nt);
+      if (wg < 0) return 2;
+      if (need <= slab_cap && nt <= kGroupTickets) {
+        g.slab = (float*)slab;
+        g.tickets = tickets;
+        return comic_gemm_group_launch(g, wg, st);
+      }
+      COMIC_REQUIRE(target > 1, "gemm_group: split-K scratch too small");
+      target = target / 2;
+    }
+  }
+};
+
 int check_desc(const comic_decoder_desc* d) {
   COMIC_REQUIRE(d, "decoder: null descriptor");
   COMIC_REQUIRE(d->D > 0 && d->E > 0 && d->A > 0 && d->V > 1 && d->C > 0 && d->Cg > 0 && d->H > 0 && d->M > 0,
@@ -788,14 +833,14 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(B * (E + A)); w.take<float>(B * (E + A));          // init x, xh
   w.take<float>(B * 4 * D); w.take<float>(B * 4 * D); w.take<float>(B * D);  // init g, gates, c_new
   w.take<float>(TB * E); w.take<int32_t>(TB);                      // emb_all, ids_tb
-  w.take<float>(TB * Wd); w.take<float>(B * 4 * D);                // xh_all, g_tmp
+  w.take<float>((TB + B) * Wd); w.take<float>(B * 4 * D);          // xh_all (+ the init step's operand rows), g_tmp
   w.take<float>(TB * 4 * D);                                       // gates_act
   w.take<float>((TB + B) * D); w.take<float>((TB + B) * D);        // cs, hs
   w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>(TB * D);  // c_new, y, q
   w.take<float>(TB * H * M);                                       // alpha
   w.take<float>(TB * Cv); w.take<float>(B * D); w.take<float>((TB + B) * A);  // ctx, att_new, att
   w.take<float>(TB * V);                                           // dlogits
-  w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>(TB * 4 * D);    // dy_all, dq_all, dg_all
+  w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>((TB + B) * 4 * D);    // dy_all, dq_all, dg_all (+ the init step's rows)
   w.take<float>(B * Wd); w.take<float>(B * D); w.take<float>(B * D);          // dxh, dc, dh
   w.take<float>(B * A); w.take<float>(B * A); w.take<float>(B * Cv);          // datt, datt_live, dctx
   w.take<float>(TB * E); w.take<float>(B * M * D); w.take<float>(B * M * Cv); // demb, dkeys, dvalues
@@ -806,7 +851,7 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 0));                  // LSTM kernel panels (fused step)
   w.take<float>(comic_lstm_panel_floats((int)D, (int)Wd, 1));
   w.take<float>(D * D);                                                        // W_q panel
-  w.take<unsigned>(kPersistSyncWords);                                         // persistent loops: error word
+  w.take<unsigned>(kPersistSyncWords + kGroupTickets);                         // persistent loops: error word; grouped GEMM: tile tickets
   w.take<float>(TB * 4 * D); w.take<float>((long)T * ((B + 15) / 16) * 16 * 4 * D);  // persistent backward: d q partials, d gates (blocked)
   w.take<float>((long)T * ((B + 15) / 16) * 16 * D);                                  // summed d q (blocked)
   w.take<float>(TB * 2 * D);                                                   // d att | d h
@@ -852,7 +897,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   ib.g = w.take<float>((long)B * 4 * D); ib.gates = w.take<float>((long)B * 4 * D); ib.c_new = w.take<float>((long)B * D);
   float* emb_all = w.take<float>(TB * E);
   int32_t* in_tb = w.take<int32_t>(TB);
-  float* xh_all = w.take<float>(TB * Wd);
+  float* xh_all = w.take<float>((TB + B) * Wd);
   float* g_tmp = w.take<float>((long)B * 4 * D);
   float* gates_all = w.take<float>(TB * 4 * D);
   float* cs = w.take<float>((TB + B) * D);
@@ -867,7 +912,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* dlogits = w.take<float>(TB * V);
   float* dy_all = w.take<float>(TB * D);
   float* dq_all = w.take<float>(TB * D);
-  float* dg_all = w.take<float>(TB * 4 * D);
+  float* dg_all = w.take<float>((TB + B) * 4 * D);
   float* dxh = w.take<float>((long)B * Wd);
   float* dc = w.take<float>((long)B * D);
   float* dh = w.take<float>((long)B * D);
@@ -885,7 +930,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* kpanel_f = w.take<float>(comic_lstm_panel_floats(D, Wd, 0));
   float* kpanel_b = w.take<float>(comic_lstm_panel_floats(D, Wd, 1));
   float* wq_panel = w.take<float>((long)D * D);
-  unsigned* persist_sync = w.take<unsigned>(kPersistSyncWords);
+  unsigned* persist_sync = w.take<unsigned>(kPersistSyncWords + kGroupTickets);
+  unsigned* gg_tickets = persist_sync + kPersistSyncWords;
   const long TB16 = (long)T * ((B + 15) / 16) * 16;
   float* dq_part = w.take<float>(TB * 4 * D);
   float* dg_blk = w.take<float>(TB16 * 4 * D);
@@ -941,13 +987,46 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       pr.p[6] = dq_sum; pr.n[6] = n16;
       pr.p[7] = dotp; pr.n[7] = (long)Tp * B * 64;
     }
-    RC(comic_persist_prepare(pr, persist_sync, st));
+    RC(comic_persist_prepare(pr, persist_sync, kPersistSyncWords + kGroupTickets, st));
   }
   // ------------------------------------------------------------------ forward ------------
-  // the rnn init state (a chain of small products) on the side lane, beside the memory projections
-  SideLane* L = side_lane();
+  // grp: the products outside the time loops as grouped launches (gemm_group.hip).  The rnn init step then keeps its
+  // operand rows [drop(x_init) ; 0] and its d gates in row block Tp of xh_all / dg_all, so that d K and d b are ONE
+  // product over (Tp + 1) * B rows.
+  // (products with a short reduction -- a handful of rows in all -- keep the separate launches, whose small shapes run the
+  // exact-fp32 kernels: gemm_big's rule)
+  const bool grp = group_gemm_enabled() && cell == COMIC_CELL_LSTM && (long)Tp * B >= 64 && (long)B * M >= 64 && B >= 16;
+  float* xh_init = xh_all + (size_t)Tp * B * Wd;
+  float* dg_init = dg_all + (size_t)Tp * B * 4 * D;
+  void* const gg_slab = g_splitk_ws;                 // both lanes' split-K blocks: consecutive in the workspace
+  const int64_t gg_slab_cap = 2 * kSplitKBytes;
+  SideLane* L = grp ? nullptr : side_lane();
   if (do_fwd) {
-  {
+  if (grp) {
+    if (!persist) COMIC_REQUIRE(hipMemsetAsync(gg_tickets, 0, sizeof(unsigned) * kGroupTickets, st) == hipSuccess, "train_step: memset");
+    if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
+    if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
+    GemmGroupRun g1;
+    g1.add(COMIC_GG_NN, fm, p->W_m, keys, B * M, D, d->C, d->C, D, D);
+    if (d->fm_projection == 1) g1.add(COMIC_GG_NN, fm, p->W_v, values_buf, B * M, D, d->C, d->C, D, D);
+    if (d->init_method == 1) {
+      g1.add(COMIC_GG_NN, im_embed, p->W_init, hs, B, D, d->Cg, d->Cg, D, D);
+    } else {
+      ComicGemmProb* q = g1.add(COMIC_GG_NN, im_embed, p->W_init, xh_init, B, EA, d->Cg, d->Cg, EA, Wd);
+      if (drop_in) { q->mask = mask_init_in; q->ld_mask = EA; q->keep = d->keep_in; }
+    }
+    RC(g1.run(gg_slab, gg_slab_cap, gg_tickets, st));
+    if (d->init_method == 1) {
+      RC(fill(cs, 0.f, (long)B * D, st));
+    } else {
+      // zero initial state: only the first E+A rows of the cell's kernel contribute
+      GemmGroupRun g2;
+      g2.add(COMIC_GG_NN, xh_init, p->K, ib.g, B, 4 * D, EA, Wd, 4 * D, 4 * D)->bias = p->b;
+      RC(g2.run(gg_slab, gg_slab_cap, gg_tickets, st));
+      RC(comic_lstm_gates_fwd(ib.g, nullptr, nullptr, ib.gates, ib.c_new, nullptr, nullptr, nullptr, 1.f, nullptr, 0, cs, hs,
+                              B, D, (void*)st));
+    }
+  } else {
     LaneScope lane(L, st, splitk_ws_b);
     RC(lane.rc);
     hipStream_t sl = lane.lane();
@@ -963,9 +1042,11 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // operand rows before the loop: the x part of every step (embedding lookup + input dropout, hoisted) and step 0's
   // att part (zero: dropout of 0 is 0) and h part (h0)
   {
-    const long n = (long)Tp * B * E + (long)B * A + (long)B * D;
+    const bool zi = grp && d->init_method != 1;
+    const long n = (long)Tp * B * E + (long)B * A + (long)B * D * (zi ? 2 : 1);
     hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, inputs_bt, in_tb,
-                       drop_in ? mask_in : nullptr, d->keep_in, xh_all, att_all, hs, Tp, B, T, E, A, D, V);
+                       drop_in ? mask_in : nullptr, d->keep_in, xh_all, att_all, hs, Tp, B, T, E, A, D, V,
+                       zi ? xh_init : (float*)nullptr);
     COMIC_LAUNCH_CHECK("embed_step0");
   }
   if (persist) {
@@ -1046,7 +1127,13 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     }
   }
   // output projection for all executed steps, loss, d logits
-  RC(gemm_big(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
+  if (grp) {
+    GemmGroupRun go;
+    go.add(COMIC_GG_NN, y_all, p->W_o, logits_tb, Tp * B, V, D, D, V, V)->bias = p->b_o;
+    RC(go.run(gg_slab, gg_slab_cap, gg_tickets, st));
+  } else {
+    RC(gemm_big(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
+  }
   }   // do_fwd
   if (!do_bwd) {
     COMIC_LAUNCH_CHECK("train_step (forward phase)");
@@ -1082,7 +1169,13 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     RC(fill(dc, 0.f, (long)((datt + (long)B * A) - dc), st));    // dc | dh | datt: consecutive workspace blocks
   }
   // dy_all = dlogits * W_o^T (d W_o, d b_o: after the loop, on the gradient lanes)
-  RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
+  if (grp) {
+    GemmGroupRun gy;
+    gy.add(COMIC_GG_NT, dlogits, p->W_o, dy_all, Tp * B, D, V, V, V, D);
+    RC(gy.run(gg_slab, gg_slab_cap, gg_tickets, st));
+  } else {
+    RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
+  }
   if (d->context_layer) RC(fill(gr->W_a, 0.f, (long)Cv * D, st));
   // softmax attention: the backward kernel runs as two workgroups per batch row (half of the memory rows each), whose
   // d q / parameter-gradient contributions are added into zero-filled rows (comic_attn_bwd_ex, pgrad_overwrite 2)
@@ -1184,6 +1277,58 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       COMIC_LAUNCH_CHECK("input_bwd");
     }
   }
+  // ---- gradients that do not feed the recurrence ---------------------------------------------------------------------
+  float* dx_im = nullptr;  // gradient w.r.t. (im_embed * W_init)
+  int n_init = 0;
+  if (grp) {
+    // ONE grouped launch: every weight gradient, the bias sums, the embedding third of d gates * K^T, d x_init
+    const bool init_step = d->init_method != 1;
+    const int rows_k = (Tp + (init_step ? 1 : 0)) * B;            // rows of the LSTM operand / d gates matrices
+    if (init_step)                                               // d gates of the init step -> row block Tp of dg_all
+      RC(comic_lstm_gates_bwd(ib.gates, nullptr, ib.c_new, nullptr, nullptr, 1.f, nullptr, 0, dc, dh, dg_init, B, D, (void*)st));
+    GemmGroupRun g1, g2;
+    g1.add(COMIC_GG_TN, xh_all, dg_all, gr->K, Wd, 4 * D, rows_k, Wd, 4 * D, 4 * D);
+    g1.add(COMIC_GG_TN, fm, dkeys, gr->W_m, d->C, D, B * M, d->C, D, D);
+    if (d->fm_projection == 1) g1.add(COMIC_GG_TN, fm, dvalues_buf, gr->W_v, d->C, D, B * M, d->C, D, D);
+    if (persist_b) {   // the embedding third of d gates * K^T, all steps at once, and its input dropout
+      ComicGemmProb* q = g1.add(COMIC_GG_NT, dg_all, p->K, demb, Tp * B, E, 4 * D, 4 * D, 4 * D, E);
+      if (drop_in) { q->mask = mask_in; q->ld_mask = EA; q->keep = d->keep_in; }
+    }
+    g1.add(COMIC_GG_TN, y_all, dq_all, gr->W_q, D, D, Tp * B, D, D, D);
+    g1.add(COMIC_GG_TN, y_all, dlogits, gr->W_o, D, V, Tp * B, D, V, V);
+    if (dfm) g1.add(COMIC_GG_NT, dkeys, p->W_m, dfm, B * M, d->C, D, D, D, d->C);
+    g1.add_colsum(dg_all, gr->b, 4 * D, rows_k, 4 * D);
+    g1.add_colsum(dlogits, gr->b_o, V, Tp * B, V);
+    if (d->method == 0) {      // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the rows
+      const float* pg = persist_b ? pgrad4 : pgrad;
+      const int pr = persist_b ? 4 * B : Tp * B, ldp = 3 * D + 1;
+      g1.add_colsum(pg, gr->v, D, pr, ldp);
+      g1.add_colsum(pg + D, gr->ln_g, D, pr, ldp);
+      g1.add_colsum(pg + 2 * D, gr->ln_b, D, pr, ldp);
+      g1.add_colsum(pg + 3 * D, gr->tau, 1, pr, ldp);
+    }
+    if (init_step) {
+      ComicGemmProb* q = g1.add(COMIC_GG_NT, dg_init, p->K, dx_init, B, EA, 4 * D, 4 * D, 4 * D, EA);
+      if (drop_in) { q->mask = mask_init_in; q->ld_mask = EA; q->keep = d->keep_in; }
+      dx_im = dx_init;
+      n_init = EA;
+      g2.add(COMIC_GG_TN, im_embed, dx_im, gr->W_init, d->Cg, n_init, B, d->Cg, n_init, n_init);
+      if (dim_embed) g2.add(COMIC_GG_NT, dx_im, p->W_init, dim_embed, B, d->Cg, n_init, n_init, n_init, d->Cg);
+    } else {
+      dx_im = dh;
+      n_init = D;
+      g1.add(COMIC_GG_TN, im_embed, dx_im, gr->W_init, d->Cg, n_init, B, d->Cg, n_init, n_init);
+      if (dim_embed) g1.add(COMIC_GG_NT, dx_im, p->W_init, dim_embed, B, d->Cg, n_init, n_init, n_init, d->Cg);
+    }
+    if (d->fm_projection == 1 && dfm) {
+      ComicGemmProb* q = g2.add(COMIC_GG_NT, dvalues_buf, p->W_v, dfm, B * M, d->C, D, D, D, d->C);
+      q->beta = 1.f;
+    }
+    RC(g1.run(gg_slab, gg_slab_cap, gg_tickets, st));
+    RC(comic_embed_bwd_set(in_tb, demb, gr->emb, Tp * B, E, V, st));
+    RC(g2.run(gg_slab, gg_slab_cap, gg_tickets, st));
+    if (d->fm_projection == 0 && dfm) RC(comic_axpy(dfm, dvalues_buf, 1.f, (int64_t)B * M * Cv, (void*)st));
+  } else {
   // ---- gradients that do not feed the recurrence, on two lanes (side_lane) ------------------------------------------
   LaneScope glane(L, st, splitk_ws_b);
   RC(glane.rc);
@@ -1227,8 +1372,6 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     RC(gemm_big(xh_all, dg_all, gr->K, nullptr, Wd, 4 * D, Tp * B, Wd, 4 * D, 4 * D, 1, 0, 0.f, st));
     if (cell == COMIC_CELL_LSTM) RC(comic_colsum_ws(dg_all, gr->b, Tp * B, 4 * D, 0.f, (float*)g_splitk_ws, st));
   }
-  float* dx_im = nullptr;  // gradient w.r.t. (im_embed * W_init)
-  int n_init = 0;
   if (d->init_method == 1) {
     dx_im = dh;
     n_init = D;
@@ -1272,6 +1415,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   RC(gemm_big(im_embed, dx_im, gr->W_init, nullptr, d->Cg, n_init, B, d->Cg, n_init, n_init, 1, 0, 0.f, st));
   if (dim_embed) RC(gemm(dx_im, p->W_init, dim_embed, nullptr, B, d->Cg, n_init, n_init, n_init, d->Cg, 0, 1, 0.f, st));
   RC(glane.join());
+  }
   if (persist) {
     // a persistent loop that timed out leaves garbage everywhere: NaN losses and zero gradients (no host check needed
     // for the optimiser step that follows to be harmless; the host raises at its next look at the loss)
@@ -1431,13 +1575,13 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
     pr.p[1] = ws.p_y; pr.n[1] = (long)max_steps * B * D;
     pr.p[2] = ws.p_q; pr.n[2] = (long)max_steps * B * D;
     pr.p[3] = ws.p_argp; pr.n[3] = (long)max_steps * B * 132;
-    RC(comic_persist_prepare(pr, ws.p_sync, st));
+    RC(comic_persist_prepare(pr, ws.p_sync, kPersistSyncWords, st));
     // step 0 operand: att = 0, h = h0 (the x third comes from the embedding table inside the loop)
     {
       const long n = (long)B * A + (long)B * D;
       hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb,
                          (const int32_t*)nullptr, (int32_t*)nullptr, (const float*)nullptr, 1.f, ws.p_xh, ws.att[0], ws.h[0],
-                         0, B, 0, E, A, D, V);
+                         0, B, 0, E, A, D, V, (float*)nullptr);
       COMIC_LAUNCH_CHECK("greedy step0");
     }
     ComicPersistFwdArgs pa{};

@@ -61,7 +61,8 @@ struct ComicPersistRanges {
   float* p[kPersistRanges];
   long n[kPersistRanges];
 };
-int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st);
+// n_zero: words of `sync` to clear (>= kPersistSyncWords; the training executor keeps the grouped GEMM's tickets behind them)
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st);
 bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, int Cv, int V, int method,
                                     int context_layer, int tied);
 int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStream_t st);

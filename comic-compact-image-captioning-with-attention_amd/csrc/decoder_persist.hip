@@ -712,10 +712,10 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   }
 }
 
-__global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync) {
+__global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync, int n_zero) {
   const uint4 v = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kPersistSyncWords) sync[i] = 0u;
+  if (i < n_zero) sync[i] = 0u;
 #pragma unroll
   for (int k = 0; k < kPersistRanges; ++k) {
     const long n4 = r.n[k] >> 2;
@@ -885,14 +885,15 @@ int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStre
   return 0;
 }
 
-int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, hipStream_t st) {
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st) {
   long n = 0;
   for (int k = 0; k < kPersistRanges; ++k) {
     COMIC_REQUIRE(r.n[k] % 4 == 0 && (r.n[k] == 0 || r.p[k]), "persistent decoder: bad hand-off range %d", k);
     n += r.n[k] / 4;
   }
-  if (n < kPersistSyncWords) n = kPersistSyncWords;
-  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, r, sync);
+  if (n_zero < kPersistSyncWords) n_zero = kPersistSyncWords;
+  if (n < n_zero) n = n_zero;
+  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, r, sync, n_zero);
   COMIC_LAUNCH_CHECK("persistent decoder prepare");
   return 0;
 }

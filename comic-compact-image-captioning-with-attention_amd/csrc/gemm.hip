@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_x3_dev.h"
 
 namespace {
 
@@ -34,17 +35,6 @@ struct GemmArgs {
 
 constexpr int BK = 16;
 constexpr int KC_ROW = 20;  // floats per LDS row, k-contiguous form (16 + 4 pad)
-
-// 4 floats from p[0..3] with element-wise validity
-__device__ __forceinline__ float4 load4(const float* __restrict__ p, int nvalid, bool vec_ok) {
-  if (nvalid >= 4 && vec_ok) return *(const float4*)p;
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (nvalid > 0) r.x = p[0];
-  if (nvalid > 1) r.y = p[1];
-  if (nvalid > 2) r.z = p[2];
-  if (nvalid > 3) r.w = p[3];
-  return r;
-}
 
 // ROWS = tile extent along the operand's non-k dimension (64 or 32)
 template <int ROWS, bool KCONTIG>
@@ -180,174 +170,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix cores: every operand element x is split on the fly into
-// hi = bf16(x), lo = bf16(x - hi) and the product is accumulated as hi*hi + hi*lo + lo*hi in fp32
-// (the dropped lo*lo term and the 16 kept mantissa bits bound the relative error of a product by
-// ~2^-15; measured 2e-6 on the decoder's shapes).  v_mfma_f32_16x16x32_bf16 does 16 384 FLOP in 16
-// cycles against 2 048 in 32 for the f32-input MFMA, so three of them are ~5x faster than the exact
-// path.  Used by the decoder executors for the time-batched products (keys, logits, every weight
-// gradient); the per-step products and the public comic_gemm_f32 keep exact fp32 products.
-// Tiles: BM x 128 x 32, operands converted while they are staged into k-contiguous LDS rows of
-// 32 bf16 (+16 B pad: ds_read_b128 fragments, conflict-free), register-prefetched double buffer.
-// (a, b) -> packed hi pair, packed lo pair
-__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  hi = pack_bf16x2(a, b);
-  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
-}
-
-// LDS images of a ROWS x 32 operand tile (bf16, one for hi and one for lo):
-//   k-contiguous operand  -> [ROWS][32 k] rows of 64 B + 16 B pad, read with ds_read_b128; the 8-byte
-//                            chunk holding physical k = 4c..4c+3 sits at chunk position 2*(c&3) + (c>>2)
-//   row-contiguous operand -> [32 k][ROWS] rows of 2*ROWS + 32 B, read with ds_read_b64_tr_b16
-// Both give lane group g the physical k {4g..4g+3, 16+4g..16+4g+3} as its 8 MFMA k-values (the
-// conflict-free transposing-read order, see conv_wgrad_tr_kernel).
-template <int ROWS, bool KC>
-struct X3Tile {
-  static constexpr int ROWB = 80;
-  static constexpr int KSTR = 2 * ROWS + 32;
-  static constexpr int BYTES = KC ? ROWS * ROWB : 32 * KSTR;
-};
-
-// chunk q of a ROWS x 32 fp32 tile.  k-contiguous operand: row = q / 8, k = (q % 8) * 4;
-// row-contiguous operand: k = q / (ROWS/4), rows (q % (ROWS/4)) * 4 .. +3
-template <int ROWS, bool KC, int NCH>
-__device__ __forceinline__ void x3_load_tile(const float* __restrict__ g, int ld, int row0, int rows_total, int k0, int K,
-                                             int tid, bool vec, float4 (&out)[NCH]) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int q = tid + 256 * i;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KC) {
-      const int row = row0 + (q >> 3), k = k0 + (q & 7) * 4;
-      if (row < rows_total && k < K) v = load4(g + (size_t)row * ld + k, K - k, vec);
-    } else {
-      constexpr int CPR = ROWS / 4;
-      const int k = k0 + q / CPR, row = row0 + (q % CPR) * 4;
-      if (k < K && row < rows_total) v = load4(g + (size_t)k * ld + row, rows_total - row, vec);
-    }
-    out[i] = v;
-  }
-}
-template <int ROWS, bool KC, int NCH>
-__device__ __forceinline__ void x3_store_tile(unsigned char* hi_base, unsigned char* lo_base, int tid,
-                                              const float4 (&in)[NCH]) {
-  using T = X3Tile<ROWS, KC>;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int q = tid + 256 * i;
-    uint32_t h0, l0, h1, l1;
-    split_bf16x2(in[i].x, in[i].y, h0, l0);
-    split_bf16x2(in[i].z, in[i].w, h1, l1);
-    int off;
-    if (KC) {
-      const int row = q >> 3, c = q & 7;
-      off = row * T::ROWB + (2 * (c & 3) + (c >> 2)) * 8;
-    } else {
-      constexpr int CPR = ROWS / 4;
-      const int kk = q / CPR, row = (q % CPR) * 4;
-      off = kk * T::KSTR + row * 2;
-    }
-    *(uint2*)(hi_base + off) = make_uint2(h0, h1);
-    *(uint2*)(lo_base + off) = make_uint2(l0, l1);
-  }
-}
-typedef __attribute__((ext_vector_type(4))) short x3_s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short x3_s16x8_t;
-// 16x32 MFMA fragment of the 16 operand rows starting at `row16`
-template <int ROWS, bool KC>
-__device__ __forceinline__ bf16x8_t x3_frag(const unsigned char* base, int row16, int lane) {
-  using T = X3Tile<ROWS, KC>;
-  if (KC) {
-    const uint4 v = *(const uint4*)(base + (row16 + (lane & 15)) * T::ROWB + (lane >> 4) * 16);
-    return __builtin_bit_cast(bf16x8_t, v);
-  } else {
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    const unsigned char* p = base + (4 * g + q) * T::KSTR + (row16 + 4 * pp) * 2;
-    const uint32_t a0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p);
-    const x3_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)a0);
-    const x3_s16x4_t hi =
-        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)(a0 + 16 * T::KSTR));
-    const x3_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-  }
-}
-
 template <int BM, bool A_KC, bool B_KC, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs a) {
   if (comic_stopped(a.stop, a.stop_t)) return;
-  constexpr int BKx = 32;
   constexpr int TM = BM / 32, TN = BN / 32;               // 16x16 tiles per wave (2 x 2 waves)
-  constexpr int ACH = BM * BKx / 4 / 256, BCH = BN * BKx / 4 / 256;   // float4 chunks per thread
-  constexpr int ABYTES = X3Tile<BM, A_KC>::BYTES, BBYTES = X3Tile<BN, B_KC>::BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ah = smem;                              // [2] tile images each
-  unsigned char* Al = Ah + 2 * ABYTES;
-  unsigned char* Bh = Al + 2 * ABYTES;
-  unsigned char* Bl = Bh + 2 * BBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const bool a_vec = (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
-  const bool b_vec = (a.ldb % 4 == 0) && (((uintptr_t)a.B & 15) == 0);
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // Register staging TWO k-tiles deep: tile t travels in register set t & 1; at the top of iteration kt the load of
-  // tile kt+2 is issued into the set tile kt has just left, so a global load has two compute phases to land (one
-  // phase left the skinny products -- e.g. the per-step 150 x 512 x 25 599 logits of beam search -- waiting on HBM).
-  float4 ar[2][ACH], br[2][BCH];
   const int kbeg = a.k_per_slice > 0 ? blockIdx.z * a.k_per_slice : 0;
   const int kend = a.k_per_slice > 0 ? min(a.K, kbeg + a.k_per_slice) : a.K;
-  const int nk = (kend - kbeg + BKx - 1) / BKx;
-  x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg, kend, tid, a_vec, ar[0]);
-  x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg, kend, tid, b_vec, br[0]);
-  if (nk > 1) {
-    x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + BKx, kend, tid, a_vec, ar[1]);
-    x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + BKx, kend, tid, b_vec, br[1]);
-  }
-  x3_store_tile<BM, A_KC, ACH>(Ah, Al, tid, ar[0]);
-  x3_store_tile<BN, B_KC, BCH>(Bh, Bl, tid, br[0]);
-  __syncthreads();
-  auto step = [&](const int kt, auto par) {
-    constexpr int P = decltype(par)::value;          // kt & 1: LDS buffer of tile kt, register set of tile kt + 2
-    if (kt + 2 < nk) {
-      x3_load_tile<BM, A_KC, ACH>(a.A, a.lda, m0, a.M, kbeg + (kt + 2) * BKx, kend, tid, a_vec, ar[P]);
-      x3_load_tile<BN, B_KC, BCH>(a.B, a.ldb, n0, a.N, kbeg + (kt + 2) * BKx, kend, tid, b_vec, br[P]);
-    }
-    bf16x8_t bh[TN], bl[TN], ah[TM], al[TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      bh[i] = x3_frag<BN, B_KC>(Bh + P * BBYTES, wn * (BN / 2) + i * 16, lane);
-      bl[i] = x3_frag<BN, B_KC>(Bl + P * BBYTES, wn * (BN / 2) + i * 16, lane);
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      ah[j] = x3_frag<BM, A_KC>(Ah + P * ABYTES, wm * (BM / 2) + j * 16, lane);
-      al[j] = x3_frag<BM, A_KC>(Al + P * ABYTES, wm * (BM / 2) + j * 16, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
-      }
-    if (kt + 1 < nk) {      // tile kt + 1 (register set P ^ 1, loaded one iteration ago) -> the other LDS buffer
-      x3_store_tile<BM, A_KC, ACH>(Ah + (P ^ 1) * ABYTES, Al + (P ^ 1) * ABYTES, tid, ar[P ^ 1]);
-      x3_store_tile<BN, B_KC, BCH>(Bh + (P ^ 1) * BBYTES, Bl + (P ^ 1) * BBYTES, tid, br[P ^ 1]);
-    }
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(kt, std::integral_constant<int, 0>());
-    if (kt + 1 < nk) step(kt + 1, std::integral_constant<int, 1>());
-  }
+  f32x4_t acc[TN][TM];
+  x3_mainloop<BM, A_KC, B_KC, BN>(a.A, a.B, a.M, a.N, a.lda, a.ldb, m0, n0, kbeg, kend, smem, acc);
 
   // epilogue: lane holds n = nb + (lane>>4)*4 + {0..3}, m = mb + (lane&15)
   const bool to_slab = a.k_per_slice > 0;

@@ -228,6 +228,30 @@ int comic_gemm_f32_split3(const float* A, const float* B, float* C, const float*
                           float beta, void* workspace /* may be NULL: no split-K */,
                           int64_t workspace_bytes, void* stream);
 
+/* Several independent products of the comic_gemm_f32_split3 kind in ONE launch (csrc/gemm_group.hip): the training
+ * step's products outside the time loops -- the memory / rnn-init projections (common/ops_rnn.py:440-447,
+ * src/model_base.py:651-689) and, after the backward loop, every weight gradient, bias sum and attention-parameter sum of
+ * tf.gradients over the dense layers (src/model_base.py:325-405; common/ops.py:200-238).  A problem is
+ *   C[M][N] = (alpha * op(A) op(B) + bias) [/ keep * mask] + beta * C
+ * with type 0: A [K][M], B [K][N] (a weight gradient X^T dY);  1: A [M][K], B [K][N];  2: A [M][K], B [N][K];
+ * ones_a: A is all ones and M = 1 (column sums of B: a bias gradient as a product; type 0).  Split-K partials are
+ * combined inside the launch in slice order (bit-reproducible).  At most 20 problems; outputs must not alias inputs of
+ * other problems of the call. */
+typedef struct comic_gemm_prob {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;   /* [N] or NULL */
+  const float* mask;   /* [M][ld_mask] dropout keep mask or NULL */
+  int32_t M, N, K, lda, ldb, ldc, ld_mask;
+  float alpha, beta, keep;
+  int32_t type, ones_a;
+} comic_gemm_prob;
+int64_t comic_gemm_group_workspace(const comic_gemm_prob* probs, int n);
+int comic_gemm_group(const comic_gemm_prob* probs, int n, void* workspace, int64_t workspace_bytes, void* stream);
+/* measurement knobs of the grouped launch (work items per launch, XCD-contiguous item order); results do not change */
+int comic_debug_gemm_group_tuning(int target_items, int xcd_remap);
+
 /* Skinny product for the decode steps: out[R][N] = x[R][Kin] W[Kin][N] + bias for 33 ... 256 rows (batch x beam), Kin a
  * multiple of 8, any N -- the [TF-1.9] dense layers inside rnn_decoder_beam_search's step (BasicLSTMCell's gate product
  * model_base.py:618-621, the query layer ops_rnn.py:440-447, the output projection model_base.py:531-594) when the
@@ -406,6 +430,8 @@ typedef struct comic_decoder_desc {
 #define COMIC_DEC_STAMPS 64u            /* diagnostic phase clocks of the persistent loops (host sync per launch) */
 #define COMIC_DEC_PHASE_FWD 512u        /* comic_decoder_train_step: only the part that needs no loss coefficient (forward to the logits) */
 #define COMIC_DEC_PHASE_BWD 1024u       /* ... only the rest (loss, backward), over the SAME workspace and arguments as the forward call */
+#define COMIC_DEC_NO_GROUP_GEMM 2048u    /* comic_decoder_train_step: the products outside the time loops as separate launches on two lanes
+                                           instead of grouped launches (comic_gemm_group) */
 #define COMIC_DEC_NO_LSTM_STREAM 256u   /* decode steps at > 32 rows with the per-row-tile fused LSTM kernel instead of the streaming one */
 #define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge (large V) / comic_beam_step's kernel (small V)
                                            instead of the streaming logits + top-k launch / the register-resident small step */

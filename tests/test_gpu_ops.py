@@ -106,6 +106,76 @@ def test_gemm_f32_split3(M, N, K, ta, tb):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
+def test_gemm_group_matches_numpy_and_is_reproducible():
+    """comic_gemm_group: the three operand layouts, bias / dropout-mask / beta epilogues, column sums as products, ragged
+    tiles and split-K tiles combined inside the launch -- every problem against numpy in float64 (5e-5 of the
+    max-norm, as comic_gemm_f32_split3), a second launch over the same buffers bit-equal to the first."""
+    rng = np.random.default_rng(7)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    keep = 0.75
+    specs = [  # type, M, N, K, extras
+        (0, 1280, 2048, 1920, {}), (0, 2048, 512, 1600, {}), (2, 1856, 256, 2048, {'mask': 768}),
+        (0, 512, 258, 1856, {}), (1, 1600, 512, 2048, {}), (1, 64, 768, 2048, {'mask': 768, 'ldc': 1280}),
+        (0, 1, 2048, 1920, {'ones': True}), (0, 1, 258, 1856, {'ones': True}), (0, 1, 1, 256, {'ones': True, 'ldb': 1537}),
+        (2, 64, 768, 2048, {'bias': True}), (0, 33, 70, 19, {'beta': 2.0}), (1, 130, 131, 45, {'bias': True, 'beta': -1.0}),
+        (2, 257, 129, 64, {}), (1, 1856, 258, 512, {'bias': True})]
+    probs = (L.GemmProb * len(specs))()
+    keepalive, refs, outs = [], [], []
+    for i, (ty, M, N, K, ex) in enumerate(specs):
+        ones = ex.get('ones', False)
+        ldb = ex.get('ldb', K if ty == 2 else N)
+        A = None if ones else (f(K, M) if ty == 0 else f(M, K))
+        Bfull = f(N, ldb) if ty == 2 else f(K, ldb)
+        Bm = Bfull[:, :K].T if ty == 2 else Bfull[:, :N]
+        Am = np.ones((1, K), np.float32) if ones else (A.T if ty == 0 else A)
+        ref = Am.astype(np.float64) @ Bm.astype(np.float64)
+        ldc = ex.get('ldc', N)
+        C0 = f(M, ldc)
+        if ex.get('bias'):
+            bias = f(N); ref = ref + bias
+        else:
+            bias = None
+        if 'mask' in ex:
+            ldm = ex['mask']
+            mask = (rng.uniform(size=(M, ldm)) < keep).astype(np.float32)
+            ref = ref / keep * mask[:, :N]
+        else:
+            mask, ldm = None, 0
+        beta = ex.get('beta', 0.0)
+        ref = ref + beta * C0[:, :N]
+        dA = None if ones else dev(A)
+        dB, dC = dev(Bfull), dev(C0)
+        db = dev(bias) if bias is not None else None
+        dm = dev(mask) if mask is not None else None
+        keepalive += [dA, dB, dC, db, dm]
+        q = probs[i]
+        q.A = dA.data_ptr() if dA is not None else None
+        q.B, q.C = dB.data_ptr(), dC.data_ptr()
+        q.bias = db.data_ptr() if db is not None else None
+        q.mask = dm.data_ptr() if dm is not None else None
+        q.M, q.N, q.K, q.lda, q.ldb, q.ldc, q.ld_mask = M, N, K, (1 if ones else A.shape[1]), ldb, ldc, ldm
+        q.alpha, q.beta, q.keep, q.type, q.ones_a = 1.0, beta, keep, ty, int(ones)
+        refs.append(ref); outs.append((dC, C0, N))
+    nbytes = lib().comic_gemm_group_workspace(probs, len(specs))
+    assert nbytes > 0
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=DEV)
+    L.check(lib().comic_gemm_group(probs, len(specs), ws.data_ptr(), nbytes, stream()), 'gemm_group')
+    sync()
+    first = []
+    for (dC, C0, N), ref, sp in zip(outs, refs, specs):
+        got = dC.cpu().numpy()
+        assert_close(got[:, :N], ref, 5e-5, 'gemm_group %r' % (sp[:4],))
+        assert np.array_equal(got[:, N:], C0[:, N:]), 'gemm_group wrote outside its columns'
+        first.append(got.copy())
+    # second launch into fresh outputs: same bits (fixed-order combine), tickets left clean by the first
+    for (dC, C0, N) in outs:
+        dC.copy_(torch.from_numpy(C0))
+    L.check(lib().comic_gemm_group(probs, len(specs), ws.data_ptr(), nbytes, stream()), 'gemm_group')
+    sync()
+    for (dC, _, _), a in zip(outs, first):
+        assert np.array_equal(dC.cpu().numpy(), a)
+
+
 # ------------------------------------------------------------------------ conv / pool -----
 def _run_conv(x, w, beta, mean, var, stride, padding, dtype, dst_channels=None, dst_coff=0, relu=1, out_f32=0, tile=0):
     B, H, W, Cin = x.shape
