@@ -607,7 +607,7 @@ struct GemmGroupRun {
   }
   int run(void* slab, int64_t slab_cap, unsigned* tickets, hipStream_t st) {
     if (g.n == 0) return 0;
-    int target = comic_gemm_group_debug_target(480);
+    int target = comic_gemm_group_debug_target(640);
     for (;;) {
       int64_t need = 0;
       int nt = 0;

@@ -21,7 +21,7 @@ struct ComicGemmProb {
   int type;            // COMIC_GG_*
   int ones_a;          // A is all ones: C[0][n] = sum_k B[k][n] (column sums as a product; M must be 1, type TN)
   // set by comic_gemm_group_plan
-  int tiles_n, S, k_per_slice, wg_begin;
+  int tiles_m, tiles_n, S, k_per_slice, wg_begin;
   int slab_tile0;      // first slab tile (128 x 128 floats) of the problem: partial (tile, slice) is slab tile slab_tile0 + tile * S + slice
   int ticket0;         // first arrival counter of the problem (one per output tile)
 };

@@ -37,6 +37,8 @@ __device__ __forceinline__ void gg_store16_sc1(__amdgpu_buffer_rsrc_t r, unsigne
 
 constexpr int kGroupLds = 4 * (X3Tile<GB, true>::BYTES + X3Tile<GB, true>::BYTES);   // the largest of the three forms
 static_assert(X3Tile<GB, true>::BYTES >= X3Tile<GB, false>::BYTES, "LDS of the k-contiguous form bounds the others");
+constexpr int kGroupLdsPc = 2 * 2 * (X3TilePc<GB, false>::BYTES + X3TilePc<GB, false>::BYTES);   // two stages of the larger (row-contiguous) images
+static_assert(X3TilePc<GB, false>::BYTES >= X3TilePc<GB, true>::BYTES, "LDS of the row-contiguous form bounds the others");
 
 // four consecutive columns n .. n+3 of output row m
 __device__ __forceinline__ void gg_emit(const ComicGemmProb& p, int m, int n, float4 a) {
@@ -60,7 +62,10 @@ __device__ __forceinline__ void gg_emit(const ComicGemmProb& p, int m, int n, fl
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
+template <bool PC>
+__global__ __launch_bounds__(PC ? 512 : 256) void gemm_group_x3_kernel(ComicGemmGroup g) {
+  constexpr int NT = PC ? 512 : 256;                   // threads; PC: waves 0-3 own the output quadrants, waves 4-7 stream operands
+  constexpr int LDS = PC ? kGroupLdsPc : kGroupLds;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Workgroup ids go round the 8 XCDs; with xcd_chunk the logical item index is made contiguous per XCD (items that share
   // operand tiles then share an L2).  speed only: any placement gives the same bits.
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
   if (g.xcd_chunk > 0 && bid < g.xcd_chunk * 8) bid = (bid & 7) * g.xcd_chunk + (bid >> 3);
   // the arrival flag of the split-K combine lives in the last bytes of the (by then idle) tile images: with a static
   // __shared__ word on top of the 80 KiB of dynamic LDS only ONE workgroup fitted a CU
-  volatile unsigned* s_last = (volatile unsigned*)(smem + kGroupLds - 16);
+  volatile unsigned* s_last = (volatile unsigned*)(smem + LDS - 16);
   // which problem: the launch's workgroups are laid out problem after problem
   int pi = 0;
 #pragma unroll 1
@@ -76,8 +81,17 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
     if (bid >= g.p[i].wg_begin) pi = i;
   const ComicGemmProb& p = g.p[pi];
   const int local = bid - p.wg_begin;
-  const int S = p.S, slice = local % S, tile = local / S;
-  const int mt = tile / p.tiles_n, nt = tile % p.tiles_n;
+  // Item order inside a problem: slice-major, and inside a slice the tiles in panels of 8 tile columns walked row by row --
+  // consecutive items (= one XCD under the xcd_chunk order, about 60 at a time) then cover a block of ~8 x 8 tiles of ONE
+  // k slice and share their operand tiles through that XCD's L2 (tile-major order with the slices innermost read every B
+  // tile from beyond the L2 once per item: 56 % L2 hits by counters).
+  const int S = p.S, ntiles = p.tiles_m * p.tiles_n;
+  const int slice = local / ntiles, tl = local - slice * ntiles;
+  constexpr int PW = 8;
+  const int panel = tl / (p.tiles_m * PW), rem = tl - panel * p.tiles_m * PW;
+  const int pw = min(PW, p.tiles_n - panel * PW);
+  const int mt = rem / pw, nt = panel * PW + rem % pw;
+  const int tile = mt * p.tiles_n + nt;
   const int m0 = mt * GB, n0 = nt * GB;
   const int kbeg = S > 1 ? slice * p.k_per_slice : 0;
   const int kend = S > 1 ? min(p.K, kbeg + p.k_per_slice) : p.K;
@@ -89,13 +103,14 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
   const unsigned sbase = (unsigned)slice * (GB * GB * 4);
   if (p.ones_a) {
     // column sums in exact fp32 (a bias gradient is a sum with cancellation: the 16 mantissa bits of a hi + lo pair are
-    // not enough for it): thread = (4 columns, k rows kg, kg + 8, ...), the eight row groups combined in a fixed order
-    float4* red = (float4*)smem;                       // [8][32]
+    // not enough for it): thread = (4 columns, k rows kg, kg + KG, ...), the row groups combined in a fixed order
+    constexpr int KG = NT / 32;
+    float4* red = (float4*)smem;                       // [KG][32]
     const int cg = tid & 31, kg = tid >> 5, n = n0 + 4 * cg;
     const bool vec = (p.ldb % 4 == 0) && (((uintptr_t)p.B & 15) == 0);
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.N)
-      for (int k = kbeg + kg; k < kend; k += 8) {
+      for (int k = kbeg + kg; k < kend; k += KG) {
         const float4 v = load4(p.B + (size_t)k * p.ldb + n, p.N - n, vec);
         sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
       }
@@ -104,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
     if (tid < 32) {
       float4 tot = red[cg];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) {
+      for (int k = 1; k < KG; ++k) {
         const float4 v = red[k * 32 + cg];
         tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
       }
@@ -114,13 +129,21 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
     if (S == 1) return;
   } else {
     f32x4_t acc[4][4];
-    if (p.type == COMIC_GG_TN)
-      x3_mainloop<GB, false, false, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
-    else if (p.type == COMIC_GG_NN)
-      x3_mainloop<GB, true, false, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
-    else
-      x3_mainloop<GB, true, true, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+    if constexpr (PC) {
+      if (p.type == COMIC_GG_TN) x3_mainloop_pc<false, false>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+      else if (p.type == COMIC_GG_NN) x3_mainloop_pc<true, false>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+      else x3_mainloop_pc<true, true>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+    } else {
+      if (p.type == COMIC_GG_TN)
+        x3_mainloop<GB, false, false, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+      else if (p.type == COMIC_GG_NN)
+        x3_mainloop<GB, true, false, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+      else
+        x3_mainloop<GB, true, true, GB>(p.A, p.B, p.M, p.N, p.lda, p.ldb, m0, n0, kbeg, kend, smem, acc);
+    }
+    const bool owner = wave < 4;                         // (PC: the streaming waves hold no results)
     if (S == 1) {
+      if (owner)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -130,6 +153,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
       return;
     }
     // partial tile -> slab tile slab_tile0 + tile * S + slice
+    if (owner)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
   __syncthreads();
   if (!*s_last) return;
   // last arriver: sum the S partials in slice order (sc1 loads: the partials were written by other CUs)
-  const int n_chunks = p.ones_a ? 1 : (GB * GB / 4) / 256;     // column sums: row 0 of the tile only (32 float4)
+  const int n_chunks = p.ones_a ? 1 : (GB * GB / 4) / NT;     // column sums: row 0 of the tile only (32 float4)
 #pragma unroll 1
   for (int c = 0; c < n_chunks; c += 4) {
     float4 sum[4];
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
     for (int s = 0; s < S; ++s) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = gg_load16_sc1(sr, (unsigned)s * (GB * GB * 4) + (unsigned)(tid + 256 * (c + u)) * 16u);
+      for (int u = 0; u < 4; ++u) v[u] = gg_load16_sc1(sr, (unsigned)s * (GB * GB * 4) + (unsigned)(tid + NT * (c + u)) * 16u);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         sum[u].x += v[u].x; sum[u].y += v[u].y; sum[u].z += v[u].z; sum[u].w += v[u].w;
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_group_x3_kernel(ComicGemmGroup g) {
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx4 = tid + 256 * (c + u);
+      const int idx4 = tid + NT * (c + u);
       if (!p.ones_a || idx4 < GB / 4) gg_emit(p, m0 + idx4 / (GB / 4), n0 + (idx4 % (GB / 4)) * 4, sum[u]);
     }
   }
@@ -186,6 +210,7 @@ int comic_gemm_group_plan(ComicGemmGroup& g, int target_items, int64_t* slab_byt
     COMIC_REQUIRE(p.ldc >= p.N && (!p.mask || p.ld_mask >= p.N), "gemm_group: leading dimension of problem %d", i);
     if (!p.ones_a) COMIC_REQUIRE(p.lda >= (p.type == COMIC_GG_TN ? p.M : p.K), "gemm_group: lda of problem %d", i);
     COMIC_REQUIRE(p.ldb >= (p.type == COMIC_GG_NT ? p.K : p.N), "gemm_group: ldb of problem %d", i);
+    p.tiles_m = cdiv(p.M, GB);
     p.tiles_n = cdiv(p.N, GB);
     cost += (long)cdiv(p.M, GB) * p.tiles_n * cdiv(p.K, 32);
   }
@@ -212,10 +237,11 @@ int comic_gemm_group_plan(ComicGemmGroup& g, int target_items, int64_t* slab_byt
   return wg;
 }
 
-static int g_dbg_target = 0, g_dbg_xcd = 1;
+static int g_dbg_target = 0, g_dbg_xcd = 1, g_dbg_pc = 2;
 extern "C" int comic_debug_gemm_group_tuning(int target_items, int xcd_remap) {
   g_dbg_target = target_items;
-  g_dbg_xcd = xcd_remap;
+  g_dbg_xcd = xcd_remap & 1;
+  g_dbg_pc = (xcd_remap & 2) ? 0 : (xcd_remap & 4) ? 2 : 1;        // bit 1: the four-wave kernel, bit 2: by launch size (default)
   return 0;
 }
 int comic_gemm_group_debug_target(int dflt) { return g_dbg_target > 0 ? g_dbg_target : dflt; }
@@ -224,14 +250,28 @@ int comic_gemm_group_launch(const ComicGemmGroup& g_in, int n_wg, hipStream_t st
   ComicGemmGroup g = g_in;
   g.xcd_chunk = g_dbg_xcd ? n_wg / 8 : 0;
   COMIC_REQUIRE(n_wg > 0, "gemm_group: empty launch");
-  static PerDeviceOnce once;
-  bool& done = once.slot();
+  // producer / consumer kernel (one 8-wave workgroup per CU) when every product can be loaded 16 bytes at a time and the
+  // launch fits the chip in one round; beyond that the four-wave kernel (two workgroups per CU) measured faster (the
+  // weight-gradient group of the decoder step: 98 against 118 us; its single-round launches 19-23 against 23-29 us)
+  bool pc = g_dbg_pc == 1 || (g_dbg_pc == 2 && n_wg <= 256);
+  for (int i = 0; i < g.n && pc; ++i) {
+    const ComicGemmProb& p = g.p[i];
+    if (p.ones_a) continue;
+    const bool a_kc = p.type != COMIC_GG_TN, b_kc = p.type == COMIC_GG_NT;
+    pc = p.lda % 4 == 0 && p.ldb % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 &&
+         (!(a_kc || b_kc) || p.K % 4 == 0);
+  }
+  static PerDeviceOnce once, once_pc;
+  bool& done = pc ? once_pc.slot() : once.slot();
+  const int lds = pc ? kGroupLdsPc : kGroupLds;
   if (!done) {
-    COMIC_REQUIRE(hipFuncSetAttribute((const void*)gemm_group_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kGroupLds) == hipSuccess, "gemm_group: cannot reserve %d bytes of LDS", kGroupLds);
+    const void* fn = pc ? (const void*)gemm_group_x3_kernel<true> : (const void*)gemm_group_x3_kernel<false>;
+    COMIC_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                  "gemm_group: cannot reserve %d bytes of LDS", lds);
     done = true;
   }
-  hipLaunchKernelGGL(gemm_group_x3_kernel, dim3((unsigned)n_wg), dim3(256), kGroupLds, st, g);
+  if (pc) hipLaunchKernelGGL(gemm_group_x3_kernel<true>, dim3((unsigned)n_wg), dim3(512), lds, st, g);
+  else hipLaunchKernelGGL(gemm_group_x3_kernel<false>, dim3((unsigned)n_wg), dim3(256), lds, st, g);
   COMIC_LAUNCH_CHECK("gemm_group");
   return 0;
 }
@@ -250,7 +290,7 @@ int gg_from_public(const comic_gemm_prob* probs, int n, ComicGemmGroup& g) {
   }
   return 0;
 }
-#define kPublicTarget comic_gemm_group_debug_target(480)
+#define kPublicTarget comic_gemm_group_debug_target(640)
 }  // namespace
 
 extern "C" int64_t comic_gemm_group_workspace(const comic_gemm_prob* probs, int n) {

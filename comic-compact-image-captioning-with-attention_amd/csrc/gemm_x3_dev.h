@@ -161,7 +161,8 @@ struct X3Src {
   const float* g;
   int ld, row0, rows_total, kend;
   __amdgpu_buffer_rsrc_t rs;
-  unsigned base;          // KC: byte offset of this thread's first chunk at k0 = 0;  !KC: ... of its first chunk of the current tile
+  unsigned base;          // !KC: byte offset of this thread's first chunk of the current tile
+  unsigned rb[NCH];       // KC: byte offset of chunk i at k0 = 0 (kOor when its row is outside the operand)
   int kc;                 // KC: k offset of this thread's chunks inside a tile
   unsigned step8;         // !KC: bytes between two chunks of this thread (256 / (ROWS / 4) k rows)
   __device__ __forceinline__ void init(const float* g_, int ld_, int row0_, int rows_total_, int kbeg, int kend_, int tid) {
@@ -170,8 +171,11 @@ struct X3Src {
       rs = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7FFFFFF0, 0x00020000);
       if (KC) {
         kc = (tid & 7) * 4;
-        // chunk i: row row0 + (tid >> 3) + 32 i
-        base = (unsigned)(((long)(row0 + (tid >> 3)) * ld + kc) * 4);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {               // chunk i: row row0 + (tid >> 3) + 32 i
+          const int r = row0 + (tid >> 3) + 32 * i;
+          rb[i] = r < rows_total ? (unsigned)(((long)r * ld + kc) * 4) : kOor;
+        }
       } else {
         constexpr int CPR = ROWS / 4;                 // chunks per k row; chunk q = tid + 256 i: k row q / CPR, columns (q % CPR) * 4
         const int r = row0 + (tid % CPR) * 4;
@@ -187,11 +191,12 @@ struct X3Src {
     if (VEC) {
       typedef __attribute__((ext_vector_type(4))) unsigned u4;
       if (KC) {
-        const bool past = k0 + kc >= kend;
+        // k0 + kc >= kend -> bit 31 set (pure arithmetic: with a select here hipcc branches around two copies of the load
+        // and waits vmcnt(0) in between)
+        const unsigned past = (unsigned)((kend - 1 - (k0 + kc)) >> 31) & kOor;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-          unsigned o = base + (unsigned)(32 * i) * (unsigned)(ld * 4) + (unsigned)k0 * 4u;
-          o = (past || row0 + (tid >> 3) + 32 * i >= rows_total) ? kOor : o;
+          const unsigned o = (rb[i] + (unsigned)k0 * 4u) | past;
           const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o, 0, 0);
           out[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
@@ -319,6 +324,152 @@ __device__ __forceinline__ void x3_mainloop(const float* __restrict__ A, const f
   const bool b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0) && (!B_KC || kend % 4 == 0);
   if (a_vec && b_vec) x3_mainloop_v<BM, A_KC, B_KC, BN, true>(A, B, M, N, lda, ldb, m0, n0, kbeg, kend, smem, acc);
   else x3_mainloop_v<BM, A_KC, B_KC, BN, false>(A, B, M, N, lda, ldb, m0, n0, kbeg, kend, smem, acc);
+}
+
+// ---- producer / consumer form of the main loop (grouped launches; 512 threads, 16-byte loads only) -----------------------
+// In the form above all four waves of a workgroup do the same thing at the same time -- load, wait, convert, store, barrier,
+// read fragments, multiply -- so a k-tile costs the SUM of those phases (about 2000 cycles alone on a CU, 2.5 us per k-tile
+// with two workgroups per CU: 20 % of the matrix peak on d K).  Here the roles are split (the loader-wave idea of the
+// convolution kernels): waves 0-3 own the 2 x 2 output quadrants and only read fragments and issue MFMAs; waves 4-7 only
+// stream: buffer loads four k-tiles deep into four register sets, hi / lo split, LDS stores into the other of two stages.
+// One workgroup barrier per k-tile: behind it tile kt + 1 is complete and stage kt % 2 is free again.  The k-contiguous LDS
+// image has 64-byte rows (no pad) and the 16-byte chunk j of row r sits at j ^ swz(r >> 2), swz = {0, 3, 2, 1}: the lane
+// groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...) then hit sixteen distinct bank quads (the padded 80-byte rows gave
+// 33 % conflict cycles by counters).
+template <int ROWS, bool KC>
+struct X3TilePc {
+  static constexpr int KSTR = 2 * ROWS + 32;
+  static constexpr int BYTES = KC ? ROWS * 64 : 32 * KSTR;
+};
+__device__ __forceinline__ int x3_swz(int row) { return (0x6C >> (((row >> 2) & 3) * 2)) & 3; }   // {0, 3, 2, 1}
+
+template <int ROWS, bool KC, int NCH>
+__device__ __forceinline__ void x3pc_store_tile(unsigned char* hi_base, unsigned char* lo_base, int tid,
+                                                const float4 (&in)[NCH]) {
+  using T = X3TilePc<ROWS, KC>;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int q = tid + 256 * i;
+    uint32_t h0, l0, h1, l1;
+    split_bf16x2(in[i].x, in[i].y, h0, l0);
+    split_bf16x2(in[i].z, in[i].w, h1, l1);
+    int off;
+    if (KC) {       // 8-byte piece c (k = 4c .. 4c+3) -> chunk c & 3, half c >> 2 (lane group g multiplies k {4g.., 16+4g..})
+      const int row = q >> 3, c = q & 7;
+      off = row * 64 + (((c & 3) ^ x3_swz(row)) * 2 + (c >> 2)) * 8;
+    } else {
+      constexpr int CPR = ROWS / 4;
+      const int kk = q / CPR, row = (q % CPR) * 4;
+      off = kk * T::KSTR + row * 2;
+    }
+    *(uint2*)(hi_base + off) = make_uint2(h0, h1);
+    *(uint2*)(lo_base + off) = make_uint2(l0, l1);
+  }
+}
+template <int ROWS, bool KC>
+__device__ __forceinline__ bf16x8_t x3pc_frag(const unsigned char* base, int row16, int lane) {
+  using T = X3TilePc<ROWS, KC>;
+  if (KC) {
+    const int row = row16 + (lane & 15);
+    const uint4 v = *(const uint4*)(base + row * 64 + (((lane >> 4) ^ x3_swz(row)) * 16));
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned char* p = base + (4 * g + q) * T::KSTR + (row16 + 4 * pp) * 2;
+    const uint32_t a0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const unsigned char*)p);
+    const x3_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)a0);
+    const x3_s16x4_t hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) x3_s16x4_t*)(uintptr_t)(a0 + 16 * T::KSTR));
+    const x3_s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+// 128 x 128 tile, 512 threads.  acc is meaningful in waves 0-3 only (quadrant wm = wave >> 1, wn = wave & 1, layout as above).
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void x3_mainloop_pc(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int lda,
+                                               int ldb, int m0, int n0, int kbeg, int kend, unsigned char* smem,
+                                               f32x4_t (&acc)[4][4]) {
+  constexpr int BM = 128, BN = 128, BKx = 32, NCH = 4;
+  constexpr int ABYTES = X3TilePc<BM, A_KC>::BYTES, BBYTES = X3TilePc<BN, B_KC>::BYTES;
+  constexpr int STAGE = 2 * (ABYTES + BBYTES);          // A hi | A lo | B hi | B lo
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // k-tiles, rounded up to a multiple of 4 (the register sets rotate with period 4; tiles past kend load zeros)
+  const int nk = ((kend - kbeg + BKx - 1) / BKx + 3) & ~3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  if (wave >= 4) {
+    // ---------------------------------------------------------------- producers ------------
+    const int pt = tid - 256;
+    X3Src<BM, A_KC, NCH, true> sa;
+    X3Src<BN, B_KC, NCH, true> sb;
+    sa.init(A, lda, m0, M, kbeg, kend, pt);
+    sb.init(B, ldb, n0, N, kbeg, kend, pt);
+    float4 ar[4][NCH], br[4][NCH];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sa.load(kbeg + s * BKx, pt, ar[s]);
+      sb.load(kbeg + s * BKx, pt, br[s]);
+    }
+    auto put = [&](int stage, const float4 (&a)[NCH], const float4 (&b)[NCH]) {
+      unsigned char* st = smem + stage * STAGE;
+      x3pc_store_tile<BM, A_KC, NCH>(st, st + ABYTES, pt, a);
+      x3pc_store_tile<BN, B_KC, NCH>(st + 2 * ABYTES, st + 2 * ABYTES + BBYTES, pt, b);
+    };
+    put(0, ar[0], br[0]);
+    sa.load(kbeg + 4 * BKx, pt, ar[0]);
+    sb.load(kbeg + 4 * BKx, pt, br[0]);
+    __syncthreads();
+    // iteration kt: tile kt + 1 (set (kt + 1) % 4) -> stage (kt + 1) % 2, then tile kt + 5 is requested into that set
+    auto step = [&](int kt, auto s_) {
+      constexpr int S = decltype(s_)::value;             // (kt + 1) % 4
+      put(S & 1, ar[S], br[S]);
+      sa.load(kbeg + (kt + 5) * BKx, pt, ar[S]);
+      sb.load(kbeg + (kt + 5) * BKx, pt, br[S]);
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      step(kt, std::integral_constant<int, 1>());
+      step(kt + 1, std::integral_constant<int, 2>());
+      step(kt + 2, std::integral_constant<int, 3>());
+      step(kt + 3, std::integral_constant<int, 0>());
+    }
+  } else {
+    // ---------------------------------------------------------------- consumers ------------
+    const int wm = wave >> 1, wn = wave & 1;
+    __syncthreads();
+    auto step = [&](auto p_) {
+      constexpr int P = decltype(p_)::value;             // kt % 2
+      const unsigned char* st = smem + P * STAGE;
+      bf16x8_t bh[4], bl[4], ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bh[i] = x3pc_frag<BN, B_KC>(st + 2 * ABYTES, wn * 64 + i * 16, lane);
+        bl[i] = x3pc_frag<BN, B_KC>(st + 2 * ABYTES + BBYTES, wn * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ah[j] = x3pc_frag<BM, A_KC>(st, wm * 64 + j * 16, lane);
+        al[j] = x3pc_frag<BM, A_KC>(st + ABYTES, wm * 64 + j * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
+        }
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(std::integral_constant<int, 0>());
+      step(std::integral_constant<int, 1>());
+    }
+  }
 }
 
 }  // namespace

@@ -106,19 +106,35 @@ def test_gemm_f32_split3(M, N, K, ta, tb):
     assert float(big[:, N:].abs().max()) == 0.0
 
 
-def test_gemm_group_matches_numpy_and_is_reproducible():
+_GG_SPECS = {  # type, M, N, K, extras
+    # any alignment: the four-wave kernel with scalar loads where rows are not 16-byte aligned
+    'mixed': [
+        (0, 1280, 2048, 1920, {}), (0, 2048, 512, 1600, {}), (2, 1856, 256, 2048, {'mask': 768}),
+        (0, 512, 258, 1856, {}), (1, 1600, 512, 2048, {}), (1, 64, 768, 2048, {'mask': 768, 'ldc': 1280}),
+        (0, 1, 2048, 1920, {'ones': True}), (0, 1, 258, 1856, {'ones': True}), (0, 1, 1, 256, {'ones': True, 'ldb': 1537}),
+        (2, 64, 768, 2048, {'bias': True}), (0, 33, 70, 19, {'beta': 2.0}), (1, 130, 131, 45, {'bias': True, 'beta': -1.0}),
+        (2, 257, 129, 64, {}), (1, 1856, 258, 512, {'bias': True})],
+    # every operand row 16-byte aligned: the producer / consumer kernel (the training step's shapes, ragged tiles, short
+    # and odd k-tile counts, N not a multiple of 4 inside a padded row)
+    'aligned': [
+        (0, 1280, 2048, 1920, {}), (0, 2048, 512, 1600, {}), (2, 1856, 256, 2048, {'mask': 768}),
+        (0, 512, 258, 1856, {'ldb': 260}), (1, 1600, 512, 2048, {}), (1, 64, 768, 2048, {'mask': 768, 'ldc': 1280}),
+        (0, 1, 2048, 1920, {'ones': True}), (0, 1, 258, 1856, {'ones': True, 'ldb': 260}), (0, 1, 1, 256, {'ones': True, 'ldb': 1537}),
+        (2, 64, 768, 2048, {'bias': True}), (0, 36, 72, 20, {'beta': 2.0}), (1, 132, 130, 44, {'bias': True, 'beta': -1.0, 'ldb': 132}),
+        (2, 257, 129, 64, {}), (1, 1856, 258, 512, {'bias': True, 'ldb': 260}), (2, 1856, 512, 260, {}), (1, 100, 100, 100, {}),
+        (0, 100, 100, 300, {})],
+}
+
+
+@pytest.mark.parametrize('which', ['mixed', 'aligned'])
+def test_gemm_group_matches_numpy_and_is_reproducible(which):
     """comic_gemm_group: the three operand layouts, bias / dropout-mask / beta epilogues, column sums as products, ragged
     tiles and split-K tiles combined inside the launch -- every problem against numpy in float64 (5e-5 of the
     max-norm, as comic_gemm_f32_split3), a second launch over the same buffers bit-equal to the first."""
     rng = np.random.default_rng(7)
     f = lambda *s: rng.standard_normal(s).astype(np.float32)
     keep = 0.75
-    specs = [  # type, M, N, K, extras
-        (0, 1280, 2048, 1920, {}), (0, 2048, 512, 1600, {}), (2, 1856, 256, 2048, {'mask': 768}),
-        (0, 512, 258, 1856, {}), (1, 1600, 512, 2048, {}), (1, 64, 768, 2048, {'mask': 768, 'ldc': 1280}),
-        (0, 1, 2048, 1920, {'ones': True}), (0, 1, 258, 1856, {'ones': True}), (0, 1, 1, 256, {'ones': True, 'ldb': 1537}),
-        (2, 64, 768, 2048, {'bias': True}), (0, 33, 70, 19, {'beta': 2.0}), (1, 130, 131, 45, {'bias': True, 'beta': -1.0}),
-        (2, 257, 129, 64, {}), (1, 1856, 258, 512, {'bias': True})]
+    specs = _GG_SPECS[which]
     probs = (L.GemmProb * len(specs))()
     keepalive, refs, outs = [], [], []
     for i, (ty, M, N, K, ex) in enumerate(specs):

@@ -50,7 +50,10 @@ def run(name, n=20):
         L.check(lib.comic_gemm_group(arr, len(arr), ws.data_ptr(), ws.numel(), st))
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+only = os.environ.get('GROUPS')
+if only:
+    groups = {k: v for k, v in groups.items() if k in only.split(',')}
 for tgt in (int(x) for x in os.environ.get('TARGETS', '480,720,960,1440').split(',')):
-    for xcd in (0, 1):
+    for xcd in (1, 3):      # 1: producer / consumer kernel, 3: four-wave kernel (both with the XCD-contiguous item order)
         lib.comic_debug_gemm_group_tuning(tgt, xcd)
         print('target %4d xcd %d: ' % (tgt, xcd) + '  '.join('%s %.1f' % (k, run(k)) for k in groups), flush=True)

@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 900 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "gemm" > $out/t_gemm.log 2>&1 || { tail -40 $out/t_gemm.log; exit 1; }
 tail -1 $out/t_gemm.log
 export M=25 C=2048 CG=2048 B=64 N=30
-COMIC_GROUP_GEMM=0 timeout -k 10 300 python tools/dec_step_time.py 2>&1 | tail -1
+
 timeout -k 10 300 python tools/dec_step_time.py 2>&1 | tail -1
 PKG=$GRAFT_REPO_ROOT/comic-compact-image-captioning-with-attention_amd
 
