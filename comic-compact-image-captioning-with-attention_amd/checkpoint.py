@@ -22,14 +22,18 @@ import re
 import numpy as np
 
 from . import tf_bundle
-from .decoder import TF_NAMES, CELL_SCOPES
+from .decoder import TF_NAMES, CELL_SCOPES, CELL_VARS, STEP_SCOPE, STEP_VARS
 
 DEC_SCOPE = 'Model/decoder/rnn_decoder/'
 CNN_SCOPE = 'Model/encoder/cnn/'
 
 
-def decoder_var_names(spec):
+def decoder_var_names(spec, legacy_flat=False):
+    """{parameter key: TensorFlow variable name} of the decoder (see decoder.TF_NAMES).
+    legacy_flat: the names rounds 1-3 of this package wrote (every variable directly under rnn_decoder/, cell variables
+    always under rnn_init_input/): still accepted on restore."""
     out = {}
+    first_input = getattr(spec, 'init_method', 'first_input') == 'first_input'
     for k in spec.param_shapes():
         n = TF_NAMES[k]
         if isinstance(n, dict):
@@ -39,8 +43,26 @@ def decoder_var_names(spec):
         rnn = getattr(spec, 'rnn_name', 'LSTM')
         if k in ('K', 'b') and rnn != 'LSTM':
             scope, kn, bn = CELL_SCOPES[rnn]
-            n = 'rnn_init_input/%s/%s' % (scope, kn if k == 'K' else bn)
+            n = '%s/%s' % (scope, kn if k == 'K' else bn)
+        if k in CELL_VARS:
+            n = ('rnn_init_input/' if (first_input or legacy_flat) else STEP_SCOPE) + n
+        elif k in STEP_VARS and not legacy_flat:
+            n = STEP_SCOPE + n
         out[k] = DEC_SCOPE + n
+    return out
+
+
+def _rename_legacy(arrays, dec_spec):
+    """Checkpoints written before the names were derived from the reference's scopes: map them to the current names."""
+    cur, old = decoder_var_names(dec_spec), decoder_var_names(dec_spec, legacy_flat=True)
+    ren = {old[k]: cur[k] for k in cur if old[k] != cur[k]}
+    if not ren or not any(o in arrays for o in ren) or any(c in arrays for c in ren.values()):
+        return arrays
+    out = {}
+    for name, v in arrays.items():
+        hit = next((o for o in ren if name == o or name == ADAM_SCOPE + o + '/Adam' or name == ADAM_SCOPE + o + '/Adam_1' or
+                    name == ADAM_SCOPE + o + '/Momentum'), None)
+        out[name.replace(hit, ren[hit]) if hit else name] = v
     return out
 
 
@@ -158,11 +180,11 @@ def restore(path, cnn_param_names, dec_spec, resume_training=False, exclude_scop
     when given, they count as model variables and a 4-tuple (cnn, dec, extra, head arrays | None) is returned."""
     if head_names != 'unset':
         hn = list(head_names or [])
-        arrays = load(path)
+        arrays = _rename_legacy(load(path), dec_spec)
         r = _restore(arrays, path, cnn_param_names, dec_spec, resume_training, exclude_scopes, hn)
         head = {n: arrays[n] for n in hn} if (r[1] is not None and hn) else None
         return r + (head,)
-    return _restore(load(path), path, cnn_param_names, dec_spec, resume_training, exclude_scopes, [])
+    return _restore(_rename_legacy(load(path), dec_spec), path, cnn_param_names, dec_spec, resume_training, exclude_scopes, [])
 
 
 def _restore(arrays, path, cnn_param_names, dec_spec, resume_training, exclude_scopes, more_model_vars):

@@ -21,25 +21,36 @@ from . import _lib as L
 from .ops import number_to_base
 
 # TF variable names (scope Model/decoder/rnn_decoder/), SURVEY Appendix C
+# TensorFlow variable names under `Model/decoder/rnn_decoder/` (checkpoint.decoder_var_names composes them; derived from
+# the reference's scopes by oracle/ref_var_names.py and pinned by tests/golden/ref_var_names.json):
+#   * created when the graph is CONSTRUCTED (model_base.py:147-176): memory / value layers, output projection, embedding
+#     map, the rnn-init projection;
+#   * STEP_VARS are created at the first decoder step, i.e. inside dynamic_decode's 'decoder' scope and the attention
+#     wrapper's own layer scope (ops_rnn.py:543-562, :735);
+#   * CELL_VARS follow the cell's FIRST call: 'rnn_init_input/' with rnn_init_method='first_input' (model_base.py:677-686),
+#     the step scope with 'project_hidden'.
+STEP_SCOPE = 'decoder/multi_head_attention_wrapper_v3/'
 TF_NAMES = {
     'W_init': {'first_input': 'rnn_init_input/projection/weight', 'project_hidden': 'rnn_initial_state/weight'},
-    'K': 'rnn_init_input/basic_lstm_cell/kernel', 'b': 'rnn_init_input/basic_lstm_cell/bias',
+    'K': 'basic_lstm_cell/kernel', 'b': 'basic_lstm_cell/bias',
     'W_m': 'memory_layer/kernel', 'W_v': 'value_layer/kernel',
     'W_q': 'multi_add_attention/query_layer/kernel', 'v': 'multi_add_attention/attention_v',
     'ln_g': 'multi_add_attention/LN_tanh/gamma', 'ln_b': 'multi_add_attention/LN_tanh/beta',
     'tau': 'softmax_temperature', 'W_a': 'a_layer/kernel',
     'W_o': 'output_projection/kernel', 'b_o': 'output_projection/bias', 'emb': 'embedding_map',
     # --rnn_name GRU: tf.contrib.rnn.GRUCell's candidate pair (its gates pair takes K / b)
-    'K_c': 'rnn_init_input/gru_cell/candidate/kernel', 'b_c': 'rnn_init_input/gru_cell/candidate/bias',
+    'K_c': 'gru_cell/candidate/kernel', 'b_c': 'gru_cell/candidate/bias',
 }
+STEP_VARS = ('W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a')
 # per cell: TF scope of the cell's variables and the names of K / b inside it (model_base.py:606-632)
 CELL_SCOPES = {'LSTM': ('basic_lstm_cell', 'kernel', 'bias'), 'LN_LSTM': ('layer_norm_basic_lstm_cell', 'kernel', None),
                'GRU': ('gru_cell', 'gates/kernel', 'gates/bias')}
 # --rnn_name LN_LSTM: LayerNormBasicLSTMCell's five layer_norm scopes, in the order of comic_decoder_params::cell_ln
 LN_LSTM_NORMS = (('i', 'input'), ('j', 'transform'), ('f', 'forget'), ('o', 'output'), ('c', 'state'))
 for _k, _scope in LN_LSTM_NORMS:
-    TF_NAMES['cln_%sg' % _k] = 'rnn_init_input/layer_norm_basic_lstm_cell/%s/gamma' % _scope
-    TF_NAMES['cln_%sb' % _k] = 'rnn_init_input/layer_norm_basic_lstm_cell/%s/beta' % _scope
+    TF_NAMES['cln_%sg' % _k] = 'layer_norm_basic_lstm_cell/%s/gamma' % _scope
+    TF_NAMES['cln_%sb' % _k] = 'layer_norm_basic_lstm_cell/%s/beta' % _scope
+CELL_VARS = ('K', 'b', 'K_c', 'b_c') + tuple('cln_%s%s' % (k, s) for k, _ in LN_LSTM_NORMS for s in 'gb')
 
 
 @dataclass

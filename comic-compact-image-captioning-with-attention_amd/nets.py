@@ -619,6 +619,7 @@ class CnnEncoder:
         self._build_group_args()
         self._graph = None
         self._calls = 0
+        self._alt = {}                 # adopted input tensors: address -> [pointer table, graph, calls, tensor]
         self._polite_lds_kb = 0
         self._fm_f32 = None
 
@@ -637,7 +638,7 @@ class CnnEncoder:
         self._polite_lds_kb = kb
         for i in range(len(self.plan.ops)):
             self._ops[i].min_lds = kb * 1024
-        self._graph, self._calls = None, 0
+        self._drop_graphs()
 
     def load_params(self, params):
         """(Re)load every CNN variable from {slim name: array} into the flat masters IN PLACE (all
@@ -861,15 +862,40 @@ class CnnEncoder:
         self._group_args.copy_(torch.from_numpy(host))
         torch.cuda.synchronize()
 
-    def _run(self):
+    def _drop_graphs(self):
+        """Captured graphs hold launch parameters: drop them (the next calls capture again)."""
+        self._graph, self._calls = None, 0
+        for a in self._alt.values():
+            a[1], a[2] = None, 0
+
+    def _run(self, bufptr=None):
+        bufptr = bufptr or self._bufptr
         if self._group_args is not None:
-            L.check(self.lib.comic_cnn_forward_grouped(self._ops, len(self.plan.ops), self._bufptr, self._bufch,
+            L.check(self.lib.comic_cnn_forward_grouped(self._ops, len(self.plan.ops), bufptr, self._bufch,
                                                        self._wt, self.batch, self.dcode,
                                                        self._group_args.data_ptr(), L.stream_ptr()),
                     'cnn_forward_grouped')
             return
-        L.check(self.lib.comic_cnn_forward(self._ops, len(self.plan.ops), self._bufptr, self._bufch, self._wt,
+        L.check(self.lib.comic_cnn_forward(self._ops, len(self.plan.ops), bufptr, self._bufch, self._wt,
                                            self.batch, self.dcode, L.stream_ptr()), 'cnn_forward')
+
+    def _adopt(self, images):
+        """Pointer table (and graph slot) for a forward that reads `images` IN PLACE instead of from a copy in the plan's
+        input buffer (385 MB of device-to-device traffic per forward of 640 images).  Possible when only ungrouped ops read
+        the input (grouped launches keep their buffer addresses in device records); at most four distinct tensors are
+        adopted -- a caller that hands over a fresh tensor every time gets the copy."""
+        key = images.data_ptr()
+        a = self._alt.get(key)
+        if a is not None:
+            return a
+        if len(self._alt) >= 4 or not images.is_contiguous() or self._train is not None:
+            return None
+        if any(o['src'] == self.plan.input and o.get('group', 0) for o in self.plan.ops):
+            return None
+        bp = (C.c_void_p * len(self.bufs))(*[b.data_ptr() for b in self.bufs])
+        bp[self.plan.input] = key
+        a = self._alt[key] = [bp, None, 0, images]
+        return a
 
     def forward(self, images, use_graph=False):
         """images fp32 NHWC [B,H,W,3] in [-1,1] (device) -> (im_embed [B,C_g], fmaps [B,M,C]) fp32.
@@ -878,20 +904,30 @@ class CnnEncoder:
         is captured on the second call."""
         inp = self.bufs[self.plan.input]
         assert images.shape == inp.shape and images.dtype == inp.dtype, (images.shape, inp.shape)
+        alt = None
         if images.data_ptr() != inp.data_ptr():
-            inp.copy_(images)
-        if use_graph and self._graph is None and self._calls >= 1:
-            g = self.torch.cuda.CUDAGraph()
+            alt = self._adopt(images)
+            if alt is None:
+                inp.copy_(images)
+        bufptr, graph, calls = (alt[0], alt[1], alt[2]) if alt is not None else (None, self._graph, self._calls)
+        if use_graph and graph is None and calls >= 1:
+            graph = self.torch.cuda.CUDAGraph()
             # thread_local: the input pipeline's prefetch thread allocates, copies and launches on this device
             # meanwhile; only the capturing thread is held to the capture rules
-            with self.torch.cuda.graph(g, capture_error_mode='thread_local'):
-                self._run()
-            self._graph = g
-        if use_graph and self._graph is not None:
-            self._graph.replay()
+            with self.torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                self._run(bufptr)
+            if alt is not None:
+                alt[1] = graph
+            else:
+                self._graph = graph
+        if use_graph and graph is not None:
+            graph.replay()
         else:
-            self._run()
-        self._calls += 1
+            self._run(bufptr)
+        if alt is not None:
+            alt[2] += 1
+        else:
+            self._calls += 1
         pooled = self.bufs[self.plan.pooled]
         B = self.batch
         if self.plan.fm is None:           # inner end point (Inception-V1 Mixed_4f): fp32 copy for the decoder
@@ -928,7 +964,7 @@ class CnnEncoder:
                     self._ops[i].tile = int(t)
                 if self._group_args is not None:
                     self._build_group_args()
-                self._graph, self._calls = None, 0
+                self._drop_graphs()
                 return {i: (None, t) for i, t in enumerate(tiles)}
         chosen = self._autotune(reps, verbose, torch, st)      # op.min_lds: tuned under the occupancy the forward runs with
         if cache:
@@ -1023,7 +1059,7 @@ class CnnEncoder:
             i += n
         if grouped:
             self._build_group_args()
-        self._graph = None        # a captured graph holds the old variants
+        self._drop_graphs()       # a captured graph holds the old variants
         self._calls = 0
         return chosen
 

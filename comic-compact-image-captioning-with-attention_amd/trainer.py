@@ -244,7 +244,7 @@ class CaptionTrainer:
         conv workgroups take a whole CU's LDS each, so the decoder's kernels always find wave slots."""
         if self.encoder.polite_lds_kb != polite_lds_kb:
             self.encoder.polite_lds_kb = polite_lds_kb
-            self.encoder._graph, self.encoder._calls = None, 0      # re-capture with the new launch parameters
+            self.encoder._drop_graphs()                             # re-capture with the new launch parameters
 
     def submit_images(self, images, events=None):
         """Start the encoder forward of a future step (group > 1: of the next `group` steps, images

@@ -339,6 +339,45 @@ def test_checkpoint_restore_three_way_logic(tmp_path):
     assert d3 is None and c3[plan_names[0]].max() == 2
 
 
+def test_checkpoint_variable_list_equals_the_reference_scopes(golden_dir, tmp_path):
+    """f1: the variables checkpoint.py writes / expects for a TF bundle, name for name and shape for shape, against the
+    list oracle/ref_var_names.py derives statically from the reference's scopes (tests/golden/ref_var_names.json; the
+    [TF-1.9] scoping rules it applies are stated in its header) -- COMIC-256 on Inception-V1 and V3, the word baseline,
+    LN_LSTM, GRU, the legacy encoder head, project_hidden, dot + context layer + independent values."""
+    import json
+    from comic_amd import encoder_head
+    gold = json.load(open(os.path.join(golden_dir, 'ref_var_names.json')))['configs']
+    specs = {
+        'comic256_v1': cdec.DecoderSpec(C=832, Cg=1024, M=196),
+        'comic256_v3': cdec.DecoderSpec(),
+        'word_baseline': cdec.DecoderSpec(V=25599, H=1, fm_projection=None, token_type='word'),
+        'ln_lstm': cdec.DecoderSpec(rnn_name='LN_LSTM'),
+        'gru': cdec.DecoderSpec(rnn_name='GRU'),
+        'legacy_v1': cdec.DecoderSpec(C=832, Cg=1024, M=196),
+        'project_hidden': cdec.DecoderSpec(init_method='project_hidden'),
+        'dot_context_independent': cdec.DecoderSpec(method='dot', context_layer=True, fm_projection='independent'),
+    }
+    assert set(specs) == set(gold)
+    for name, spec in specs.items():
+        names, shapes = ckpt.decoder_var_names(spec), spec.param_shapes()
+        mine = {names[k]: list(shapes[k]) for k in names}
+        if name == 'legacy_v1':
+            mine.update({encoder_head.TF_NAMES['ln_beta']: [1024], encoder_head.TF_NAMES['ln_gamma']: [1024],
+                         encoder_head.TF_NAMES['W']: [1024, 1024]})
+        assert mine == gold[name], (name, sorted(set(mine) ^ set(gold[name])))
+    # a checkpoint of this package's earlier rounds (flat names) still restores
+    spec = cdec.DecoderSpec(D=64, E=32, C=64, Cg=64, M=4)
+    dec = cdec.init_params(spec, 0)
+    old = ckpt.decoder_var_names(spec, legacy_flat=True)
+    assert old['W_q'] == 'Model/decoder/rnn_decoder/multi_add_attention/query_layer/kernel'
+    arrays = {old[k]: v for k, v in dec.items()}
+    arrays.update({ckpt.ADAM_SCOPE + old['W_q'] + '/Adam': np.ones((64, 64), np.float32)})
+    np.savez(tmp_path / 'model-3.npz', global_step=np.asarray(3, np.int32), **arrays)
+    _, d2, extra = ckpt.restore(str(tmp_path / 'model-3.npz'), [], spec, resume_training=True)
+    assert d2 is not None and np.array_equal(d2['W_q'], dec['W_q'])
+    assert ckpt.ADAM_SCOPE + ckpt.decoder_var_names(spec)['W_q'] + '/Adam' in extra
+
+
 def test_schedules():
     assert np.isclose(optim.cosine_lr(0, 100, 1e-2, 1e-5), 1e-2)
     assert np.isclose(optim.cosine_lr(100, 100, 1e-2, 1e-5), 1e-5)
