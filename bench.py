@@ -742,6 +742,10 @@ def main():
     dec_Tp = int(rd['Tp'])
     dec_path = int(tr.decoder.lib.comic_decoder_train_path())
     loss = float(res['loss'])
+    voided = tr.decoder.voided_steps()          # steps the device voided (persistent-loop timeout): must be none
+    if world > 1:
+        voided = int(dp.max_scalar(voided))
+    assert voided == 0, 'the device voided %d training step(s) inside the run ("voided_steps": %d): no valid bench line' % (voided, voided)
     assert np.isfinite(loss), 'non-finite loss'
     top = heaviest_conv_launch(tr.encoder, plan) if rank == 0 else None
 
@@ -778,7 +782,7 @@ def main():
                                   'the same forward while it runs on a second stream under the decoder step of the '
                                   'previous batch%s (frozen CNN) at one conv workgroup per CU' %
                                   (' group: one forward per %d steps' % GROUP if GROUP > 1 else '')) if overlap else ''},
-            'final_loss': round(loss, 5),
+            'final_loss': round(loss, 5), 'voided_steps': voided,
         }
         # Second roofline entry: the decoder chain.  Algorithmic HBM bytes of one decoder step = every tensor of the step
         # moved once in each direction it is needed: parameters read in forward and backward, gradients written, Adam

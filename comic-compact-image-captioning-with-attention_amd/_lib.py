@@ -76,7 +76,7 @@ IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 laye
 def is_im2col_tile(tile):
     """Every layer is eligible for these ids (a failure is an error); the patch-resident ids may refuse a layer."""
     return tile <= IM2COL_CONV_TILES or 26 <= tile <= 47        # 48..53: patch-resident with loader waves
-PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb', 'cell_ln', 'K_c', 'b_c')
+PARAM_NAMES = ('W_init', 'K', 'b', 'W_m', 'W_v', 'W_q', 'v', 'ln_g', 'ln_b', 'tau', 'W_a', 'W_o', 'b_o', 'emb', 'cell_ln', 'K_c', 'b_c', 'status')
 
 
 class DecoderParams(C.Structure):
@@ -138,6 +138,9 @@ _SIGS = {
     'comic_gather_rows': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_gather_tree': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'comic_adam_tf': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    'comic_adam_tf_gated': (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, P, P]),
+    'comic_momentum_tf_gated': (c_int, [P, P, P, c_int64, c_float, c_float, c_float, c_float, P, P]),
+    'comic_debug_occupy_cus': (c_int, [c_int, c_int, P]),
     'comic_colsum': (c_int, [P, P, c_int, c_int, c_float, P]),
     'comic_ln_tanh_fwd': (c_int, [P, P, P, P, P, c_int, c_int, c_float, P]),
     'comic_ln_tanh_bwd_rows': (c_int, [P, P, P, P, P, c_int, c_int, P]),

@@ -952,7 +952,8 @@ __global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, c
 // ------------------------------------------------------------------ optimiser etc. ----
 __global__ void adam_tf_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps, float l2,
-                               float gscale) {
+                               float gscale, const float* __restrict__ skip) {
+  if (skip && skip[0] != 0.f) return;                     // a voided step (comic_decoder_params::status): no update at all
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float wi = w[i];
@@ -1019,7 +1020,8 @@ __global__ void ln_tanh_bwd_rows_kernel(const float* __restrict__ dy, const floa
 
 // tf.train.MomentumOptimizer (use_nesterov=False), ApplyMomentum [TF-1.9]: accum = momentum*accum + g; w -= lr*accum
 __global__ void momentum_tf_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ accum, long n,
-                                   float lr, float momentum, float l2, float gscale) {
+                                   float lr, float momentum, float l2, float gscale, const float* __restrict__ skip) {
+  if (skip && skip[0] != 0.f) return;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float wi = w[i];
@@ -1350,8 +1352,16 @@ extern "C" int comic_adam_tf(float* w, const float* g, float* m, float* v, int64
                              float beta2, float eps, float l2, float gscale, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
-                     (long)n, lr_t, beta1, beta2, eps, l2, gscale);
+                     (long)n, lr_t, beta1, beta2, eps, l2, gscale, (const float*)nullptr);
   COMIC_LAUNCH_CHECK("adam_tf");
+  return 0;
+}
+extern "C" int comic_adam_tf_gated(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                                   float beta2, float eps, float l2, float gscale, const float* skip_flag, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
+                     (long)n, lr_t, beta1, beta2, eps, l2, gscale, skip_flag);
+  COMIC_LAUNCH_CHECK("adam_tf_gated");
   return 0;
 }
 
@@ -1377,8 +1387,28 @@ extern "C" int comic_momentum_tf(float* w, const float* g, float* accum, int64_t
                                  float gscale, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(momentum_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, accum,
-                     (long)n, lr, momentum, l2, gscale);
+                     (long)n, lr, momentum, l2, gscale, (const float*)nullptr);
   COMIC_LAUNCH_CHECK("momentum_tf");
+  return 0;
+}
+extern "C" int comic_momentum_tf_gated(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
+                                       float gscale, const float* skip_flag, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(momentum_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, accum,
+                     (long)n, lr, momentum, l2, gscale, skip_flag);
+  COMIC_LAUNCH_CHECK("momentum_tf_gated");
+  return 0;
+}
+
+// test aid: workgroups that stay resident for a while (bounded)
+__global__ void occupy_kernel(long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int comic_debug_occupy_cus(int n_workgroups, int microseconds, void* stream) {
+  COMIC_REQUIRE(n_workgroups > 0 && n_workgroups <= 4096 && microseconds >= 0 && microseconds <= 2000000, "occupy: bad arguments");
+  hipLaunchKernelGGL(occupy_kernel, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, (long)microseconds * 100);
+  COMIC_LAUNCH_CHECK("occupy");
   return 0;
 }
 

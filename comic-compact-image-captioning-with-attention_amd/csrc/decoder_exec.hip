@@ -1434,7 +1434,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     add(dfm, (long)B * M * d->C); add(dim_embed, (long)B * d->Cg);
     if (g_inject_timeout.exchange(0) != 0)       // comic_debug_inject_persist_timeout: raise the error word by hand
       COMIC_REQUIRE(hipMemsetAsync(persist_sync, 0xFF, sizeof(unsigned), st) == hipSuccess, "train_step: memset");
-    RC(comic_persist_gate(persist_sync, loss_rows, map_loss, gr_, st));
+    RC(comic_persist_gate(persist_sync, loss_rows, map_loss, gr_, gr->status, p->status, st));
   }
   COMIC_LAUNCH_CHECK("train_step");
   return 0;

@@ -77,7 +77,9 @@ struct ComicGateRanges {
   float* p[16];
   long n[16];
 };
-int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, hipStream_t st);
+// step_flag (may be null): 1 / 0 = this step was voided / is healthy; sticky (may be null): += 1 per voided step.
+int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, float* step_flag,
+                       float* sticky, hipStream_t st);
 
 // ---- backward loop (decoder_persist_bwd.hip) ---------------------------------------------------------------------------
 struct ComicPersistBwdArgs {

@@ -728,8 +728,13 @@ __global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync, int n
 }
 
 __global__ __launch_bounds__(256) void persist_gate_kernel(const unsigned* err, float* loss_rows, float* map_loss,
-                                                           ComicGateRanges r) {
-  if (err[0] == 0u) return;                       // uniform over the launch: a healthy step ends here
+                                                           ComicGateRanges r, float* step_flag, float* sticky) {
+  const bool bad = err[0] != 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (step_flag) step_flag[0] = bad ? 1.f : 0.f;   // read by the gated optimiser entries (and summed by the all-reduce)
+    if (bad && sticky) sticky[0] += 1.f;             // voided steps so far: the host reads it at its log points
+  }
+  if (!bad) return;                               // uniform over the launch: a healthy step ends here
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     loss_rows[0] = __int_as_float(0x7fc00000);
     map_loss[0] = __int_as_float(0x7fc00000);
@@ -913,8 +918,9 @@ bool comic_persist_fits_device(int B) {
   return cus[dev] >= (groups < kMaxGroups ? groups : kMaxGroups) * kGroupWgs;
 }
 
-int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, hipStream_t st) {
-  hipLaunchKernelGGL(persist_gate_kernel, dim3(128), dim3(256), 0, st, sync, loss_rows, map_loss, r);
+int comic_persist_gate(const unsigned* sync, float* loss_rows, float* map_loss, const ComicGateRanges& r, float* step_flag,
+                       float* sticky, hipStream_t st) {
+  hipLaunchKernelGGL(persist_gate_kernel, dim3(128), dim3(256), 0, st, sync, loss_rows, map_loss, r, step_flag, sticky);
   COMIC_LAUNCH_CHECK("persistent decoder gate");
   return 0;
 }

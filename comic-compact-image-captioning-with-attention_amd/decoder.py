@@ -188,7 +188,7 @@ class FlatParams:
     """One flat fp32 device buffer with named views (+ identical layouts for grads/Adam slots)."""
     ALIGN = 64      # floats: keeps every view 256-byte aligned (16-byte vector loads in the GEMM)
 
-    def __init__(self, shapes: dict, device='cuda:0'):
+    def __init__(self, shapes: dict, device='cuda:0', status_tail=False):
         import torch
         self.torch = torch
         self.shapes = dict(shapes)
@@ -200,13 +200,27 @@ class FlatParams:
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
         self.device = device
-        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        # status_tail: one aligned block behind the variables whose first float is the buffer's status word
+        # (comic_decoder_params::status: voided-step flag of a gradient buffer, sticky count of a parameter buffer)
+        self.tail = self.ALIGN if status_tail else 0
+        self.data = torch.zeros(off + self.tail, dtype=torch.float32, device=device)
 
     def like(self):
         o = FlatParams.__new__(FlatParams)
         o.torch, o.shapes, o.offsets, o.numel, o.device = self.torch, self.shapes, self.offsets, self.numel, self.device
-        o.data = self.torch.zeros(self.numel, dtype=self.torch.float32, device=self.device)
+        o.tail = self.tail
+        o.data = self.torch.zeros(self.numel + self.tail, dtype=self.torch.float32, device=self.device)
         return o
+
+    @property
+    def status(self):
+        """The status word (a 1-element view) or None."""
+        return self.data[self.numel:self.numel + 1] if self.tail else None
+
+    @property
+    def flat(self):
+        """The variables without the status tail (what checkpoints hold)."""
+        return self.data[:self.numel]
 
     def view(self, k):
         shp = self.shapes[k]
@@ -227,6 +241,7 @@ class FlatParams:
         base = self.data.data_ptr()
         for k in L.PARAM_NAMES:
             setattr(t, k, base + 4 * self.offsets[k] if k in self.offsets else None)
+        t.status = base + 4 * self.numel if self.tail else None
         if 'cln_ig' in self.offsets:          # LN_LSTM: the ten vectors are consecutive views, ALIGN-padded (= the C stride)
             t.cell_ln = base + 4 * self.offsets['cln_ig']
         return t
@@ -260,7 +275,7 @@ class Decoder:
         self.torch = torch
         self.lib = L.load()
         self.spec, self.device = spec, device
-        self.params = FlatParams(spec.param_shapes(), device)
+        self.params = FlatParams(spec.param_shapes(), device, status_tail=True)
         self.params.load(params if params is not None else init_params(spec, seed))
         self.grads = self.params.like()
         self._ws = None
@@ -357,6 +372,11 @@ class Decoder:
         ctx.ws = torch.empty(int(ctx.nbytes), dtype=torch.uint8, device=dev)
         self._ctx[key] = ctx
         return ctx
+
+    def voided_steps(self):
+        """Training steps the device voided so far (a bounded wait of a persistent loop expired: NaN loss, no update;
+        comic_decoder_params::status of the parameter table).  Synchronises: for log points, not for every step."""
+        return int(float(self.params.status))
 
     def set_dropout_stream(self, seed, rank=0):
         """Base of the per-step dropout seeds: a function of the run's seed (tf.set_random_seed(rand_seed), train_fn.py:35)

@@ -208,8 +208,8 @@ class ModelBase(object):
             o = self._share['opt']
             o.t = int(extra.get('global_step', 0))
             if 'optimise/caption/adam_m' in extra:
-                o.m.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_m']))
-                o.v.data.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v']))
+                o.m.flat.copy_(self.torch.from_numpy(extra['optimise/caption/adam_m'])[:o.m.numel])
+                o.v.flat.copy_(self.torch.from_numpy(extra['optimise/caption/adam_v'])[:o.v.numel])
             else:
                 slots = ckpt.adam_from_tf(self.spec, extra)        # TF bundle: per-variable Adam / Adam_1
                 accum = ckpt.momentum_from_tf(self.spec, extra)    # ... or MomentumOptimizer's single `Momentum` slot
@@ -253,6 +253,10 @@ class ModelBase(object):
             self.update_lr(lr)
         return self.lr
 
+    def voided_steps(self):
+        """Training steps the device voided so far (Decoder.voided_steps; synchronises)."""
+        return self.decoder.voided_steps()
+
     def sync_parameters(self):
         """Data parallel: broadcast every variable and optimiser slot from rank 0 (parameters initialised or restored
         per rank would otherwise differ wherever a checkpoint does not cover them, and the replicas would never agree).
@@ -291,8 +295,8 @@ class ModelBase(object):
             elif fmt == 'tf':
                 extra = ckpt.adam_to_tf(self.spec, o.m.to_numpy(), o.v.to_numpy(), o.t, o.beta1, o.beta2)
             else:
-                extra = {'optimise/caption/adam_m': o.m.data.cpu().numpy(),
-                         'optimise/caption/adam_v': o.v.data.cpu().numpy()}
+                extra = {'optimise/caption/adam_m': o.m.flat.cpu().numpy(),
+                         'optimise/caption/adam_v': o.v.flat.cpu().numpy()}
         if self.head is not None:
             extra.update(self.head.export_params())
             if not compact and 'opt_head' in self._share:

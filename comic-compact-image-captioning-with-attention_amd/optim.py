@@ -40,9 +40,15 @@ class AdamTF:
     def step(self, grads, lr, grad_scale=1.0):
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
-        L.check(self.lib.comic_adam_tf(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
-                                       self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
-                                       self.eps, self.l2, grad_scale, L.stream_ptr()), 'adam_tf')
+        # a gradient buffer with a status word (decoder.FlatParams(status_tail=True)): the update is skipped on the device
+        # when comic_decoder_train_step voided the step (on any rank: the word is part of the all-reduced buffer).  The
+        # host-side step count `t` advances regardless -- one bias-correction step of drift per voided step, and the run
+        # stops at the next log point anyway (train_fn._check_loss reads the sticky count).
+        st = getattr(grads, 'status', None)
+        L.check(self.lib.comic_adam_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
+                                             self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
+                                             self.eps, self.l2, grad_scale, st.data_ptr() if st is not None else None,
+                                             L.stream_ptr()), 'adam_tf')
 
     def state_dict(self):
         return dict(t=self.t, m=self.m.data.clone(), v=self.v.data.clone())
@@ -69,9 +75,10 @@ class MomentumTF:
 
     def step(self, grads, lr, grad_scale=1.0):
         self.t += 1
-        L.check(self.lib.comic_momentum_tf(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
-                                           self.params.numel, lr, self.momentum, self.l2, grad_scale, L.stream_ptr()),
-                'momentum_tf')
+        st = getattr(grads, 'status', None)
+        L.check(self.lib.comic_momentum_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
+                                                 self.params.numel, lr, self.momentum, self.l2, grad_scale,
+                                                 st.data_ptr() if st is not None else None, L.stream_ptr()), 'momentum_tf')
 
     state_dict = AdamTF.state_dict
     load_state_dict = AdamTF.load_state_dict

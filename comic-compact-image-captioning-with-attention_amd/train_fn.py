@@ -75,11 +75,12 @@ def _train_loop(inputs_man, device, dp):
         ppl = m_train.run_train_step()
         global_step = m_train.global_step
         if (step + 1) % (n_steps_log * 5) == 0:
+            _check_loss(ppl, global_step, m_train, dp)
             t = time.time() - start_epoch
             speed = (step + 1 - start_step) * c.batch_size_train / t
             print('   Training speed: {:7.2f} examples/sec.'.format(speed))
         elif (step + 1) % n_steps_log == 0:
-            _check_loss(ppl, global_step)
+            _check_loss(ppl, global_step, m_train, dp)
             logstr = 'Epoch {:2d} ~~ {:6.2f} %  ~  '.format(epoch, ((step % num_batches) + 1) / num_batches * 100)
             logstr += 'Perplexity {:8.4f} ~ LR {:5.3e} ~ '.format(float(np.exp(float(ppl))), m_train.lr)
             logstr += 'Step {}'.format(global_step)
@@ -177,7 +178,7 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
             logstr += '\n   top beam: \t\t`{}`\n'.format(hypos[0][0])
             print(logstr)
         elif (step + 1) % n_steps_log == 0:
-            _check_loss(ppl, global_step)
+            _check_loss(ppl, global_step, m_train, dp)
             logstr = '   Epoch {:2d} ~~ {:6.2f} %  ~  '.format(epoch, ((step % num_batches) + 1) / num_batches * 100)
             logstr += 'Greedy score {:8.4f} ~ Loss {:8.4f} ~ LR {:5.3e} ~ Step {}'.format(
                 np.mean(sc_greedy), float(ppl), m_train.lr, global_step)
@@ -208,15 +209,25 @@ def _lr_reduce_check(config, epoch, learning_rate):
     return learning_rate
 
 
-def _check_loss(loss, step):
-    """Log points are where the host looks at the loss (one device sync per `num_logs_per_epoch`-th of an epoch): a NaN
-    there is either a diverged run or a step the device voided -- comic_decoder_train_step turns its losses into NaN
-    and its gradients into zeros when a bounded wait of a persistent time loop expired (include/comic_hip.h), so nothing
-    was trained on garbage.  Either way the run stops here; try_to_train writes the error file."""
+def _check_loss(loss, step, model=None, dp=None):
+    """Log points are where the host looks at the device (one sync per `num_logs_per_epoch`-th of an epoch).  Two things
+    stop the run here: a non-finite loss of THIS step, and a non-zero count of steps the device voided since the start --
+    comic_decoder_train_step turns a step's losses into NaN, raises the gradient buffer's status word (the gated optimiser
+    then skips the update on the device) and counts it in the parameter buffer's sticky word when a bounded wait of a
+    persistent time loop expired (include/comic_hip.h), so a voided step BETWEEN two log points is seen too.  Under data
+    parallelism the count is max-reduced, so every rank raises at the same log point instead of leaving the others in
+    the next collective.  try_to_train writes the error file."""
     v = float(loss)
+    voided = int(model.voided_steps()) if model is not None and hasattr(model, 'voided_steps') else 0
+    if dp is not None and getattr(dp, 'world', 1) > 1:
+        voided = int(dp.max_scalar(voided))
+        any_bad = dp.max_scalar(0 if np.isfinite(v) else 1)       # (every rank takes part, whatever its own loss)
+        v = float('nan') if any_bad else v
+    if voided:
+        raise RuntimeError('step {}: the device voided {} training step(s) -- a persistent decoder loop timed out (retry with '
+                           'COMIC_PERSIST=0 to run the per-step kernels)'.format(step, voided))
     if not np.isfinite(v):
-        raise RuntimeError('step {}: the training loss is {} -- diverged, or a persistent decoder loop timed out and the '
-                           'device voided the step (retry with COMIC_PERSIST=0 to run the per-step kernels)'.format(step, v))
+        raise RuntimeError('step {}: the training loss is {} (on this or another rank) -- the run diverged'.format(step, v))
 
 
 def _run_eval_loop(c, m, global_step):

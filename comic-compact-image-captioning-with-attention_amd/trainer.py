@@ -46,6 +46,16 @@ class DataParallel:
         return t / self.world + 1e-12
 
     # ---- bucketed gradient exchange: buckets are reduced on a side stream while the backward pass goes on ----------
+    def max_scalar(self, value):
+        """max over the ranks of a host number (a collective: every rank calls it at the same point)."""
+        if self.world == 1:
+            return value
+        import torch
+        dev = 'cpu' if self.dist.get_backend() == 'gloo' else 'cuda'
+        x = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
+        return float(x.item())
+
     def reduce_async(self, flat_slice):
         """Start the sum all-reduce of `flat_slice` (a contiguous view of a flat gradient buffer whose producers have
         been enqueued on the current stream).  CUDA tensors: the collective is issued from a communication stream

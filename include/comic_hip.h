@@ -395,6 +395,16 @@ int comic_ln_tanh_bwd_rows(const float* dy, const float* y, const float* xhat, f
  * g_eff = g*gscale + l2*w; accum = momentum*accum + g_eff; w -= lr*accum. */
 int comic_momentum_tf(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
                       float gscale, void* stream);
+/* The same updates, skipped ON THE DEVICE (w, m, v / accum untouched) when skip_flag[0] != 0: the optimiser step behind a
+ * training step that comic_decoder_train_step voided (comic_decoder_params::status of the gradient table).  NULL = never
+ * skip. */
+int comic_adam_tf_gated(float* w, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                        float epsilon, float l2, float gscale, const float* skip_flag, void* stream);
+int comic_momentum_tf_gated(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
+                            float gscale, const float* skip_flag, void* stream);
+/* Test aid: n_workgroups workgroups (256 threads) that stay resident for about `microseconds` each (bounded spin on the
+ * 100 MHz clock) -- what a collective's kernels do to some CUs while a training step runs beside them. */
+int comic_debug_occupy_cus(int n_workgroups, int microseconds, void* stream);
 /* out[j] = sum_i in[i*cols + j]  (deterministic column sums; parameter-partial reduce) */
 int comic_colsum(const float* in, float* out, int rows, int cols, float beta, void* stream);
 int comic_axpy(float* y, const float* x, float a, int64_t n, void* stream);
@@ -442,6 +452,11 @@ typedef struct comic_decoder_params {
   float* cell_ln;   /* LN_LSTM: ten [D] vectors gamma, beta of the scopes input, transform, forget, output, state, in that
                        order, (D + 63) / 64 * 64 floats apart; NULL otherwise */
   float *K_c, *b_c; /* GRU: candidate kernel and bias; NULL otherwise */
+  float* status;    /* optional (may be NULL), one float behind the flat buffer.  In the GRADIENT table: comic_decoder_train_step
+                       writes 1 when it voided the step (a bounded wait of a persistent loop expired), else 0 -- the word the
+                       gated optimiser entries read; it lies inside the all-reduced buffer, so under data parallelism every
+                       rank sees a non-zero sum and skips the same update.  In the PARAMETER table: a sticky count of voided
+                       steps (incremented, never cleared by the library) for the host to read at its log points. */
 } comic_decoder_params;
 
 /* Workspace size in bytes for a training step at (B, T, M) / a decode at rows=B*W. */

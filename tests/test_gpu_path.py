@@ -7,6 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import comic_amd._lib as L
 from comic_amd import decoder as cdec, nets
 from oracle import beam_ref, cnn_ref, decoder_ref as dr
 from tests.gpu_util import DEV, F32_RTOL, assert_close, dev, rel_err, sync
@@ -601,11 +602,53 @@ def test_persistent_loop_timeout_voids_the_step():
     bad = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
     sync()
     assert np.isnan(float(bad['loss'])) and np.isnan(float(bad['map_loss']))
-    assert float(dec.grads.data.abs().max()) == 0.0
+    assert float(dec.grads.flat.abs().max()) == 0.0
     assert float(bad['dfm'].abs().max()) == 0.0 and float(bad['dim_embed'].abs().max()) == 0.0
+    # the voided step is LOUD and a no-op: the gradient buffer's status word says "voided", the parameter
+    # buffer's sticky count went up, and the gated optimiser leaves parameters AND its moments untouched
+    assert float(dec.grads.status) == 1.0 and dec.voided_steps() == 1
+    from comic_amd import optim
+    for opt in (optim.AdamTF(dec.params), optim.MomentumTF(dec.params)):
+        opt.m.data.fill_(0.25); opt.v.data.fill_(0.5)
+        before = (dec.params.data.clone(), opt.m.data.clone(), opt.v.data.clone())
+        opt.step(dec.grads, 1e-2)
+        sync()
+        assert torch.equal(dec.params.data, before[0]) and torch.equal(opt.m.data, before[1]) and torch.equal(opt.v.data, before[2])
     again = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)   # one shot
     sync()
-    assert float(again['loss']) == want[0] and torch.equal(dec.grads.data, want[1]) and torch.equal(again['dfm'], want[2])
+    assert float(again['loss']) == want[0] and torch.equal(dec.grads.flat, want[1][:dec.grads.numel]) and torch.equal(again['dfm'], want[2])
+    assert float(dec.grads.status) == 0.0 and dec.voided_steps() == 1      # healthy again; the count stays
+    opt = optim.AdamTF(dec.params)
+    before = dec.params.data.clone()
+    opt.step(dec.grads, 1e-2)
+    sync()
+    assert not torch.equal(dec.params.flat, before[:dec.params.numel])   # ... and a healthy step's update is applied
+
+
+def test_persistent_loops_beside_resident_kernels_of_another_stream():
+    """What a collective's kernels do to a training step (VERDICT r3, N > 1 risk): workgroups of ANOTHER stream stay
+    resident on some CUs (comic_debug_occupy_cus: 24 workgroups for ~3 ms, about what RCCL's channels hold) while the
+    persistent loops -- which need a workgroup on every CU -- are launched.  The loops must wait for those CUs and then
+    complete: same bits as the undisturbed step, no voided step (a bounded wait of 2^20 polls is seconds, not
+    milliseconds)."""
+    spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
+    B, Lc = 64, 14
+    dec = cdec.Decoder(spec, _rand_params(cfg, 8), DEV)
+    fm, im, caps = _batch(spec, B, Lc, 47)
+    _, _, _, lens = dr.process_inputs(caps, cfg.token_type)
+    masks = dr.make_dropout_masks(cfg, B, int(lens.max()), spec.M, 47)
+    quiet = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True)
+    sync()
+    assert dec.lib.comic_decoder_train_path() == 3
+    want = (float(quiet['loss']), dec.grads.flat.clone())
+    side = torch.cuda.Stream()
+    for n_wg, usec in ((24, 3000), (256, 1500), (512, 500)):
+        with torch.cuda.stream(side):
+            L.check(dec.lib.comic_debug_occupy_cus(n_wg, usec, side.cuda_stream))
+        res = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True)
+        sync()
+        assert float(res['loss']) == want[0] and torch.equal(dec.grads.flat, want[1]), (n_wg, usec)
+        assert float(dec.grads.status) == 0.0 and dec.voided_steps() == 0, (n_wg, usec)
 
 
 @pytest.mark.parametrize('kw,B,Lc', [

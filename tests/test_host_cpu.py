@@ -65,7 +65,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.CnnOp) == 26 * 4                    # ... flags, min_lds
     assert C.sizeof(L.AttnDesc) == 8 * 4
     assert C.sizeof(L.DecoderDesc) == 16 * 4 + 4 * 4 + 4 + 4 + 4  # ... map_loss_scale, flags, length_penalty_weight, cell
-    assert C.sizeof(L.DecoderParams) == 17 * 8               # ... emb, cell_ln, K_c, b_c
+    assert C.sizeof(L.DecoderParams) == 18 * 8               # ... emb, cell_ln, K_c, b_c, status
     assert C.sizeof(L.ConvWeight) == 4 * 8                # w, scale, shift, w_frag
 
 
