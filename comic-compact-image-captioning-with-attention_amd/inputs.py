@@ -134,8 +134,10 @@ class DecodePool(object):
     pixels in place; the consumer registers each block once as pinned host memory (cudaHostRegister) and copies from
     it directly.  Blocks return to the free list when the event behind their copy has completed."""
 
-    def __init__(self, processes, blocks=6, block_bytes=None, slot_bytes=640 * 640 * 3, max_batch=64):
+    def __init__(self, processes, blocks=6, block_bytes=None, slot_bytes=640 * 640 * 3, max_batch=64, timeout_s=120.0):
         import multiprocessing as mp
+        self.timeout_s = float(timeout_s)                     # config.loader_timeout_s: bound of the wait for one batch
+        self._retired = []                                    # blocks surviving workers may still write into
         self.slot_bytes = int(slot_bytes)                     # MS-COCO images are at most 640 x 640
         block_bytes = int(block_bytes or self.slot_bytes * max_batch)
         from multiprocessing import shared_memory
@@ -177,16 +179,23 @@ class DecodePool(object):
                                                    for i, p in enumerate(paths)])
         return blk, n * self.slot_bytes, res
 
-    def geometry(self, paths, res, blk=None, timeout=120.0):
+    def geometry(self, paths, res, blk=None, timeout=None):
         """Waits for the workers of one batch.  multiprocessing.Pool silently replaces a worker that dies (out of
         memory, a crash inside libjpeg on a corrupt file) and the task it held never completes: the wait is bounded,
-        the staging block goes back to the free list and the batch fails with the file names instead of hanging."""
+        the batch fails with the file names instead of hanging, and its staging block is RETIRED, not returned to the
+        free list -- workers of that batch that are still alive may yet write pixels into it, which must not land in
+        the next batch's images (a fresh block takes its place, so the pool keeps its depth)."""
         import multiprocessing as mp
+        timeout = self.timeout_s if timeout is None else timeout
         try:
             sizes = res.get(timeout=timeout)
         except mp.TimeoutError:
             if blk is not None:
-                self.release(blk)
+                from multiprocessing import shared_memory
+                self._retired.append(blk)
+                fresh = shared_memory.SharedMemory(create=True, size=self.block_bytes)
+                self._blocks.append(fresh)
+                self._free.put(fresh)
             raise RuntimeError('JPEG decode workers did not return within %.0f s (a worker process died?) for: %s'
                                % (timeout, ', '.join(str(p) for p in paths[:4]) + (' ...' if len(paths) > 4 else '')))
         out = []
@@ -332,9 +341,11 @@ class DevicePreprocessor(object):
         dbytes = n * C.sizeof(L.ImageDesc)
         slot = packed.slot
         if isinstance(slot, tuple):
+            # waits: the workers have written every image of this batch (on a timeout the pool retires the block itself;
+            # any other failure -- an oversized image -- leaves no writer behind: the block goes back)
             try:
-                geo = slot[1].geometry(slot[4], slot[3])      # waits: the workers have written every image of this batch
-            except Exception:
+                geo = slot[1].geometry(slot[4], slot[3], slot[2])
+            except ValueError:
                 slot[1].release(slot[2])
                 raise
             packed.desc = self._fill_desc(geo, slot[5])
@@ -540,7 +551,8 @@ class InputManager(object):
             self._decode_pool = DecodePool(nproc, blocks=self._prefetch_depth + 2,
                                            slot_bytes=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)),
                                            max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
-                                                         getattr(c, 'batch_size_infer', 1)))
+                                                         getattr(c, 'batch_size_infer', 1)),
+                                           timeout_s=float(getattr(c, 'loader_timeout_s', 120.0)))
 
     def _finish_batch(self, item):
         """Consumer-thread half of a batch: packed images -> device tensor (see DevicePreprocessor)."""

@@ -250,12 +250,37 @@ def _dp_barrier():
         pass
 
 
+def _dp_any_failed(failed_here):
+    """True on every rank when any rank reports a failure (a collective; a no-op without torch.distributed)."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return bool(failed_here)
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(failed_here)
+    dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
+    x = torch.tensor([1.0 if failed_here else 0.0], device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    return bool(x.item() > 0)
+
+
 def try_to_train(train_fn, try_block=True, overwrite=False, **kargs):
     """Wrapper for the main training function."""
     config = conf.Config(**kargs)
-    if int(kargs.get('dp_rank', 0) or 0) == 0:         # data parallel: rank 0 alone checks / creates the run directory
-        config.overwrite_safety_check(overwrite)
-    _dp_barrier()
+    # data parallel: rank 0 alone checks / creates the run directory, and every rank learns its verdict -- a rank 0 that
+    # left here on its own (SystemExit has exit code 0: torchrun does not tear the job down) would leave the others in
+    # the barrier until the collective times out
+    verdict = None
+    if int(kargs.get('dp_rank', 0) or 0) == 0:
+        try:
+            config.overwrite_safety_check(overwrite)
+        except BaseException as e:                     # incl. SystemExit
+            verdict = e
+    if _dp_any_failed(verdict is not None):
+        if verdict is not None:
+            raise verdict
+        raise SystemExit('rank 0 refused the run directory %s' % config.log_path)
     if config.resume_training:
         print('INFO: Resuming training from checkpoint.')
         config = conf.load_config(pjoin(config.log_path, 'config.pkl'))
@@ -290,3 +315,9 @@ def try_to_train(train_fn, try_block=True, overwrite=False, **kargs):
             f.write(err_msg)
         print('\nWARNING: An error has occurred.\n')
         print(err_msg)
+        if int(getattr(config, 'dp_world', 1) or 1) > 1:
+            # a rank-local failure under data parallelism: the other ranks sit in (or are about to enter) a collective.
+            # Leaving with a non-zero exit code makes the launcher end the whole job instead of letting them wait for
+            # the collective's timeout.
+            sys.stdout.flush()
+            os._exit(1)
