@@ -882,17 +882,19 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ cross-entropy -----
-__global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ targets_bt,
-                                                   const float* __restrict__ coef_bt,
-                                                   const float* __restrict__ wmask_bt,
-                                                   const int32_t* __restrict__ lens, float* __restrict__ loss_rows,
-                                                   float* __restrict__ dlogits, int32_t* __restrict__ ids_tb, int T,
-                                                   int B, int V) {  // T = stride of the [B,T] tables
-  __shared__ float smax[256];
-  __shared__ int sidx[256];
-  const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+// one row of the sequence loss: softmax cross-entropy of logits[row], d logits (row stride ld_dl >= V, the padding
+// columns are written as zeros), arg-max id; `smax` / `sidx`: 256-entry LDS scratch of the calling workgroup
+__device__ __forceinline__ void xent_row(int row, float* __restrict__ logits, const int32_t* __restrict__ targets_bt,
+                                         const float* __restrict__ coef_bt, const float* __restrict__ wmask_bt,
+                                         const int32_t* __restrict__ lens, float* __restrict__ loss_rows,
+                                         float* __restrict__ dlogits, int32_t* __restrict__ ids_tb, int T, int B, int V,
+                                         int ld_dl, float* smax, int* sidx) {
+  const int t = row / B, b = row % B, tid = threadIdx.x;
   float* lg = logits + (size_t)row * V;
-  float* dl = dlogits ? dlogits + (size_t)row * V : nullptr;
+  float* dl = dlogits ? dlogits + (size_t)row * ld_dl : nullptr;
+  if (dl)
+    for (int v = V + tid; v < ld_dl; v += 256) dl[v] = 0.f;
+  // T = stride of the [B,T] tables
   if (lens && t >= lens[b]) {  // impute_finished: zero outputs
     for (int v = tid; v < V; v += 256) {
       lg[v] = 0.f;
@@ -947,6 +949,82 @@ __global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, c
     if (loss_rows) loss_rows[row] = (logf(sum) - (lg[tgt] - mx)) * (wmask_bt ? wmask_bt[(size_t)b * T + t] : 1.f);
     if (ids_tb) ids_tb[row] = amax;
   }
+}
+
+__global__ __launch_bounds__(256) void xent_kernel(float* __restrict__ logits, const int32_t* __restrict__ targets_bt,
+                                                   const float* __restrict__ coef_bt,
+                                                   const float* __restrict__ wmask_bt,
+                                                   const int32_t* __restrict__ lens, float* __restrict__ loss_rows,
+                                                   float* __restrict__ dlogits, int32_t* __restrict__ ids_tb, int T,
+                                                   int B, int V, int ld_dl) {  // T = stride of the [B,T] tables
+  __shared__ float smax[256];
+  __shared__ int sidx[256];
+  xent_row(blockIdx.x, logits, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, T, B, V, ld_dl, smax, sidx);
+}
+
+// The sequence loss AND the attention-map loss (model_base.py:349-360: mean((1 - sum_h alpha)^2) * scale, with its
+// gradient) in one launch: workgroups [0, rows) take one logits row each, the next `nparts` one 256-element piece of the
+// map each; the piece sums are combined in piece order by whichever map workgroup arrives last (sc1 stores / loads and an
+// agent-scope ticket: the hand-off form of gemm_group.hip), so map_loss has the bits of the two-launch form.
+struct MapLossArgs {
+  const float* hist;   // [Tp][B][H][M] attention probabilities
+  float* dmap;         // [Tp][B][M] or null
+  float* partial;      // [nparts] scratch
+  float* map_loss;     // [1]
+  unsigned* ticket;    // zero before the launch, zero after it
+  int Tp, B, H, M, nparts;
+  float scale;
+};
+__global__ __launch_bounds__(256) void xent_maploss_kernel(float* __restrict__ logits, const int32_t* __restrict__ targets_bt,
+                                                           const float* __restrict__ coef_bt, const float* __restrict__ wmask_bt,
+                                                           const int32_t* __restrict__ lens, float* __restrict__ loss_rows,
+                                                           float* __restrict__ dlogits, int32_t* __restrict__ ids_tb, int T,
+                                                           int B, int V, int ld_dl, int rows, MapLossArgs ma) {
+  __shared__ float smax[256];
+  __shared__ int sidx[256];
+  if ((int)blockIdx.x < rows) {
+    xent_row(blockIdx.x, logits, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, T, B, V, ld_dl, smax, sidx);
+    return;
+  }
+  const int piece = blockIdx.x - rows, tid = threadIdx.x;
+  const long n = (long)ma.Tp * ma.B * ma.M;
+  const long i = (long)piece * 256 + tid;
+  float acc = 0.f;
+  if (i < n) {
+    const int m = (int)(i % ma.M);
+    const long tb = i / ma.M;
+    const float* p = ma.hist + (size_t)tb * ma.H * ma.M + m;
+    float f = 0.f;
+    for (int h = 0; h < ma.H; ++h) f += p[(size_t)h * ma.M];
+    const float d = 1.0f - f;
+    acc = d * d;
+    if (ma.dmap) ma.dmap[i] = 2.0f * (f - 1.0f) / (float)n * ma.scale;
+  }
+  smax[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) smax[tid] += smax[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    __hip_atomic_store(ma.partial + piece, smax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ma.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sidx[0] = (t == (unsigned)(ma.nparts - 1)) ? 1 : 0;
+    if (sidx[0]) __hip_atomic_store(ma.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!sidx[0]) return;
+  __syncthreads();
+  float tot = 0.f;
+  for (int k = tid; k < ma.nparts; k += 256) tot += __hip_atomic_load(ma.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  smax[tid] = tot;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) smax[tid] += smax[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) ma.map_loss[0] = smax[0] / (float)n * ma.scale;
 }
 
 // ------------------------------------------------------------------ optimiser etc. ----
@@ -1336,8 +1414,21 @@ int comic_xent_ex(float* logits, const int32_t* targets_bt, const float* coef_bt
   COMIC_REQUIRE(logits && targets_bt, "xent: null pointer");
   COMIC_REQUIRE(t_rows > 0 && t_rows <= t_stride, "xent: bad time extent");
   hipLaunchKernelGGL(xent_kernel, dim3(t_rows * B), dim3(256), 0, st, logits, targets_bt, coef_bt, wmask_bt, lens,
-                     loss_rows, dlogits, ids_tb, t_stride, B, V);
+                     loss_rows, dlogits, ids_tb, t_stride, B, V, V);
   COMIC_LAUNCH_CHECK("xent");
+  return 0;
+}
+// sequence loss (d logits with row stride ld_dl) + map loss in one launch; `partial`: >= ceil(Tp*B*M / 256) floats
+int comic_xent_maploss(float* logits, const int32_t* targets_bt, const float* coef_bt, const float* wmask_bt,
+                       const int32_t* lens, float* loss_rows, float* dlogits, int ld_dl, int32_t* ids_tb, int t_rows,
+                       int t_stride, int B, int V, const float* hist, float* dmap, float* partial, float* map_loss,
+                       unsigned* ticket, int H, int M, float scale, hipStream_t st) {
+  COMIC_REQUIRE(logits && targets_bt && hist && partial && map_loss && ticket, "xent_maploss: null pointer");
+  COMIC_REQUIRE(t_rows > 0 && t_rows <= t_stride && ld_dl >= V, "xent_maploss: bad extents");
+  MapLossArgs ma{hist, dmap, partial, map_loss, ticket, t_rows, B, H, M, (int)cdiv64((long)t_rows * B * M, 256), scale};
+  hipLaunchKernelGGL(xent_maploss_kernel, dim3(t_rows * B + ma.nparts), dim3(256), 0, st, logits, targets_bt, coef_bt,
+                     wmask_bt, lens, loss_rows, dlogits, ids_tb, t_stride, B, V, ld_dl, t_rows * B, ma);
+  COMIC_LAUNCH_CHECK("xent_maploss");
   return 0;
 }
 

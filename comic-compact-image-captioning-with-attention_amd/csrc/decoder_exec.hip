@@ -56,6 +56,10 @@ int comic_lstm_gates_fwd_ex(const float* g, const float* c_prev, const float* h_
                             float* c_state, float* h_state, int B, int D, float* xh_next, int xh_ld, int S,
                             const float* bias, hipStream_t st);
 
+int comic_xent_maploss(float* logits, const int32_t* targets_bt, const float* coef_bt, const float* wmask_bt,
+                       const int32_t* lens, float* loss_rows, float* dlogits, int ld_dl, int32_t* ids_tb, int t_rows,
+                       int t_stride, int B, int V, const float* hist, float* dmap, float* partial, float* map_loss,
+                       unsigned* ticket, int H, int M, float scale, hipStream_t st);
 int comic_embed_bwd_set(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V, hipStream_t st);
 // gemm.hip
 int comic_gemm_bf16x3_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -613,7 +617,7 @@ struct GemmGroupRun {
       int nt = 0;
       const int wg = comic_gemm_group_plan(g, target, &need, &nt);
       if (wg < 0) return 2;
-      if (need <= slab_cap && nt <= kGroupTickets) {
+      if (need <= slab_cap && nt <= kGroupTickets - 8) {      // (the last words serve other launches' tickets)
         g.slab = (float*)slab;
         g.tickets = tickets;
         return comic_gemm_group_launch(g, wg, st);
@@ -839,7 +843,8 @@ extern "C" int64_t comic_decoder_train_workspace(const comic_decoder_desc* d, in
   w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>(TB * D);  // c_new, y, q
   w.take<float>(TB * H * M);                                       // alpha
   w.take<float>(TB * Cv); w.take<float>(B * D); w.take<float>((TB + B) * A);  // ctx, att_new, att
-  w.take<float>(TB * V);                                           // dlogits
+  w.take<float>(TB * ((V + 3) / 4 * 4));                           // dlogits (rows padded to a multiple of 4 columns)
+  w.take<float>(D * ((V + 3) / 4 * 4));                            // W_o with padded rows (grouped GEMM launches)
   w.take<float>(TB * D); w.take<float>(TB * D); w.take<float>((TB + B) * 4 * D);    // dy_all, dq_all, dg_all (+ the init step's rows)
   w.take<float>(B * Wd); w.take<float>(B * D); w.take<float>(B * D);          // dxh, dc, dh
   w.take<float>(B * A); w.take<float>(B * A); w.take<float>(B * Cv);          // datt, datt_live, dctx
@@ -909,7 +914,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   float* ctx_all = w.take<float>(TB * Cv);
   float* att_new = w.take<float>((long)B * D);
   float* att_all = w.take<float>((TB + B) * A);
-  float* dlogits = w.take<float>(TB * V);
+  const int Vp = (V + 3) / 4 * 4;                 // d logits / W_o rows padded to 16 bytes: every product loads them 16 bytes at a time
+  float* dlogits = w.take<float>(TB * Vp);
+  float* wo_pad = w.take<float>((long)D * Vp);
   float* dy_all = w.take<float>(TB * D);
   float* dq_all = w.take<float>(TB * D);
   float* dg_all = w.take<float>((TB + B) * 4 * D);
@@ -996,6 +1003,8 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // (products with a short reduction -- a handful of rows in all -- keep the separate launches, whose small shapes run the
   // exact-fp32 kernels: gemm_big's rule)
   const bool grp = group_gemm_enabled() && cell == COMIC_CELL_LSTM && (long)Tp * B >= 64 && (long)B * M >= 64 && B >= 16;
+  const int ldl = grp ? Vp : V;                                // row stride of d logits
+  const float* wo_g = (grp && Vp != V) ? wo_pad : p->W_o;      // W_o with rows of ldl floats
   float* xh_init = xh_all + (size_t)Tp * B * Wd;
   float* dg_init = dg_all + (size_t)Tp * B * 4 * D;
   void* const gg_slab = g_splitk_ws;                 // both lanes' split-K blocks: consecutive in the workspace
@@ -1006,6 +1015,11 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (!persist) COMIC_REQUIRE(hipMemsetAsync(gg_tickets, 0, sizeof(unsigned) * kGroupTickets, st) == hipSuccess, "train_step: memset");
     if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
     if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
+    if (Vp != V) {
+      const long n = (long)D * Vp;
+      hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->W_o, wo_pad, V, Vp, n);
+      COMIC_LAUNCH_CHECK("pad W_o");
+    }
     GemmGroupRun g1;
     g1.add(COMIC_GG_NN, fm, p->W_m, keys, B * M, D, d->C, d->C, D, D);
     if (d->fm_projection == 1) g1.add(COMIC_GG_NN, fm, p->W_v, values_buf, B * M, D, d->C, d->C, D, D);
@@ -1129,7 +1143,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // output projection for all executed steps, loss, d logits
   if (grp) {
     GemmGroupRun go;
-    go.add(COMIC_GG_NN, y_all, p->W_o, logits_tb, Tp * B, V, D, D, V, V)->bias = p->b_o;
+    go.add(COMIC_GG_NN, y_all, wo_g, logits_tb, Tp * B, V, D, D, ldl, V)->bias = p->b_o;
     RC(go.run(gg_slab, gg_slab_cap, gg_tickets, st));
   } else {
     RC(gemm_big(y_all, p->W_o, logits_tb, p->b_o, Tp * B, V, D, D, V, V, 0, 0, 0.f, st));
@@ -1139,7 +1153,15 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     COMIC_LAUNCH_CHECK("train_step (forward phase)");
     return 0;
   }
-  RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
+  if (grp) {       // sequence loss + attention-map loss: one launch (d logits rows are ldl floats apart)
+    const int nparts = (int)cdiv64((long)Tp * B * M, 256);
+    COMIC_REQUIRE(nparts <= B * Wd, "train_step: map-loss scratch too small");
+    RC(comic_xent_maploss(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ldl, ids_tb, Tp, T, B, V, attn_hist,
+                          dmap, dxh /* free until the backward loop */, map_loss, gg_tickets + kGroupTickets - 1, H, M,
+                          d->map_loss_scale, st));
+  } else {
+    RC(comic_xent_ex(logits_tb, targets_bt, coef_bt, wmask_bt, lens, loss_rows, dlogits, ids_tb, Tp, T, B, V, st));
+  }
   for (int t = Tp; t < T; ++t) {  // ops_rnn.py:235-241: pad by copying the last executed step
     (void)hipMemcpyAsync(logits_tb + (size_t)t * B * V, logits_tb + (size_t)(Tp - 1) * B * V, sizeof(float) * B * V,
                          hipMemcpyDeviceToDevice, st);
@@ -1147,7 +1169,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
                          hipMemcpyDeviceToDevice, st);
     RC(fill(loss_rows + (size_t)t * B, 0.f, B, st));
   }
-  {
+  if (!grp) {
     const long n = (long)Tp * B * M;
     const int nparts = (int)cdiv64(n, 256);
     float* partial = dxh;  // free until the backward loop; needs nparts floats
@@ -1171,7 +1193,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // dy_all = dlogits * W_o^T (d W_o, d b_o: after the loop, on the gradient lanes)
   if (grp) {
     GemmGroupRun gy;
-    gy.add(COMIC_GG_NT, dlogits, p->W_o, dy_all, Tp * B, D, V, V, V, D);
+    gy.add(COMIC_GG_NT, dlogits, wo_g, dy_all, Tp * B, D, ldl, ldl, ldl, D);     // (K = padded columns: zeros on both sides)
     RC(gy.run(gg_slab, gg_slab_cap, gg_tickets, st));
   } else {
     RC(gemm_big(dlogits, p->W_o, dy_all, nullptr, Tp * B, D, V, V, V, D, 0, 1, 0.f, st));
@@ -1295,10 +1317,10 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       if (drop_in) { q->mask = mask_in; q->ld_mask = EA; q->keep = d->keep_in; }
     }
     g1.add(COMIC_GG_TN, y_all, dq_all, gr->W_q, D, D, Tp * B, D, D, D);
-    g1.add(COMIC_GG_TN, y_all, dlogits, gr->W_o, D, V, Tp * B, D, V, V);
+    g1.add(COMIC_GG_TN, y_all, dlogits, gr->W_o, D, V, Tp * B, D, ldl, V);
     if (dfm) g1.add(COMIC_GG_NT, dkeys, p->W_m, dfm, B * M, d->C, D, D, D, d->C);
     g1.add_colsum(dg_all, gr->b, 4 * D, rows_k, 4 * D);
-    g1.add_colsum(dlogits, gr->b_o, V, Tp * B, V);
+    g1.add_colsum(dlogits, gr->b_o, V, Tp * B, ldl);
     if (d->method == 0) {      // pgrad rows are [v | ln_g | ln_b | tau]: column sums over the rows
       const float* pg = persist_b ? pgrad4 : pgrad;
       const int pr = persist_b ? 4 * B : Tp * B, ldp = 3 * D + 1;
