@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "decoder_math.h"
 #include "decoder_persist.h"
 #include "gemm_group.h"
 #include "lstm_prep.h"
@@ -292,7 +293,9 @@ __global__ void embed_to_xh_kernel(const float* __restrict__ table, const int32_
 __global__ void embed_step0_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids_bt,
                                    int32_t* __restrict__ ids_tb, const float* __restrict__ mask, float keep,
                                    float* __restrict__ xh, float* __restrict__ att0, const float* __restrict__ h0, int Tp,
-                                   int B, int T, int E, int A, int D, int V, float* __restrict__ xh_init) {
+                                   int B, int T, int E, int A, int D, int V, float* __restrict__ xh_init,
+                                   const float* __restrict__ cell_g, float* __restrict__ cell_gates,
+                                   float* __restrict__ cell_cnew, float* __restrict__ c0, float* __restrict__ h0_out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n_x = (long)Tp * B * E;
   const int EA = E + A, Wd = E + A + D;
@@ -310,7 +313,23 @@ __global__ void embed_step0_kernel(const float* __restrict__ table, const int32_
     xh[(size_t)(j / A) * Wd + E + (j % A)] = 0.f;
   } else if (i < n_x + (long)B * A + (long)B * D) {
     const long j = i - n_x - (long)B * A;
-    xh[(size_t)(j / D) * Wd + EA + (j % D)] = h0[j];
+    float hv;
+    if (cell_g) {      // the rnn-init step's LSTM cell from a zero state (lstm_gates_fwd_kernel's arithmetic; the bias is in g)
+      const int b = (int)(j / D), dd = (int)(j % D);
+      const float* gr = cell_g + (size_t)b * 4 * D;
+      const float si = sigmoidf_(gr[dd]), tj = tanhf(gr[D + dd]);
+      const float sf = sigmoidf_(gr[2 * D + dd] + 1.0f), so = sigmoidf_(gr[3 * D + dd]);
+      const float c2 = 0.f * sf + si * tj;
+      hv = tanhf(c2) * so;
+      float* ga = cell_gates + (size_t)b * 4 * D;
+      ga[dd] = si; ga[D + dd] = tj; ga[2 * D + dd] = sf; ga[3 * D + dd] = so;
+      cell_cnew[j] = c2;
+      c0[j] = c2;
+      h0_out[j] = hv;
+    } else {
+      hv = h0[j];
+    }
+    xh[(size_t)(j / D) * Wd + EA + (j % D)] = hv;
   } else if (xh_init && i < n_x + (long)B * A + 2L * B * D) {   // zero state of the init step: the h third of its operand rows
     const long j = i - n_x - (long)B * A - (long)B * D;
     xh_init[(size_t)(j / D) * Wd + EA + (j % D)] = 0.f;
@@ -978,6 +997,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   // partials of the persistent backward loop, free whenever the per-step kernels run ([Tp][B][4][D] >= 2 x [B][H][M])
   float* attn_ws = (!persist_b && comic_attn_splits(B, M) > 1 &&
                     TB * 4 * D >= (long)B * H * M + comic_attn_bwd_scratch(B, H, M, D)) ? dq_part : nullptr;
+  bool prologue_rides = false;
   if (persist && do_fwd) {   // every hand-off buffer of the step starts as "not written yet"; the error word as zero
     ComicPersistRanges pr{};
     const long n16 = (long)Tp * ((B + 15) / 16) * 16 * D;
@@ -994,7 +1014,14 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       pr.p[6] = dq_sum; pr.n[6] = n16;
       pr.p[7] = dotp; pr.n[7] = (long)Tp * B * 64;
     }
-    RC(comic_persist_prepare(pr, persist_sync, kPersistSyncWords + kGroupTickets, st));
+    // grouped path: the forward panel of the LSTM kernel and the padded W_o ride on the same launch
+    ComicPrologueExtra px{};
+    prologue_rides = group_gemm_enabled() && cell == COMIC_CELL_LSTM && fused;
+    if (prologue_rides) {
+      px.K = p->K; px.panel = kpanel_f; px.D = D; px.Wd = Wd; px.n_pack = comic_lstm_panel_floats(D, Wd, 0);
+      if (Vp != V) { px.W_o = p->W_o; px.wo_pad = wo_pad; px.V = V; px.Vp = Vp; px.n_pad = (long)D * Vp; }
+    }
+    RC(comic_persist_prepare(pr, persist_sync, kPersistSyncWords + kGroupTickets, st, prologue_rides ? &px : nullptr));
   }
   // ------------------------------------------------------------------ forward ------------
   // grp: the products outside the time loops as grouped launches (gemm_group.hip).  The rnn init step then keeps its
@@ -1013,9 +1040,9 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   if (do_fwd) {
   if (grp) {
     if (!persist) COMIC_REQUIRE(hipMemsetAsync(gg_tickets, 0, sizeof(unsigned) * kGroupTickets, st) == hipSuccess, "train_step: memset");
-    if (fused) RC(comic_pack_lstm_panels(p->K, kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
+    if (fused && !(prologue_rides && persist_b)) RC(comic_pack_lstm_panels(p->K, prologue_rides ? nullptr : kpanel_f, persist_b ? nullptr : kpanel_b, D, Wd, st));
     if (fused_q && !persist_b) RC(comic_pack_wq_panel(p->W_q, wq_panel, D, st));
-    if (Vp != V) {
+    if (Vp != V && !prologue_rides) {
       const long n = (long)D * Vp;
       hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->W_o, wo_pad, V, Vp, n);
       COMIC_LAUNCH_CHECK("pad W_o");
@@ -1036,9 +1063,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
       // zero initial state: only the first E+A rows of the cell's kernel contribute
       GemmGroupRun g2;
       g2.add(COMIC_GG_NN, xh_init, p->K, ib.g, B, 4 * D, EA, Wd, 4 * D, 4 * D)->bias = p->b;
-      RC(g2.run(gg_slab, gg_slab_cap, gg_tickets, st));
-      RC(comic_lstm_gates_fwd(ib.g, nullptr, nullptr, ib.gates, ib.c_new, nullptr, nullptr, nullptr, 1.f, nullptr, 0, cs, hs,
-                              B, D, (void*)st));
+      RC(g2.run(gg_slab, gg_slab_cap, gg_tickets, st));      // (the cell itself: inside the operand-row launch below)
     }
   } else {
     LaneScope lane(L, st, splitk_ws_b);
@@ -1060,7 +1085,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     const long n = (long)Tp * B * E + (long)B * A + (long)B * D * (zi ? 2 : 1);
     hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb, inputs_bt, in_tb,
                        drop_in ? mask_in : nullptr, d->keep_in, xh_all, att_all, hs, Tp, B, T, E, A, D, V,
-                       zi ? xh_init : (float*)nullptr);
+                       zi ? xh_init : (float*)nullptr, zi ? ib.g : (const float*)nullptr, ib.gates, ib.c_new, cs, hs);
     COMIC_LAUNCH_CHECK("embed_step0");
   }
   if (persist) {
@@ -1603,7 +1628,8 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
       const long n = (long)B * A + (long)B * D;
       hipLaunchKernelGGL(embed_step0_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, p->emb,
                          (const int32_t*)nullptr, (int32_t*)nullptr, (const float*)nullptr, 1.f, ws.p_xh, ws.att[0], ws.h[0],
-                         0, B, 0, E, A, D, V, (float*)nullptr);
+                         0, B, 0, E, A, D, V, (float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                         (float*)nullptr, (float*)nullptr);
       COMIC_LAUNCH_CHECK("greedy step0");
     }
     ComicPersistFwdArgs pa{};

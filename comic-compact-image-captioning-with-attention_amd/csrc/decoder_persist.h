@@ -61,8 +61,21 @@ struct ComicPersistRanges {
   float* p[kPersistRanges];
   long n[kPersistRanges];
 };
+// Riders of the prepare launch (the training step's other start-of-step chores, one launch instead of three): the forward
+// MFMA panel of the LSTM kernel (comic_pack_lstm_panels, mode 0) and W_o with rows padded to Vp floats.  Null = none.
+struct ComicPrologueExtra {
+  const float* K;       // [Wd][4D]
+  float* panel;         // forward panel, n_pack floats (null: skip)
+  int D, Wd;
+  long n_pack;
+  const float* W_o;     // [D][V]
+  float* wo_pad;        // [D][Vp] (null: skip)
+  int V, Vp;
+  long n_pad;
+};
 // n_zero: words of `sync` to clear (>= kPersistSyncWords; the training executor keeps the grouped GEMM's tickets behind them)
-int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st);
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st,
+                          const ComicPrologueExtra* extra = nullptr);
 bool comic_persist_greedy_supported(int B, int D, int E, int A, int M, int H, int Cv, int V, int method,
                                     int context_layer, int tied);
 int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStream_t st);

@@ -712,7 +712,7 @@ __global__ __launch_bounds__(kThreads) void decoder_fwd_persistent_kernel(ComicP
   }
 }
 
-__global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync, int n_zero) {
+__global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync, int n_zero, ComicPrologueExtra x) {
   const uint4 v = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_zero) sync[i] = 0u;
@@ -724,6 +724,23 @@ __global__ void sentinel_fill_kernel(ComicPersistRanges r, unsigned* sync, int n
       return;
     }
     i -= n4;
+  }
+  // riders: the LSTM kernel's forward panel (the element order of pack_lstm_panels_kernel, mode 0) ...
+  if (i < x.n_pack) {
+    const int kk = (int)(i & 15), rr = (int)((i >> 4) & 15);
+    const long blk = i >> 8;
+    const int KB = (x.Wd + 15) >> 4;
+    const int kb = (int)(blk % KB), tile = (int)(blk / KB);
+    const int k = kb * 16 + kk, unit = tile * 4 + (rr >> 2);
+    x.panel[i] = (k < x.Wd && unit < x.D) ? x.K[(size_t)k * 4 * x.D + (rr & 3) * x.D + unit] : 0.f;
+    return;
+  }
+  i -= x.n_pack;
+  // ... and W_o with padded rows
+  if (i < x.n_pad) {
+    const long row = i / x.Vp;
+    const int c = (int)(i - row * x.Vp);
+    x.wo_pad[i] = c < x.V ? x.W_o[row * x.V + c] : 0.f;
   }
 }
 
@@ -890,15 +907,21 @@ int comic_persist_check_greedy(const unsigned* sync, int32_t* first_eos, hipStre
   return 0;
 }
 
-int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st) {
+int comic_persist_prepare(const ComicPersistRanges& r, unsigned* sync, int n_zero, hipStream_t st,
+                          const ComicPrologueExtra* extra) {
   long n = 0;
   for (int k = 0; k < kPersistRanges; ++k) {
     COMIC_REQUIRE(r.n[k] % 4 == 0 && (r.n[k] == 0 || r.p[k]), "persistent decoder: bad hand-off range %d", k);
     n += r.n[k] / 4;
   }
   if (n_zero < kPersistSyncWords) n_zero = kPersistSyncWords;
+  ComicPrologueExtra x{};
+  if (extra) x = *extra;
+  if (!x.panel) x.n_pack = 0;
+  if (!x.wo_pad) x.n_pad = 0;
+  n += x.n_pack + x.n_pad;
   if (n < n_zero) n = n_zero;
-  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, r, sync, n_zero);
+  hipLaunchKernelGGL(sentinel_fill_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, r, sync, n_zero, x);
   COMIC_LAUNCH_CHECK("persistent decoder prepare");
   return 0;
 }
