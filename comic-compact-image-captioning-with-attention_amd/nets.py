@@ -620,6 +620,7 @@ class CnnEncoder:
         self._graph = None
         self._calls = 0
         self._alt = {}                 # adopted input tensors: address -> [pointer table, graph, calls, tensor]
+        self._last_bufptr = None
         self._polite_lds_kb = 0
         self._fm_f32 = None
 
@@ -838,7 +839,7 @@ class CnnEncoder:
         for bk in (buckets or [(0, len(self.plan.ops), None, None)]):
             lo, hi = bk[0], bk[1]
             first = C.byref(self._ops, lo * C.sizeof(L.CnnOp))
-            L.check(self.lib.comic_cnn_backward(first, hi - lo, self._bufptr, t.gptr, self._bufch, self._wt,
+            L.check(self.lib.comic_cnn_backward(first, hi - lo, self._last_bufptr or self._bufptr, t.gptr, self._bufch, self._wt,
                                                 t.grads, self.batch, self.dcode, int(ready), t.scratch.data_ptr(),
                                                 t.scratch_bytes, L.stream_ptr()), 'cnn_backward')
             if on_bucket is not None:
@@ -910,6 +911,7 @@ class CnnEncoder:
             if alt is None:
                 inp.copy_(images)
         bufptr, graph, calls = (alt[0], alt[1], alt[2]) if alt is not None else (None, self._graph, self._calls)
+        self._last_bufptr = bufptr      # backward() reads the activations (the input among them) where this forward did
         if use_graph and graph is None and calls >= 1:
             graph = self.torch.cuda.CUDAGraph()
             # thread_local: the input pipeline's prefetch thread allocates, copies and launches on this device
