@@ -104,8 +104,8 @@ _SIGS = {
     'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
     'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
     'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),
-    'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int]),
-    'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P]),
+    'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int, c_int]),
+    'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
     'comic_cnn_pack_bwd_filters': (c_int, [P, c_int, P, c_int, P]),
     'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
     'comic_cnn_pack_frag_weights': (c_int, [P, P, P, c_int, c_int64, P]),

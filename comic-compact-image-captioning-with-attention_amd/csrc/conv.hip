@@ -2561,10 +2561,28 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
 // atomic pass over the filter; fewer splits measured slower)
 int wgrad_blocks_target() { return 1024; }
 
+// bytes of a conv's (zero-dilated) d-conv tensor, and of the scratch a backward pass needs: the largest one, or -- when the
+// weight gradients run on a lane of their own -- all of them side by side
+size_t dz_bytes_of(const comic_cnn_op* op, int batch, size_t es) {
+  const int Hd = (op->Ho - 1) * op->SH + 1;
+  const int Wd = (op->Wo - 1) * op->SW + 1;
+  return ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
+}
+int64_t backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, size_t es, bool all) {
+  size_t best = 0, sum = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    if (ops[i].kind > 1) continue;
+    const size_t dz = dz_bytes_of(ops + i, batch, es);
+    best = std::max(best, dz);
+    sum += dz;
+  }
+  return (int64_t)(all ? sum : best);
+}
+
 template <typename T>
 int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
                   const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
-                  int64_t scratch_bytes, hipStream_t st, bool filters_ready) {
+                  int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w) {
   constexpr int EPC = Elem<T>::EPC;
   const bool stem = op->kind == 1;
   COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
@@ -2589,7 +2607,17 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
     hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(P, ppb), cdiv(op->Cout, 64)), dim3(256), 0, st, a,
                        gr->dbeta, ppb);
   }
+  if (st_w != st) {     // the weight gradient runs on its own lane, beside the backward-data chain (dz is this conv's own)
+    hipEvent_t ev;
+    COMIC_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "conv backward: event");
+    const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(st_w, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);   // released once it has completed
+    COMIC_REQUIRE(ok, "conv backward: fork of the weight-gradient lane failed");
+  }
   {
+    hipStream_t st_chain = st;
+    hipStream_t st = st_w;      // the launches of this scope go to the weight-gradient lane
+    (void)st_chain;
     WgradArgs a{};
     a.dz = dz; a.Hd = Hd; a.Wd = Wd; a.dil = dil; a.x = x; a.x_cs = xc; a.x_co = op->src_coff; a.dw = gr->dw;
     a.B = batch; a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout; a.KH = op->KH; a.KW = op->KW;
@@ -2688,7 +2716,13 @@ int pack_bwd_filters_impl(const comic_cnn_op* ops, int n_ops, const comic_conv_g
 template <typename T>
 int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, const comic_conv_grad* grads,
-                      int batch, void* scratch, int64_t scratch_bytes, hipStream_t st, bool filters_ready) {
+                      int batch, void* scratch, int64_t scratch_bytes, hipStream_t st, bool filters_ready,
+                      hipStream_t st_w) {
+  // Two lanes (st_w != st): every conv gets its own d-conv slice of the scratch, so its weight gradient (st_w) only
+  // waits for its act_grad launch and runs beside the act_grad / backward-data chain of the earlier layers (st).
+  const int64_t all = backward_scratch_bytes(ops, n_ops, batch, sizeof(T), true);
+  if (st_w == nullptr || all > scratch_bytes) st_w = st;
+  size_t dz_off = 0;
   for (int i = n_ops - 1; i >= 0; --i) {
     const comic_cnn_op* op = ops + i;
     if (op->kind == 5 || op->kind == 6) continue;
@@ -2697,9 +2731,13 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
     void* gx = grad_buffers[op->src];
     const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
     if (op->kind <= 1) {
+      const size_t dzb = dz_bytes_of(op, batch, sizeof(T));
+      void* dz = st_w != st ? (void*)((char*)scratch + dz_off) : scratch;
       if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
-                                    grads + op->weight, batch, scratch, scratch_bytes, st, filters_ready))
+                                    grads + op->weight, batch, dz, st_w != st ? (int64_t)dzb : scratch_bytes, st,
+                                    filters_ready, st_w))
         return rc;
+      dz_off += dzb;
     } else if (op->kind <= 4) {
       if (!gx) continue;
       if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st)) return rc;
@@ -2707,24 +2745,21 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
       COMIC_REQUIRE(false, "cnn_backward: unknown op kind %d", op->kind);
     }
   }
+  if (st_w != st) {      // join: what follows on st (all-reduce, optimiser) sees every weight gradient
+    hipEvent_t ev;
+    COMIC_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "cnn_backward: event");
+    const bool ok = hipEventRecord(ev, st_w) == hipSuccess && hipStreamWaitEvent(st, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    COMIC_REQUIRE(ok, "cnn_backward: join of the weight-gradient lane failed");
+  }
   return 0;
 }
 
 }  // namespace
 
-extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype) {
+extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype, int lanes) {
   if (!ops) return -1;
-  const size_t es = dtype == COMIC_BF16 ? 2 : 4;
-  size_t best = 0;
-  for (int i = 0; i < n_ops; ++i) {
-    const comic_cnn_op* op = ops + i;
-    if (op->kind > 1) continue;
-    const int Hd = (op->Ho - 1) * op->SH + 1;
-    const int Wd = (op->Wo - 1) * op->SW + 1;
-    const size_t dz = ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
-    best = std::max(best, dz);
-  }
-  return (int64_t)best;
+  return backward_scratch_bytes(ops, n_ops, batch, dtype == COMIC_BF16 ? 2 : 4, lanes > 1);
 }
 
 extern "C" int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads, int dtype,
@@ -2739,16 +2774,16 @@ extern "C" int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, co
 extern "C" int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
                                   const int32_t* buf_channels, const comic_conv_weight* weights,
                                   const comic_conv_grad* grads, int batch, int dtype, int filters_ready, void* scratch,
-                                  int64_t scratch_bytes, void* stream) {
+                                  int64_t scratch_bytes, void* stream, void* wgrad_stream) {
   COMIC_REQUIRE(ops && buffers && grad_buffers && buf_channels && weights && grads && scratch,
                 "comic_cnn_backward: null argument");
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = (hipStream_t)stream, st_w = (hipStream_t)wgrad_stream;
   if (dtype == COMIC_BF16)
     return cnn_backward_impl<bf16_t>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
-                                     scratch_bytes, st, filters_ready != 0);
+                                     scratch_bytes, st, filters_ready != 0, st_w);
   if (dtype == COMIC_F32)
     return cnn_backward_impl<float>(ops, n_ops, buffers, grad_buffers, buf_channels, weights, grads, batch, scratch,
-                                    scratch_bytes, st, filters_ready != 0);
+                                    scratch_bytes, st, filters_ready != 0, st_w);
   COMIC_REQUIRE(false, "unknown dtype %d", dtype);
   return 2;
 }

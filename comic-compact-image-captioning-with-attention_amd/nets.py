@@ -621,6 +621,7 @@ class CnnEncoder:
         self._calls = 0
         self._alt = {}                 # adopted input tensors: address -> [pointer table, graph, calls, tensor]
         self._last_bufptr = None
+        self.backward_lanes = True     # cnn_finetune: weight gradients on a lane of their own (enable_training)
         self._polite_lds_kb = 0
         self._fm_f32 = None
 
@@ -801,9 +802,12 @@ class CnnEncoder:
             t.grads[i].dw = t.dw.view('w%d' % i).data_ptr()
             t.grads[i].dbeta = t.dbeta.view('b%d' % i).data_ptr()
             t.grads[i].w_bwd = None if stem else t.w_bwd.data_ptr() + wb_off[i]
+        # two lanes: every conv's d-conv tensor side by side, so the weight gradients (t.wlane) run beside the
+        # backward-data chain (comic_hip.h, comic_cnn_backward)
         t.scratch_bytes = int(self.lib.comic_cnn_backward_scratch_bytes(self._ops, len(plan.ops), self.batch,
-                                                                         self.dcode))
+                                                                         self.dcode, 2 if self.backward_lanes else 1))
         t.scratch = torch.empty(t.scratch_bytes, dtype=torch.uint8, device=self.device)
+        t.wlane = torch.cuda.Stream(device=self.device) if self.backward_lanes else None
         t.aux = torch.cuda.Stream(device=self.device)
         t.filters_ev = torch.cuda.Event()
         t.filters_ver = -1
@@ -841,7 +845,8 @@ class CnnEncoder:
             first = C.byref(self._ops, lo * C.sizeof(L.CnnOp))
             L.check(self.lib.comic_cnn_backward(first, hi - lo, self._last_bufptr or self._bufptr, t.gptr, self._bufch, self._wt,
                                                 t.grads, self.batch, self.dcode, int(ready), t.scratch.data_ptr(),
-                                                t.scratch_bytes, L.stream_ptr()), 'cnn_backward')
+                                                t.scratch_bytes, L.stream_ptr(),
+                                                t.wlane.cuda_stream if t.wlane is not None else None), 'cnn_backward')
             if on_bucket is not None:
                 on_bucket(t, bk)
         return t
