@@ -104,6 +104,7 @@ _SIGS = {
     'comic_cnn_group_args_bytes': (C.c_long, [P, c_int]),
     'comic_cnn_build_group_args': (c_int, [P, c_int, P, P, P, c_int, P]),
     'comic_cnn_forward_grouped': (c_int, [P, c_int, P, P, P, c_int, c_int, P, P]),
+    'comic_clip_by_norm': (c_int, [P, P, P, c_int, c_float, c_float, c_float, P, P, P]),
     'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int, c_int]),
     'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
     'comic_cnn_pack_bwd_filters': (c_int, [P, c_int, P, c_int, P]),
@@ -159,6 +160,7 @@ _SIGS = {
     'comic_decoder_train_step': (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P,
                                          P, P, P, P, P, c_int64, P]),
     'comic_decoder_greedy': (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, c_int64, P]),
+    'comic_decoder_sample': (c_int, [P, P, P, P, c_int, c_int, P, P, P, P, P, P, c_int64, P]),
     'comic_decoder_beam': (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_int64, P]),
     'comic_scorer_create': (c_void_p, [c_char_p, P, c_int64, c_double]),
     'comic_scorer_destroy': (None, [c_void_p]),

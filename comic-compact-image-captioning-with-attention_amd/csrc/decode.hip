@@ -62,14 +62,17 @@ __device__ __forceinline__ ValIdx block_argmax_1b(float v, int i, ValIdx* sh8, i
   return r;
 }
 
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
-                                                          int V) {
+// noise (may be null): per-element Gumbel noise of SampleEmbeddingHelper's categorical draw -- argmax(logits + g) is a
+// sample of softmax(logits)
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                          int32_t* __restrict__ idx, int V) {
   __shared__ ValIdx sh[256];
   const float* row = x + (size_t)blockIdx.x * V;
+  const float* nrow = noise ? noise + (size_t)blockIdx.x * V : nullptr;
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   for (int v = threadIdx.x; v < V; v += 256) {
-    const float t = row[v];
+    const float t = nrow ? row[v] + nrow[v] : row[v];
     if (better(t, v, bv, bi)) {
       bv = t;
       bi = v;
@@ -437,11 +440,15 @@ __global__ void gather_tree_kernel(const int32_t* __restrict__ step_ids, const i
 
 }  // namespace
 
-extern "C" int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, void* stream) {
+// executor-internal: argmax of x + noise (noise null: of x)
+int comic_argmax_rows_noise(const float* x, const float* noise, int32_t* idx, int rows, int V, hipStream_t st) {
   COMIC_REQUIRE(x && idx && rows > 0 && V > 0, "argmax_rows: bad arguments");
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, idx, V);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, st, x, noise, idx, V);
   COMIC_LAUNCH_CHECK("argmax_rows");
   return 0;
+}
+extern "C" int comic_argmax_rows(const float* x, int32_t* idx, int rows, int V, void* stream) {
+  return comic_argmax_rows_noise(x, nullptr, idx, rows, V, (hipStream_t)stream);
 }
 
 // executor-internal: the step with BeamSearchDecoder's length penalty (length_penalty_weight; 0 = none)

@@ -1109,6 +1109,50 @@ __global__ void momentum_tf_kernel(float* __restrict__ w, const float* __restric
   w[i] = wi - lr * ai;
 }
 
+// ---- per-variable gradient clipping: slim.learning.clip_gradient_norms -> tf.clip_by_norm per tensor (model_base.py:394-401) ----
+// chunk table: (segment, first element, elements, first chunk of the segment, chunks of the segment) per chunk of a variable.
+// Both kernels sum in a fixed order (strided thread partials, wave tree, waves in order): the clipped step is reproducible.
+struct ClipChunk { long seg, start, len, first, count; };
+__device__ __forceinline__ float clip_block_sum(float s, float* red) {
+  s = wave_sum(s);
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void clip_partial_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                           const ClipChunk* __restrict__ chunks, float l2, float gscale,
+                                                           float* __restrict__ partial) {
+  __shared__ float red[4];
+  const ClipChunk c = chunks[blockIdx.x];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < c.len; i += 256) {
+    const float ge = g[c.start + i] * gscale + l2 * w[c.start + i];
+    s = fmaf(ge, ge, s);
+  }
+  s = clip_block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_apply_kernel(float* __restrict__ g, const float* __restrict__ w,
+                                                         const ClipChunk* __restrict__ chunks, float l2, float gscale,
+                                                         float clip, const float* __restrict__ partial,
+                                                         const float* __restrict__ skip) {
+  __shared__ float red[4];
+  if (skip && skip[0] != 0.f) return;
+  const ClipChunk c = chunks[blockIdx.x];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < c.count; i += 256) s += partial[c.first + i];
+  const float norm = sqrtf(clip_block_sum(s, red));
+  if (!(norm > clip)) return;                       // t * clip / max(norm, clip) == t
+  const float f = clip / norm, inv = 1.0f / gscale;
+  for (long i = threadIdx.x; i < c.len; i += 256) {
+    const float lw = l2 * w[c.start + i];
+    const float ge = g[c.start + i] * gscale + lw;
+    g[c.start + i] = (ge * f - lw) * inv;           // the optimiser's g*gscale + l2*w is then the clipped g_eff
+  }
+}
+
 // out[j] = beta*out[j] + sum_i in[i*cols+j]; one thread per column (coalesced over j)
 __global__ void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, float beta) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1453,6 +1497,19 @@ extern "C" int comic_adam_tf_gated(float* w, const float* g, float* m, float* v,
   hipLaunchKernelGGL(adam_tf_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
                      (long)n, lr_t, beta1, beta2, eps, l2, gscale, skip_flag);
   COMIC_LAUNCH_CHECK("adam_tf_gated");
+  return 0;
+}
+
+extern "C" int comic_clip_by_norm(float* g, const float* w, const int64_t* chunks, int n_chunks, float l2, float gscale,
+                                  float clip_norm, float* partial, const float* skip_flag, void* stream) {
+  if (n_chunks == 0 || !(clip_norm > 0.f)) return 0;
+  COMIC_REQUIRE(g && w && chunks && partial && gscale != 0.f, "clip_by_norm: bad arguments");
+  static_assert(sizeof(ClipChunk) == 5 * sizeof(int64_t), "chunk records are five int64");
+  hipLaunchKernelGGL(clip_partial_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, g, w,
+                     (const ClipChunk*)chunks, l2, gscale, partial);
+  hipLaunchKernelGGL(clip_apply_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, g, w, (const ClipChunk*)chunks,
+                     l2, gscale, clip_norm, (const float*)partial, skip_flag);
+  COMIC_LAUNCH_CHECK("clip_by_norm");
   return 0;
 }
 

@@ -1586,10 +1586,13 @@ const float* aligned_w_o(const comic_decoder_desc* d, const comic_decoder_params
 }
 }  // namespace
 
-extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
-                                    const float* im_embed, int B, int max_steps, int32_t* ids_tb, float* logits_tb,
-                                    float* attn_hist, int32_t* first_eos, void* workspace, int64_t workspace_bytes,
-                                    void* stream) {
+int comic_argmax_rows_noise(const float* x, const float* noise, int32_t* idx, int rows, int V, hipStream_t st);
+
+// greedy (gumbel_tb null) or sampled (gumbel_tb [max_steps][B][V]: ids = argmax(logits + noise)) decode loop
+static int decoder_search(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                          const float* im_embed, int B, int max_steps, const float* gumbel_tb, int32_t* ids_tb,
+                          float* logits_tb, float* attn_hist, int32_t* first_eos, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
   RC(check_desc(d));
   FlagScope flag_scope__(d);
   COMIC_REQUIRE(p && fm && im_embed && ids_tb && attn_hist && first_eos && workspace, "greedy: null pointer");
@@ -1613,7 +1616,7 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
   if (fused) RC(comic_pack_lstm_panels(p->K, ws.kpanel, nullptr, D, E + A + D, st));
   // the whole loop as one persistent launch (decoder_persist.hip, GREEDY) when the shape allows it
   g_greedy_path = 0;
-  if (fused && persist_enabled() && ws.p_xh &&
+  if (!gumbel_tb && fused && persist_enabled() && ws.p_xh &&
       comic_persist_greedy_supported(B, D, E, A, M, H, Cv, V, d->method, d->context_layer, ad.tied) &&
       comic_persist_fits_device(B)) {
     const int Wd = E + A + D;
@@ -1679,13 +1682,29 @@ extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_dec
     float* lg = logits_tb ? logits_tb + (size_t)t * B * V : ws.logits;
     RC(gemm(sb.y, w_o, lg, p->b_o, B, V, D, D, ld_wo, V, 0, 0, 0.f, st));
     int32_t* ids_out = ids_tb + (size_t)t * B;
-    RC(comic_argmax_rows(lg, ids_out, B, V, (void*)st));
+    RC(comic_argmax_rows_noise(lg, gumbel_tb ? gumbel_tb + (size_t)t * B * V : nullptr, ids_out, B, V, st));
     hipLaunchKernelGGL(eos_track_done_kernel, dim3(1), dim3(256), 0, st, (const int32_t*)ids_out, first_eos, t,
                        d->end_id, B, steps_done, max_steps);
     COMIC_LAUNCH_CHECK("eos_track");
   }
   (void)Cv; (void)M;
   return 0;
+}
+
+extern "C" int comic_decoder_greedy(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                                    const float* im_embed, int B, int max_steps, int32_t* ids_tb, float* logits_tb,
+                                    float* attn_hist, int32_t* first_eos, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+  return decoder_search(d, p, fm, im_embed, B, max_steps, nullptr, ids_tb, logits_tb, attn_hist, first_eos, workspace,
+                        workspace_bytes, stream);
+}
+extern "C" int comic_decoder_sample(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                                    const float* im_embed, int B, int max_steps, const float* gumbel_tb, int32_t* ids_tb,
+                                    float* logits_tb, float* attn_hist, int32_t* first_eos, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  COMIC_REQUIRE(gumbel_tb, "sample: null noise");
+  return decoder_search(d, p, fm, im_embed, B, max_steps, gumbel_tb, ids_tb, logits_tb, attn_hist, first_eos, workspace,
+                        workspace_bytes, stream);
 }
 
 // ---- one beam step from the decoder outputs, as an operator (C-ABI) -----------------------------------------------------

@@ -637,6 +637,32 @@ class Decoder:
             return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
         return fetch if defer else fetch()
 
+    def sample(self, fm, im_embed, max_steps, seed=0, noise=None, want_logits=False):
+        """rnn_decoder_search(greedy_search=False) (ops_rnn.py:158-166; ModelBase._rnn_dynamic_decoder(sample=True),
+        model_base.py:716-726): SampleEmbeddingHelper draws every next token from Categorical(logits).  The draw is
+        argmax(logits + Gumbel noise); `noise` [max_steps,B,V] (device fp32) may be supplied, else it is generated from
+        `seed` (torch's generator: the stream is not TensorFlow's Philox, only the distribution is the reference's).
+        -> ids [B,T_exec], attn_maps [B,H,T_exec,M], logits [B,T_exec,V] or None, as greedy()."""
+        torch, s = self.torch, self.spec
+        B = fm.shape[0]
+        ctx = self._infer_ctx('greedy', B, 1, max_steps, want_logits, fm, im_embed)
+        if noise is None:
+            gen = torch.Generator(device=self.device)
+            gen.manual_seed(int(seed))
+            u = torch.rand((max_steps, B, s.V), generator=gen, device=self.device, dtype=torch.float32)
+            noise = -torch.log(-torch.log(u.clamp_(1e-20, 1.0 - 1e-7)))
+        assert tuple(noise.shape) == (max_steps, B, s.V) and noise.dtype == torch.float32 and noise.is_contiguous()
+        ctx.desc.flags = L.decoder_flags_from_env()
+        L.check(self.lib.comic_decoder_sample(C.byref(ctx.desc), C.byref(ctx.ptab), ctx.fm.data_ptr(), ctx.im.data_ptr(), B,
+                                              max_steps, noise.data_ptr(), ctx.ids.data_ptr(), L.ptr(ctx.logits),
+                                              ctx.hist.data_ptr(), ctx.first_eos.data_ptr(), ctx.ws.data_ptr(), ctx.nbytes,
+                                              L.stream_ptr()), 'decoder_sample')
+        fe = ctx.first_eos.cpu().numpy()
+        t_exec = int(min(max_steps, fe.max() + 1))
+        out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
+        hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
+        return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
+
     def beam_search_ids(self, fm, im_embed, beam, max_steps, use_graph=True):
         """Beam search for its predicted ids alone, fetched WITHOUT draining the stream: the loop, gather_tree over all
         max_steps rows (rows past the executed steps come out as end_id) and the copies to pinned memory are enqueued, an

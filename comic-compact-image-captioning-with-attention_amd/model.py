@@ -144,21 +144,24 @@ class ModelBase(object):
     # ---- optimiser / LR (model_base.py:775-883) -----------------------------------------
     def _create_optimiser(self):
         c, share = self._config, self._share
+        clip = float(getattr(c, 'clip_gradient_norm', 0) or 0)      # per-variable tf.clip_by_norm (model_base.py:394-401)
         if 'opt' not in share:
             share['opt'] = optim.make_optimiser(c.optimiser, self.decoder.params, epsilon=c.adam_epsilon,
-                                                l2_decay=getattr(c, 'l2_decay', 1e-5))
+                                                l2_decay=getattr(c, 'l2_decay', 1e-5), clip_norm=clip)
             share['legacy_lr'] = c.lr_start
         self.opt = share['opt']
         if self.head is not None and 'opt_head' not in share:
             share['opt_head'] = optim.make_optimiser(c.optimiser, self.head.params, epsilon=c.adam_epsilon,
-                                                     l2_decay=getattr(c, 'l2_decay', 1e-5))
+                                                     l2_decay=getattr(c, 'l2_decay', 1e-5), clip_norm=clip)
         if self.cnn_trainable and 'opt_cnn' not in share:
             # gradient_multipliers scale the whole CNN gradient, L2 term included (model_base.py:388-401)
             enc = self._encoder_for(self._batch_size)
             mult = float(getattr(c, 'cnn_grad_multiplier', 1.0))
             l2 = getattr(c, 'l2_decay', 1e-5) * mult
-            share['opt_cnn'] = (optim.make_optimiser(c.optimiser, enc.w_master, epsilon=c.adam_epsilon, l2_decay=l2),
-                                optim.make_optimiser(c.optimiser, enc.beta, epsilon=c.adam_epsilon, l2_decay=l2), mult)
+            share['opt_cnn'] = (optim.make_optimiser(c.optimiser, enc.w_master, epsilon=c.adam_epsilon, l2_decay=l2,
+                                                     clip_norm=clip),
+                                optim.make_optimiser(c.optimiser, enc.beta, epsilon=c.adam_epsilon, l2_decay=l2,
+                                                     clip_norm=clip), mult)
 
     @property
     def global_step(self):
@@ -358,6 +361,12 @@ class ModelBase(object):
             if top_beam:
                 return pred[:, :, 0].T.copy(), attn
             return pred.transpose(2, 1, 0).copy(), attn               # (W, B, T)
+        if beam_size == 0:
+            # _decoder_rnn_scst(0): the sampled rollout (model_base.py:716-726 sample=True -> SampleEmbeddingHelper,
+            # ops_rnn.py:158-166; commented out of the reference's SCST graph, model.py:127-129, kept callable here)
+            n = self._share['sample_draws'] = self._share.get('sample_draws', 0) + 1
+            ids, amap, _ = self.decoder.sample(fm, im_embed, iters, seed=int(getattr(c, 'rand_seed', 0)) + n)
+            return ids, amap.cpu().numpy()
         ids, amap, _ = self.decoder.greedy(fm, im_embed, iters)
         return ids, amap.cpu().numpy()
 

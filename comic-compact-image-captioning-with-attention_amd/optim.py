@@ -28,14 +28,43 @@ def legacy_lr_reduce(lr, epoch, lr_end, every_n_epochs):
     return lr
 
 
+class GradClip:
+    """`--clip_gradient_norm c` (train.py:137 -> model_base.py:394-401): slim.learning.create_train_op clips EVERY variable's
+    gradient by that tensor's own norm (clip_gradient_norms -> tf.clip_by_norm [TF-1.9 slim]), after the gradient
+    multipliers; the L2 term is part of the loss and therefore of the clipped gradient.  One chunk table per flat
+    parameter buffer (comic_clip_by_norm, include/comic_hip.h)."""
+    CHUNK = 8192
+
+    def __init__(self, params, clip_norm):
+        import torch
+        self.lib = L.load()
+        self.clip_norm = float(clip_norm)
+        rows = []
+        for seg, k in enumerate(params.shapes):
+            n = int(np.prod(params.shapes[k])) if len(params.shapes[k]) else 1
+            first, count = len(rows), (n + self.CHUNK - 1) // self.CHUNK
+            for c in range(count):
+                rows.append((seg, params.offsets[k] + c * self.CHUNK, min(self.CHUNK, n - c * self.CHUNK), first, count))
+        self.n_chunks = len(rows)
+        self.chunks = torch.from_numpy(np.asarray(rows, np.int64).reshape(-1, 5)).to(params.device)
+        self.partial = torch.zeros(max(1, self.n_chunks), dtype=torch.float32, device=params.device)
+
+    def apply(self, params, grads, l2, grad_scale):
+        st = getattr(grads, 'status', None)
+        L.check(self.lib.comic_clip_by_norm(grads.data.data_ptr(), params.data.data_ptr(), self.chunks.data_ptr(),
+                                            self.n_chunks, l2, grad_scale, self.clip_norm, self.partial.data_ptr(),
+                                            st.data_ptr() if st is not None else None, L.stream_ptr()), 'clip_by_norm')
+
+
 class AdamTF:
-    def __init__(self, params, beta1=0.9, beta2=0.999, epsilon=1e-2, l2_decay=1e-5):
+    def __init__(self, params, beta1=0.9, beta2=0.999, epsilon=1e-2, l2_decay=1e-5, clip_norm=0.0):
         self.lib = L.load()
         self.params = params
         self.m = params.like()
         self.v = params.like()
         self.beta1, self.beta2, self.eps, self.l2 = beta1, beta2, epsilon, l2_decay
         self.t = 0                      # number of applied updates (== global_step)
+        self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
     def step(self, grads, lr, grad_scale=1.0):
         self.t += 1
@@ -45,6 +74,8 @@ class AdamTF:
         # host-side step count `t` advances regardless -- one bias-correction step of drift per voided step, and the run
         # stops at the next log point anyway (train_fn._check_loss reads the sticky count).
         st = getattr(grads, 'status', None)
+        if self.clip is not None:
+            self.clip.apply(self.params, grads, self.l2, grad_scale)
         L.check(self.lib.comic_adam_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
                                              self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
                                              self.eps, self.l2, grad_scale, st.data_ptr() if st is not None else None,
@@ -64,7 +95,7 @@ class MomentumTF:
     `--optimiser sgd`): accum = momentum*accum + g, w -= lr*accum, with the same L2 fold as AdamTF.  Same interface
     (`t`, `step`, `m` = the accumulator; `v` stays zero so checkpoints keep one layout)."""
 
-    def __init__(self, params, momentum=0.9, l2_decay=1e-5, **_):
+    def __init__(self, params, momentum=0.9, l2_decay=1e-5, clip_norm=0.0, **_):
         self.lib = L.load()
         self.params = params
         self.m = params.like()
@@ -72,10 +103,13 @@ class MomentumTF:
         self.momentum, self.l2 = momentum, l2_decay
         self.beta1, self.beta2, self.eps = momentum, 0.0, 0.0
         self.t = 0
+        self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
     def step(self, grads, lr, grad_scale=1.0):
         self.t += 1
         st = getattr(grads, 'status', None)
+        if self.clip is not None:
+            self.clip.apply(self.params, grads, self.l2, grad_scale)
         L.check(self.lib.comic_momentum_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
                                                  self.params.numel, lr, self.momentum, self.l2, grad_scale,
                                                  st.data_ptr() if st is not None else None, L.stream_ptr()), 'momentum_tf')
@@ -84,10 +118,10 @@ class MomentumTF:
     load_state_dict = AdamTF.load_state_dict
 
 
-def make_optimiser(name, params, epsilon=1e-2, l2_decay=1e-5):
-    """`_get_optimiser` (model_base.py:852-883)."""
+def make_optimiser(name, params, epsilon=1e-2, l2_decay=1e-5, clip_norm=0.0):
+    """`_get_optimiser` (model_base.py:852-883) + create_train_op's clip_gradient_norm (model_base.py:394-401)."""
     if name == 'adam':
-        return AdamTF(params, epsilon=epsilon, l2_decay=l2_decay)
+        return AdamTF(params, epsilon=epsilon, l2_decay=l2_decay, clip_norm=clip_norm)
     if name == 'sgd':
-        return MomentumTF(params, l2_decay=l2_decay)
+        return MomentumTF(params, l2_decay=l2_decay, clip_norm=clip_norm)
     raise ValueError('Unknown optimiser.')

@@ -408,6 +408,16 @@ int comic_adam_tf_gated(float* w, const float* g, float* m, float* v, int64_t n,
                         float epsilon, float l2, float gscale, const float* skip_flag, void* stream);
 int comic_momentum_tf_gated(float* w, const float* g, float* accum, int64_t n, float lr, float momentum, float l2,
                             float gscale, const float* skip_flag, void* stream);
+/* Gradient clipping of `--clip_gradient_norm` (train.py:137 -> model_base.py:394-401: slim.learning.create_train_op(
+ * clip_gradient_norm=c) = clip_gradient_norms [TF-1.9 slim]: tf.clip_by_norm on EVERY variable's gradient by that tensor's
+ * own L2 norm, after the gradient multipliers).  The clipped quantity is g_eff = g*gscale + l2*w (the L2 term is part of
+ * the reference's loss; gscale carries the data-parallel 1/W and the CNN multiplier): g_eff * clip / max(||g_eff||, clip).
+ * In place on g, such that the optimiser's own g*gscale + l2*w yields the clipped g_eff.  chunks: n_chunks records of five
+ * int64 on the device -- (variable, first element, elements, first chunk of the variable, chunks of the variable), a
+ * variable cut into pieces of <= 8192 elements; partial: n_chunks floats of scratch.  Sums run in a fixed order.  skip_flag
+ * as in comic_adam_tf_gated. */
+int comic_clip_by_norm(float* g, const float* w, const int64_t* chunks, int n_chunks, float l2, float gscale,
+                       float clip_norm, float* partial, const float* skip_flag, void* stream);
 /* Test aid: n_workgroups workgroups (256 threads) that stay resident for about `microseconds` each (bounded spin on the
  * 100 MHz clock) -- what a collective's kernels do to some CUs while a training step runs beside them. */
 int comic_debug_occupy_cus(int n_workgroups, int microseconds, void* stream);
@@ -518,6 +528,16 @@ int comic_decoder_beam_path(void);
  * row in first_eos [B] (max_steps when no EOS).  The host trims to the executed length. */
 int comic_decoder_greedy(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
                          const float* im_embed, int B, int max_steps, int32_t* ids_tb,
+                         float* logits_tb, float* attn_hist, int32_t* first_eos, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/* Sampled decode (rnn_decoder_search(greedy_search=False), ops_rnn.py:158-166: SampleEmbeddingHelper [TF-1.9]: the next
+ * token is a draw of Categorical(logits), fed back through the embedding; finished when it is EOS).  The draw is
+ * argmax(logits + g) with Gumbel noise g = -log(-log u) supplied by the caller (gumbel_tb [max_steps,B,V]), i.e. the
+ * random stream is the caller's; logits_tb stays the undisturbed projection (BasicDecoder's rnn_output).  Per-step
+ * launches; outputs as comic_decoder_greedy. */
+int comic_decoder_sample(const comic_decoder_desc* d, const comic_decoder_params* p, const float* fm,
+                         const float* im_embed, int B, int max_steps, const float* gumbel_tb, int32_t* ids_tb,
                          float* logits_tb, float* attn_hist, int32_t* first_eos, void* workspace,
                          int64_t workspace_bytes, void* stream);
 

@@ -34,8 +34,10 @@ def max_iterations(cfg, infer_max_length, vocab_len):
     return it
 
 
-def greedy_decode(p, cfg, fm, im_embed, max_iters):
-    """-> ids [B,T_exec] int32, logits [B,T_exec,V], attn_maps [B,H,T_exec,M]."""
+def greedy_decode(p, cfg, fm, im_embed, max_iters, gumbel=None):
+    """-> ids [B,T_exec] int32, logits [B,T_exec,V], attn_maps [B,H,T_exec,M].
+    gumbel [max_iters,B,V]: SampleEmbeddingHelper instead of GreedyEmbeddingHelper (ops_rnn.py:158-166; [TF-1.9]
+    sample_ids = Categorical(logits).sample()): the draw is argmax(logits + Gumbel noise), the noise being the caller's."""
     B, M, _ = fm.shape
     keys, values = dr.memory_projections(p, cfg, fm)
     c, h, _ = dr.rnn_init(p, cfg, im_embed, None)
@@ -47,7 +49,7 @@ def greedy_decode(p, cfg, fm, im_embed, max_iters):
         x = dr.embed(p['emb'], ids)
         y, c, h, att, alpha, _ = dr.decoder_step(p, cfg, keys, values, x, c, h, att, None)
         lg = y @ p['W_o'] + p['b_o']
-        ids = lg.argmax(axis=1)                 # lowest index wins ties (A.8)
+        ids = (lg if gumbel is None else lg + gumbel[t]).argmax(axis=1)   # lowest index wins ties (A.8)
         out_ids.append(ids.astype(np.int32)); out_logits.append(lg); out_alpha.append(alpha)
         finished |= (ids == cfg.end_id)
         if finished.all():

@@ -655,6 +655,14 @@ def adam_tf_update(w, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-2):
     return w, m, v
 
 
+def clip_by_norm(g, clip_norm):
+    """slim.learning.clip_gradient_norms -> tf.clip_by_norm on ONE variable's gradient [TF-1.9 slim / clip_ops]
+    (model_base.py:394-401, create_train_op(clip_gradient_norm=c)): g * clip / max(||g||_2, clip)."""
+    g = np.asarray(g, np.float32)
+    norm = np.sqrt(np.sum(g.astype(np.float64) ** 2))
+    return (g * np.float32(clip_norm / max(norm, clip_norm))).astype(np.float32)
+
+
 def momentum_tf_update(w, g, accum, lr, momentum=0.9):
     """tf.train.MomentumOptimizer.ApplyMomentum, use_nesterov=False [TF-1.9] (model_base.py:867-880):
     accum = momentum*accum + g; w -= lr*accum."""

@@ -145,11 +145,10 @@ def build_kwargs(args):
 
 def check_supported(kw):
     """Options of the reference that this hot path does not implement fail HERE instead of silently training a different
-    model (model_base.py:394-401 gradient clipping).  --rnn_name LN_LSTM / GRU (model_base.py:622-629) build: their
-    cells run on the per-step launch chain."""
+    model.  Nothing is refused at present: --clip_gradient_norm (model_base.py:394-401) is per-variable tf.clip_by_norm
+    in front of the optimiser (optim.GradClip), --rnn_name LN_LSTM / GRU (model_base.py:622-629) run on the per-step
+    launch chain."""
     bad = []
-    if kw.get('clip_gradient_norm'):
-        bad.append('clip_gradient_norm != 0')
     # --initialiser: `he` / `none` select TensorFlow's default initialiser in the reference (model_base.py:823-831:
     # every value but `xavier` returns None), which for these float variables is glorot_uniform == Xavier-uniform
     # [TF-1.9 get_variable default]: all three choices build the same model, here too.

@@ -832,6 +832,39 @@ def test_adam_tf_matches_oracle():
     assert_close(dv.cpu().numpy(), v, 1e-5, 'adam v')
 
 
+def test_gradient_clipping_matches_oracle():
+    """clip_gradient_norm (model_base.py:394-401): tf.clip_by_norm per variable on g*gscale + l2*w, then the TF-Adam update;
+    variables of one element, of less than a chunk and of several chunks, norms above and below the threshold, and the
+    voided-step flag."""
+    from comic_amd import decoder as cdec, optim
+    rng = np.random.default_rng(11)
+    shapes = {'a': (3, 5000), 'b': (700,), 'c': (), 'd': (40000,), 'e': (128, 64)}
+    scale_of = {'a': 1.0, 'b': 1e-3, 'c': 50.0, 'd': 0.2, 'e': 1e-2}
+    PP = cdec.FlatParams(shapes, DEV, status_tail=True)
+    G = PP.like()
+    w = {k: rng.standard_normal(shapes[k]).astype(np.float32) for k in shapes}
+    g = {k: (scale_of[k] * rng.standard_normal(shapes[k])).astype(np.float32) for k in shapes}
+    PP.load(w); G.load(g)
+    clip, l2, gs, lr = 2.5, 1e-3, 0.5, 1e-2
+    opt = optim.AdamTF(PP, l2_decay=l2, clip_norm=clip)
+    opt.step(G, lr, grad_scale=gs)
+    got = PP.to_numpy()
+    n_clipped = 0
+    for k in shapes:
+        ge = np.float32(gs) * g[k] + np.float32(l2) * w[k]
+        n_clipped += float(np.sqrt((ge.astype(np.float64) ** 2).sum())) > clip
+        ge = dr.clip_by_norm(ge, clip)
+        wk, m, v = w[k].copy(), np.zeros_like(w[k]), np.zeros_like(w[k])
+        dr.adam_tf_update(wk, ge, m, v, 1, lr, eps=1e-2)
+        assert_close(got[k], wk, 1e-5, 'clipped adam ' + k)
+    assert 2 <= n_clipped < len(shapes)                      # both sides of the threshold are exercised
+    # a voided step: neither the clip nor the update touches anything
+    G.status.fill_(1.0)
+    before, gbefore = PP.data.clone(), G.data.clone()
+    opt.step(G, lr, grad_scale=gs)
+    assert torch.equal(PP.data, before) and torch.equal(G.data, gbefore)
+
+
 def test_momentum_tf_matches_oracle():
     """--optimiser sgd: tf.train.MomentumOptimizer(0.9, use_nesterov=False) (model_base.py:867-880), two updates."""
     rng = np.random.default_rng(8)

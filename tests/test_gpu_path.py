@@ -1197,3 +1197,37 @@ def test_fullsize_cnn_finetune_step_properties():
     assert float((d0 - d1).abs().max()) <= 1e-4 * float(d0.abs().max())
     w_init = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), cnn_p, 1, 'bf16', DEV).w_master.data
     assert float((w0 - w_init).abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(), dict(fm_projection=None, H=1, token_type='word', V=9000,
+                                             init_method='project_hidden', start_id=8998, end_id=8999)])
+def test_sampled_decode_matches_oracle_on_the_same_noise(kw):
+    """rnn_decoder_search(greedy_search=False) (ops_rnn.py:158-166, SampleEmbeddingHelper): with the SAME Gumbel noise the
+    device's draws equal the oracle's id for id (argmax of logits + noise); the returned logits stay the undisturbed
+    projection (the distribution of the draws is checked on the oracle, tests/test_oracle_decoder.py)."""
+    spec, cfg = _spec_and_cfg(**kw)
+    p = _rand_params(cfg, 5)
+    p['b_o'][spec.end_id] = 1.5
+    B, max_steps = 5, 12
+    fm, im, _ = _batch(spec, B, 6, 21)
+    dec = cdec.Decoder(spec, p, DEV)
+    rng = np.random.default_rng(3)
+    gum = (-np.log(-np.log(rng.uniform(1e-9, 1.0, (max_steps, B, spec.V))))).astype(np.float32)
+    o_ids, o_logits, o_map = beam_ref.greedy_decode(p, cfg, fm, im, max_steps, gumbel=gum)
+    ids, amap, logits = dec.sample(dev(fm), dev(im), max_steps, noise=dev(gum), want_logits=True)
+    np.testing.assert_array_equal(ids, o_ids)
+    assert_close(logits.cpu().numpy(), o_logits, F32_RTOL, 'sampled-decode logits')
+    assert_close(amap.cpu().numpy(), o_map, F32_RTOL, 'sampled-decode attention maps')
+    g_ids, _, _ = beam_ref.greedy_decode(p, cfg, fm, im, max_steps)
+    assert not np.array_equal(o_ids[:, :g_ids.shape[1]], g_ids[:, :o_ids.shape[1]]), 'the noise never changed a token'
+    # generated noise: different seeds give different rollouts, one seed the same rollout
+    a1, _, _ = dec.sample(dev(fm), dev(im), max_steps, seed=1)
+    a2, _, _ = dec.sample(dev(fm), dev(im), max_steps, seed=1)
+    b1, _, _ = dec.sample(dev(fm), dev(im), max_steps, seed=2)
+    np.testing.assert_array_equal(a1, a2)
+    assert a1.shape != b1.shape or not np.array_equal(a1, b1)
+
+
+
+

@@ -540,10 +540,10 @@ def test_checkpoint_tf_container_three_way_restore(tmp_path):
     assert acc is not None and all(np.array_equal(acc[k], m[k]) for k in dec) and ckpt.adam_from_tf(spec, ex2) is None
 
 
-def test_cli_refuses_options_it_does_not_implement(tmp_path):
-    """Gradient clipping fails at argument time instead of training a different model; sgd, every --initialiser value (all
-    Xavier-uniform in the reference, model_base.py:823-831), --legacy, variational recurrent dropout and the LN_LSTM / GRU
-    cells (built in round 3) build."""
+def test_cli_accepts_every_option_of_the_reference(tmp_path):
+    """Nothing is refused any more: gradient clipping (clip_gradient_norm in the kwargs, model_base.py:394-401; round 4),
+    sgd, every --initialiser value (all Xavier-uniform in the reference, model_base.py:823-831), --legacy, variational
+    recurrent dropout and the LN_LSTM / GRU cells (round 3) build."""
     import importlib.util
     spec = importlib.util.spec_from_file_location('train_cli2', os.path.join(ROOT, 'src', 'train.py'))
     train = importlib.util.module_from_spec(spec)
@@ -551,8 +551,7 @@ def test_cli_refuses_options_it_does_not_implement(tmp_path):
     base = ['--log_root', str(tmp_path)]
     kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base))
     kw['clip_gradient_norm'] = 5.0
-    with pytest.raises(NotImplementedError):
-        train.check_supported(kw)
+    train.check_supported(kw)
     for ok in (['--optimiser', 'sgd'], ['--initialiser', 'he'], ['--initialiser', 'none'], ['--rnn_recurr_dropout', 'True'],
                ['--rnn_name', 'GRU'], ['--rnn_name', 'LN_LSTM'], ['--legacy', 'True']):
         kw, _, _ = train.build_kwargs(train.create_parser().parse_args(base + ok))

@@ -234,3 +234,27 @@ def test_momentum_oracle_formula():
     dr.momentum_tf_update(w, g, acc, 0.1)
     np.testing.assert_allclose(acc, 1.9 * g, rtol=1e-6)                 # 0.9*g + g
     np.testing.assert_allclose(w, 1 - 0.1 * g - 0.1 * 1.9 * g, rtol=1e-6)
+
+
+def test_sampled_decode_draws_follow_the_softmax():
+    """SampleEmbeddingHelper restated as argmax(logits + Gumbel noise) (beam_ref.greedy_decode(gumbel=...)): over many
+    noise draws the first token's empirical distribution is softmax(logits) [Gumbel-max], and zero noise is greedy."""
+    cfg = dr.DecoderConfig(rnn_size=16, rnn_word_size=8, attn_num_heads=2, radix_base=6, softmax_size=8, fm_channels=16,
+                           im_embed_size=16, start_id=6, end_id=7)
+    p = dr.init_params(cfg, 3)
+    rng = np.random.default_rng(0)
+    fm = rng.standard_normal((1, 4, cfg.fm_channels)).astype(np.float32)
+    im = rng.standard_normal((1, cfg.im_embed_size)).astype(np.float32)
+    V = p['b_o'].shape[0]
+    _, lg, _ = beam_ref.greedy_decode(p, cfg, fm, im, 1)
+    prob = dr.softmax(lg[0, 0].astype(np.float64))
+    n = 4000
+    counts = np.zeros(V)
+    for i in range(n):
+        g = (-np.log(-np.log(rng.uniform(1e-12, 1.0, (1, 1, V))))).astype(np.float32)
+        ids, _, _ = beam_ref.greedy_decode(p, cfg, fm, im, 1, gumbel=g)
+        counts[ids[0, 0]] += 1
+    assert np.abs(counts / n - prob).max() < 4.0 * np.sqrt(0.25 / n)
+    z_ids, _, _ = beam_ref.greedy_decode(p, cfg, fm, im, 3, gumbel=np.zeros((3, 1, V), np.float32))
+    g_ids, _, _ = beam_ref.greedy_decode(p, cfg, fm, im, 3)
+    np.testing.assert_array_equal(z_ids, g_ids)
