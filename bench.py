@@ -363,6 +363,60 @@ def extras(device, enc, cnn_params, plan):
                      'bf16_plan_vs_f32_plan': {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev_rel.items()},
                      'note': 'bf16_plan_vs_f32_plan: max|a-b| / max|b| per tensor between the benchmarked bf16 plan and the fp32 plan '
                              'on one XE step of the same batch and weights, dropout off -- the price of the benchmarked precision'}
+    # ---- the fast plan AT the parity bar: bf16x3 (hi / lo split activations and filters on the bf16 matrix cores, nets.CnnPlan(x3=
+    # True), COMIC_OP_X3): its deviation from the fp32 plan on the same step, and its throughput with one forward per G_X3 steps --
+    G_X3 = 5                                    # 320 images per forward (a bf16x3 buffer of 109x109x192 stays below 2^31 bytes)
+    plan_x3 = nets.CnnPlan('inception_v3', (IMG, IMG), x3=True)
+    trx1 = trainer.CaptionTrainer(cnn_params, spec0, p_same, BATCH, (IMG, IMG), 'bf16x3', device, seed=8, plan=plan_x3)
+    im_e, fm_e = trx1.encoder.forward(imgs, use_graph=False)
+    r = trx1.decoder.train_step(fm_e, im_e, caps, training=False)
+    torch.cuda.synchronize()
+    gx = dict(fm=fm_e.float().cpu().numpy(), logits=r['logits'].cpu().numpy(), loss=float(r['loss']), grads=trx1.decoder.grads.to_numpy())
+    dev_x3 = {'feature_map': rel(gx['fm'], got['f32']['fm']), 'logits': rel(gx['logits'], got['f32']['logits']),
+              'loss': abs(gx['loss'] - got['f32']['loss']) / abs(got['f32']['loss'])}
+    gk = {k: rel(gx['grads'][k], got['f32']['grads'][k]) for k in got['f32']['grads']}
+    dev_x3['grad_max'] = max(gk.values())
+    dev_x3['grad_worst'] = max(gk, key=gk.get)
+    del trx1, gx
+    trx = trainer.CaptionTrainer(cnn_params, spec0, None, BATCH, (IMG, IMG), 'bf16x3', device, seed=8, plan=plan_x3,
+                                 encoder_group=G_X3)
+    if tune:
+        trx.encoder.autotune()
+    imgs_x = torch.from_numpy(rng.uniform(-1, 1, (BATCH * G_X3, IMG, IMG, 3)).astype(np.float32)).to(device)
+
+    def x3_group():
+        im_g, fm_g = trx.encoder.forward(imgs_x, use_graph=True)
+        for j in range(G_X3):
+            rr = trx.decoder.train_step(fm_g[j * BATCH:(j + 1) * BATCH], im_g[j * BATCH:(j + 1) * BATCH], np.asarray(caps),
+                                        training=True, use_graph=trx.use_graph_decoder)
+            trx.opt.step(trx.decoder.grads, trx.lr())
+        return rr
+    for _ in range(2):
+        x3_group()
+    torch.cuda.synchronize()
+    n, t0 = 4, time.perf_counter()
+    for _ in range(n):
+        res = x3_group()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (n * G_X3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        trx.encoder.forward(imgs_x, use_graph=True)
+    e1.record(); e1.synchronize()
+    x3_ms = e0.elapsed_time(e1) / 5 / G_X3                      # per step of 64 images
+    out['xe_x3'] = {'images_per_sec': round(BATCH / dt, 1), 'ms_per_step': round(dt * 1e3, 3),
+                    'config': 'the same step with the bf16x3 CNN plan: activations stored as [hi | lo | hi] bf16 channel regions, filters '
+                              '[W_hi | W_hi | W_lo], v_mfma_f32_16x16x32_bf16 over 3x the input channels (hi*W_hi + lo*W_hi + hi*W_lo, fp32 '
+                              'accumulation), plain op order; batch 64, one forward per %d steps, not overlapped' % G_X3,
+                    'cnn_forward_ms_per_step': round(x3_ms, 3),
+                    'cnn_mfma_frac_useful': round(FLOP_PER_IMAGE_CNN * BATCH / (x3_ms * 1e-3) / PEAK_BF16_MFMA, 5),
+                    'cnn_mfma_frac_issued': round(3 * FLOP_PER_IMAGE_CNN * BATCH / (x3_ms * 1e-3) / PEAK_BF16_MFMA, 5),
+                    'bf16x3_plan_vs_f32_plan': {k: (round(v, 7) if isinstance(v, float) else v) for k, v in dev_x3.items()},
+                    'loss': round(float(res['loss']), 4),
+                    'note': 'bf16x3_plan_vs_f32_plan as bf16_plan_vs_f32_plan above; against the ORACLE the plan passes the 1e-3 end-point test '
+                            'of the fp32 plan (tests/test_gpu_path.py::test_inception_v3_forward_224_bf16x3_meets_the_fp32_bar)'}
+    del trx, imgs_x
     del tr32, tr16, got
     torch.cuda.empty_cache()
     # ---- the reference CLI's DEFAULT backbone: Inception-V1, attention over Mixed_4f = 14x14x832 (M = 196), batch 64 ------

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
   // epilogue: lane holds channels i*16 + fg*4 .. +3 of pixel mrow[t]
   if constexpr (NT == 2 && sizeof(T) == 2) {
     // 32 bf16 channels: the two tiles are exchanged row-wise (see conv_store_tiles) and a lane stores 16 bytes
-    if (!a.out_f32 && (((a.y_cs | a.y_co) & 7) == 0)) {
+    if (!a.out_f32 && !a.x3 && (((a.y_cs | a.y_co) & 7) == 0)) {
       float4 sc[2], sh[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -412,10 +412,19 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(ConvArgs a) {
       }
       if (mrow[t] < 0) continue;
       const size_t off = (size_t)mrow[t] * a.y_cs + a.y_co + n0;
-      if (sizeof(T) == 4 || a.out_f32)
+      if (sizeof(T) == 4 || a.out_f32) {
         *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
-      else
+      } else if (a.x3) {                  // COMIC_OP_X3: [hi | lo | hi] regions
+        const uint32_t h01 = pack_bf16x2(v0, v1), h23 = pack_bf16x2(v2, v3);
+        const uint32_t l01 = pack_bf16x2(v0 - __uint_as_float(h01 << 16), v1 - __uint_as_float(h01 & 0xFFFF0000u));
+        const uint32_t l23 = pack_bf16x2(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xFFFF0000u));
+        bf16_t* yp = (bf16_t*)a.y + off;
+        *(uint2*)yp = make_uint2(h01, h23);
+        *(uint2*)(yp + a.x3) = make_uint2(l01, l23);
+        *(uint2*)(yp + 2 * a.x3) = make_uint2(h01, h23);
+      } else {
         *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
     }
   }
   }
@@ -639,6 +648,69 @@ __global__ __launch_bounds__(256) void pool_kernel(ConvArgs a) {
     for (int j = 0; j < EPC; ++j) acc[j] = acc[j] / c;
   }
   store_vec<T>((T*)a.y + (size_t)pix * a.y_cs + a.y_co + cv * EPC, acc);
+}
+
+// The same pools over COMIC_OP_X3 buffers: a value is hi + lo of two channel regions.  Max: the pair with the larger hi, then
+// the larger lo (|lo| <= ulp(hi) / 2, so this is the order of hi + lo); the winning pair is copied.  Average: fp32 sum of
+// hi + lo over the valid taps, divided, split again.  Output: the three regions [hi | lo | hi].
+template <int MODE>
+__global__ __launch_bounds__(256) void pool_x3_kernel(ConvArgs a) {
+  constexpr int EPC = 8;
+  const int cvecs = a.Cin / EPC;
+  const long total = (long)a.M * cvecs;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (int)(idx % cvecs);
+  int mm = (int)(idx / cvecs);
+  const int pix = mm;
+  const int wo = mm % a.Wo;
+  mm /= a.Wo;
+  const int ho = mm % a.Ho;
+  const int b = mm / a.Ho;
+  const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
+  float hi[EPC], lo[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    hi[j] = MODE == 0 ? -INFINITY : 0.f;
+    lo[j] = 0.f;
+  }
+  int cnt = 0;
+  for (int kh = 0; kh < a.KH; ++kh) {
+    const int hy = ho * a.SH - a.PT + kh;
+    if ((unsigned)hy >= (unsigned)a.H) continue;
+    for (int kw = 0; kw < a.KW; ++kw) {
+      const int wx = wo * a.SW - a.PL + kw;
+      if ((unsigned)wx >= (unsigned)a.W) continue;
+      float vh[EPC], vl[EPC];
+      const bf16_t* src = xg + ((size_t)(b * a.H + hy) * a.W + wx) * a.x_cs + a.x_co + cv * EPC;
+      load_vec<bf16_t>(src, vh);
+      load_vec<bf16_t>(src + a.x3_src, vl);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        if (MODE == 0) {
+          const bool take = vh[j] > hi[j] || (vh[j] == hi[j] && vl[j] > lo[j]);
+          hi[j] = take ? vh[j] : hi[j];
+          lo[j] = take ? vl[j] : lo[j];
+        } else {
+          hi[j] += vh[j] + vl[j];
+        }
+      }
+      ++cnt;
+    }
+  }
+  if (MODE == 1) {
+    const float c = (float)cnt;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const float v = hi[j] / c;
+      hi[j] = bf16_to_f32(f32_to_bf16(v));
+      lo[j] = v - hi[j];
+    }
+  }
+  bf16_t* dst = (bf16_t*)a.y + (size_t)pix * a.y_cs + a.y_co + cv * EPC;
+  store_vec<bf16_t>(dst, hi);
+  store_vec<bf16_t>(dst + a.x3, lo);
+  store_vec<bf16_t>(dst + 2 * a.x3, hi);
 }
 
 // 3x3 stride-1 SAME max-pool (the pool branches of the Inception-V1 / V3 blocks) as one thread per (image row, channel
@@ -1439,7 +1511,7 @@ bool ws_group_eligible(const comic_cnn_op* ops, int n) {
     if (o.src != ops[0].src || o.src_coff != ops[0].src_coff || o.Cin != ops[0].Cin || o.H != ops[0].H ||
         o.W != ops[0].W || o.Ho != ops[0].Ho || o.Wo != ops[0].Wo || (o.flags & COMIC_OP_POOLED_SRC) != (ops[0].flags & COMIC_OP_POOLED_SRC))
       return false;
-    if (o.Cout % 16 != 0) return false;
+    if (o.Cout % 16 != 0 || (o.flags & COMIC_OP_X3)) return false;   // (conv_ws.hip has its own epilogue: plain stores)
     tiles += o.Cout / 16;
   }
   const comic_cnn_op& o = ops[0];
@@ -1619,6 +1691,10 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.w_frag = wt ? wt->w_frag : nullptr;
   a.min_lds = std::min(std::max(op->min_lds, 0), 160 * 1024);
   a.remap = 1;
+  // COMIC_OP_X3: bf16 buffers hold [hi | lo | hi] regions of a third of their channels each
+  const bool x3 = (op->flags & COMIC_OP_X3) != 0;
+  a.x3 = (x3 && !op->out_f32) ? y_channels / 3 : 0;
+  a.x3_src = (x3 && op->kind >= 2 && op->kind <= 3) ? x_channels / 3 : 0;
   return 0;
 }
 
@@ -1640,7 +1716,9 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "conv: Cin/offset/stride must be multiples of %d", EPC);
       COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
                     "conv: Cout must be a multiple of 16 (got %d)", op->Cout);
-      COMIC_REQUIRE(op->dst_coff + op->Cout <= yc, "conv: destination channel slice out of range");
+      COMIC_REQUIRE(op->dst_coff + op->Cout <= (a.x3 ? a.x3 : yc), "conv: destination channel slice out of range");
+      COMIC_REQUIRE(!(op->flags & COMIC_OP_X3) || (sizeof(T) == 2 && yc % 3 == 0 && (yc / 3) % 4 == 0 && !accum),
+                    "conv: COMIC_OP_X3 needs a bf16 plan and a destination of three equal channel regions");
       if constexpr (sizeof(T) == 2) {
         COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
         COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "conv: activation tensor too large");
@@ -1689,6 +1767,20 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "pool: channel counts/offsets must be multiples of %d", EPC);
       COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool: destination channel slice out of range");
       const long total = (long)a.M * (op->Cin / EPC);
+      if (op->flags & COMIC_OP_X3) {
+        if constexpr (sizeof(T) == 2) {
+          COMIC_REQUIRE(xc % 3 == 0 && yc % 3 == 0 && a.x3 > 0 && a.x3_src > 0 && op->src_coff + op->Cin <= a.x3_src &&
+                            op->dst_coff + op->Cin <= a.x3 && a.x3 % 8 == 0 && a.x3_src % 8 == 0,
+                        "pool (x3): channel regions do not fit the buffers");
+          if (op->kind == 2)
+            hipLaunchKernelGGL((pool_x3_kernel<0>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+          else
+            hipLaunchKernelGGL((pool_x3_kernel<1>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, a);
+          break;
+        } else {
+          COMIC_REQUIRE(false, "pool: COMIC_OP_X3 is a bf16-plan layout");
+        }
+      }
       // row-walking form when there are enough rows to occupy the chip (op->tile: 1 forces it, 2 forces the per-pixel form)
       if (op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1 && op->PT == 1 && op->PL == 1 &&
           op->Ho == op->H && op->Wo == op->W &&

@@ -26,6 +26,8 @@ struct ConvArgs {
   int member_kind;   // grouped launch: 0 conv tile, 1 pool + BN + ReLU (kind 7) work items
   int min_lds;       // host only: lower bound on the dynamic LDS of the launch (comic_cnn_op::min_lds)
   const void* w_frag; // host only: the weights in MFMA-fragment order (comic_conv_weight::w_frag), or null
+  int x3;            // COMIC_OP_X3: channel stride between the [hi | lo | hi] regions of the bf16 destination (0: plain store)
+  int x3_src;        // pools of a COMIC_OP_X3 plan: the same for the source buffer
 };
 
 namespace {
@@ -94,6 +96,30 @@ __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&ac
   }
   const float lo = a.relu ? 0.f : -INFINITY;             // relu as one v_max per value
   const int esz = a.out_f32 ? 4 : 2;
+  if (a.x3 && !a.out_f32) {    // COMIC_OP_X3: v -> hi = bf16(v), lo = bf16(v - hi), stored as regions [hi | lo | hi]
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const bool mok = mrow[j] >= 0;
+      unsigned char* yrow = (unsigned char*)a.y + ((size_t)(mok ? mrow[j] : 0) * a.y_cs + a.y_co + nbase + nq) * 2;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        float v[4] = {fmaf(acc[i][j][0], sc[i].x, sh[i].x), fmaf(acc[i][j][1], sc[i].y, sh[i].y),
+                      fmaf(acc[i][j][2], sc[i].z, sh[i].z), fmaf(acc[i][j][3], sc[i].w, sh[i].w)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+        const uint32_t h01 = pack_bf16x2(v[0], v[1]), h23 = pack_bf16x2(v[2], v[3]);
+        const uint32_t l01 = pack_bf16x2(v[0] - __uint_as_float(h01 << 16), v[1] - __uint_as_float(h01 & 0xFFFF0000u));
+        const uint32_t l23 = pack_bf16x2(v[2] - __uint_as_float(h23 << 16), v[3] - __uint_as_float(h23 & 0xFFFF0000u));
+        if (nv[i] & mok) {
+          unsigned char* yp = yrow + i * 32;
+          *(uint2*)yp = make_uint2(h01, h23);
+          *(uint2*)(yp + (size_t)a.x3 * 2) = make_uint2(l01, l23);
+          *(uint2*)(yp + (size_t)a.x3 * 4) = make_uint2(h01, h23);
+        }
+      }
+    }
+    return;
+  }
   // bf16, plain store, 16-byte aligned pixel rows: pairs of channel tiles are written as 16 B per lane.  A lane
   // holds channels [4q, 4q+4) of both tiles (q = lane >> 4); v_permlane16_swap exchanges the odd 16-lane rows of
   // tile i with the even rows of tile i+1, after which rows 0 / 2 hold channels [0,8) / [8,16) of tile i and rows

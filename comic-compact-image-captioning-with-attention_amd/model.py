@@ -51,8 +51,13 @@ class ModelBase(object):
         if 'plan' not in share:
             # frozen CNN (every mode but cnn_finetune): forward-only plan with the pool branches rewritten
             frozen = bool(getattr(c, 'freeze_scopes', 'Model/encoder/cnn'))
+            # --cnn_dtype bf16x3: hi / lo split activations and filters on the bf16 kernels (nets.CnnPlan(x3=True)),
+            # the fast plan at the fp32 parity bar; frozen-CNN modes only (no backward over the split layout)
+            x3 = getattr(c, 'cnn_dtype', 'bf16') == 'bf16x3'
+            if x3 and not frozen:
+                raise ValueError('cnn_dtype bf16x3 is a forward-only plan: use bf16 or f32 for train_mode cnn_finetune')
             plan = nets.get_network_fn(c.cnn_name, num_classes=None, is_training=False)(
-                tuple(c.cnn_input_size), c.cnn_fm_attention, pool_after_projection=frozen, fuse_pools=frozen)
+                tuple(c.cnn_input_size), c.cnn_fm_attention, pool_after_projection=frozen, fuse_pools=frozen, x3=x3)
             share['plan'] = plan
             share['cnn_params'] = plan.init_params(seed=c.rand_seed % (2 ** 31))
             fm = plan.fm_dims()
@@ -88,7 +93,7 @@ class ModelBase(object):
             # config.cnn_autotune is False; the trainable CNN keeps the heuristic choice (its plan differs).
             H, W = self.plan.buffers[self.plan.input][:2]
             c = self._config
-            if (getattr(c, 'cnn_autotune', True) and dtype == 'bf16' and str(self.device).startswith('cuda')
+            if (getattr(c, 'cnn_autotune', True) and dtype in ('bf16', 'bf16x3') and str(self.device).startswith('cuda')
                     and batch_size * H * W >= 16 * 224 * 224 and getattr(c, 'freeze_scopes', 'Model/encoder/cnn')):
                 log_path = getattr(c, 'log_path', None)
                 cache = os.path.join(log_path, 'conv_variants.json') if log_path and os.path.isdir(log_path) else None

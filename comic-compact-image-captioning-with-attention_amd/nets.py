@@ -118,7 +118,7 @@ class CnnPlan:
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
                  group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None,
-                 fuse_pools=False):
+                 fuse_pools=False, x3=False):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -163,6 +163,19 @@ class CnnPlan:
             self._build_v1(image_size, 'Mixed_4f' if final_endpoint == 'Mixed_7c' else final_endpoint)
         else:
             self._build_v3(image_size, final_endpoint)
+        # "bf16x3": fp32-class accuracy on the bf16 kernels (COMIC_OP_X3, include/comic_hip.h).  Every bf16 activation
+        # buffer holds its tensor as three channel regions [hi | lo | hi]; a conv reads all 3C channels against a filter
+        # packed [W_hi | W_hi | W_lo] per tap (CnnEncoder), i.e. hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation.
+        self.x3 = bool(x3)
+        if self.x3:
+            if pool_after_projection or fuse_pools or self._logical or name == 'inception_v1':
+                raise ValueError('x3 plans: plain InceptionV3 / chain layouts only (no pool rewrites, no padded channels)')
+            for o in self.ops:
+                if o['kind'] == 0:
+                    o['Cin'] *= 3
+                if o['kind'] in (0, 1, 2, 3):
+                    o['flags'] = o.get('flags', 0) | L.OP_X3
+            self.buffers = [(H, W, Cc if f32 else 3 * Cc, f32) for (H, W, Cc, f32) in self.buffers]
 
     # -- builder helpers ---------------------------------------------------------------
     def _buf(self, H, W, Cc, f32=False):
@@ -549,6 +562,10 @@ class CnnEncoder:
         from .decoder import FlatParams
         self.torch = torch
         self.lib = L.load()
+        if dtype == 'bf16x3':              # the bf16 kernels over an x3 plan (CnnPlan(x3=True)): fp32-class accuracy
+            assert getattr(plan, 'x3', False), "dtype 'bf16x3' needs a plan built with x3=True"
+            dtype = 'bf16'
+        assert dtype in ('bf16', 'f32') and (dtype == 'bf16' or not getattr(plan, 'x3', False))
         self.plan, self.batch, self.dtype, self.device = plan, batch, dtype, device
         self.dcode = 1 if dtype == 'bf16' else 0
         if getattr(plan, 'fuse_pools', False) and dtype != 'bf16':
@@ -567,6 +584,8 @@ class CnnEncoder:
             self.w_master, self.beta, self.mean, self.scale, self.shift = o.w_master, o.beta, o.mean, o.scale, o.shift
             self.w_plan, wt = o.w_plan, o._wt
             self.w_frag, self._frag_table = o.w_frag, o._frag_table
+            self._x3_off = o._x3_off
+            assert getattr(o.plan, 'x3', False) == getattr(plan, 'x3', False)
         else:
             wshapes, bshapes = flat_layout(plan)
             self.w_master = FlatParams(wshapes, device)
@@ -575,10 +594,22 @@ class CnnEncoder:
             self.scale.data.fill_(1.0)
             self.w_plan = self.w_master.data if self.dcode == 0 else torch.zeros(self.w_master.numel, dtype=tdt,
                                                                                   device=device)
+            # x3 plans: the plan copy holds [W_hi | W_hi | W_lo] per filter tap, rows of roundup64(3K) elements
+            self._x3_off = None
+            if getattr(plan, 'x3', False):
+                assert self.dcode == 1, 'x3 plans run on the bf16 kernels'
+                offs, n = [], 0
+                for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
+                    cin_p, cout_p = plan.wphys[i]
+                    offs.append(n)
+                    if not stem:
+                        n += cout_p * ((3 * kh * kw * cin_p + 63) // 64 * 64)
+                self._x3_off = offs
+                self.w_plan = torch.zeros(max(n, 64), dtype=tdt, device=device)
             # bf16 plans: a second copy of the weights in MFMA-fragment order for the image-resident kernel
             # (csrc/conv_img.hip), refreshed with the plan copy; table = {element offset, Cout, Kpad} per weight
             self.w_frag, self._frag_table = None, None
-            if self.dcode == 1:
+            if self.dcode == 1 and self._x3_off is None:
                 self.w_frag = torch.zeros(self.w_master.numel, dtype=tdt, device=device)
                 tab = []
                 for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
@@ -593,7 +624,8 @@ class CnnEncoder:
                 bk = 'b%d' % i
                 esz = 4 if (stem or self.dcode == 0) else 2
                 wbase = self.w_master.data.data_ptr() if (stem or self.dcode == 0) else self.w_plan.data_ptr()
-                wt[i].w = wbase + esz * self.w_master.offsets['w%d' % i]
+                wt[i].w = wbase + esz * (self._x3_off[i] if (self._x3_off is not None and not stem) else
+                                         self.w_master.offsets['w%d' % i])
                 wt[i].scale = self.scale.view(bk).data_ptr()
                 wt[i].shift = self.shift.view(bk).data_ptr()
                 if self.w_frag is not None and not stem:
@@ -678,7 +710,9 @@ class CnnEncoder:
     def refresh_weights(self):
         """Re-derive what the forward reads from the fp32 masters: the plan-dtype weight copy and
         shift = beta - mean*scale (after loading a checkpoint or an optimiser step)."""
-        plan_copy = self.w_plan.data_ptr() if self.dcode == 1 else None
+        plan_copy = self.w_plan.data_ptr() if (self.dcode == 1 and self._x3_off is None) else None
+        if self._x3_off is not None:
+            self._pack_x3()
         L.check(self.lib.comic_cnn_refresh_weights(self.w_master.data.data_ptr(), plan_copy, self.w_master.numel,
                                                    self.beta.data.data_ptr(), self.mean.data.data_ptr(),
                                                    self.scale.data.data_ptr(), self.shift.data.data_ptr(),
@@ -700,6 +734,23 @@ class CnnEncoder:
                                                             L.stream_ptr()), 'cnn_pack_bwd_filters')
                 t.filters_ev.record(t.aux)
             t.filters_ver = self.w_master.__dict__['_ver']
+
+    def _pack_x3(self):
+        """The x3 plan copy of every conv filter from its fp32 master [Cout][Kpad]: per tap the channels
+        [bf16(w) | bf16(w) | bf16(w - bf16(w))] against activations stored [hi | lo | hi] (COMIC_OP_X3).  Tensor glue at
+        load / after an optimiser step of a frozen-CNN plan (torch ops, 94 small tensors)."""
+        torch = self.torch
+        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
+            if stem:
+                continue
+            cin_p, cout_p = self.plan.wphys[i]
+            K = kh * kw * cin_p
+            kpad, kpad3 = (K + 63) // 64 * 64, (3 * K + 63) // 64 * 64
+            m = self.w_master.view('w%d' % i).view(cout_p, kpad)[:, :K].reshape(cout_p, kh * kw, cin_p)
+            hi = m.to(torch.bfloat16)
+            lo = (m - hi.to(torch.float32)).to(torch.bfloat16)
+            dst = self.w_plan[self._x3_off[i]:self._x3_off[i] + cout_p * kpad3].view(cout_p, kpad3)
+            dst[:, :3 * K] = torch.cat([hi, hi, lo], dim=2).reshape(cout_p, 3 * K)
 
     def _unpack(self, i, flat_w, flat_b):
         """Packed master-layout buffers of weight i -> (HWIO array, per-channel vector) of the variable's shape."""
@@ -770,8 +821,8 @@ class CnnEncoder:
         if self._train is not None:
             return self._train
         torch, plan = self.torch, self.plan
-        if plan.pool_after_projection:
-            raise ValueError('cnn_finetune needs a plan built with pool_after_projection=False (forward-only rewrite)')
+        if plan.pool_after_projection or getattr(plan, 'x3', False):
+            raise ValueError('cnn_finetune needs a plan built with pool_after_projection=False and x3=False (forward-only layouts)')
         t = type('CnnTrainState', (), {})()
         t.dw, t.dbeta = self.w_master.like(), self.beta.like()
         sizes, total = [], 0
@@ -951,7 +1002,8 @@ class CnnEncoder:
         p = self.plan
         H, W = p.buffers[p.input][:2]
         return '%s:%dx%d:B%d:%s%s:%dops:polite%d' % (p.name, H, W, self.batch, 'par' if p.pool_after_projection else 'plain',
-                                                    '+fp' if getattr(p, 'fuse_pools', False) else '',
+                                                    ('+fp' if getattr(p, 'fuse_pools', False) else '') +
+                                                    ('+x3' if getattr(p, 'x3', False) else ''),
                                                   len(p.ops), self.polite_lds_kb)
 
     def autotune(self, reps=5, verbose=False, cache=None):
@@ -1071,7 +1123,11 @@ class CnnEncoder:
         return chosen
 
     def end_point(self, name):
-        return self.bufs[self.plan.end_points[name]]
+        b = self.bufs[self.plan.end_points[name]]
+        if getattr(self.plan, 'x3', False) and b.dtype != self.torch.float32:
+            C3 = b.shape[-1] // 3                   # [hi | lo | hi] regions (COMIC_OP_X3): the value is hi + lo
+            return b[..., :C3].float() + b[..., C3:2 * C3].float()
+        return b
 
     @property
     def flops_per_image(self):
@@ -1086,9 +1142,9 @@ def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
     if is_training:
         raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
 
-    def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False, fuse_pools=False):
-        par = pool_after_projection and name == 'inception_v3'
+    def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False, fuse_pools=False, x3=False):
+        par = pool_after_projection and name == 'inception_v3' and not x3
         return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'),
-                       pool_after_projection=par, fuse_pools=fuse_pools and par)
+                       pool_after_projection=par, fuse_pools=fuse_pools and par, x3=x3)
     network_fn.default_image_size = 224 if name == 'inception_v1' else 299
     return network_fn

@@ -111,6 +111,17 @@ typedef struct comic_cnn_op {
                                    max-pool (H, W = the un-pooled source, Ho, Wo = the pooled grid); the pooled map is never
                                    materialised (slim.max_pool2d + slim.conv2d 1x1, inception_v3.py:111-114,124-199) */
 
+#define COMIC_OP_X3 4           /* bit 2, bf16 plans at fp32-class accuracy ("bf16x3" plans): every bf16 activation buffer
+                                   holds a tensor of C channels as THREE channel regions [hi | lo | hi] of its 3C physical
+                                   channels -- hi = bf16(v), lo = bf16(v - hi) -- and a conv's packed filter holds
+                                   [W_hi | W_hi | W_lo] per tap, so that the ordinary bf16 product over 3C input channels is
+                                   hi*W_hi + lo*W_hi + hi*W_lo: the split-bf16 product of the decoder's GEMMs (~2^-16 per
+                                   product, fp32 accumulation) on the unchanged conv kernels.  With the bit set a conv /
+                                   stem conv stores its bf16 output as the three regions (region stride = a third of the
+                                   destination buffer's channels; Cout, dst_coff count channels of ONE region) and a pool
+                                   reads hi + lo and writes the three regions (Cin = channels of one region).  fp32
+                                   outputs (out_f32) are stored once, as always. */
+
 typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */
   const float* scale;  /* [Cout] */

@@ -2,7 +2,7 @@
 """train.py -- same flags, mode chaining, run-directory naming and kwargs as the reference
 CLI (reference src/train.py:25-312), driving the MI355X-native path.
 
-Differences (all additive): `--cnn_dtype {bf16,f32}`, `--checkpoint_format {npz,tf}`; launched under
+Differences (all additive): `--cnn_dtype {bf16,f32,bf16x3}`, `--checkpoint_format {npz,tf}`; launched under
 `python -m torch.distributed.run --nproc-per-node N` it trains data-parallel (one process
 per GPU, RCCL gradient all-reduce); the slim checkpoint is not downloaded (no network):
 pass `--checkpoint_path` (an .npz with slim variable names) or train the CNN from random init.
@@ -69,7 +69,9 @@ def create_parser():
     a('--gpu', type=str, default='0', help='The gpu number.')
     a('--run', type=int, default=1, help='The run number.')
     # additions of this framework
-    a('--cnn_dtype', type=str, default='bf16', choices=['bf16', 'f32'], help='CNN activation / MFMA input type.')
+    a('--cnn_dtype', type=str, default='bf16', choices=['bf16', 'f32', 'bf16x3'],
+      help='CNN activation / MFMA input type.  bf16x3: hi/lo-split activations and filters on the bf16 matrix cores '
+           '(fp32-class accuracy, frozen-CNN modes).')
     a('--checkpoint_format', type=str, default='npz', choices=['npz', 'tf'],
       help='Container of saved checkpoints: .npz or the TF checkpoint-V2 tensor bundle (both restore).')
     a('--log_root', type=str, default='', help='Root of the experiments directory (default: ../experiments).')
