@@ -120,11 +120,14 @@ def extras(device, enc, cnn_params, plan):
     torch.cuda.synchronize()
     steps_ex = int(r['predicted_ids'].shape[0])
     us_step = (time.perf_counter() - t0) / n / steps_ex * 1e6
-    bytes_step = spec.D * V * 4 + B * 3 * V * 4
+    # bytes that move per step: W_o and the LSTM kernel once each (packed hi / lo bf16 = 4 bytes per weight); the streaming
+    # projection never writes its logits, so none are counted
+    bytes_step = spec.D * V * 4 + (spec.E + spec.A + spec.D) * 4 * spec.D * 4
     out['beam3_roofline'] = {'bound': 'hbm', 'bytes_per_step': bytes_step, 'us_per_step': round(us_step, 1),
                              'achieved': round(bytes_step / us_step / 1e3, 1), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(bytes_step / us_step / 1e3 / 8000.0, 4),
-                             'note': 'whole decode step (streaming LSTM, attention, streaming logits + top-k, merge) over the bytes of W_o and of a full logits write'}
+                             'note': 'whole decode step (streaming LSTM, attention, streaming logits + top-k, merge) over the bytes of W_o '
+                                     'and of the LSTM kernel, each streamed once per step for all 150 rows'}
     del dec, enc50
     # ---- SCST step, COMIC-256 -------------------------------------------------------------
     Bs, W = 32, 7
@@ -545,8 +548,8 @@ def cpu_baseline(seconds_budget=20.0):
             break
     dt = time.time() - t0
     out = dict(value=round(n * B / dt, 3), unit='images/sec', cores=os.cpu_count(), kind='port',
-               sample='%d decoder-mode XE steps at batch %d (InceptionV3 fwd + decoder fwd/bwd + SGD update), '
-                      'numpy/OpenBLAS oracle on all host cores' % (n, B))
+               sample='%d decoder-mode XE steps at batch %d (BASELINE configs[0], a plumbing-size batch: InceptionV3 fwd + decoder '
+                      'fwd/bwd + SGD update), numpy/OpenBLAS oracle on all host cores' % (n, B))
     # the "framework CPU path" stand-in of BASELINE.md section 3.2(b): the same step on torch-CPU (oneDNN convolutions,
     # autograd backward of the decoder, TF-Adam), fp32 -- the literal TF-1 binary is not installable here
     try:
@@ -562,8 +565,8 @@ def cpu_baseline(seconds_budget=20.0):
             if time.time() - t1 > 10.0 or m >= 8:
                 break
         out['torch_cpu'] = dict(value=round(m * B / (time.time() - t1), 3), unit='images/sec', threads=torch.get_num_threads(),
-                                sample='%d steps at batch %d: torch %s CPU, oneDNN conv forward + autograd decoder backward + '
-                                       'TF-Adam, fp32' % (m, B, torch.__version__))
+                                sample='%d steps at batch %d (BASELINE configs[0]: a plumbing-size batch, not a tuned CPU run): torch %s '
+                                       'CPU, oneDNN conv forward + autograd decoder backward + TF-Adam, fp32' % (m, B, torch.__version__))
     except Exception as e:
         out['torch_cpu'] = {'error': repr(e)}
     return out

@@ -122,6 +122,35 @@ def test_train_infer_cli_default_backbone(tmp_path):
     assert caps and len(json.load(open(caps[0]))) == 4
 
 
+def test_train_infer_cli_bf16x3_plan(tmp_path):
+    """--cnn_dtype bf16x3 (the bf16 matrix cores at fp32-class accuracy: nets.CnnPlan(x3=True)): one decoder-mode epoch on
+    InceptionV3 and beam-3 inference from the run directory (the plan follows config.pkl); cnn_finetune refuses the
+    forward-only layout at build time."""
+    from tests import tiny_dataset
+    from comic_amd import configuration as conf
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=4, n_test=4)
+    logs = str(tmp_path / 'experiments')
+    common = ['--dataset_dir', ds, '--log_root', logs, '--cnn_name', 'inception_v3', '--cnn_fm_attention', 'Mixed_7c',
+              '--cnn_input_size', '139,139', '--batch_size_eval', '4', '--rnn_size', '128', '--rnn_word_size', '64',
+              '--cnn_dtype', 'bf16x3']
+    _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'decoder', '--batch_size_train', '4',
+                                                          '--max_epoch', '1'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01')
+    assert conf.load_config(os.path.join(run_dir, 'config.pkl')).cnn_dtype == 'bf16x3'
+    assert sorted(glob.glob(os.path.join(run_dir, 'model_compact-*.npz')))
+    _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--get_metric_score', ''])
+    caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
+    assert caps and len(json.load(open(caps[0]))) == 4
+    from comic_amd import nets
+    with pytest.raises(ValueError):
+        px = nets.CnnPlan('inception_v3', (139, 139), x3=True)
+        nets.CnnEncoder(px, px.init_params(0), 2, 'bf16x3', 'cuda:0').enable_training()
+
+
 @pytest.mark.parametrize('rnn,var', [('LN_LSTM', 'layer_norm_basic_lstm_cell/state/gamma'), ('GRU', 'gru_cell/candidate/kernel')])
 def test_train_infer_cli_other_cells(tmp_path, rnn, var):
     """--rnn_name LN_LSTM / GRU (train.py:73-75, model_base.py:622-629): one decoder-mode epoch, the cell's variables under
