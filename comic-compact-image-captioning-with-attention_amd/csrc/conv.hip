@@ -2089,25 +2089,39 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       st = lanes->s[op->lane - 1];
       used[op->lane - 1] = true;
     }
-    if (op->kind == 8) {      // streaming Conv2d_2a -> Conv2d_2b -> MaxPool_3a (conv_stem.hip); weights[op->weight], [op->weight + 1]
+    if (op->kind == 8 || op->kind == 9) {
+      // streaming Conv2d_2a -> Conv2d_2b -> MaxPool_3a (conv_stem.hip); weights[op->weight], [op->weight + 1].
+      // kind 9: Conv2d_1a_3x3 inside the same pass -- src is the fp32 image (H, W = the image), the weight records are
+      // Conv2d_1a (stem layout), Conv2d_2a, Conv2d_2b
+      const bool with_1a = op->kind == 9;
+      const int H0 = with_1a ? (op->H - 3) / 2 + 1 : op->H, W0 = with_1a ? (op->W - 3) / 2 + 1 : op->W;
       COMIC_REQUIRE(dtype == COMIC_BF16 && op->lane == 0, "stem stream: bf16 plans on the caller's stream only");
-      COMIC_REQUIRE(op->Cin == 32 && op->Cout == 64 && op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1,
-                    "stem stream: expects the 32 -> 32 -> 64 3x3 stem (got Cin %d, Cout %d)", op->Cin, op->Cout);
-      COMIC_REQUIRE(comic_stem_stream_supported(op->H, op->W), "stem stream: map %dx%d is not supported", op->H, op->W);
-      const int Hp = (op->H - 2 - 3) / 2 + 1, Wp = (op->W - 2 - 3) / 2 + 1;
+      COMIC_REQUIRE(op->Cin == (with_1a ? 3 : 32) && op->Cout == 64 && op->KH == 3 && op->KW == 3 && op->SH == 1 && op->SW == 1,
+                    "stem stream: expects the (3 ->) 32 -> 32 -> 64 3x3 stem (got Cin %d, Cout %d)", op->Cin, op->Cout);
+      COMIC_REQUIRE(comic_stem_stream_supported(H0, W0) && (!with_1a || comic_stem_stream_1a_supported(op->H, op->W)),
+                    "stem stream: map %dx%d is not supported", op->H, op->W);
+      const int Hp = (H0 - 2 - 3) / 2 + 1, Wp = (W0 - 2 - 3) / 2 + 1;
       COMIC_REQUIRE(op->Ho == Hp && op->Wo == Wp, "stem stream: Ho/Wo must be the pooled grid %dx%d", Hp, Wp);
-      const comic_conv_weight* wa = weights + op->weight;
-      const comic_conv_weight* wb = weights + op->weight + 1;
+      const comic_conv_weight* w0 = with_1a ? weights + op->weight : nullptr;
+      const comic_conv_weight* wa = weights + op->weight + (with_1a ? 1 : 0);
+      const comic_conv_weight* wb = wa + 1;
       const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
       COMIC_REQUIRE(buffers[op->src] && buffers[op->dst] && wa->w && wb->w && wa->scale && wa->shift && wb->scale && wb->shift,
                     "stem stream: null buffer / weights");
-      COMIC_REQUIRE(op->src_coff + 32 <= xc && xc % 8 == 0 && op->src_coff % 8 == 0 && op->dst_coff + 64 <= yc &&
-                        yc % 4 == 0 && op->dst_coff % 4 == 0, "stem stream: bad channel slices");
-      COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31) && (long)batch * Hp * Wp * yc * 2 < (1L << 31),
-                    "stem stream: tensor too large");
-      ComicStemArgs sa;
-      sa.x = (const bf16_t*)buffers[op->src];
-      sa.B = batch; sa.H0 = op->H; sa.W0 = op->W; sa.x_cs = xc; sa.x_co = op->src_coff;
+      COMIC_REQUIRE(op->dst_coff + 64 <= yc && yc % 4 == 0 && op->dst_coff % 4 == 0, "stem stream: bad destination slice");
+      COMIC_REQUIRE((long)batch * Hp * Wp * yc * 2 < (1L << 31), "stem stream: tensor too large");
+      ComicStemArgs sa{};
+      if (with_1a) {
+        COMIC_REQUIRE(w0->w && w0->scale && w0->shift && xc == 3 && op->src_coff == 0, "stem stream: Conv2d_1a needs the whole fp32 image");
+        sa.img = (const float*)buffers[op->src]; sa.Hi = op->H; sa.Wi = op->W;
+        sa.w0 = (const float*)w0->w; sa.sc0 = w0->scale; sa.sh0 = w0->shift;
+        sa.x = nullptr; sa.x_cs = 32; sa.x_co = 0;
+      } else {
+        COMIC_REQUIRE(op->src_coff + 32 <= xc && xc % 8 == 0 && op->src_coff % 8 == 0, "stem stream: bad source slice");
+        COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "stem stream: tensor too large");
+        sa.x = (const bf16_t*)buffers[op->src]; sa.x_cs = xc; sa.x_co = op->src_coff;
+      }
+      sa.B = batch; sa.H0 = H0; sa.W0 = W0;
       sa.w1 = (const bf16_t*)wa->w; sa.w2 = (const bf16_t*)wb->w; sa.Kpad = (9 * 32 + 63) / 64 * 64;
       sa.sc1 = wa->scale; sa.sh1 = wa->shift; sa.sc2 = wb->scale; sa.sh2 = wb->shift;
       sa.y = (bf16_t*)buffers[op->dst]; sa.y_cs = yc; sa.y_co = op->dst_coff; sa.Hp = Hp; sa.Wp = Wp;

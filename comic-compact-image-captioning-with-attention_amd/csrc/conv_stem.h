@@ -12,7 +12,13 @@ struct ComicStemArgs {
   bf16_t* y;              // pooled output [B][Hp][Wp][y_cs], channels [y_co, y_co + 64)
   int y_cs, y_co, Hp, Wp;
   int n_tasks;            // 2 * B: (image, half of the pooled rows)
+  // op kind 9 (Conv2d_1a_3x3 inside the pass): the fp32 image instead of x; null = kind 8
+  const float* img;       // [B][Hi][Wi][3]
+  int Hi, Wi;
+  const float* w0;        // Conv2d_1a filter, stem layout fp32 [27][32]
+  const float *sc0, *sh0;
 };
 
 bool comic_stem_stream_supported(int H0, int W0);
+bool comic_stem_stream_1a_supported(int Hi, int Wi);
 int comic_stem_stream_launch(const ComicStemArgs& a, hipStream_t st);

@@ -24,6 +24,13 @@
 // pooling window inside one accumulator register), Y1 wave (p, h) channels [16p, 16p+16) x pixels [64h, 64h+64).
 // k order per accumulator = taps ascending = the im2col kernels' order: the pooled map is bit-identical to the three
 // separate launches (tests/test_gpu_path.py).
+//
+// FUSE1A (op kind 9): Conv2d_1a_3x3 (3x3 / 2 VALID, 3 -> 32, inception_v3.py:100-104) joins the pass.  The Y1 waves no
+// longer load X0 rows: they load the fp32 IMAGE rows (two new rows of 224 x 3 floats per step, 16-byte loads, two steps
+// ahead -> a 16-row LDS ring), gather the 27-deep im2col operand of X0 row q+3 from the ring (k = 8 fg + s of the lane,
+// the stand-alone stem kernel's lane -> k map), split it into bf16 hi / lo and issue the same hi*hi + hi*lo + lo*hi
+// 16x16x32 MFMAs, BatchNorm + ReLU epilogue and bf16 rounding as conv_stem_mfma_kernel -- X0 is bit-identical to the
+// separate launch, but the 1.0 GB it wrote and this kernel re-read per 1280 images never exist (the image is 0.77 GB).
 #include <algorithm>
 
 #include "conv_common.h"
@@ -36,6 +43,7 @@ constexpr int kRowPx = 132;              // pixels per ring row (W0 <= 116, + ti
 constexpr int kRowB = kRowPx * kPxB;
 constexpr int kRing = 4;
 constexpr int kTableFloats = 2 * (32 + 64);
+constexpr int kImgRing = 16;             // FUSE1A: image rows resident in LDS (fp32, Wi * 3 floats each)
 
 #define STEM_BARRIER()                                    \
   do {                                                    \
@@ -48,11 +56,13 @@ constexpr int kTableFloats = 2 * (32 + 64);
 __device__ __forceinline__ float row_next1(float v) { return dpp_move<0x12F>(v, v); }
 __device__ __forceinline__ float row_next2(float v) { return dpp_move<0x12E>(v, v); }
 
+template <bool FUSE1A>
 __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* table = (float*)smem;                                   // sc1[32] sh1[32] sc2[64] sh2[64]
   unsigned char* xring = smem + kTableFloats * 4;
   unsigned char* yring = xring + kRing * kRowB;
+  float* imgring = (float*)(yring + kRing * kRowB);              // FUSE1A: [kImgRing][Wi * 3]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,6 +79,8 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
     table[128 + tid] = a.sh2[tid];
   }
   for (int i = tid; i < kRing * kRowPx * (kPxB / 16); i += 512) *(uint4*)(yring + i * 16) = make_uint4(0, 0, 0, 0);
+  if constexpr (FUSE1A)   // finite contents from the start: the k >= 27 operand positions meet zero weights
+    for (int i = tid; i < kImgRing * a.Wi * 3 / 4; i += 512) *(float4*)(imgring + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t x_lane = (uint32_t)(fr * kPxB + fg * 16);
@@ -119,6 +131,95 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) w1[tap] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(wp1 + tap * 32));
     }
+    // ---- FUSE1A: Conv2d_1a from the image ------------------------------------------------------------------------------
+    const int rowf = a.Wi * 3, row4 = rowf >> 2;          // floats / 16-byte pieces per image row (Wi % 4 == 0)
+    // the two NEW image rows of X0 row j (2j+1, 2j+2: contiguous in memory), two 16-byte pieces a thread
+    struct ImgRows { float4 c0, c1; };
+    auto x0_wanted = [&](int j) { return j >= 0 && j < a.H0; };
+    auto load_img = [&](int b, int j) {
+      ImgRows v;
+      const int jc = min(max(j, 0), a.H0 - 1);
+      const float4* src = (const float4*)(a.img + ((size_t)b * a.Hi + 2 * jc + 1) * rowf);
+      v.c0 = src[min(ltid, 2 * row4 - 1)];
+      v.c1 = src[min(ltid + 256, 2 * row4 - 1)];
+      return v;
+    };
+    auto store_img = [&](int j, const ImgRows& v) {
+      if (!x0_wanted(j)) return;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = ltid + 256 * e;
+        if (i < 2 * row4) {
+          const int r = 2 * j + 1 + (i >= row4 ? 1 : 0), c4 = i >= row4 ? i - row4 : i;
+          *(float4*)(imgring + (size_t)(r & (kImgRing - 1)) * rowf + 4 * c4) = e == 0 ? v.c0 : v.c1;
+        }
+      }
+    };
+    // Wave wv of the four owns the pixel tiles 2 wv, 2 wv + 1 (32 pixels) x all 32 channels: the gathered and split pixel
+    // operand serves both channel tiles.
+    bf16x8_t w0h[2], w0l[2];
+    int k_kh[8], k_col[8];                 // lane's eight k = 8 fg + s: filter row, float offset (kw * 3 + c) inside an image row
+    float4 sc0[2], sh0[2];
+    if constexpr (FUSE1A) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        float wf[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const int k = 8 * fg + s8;
+          const bool kv = k < 27;
+          const int kk = kv ? k : 0;
+          k_kh[s8] = kv ? kk / 9 : 0;        // k >= 27: zero weights against finite ring contents (the ring starts zeroed)
+          k_col[s8] = kk % 9;
+          wf[s8] = kv ? a.w0[kk * 32 + n * 16 + fr] : 0.f;
+        }
+        uint32_t hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = pack_bf16x2(wf[2 * e], wf[2 * e + 1]);
+          ll[e] = pack_bf16x2(wf[2 * e] - __uint_as_float(hh[e] << 16), wf[2 * e + 1] - __uint_as_float(hh[e] & 0xFFFF0000u));
+        }
+        w0h[n] = __builtin_bit_cast(bf16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+        w0l[n] = __builtin_bit_cast(bf16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+        sc0[n] = *(const float4*)(a.sc0 + n * 16 + fg * 4);
+        sh0[n] = *(const float4*)(a.sh0 + n * 16 + fg * 4);
+      }
+    }
+    // X0 row j = relu(bn(conv3x3/2(image))) for this wave's 32 pixels x 32 channels -> X0 ring (the arithmetic of
+    // conv_stem_mfma_kernel<bf16_t, 2>: same operand split, same MFMA order per accumulator, same epilogue)
+    auto compute_x0 = [&](int j) {
+      if (!x0_wanted(j) || !(32 * wv < a.W0)) return;
+      unsigned char* dst = xring + ((j + 8) & 3) * kRowB + (fg * 4) * 2;
+      int rb[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) rb[s8] = ((2 * j + k_kh[s8]) & (kImgRing - 1)) * rowf + k_col[s8];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int x = 32 * wv + 16 * i + fr;
+        const int x6 = 6 * min(x, a.W0 - 1);
+        float xv[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) xv[s8] = imgring[rb[s8] + x6];
+        uint32_t hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = pack_bf16x2(xv[2 * e], xv[2 * e + 1]);
+          ll[e] = pack_bf16x2(xv[2 * e] - __uint_as_float(hh[e] << 16), xv[2 * e + 1] - __uint_as_float(hh[e] & 0xFFFF0000u));
+        }
+        const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+        const bf16x8_t xl = __builtin_bit_cast(bf16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0h[n], xh, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0h[n], xl, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0l[n], xh, acc0, 0, 0, 0);
+          const float v0 = fmaxf(fmaf(acc0[0], sc0[n].x, sh0[n].x), 0.f), v1 = fmaxf(fmaf(acc0[1], sc0[n].y, sh0[n].y), 0.f);
+          const float v2 = fmaxf(fmaf(acc0[2], sc0[n].z, sh0[n].z), 0.f), v3 = fmaxf(fmaf(acc0[3], sc0[n].w, sh0[n].w), 0.f);
+          if (x < a.W0) *(uint2*)(dst + x * kPxB + n * 32) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+      }
+    };
     STEM_BARRIER();                                  // LDS initialised
     const float4 sc1 = *(const float4*)(table + p * 16 + fg * 4), sh1 = *(const float4*)(table + 32 + p * 16 + fg * 4);
     for (int task = blockIdx.x; task < a.n_tasks; task += gridDim.x) {
@@ -126,16 +227,35 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
       const int p0 = h * half_rows, p1 = min(a.Hp, p0 + half_rows) - 1;
       const int qa = 2 * p0 - 1, r_last = 2 * p1 + 2;
       const int nsteps = r_last + 2 - qa + 1;
-      Row r0 = load_row(b, qa), r1 = load_row(b, qa + 1), r2 = load_row(b, qa + 2);
-      store_row(qa, r0);
-      store_row(qa + 1, r1);
-      store_row(qa + 2, r2);
-      r0 = load_row(b, qa + 3);                      // queue: r0 = the row stored in step 0, r1 = step 1
-      r1 = load_row(b, qa + 4);
+      Row r0, r1, r2;
+      ImgRows ia, ib, ic;
+      if constexpr (FUSE1A) {
+        // image rows of X0 rows qa .. qa+3 (2 qa .. 2 qa + 8, those inside the image) straight into the ring
+        const int ir0 = 2 * max(qa, 0), ir1 = min(2 * (qa + 3) + 2, a.Hi - 1);
+        const float4* src = (const float4*)(a.img + ((size_t)b * a.Hi + ir0) * rowf);
+        for (int i = ltid; i < (ir1 - ir0 + 1) * row4; i += 256) {
+          const int r = ir0 + i / row4, c4 = i % row4;
+          *(float4*)(imgring + (size_t)(r & (kImgRing - 1)) * rowf + 4 * c4) = src[i];
+        }
+        ia = load_img(b, qa + 4);                    // queue: stored in step 0 / step 1
+        ib = load_img(b, qa + 5);
+        STEM_BARRIER();                              // (matched by the Y2 waves) the image rows are in the ring
+        compute_x0(qa);
+        compute_x0(qa + 1);
+        compute_x0(qa + 2);
+      } else {
+        r0 = load_row(b, qa); r1 = load_row(b, qa + 1); r2 = load_row(b, qa + 2);
+        store_row(qa, r0);
+        store_row(qa + 1, r1);
+        store_row(qa + 2, r2);
+        r0 = load_row(b, qa + 3);                    // queue: r0 = the row stored in step 0, r1 = step 1
+        r1 = load_row(b, qa + 4);
+      }
       STEM_BARRIER();                                // rows qa .. qa+2 are in the ring
       for (int t = 0; t < nsteps; ++t) {
         const int q = qa + t;
-        r2 = load_row(b, q + 5);
+        if constexpr (FUSE1A) ic = load_img(b, q + 6);
+        else r2 = load_row(b, q + 5);
         // ---- Y1 row q (rows -1 and H1 are the zero padding of the SAME conv that follows) -------------------------
         if (q <= r_last + 1 && y1_work) {
           const bool real = q >= 0 && q < H1;
@@ -178,9 +298,16 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
             if (x < W1) *(uint2*)(dst + (x + 1) * kPxB) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
           }
         }
-        store_row(q + 3, r0);
-        r0 = r1;
-        r1 = r2;
+        if constexpr (FUSE1A) {
+          compute_x0(q + 3);                         // from image rows stored one and two steps ago
+          store_img(q + 4, ia);
+          ia = ib;
+          ib = ic;
+        } else {
+          store_row(q + 3, r0);
+          r0 = r1;
+          r1 = r2;
+        }
         STEM_BARRIER();
       }
     }
@@ -224,6 +351,7 @@ __global__ __launch_bounds__(512) void conv_stem_stream_kernel(ComicStemArgs a) 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) run[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSE1A) STEM_BARRIER();             // the Y1 waves' image-row prologue
     STEM_BARRIER();                                   // first three X0 rows are in the ring
     auto mfma_row = [&](int r, f32x4_t (&acc)[2][4]) {
 #pragma unroll
@@ -309,16 +437,26 @@ bool comic_stem_stream_supported(int H0, int W0) {
   return H0 >= 7 && W0 >= 7 && Wp <= 56;
 }
 
+// FUSE1A: the image rows are moved as 16-byte pieces (Wi % 4 == 0), two new rows by 256 threads with two pieces each, the
+// ring fits beside the X0 / Y1 rings, and X0 has the 3x3 / 2 VALID geometry
+bool comic_stem_stream_1a_supported(int Hi, int Wi) {
+  const int H0 = (Hi - 3) / 2 + 1, W0 = (Wi - 3) / 2 + 1;
+  return Hi >= 17 && Wi % 4 == 0 && 2 * (Wi * 3 / 4) <= 512 && comic_stem_stream_supported(H0, W0) &&
+         kTableFloats * 4 + 2 * kRing * kRowB + kImgRing * Wi * 3 * 4 <= 160 * 1024;
+}
+
 int comic_stem_stream_launch(const ComicStemArgs& a, hipStream_t st) {
-  if (!comic_stem_stream_supported(a.H0, a.W0)) {
+  if (!comic_stem_stream_supported(a.H0, a.W0) || (a.img && !comic_stem_stream_1a_supported(a.Hi, a.Wi))) {
     comic_set_error("conv_stem: unsupported map %dx%d", a.H0, a.W0);
     return 2;
   }
-  constexpr int lds = kTableFloats * 4 + 2 * kRing * kRowB;
+  const int lds = kTableFloats * 4 + 2 * kRing * kRowB + (a.img ? kImgRing * a.Wi * 3 * 4 : 0);
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_stem_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_stem_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_stem_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       comic_set_error("conv_stem: cannot reserve %d bytes of LDS", lds);
       return 1;
@@ -328,6 +466,9 @@ int comic_stem_stream_launch(const ComicStemArgs& a, hipStream_t st) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int grid = std::min(a.n_tasks, cus);
-  hipLaunchKernelGGL(conv_stem_stream_kernel, dim3(grid), dim3(512), lds, st, a);
+  if (a.img)
+    hipLaunchKernelGGL(conv_stem_stream_kernel<true>, dim3(grid), dim3(512), lds, st, a);
+  else
+    hipLaunchKernelGGL(conv_stem_stream_kernel<false>, dim3(grid), dim3(512), lds, st, a);
   return 0;
 }

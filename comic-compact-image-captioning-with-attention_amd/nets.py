@@ -105,6 +105,13 @@ def stem_stream_supported(H0, W0):
     return H0 >= 7 and W0 >= 7 and (W0 - 2 - 3) // 2 + 1 <= 56
 
 
+def stem_stream_1a_supported(Hi, Wi):
+    """Mirror of comic_stem_stream_1a_supported: image rows in 16-byte pieces, two new rows by 256 threads, 16 rows in LDS."""
+    H0, W0 = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+    return (Hi >= 17 and Wi % 4 == 0 and 2 * (Wi * 3 // 4) <= 512 and stem_stream_supported(H0, W0)
+            and 2 * (32 + 64) * 4 + 2 * 4 * 132 * 96 + 16 * Wi * 3 * 4 <= 160 * 1024)
+
+
 def _out(size, k, s, pad):
     if pad == 'SAME':
         o = -(-size // s)
@@ -118,7 +125,7 @@ class CnnPlan:
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
                  group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None,
-                 fuse_pools=False, x3=False):
+                 fuse_pools=False, x3=False, fuse_stem_1a=True):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -152,6 +159,7 @@ class CnnPlan:
         # (MaxPool_3a -> Conv2d_3b_1x1, MaxPool_5a -> the four 1x1 convs at the head of Mixed_5b) is folded into
         # their loads (COMIC_OP_POOLED_SRC, csrc/conv_ws.hip): the pooled map is never written or re-read.
         self.fuse_pools = bool(fuse_pools)
+        self.fuse_stem_1a = bool(fuse_stem_1a)   # with fuse_pools: Conv2d_1a inside the streaming stem op (kind 9)
         if self.fuse_pools and not (pool_after_projection and name == 'inception_v3'):
             raise ValueError('fuse_pools needs an inception_v3 plan with pool_after_projection=True')
         self._pooled_src = None  # (buffer id, pooled H, pooled W) while a folded max-pool waits for its consumers
@@ -215,11 +223,21 @@ class CnnPlan:
         """(H0, W0) of Conv2d_1a_3x3's output (3x3 / 2 VALID) for an H x W image."""
         return _out(H, 3, 2, 'VALID')[0], _out(W, 3, 2, 'VALID')[0]
 
-    def _stem_stream(self, src, scope, spec_a, spec_b):
+    def _stem_stream(self, src, scope, spec_a, spec_b, spec_1a=None):
         """kind 8: conv 3x3 VALID 32 -> 32, conv 3x3 SAME 32 -> 64 (+ BN + ReLU each), max-pool 3x3 / 2 VALID in one
-        streaming pass; the weight records of the two convs are adjacent."""
-        H0, W0, Cin, _ = self.buffers[src]
-        assert Cin == 32 and spec_a[2:] == (32, (3, 3), 1, 'VALID') and spec_b[2:] == (64, (3, 3), 1, 'SAME')
+        streaming pass; the weight records of the two convs are adjacent.  spec_1a: kind 9 -- `src` is the fp32 image and
+        Conv2d_1a_3x3 (3x3 / 2 VALID, 3 -> 32) runs inside the same pass, its record in front of the other two."""
+        Hs, Ws, Cin, _ = self.buffers[src]
+        assert spec_a[2:] == (32, (3, 3), 1, 'VALID') and spec_b[2:] == (64, (3, 3), 1, 'SAME')
+        if spec_1a is not None:
+            assert Cin == 3 and spec_1a[2:] == (32, (3, 3), 2, 'VALID')
+            H0, W0 = self._stem_dims(Hs, Ws)
+            self.weights.append((scope + '/' + spec_1a[1], 3, 3, 3, 32, True))
+            self.wphys.append((3, 32))
+            self.macs += H0 * W0 * 27 * 32
+        else:
+            assert Cin == 32
+            H0, W0 = Hs, Ws
         H1, W1 = H0 - 2, W0 - 2
         Hp, Wp = _out(H1, 3, 2, 'VALID')[0], _out(W1, 3, 2, 'VALID')[0]
         dst = self._buf(Hp, Wp, 64)
@@ -227,9 +245,10 @@ class CnnPlan:
         self.wphys.append((32, 32))
         self.weights.append((scope + '/' + spec_b[1], 3, 3, 32, 64, False))
         self.wphys.append((32, 64))
-        self.ops.append(dict(kind=8, src=src, dst=dst, src_coff=0, dst_coff=0, H=H0, W=W0, Cin=32, Cout=64, KH=3, KW=3,
-                             SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp, weight=len(self.weights) - 2, relu=1, out_f32=0,
-                             lane=0, depth=0))
+        n_w = 3 if spec_1a is not None else 2
+        self.ops.append(dict(kind=9 if spec_1a is not None else 8, src=src, dst=dst, src_coff=0, dst_coff=0, H=Hs, W=Ws,
+                             Cin=Cin, Cout=64, KH=3, KW=3, SH=1, SW=1, PT=0, PL=0, Ho=Hp, Wo=Wp,
+                             weight=len(self.weights) - n_w, relu=1, out_f32=0, lane=0, depth=0))
         self.macs += H1 * W1 * 9 * 32 * 32 + H1 * W1 * 9 * 32 * 64
         return dst
 
@@ -404,10 +423,14 @@ class CnnPlan:
         root = 'InceptionV3'
         stem = list(_STEM)
         if self.fuse_pools and stem_stream_supported(*self._stem_dims(H, W)):
-            # Conv2d_2a -> Conv2d_2b -> MaxPool_3a as one streaming op (kind 8, csrc/conv_stem.hip)
-            cur, _ = self._conv(cur, root, stem[0])
-            self.end_points[stem[0][1]] = cur
-            cur = self._stem_stream(cur, root, stem[1], stem[2])
+            # Conv2d_2a -> Conv2d_2b -> MaxPool_3a as one streaming op (kind 8, csrc/conv_stem.hip); with Conv2d_1a in
+            # front of them in the same pass (kind 9) when the image rows split into 16-byte pieces
+            if self.fuse_stem_1a and stem_stream_1a_supported(H, W):
+                cur = self._stem_stream(cur, root, stem[1], stem[2], spec_1a=stem[0])
+            else:
+                cur, _ = self._conv(cur, root, stem[0])
+                self.end_points[stem[0][1]] = cur
+                cur = self._stem_stream(cur, root, stem[1], stem[2])
             self.end_points[stem[3][1]] = cur
             stem = stem[4:]
         for op in stem:
@@ -532,7 +555,7 @@ def plan_grad_buckets(plan, w_flat, b_flat, n=6):
     assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), 'block ranges must tile the op list'
 
     def widx(r):
-        ws = [plan.ops[i]['weight'] for i in range(*r) if plan.ops[i].get('weight', -1) >= 0 and plan.ops[i]['kind'] in (0, 1, 8)]
+        ws = [plan.ops[i]['weight'] for i in range(*r) if plan.ops[i].get('weight', -1) >= 0 and plan.ops[i]['kind'] in (0, 1, 8, 9)]
         return (min(ws), max(ws) + 1) if ws else None
     nW = len(plan.weights)
     woff = [w_flat.offsets['w%d' % i] for i in range(nW)] + [w_flat.numel]

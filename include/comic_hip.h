@@ -72,7 +72,11 @@ typedef struct comic_cnn_op {
                           SAME 32 -> 64 (record `weight` + 1), each + BatchNorm + ReLU, then max-pool 3x3 / 2 VALID,
                           as ONE line-buffered pass (csrc/conv_stem.hip; inception_v3.py:104-111): H, W = the source
                           map, Cin 32, Cout 64, KH = KW = 3, Ho, Wo = the pooled grid; the two intermediate maps
-                          are never materialised */
+                          are never materialised
+                        9 (bf16 plans) kind 8 with Conv2d_1a_3x3 (3x3 / 2 VALID, 3 -> 32, inception_v3.py:100-104) in
+                          front, in the same pass: src = the fp32 image (H, W = the image, W % 4 == 0, Cin 3), weight
+                          records `weight` (Conv2d_1a, stem layout), + 1, + 2; the 32-channel map between the stem
+                          conv and Conv2d_2a is never materialised either (bit-identical to kinds 1 + 8) */
   int32_t src, dst;  /* indices into the buffer table */
   int32_t src_coff, dst_coff; /* channel offsets inside src/dst (concat without a copy) */
   int32_t H, W, Cin, Cout, KH, KW, SH, SW, PT, PL, Ho, Wo;

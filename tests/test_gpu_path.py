@@ -95,6 +95,32 @@ def test_inception_v3_pool_after_projection(cnn_params, dtype, tol):
         enc.enable_training()
 
 
+@pytest.mark.parametrize('B', [3, 70])
+def test_stem_stream_with_conv2d_1a_is_bit_identical(cnn_params, B):
+    """Op kind 9 (Conv2d_1a_3x3 inside the streaming stem pass, csrc/conv_stem.hip FUSE1A; inception_v3.py:100-111) against
+    the separate stem launch + kind 8: the pooled stem output and the whole forward bit for bit (the same operand split,
+    MFMA order and epilogue), eagerly and replayed from a graph; more tasks than CUs at B = 70 (a workgroup walks several
+    half-images, the image-row ring is re-primed per task)."""
+    x = np.random.default_rng(5 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    sep = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_stem_1a=False)
+    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    assert [o['kind'] for o in sep.ops[:2]] == [1, 8] and fus.ops[0]['kind'] == 9 and len(fus.ops) == len(sep.ops) - 1
+    assert fus.macs == sep.macs and [w[0] for w in fus.weights] == [w[0] for w in sep.weights]
+    e0 = nets.CnnEncoder(sep, cnn_params, B, 'bf16', DEV)
+    e1 = nets.CnnEncoder(fus, cnn_params, B, 'bf16', DEV, weights_from=e0)
+    im0, fm0 = (t.clone() for t in e0.forward(dev(x)))
+    p0 = e0.end_point('MaxPool_3a_3x3').clone()
+    im1, fm1 = (t.clone() for t in e1.forward(dev(x)))
+    sync()
+    assert torch.equal(e1.end_point('MaxPool_3a_3x3'), p0), 'pooled stem output differs'
+    assert torch.equal(fm1, fm0) and torch.equal(im1, im0)
+    for _ in range(2):
+        im2, fm2 = e1.forward(dev(x), use_graph=True)
+    assert torch.equal(fm2, fm0) and torch.equal(im2, im0)
+    net_ref, ep = cnn_ref.inception_v3(cnn_params, x[:2], act_dtype='bf16')
+    assert_close(e1.end_point('MaxPool_3a_3x3')[:2].float().cpu().numpy(), ep['MaxPool_3a_3x3'], 3e-2, 'MaxPool_3a (kind 9)')
+
+
 def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
     """Second forward-only rewrite (bf16): MaxPool_3a / MaxPool_5a folded into the loads of the 1x1 convs behind them
     and the thin 1x1 groups of Mixed_5b-d on the weight-stationary kernel (csrc/conv_ws.hip; reference
@@ -106,8 +132,8 @@ def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
     pa = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
     pb = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
     assert sum(1 for o in pb.ops if o['kind'] == 2) == sum(1 for o in pa.ops if o['kind'] == 2) - 2
-    # MaxPool_5a folded into the four 1x1 convs of Mixed_5b; Conv2d_2a -> 2b -> MaxPool_3a is one streaming op (kind 8)
-    assert sum(1 for o in pb.ops if o.get('flags', 0) & 2) == 4 and sum(1 for o in pb.ops if o['kind'] == 8) == 1
+    # MaxPool_5a folded into the four 1x1 convs of Mixed_5b; Conv2d_1a -> 2a -> 2b -> MaxPool_3a is one streaming op (kind 9)
+    assert sum(1 for o in pb.ops if o.get('flags', 0) & 2) == 4 and sum(1 for o in pb.ops if o['kind'] == 9) == 1
     assert pb.macs == pa.macs and pb.weights == pa.weights
     ea = nets.CnnEncoder(pa, cnn_params, B, 'bf16', DEV)
     eb = nets.CnnEncoder(pb, cnn_params, B, 'bf16', DEV, weights_from=ea)

@@ -7,7 +7,7 @@ B = int(os.environ.get('B', '64'))
 plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (224, 224), group_branches=os.environ.get('COMIC_CNN_GROUP', '1') == '1',
                     pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1',
                     fuse_pools=os.environ.get('COMIC_POOL_REWRITE', '1') == '1' and os.environ.get('COMIC_FUSE_POOLS', '1') == '1',
-                    x3=os.environ.get('X3', '0') == '1')
+                    x3=os.environ.get('X3', '0') == '1', fuse_stem_1a=os.environ.get('COMIC_FUSE_1A', '1') == '1')
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
