@@ -1152,6 +1152,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
 #ifdef COMIC_STAMPS
     const unsigned long long ti0 = __builtin_amdgcn_s_memtime();
     t_wait += ti0 - tw0;
+    if (kt == 0 && tid == 0) g_stamps[(blockIdx.x & 16383) * 8 + 7] = ti0 - tw0;    // the wait for the FIRST k-tile
 #endif
     if constexpr (!SPEC) {
       if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NSTAGE);
@@ -1204,6 +1205,244 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
   STAMP(3);
 }
 
+
+
+// ---------------------------------------------------------------------------------------------
+// "Walk" form of the loader-wave kernel for launches whose members read the SAME im2col matrix (the 1x1 convs at the head
+// of an Inception block; ConvArgs::remap == 3): ONE workgroup per pixel tile walks over the out-channel tiles of ALL
+// members.  Why (phase stamps of the 12x12 768 -> 704 groups at 1280 images, one tile per workgroup): the wait for the first
+// k-tile is 14 % of a workgroup's life, 43 % of the k loop is spent at the barrier waiting for rows that come from HBM again
+// although three sibling workgroups fetch the same rows (L2 hit rate of the pixel operand 0.54), the epilogue another 14 %.
+// Here the k-tile stream of the loader waves runs on across the out-channel tiles (the ring never drains: the first
+// k-tiles of the next tile land under the epilogue of this one), and after the first tile the pixel rows come from the
+// L2 this workgroup has just filled.  Same operands in the same order per accumulator as conv_igemm_dma_body: identical bits.
+template <int BM, int BN, int WM, int WN, int NSTAGE_, bool ALIGNED>
+__device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restrict__ args, const int n_members, const int block_m) {
+  constexpr int BKE = 64;
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE_BYTES = ROWS * 128;
+  constexpr int NSTAGE = ring_stages(NSTAGE_);
+  static_assert(NSTAGE_ >= kLoaderWaves, "the walk form needs the loader waves");
+  constexpr int NWC = WM * WN;
+  constexpr int NW = 4;
+  constexpr int IPW_A = BM / (8 * NW);
+  constexpr int IPW_B = BN / (8 * NW);
+  constexpr int LPT = IPW_A + IPW_B;
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int AHEAD = NSTAGE - 1;
+  static_assert(NWC == 4 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const ConvArgs& a = args[0];                   // everything about the pixel operand is common to the members
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave_id >= NWC;
+  const int wave = loader ? wave_id - NWC : wave_id;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bm0 = block_m * BM;
+  const int R = a.grp_nt;                        // out-channel tiles of all members
+  const int nk = a.Kpad / BKE;
+  const int total = R * nk;                      // k-tiles of the whole walk
+  const int slot = lane & 7, rsub = lane >> 3;
+
+  if (loader) {
+    const bf16_t* __restrict__ xg = (const bf16_t*)a.x;
+    const bf16_t* zp = (const bf16_t*)a.zero;
+    int xbase[IPW_A], hi0[IPW_A], wi0[IPW_A];
+    bool mok[IPW_A];
+#pragma unroll
+    for (int i = 0; i < IPW_A; ++i) {
+      const int r = (wave * IPW_A + i) * 8 + rsub;
+      const int m = bm0 + r;
+      mok[i] = m < a.M;
+      int mm = mok[i] ? m : 0;
+      const int wo = mm % a.Wo;
+      mm /= a.Wo;
+      const int ho = mm % a.Ho;
+      const int b = mm / a.Ho;
+      hi0[i] = ho * a.SH - a.PT;
+      wi0[i] = wo * a.SW - a.PL;
+      xbase[i] = ((b * a.H + hi0[i]) * a.W + wi0[i]) * a.x_cs + a.x_co;
+    }
+    int kc[2], kkw[2], kkh[2], chunk8[2];
+    int s_kh = 0, s_kw = 0, s_c0 = 0;
+    auto reset_k = [&]() {
+      s_kh = s_kw = s_c0 = 0;
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int chunk = slot ^ ((4 * par + (rsub >> 1)) & 7);
+        const int kk = chunk * 8;
+        chunk8[par] = kk;
+        kc[par] = kk % a.Cin;
+        const int tap = kk / a.Cin;
+        kkw[par] = tap % a.KW;
+        kkh[par] = tap / a.KW;
+      }
+    };
+    const bf16_t* wsrc[IPW_B];
+    bool nok[IPW_B];
+    auto set_tile = [&](int r) {                 // weight rows of out-channel tile r (member p, its tile r - blk0)
+      int p = 0;
+      for (int i = 1; i < n_members; ++i)
+        if (r >= args[i].blk0) p = i;
+      const bf16_t* wg = (const bf16_t*)args[p].w;
+      const int bn0 = (r - args[p].blk0) * BN, cout = args[p].Cout;
+#pragma unroll
+      for (int i = 0; i < IPW_B; ++i) {
+        const int gb = wave * IPW_B + i;
+        const int nn = bn0 + gb * 8 + rsub;
+        nok[i] = nn < cout;
+        const int chunk = slot ^ ((4 * (gb & 1) + (rsub >> 1)) & 7);
+        wsrc[i] = wg + (size_t)(nok[i] ? nn : 0) * a.Kpad + chunk * 8;
+      }
+    };
+    int gi = 0, gi_kt = 0, gi_r = 0;             // issue pointer: stream index, its k-tile and out-channel tile
+    auto issue = [&]() {
+      if (gi_kt == 0) {
+        set_tile(gi_r);
+        reset_k();
+      }
+      unsigned char* sbase = smem + (gi % NSTAGE) * STAGE_BYTES;
+      if constexpr (ALIGNED) {
+        const bool kvalid = s_kh < a.KH;
+        const int koff = (s_kh * a.W + s_kw) * a.x_cs + s_c0;
+#pragma unroll
+        for (int i = 0; i < IPW_A; ++i) {
+          const int ga = wave * IPW_A + i;
+          const int hi = hi0[i] + s_kh, wi = wi0[i] + s_kw;
+          const bool ok = mok[i] & kvalid & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+          const bf16_t* src = xg + (xbase[i] + koff + chunk8[ga & 1]);
+          src = ok ? src : zp;
+          dma16(src, sbase + ga * 1024);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < IPW_A; ++i) {
+          const int ga = wave * IPW_A + i;
+          const int par = ga & 1;
+          const int hi = hi0[i] + kkh[par], wi = wi0[i] + kkw[par];
+          const bool ok = mok[i] & (kkh[par] < a.KH) & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+          const bf16_t* src = xg + (xbase[i] + (kkh[par] * a.W + kkw[par]) * a.x_cs + kc[par]);
+          src = ok ? src : zp;
+          dma16(src, sbase + ga * 1024);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < IPW_B; ++i) {
+        const int gb = wave * IPW_B + i;
+        const bf16_t* src = wsrc[i] + (size_t)gi_kt * BKE;
+        src = nok[i] ? src : zp;
+        dma16(src, sbase + BM * 128 + gb * 1024);
+      }
+      if constexpr (ALIGNED) {
+        s_c0 += BKE;
+        if (s_c0 >= a.Cin) {
+          s_c0 = 0;
+          if (++s_kw == a.KW) {
+            s_kw = 0;
+            ++s_kh;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          kc[par] += BKE;
+          while (kc[par] >= a.Cin) {
+            kc[par] -= a.Cin;
+            if (++kkw[par] == a.KW) {
+              kkw[par] = 0;
+              ++kkh[par];
+            }
+          }
+        }
+      }
+      ++gi;
+      if (++gi_kt == nk) {
+        gi_kt = 0;
+        ++gi_r;
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+      if (gi < total) issue();
+    for (int g = 0; g < total; ++g) {
+      const int pending = min(AHEAD - 1, total - 1 - g);
+      if (pending >= 2)
+        wait_vmcnt<2 * LPT>();
+      else if (pending == 1)
+        wait_vmcnt<LPT>();
+      else
+        wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (gi < total) issue();
+    }
+    return;
+  }
+
+  // ---- MFMA waves ---------------------------------------------------------------------------------------------------------
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t sw = (fr >> 1) & 7;
+  const uint32_t x_off0 = (wm * (BM / WM) + fr) * 128 + (((0 + fg) ^ sw) & 7) * 16;
+  const uint32_t x_off1 = (wm * (BM / WM) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
+  const uint32_t w_off0 = (BM + wn * (BN / WN) + fr) * 128 + (((0 + fg) ^ sw) & 7) * 16;
+  const uint32_t w_off1 = (BM + wn * (BN / WN) + fr) * 128 + (((4 + fg) ^ sw) & 7) * 16;
+  int mrow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = bm0 + wm * (BM / WM) + j * 16 + (lane & 15);
+    mrow[j] = m < a.M ? m : -1;
+  }
+  int g = 0;
+  for (int r = 0; r < R; ++r) {
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      __builtin_amdgcn_s_barrier();
+      const uint32_t sb = lds0 + (g % NSTAGE) * STAGE_BYTES;
+      u32x4_t xf0[TM], xf1[TM], wf0[TN], wf1[TN];
+      static_assert(TM + TN <= 15, "lgkmcnt holds 4 bits");
+      static_for<0, TN>([&](auto i) { wf0[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off0); });
+      static_for<0, TM>([&](auto j) { xf0[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off0); });
+      static_for<0, TN>([&](auto i) { wf1[i] = lds_read128<decltype(i)::value * 2048>(sb + w_off1); });
+      static_for<0, TM>([&](auto j) { xf1[j] = lds_read128<decltype(j)::value * 2048>(sb + x_off1); });
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TM + TN) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf0[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf0[j]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[i]),
+                                                              __builtin_bit_cast(bf16x8_t, xf1[j]), acc[i][j], 0, 0, 0);
+    }
+    int p = 0;
+    for (int i = 1; i < n_members; ++i)
+      if (r >= args[i].blk0) p = i;
+    conv_store_tiles<TN, TM>(args[p], acc, (r - args[p].blk0) * BN + wn * (BN / WN), (lane >> 4) * 4, mrow);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_walk_kernel(const ConvArgs* __restrict__ args, int n, int total) {
+  const int bm = xcd_tile_index(total);
+  if (bm < 0) return;
+  if (args[0].Cin % 64 == 0)
+    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, true>(args, n, bm);
+  else
+    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, false>(args, n, bm);
+}
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
 __global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_kernel(ConvArgs a) {
@@ -1302,6 +1541,25 @@ int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, int mi
   return 0;
 }
 
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_dma_walk(const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st) {
+  constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
+  const int lds = std::max(lds0, min_lds);
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_walk_kernel<BM, BN, WM, WN, NSTAGE>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_dma_walk_kernel<BM, BN, WM, WN, NSTAGE>), dim3((total_blocks + 7) / 8 * 8),
+                     dim3(dma_threads(WM, WN, NSTAGE)), lds, st, args_dev, n, total_blocks);
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 int launch_dma(const ConvArgs& a, hipStream_t st) {
   static_assert(ring_stages(NSTAGE) >= 2 && ring_stages(NSTAGE) <= 4, "pipeline depth");
@@ -1378,7 +1636,10 @@ constexpr int kNumConvTiles = 12;
 // costs (BM+BN)*128 bytes of fill for BM*BN/32 MFMA cycles, so 64x128 cannot pass ~31 % of the MFMA peak, 128x128
 // 47 %, 128x192 56 %; with two stages (instead of three) two such workgroups still share a CU.
 constexpr int kWideTile0 = 26, kNumWideTiles = 22;      // 35..47: four MFMA waves + four loader waves      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
-inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles); }
+// 56..58: "walk" forms of 44 / 38 / 35 for launches whose members share their im2col matrix (conv_igemm_dma_walk_body)
+constexpr int kWalkTile0 = 56, kNumWalkTiles = 3;
+inline bool is_walk_tile(int t) { return t >= kWalkTile0 && t < kWalkTile0 + kNumWalkTiles; }
+inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles) || is_walk_tile(t); }
 int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
   switch (tile) {
     case 26: return launch_dma<128, 128, 2, 2, 2>(a, st);
@@ -1449,9 +1710,10 @@ constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 1
 constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
 constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192, 128, 128, 128, 192, 128, 192, 128, 160, 192, 192, 64, 128, 64};
 constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96, 192, 128, 256, 128, 160, 192, 192, 192, 160, 192, 128, 64, 64};
+constexpr int kWalkBase[kNumWalkTiles] = {44, 38, 35};
 inline int im2col_tile_threads(int t) { return (t >= 29 && t <= 31) || t >= 35 ? 512 : 256; }
-inline int tile_bm(int t) { return t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
-inline int tile_bn(int t) { return t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
+inline int tile_bm(int t) { return is_walk_tile(t) ? kWideBM[kWalkBase[t - kWalkTile0] - kWideTile0] : t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
+inline int tile_bn(int t) { return is_walk_tile(t) ? kWideBN[kWalkBase[t - kWalkTile0] - kWideTile0] : t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
 
 int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st) {
   switch (tile) {
@@ -1477,6 +1739,9 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
     case 45: return launch_dma_grouped<64, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
     case 46: return launch_dma_grouped<128, 64, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
     case 47: return launch_dma_grouped<64, 64, 2, 2, kLoaderWaves + 4>(args_dev, n, total_blocks, min_lds, st);
+    case 56: return launch_dma_walk<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 57: return launch_dma_walk<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 58: return launch_dma_walk<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
     case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
     case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
     case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
@@ -1574,6 +1839,7 @@ bool ws_group_selected(const comic_cnn_op* ops, int n, int batch) {
 int group_tile(const comic_cnn_op* ops, int n, int batch) {
   if (ops[0].tile == COMIC_IMG_TILE) return COMIC_IMG_TILE;
   if (ops[0].tile > 0 && ops[0].tile < COMIC_WS_TILE) return ops[0].tile;
+  if (is_walk_tile(ops[0].tile)) return ops[0].tile;
   bool all128 = true;
   for (int i = 0; i < n; ++i) all128 = all128 && ops[i].Cout % 128 == 0;
   auto blocks = [&](int t) {
@@ -1925,10 +2191,12 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
                     op->Cin, tile);
       blk += (int)nb;
     }
+    COMIC_REQUIRE(!is_walk_tile(tile) || shared_input_group(out, n),
+                  "conv: tile %d walks over members that share their im2col matrix; this launch's do not", tile);
     if (is_im2col_tile(tile) && shared_input_group(out, n)) {
       int nt = 0;
       for (int j = 0; j < n; ++j) {
-        out[j].remap = 2;
+        out[j].remap = is_walk_tile(tile) ? 3 : 2;     // 3: one workgroup per pixel tile walks all nt out-channel tiles
         out[j].blk0 = nt;
         nt += cdiv(out[j].Cout, tile_bn(tile));
       }
@@ -2073,6 +2341,7 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
         lds_max = std::max(lds_max, lds);
       }
       COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
+      if (is_walk_tile(tile)) blocks = cdiv(batch * op->Ho * op->Wo, tile_bm(tile));   // one workgroup per pixel tile
       if (!is_im2col_tile(tile)) {
         if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, std::max(lds_max, op->min_lds), main_st)) return rc;
       } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, op->min_lds, main_st)) {

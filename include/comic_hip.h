@@ -32,7 +32,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 55
+#define COMIC_CONV_TILES 58
 #define COMIC_WS_TILE 54     /* weight-stationary 1x1 group kernel (csrc/conv_ws.hip) */
 #define COMIC_IMG_TILE 55    /* image-resident kernel for stride-1 SAME convs on small maps (csrc/conv_img.hip) */
 
@@ -96,7 +96,11 @@ typedef struct comic_cnn_op {
                         loader waves.  Id 54 (COMIC_WS_TILE): weight-stationary kernel for 1x1 convs / groups of 1x1 convs
                         over one source with Cin <= 288 and <= 256 output channels in total (all weights in registers,
                         persistent workgroups, activation tiles streamed once).  An ineligible layer returns an error
-                        for ids 13..25 and 48..55.  Id 55 (COMIC_IMG_TILE): image-resident kernel for the stride-1 SAME
+                        for ids 13..25 and 48..58.  Ids 56..58: "walk" forms of 44 / 38 / 35 for grouped launches whose
+                        members share their im2col matrix (the 1x1 convs at the head of an Inception block): one workgroup per
+                        pixel tile walks over the out-channel tiles of all members -- the loader waves' k-tile stream runs on
+                        across the tiles (no pipeline fill after the first) and the pixel rows are re-read from the L2 the
+                        workgroup has just filled.  Id 55 (COMIC_IMG_TILE): image-resident kernel for the stride-1 SAME
                         convs of Mixed_5 / Mixed_6 / Mixed_7 (whole 25x25 / 12x12 / 5x5 images in the LDS without halo,
                         weights streamed global -> VGPR in fragment order: needs comic_conv_weight::w_frag).  In a group
                         the id of the first member applies to all members.  Every variant gives identical bits. */

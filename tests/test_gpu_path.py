@@ -121,6 +121,39 @@ def test_stem_stream_with_conv2d_1a_is_bit_identical(cnn_params, B):
     assert_close(e1.end_point('MaxPool_3a_3x3')[:2].float().cpu().numpy(), ep['MaxPool_3a_3x3'], 3e-2, 'MaxPool_3a (kind 9)')
 
 
+@pytest.mark.parametrize('B', [3, 40])
+def test_walk_tiles_give_the_bits_of_the_one_tile_launch(cnn_params, B):
+    """Tile ids 56..58 (conv_igemm_dma_walk_body: one workgroup per pixel tile walks over the out-channel tiles of all members of a
+    shared-input group) against the same groups on tile 44: the whole forward bit for bit, with the 1x1 groups at the head
+    of every Inception block on each walk form; a launch whose members do not share their input refuses the ids."""
+    x = np.random.default_rng(7 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    enc = nets.CnnEncoder(plan, cnn_params, B, 'bf16', DEV)
+    heads = [i for i, o in enumerate(plan.ops) if o['kind'] == 0 and o.get('group', 0) and o['KH'] == 1 and o['KW'] == 1 and o['depth'] == 0
+             and (i == 0 or plan.ops[i - 1].get('group', 0) != o['group'])]
+    assert len(heads) >= 9
+
+    def forward_with(tile):
+        for i in heads:
+            enc._ops[i].tile = tile
+        enc._build_group_args(); enc._drop_graphs()
+        im, fm = enc.forward(dev(x))
+        sync()
+        return im.clone(), fm.clone()
+    im0, fm0 = forward_with(44)
+    for tile in (56, 57, 58):
+        im1, fm1 = forward_with(tile)
+        assert torch.equal(fm1, fm0) and torch.equal(im1, im0), 'walk tile %d differs' % tile
+    # a group over different inputs (depth 1: 1x7 | 7x1 of two branches) is not eligible
+    other = [i for i, o in enumerate(plan.ops) if o['kind'] == 0 and o.get('group', 0) and o['KH'] * o['KW'] == 7
+             and plan.ops[i - 1].get('group', 0) != o['group']]
+    enc._ops[other[0]].tile = 56
+    with pytest.raises(L.ComicHipError):
+        enc._build_group_args()
+    enc._ops[other[0]].tile = 0
+    enc._build_group_args()
+
+
 def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
     """Second forward-only rewrite (bf16): MaxPool_3a / MaxPool_5a folded into the loads of the 1x1 convs behind them
     and the thin 1x1 groups of Mixed_5b-d on the weight-stationary kernel (csrc/conv_ws.hip; reference

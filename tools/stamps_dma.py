@@ -24,4 +24,6 @@ for tile in tiles:
     print('   k loop          median %8.0f  per k-tile %6.0f' % (np.median(t[:, 2] - t[:, 1]), np.median(t[:, 2] - t[:, 1]) / nk))
     print('      of which wait+barrier %8.0f  per k-tile %6.0f' % (np.median(t[:, 5]), np.median(t[:, 5]) / nk))
     print('      of which DMA issue    %8.0f  per k-tile %6.0f' % (np.median(t[:, 4]), np.median(t[:, 4]) / nk))
+    print('      first k-tile wait     %8.0f' % np.median(t[:, 7]))
     print('   epilogue        median %8.0f' % np.median(t[:, 3] - t[:, 2]))
+    print('   workgroup total median %8.0f   (s_memtime ticks)' % np.median(t[:, 3] - t[:, 0]))
