@@ -860,13 +860,14 @@ def main():
             'frac': round(dec_bytes / (dec_ms * 1e-3) / 8e12, 5), 'loops_persistent': dec_path,
             'note': 'the chain is latency-bound, not bandwidth-bound: 2 x T\' dependent phases of three to four '
                     'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
-        tfile = os.path.join(ROOT, 'profiles', 'r03_cnn_hbm_traffic.json')
-        if os.path.isfile(tfile):       # committed PMC pass (FETCH_SIZE / WRITE_SIZE, corrected per the microarch guide)
-            tj = json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH))
+        for tname in ('r04_cnn_hbm_traffic.json', 'r03_cnn_hbm_traffic.json'):   # committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+            tfile = os.path.join(ROOT, 'profiles', tname)                         # corrected per the microarch guide), newest first
+            tj = (json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH)) if os.path.isfile(tfile) else None)
             if tj:
                 out['roofline']['traffic'] = tj['per_forward']['conv_only_bytes_corrected']
-                out['roofline']['traffic_source'] = ('profiles/r03_cnn_hbm_traffic.json (bytes per InceptionV3 forward of %d '
-                                                     'images, conv kernels)' % ENC_BATCH)
+                out['roofline']['traffic_source'] = ('profiles/%s (bytes per InceptionV3 forward of %d images, conv kernels)'
+                                                     % (tname, ENC_BATCH))
+                break
         if not args.no_extras and world == 1:
             try:
                 out['extras'] = extras(device, tr.encoder, cnn_params, plan)

@@ -29,7 +29,8 @@ def one_forward(d):
                                     us=(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, c={}))
         e['c'][r['Counter_Name']] = e['c'].get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
     ids = sorted(disp)
-    stems = [i for i, k in enumerate(ids) if 'conv_stem_mfma' in disp[k]['kernel']]
+    first = 'conv_stem_mfma' if any('conv_stem_mfma' in disp[k]['kernel'] for k in ids) else 'conv_stem_stream'   # (kind 9: the stem conv is inside the streaming op)
+    stems = [i for i, k in enumerate(ids) if first in disp[k]['kernel']]
     a, b = stems[-2], stems[-1]
     return [disp[k] for k in ids[a:b]]
 

@@ -5,7 +5,8 @@ def per_forward(d, counter):
     f = glob.glob(d + '/*/*counter_collection.csv')[0]
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    stems = [i for i, r in enumerate(rows) if 'conv_stem_mfma' in r['Kernel_Name']]   # first launch of a forward
+    first = 'conv_stem_mfma' if any('conv_stem_mfma' in r['Kernel_Name'] for r in rows) else 'conv_stem_stream'
+    stems = [i for i, r in enumerate(rows) if first in r['Kernel_Name']]   # first launch of a forward
     a, b = stems[-2], stems[-1]            # one whole forward: stem conv .. next stem conv
     seg = rows[a:b]
     conv = sum(float(r['Counter_Value']) for r in seg if 'conv_' in r['Kernel_Name'] and 'pack_conv' not in r['Kernel_Name'])
