@@ -834,29 +834,53 @@ __global__ __launch_bounds__(256) void pool_bn_relu_rows_kernel(ConvArgs a) {
   const float nrows = (float)(r1 - r0 + 1);
   const float4 sc = *(const float4*)(a.scale + cv * 4), sh = *(const float4*)(a.shift + cv * 4);
   const float lo = a.relu ? 0.f : -INFINITY;
-  auto colsum = [&](int w) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = r0; r <= r1; ++r) {
-      const float4 v = *(const float4*)(xg + ((size_t)(b * a.H + r) * a.W + w) * a.x_cs + a.x_co + cv * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  // The row is walked in blocks of kAhead columns whose source loads are all issued before the first of them is used: with
+  // the loads of column wo + 1 requested in the iteration that consumes them, every output pixel waited a full memory
+  // round trip (84 us for 1280 x 25 x 25 x 64: twice the HBM floor).  Same sums in the same order.
+  constexpr int kAhead = 4;
+  auto col_loads = [&](int w, float4 (&v)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = r0 + k;
+      v[k] = (w < a.W && r <= r1) ? *(const float4*)(xg + ((size_t)(b * a.H + r) * a.W + w) * a.x_cs + a.x_co + cv * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto col_sum = [&](const float4 (&v)[3]) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (r0 + k <= r1) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
     return s;
   };
-  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = colsum(0), c2;
-  for (int wo = 0; wo < a.W; ++wo) {
-    const bool right = wo + 1 < a.W;
-    c2 = right ? colsum(wo + 1) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float cnt = nrows * (float)(1 + (wo > 0) + right);
-    float v0 = ((c0.x + c1.x) + c2.x) / cnt * sc.x + sh.x, v1 = ((c0.y + c1.y) + c2.y) / cnt * sc.y + sh.y;
-    float v2 = ((c0.z + c1.z) + c2.z) / cnt * sc.z + sh.z, v3 = ((c0.w + c1.w) + c2.w) / cnt * sc.w + sh.w;
-    v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
-    const size_t off = ((size_t)(b * a.H + ho) * a.W + wo) * a.y_cs + a.y_co + cv * 4;
-    if (a.out_f32)
-      *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
-    else
-      *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-    c0 = c1;
-    c1 = c2;
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1, c2;
+  {
+    float4 v[3];
+    col_loads(0, v);
+    c1 = col_sum(v);
+  }
+  for (int w0 = 0; w0 < a.W; w0 += kAhead) {
+    float4 nx[kAhead][3];
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) col_loads(w0 + u + 1, nx[u]);      // columns w0 + 1 .. w0 + kAhead (zeros past the row)
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      const int wo = w0 + u;
+      if (wo >= a.W) break;
+      const bool right = wo + 1 < a.W;
+      c2 = right ? col_sum(nx[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float cnt = nrows * (float)(1 + (wo > 0) + right);
+      float v0 = ((c0.x + c1.x) + c2.x) / cnt * sc.x + sh.x, v1 = ((c0.y + c1.y) + c2.y) / cnt * sc.y + sh.y;
+      float v2 = ((c0.z + c1.z) + c2.z) / cnt * sc.z + sh.z, v3 = ((c0.w + c1.w) + c2.w) / cnt * sc.w + sh.w;
+      v0 = fmaxf(v0, lo); v1 = fmaxf(v1, lo); v2 = fmaxf(v2, lo); v3 = fmaxf(v3, lo);
+      const size_t off = ((size_t)(b * a.H + ho) * a.W + wo) * a.y_cs + a.y_co + cv * 4;
+      if (a.out_f32)
+        *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
+      else
+        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      c0 = c1;
+      c1 = c2;
+    }
   }
 }
 

@@ -132,29 +132,23 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ComicWsArgs a) {
       }
       return make_uint4(bf16x2_order(r[0]), bf16x2_order(r[1]), bf16x2_order(r[2]), bf16x2_order(r[3]));
     };
+    // three windows' loads (27 x 16 bytes a thread) stay in flight: with two, the launch behind MaxPool_5a moved 1.33 GB in
+    // 437 us, request-latency bound at 73 KB in flight per CU (the loader waves own registers the matrix waves' weight
+    // fragments do not need)
+    // (the pooled sources have Cin 64 / 192: KS 2 / 6; wider instantiations keep two windows -- their matrix waves hold more
+    // weight fragments and the allocation is per kernel)
+    constexpr int NWIN = KS <= 6 ? 3 : 2;
     auto pooled_tile = [&](int tile, int buf) {
-      uint4 ta[9], tb[9];
-      bool oka, okb;
-      const bf16_t* pa = window_base(tile, 0, oka);
-      load_window(pa, ta);
+      uint4 tw[NWIN][9];
+      bool okw[NWIN];
 #pragma unroll
-      for (int i = 0; i < KS; i += 2) {
-        if (i + 1 < KS) {
-          const bf16_t* pb = window_base(tile, i + 1, okb);
-          load_window(pb, tb);
-        }
-        {
-          const uint4 r = reduce_window(ta);
-          *(uint4*)(abuf + buf * ABYTES + loff[i]) = oka ? r : make_uint4(0, 0, 0, 0);
-        }
-        if (i + 2 < KS) {
-          pa = window_base(tile, i + 2, oka);
-          load_window(pa, ta);
-        }
-        if (i + 1 < KS) {
-          const uint4 r = reduce_window(tb);
-          *(uint4*)(abuf + buf * ABYTES + loff[i + 1]) = okb ? r : make_uint4(0, 0, 0, 0);
-        }
+      for (int i = 0; i < NWIN; ++i)
+        if (i < KS) load_window(window_base(tile, i, okw[i]), tw[i]);
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const uint4 r = reduce_window(tw[i % NWIN]);
+        *(uint4*)(abuf + buf * ABYTES + loff[i]) = okw[i % NWIN] ? r : make_uint4(0, 0, 0, 0);
+        if (i + NWIN < KS) load_window(window_base(tile, i + NWIN, okw[i % NWIN]), tw[i % NWIN]);
       }
     };
 
