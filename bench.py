@@ -255,7 +255,7 @@ def extras(device, enc, cnn_params, plan):
     Bf = 32
     plan_ft = nets.CnnPlan('inception_v3', (IMG, IMG))           # trainable CNN: the plain plan (has a backward)
     tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16', device, seed=5, plan=plan_ft)
-    tr.enable_cnn_finetune()
+    tr.enable_cnn_finetune()            # (CnnEncoder.autotune_backward exists; measured equal to the heuristic tiles: 6.3-6.5 ms either way)
     if tune:
         tr.encoder.autotune()              # forward variants of the plain plan (setup, untimed)
     imgs = torch.from_numpy(rng.uniform(-1, 1, (Bf, IMG, IMG, 3)).astype(np.float32)).to(device)

@@ -90,7 +90,8 @@ class GemmProb(C.Structure):         # struct comic_gemm_prob
 
 
 class ConvGrad(C.Structure):         # struct comic_conv_grad
-    _fields_ = [('w_master', c_void_p), ('dw', c_void_p), ('dbeta', c_void_p), ('w_bwd', c_void_p)]
+    _fields_ = [('w_master', c_void_p), ('dw', c_void_p), ('dbeta', c_void_p), ('w_bwd', c_void_p),
+                ('bwd_tile', c_int32), ('reserved', c_int32)]
 
 
 P = c_void_p

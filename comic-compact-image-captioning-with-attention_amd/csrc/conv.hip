@@ -3069,7 +3069,7 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   t.H = Hd; t.W = Wd; t.Cin = op->Cout; t.Cout = op->Cin; t.SH = t.SW = 1;
   t.PT = op->KH - 1 - op->PT; t.PL = op->KW - 1 - op->PL;
   t.Ho = op->H; t.Wo = op->W;
-  t.src_coff = 0; t.dst_coff = op->src_coff; t.relu = 0; t.out_f32 = 0; t.tile = 0; t.group = 0; t.lane = 0;
+  t.src_coff = 0; t.dst_coff = op->src_coff; t.relu = 0; t.out_f32 = 0; t.tile = gr->bwd_tile; t.group = 0; t.lane = 0;
   comic_conv_weight w2{gr->w_bwd, nullptr, nullptr};
   return run_op<T>(&t, dz, op->Cout, gx, xc, &w2, batch, st, /*accum=*/1);
 }

@@ -888,6 +888,86 @@ class CnnEncoder:
         self._train = t
         return t
 
+    def autotune_backward(self, reps=3, verbose=False, cache=None):
+        """cnn_finetune: pick the kernel variant of every conv's BACKWARD-DATA convolution (the forward conv of the masked
+        d-conv tensor with the flipped / transposed filter; comic_conv_grad.bwd_tile) by timing the candidates on the real
+        buffers, as autotune() does for the forward -- the heuristic picks 32x64 / 64x64 tiles for most of them at batch
+        32.  Every variant gives the same bits.  -> {weight index: (ms, tile)}."""
+        if self.dcode != 1:
+            return {}
+        t = self.enable_training()
+        torch, plan = self.torch, self.plan
+        st = L.stream_ptr()
+        key = self._tune_key() + ':bwd'
+        if cache and os.path.isfile(cache):
+            tiles = json.load(open(cache)).get(key)
+            if tiles is not None and len(tiles) == len(plan.weights):
+                for i, tl in enumerate(tiles):
+                    t.grads[i].bwd_tile = int(tl)
+                return {i: (None, tl) for i, tl in enumerate(tiles)}
+        L.check(self.lib.comic_cnn_pack_bwd_filters(self._ops, len(plan.ops), t.grads, self.dcode, st), 'cnn_pack_bwd_filters')
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        chosen = {}
+        for i, o in enumerate(plan.ops):
+            if o['kind'] != 0 or t.gbufs[o['src']] is None:
+                continue
+            wi = o['weight']
+            S = o['SH']
+            Hd, Wd = (o['Ho'] - 1) * S + 1, (o['Wo'] - 1) * S + 1
+            gx = t.gbufs[o['src']]
+            op = L.CnnOp(kind=0, src=0, dst=1, src_coff=0, dst_coff=o['src_coff'], H=Hd, W=Wd, Cin=o['Cout'], Cout=o['Cin'],
+                         KH=o['KH'], KW=o['KW'], SH=1, SW=1, PT=o['KH'] - 1 - o['PT'], PL=o['KW'] - 1 - o['PL'], Ho=o['H'],
+                         Wo=o['W'], weight=0, relu=0, out_f32=0, tile=0, flags=L.OP_RAW)
+            wt = L.ConvWeight(t.grads[wi].w_bwd, None, None, None)
+            x_ptr, y_ptr, yc = t.scratch.data_ptr(), gx.data_ptr(), gx.shape[3]
+
+            def run():
+                L.check(self.lib.comic_conv2d_bn_relu(C.byref(op), x_ptr, o['Cout'], y_ptr, yc, C.byref(wt), self.batch,
+                                                      self.dcode, st), 'backward-data conv (autotune)')
+
+            def timed(n_rep, blocks=2):
+                best = None
+                for _ in range(blocks):
+                    ev0.record()
+                    for _ in range(n_rep):
+                        run()
+                    ev1.record()
+                    ev1.synchronize()
+                    tb = ev0.elapsed_time(ev1) / n_rep
+                    best = tb if best is None else min(best, tb)
+                return best
+            cands = []
+            for tile in range(0, L.IMG_TILE):              # (no fragment-order copy of the backward filters: id 55 is out)
+                if tile == L.WS_TILE:
+                    continue
+                op.tile = tile
+                try:
+                    run(); run()
+                except L.ComicHipError:
+                    if L.is_im2col_tile(tile):
+                        raise
+                    continue
+                cands.append((timed(reps), tile))
+            cands.sort()
+            finals = []
+            for _, tile in cands[:3]:
+                op.tile = tile
+                run()
+                finals.append((timed(4 * reps, 3), tile))
+            best = min(finals)
+            t.grads[wi].bwd_tile = best[1]
+            chosen[wi] = best
+            if verbose:
+                print('autotune bwd-data op %3d %3dx%-3d %4d->%4d %dx%d -> tile %2d  %.1f us (heuristic %.1f us)' % (
+                    i, o['H'], o['W'], o['Cout'], o['Cin'], o['KH'], o['KW'], best[1], best[0] * 1e3,
+                    dict((tl, ms) for ms, tl in cands)[0] * 1e3))
+        t.gflat.zero_()
+        if cache:
+            db = json.load(open(cache)) if os.path.isfile(cache) else {}
+            db[key] = [int(t.grads[i].bwd_tile) for i in range(len(plan.weights))]
+            json.dump(db, open(cache, 'w'))
+        return chosen
+
     def grad_buckets(self, n=6):
         """Partition of the backward pass for the data-parallel gradient exchange: runs of whole
         blocks, LAST block first (the order the backward produces gradients), of roughly equal weight bytes.

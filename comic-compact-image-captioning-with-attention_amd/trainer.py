@@ -209,13 +209,16 @@ class CaptionTrainer:
         self.opt.step(self.decoder.grads, self.lr(), grad_scale=scale)
         return res
 
-    def enable_cnn_finetune(self, cnn_grad_multiplier=1.0):
-        """train_mode cnn_finetune (train.py:241-249): the CNN variables join the trainable set."""
+    def enable_cnn_finetune(self, cnn_grad_multiplier=1.0, autotune_backward=False, tune_cache=None):
+        """train_mode cnn_finetune (train.py:241-249): the CNN variables join the trainable set.
+        autotune_backward: time the kernel variants of every backward-data convolution once (CnnEncoder.autotune_backward)."""
         mult = float(cnn_grad_multiplier)
         l2 = self.opt.l2 * mult
         self.opt_cnn = (optim.AdamTF(self.encoder.w_master, epsilon=self.opt.eps, l2_decay=l2),
                         optim.AdamTF(self.encoder.beta, epsilon=self.opt.eps, l2_decay=l2), mult)
         self.encoder.enable_training()
+        if autotune_backward:
+            self.encoder.autotune_backward(cache=tune_cache)
 
     def finetune_step(self, images, captions, masks=None, training=True):
         """One cnn_finetune update: CNN forward -> decoder forward/backward (with input gradients)

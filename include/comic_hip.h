@@ -204,6 +204,8 @@ typedef struct comic_conv_grad {
   float* dw;
   float* dbeta;
   void* w_bwd;
+  int32_t bwd_tile;   /* kernel variant of the backward-data convolution (the ids of comic_cnn_op::tile; 0 = heuristic) */
+  int32_t reserved;
 } comic_conv_grad;
 /* Two lanes: with wgrad_stream != NULL (and != stream) and a scratch of comic_cnn_backward_scratch_bytes(..., lanes = 2)
  * bytes -- every conv's d-conv tensor side by side instead of the largest one -- the weight-gradient launch of a conv goes

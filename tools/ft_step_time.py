@@ -8,7 +8,7 @@ dev = 'cuda:0'
 Bf = int(os.environ.get('B', '32'))
 plan = nets.CnnPlan('inception_v3', (224, 224))
 tr = trainer.CaptionTrainer(plan.init_params(0), cdec.DecoderSpec(), None, Bf, (224, 224), 'bf16', dev, seed=5, plan=plan)
-tr.enable_cnn_finetune()
+tr.enable_cnn_finetune(autotune_backward=os.environ.get('COMIC_AUTOTUNE_BWD', '0') == '1', tune_cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     tr.encoder.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 rng = np.random.default_rng(0)
