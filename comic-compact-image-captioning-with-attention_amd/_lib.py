@@ -108,6 +108,7 @@ _SIGS = {
     'comic_clip_by_norm': (c_int, [P, P, P, c_int, c_float, c_float, c_float, P, P, P]),
     'comic_cnn_backward_scratch_bytes': (c_int64, [P, c_int, c_int, c_int, c_int]),
     'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
+    'comic_cnn_backward_sched': (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
     'comic_cnn_pack_bwd_filters': (c_int, [P, c_int, P, c_int, P]),
     'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
     'comic_cnn_pack_frag_weights': (c_int, [P, P, P, c_int, c_int64, P]),

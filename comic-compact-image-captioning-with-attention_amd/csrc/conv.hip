@@ -20,6 +20,8 @@
 #include "conv_img.h"
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -3154,7 +3156,123 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
   return 0;
 }
 
+// y += x; x = 0 (the join of the two chain lanes of comic_cnn_backward_sched)
+template <typename T>
+__global__ void add_clear_kernel(T* __restrict__ y, T* __restrict__ x, long n_chunks) {
+  constexpr int EPC = Elem<T>::EPC;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_chunks) return;
+  float a[EPC], b[EPC];
+  load_vec<T>(y + i * EPC, a);
+  load_vec<T>(x + i * EPC, b);
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    a[j] += b[j];
+    b[j] = 0.f;
+  }
+  store_vec<T>(y + i * EPC, a);
+  store_vec<T>(x + i * EPC, b);
+}
+
+inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits for everything issued on `from` so far
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+  const bool ok = hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
+  (void)hipEventDestroy(ev);
+  return ok;
+}
+
+template <typename T>
+int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched, void* const* buffers,
+                            void* const* grad_buffers, void* const* grad_alt, const int32_t* buf_channels,
+                            const comic_conv_weight* weights, const comic_conv_grad* grads, int batch, void* scratch,
+                            int64_t scratch_bytes, hipStream_t s0, hipStream_t s1, hipStream_t st_w, bool filters_ready) {
+  constexpr int EPC = Elem<T>::EPC;
+  COMIC_REQUIRE(s1 && s1 != s0 && st_w && st_w != s0 && st_w != s1, "cnn_backward_sched: needs three distinct streams");
+  COMIC_REQUIRE(backward_scratch_bytes(ops, n_ops, batch, sizeof(T), true) <= scratch_bytes,
+                "cnn_backward_sched: scratch too small (every conv needs its own d-conv slice)");
+  std::vector<size_t> dz_off((size_t)n_ops, 0);
+  size_t off = 0;
+  for (int i = 0; i < n_ops; ++i)
+    if (ops[i].kind <= 1) {
+      dz_off[i] = off;
+      off += dz_bytes_of(ops + i, batch, sizeof(T));
+    }
+  std::vector<char> seen((size_t)n_ops, 0);
+  bool lane1_open = false;
+  for (int k = 0; k < n_sched; ++k) {
+    const int32_t* r = sched + 4 * k;
+    if (r[0] == 1) {                       // FORK
+      COMIC_REQUIRE(link_streams(s0, s1), "cnn_backward_sched: fork failed");
+      lane1_open = true;
+      continue;
+    }
+    if (r[0] == 2) {                       // JOIN_ADD
+      COMIC_REQUIRE(link_streams(s1, s0), "cnn_backward_sched: join failed");
+      lane1_open = false;
+      if (r[1] >= 0) {
+        const comic_cnn_op* any = nullptr;
+        for (int i = 0; i < n_ops && !any; ++i)
+          if (ops[i].kind != 5 && ops[i].kind != 6 && ops[i].src == r[1]) any = ops + i;
+        COMIC_REQUIRE(any && grad_buffers[r[1]] && grad_alt && grad_alt[r[1]], "cnn_backward_sched: no alternate buffer %d", r[1]);
+        const long n = (long)batch * any->H * any->W * buf_channels[r[1]];
+        COMIC_REQUIRE(n % EPC == 0, "cnn_backward_sched: buffer %d is not a whole number of 16-byte chunks", r[1]);
+        hipLaunchKernelGGL((add_clear_kernel<T>), dim3((unsigned)cdiv64(n / EPC, 256)), dim3(256), 0, s0,
+                           (T*)grad_buffers[r[1]], (T*)grad_alt[r[1]], n / EPC);
+      }
+      continue;
+    }
+    COMIC_REQUIRE(r[0] == 0 && r[1] >= 0 && r[1] < n_ops && !seen[r[1]], "cnn_backward_sched: bad schedule row %d", k);
+    seen[r[1]] = 1;
+    const comic_cnn_op* op = ops + r[1];
+    COMIC_REQUIRE(r[2] == 0 || lane1_open, "cnn_backward_sched: lane 1 used outside a fork / join region");
+    hipStream_t st = r[2] ? s1 : s0;
+    void* gy = grad_buffers[op->dst];
+    COMIC_REQUIRE(gy, "cnn_backward_sched: op %d has no output gradient buffer", r[1]);
+    void* gx = r[3] ? (grad_alt ? grad_alt[op->src] : nullptr) : grad_buffers[op->src];
+    COMIC_REQUIRE(!r[3] || gx, "cnn_backward_sched: op %d has no alternate input-gradient buffer", r[1]);
+    const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
+    if (op->kind <= 1) {
+      void* dz = (char*)scratch + dz_off[r[1]];
+      if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
+                                    grads + op->weight, batch, dz, (int64_t)dz_bytes_of(op, batch, sizeof(T)), st,
+                                    filters_ready, st_w))
+        return rc;
+    } else if (op->kind <= 4) {
+      if (!gx) continue;
+      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st)) return rc;
+    } else {
+      COMIC_REQUIRE(false, "cnn_backward_sched: unknown op kind %d", op->kind);
+    }
+  }
+  COMIC_REQUIRE(!lane1_open, "cnn_backward_sched: the schedule ends inside a fork / join region");
+  for (int i = 0; i < n_ops; ++i)
+    COMIC_REQUIRE(seen[i] || ops[i].kind == 5 || ops[i].kind == 6, "cnn_backward_sched: op %d is not in the schedule", i);
+  COMIC_REQUIRE(link_streams(st_w, s0), "cnn_backward_sched: join of the weight-gradient lane failed");
+  COMIC_LAUNCH_CHECK("cnn_backward_sched");
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched,
+                                        void* const* buffers, void* const* grad_buffers, void* const* grad_buffers_alt,
+                                        const int32_t* buf_channels, const comic_conv_weight* weights,
+                                        const comic_conv_grad* grads, int batch, int dtype, int filters_ready, void* scratch,
+                                        int64_t scratch_bytes, void* stream0, void* stream1, void* wgrad_stream) {
+  COMIC_REQUIRE(ops && sched && buffers && grad_buffers && buf_channels && weights && grads && scratch,
+                "comic_cnn_backward_sched: null argument");
+  if (dtype == COMIC_BF16)
+    return cnn_backward_sched_impl<bf16_t>(ops, n_ops, sched, n_sched, buffers, grad_buffers, grad_buffers_alt, buf_channels,
+                                           weights, grads, batch, scratch, scratch_bytes, (hipStream_t)stream0,
+                                           (hipStream_t)stream1, (hipStream_t)wgrad_stream, filters_ready != 0);
+  if (dtype == COMIC_F32)
+    return cnn_backward_sched_impl<float>(ops, n_ops, sched, n_sched, buffers, grad_buffers, grad_buffers_alt, buf_channels,
+                                          weights, grads, batch, scratch, scratch_bytes, (hipStream_t)stream0,
+                                          (hipStream_t)stream1, (hipStream_t)wgrad_stream, filters_ready != 0);
+  COMIC_REQUIRE(false, "unknown dtype %d", dtype);
+  return 2;
+}
 
 extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype, int lanes) {
   if (!ops) return -1;

@@ -137,6 +137,7 @@ class CnnPlan:
         self.end_points = {}     # name -> buffer id
         self.macs = 0
         self._lane = 0
+        self._branch = None
         self.branch_streams = branch_streams
         # same-depth convs of the parallel branches share one launch (comic_cnn_forward_grouped)
         self.group_branches = group_branches and not branch_streams
@@ -214,7 +215,8 @@ class CnnPlan:
         self.ops.append(dict(kind=1 if stem else 0, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W,
                              Cin=Cin_p, Cout=cout_p, KH=kh, KW=kw, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo,
                              weight=len(self.weights) - 1, relu=0 if raw else 1, out_f32=int(out_f32), lane=self._lane,
-                             depth=self._depth, flags=(L.OP_RAW if raw else 0) | (L.OP_POOLED_SRC if pooled else 0)))
+                             depth=self._depth, flags=(L.OP_RAW if raw else 0) | (L.OP_POOLED_SRC if pooled else 0),
+                             branch=self._branch))
         self.macs += Ho * Wo * kh * kw * Cin * cout
         return dst, (Ho, Wo, cout)
 
@@ -268,7 +270,7 @@ class CnnPlan:
             dst = self._buf(Ho, Wo, Cc)
         self.ops.append(dict(kind=kind, src=src, dst=dst, src_coff=0, dst_coff=dst_coff, H=H, W=W, Cin=Cc, Cout=Cc,
                              KH=k, KW=k, SH=stride, SW=stride, PT=pt, PL=pl, Ho=Ho, Wo=Wo, weight=-1, relu=0,
-                             out_f32=0, lane=self._lane, depth=self._depth))
+                             out_f32=0, lane=self._lane, depth=self._depth, branch=self._branch))
         return dst, (Ho, Wo, Cc)
 
     def _schedule_by_depth(self, first_op):
@@ -464,6 +466,7 @@ class CnnPlan:
             for bi, branch in enumerate(branches):
                 scope = '%s/%s/Branch_%d' % (root, bname, bi)
                 self._lane = bi if self.branch_streams else 0   # branch 0 stays on the caller's stream
+                self._branch = bi
                 x = cur
                 if (self.pool_after_projection and len(branch) == 2 and branch[0][0] == 'avg' and branch[1][0] == 'c'
                         and branch[1][3] == (1, 1) and branch[1][2] % 16 == 0):
@@ -497,7 +500,10 @@ class CnnPlan:
                 coff += outs[bi][2]
             self._lane = 0
             self._depth = 0
+            self._branch = None
             self._pooled_src = None
+            for o in self.ops[first_op:]:
+                o.setdefault('block_in', cur)        # (python-side: the block's shared input buffer, see backward_schedule)
             if self.group_branches:
                 self._schedule_by_depth(first_op)
             if self.branch_streams:
@@ -535,6 +541,49 @@ class CnnPlan:
             p[prefix + '/BatchNorm/moving_mean'] = np.zeros(cout, np.float32)
             p[prefix + '/BatchNorm/moving_variance'] = np.ones(cout, np.float32)
         return p
+
+
+SCHED_RUN, SCHED_FORK, SCHED_JOIN_ADD = 0, 1, 2
+
+
+def backward_schedule(plan):
+    """cnn_finetune: the order and lanes of the backward pass for comic_cnn_backward_sched -- rows (action, index, lane, alt).
+    The parallel branches of an Inception block are independent chains until the backward-data products of their head convs
+    (and the pool branch's pool gradient) ACCUMULATE into the gradient of the block's shared input.  Inside a block the
+    branches are dealt to two lanes (longest first, by conv count); lane 1 accumulates into an alternate copy of that shared
+    gradient, and the join at the block's end adds it in.  Outside the blocks (stem, head) everything is lane 0."""
+    rows = []
+    alt_bufs = set()
+    done = set()
+    for (lo, hi) in reversed([tuple(r) for r in plan.block_ranges]):
+        idx = [i for i in range(hi - 1, lo - 1, -1) if plan.ops[i]['kind'] not in (5, 6)]
+        br = sorted({plan.ops[i].get('branch') for i in idx} - {None})
+        lanes = {}
+        if len(br) >= 2:
+            load = [0, 0]
+            weight = {b: sum(1 + (plan.ops[i]['kind'] <= 1) for i in idx if plan.ops[i].get('branch') == b) for b in br}
+            for b in sorted(br, key=lambda b: -weight[b]):
+                ln = 0 if load[0] <= load[1] else 1
+                lanes[b] = ln
+                load[ln] += weight[b]
+        forked = False
+        blk_in = None
+        for i in idx:
+            o = plan.ops[i]
+            ln = lanes.get(o.get('branch'), 0)
+            if ln == 1 and not forked:
+                rows.append((SCHED_FORK, 0, 0, 0))
+                forked = True
+            alt = 0
+            if ln == 1 and o.get('block_in') is not None and o['src'] == o['block_in'] and o['src'] != plan.input:
+                alt, blk_in = 1, o['src']
+                alt_bufs.add(o['src'])
+            rows.append((SCHED_RUN, i, ln, alt))
+            done.add(i)
+        if forked:
+            rows.append((SCHED_JOIN_ADD, blk_in if blk_in is not None else -1, 0, 0))
+    assert done == {i for i, o in enumerate(plan.ops) if o['kind'] not in (5, 6)}
+    return np.asarray(rows, np.int32).reshape(-1, 4), sorted(alt_bufs)
 
 
 def flat_layout(plan):
@@ -665,7 +714,7 @@ class CnnEncoder:
         ops = (L.CnnOp * len(plan.ops))()
         for i, o in enumerate(plan.ops):
             for k, v in o.items():
-                if k != 'depth':
+                if k not in ('depth', 'branch', 'block_in'):
                     setattr(ops[i], k, v)
             if self.dcode != 1:
                 ops[i].group = 0               # the fp32 parity path launches every conv on its own
@@ -677,6 +726,7 @@ class CnnEncoder:
         self._alt = {}                 # adopted input tensors: address -> [pointer table, graph, calls, tensor]
         self._last_bufptr = None
         self.backward_lanes = True     # cnn_finetune: weight gradients on a lane of their own (enable_training)
+        self.backward_branch_lanes = True   # ... and the branches of an Inception block on two chain lanes (backward_schedule)
         self._polite_lds_kb = 0
         self._fm_f32 = None
 
@@ -882,6 +932,17 @@ class CnnEncoder:
                                                                          self.dcode, 2 if self.backward_lanes else 1))
         t.scratch = torch.empty(t.scratch_bytes, dtype=torch.uint8, device=self.device)
         t.wlane = torch.cuda.Stream(device=self.device) if self.backward_lanes else None
+        # branch lanes of the backward (backward_schedule): a second chain stream and alternate gradient buffers of the
+        # blocks' shared inputs (zero between steps: the join adds them in and clears them)
+        t.sched, t.lane1 = None, None
+        if self.backward_lanes and self.backward_branch_lanes and plan.name == 'inception_v3':
+            sched, alt_bufs = backward_schedule(plan)
+            if alt_bufs:
+                t.sched = np.ascontiguousarray(sched)
+                t.lane1 = torch.cuda.Stream(device=self.device)
+                t.galt = {b: torch.zeros_like(t.gbufs[b]) for b in alt_bufs}
+                t.gptr_alt = (C.c_void_p * len(t.gbufs))(*[t.galt[b].data_ptr() if b in t.galt else None
+                                                           for b in range(len(t.gbufs))])
         t.aux = torch.cuda.Stream(device=self.device)
         t.filters_ev = torch.cuda.Event()
         t.filters_ver = -1
@@ -994,6 +1055,13 @@ class CnnEncoder:
         ready = t.filters_ver == self.w_master.__dict__.get('_ver', 0)   # else: packed inline by the executor
         if ready:
             self.torch.cuda.current_stream().wait_event(t.filters_ev)
+        if buckets is None and on_bucket is None and t.sched is not None:
+            L.check(self.lib.comic_cnn_backward_sched(self._ops, len(self.plan.ops), t.sched.ctypes.data, len(t.sched),
+                                                      self._last_bufptr or self._bufptr, t.gptr, t.gptr_alt, self._bufch,
+                                                      self._wt, t.grads, self.batch, self.dcode, int(ready),
+                                                      t.scratch.data_ptr(), t.scratch_bytes, L.stream_ptr(),
+                                                      t.lane1.cuda_stream, t.wlane.cuda_stream), 'cnn_backward_sched')
+            return t
         for bk in (buckets or [(0, len(self.plan.ops), None, None)]):
             lo, hi = bk[0], bk[1]
             first = C.byref(self._ops, lo * C.sizeof(L.CnnOp))

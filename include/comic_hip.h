@@ -219,6 +219,21 @@ int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
                        const comic_conv_weight* weights, const comic_conv_grad* grads, int batch,
                        int dtype, int filters_ready /* 1: w_bwd already packed, see below */,
                        void* scratch, int64_t scratch_bytes, void* stream, void* wgrad_stream);
+/* The same pass with the parallel branches of the Inception blocks on TWO chain lanes (cnn_finetune at batch 32 is a chain of
+ * ~300 dependent small launches).  sched: n_sched rows of four int32 (action, index, lane, alt) in issue order --
+ *   0 RUN       backward of ops[index] on chain lane `lane` (0: stream0, 1: stream1); alt = 1: its input gradient
+ *               accumulates into grad_buffers_alt[ops[index].src] instead of grad_buffers[...] (lane 1's contributions to a
+ *               block's shared input)
+ *   1 FORK      stream1 waits for everything issued on stream0 so far
+ *   2 JOIN_ADD  stream0 waits for stream1; index >= 0: grad_buffers[index] += grad_buffers_alt[index], the alternate buffer is
+ *               cleared (alternate buffers are zero between calls)
+ * Every op (kinds 5 / 6 excepted) appears exactly once, consumers before producers inside a lane; the scratch is the
+ * lanes = 2 size; weight gradients go to wgrad_stream as in comic_cnn_backward.  All lanes are joined into stream0. */
+int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched, void* const* buffers,
+                             void* const* grad_buffers, void* const* grad_buffers_alt, const int32_t* buf_channels,
+                             const comic_conv_weight* weights, const comic_conv_grad* grads, int batch, int dtype,
+                             int filters_ready, void* scratch, int64_t scratch_bytes, void* stream0, void* stream1,
+                             void* wgrad_stream);
 /* Packs the backward-data filters of every conv from the masters (what comic_cnn_backward does per
  * conv when filters_ready == 0).  They only change with the optimiser step, so the caller can do
  * this once per step off the critical path (e.g. on a second stream during the next forward). */
