@@ -25,5 +25,9 @@ tail -1 $out/bench_eager.log | cut -c1-200; cp /tmp/kt/b_kernel_stats.csv $out/b
 python3 $GRAFT_REPO_ROOT/tools/step_timeline.py /tmp/kt/b_kernel_trace.csv > $out/decoder_step_timeline.txt; tail -1 $out/decoder_step_timeline.txt
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_mfma.sh $out 1280 || echo "mfma 1280 failed"
-bash tools/pmc_cnn.sh $out 1280 || echo "traffic 1280 failed"
+bash tools/pmc_mfma.sh $out 64 || echo "mfma 64 failed"
+for nb in 1920 1280 640; do
+  rm -rf $out/tr_$nb; mkdir -p $out/tr_$nb
+  bash tools/pmc_cnn.sh $out/tr_$nb $nb || echo "traffic $nb failed"
+done
 ls $out | head -40
