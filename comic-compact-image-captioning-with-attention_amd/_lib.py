@@ -51,11 +51,13 @@ CELLS = {'LSTM': 0, 'LN_LSTM': 1, 'GRU': 2}          # include/comic_hip.h COMIC
  DEC_NO_BEAM_LOGITS, DEC_NO_LSTM_STREAM) = (1, 2, 4, 8, 16, 32, 64, 128, 256)
 DEC_PHASE_FWD, DEC_PHASE_BWD = 512, 1024       # comic_decoder_train_step in two calls (Decoder.train_step(phase=...))
 DEC_NO_GROUP_GEMM = 2048
+DEC_BWD_OWN_ROWS = 4096
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
             ('COMIC_PERSIST_STAMPS', '1', DEC_STAMPS), ('COMIC_BEAM_LOGITS', '0', DEC_NO_BEAM_LOGITS),
-            ('COMIC_LSTM_STREAM', '0', DEC_NO_LSTM_STREAM), ('COMIC_GROUP_GEMM', '0', DEC_NO_GROUP_GEMM))
+            ('COMIC_LSTM_STREAM', '0', DEC_NO_LSTM_STREAM), ('COMIC_GROUP_GEMM', '0', DEC_NO_GROUP_GEMM),
+            ('COMIC_BWD_OWN_ROWS', '1', DEC_BWD_OWN_ROWS))
 
 
 def decoder_flags_from_env():

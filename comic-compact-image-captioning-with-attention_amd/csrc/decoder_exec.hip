@@ -1229,8 +1229,10 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
   const int attn_bwd_mode = (d->prob == 0 && split_attn_bwd_enabled()) ? 2 : 1;
   if (persist_b) {
     // M > 64: the loop ADDS its rows' d keys into memory step by step (one writer per address, in step order)
-    if (M > 64) RC(fill(dkeys, 0.f, (long)B * M * D, st));
+    const bool own_rows = (d->flags & COMIC_DEC_BWD_OWN_ROWS) != 0;
+    if (M > 64 || own_rows) RC(fill(dkeys, 0.f, (long)B * M * D, st));
     ComicPersistBwdArgs pb{};
+    pb.own_rows = own_rows ? 1 : 0;
     pb.K = p->K; pb.W_q = p->W_q; pb.keys = keys;
     pb.ln_g = p->ln_g; pb.ln_b = p->ln_b; pb.v = p->v; pb.tau = p->tau; pb.lens = lens;
     pb.mask_in = drop_in ? mask_in : nullptr; pb.mask_out = drop_out ? mask_out : nullptr;

@@ -131,6 +131,7 @@ struct ComicPersistBwdArgs {
   int B, E, M, H, Tp;
   int method;
   int grp0, n_groups;     // as in ComicPersistFwdArgs
+  int own_rows;           // 1: the own-rows form of the large memories (template MODE 2) whatever M is (dkeys zero-filled by the caller)
 };
 
 bool comic_persist_bwd_supported(int B, int D, int E, int A, int M, int H, int Cv, int method, int prob,

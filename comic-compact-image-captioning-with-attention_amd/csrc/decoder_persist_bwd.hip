@@ -761,8 +761,8 @@ __global__ __launch_bounds__(kThreads) void decoder_bwd_persistent_kernel(ComicP
 }
 
 inline int bwd_mode(int M) { return M <= 28 ? 0 : M <= 64 ? 1 : 2; }   // the whole key matrix fits up to M = 28
-int64_t bwd_lds_bytes(int M) {
-  const int mode = bwd_mode(M);
+int64_t bwd_lds_bytes(int M, int mode = -1) {
+  if (mode < 0) mode = bwd_mode(M);
   const int64_t key_rows = mode == 0 ? M : mode == 1 ? 16 : (M + 3) / 4;
   return key_rows * kD * 4 + 8 * kD * 4 + kWaves * 64 * 16 + kWaves * kD * 4 + 3 * 16 * (mode == 2 ? 64 : 32) * 4 + 3 * kD * 4 +
          (mode == 2 ? 0 : 3 * kWaves * kD * 4) + 32 * 4;
@@ -788,12 +788,12 @@ int comic_dropout_rows(float* x, const float* mask, float keep, long rows, int c
 int comic_persist_bwd_launch(const ComicPersistBwdArgs& a_in, hipStream_t st) {
   ComicPersistBwdArgs a = a_in;
   a.stamps = a.grp0 == 0 ? comic_persist_stamps(1, a.Tp, st) : nullptr;
-  const int mode = bwd_mode(a.M);
+  const int mode = a.own_rows ? 2 : bwd_mode(a.M);     // own_rows: the own-rows form (MODE 2) at any M (its d keys go to memory with atomics: zero-filled by the caller)
   if (mode != 0 && !a.dotp) {
     comic_set_error("persistent decoder backward: M = %d needs the dot-product hand-off buffer", a.M);
     return 2;
   }
-  int64_t lds = bwd_lds_bytes(a.M);
+  int64_t lds = bwd_lds_bytes(a.M, mode);
   if (lds < 96 * 1024) lds = 96 * 1024;                        // more than half of the LDS: one workgroup per CU
   static PerDeviceOnce attr_once__[3];
   bool& attr_set = attr_once__[mode].slot();   // hipFuncSetAttribute holds per device

@@ -494,6 +494,7 @@ typedef struct comic_decoder_desc {
 #define COMIC_DEC_PHASE_BWD 1024u       /* ... only the rest (loss, backward), over the SAME workspace and arguments as the forward call */
 #define COMIC_DEC_NO_GROUP_GEMM 2048u    /* comic_decoder_train_step: the products outside the time loops as separate launches on two lanes
                                            instead of grouped launches (comic_gemm_group) */
+#define COMIC_DEC_BWD_OWN_ROWS 4096u    /* persistent backward loop in its own-rows form (the form of memories of more than 64 rows) whatever M is */
 #define COMIC_DEC_NO_LSTM_STREAM 256u   /* decode steps at > 32 rows with the per-row-tile fused LSTM kernel instead of the streaming one */
 #define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge (large V) / comic_beam_step's kernel (small V)
                                            instead of the streaming logits + top-k launch / the register-resident small step */
