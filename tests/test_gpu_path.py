@@ -638,12 +638,15 @@ def test_persistent_time_loop_equals_step_launches(B, geo, monkeypatch):
             assert abs(g['loss'] - ref['loss']) <= 1e-5 * abs(ref['loss'])
 
 
-@pytest.mark.parametrize('B', [64, 224])
-def test_persistent_loops_match_oracle_at_bench_geometry(B):
+@pytest.mark.parametrize('B', [64, 224, -64])
+def test_persistent_loops_match_oracle_at_bench_geometry(B, monkeypatch):
     """The persistent forward and backward time loops against the ORACLE (not against the per-step launches) at the
     geometry bench.py times -- COMIC-256: D = 512, E = 256, C = 2048, M = 25, 8 heads, tied, T' = 29, every dropout on
     with injected masks -- at batch 64 (four 16-row groups in one launch) and at the SCST step's 224 hypotheses (four
     consecutive launches).  Same 1e-3 bar as the small cases, max-norm and element-wise."""
+    if B < 0:      # the backward loop in its own-rows form (the form of memories of more than 64 rows) at M = 25
+        B = -B
+        monkeypatch.setenv('COMIC_BWD_OWN_ROWS', '1')
     spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
     Lc = 30                                               # row 0 has the longest caption: T' = Lc - 1 = 29
     p = _rand_params(cfg, 13)
