@@ -220,8 +220,25 @@ def extras(device, enc, cnn_params, plan):
             ids2d[r, L:] = 257
         return ids2d
 
+    # as train_fn's SCST loop with --encoder_group 8 (its auto value at batch 32: the frozen CNN's forward for the images of
+    # the next eight steps is ONE launch chain of 256 images, enqueued while the host scores the step that used up the
+    # previous group)
+    G_S = 8
+    enc_g = nets.CnnEncoder(plan, cnn_params, Bs * G_S, 'bf16', device, weights_from=enc_s)
+    if tune:
+        enc_g.autotune()
+    imgs_g = torch.from_numpy(rng.uniform(-1, 1, (Bs * G_S, IMG, IMG, 3)).astype(np.float32)).to(device)
+    feats = []
+
+    def encode_group():
+        im_g, fm_g = enc_g.forward(imgs_g, use_graph=True)
+        im_g, fm_g = im_g.clone(), fm_g.clone()
+        feats.extend((im_g[k * Bs:(k + 1) * Bs], fm_g[k * Bs:(k + 1) * Bs]) for k in range(G_S))
+
     def scst_step_realistic():
-        im, fm = encode_now()
+        if not feats:
+            encode_group()
+        im, fm = feats.pop(0)
         fetch_beam = dec.beam_search_ids(fm, im, W, real_iters)
         fetch_greedy = dec.greedy(fm, im, real_iters, defer=True)
         beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
@@ -230,15 +247,16 @@ def extras(device, enc, cnn_params, plan):
         cap_greedy = [[c] for c in id_to_caption(cut(fetch_greedy()[0]), cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
-        encode_ahead()
+        if not feats:
+            encode_group()
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
         opt.step(dec.grads, 1e-3)
         return res
-    for _ in range(2):
+    for _ in range(G_S):
         res = scst_step_realistic()
     torch.cuda.synchronize()
-    n, t0 = 5, time.perf_counter()
+    n, t0 = 2 * G_S, time.perf_counter()       # whole groups: two encoder forwards of 256 images inside the timed region
     for _ in range(n):
         res = scst_step_realistic()
     torch.cuda.synchronize()
@@ -246,7 +264,8 @@ def extras(device, enc, cnn_params, plan):
     out['scst_conv_mfma_frac'] = round(out['scst_images_per_sec'] * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
     out['scst_config'] = ('COMIC-256, batch 32, greedy + beam-7 rollouts of %d steps (the longest caption of a batch), every '
                           'hypothesis cut at its own length N ~ U{8..14} words (16..28 radix digits + EOS), C++ CIDEr-D+BLEU-4 '
-                          'reward, 224-hypothesis training step with T\' = %d (encoder once, features tiled); brackets: '
+                          'reward, 224-hypothesis training step with T\' = %d (encoder once per 8 steps: 256 images per forward, '
+                          'features tiled); brackets: '
                           'scst_one_step (rollouts end at once) and scst_full_length (40 steps)' % (real_iters, int(res['Tp'])))
     del enc_s, dec, opt
     torch.cuda.empty_cache()

@@ -142,9 +142,21 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
     start_epoch = time.time()
     greedy_high_sc = 0
     ahead = None
+    # --encoder_group G > 1 (frozen CNN): the images of the next G steps go through ONE encoder forward, enqueued while the
+    # host scores the current step (CaptionModel_SCST.prefetch_group); 1 = one forward per step, prefetched one step ahead
+    group = int(getattr(c, 'encoder_group', 1) or 0)
+    if group <= 0:                              # --encoder_group 0 (auto): about 256 images per forward, at most 8 steps ahead
+        group = mdl.auto_encoder_group(c.batch_size_train, images_per_forward=256, cap=8)
+    queue = []
     for step in range(start_step, c.max_step):
         epoch = int(step / num_batches) + 1
-        imgs, refs = ahead if ahead is not None else next(inputs_man.batch_train)
+        if group > 1:
+            if not queue:                       # (the first step, or a group that could not be prefetched)
+                queue = [next(inputs_man.batch_train) for _ in range(min(group, c.max_step - step))]
+                m_sample.prefetch_group([b[0] for b in queue])
+            imgs, refs = queue.pop(0)
+        else:
+            imgs, refs = ahead if ahead is not None else next(inputs_man.batch_train)
         # `cap_beam` is (beam_size, batch_size, time) -> (beam_size * batch_size, time):
         # [[im0_hypo0], ..., [imN_hypo0], [im0_hypo1], ..., [imN_hypo1]]   (train_fn.py:226-238)
         # (the greedy rollout runs on the device while the host turns the beam rollouts into text and ids)
@@ -159,9 +171,14 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
         cap_greedy = [[s] for s in id_to_caption(fetch_greedy(), c)]
         m_train.begin_train_scst(imgs, hypos_idx, tile=c.scst_beam_size)
         # the next batch's encoder forward joins the update's forward pass on the device while the host scores
-        ahead = next(inputs_man.batch_train) if step + 1 < c.max_step else None
-        if ahead is not None:
-            m_sample.prefetch_features(ahead[0])
+        if group > 1:
+            if not queue and step + 1 < c.max_step:
+                queue = [next(inputs_man.batch_train) for _ in range(min(group, c.max_step - step - 1))]
+                m_sample.prefetch_group([b[0] for b in queue])
+        else:
+            ahead = next(inputs_man.batch_train) if step + 1 < c.max_step else None
+            if ahead is not None:
+                m_sample.prefetch_features(ahead[0])
         hypos, sc_sample, sc_greedy = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         rewards = sc_sample - sc_greedy
         greedy_high_sc = max(greedy_high_sc, np.amax(sc_greedy))
