@@ -626,3 +626,55 @@ def test_bench_encoder_group_divides_the_timed_steps():
         g = bench.pick_encoder_group(k)
         assert 1 <= g <= max(bench.DEFAULT_ENC_GROUP, 1) and (k % g == 0 or g == bench.DEFAULT_ENC_GROUP)
 
+
+
+def test_backward_schedule_of_the_branch_lanes():
+    """nets.backward_schedule (comic_cnn_backward_sched): every op of the plan exactly once, consumers before producers
+    inside a lane, lane 1 only between a FORK and its JOIN_ADD, and a lane-1 op that feeds a block's shared input gradient
+    goes to the alternate buffer that the block's join adds in."""
+    from comic_amd import nets
+    for name in ('inception_v3',):
+        plan = nets.CnnPlan(name, (224, 224))
+        sched, alt = nets.backward_schedule(plan)
+        runs = [r for r in sched if r[0] == nets.SCHED_RUN]
+        assert sorted(int(r[1]) for r in runs) == [i for i, o in enumerate(plan.ops) if o['kind'] not in (5, 6)]
+        assert sum(1 for r in sched if r[0] == nets.SCHED_FORK) == sum(1 for r in sched if r[0] == nets.SCHED_JOIN_ADD) == 11
+        open_, produced_later = False, set()
+        pos = {int(r[1]): k for k, r in enumerate(sched) if r[0] == nets.SCHED_RUN}
+        for k, r in enumerate(sched):
+            if r[0] == nets.SCHED_FORK:
+                assert not open_
+                open_ = True
+            elif r[0] == nets.SCHED_JOIN_ADD:
+                assert open_ and int(r[1]) in alt
+                open_ = False
+            else:
+                o = plan.ops[int(r[1])]
+                assert r[2] == 0 or open_
+                if r[3]:
+                    assert r[2] == 1 and o['src'] == o['block_in'] and o['src'] in alt
+                elif r[2] == 1:
+                    assert o['src'] != o.get('block_in')           # lane 1 never touches the shared gradient directly
+                # every consumer of this op's output runs earlier in the schedule (reverse topological order)
+                for j, c in enumerate(plan.ops):
+                    if c['kind'] not in (5, 6) and c['src'] == o['dst'] and j in pos:
+                        assert pos[j] < k, (j, int(r[1]))
+        assert not open_
+        assert len(alt) == 11 and plan.input not in alt
+
+
+def test_gradient_clip_chunk_table():
+    """optim.GradClip: a variable is cut into chunks of <= 8192 elements; every record names its variable's first chunk and
+    chunk count (the second kernel sums exactly those partials in order)."""
+    from comic_amd import decoder as cdec, optim
+    shapes = {'a': (3, 5000), 'b': (700,), 'c': (), 'd': (40000,)}
+    p = cdec.FlatParams(shapes, 'cpu')
+    gc = optim.GradClip(p, 2.5)
+    t = gc.chunks.numpy()
+    assert t.shape == (2 + 1 + 1 + 5, 5) and gc.partial.numel() == 9
+    for seg, k in enumerate(shapes):
+        rows = t[t[:, 0] == seg]
+        n = int(np.prod(shapes[k])) if shapes[k] else 1
+        assert rows[:, 2].sum() == n and (rows[:, 2] <= 8192).all()
+        assert (rows[:, 3] == np.flatnonzero(t[:, 0] == seg)[0]).all() and (rows[:, 4] == len(rows)).all()
+        assert rows[0, 1] == p.offsets[k] and (np.diff(rows[:, 1]) == 8192).all()
