@@ -132,6 +132,8 @@ _SIGS = {
     'comic_dropout_mask_dev': (c_int, [P, c_int64, c_float, P, c_uint64, P]),
     'comic_dropout_masks4_dev': (c_int, [P, P, P, P, P]),
     'comic_image_preprocess': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
+    'comic_jpeg_pixels': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'comic_copy_rows_h2d': (c_int, [P, C.c_int64, P, C.c_int64, C.c_int64, c_int, P]),
     'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
@@ -207,6 +209,59 @@ def load():
     if lib.comic_abi_version() != 1:
         raise ComicHipError('ABI version mismatch')
     _lib = lib
+    return lib
+
+
+# ---- libcomic_jpeg.so: host half of the split JPEG decoder (include/comic_jpeg.h; plain C, no GPU runtime) ----------------
+JPEG_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libcomic_jpeg.so')
+JPEG_OK, JPEG_UNSUPPORTED, JPEG_CORRUPT, JPEG_TOO_SMALL, JPEG_IO = 0, 1, -1, -2, -3
+
+
+class JpegInfo(C.Structure):
+    """comic_jpeg_info (include/comic_jpeg.h), 512 bytes; the device reads the same records."""
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('ncomp', C.c_int32), ('hmax', C.c_int32), ('vmax', C.c_int32),
+                ('mcus_x', C.c_int32), ('mcus_y', C.c_int32), ('restart_interval', C.c_int32),
+                ('blocks_w', C.c_int32 * 3), ('blocks_h', C.c_int32 * 3), ('comp_w', C.c_int32 * 3), ('comp_h', C.c_int32 * 3),
+                ('coef_off', C.c_int64 * 3), ('coef_count', C.c_int64), ('coef_base', C.c_int64), ('pixel_off', C.c_int64),
+                ('quant', (C.c_uint16 * 64) * 3)]
+
+
+# the same record as a numpy structured dtype (vectorised access to a batch's records)
+JPEG_INFO_DTYPE = [('width', '<i4'), ('height', '<i4'), ('ncomp', '<i4'), ('hmax', '<i4'), ('vmax', '<i4'), ('mcus_x', '<i4'),
+                   ('mcus_y', '<i4'), ('restart_interval', '<i4'), ('blocks_w', '<i4', 3), ('blocks_h', '<i4', 3),
+                   ('comp_w', '<i4', 3), ('comp_h', '<i4', 3), ('coef_off', '<i8', 3), ('coef_count', '<i8'),
+                   ('coef_base', '<i8'), ('pixel_off', '<i8'), ('quant', '<u2', (3, 64))]
+
+_JPEG_SIGS = {
+    'comic_jpeg_read_header': (c_int, [P, C.c_int64, P]),
+    'comic_jpeg_decode_coefficients': (c_int, [P, C.c_int64, P, P]),
+    'comic_jpeg_decode_file': (c_int, [C.c_char_p, P, P, C.c_int64]),
+    'comic_jpeg_pool_create': (P, [c_int]),
+    'comic_jpeg_pool_destroy': (None, [P]),
+    'comic_jpeg_pool_submit': (P, [P, P, c_int, P, P, P, C.c_int64]),
+    'comic_jpeg_pool_wait': (c_int, [P, P, C.c_double, P]),
+}
+JPEG_EXPORTED_SYMBOLS = tuple(_JPEG_SIGS)
+_jpeg_lib = None
+
+
+def load_jpeg():
+    """Load libcomic_jpeg.so (built by `make -C csrc`).  Never touches the GPU runtime."""
+    global _jpeg_lib
+    if _jpeg_lib is not None:
+        return _jpeg_lib
+    if not os.path.exists(JPEG_LIB_PATH):
+        raise ComicHipError('JPEG entropy library not built: %s is missing (run `make -C csrc`)' % JPEG_LIB_PATH)
+    assert C.sizeof(JpegInfo) == 512
+    lib = C.CDLL(JPEG_LIB_PATH)
+    for name, (res, args) in _JPEG_SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ComicHipError('libcomic_jpeg.so does not export %s' % name)
+        fn.restype = res
+        fn.argtypes = args
+    _jpeg_lib = lib
     return lib
 
 

@@ -224,6 +224,51 @@ class DecodePool(object):
         self._blocks = []
 
 
+class JpegSplitPool(object):
+    """Split JPEG decode (config.loader_split_jpeg): host threads undo the entropy coding only, the device does the rest.
+
+    A persistent pool of C threads (libcomic_jpeg.so, include/comic_jpeg.h: no interpreter work per image, no GPU runtime)
+    turns the files of a batch into quantised DCT coefficients, written straight into a pinned staging slot; inverse DCT,
+    chroma upsampling and colour conversion run on the device in libjpeg's integer arithmetic (comic_jpeg_pixels), so the
+    RGB bytes are PIL's.  Stands where the reference's tf.data map decodes on host cores
+    (common/inputs/manager_image_caption.py:163-175).  Files the split decoder does not take (progressive, CMYK, ...) are
+    decoded by PIL when their batch is finished."""
+
+    def __init__(self, threads, slot_elems=640 * 640 * 3, max_batch=64, timeout_s=120.0):
+        from . import _lib as L
+        self.L, self.lib = L, L.load_jpeg()
+        self.threads = int(threads)
+        self.slot_elems = (int(slot_elems) + 7) // 8 * 8              # slots stay 16-byte aligned
+        self.max_batch = int(max_batch)
+        self.timeout_s = float(timeout_s)
+        self._pool = self.lib.comic_jpeg_pool_create(self.threads)
+        if not self._pool:
+            raise RuntimeError('comic_jpeg_pool_create(%d) failed' % self.threads)
+
+    def submit(self, paths, infos_ptr, status_ptr, coef_ptr):
+        import ctypes as C
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, self.slot_elems)
+        if not h:
+            raise RuntimeError('comic_jpeg_pool_submit failed')
+        return h
+
+    def wait(self, handle, paths=()):
+        """-> bytes of the decoded images' RGB blob (their pixel_off assigned).  Bounded like DecodePool.geometry."""
+        import ctypes as C
+        total = C.c_int64(0)
+        rc = self.lib.comic_jpeg_pool_wait(self._pool, handle, self.timeout_s, C.byref(total))
+        if rc != 0:
+            raise RuntimeError('JPEG decode threads did not return within %.0f s for: %s'
+                               % (self.timeout_s, ', '.join(str(p) for p in list(paths)[:4])))
+        return int(total.value)
+
+    def close(self):
+        if self._pool:
+            self.lib.comic_jpeg_pool_destroy(self._pool)          # waits for queued work
+            self._pool = None
+
+
 class PackedImages(object):
     """A batch of decoded images packed back to back (+ one comic_image_desc per image) by the producer thread."""
     __slots__ = ('slot', 'blob', 'desc', 'n', 'total')
@@ -297,6 +342,102 @@ class DevicePreprocessor(object):
         blk, total, pending = pool.decode_batch_async(paths)
         return PackedImages(('shm', pool, blk, pending, list(paths), list(params)), None, None, len(paths), total)
 
+    # ---- split JPEG decode: coefficients from the host threads, pixels on the device ------------------------------------
+    _DESC_DTYPE = np.dtype({'names': ['offset', 'in_h', 'in_w', 'flip', 'oy', 'ox', 'sy', 'sx'],
+                            'formats': ['<i8', '<i4', '<i4', '<i4', '<i4', '<i4', '<f4', '<f4'],
+                            'offsets': [0, 8, 12, 16, 20, 24, 28, 32], 'itemsize': 40})
+
+    def enable_split(self, jpool, slots):
+        """Consumer thread, once: the pinned staging slots the decode threads write coefficients into (the producer blocks
+        while all of them are in flight) and the device buffers of one batch."""
+        torch = self.torch
+        self._jpool = jpool
+        self._free_coef = queue.Queue()
+        n = jpool.max_batch
+        for _ in range(int(slots)):
+            self._free_coef.put(dict(coef=torch.empty(n * jpool.slot_elems, dtype=torch.int16).pin_memory(),
+                                     infos=torch.zeros(n * 512, dtype=torch.uint8).pin_memory(),
+                                     status=np.zeros(n, np.int32)))
+        with torch.cuda.device(self.device):
+            self._dev_coef = torch.empty(n * jpool.slot_elems, dtype=torch.int16, device=self.device)
+            self._dev_planes = torch.empty(n * jpool.slot_elems, dtype=torch.uint8, device=self.device)
+
+    def pack_paths_split(self, paths, params):
+        """Producer half: queue the files with the decode threads (which write into a pinned slot) and go on."""
+        jpool = self._jpool
+        if len(paths) > jpool.max_batch:
+            raise ValueError('batch of %d images exceeds the split decoder\'s staging slots (%d)' % (len(paths), jpool.max_batch))
+        slot = self._free_coef.get()
+        handle = jpool.submit(paths, slot['infos'].data_ptr(), slot['status'].ctypes.data, slot['coef'].data_ptr())
+        return PackedImages(('split', jpool, handle, slot, list(paths), list(params)), None, None, len(paths), 0)
+
+    def _finish_split(self, packed):
+        import ctypes as C
+        torch, L = self.torch, self.L
+        _, jpool, handle, slot, paths, params = packed.slot
+        n = packed.n
+        try:
+            pixel_bytes = jpool.wait(handle, paths)
+        except RuntimeError:
+            # threads of this batch may still write into the slot: it is retired with the batch, a fresh one takes its place
+            self.__dict__.setdefault('_retired_coef', []).append(slot)
+            self._free_coef.put(dict(coef=torch.empty_like(slot['coef']).pin_memory(),
+                                     infos=torch.zeros_like(slot['infos']).pin_memory(), status=np.zeros_like(slot['status'])))
+            raise
+        try:
+            return self._launch_split(packed, pixel_bytes)
+        except Exception:
+            self._free_coef.put(slot)             # (the wait has returned: no thread writes into it any more)
+            raise
+
+    def _launch_split(self, packed, pixel_bytes):
+        torch, L = self.torch, self.L
+        _, jpool, handle, slot, paths, params = packed.slot
+        n = packed.n
+        status = slot['status'][:n]
+        infos = slot['infos'].numpy()[:n * 512].view(L.JPEG_INFO_DTYPE)
+        ok = status == L.JPEG_OK
+        h, w = infos['height'].astype(np.int64), infos['width'].astype(np.int64)
+        off = infos['pixel_off'].astype(np.int64)
+        # files the split decoder does not take: PIL, appended behind the device-decoded images of the blob
+        late = []
+        for i in np.nonzero(~ok)[0]:
+            im = decode_image(paths[i])
+            infos['ncomp'][i] = 0
+            h[i], w[i], off[i] = im.shape[0], im.shape[1], pixel_bytes
+            late.append((int(pixel_bytes), im))
+            pixel_bytes += (im.size + 15) // 16 * 16
+        desc = np.zeros(n, self._DESC_DTYPE)
+        desc['offset'], desc['in_h'], desc['in_w'] = off, h, w
+        desc['flip'] = [int(bool(p[0])) for p in params]
+        desc['oy'] = [int(p[1]) for p in params]
+        desc['ox'] = [int(p[2]) for p in params]
+        desc['sy'] = (h / self.resize).astype(np.float32)
+        desc['sx'] = (w / self.resize).astype(np.float32)
+        with torch.cuda.device(self.device):
+            if self._dev_blob is None or self._dev_blob.numel() < pixel_bytes:
+                self._dev_blob = torch.empty(int(pixel_bytes * 1.3) + 4096, dtype=torch.uint8, device=self.device)
+            st = L.stream_ptr()
+            if ok.any():
+                used = int(infos['coef_count'][ok].max())
+                dev_infos = slot['infos'][:n * 512].to(self.device, non_blocking=True)
+                # only the used head of every fixed slot crosses the bus: one strided copy
+                L.check(self.lib.comic_copy_rows_h2d(self._dev_coef.data_ptr(), jpool.slot_elems * 2, slot['coef'].data_ptr(),
+                                                     jpool.slot_elems * 2, used * 2, n, st), 'copy_rows_h2d')
+                L.check(self.lib.comic_jpeg_pixels(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n, used // 64,
+                                                   int(w[ok].max()), int(h[ok].max()), self._dev_planes.data_ptr(),
+                                                   self._dev_blob.data_ptr(), st), 'jpeg_pixels')
+            for o, im in late:
+                self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.ascontiguousarray(im).reshape(-1)))
+            dev_desc = torch.from_numpy(desc.view(np.uint8)).to(self.device)
+            out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
+            L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
+                                                    self.h, self.w, self.resize, st), 'image_preprocess')
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        self._pending.append((('coef', slot), ev))
+        return out
+
     def _fill_desc(self, geo, params):
         import ctypes as C
         L = self.L
@@ -314,7 +455,9 @@ class DevicePreprocessor(object):
     def _reap(self):
         while self._pending and self._pending[0][1].query():
             slot = self._pending.pop(0)[0]
-            if isinstance(slot, tuple):          # shared-memory block of a DecodePool
+            if isinstance(slot, tuple) and slot[0] == 'coef':    # coefficient staging slot of the split JPEG decoder
+                self._free_coef.put(slot[1])
+            elif isinstance(slot, tuple):        # shared-memory block of a DecodePool
                 slot[1].release(slot[2])
             else:
                 self._free.put(slot)
@@ -333,6 +476,16 @@ class DevicePreprocessor(object):
             cache[blk.name] = t
         return t
 
+    def unregister_shm(self):
+        """Before a DecodePool is closed: its blocks stop being registered pinned memory (a mapping that goes away while
+        the runtime still lists it as pinned made later host-to-device copies of OTHER buffers fail)."""
+        torch = self.torch
+        cache = self.__dict__.pop('_shm_tensors', {})
+        if cache:
+            torch.cuda.synchronize()
+        for t in cache.values():
+            torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+
     def finish(self, packed):
         import ctypes as C
         torch, L = self.torch, self.L
@@ -340,6 +493,8 @@ class DevicePreprocessor(object):
         n, total = packed.n, packed.total
         dbytes = n * C.sizeof(L.ImageDesc)
         slot = packed.slot
+        if isinstance(slot, tuple) and slot[0] == 'split':
+            return self._finish_split(packed)
         if isinstance(slot, tuple):
             # waits: the workers have written every image of this batch (on a timeout the pool retires the block itself;
             # any other failure -- an oversized image -- leaves no writer behind: the block goes back)
@@ -422,8 +577,13 @@ class InputManager(object):
                 it.close()
         self._pool.shutdown(wait=False)
         if getattr(self, '_decode_pool', None) is not None:
+            if getattr(self, '_devpre', None) is not None:
+                self._devpre.unregister_shm()
             self._decode_pool.close()
             self._decode_pool = None
+        if getattr(self, '_jpeg_pool', None) is not None:
+            self._jpeg_pool.close()
+            self._jpeg_pool = None
 
     def _setup(self, config, is_inference):
         config.split_sizes = {}
@@ -545,6 +705,15 @@ class InputManager(object):
             return
         h, w = self.config.cnn_input_size
         self._devpre = DevicePreprocessor(device, h, w)
+        c = self.config
+        if getattr(c, 'loader_split_jpeg', False) and getattr(self, '_jpeg_pool', None) is None:
+            self._jpeg_pool = JpegSplitPool(int(getattr(c, 'loader_threads', 0)) or min(16, os.cpu_count() or 3),
+                                            slot_elems=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)),
+                                            max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
+                                                          getattr(c, 'batch_size_infer', 1)),
+                                            timeout_s=float(getattr(c, 'loader_timeout_s', 120.0)))
+            self._devpre.enable_split(self._jpeg_pool, self._prefetch_depth + 2)
+            return
         nproc = int(getattr(self.config, 'loader_processes', 0) or 0)
         if nproc > 0 and getattr(self, '_decode_pool', None) is None:
             c = self.config
@@ -566,6 +735,8 @@ class InputManager(object):
         params = [draw_augmentation(augment, h, w, self._aug_rng) for _ in paths]
         devpre = getattr(self, '_devpre', None)
         dpool = getattr(self, '_decode_pool', None)
+        if devpre is not None and getattr(self, '_jpeg_pool', None) is not None and all(isinstance(p, str) for p in paths):
+            return devpre.pack_paths_split(paths, params)       # entropy decode on C threads, pixels on the device
         if devpre is not None and dpool is not None and all(isinstance(p, str) for p in paths):
             return devpre.pack_paths(dpool, paths, params)      # decode in worker processes, straight into staging
         if devpre is not None:       # CPU half here (producer thread); the device half runs in Prefetch's consumer hook

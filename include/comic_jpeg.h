@@ -1,0 +1,76 @@
+/* comic_jpeg.h -- host half of the split JPEG decoder of the input pipeline.
+ *
+ * The reference decodes every training image inside its tf.data map (tf.image.decode_jpeg, i.e. libjpeg, in
+ * common/inputs/manager_image_caption.py:163-175 -> inception_preprocessing_radix.py).  Here the host only
+ * undoes the ENTROPY CODING of a baseline JPEG (Huffman codes -> quantised DCT coefficients, this header,
+ * libcomic_jpeg.so: plain C, no GPU runtime, callable from loader threads with the interpreter lock released);
+ * dequantisation, the inverse DCT, chroma upsampling and the YCbCr -> RGB conversion run on the device
+ * (comic_jpeg_pixels in comic_hip.h) with libjpeg's integer arithmetic (jidctint.c "ISLOW", jdsample.c fancy
+ * upsampling, jdcolor.c), so the pixels are the bits PIL / libjpeg-turbo produce.
+ *
+ * Files the split decoder does not take (progressive or arithmetic coding, multi-scan, CMYK / RGB colour spaces,
+ * 12-bit samples, sampling other than 1x1 / 2x1 / 2x2 with 1x1 chroma) are reported as COMIC_JPEG_UNSUPPORTED: the
+ * loader sends them through its PIL path.
+ */
+#ifndef COMIC_JPEG_H
+#define COMIC_JPEG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMIC_JPEG_OK 0
+#define COMIC_JPEG_UNSUPPORTED 1   /* a valid file the split decoder does not handle: fall back */
+#define COMIC_JPEG_CORRUPT (-1)    /* malformed or truncated stream */
+#define COMIC_JPEG_TOO_SMALL (-2)  /* the coefficient buffer handed in is smaller than coef_count */
+#define COMIC_JPEG_IO (-3)         /* the file could not be read */
+
+/* Geometry of one image and where its coefficients live.  Identical layout on the device (comic_jpeg_pixels reads an
+ * array of these records): 8-byte aligned, 512 bytes. */
+typedef struct comic_jpeg_info {
+  int32_t width, height;        /* image size in pixels */
+  int32_t ncomp;                /* 1 (greyscale) or 3 (YCbCr) */
+  int32_t hmax, vmax;           /* luma sampling factors (chroma is 1x1): 1x1, 2x1 or 2x2 */
+  int32_t mcus_x, mcus_y;       /* MCU grid */
+  int32_t restart_interval;     /* MCUs between RSTn markers (0: none) */
+  int32_t blocks_w[3], blocks_h[3];   /* block grid of each component, whole MCUs */
+  int32_t comp_w[3], comp_h[3];       /* libjpeg's downsampled_width / _height: the real samples of each component */
+  int64_t coef_off[3];          /* first coefficient of each component plane, in int16 elements from the image's base */
+  int64_t coef_count;           /* int16 elements of the image: sum of blocks_w * blocks_h * 64 */
+  int64_t coef_base;            /* filled by the caller: element offset of this image in the batch's coefficient blob */
+  int64_t pixel_off;            /* filled by the caller: byte offset of the RGB image in the batch's pixel blob */
+  uint16_t quant[3][64];        /* quantisation table of each component, natural (row-major) order */
+} comic_jpeg_info;
+
+/* Header only (SOI .. SOS): fills `info` (coef_base / pixel_off left 0).  COMIC_JPEG_OK / _UNSUPPORTED / _CORRUPT. */
+int comic_jpeg_read_header(const uint8_t* data, int64_t n, comic_jpeg_info* info);
+
+/* Entropy decode of the whole scan: block (by, bx) of component c lands at coef[coef_off[c] + (by * blocks_w[c] + bx) * 64],
+ * 64 quantised coefficients in natural order (DC prediction undone, not dequantised).  `coef` must hold
+ * info->coef_count elements; every block is written (zeros included). */
+int comic_jpeg_decode_coefficients(const uint8_t* data, int64_t n, const comic_jpeg_info* info, int16_t* coef);
+
+/* read_header + decode_coefficients of a file.  `coef_capacity` in int16 elements; COMIC_JPEG_TOO_SMALL leaves `info`
+ * filled so that the caller can size a larger buffer. */
+int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coef, int64_t coef_capacity);
+
+/* ---- a batch at a time: a persistent pool of decode threads ------------------------------------------------------------
+ * The loader's producer thread queues the files of a batch and goes on (several batches may be queued: the threads flow from
+ * one into the next, no batch waits for the stragglers of the one before); no interpreter work per image.
+ * Image i of a batch is decoded into the fixed slot coef + i * slot_elems (infos[i].coef_base = i * slot_elems), status[i]
+ * gets its code; an image that is unsupported, corrupt, unreadable or larger than its slot takes the loader's PIL path. */
+typedef struct comic_jpeg_pool comic_jpeg_pool;
+comic_jpeg_pool* comic_jpeg_pool_create(int threads);
+void comic_jpeg_pool_destroy(comic_jpeg_pool* pool);          /* waits for queued work */
+/* Returns a batch handle (NULL: bad arguments / out of memory).  `paths` is copied; infos / status / coef must stay valid
+ * until comic_jpeg_pool_wait has returned 0 for the handle. */
+void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, int n, comic_jpeg_info* infos, int32_t* status,
+                             int16_t* coef, int64_t slot_elems);
+/* 0: every image of the batch is done -- pixel_off of the decoded images assigned back to back (16-byte aligned, width *
+ * height * 3 bytes each), their sum in *pixel_bytes, the handle released.  1: not done within timeout_s (handle still valid). */
+int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* pixel_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

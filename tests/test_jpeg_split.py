@@ -1,0 +1,265 @@
+"""Split JPEG decoder of the input pipeline: libcomic_jpeg.so undoes the entropy coding on the host, the device
+(comic_jpeg_pixels) does inverse DCT / upsampling / colour conversion in libjpeg's integer arithmetic.
+
+CPU tests pin the host half + oracle/jpeg_ref.py (the restated pixel stage) against PIL's own decode and the committed golden
+vectors; the `gpu` tests compare the device half and the loader path with PIL, bit for bit."""
+import ctypes as C
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+from comic_amd import _lib as L
+from oracle import jpeg_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _split(data):
+    lib = L.load_jpeg()
+    info = L.JpegInfo()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    rc = lib.comic_jpeg_read_header(buf, len(data), C.byref(info))
+    if rc:
+        return rc, info, None
+    coef = np.zeros(info.coef_count, np.int16)
+    rc = lib.comic_jpeg_decode_coefficients(buf, len(data), C.byref(info), coef.ctypes.data)
+    return rc, info, coef
+
+
+def _encode(arr, **kw):
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(arr).save(b, 'JPEG', **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+
+
+def _photo(h, w, seed=0):
+    """Photograph-like content: smooth structure + texture + a few hard edges."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([127 + 110 * np.sin(xx / 17.0 + seed) * np.cos(yy / 13.0), 127 + 90 * np.cos((xx - yy) / 23.0),
+                     127 + 100 * np.sin((xx + 2 * yy) / 31.0)], -1)
+    base[h // 3:h // 2, w // 4:w // 2] = (250, 20, 30)
+    return np.clip(base + rng.normal(0, 10, base.shape), 0, 255).astype(np.uint8)
+
+
+def test_jpeg_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'comic_jpeg.h')).read()
+    declared = set(re.findall(r'\b(comic_jpeg_[a-z0-9_]+)\s*\(', header))
+    lib = L.load_jpeg()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(L.JPEG_EXPORTED_SYMBOLS) == declared, set(L.JPEG_EXPORTED_SYMBOLS) ^ declared
+    assert C.sizeof(L.JpegInfo) == 512 == np.dtype(L.JPEG_INFO_DTYPE).itemsize
+
+
+def test_golden_files_decode_to_the_committed_pixels(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'jpeg_split_golden.npz'))
+    names = sorted(k[:-4] for k in g.files if k.endswith('.jpg'))
+    assert len(names) == 6
+    for name in names:
+        rc, info, coef = _split(g[name + '.jpg'].tobytes())
+        assert rc == 0, (name, rc)
+        assert np.array_equal(jpeg_ref.pixels(info, coef), g[name + '.rgb']), name
+
+
+@pytest.mark.parametrize('sub', [0, 1, 2])
+def test_host_half_plus_oracle_give_pils_pixels(sub):
+    """Samplings x sizes (whole / partial MCUs, one-row, one-column strips) x qualities, restart intervals, optimised tables."""
+    n = 0
+    for (w, h) in ((160, 120), (159, 107), (83, 125), (17, 9), (8, 8), (9, 33), (100, 1), (5, 200), (161, 3)):
+        img = _photo(h, w, seed=w + h)
+        for q in (35, 85, 98):
+            data = _encode(img, quality=q, subsampling=sub)
+            rc, info, coef = _split(data)
+            if sub and (w + 1) // 2 <= 2:
+                assert rc == L.JPEG_UNSUPPORTED          # libjpeg uses the box filter there: left to PIL
+                continue
+            assert rc == 0, (w, h, q, rc)
+            assert np.array_equal(jpeg_ref.pixels(info, coef), _pil(data)), (w, h, q)
+            n += 1
+    img = _photo(96, 130, seed=5)
+    for kw in (dict(restart_marker_blocks=7), dict(restart_marker_rows=1), dict(optimize=True), dict(restart_marker_blocks=1)):
+        data = _encode(img, quality=88, subsampling=sub, **kw)
+        rc, info, coef = _split(data)
+        assert rc == 0, (kw, rc)
+        if 'optimize' not in kw:
+            assert info.restart_interval > 0
+        assert np.array_equal(jpeg_ref.pixels(info, coef), _pil(data)), kw
+    noise = np.random.default_rng(1).integers(0, 256, (41, 67, 3), dtype=np.uint8)          # every coefficient large
+    for q in (30, 100):
+        data = _encode(noise, quality=q, subsampling=sub)
+        rc, info, coef = _split(data)
+        assert rc == 0 and np.array_equal(jpeg_ref.pixels(info, coef), _pil(data)), q
+    assert n >= 20
+
+
+def test_greyscale_and_real_photographs():
+    grey = _photo(70, 90)[:, :, 0]
+    data = _encode(grey, quality=80)
+    rc, info, coef = _split(data)
+    assert rc == 0 and info.ncomp == 1
+    assert np.array_equal(jpeg_ref.pixels(info, coef), _pil(data))
+    import sklearn
+    d = os.path.join(os.path.dirname(sklearn.__file__), 'datasets', 'images')
+    for f in ('china.jpg', 'flower.jpg'):                 # camera files as they are (4:4:4, quantisation tables of their own)
+        data = open(os.path.join(d, f), 'rb').read()
+        rc, info, coef = _split(data)
+        assert rc == 0, f
+        assert np.array_equal(jpeg_ref.pixels(info, coef), _pil(data)), f
+
+
+def test_files_the_split_decoder_does_not_take_are_reported():
+    from PIL import Image
+    img = _photo(64, 64)
+    assert _split(_encode(img, progressive=True))[0] == L.JPEG_UNSUPPORTED
+    b = io.BytesIO()
+    Image.fromarray(img).convert('CMYK').save(b, 'JPEG')
+    assert _split(b.getvalue())[0] == L.JPEG_UNSUPPORTED
+    data = _encode(img, quality=90, subsampling=2)
+    assert _split(data[:len(data) // 2])[0] == L.JPEG_CORRUPT          # truncated inside the scan (PIL refuses it too)
+    assert _split(data[:100])[0] == L.JPEG_CORRUPT                     # truncated inside the headers
+    assert _split(b'not a jpeg at all')[0] == L.JPEG_CORRUPT
+    bad = bytearray(data)
+    bad[len(bad) // 2:len(bad) // 2 + 64] = b'\xff' * 64               # garbage in the scan: an error code or pixels, no crash
+    assert _split(bytes(bad))[0] in (L.JPEG_OK, L.JPEG_CORRUPT)
+
+
+def test_pool_decodes_queued_batches_into_fixed_slots(tmp_path):
+    lib = L.load_jpeg()
+    sizes = [(64, 48), (33, 70), (120, 90), (16, 16), (50, 50), (71, 29), (90, 120)]
+    paths, want = [], []
+    for i, (w, h) in enumerate(sizes):
+        data = _encode(_photo(h, w, seed=i), quality=70 + 3 * i, subsampling=i % 3)
+        p = str(tmp_path / ('%d.jpg' % i))
+        open(p, 'wb').write(data)
+        paths.append(p)
+        want.append(_pil(data))
+    prog = str(tmp_path / 'prog.jpg')
+    open(prog, 'wb').write(_encode(_photo(40, 40), progressive=True))
+    big = str(tmp_path / 'big.jpg')
+    open(big, 'wb').write(_encode(_photo(200, 200), quality=90, subsampling=0))
+    missing = str(tmp_path / 'missing.jpg')
+    batch = paths + [prog, big, missing]
+    slot = 120 * 96 * 3                                     # the 200 x 200 4:4:4 file does not fit
+    pool = lib.comic_jpeg_pool_create(3)
+    assert pool
+    runs = []
+    for rep in range(3):                                    # several batches queued before the first wait
+        order = batch[rep:] + batch[:rep]
+        n = len(order)
+        infos = np.zeros(n, L.JPEG_INFO_DTYPE)
+        status = np.full(n, 99, np.int32)
+        coef = np.full(n * slot, 7, np.int16)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in order])
+        h = lib.comic_jpeg_pool_submit(pool, arr, n, infos.ctypes.data, status.ctypes.data, coef.ctypes.data, slot)
+        assert h
+        runs.append((order, infos, status, coef, h))
+    for order, infos, status, coef, h in runs:
+        total = C.c_int64(-1)
+        assert lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(total)) == 0
+        off = 0
+        for i, p in enumerate(order):
+            if p == prog:
+                assert status[i] == L.JPEG_UNSUPPORTED
+            elif p == big:
+                assert status[i] == L.JPEG_TOO_SMALL and infos['coef_count'][i] > slot
+            elif p == missing:
+                assert status[i] == L.JPEG_IO
+            else:
+                assert status[i] == 0 and infos['coef_base'][i] == i * slot and infos['pixel_off'][i] == off
+                info = infos[i]
+                img = jpeg_ref.pixels(info, coef[i * slot:i * slot + int(info['coef_count'])])
+                assert np.array_equal(img, want[paths.index(p)]), p
+                off += (img.size + 15) // 16 * 16
+        assert total.value == off
+    lib.comic_jpeg_pool_destroy(pool)
+
+
+# ---- device half -----------------------------------------------------------------------------------------------------------
+def _mixed_files(tmp_path, count=12):
+    import sklearn
+    from PIL import Image
+    d = os.path.join(os.path.dirname(sklearn.__file__), 'datasets', 'images')
+    photos = [np.asarray(Image.open(os.path.join(d, f)).convert('RGB')) for f in ('china.jpg', 'flower.jpg')]
+    sizes = [(640, 480), (480, 640), (640, 427), (500, 375), (333, 500), (640, 640), (97, 131), (17, 9), (161, 3), (9, 200)]
+    paths = []
+    for i in range(count):
+        w, h = sizes[i % len(sizes)]
+        src = Image.fromarray(photos[i % 2]).resize((w, h)) if i % 4 != 3 else Image.fromarray(_photo(h, w, seed=i))
+        if i % 6 == 5:
+            src = src.convert('L')
+        p = str(tmp_path / ('m%d.jpg' % i))
+        kw = dict(quality=(60, 75, 90, 96)[i % 4], subsampling=(2, 2, 1, 0)[i % 4])
+        if i % 5 == 4:
+            kw['restart_marker_blocks'] = 11
+        src.save(p, 'JPEG', **kw)
+        paths.append(p)
+    return paths
+
+
+@pytest.mark.gpu
+def test_device_pixels_are_pils_pixels(tmp_path):
+    import torch
+    lib, jl = L.load(), L.load_jpeg()
+    paths = _mixed_files(tmp_path)
+    n = len(paths)
+    slot = 640 * 640 * 3
+    infos = np.zeros(n, L.JPEG_INFO_DTYPE)
+    coef = torch.zeros(n * slot, dtype=torch.int16)
+    off = 0
+    for i, p in enumerate(paths):
+        info = L.JpegInfo()
+        rc = jl.comic_jpeg_decode_file(os.fsencode(p), C.byref(info), coef.data_ptr() + 2 * i * slot, slot)
+        assert rc == 0, (p, rc)
+        info.coef_base, info.pixel_off = i * slot, off
+        off += (info.width * info.height * 3 + 15) // 16 * 16
+        infos[i] = np.frombuffer(bytes(info), L.JPEG_INFO_DTYPE)[0]
+    dev_coef = coef.cuda()
+    dev_infos = torch.from_numpy(infos.view(np.uint8)).cuda()
+    planes = torch.empty(n * slot, dtype=torch.uint8, device='cuda')
+    pixels = torch.zeros(off, dtype=torch.uint8, device='cuda')
+    L.check(lib.comic_jpeg_pixels(dev_coef.data_ptr(), dev_infos.data_ptr(), n, int(infos['coef_count'].max()) // 64,
+                                  int(infos['width'].max()), int(infos['height'].max()), planes.data_ptr(), pixels.data_ptr(),
+                                  L.stream_ptr()), 'jpeg_pixels')
+    got = pixels.cpu().numpy()
+    for i, p in enumerate(paths):
+        want = _pil(open(p, 'rb').read())
+        o = int(infos['pixel_off'][i])
+        img = got[o:o + want.size].reshape(want.shape)
+        assert np.array_equal(img, want), (p, np.argwhere(img != want)[:4])
+        # and the oracle agrees with both
+        assert np.array_equal(jpeg_ref.pixels(infos[i], coef.numpy()[i * slot:i * slot + int(infos['coef_count'][i])]), want)
+
+
+@pytest.mark.gpu
+def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
+    """The loader path end to end (pool -> pinned slot -> strided copy -> comic_jpeg_pixels -> comic_image_preprocess) against
+    PIL decode + the same device preprocessing; a progressive file and one larger than its slot take the PIL path inside."""
+    import torch
+    from comic_amd import inputs
+    paths = _mixed_files(tmp_path, 10)
+    prog = str(tmp_path / 'prog.jpg')
+    open(prog, 'wb').write(_encode(_photo(300, 400), progressive=True, quality=85))
+    paths.insert(3, prog)
+    pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
+    jpool = inputs.JpegSplitPool(4, slot_elems=640 * 480 * 3, max_batch=16)       # the 640 x 640 4:4:4 file exceeds it
+    pre.enable_split(jpool, 3)
+    params = [(bool(i % 2), (i * 7) % 33, (i * 5) % 33) for i in range(len(paths))]
+    ref = pre(list(map(inputs.decode_image, paths)), params).cpu()
+    inflight = [pre.pack_paths_split(paths, params) for _ in range(3)]
+    for packed in inflight:
+        got = pre.finish(packed).cpu()
+        assert torch.equal(got, ref)
+    torch.cuda.synchronize()
+    pre._reap()
+    assert pre._free_coef.qsize() == 3                     # every staging slot came back
+    jpool.close()
