@@ -31,6 +31,10 @@ def create_parser():
     a('--infer_length_penalty_weight', type=float, default=0.0, help='The length penalty weight used in beam search.')
     a('--infer_max_length', type=int, default=30, help='The maximum caption length allowed during inference.')
     a('--batch_size_infer', type=int, default=25, help='The batch size.')
+    # additions of this framework (the training run's choices apply when left out)
+    a('--loader_split_jpeg', action='store_true', default=None,
+      help='Split JPEG decode: C threads undo the entropy coding, the device does the pixels (bit-identical to PIL).')
+    a('--loader_threads', type=int, default=None, help='Decode threads of the loader.')
     return p
 
 
@@ -55,7 +59,7 @@ def main(argv=None):
         if len(args.infer_checkpoints) < 1:
             raise ValueError('`infer_checkpoints` must be either `all` or a list of comma-separated checkpoint numbers.')
     c = conf.load_config(pjoin(args.infer_checkpoints_dir, 'config.pkl'))
-    c.__dict__.update(args.__dict__)
+    c.__dict__.update({k: v for k, v in args.__dict__.items() if v is not None})
     save_name = 'beam_{}_lpen_{}'.format(c.infer_beam_size, c.infer_length_penalty_weight)
     save_name = {'test': 'infer_test_', 'valid': 'infer_valid_', 'coco_test': 'infer_cocoTest_',
                  'coco_valid': 'infer_cocoValid_'}[c.infer_set] + save_name

@@ -263,3 +263,31 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     pre._reap()
     assert pre._free_coef.qsize() == 3                     # every staging slot came back
     jpool.close()
+
+
+@pytest.mark.gpu
+def test_input_manager_with_split_decode_yields_the_batches_of_the_thread_decode(tmp_path):
+    """config.loader_split_jpeg (train.py / infer.py --loader_split_jpeg): the managers' batches -- images on the device,
+    captions -- are the ones of the default loader (PIL decode threads + device preprocessing), bit for bit."""
+    import torch
+    from tests import tiny_dataset
+    from comic_amd import inputs, configuration as conf
+    ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=24, n_valid=4, n_test=4)
+    kw = dict(dataset_dir=ds, dataset_file_pattern='mscoco_{}_w5_s20_include_restval', cnn_name='inception_v3',
+              cnn_input_size=[224, 224], cnn_input_augment=True, batch_size_train=8, batch_size_eval=2, max_epoch=3,
+              rand_seed=7, token_type='radix', radix_base=256, loader_threads=4)
+    a = inputs.InputManager_Radix(conf.Config(loader_split_jpeg=True, **kw))
+    b = inputs.InputManager_Radix(conf.Config(**kw))
+    try:
+        a.enable_device_preprocess('cuda:0')
+        b.enable_device_preprocess('cuda:0')
+        assert a._jpeg_pool is not None and getattr(b, '_jpeg_pool', None) is None
+        for it_a, it_b in ((a.batch_train, b.batch_train), (a.batch_eval, b.batch_eval)):
+            for _ in range(5):
+                (ia, ca), (ib, cb) = next(it_a), next(it_b)
+                assert ia.is_cuda and ia.dtype == torch.float32 and tuple(ia.shape[1:]) == (224, 224, 3)
+                assert torch.equal(ia, ib)
+                np.testing.assert_array_equal(ca, cb)
+    finally:
+        a.close()
+        b.close()
