@@ -133,7 +133,6 @@ _SIGS = {
     'comic_dropout_masks4_dev': (c_int, [P, P, P, P, P]),
     'comic_image_preprocess': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     'comic_jpeg_pixels': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
-    'comic_copy_rows_h2d': (c_int, [P, C.c_int64, P, C.c_int64, C.c_int64, c_int, P]),
     'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
@@ -239,7 +238,7 @@ _JPEG_SIGS = {
     'comic_jpeg_pool_create': (P, [c_int]),
     'comic_jpeg_pool_destroy': (None, [P]),
     'comic_jpeg_pool_submit': (P, [P, P, c_int, P, P, P, C.c_int64]),
-    'comic_jpeg_pool_wait': (c_int, [P, P, C.c_double, P]),
+    'comic_jpeg_pool_wait': (c_int, [P, P, C.c_double, P, P]),
 }
 JPEG_EXPORTED_SYMBOLS = tuple(_JPEG_SIGS)
 _jpeg_lib = None

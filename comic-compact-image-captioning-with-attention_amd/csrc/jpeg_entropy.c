@@ -408,13 +408,60 @@ int comic_jpeg_decode_coefficients(const uint8_t* data, int64_t n, const comic_j
   return rc;
 }
 
-// file bytes of the calling thread: grows, never shrinks (a fresh 100-200 KB malloc per image is an mmap + page faults)
-static __thread uint8_t* tl_data = NULL;
-static __thread size_t tl_cap = 0;
-static __thread Parsed* tl_parsed = NULL;
+static int read_file(const char* path, uint8_t** out, int64_t* out_n);
 
 int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coef, int64_t coef_capacity) {
   if (!path || !info) return COMIC_JPEG_CORRUPT;
+  uint8_t* data = NULL;
+  int64_t n = 0;
+  int rc = read_file(path, &data, &n);
+  if (rc) return rc;
+  Parsed* ps = (Parsed*)malloc(sizeof(Parsed));
+  rc = ps ? parse(data, n, ps, 1) : COMIC_JPEG_IO;
+  if (ps) *info = ps->info;
+  if (rc == COMIC_JPEG_OK) {
+    if (!coef || coef_capacity < ps->info.coef_count) rc = COMIC_JPEG_TOO_SMALL;
+    else rc = decode_scan(data, n, ps, coef);
+  }
+  free(ps);
+  free(data);
+  return rc;
+}
+
+// ---- the decode pool ---------------------------------------------------------------------------------------------------------
+// Two passes per batch so that the coefficients of its images lie back to back (ONE host-to-device copy per batch; a copy per
+// image cost the consumer thread 30 us each): pass 1 reads every file and parses its headers, the thread that finishes the
+// last one lays the images out, pass 2 decodes the scans.  Threads that find a batch between its passes go on to the next
+// queued batch.
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+  uint8_t* data;                   // the file, kept from pass 1 to pass 2
+  int64_t n;
+  Parsed* ps;                      // its tables
+} Item;
+
+typedef struct Batch {
+  char** paths;
+  Item* items;
+  int n, next1, done1, next2, done2;
+  comic_jpeg_info* infos;
+  int32_t* status;
+  int16_t* coef;
+  int64_t capacity, used;
+  struct Batch* link;
+} Batch;
+
+struct comic_jpeg_pool {
+  pthread_mutex_t mu;
+  pthread_cond_t work, done;
+  Batch* head;                     // batches with passes left, in submission order
+  int stop, nthreads;
+  pthread_t* threads;
+};
+
+static int read_file(const char* path, uint8_t** out, int64_t* out_n) {
   const int fd = open(path, O_RDONLY | O_CLOEXEC);
   if (fd < 0) return COMIC_JPEG_IO;
   struct stat st;
@@ -423,87 +470,116 @@ int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coe
     return COMIC_JPEG_IO;
   }
   const size_t n = (size_t)st.st_size;
-  if (tl_cap < n + 8) {
-    free(tl_data);
-    tl_cap = (n + 8) * 3 / 2;
-    tl_data = (uint8_t*)malloc(tl_cap);
-    if (!tl_data) {
-      tl_cap = 0;
-      close(fd);
-      return COMIC_JPEG_IO;
-    }
+  uint8_t* data = (uint8_t*)malloc(n + 8);
+  if (!data) {
+    close(fd);
+    return COMIC_JPEG_IO;
   }
   size_t got = 0;
   while (got < n) {
-    const ssize_t r = read(fd, tl_data + got, n - got);
+    const ssize_t r = read(fd, data + got, n - got);
     if (r <= 0) break;
     got += (size_t)r;
   }
   close(fd);
-  if (got != n) return COMIC_JPEG_IO;
-  memset(tl_data + n, 0, 8);
-  if (!tl_parsed) tl_parsed = (Parsed*)malloc(sizeof(Parsed));
-  if (!tl_parsed) return COMIC_JPEG_IO;
-  Parsed* ps = tl_parsed;
-  int rc = parse(tl_data, (int64_t)n, ps, 1);
-  *info = ps->info;
-  if (rc == COMIC_JPEG_OK) {
-    if (!coef || coef_capacity < ps->info.coef_count) rc = COMIC_JPEG_TOO_SMALL;
-    else rc = decode_scan(tl_data, (int64_t)n, ps, coef);
+  if (got != n) {
+    free(data);
+    return COMIC_JPEG_IO;
   }
-  return rc;
+  memset(data + n, 0, 8);
+  *out = data;
+  *out_n = (int64_t)n;
+  return COMIC_JPEG_OK;
 }
 
-// ---- the decode pool ---------------------------------------------------------------------------------------------------------
-#include <pthread.h>
-#include <time.h>
+static void item_free(Item* it) {
+  free(it->data);
+  free(it->ps);
+  it->data = NULL;
+  it->ps = NULL;
+}
 
-typedef struct Batch {
-  char** paths;
-  int n, next, remaining;
-  comic_jpeg_info* infos;
-  int32_t* status;
-  int16_t* coef;
-  int64_t slot_elems;
-  struct Batch* link;
-} Batch;
+static void pass1(Batch* b, int i) {
+  Item* it = &b->items[i];
+  comic_jpeg_info* in = &b->infos[i];
+  memset(in, 0, sizeof(*in));
+  int rc = read_file(b->paths[i], &it->data, &it->n);
+  if (rc == COMIC_JPEG_OK) {
+    it->ps = (Parsed*)malloc(sizeof(Parsed));
+    rc = it->ps ? parse(it->data, it->n, it->ps, 1) : COMIC_JPEG_IO;
+    if (it->ps) *in = it->ps->info;
+  }
+  b->status[i] = rc;
+  if (rc != COMIC_JPEG_OK) item_free(it);
+}
 
-struct comic_jpeg_pool {
-  pthread_mutex_t mu;
-  pthread_cond_t work, done;
-  Batch* head;                     // batches with images left to hand out, in submission order
-  Batch* tail;
-  int stop, nthreads;
-  pthread_t* threads;
-};
+// (under the pool's lock, by the thread that finished the batch's last header)
+static void lay_out(Batch* b) {
+  int64_t used = 0;
+  for (int i = 0; i < b->n; ++i) {
+    if (b->status[i] != COMIC_JPEG_OK) continue;
+    const int64_t count = b->infos[i].coef_count;            // whole blocks: a multiple of 64 elements
+    if (used + count > b->capacity) {
+      b->status[i] = COMIC_JPEG_TOO_SMALL;
+      item_free(&b->items[i]);
+      continue;
+    }
+    b->infos[i].coef_base = used;
+    used += count;
+  }
+  b->used = used;
+}
+
+static void pass2(Batch* b, int i) {
+  if (b->status[i] != COMIC_JPEG_OK) return;
+  Item* it = &b->items[i];
+  it->ps->info.coef_base = b->infos[i].coef_base;
+  const int rc = decode_scan(it->data, it->n, it->ps, b->coef + b->infos[i].coef_base);
+  b->status[i] = rc;
+  item_free(it);
+}
 
 static void* pool_worker(void* arg) {
   comic_jpeg_pool* pool = (comic_jpeg_pool*)arg;
   pthread_mutex_lock(&pool->mu);
   for (;;) {
-    while (!pool->head && !pool->stop) pthread_cond_wait(&pool->work, &pool->mu);
-    if (!pool->head) break;        // stop, and nothing queued
     Batch* b = pool->head;
-    const int i = b->next++;
-    if (b->next == b->n) {
-      pool->head = b->link;
-      if (!pool->head) pool->tail = NULL;
+    int i = -1, pass = 0;
+    for (; b; b = b->link) {
+      if (b->next1 < b->n) {
+        i = b->next1++;
+        pass = 1;
+        break;
+      }
+      if (b->done1 == b->n && b->next2 < b->n) {
+        i = b->next2++;
+        pass = 2;
+        break;
+      }
+    }
+    if (!pass) {
+      if (pool->stop && !pool->head) break;
+      pthread_cond_wait(&pool->work, &pool->mu);
+      continue;
     }
     pthread_mutex_unlock(&pool->mu);
-    comic_jpeg_info* in = &b->infos[i];
-    int rc = comic_jpeg_decode_file(b->paths[i], in, b->coef + (int64_t)i * b->slot_elems, b->slot_elems);
-    in->coef_base = (int64_t)i * b->slot_elems;
-    in->pixel_off = 0;
-    b->status[i] = rc;
+    if (pass == 1) pass1(b, i);
+    else pass2(b, i);
     pthread_mutex_lock(&pool->mu);
-    if (--b->remaining == 0) pthread_cond_broadcast(&pool->done);
+    if (pass == 1) {
+      if (++b->done1 == b->n) {
+        lay_out(b);
+        pthread_cond_broadcast(&pool->work);                 // pass 2 of this batch is open
+      }
+    } else if (++b->done2 == b->n) {
+      Batch** at = &pool->head;                              // out of the list; the waiter frees it
+      while (*at && *at != b) at = &(*at)->link;
+      if (*at) *at = b->link;
+      pthread_cond_broadcast(&pool->done);
+      if (pool->stop) pthread_cond_broadcast(&pool->work);
+    }
   }
   pthread_mutex_unlock(&pool->mu);
-  free(tl_data);
-  free(tl_parsed);
-  tl_data = NULL;
-  tl_parsed = NULL;
-  tl_cap = 0;
   return NULL;
 }
 
@@ -549,18 +625,22 @@ static void batch_free(Batch* b) {
   if (!b) return;
   if (b->paths)
     for (int i = 0; i < b->n; ++i) free(b->paths[i]);
+  if (b->items)
+    for (int i = 0; i < b->n; ++i) item_free(&b->items[i]);
   free(b->paths);
+  free(b->items);
   free(b);
 }
 
 void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, int n, comic_jpeg_info* infos, int32_t* status,
-                             int16_t* coef, int64_t slot_elems) {
-  if (!pool || !paths || n <= 0 || !infos || !status || !coef || slot_elems <= 0) return NULL;
+                             int16_t* coef, int64_t capacity) {
+  if (!pool || !paths || n <= 0 || !infos || !status || !coef || capacity <= 0) return NULL;
   Batch* b = (Batch*)calloc(1, sizeof(Batch));
   if (!b) return NULL;
-  b->paths = (char**)calloc((size_t)n, sizeof(char*));
   b->n = n;
-  if (!b->paths) {
+  b->paths = (char**)calloc((size_t)n, sizeof(char*));
+  b->items = (Item*)calloc((size_t)n, sizeof(Item));
+  if (!b->paths || !b->items) {
     batch_free(b);
     return NULL;
   }
@@ -571,21 +651,20 @@ void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, in
       return NULL;
     }
   }
-  b->remaining = n;
   b->infos = infos;
   b->status = status;
   b->coef = coef;
-  b->slot_elems = slot_elems;
+  b->capacity = capacity;
   pthread_mutex_lock(&pool->mu);
-  if (pool->tail) pool->tail->link = b;
-  else pool->head = b;
-  pool->tail = b;
+  Batch** at = &pool->head;
+  while (*at) at = &(*at)->link;
+  *at = b;
   pthread_cond_broadcast(&pool->work);
   pthread_mutex_unlock(&pool->mu);
   return b;
 }
 
-int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* pixel_bytes) {
+int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* coef_elems, int64_t* pixel_bytes) {
   if (!pool || !batch) return COMIC_JPEG_CORRUPT;
   Batch* b = (Batch*)batch;
   struct timespec until;
@@ -598,11 +677,11 @@ int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, i
     until.tv_nsec -= 1000000000L;
   }
   pthread_mutex_lock(&pool->mu);
-  while (b->remaining > 0)
+  while (b->done2 < b->n)
     if (pthread_cond_timedwait(&pool->done, &pool->mu, &until)) break;
-  const int left = b->remaining;
+  const int finished = b->done2 == b->n;
   pthread_mutex_unlock(&pool->mu);
-  if (left > 0) return 1;
+  if (!finished) return 1;
   int64_t off = 0;
   for (int i = 0; i < b->n; ++i)
     if (b->status[i] == COMIC_JPEG_OK) {
@@ -610,6 +689,7 @@ int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, i
       off += ((int64_t)b->infos[i].width * b->infos[i].height * 3 + 15) & ~(int64_t)15;
     }
   if (pixel_bytes) *pixel_bytes = off;
+  if (coef_elems) *coef_elems = b->used;
   batch_free(b);
   return 0;
 }

@@ -72,19 +72,3 @@ extern "C" int comic_image_preprocess(const uint8_t* blob, const void* desc, int
   COMIC_LAUNCH_CHECK("image_preprocess");
   return 0;
 }
-
-// The used head of every fixed staging slot of a batch (pinned host memory) -> the same slots on the device, in stream
-// order: one call from the loader instead of one per image.  (Plain 1-D copies: hipMemcpy2DAsync refused the 2.4 MB pitch of
-// the default slots.)
-extern "C" int comic_copy_rows_h2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t row_bytes,
-                                   int rows, void* stream) {
-  COMIC_REQUIRE(dst && src, "copy_rows_h2d: null pointer");
-  COMIC_REQUIRE(rows > 0 && row_bytes > 0 && row_bytes <= dst_pitch && row_bytes <= src_pitch, "copy_rows_h2d: bad sizes");
-  for (int i = 0; i < rows; ++i) {
-    const hipError_t e = hipMemcpyAsync((char*)dst + (size_t)i * dst_pitch, (const char*)src + (size_t)i * src_pitch,
-                                        (size_t)row_bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
-    COMIC_REQUIRE(e == hipSuccess, "copy_rows_h2d: hipMemcpyAsync of row %d (%lld bytes) failed: %s", i, (long long)row_bytes,
-                  hipGetErrorString(e));
-  }
-  return 0;
-}

@@ -228,40 +228,44 @@ class JpegSplitPool(object):
     """Split JPEG decode (config.loader_split_jpeg): host threads undo the entropy coding only, the device does the rest.
 
     A persistent pool of C threads (libcomic_jpeg.so, include/comic_jpeg.h: no interpreter work per image, no GPU runtime)
-    turns the files of a batch into quantised DCT coefficients, written straight into a pinned staging slot; inverse DCT,
+    turns the files of a batch into quantised DCT coefficients, written back to back into a pinned staging slot (one
+    host-to-device copy per batch); inverse DCT,
     chroma upsampling and colour conversion run on the device in libjpeg's integer arithmetic (comic_jpeg_pixels), so the
     RGB bytes are PIL's.  Stands where the reference's tf.data map decodes on host cores
     (common/inputs/manager_image_caption.py:163-175).  Files the split decoder does not take (progressive, CMYK, ...) are
     decoded by PIL when their batch is finished."""
 
-    def __init__(self, threads, slot_elems=640 * 640 * 3, max_batch=64, timeout_s=120.0):
+    def __init__(self, threads, slot_elems=640 * 640 * 3 // 2, max_batch=64, timeout_s=120.0):
         from . import _lib as L
         self.L, self.lib = L, L.load_jpeg()
         self.threads = int(threads)
-        self.slot_elems = (int(slot_elems) + 7) // 8 * 8              # slots stay 16-byte aligned
+        # coefficient budget per image: a staging slot holds max_batch x slot_elems elements, the images of a batch back to
+        # back (640 x 640 at 4:2:0 is 614 400; images the rest of a slot cannot take go through PIL)
+        self.slot_elems = (int(slot_elems) + 7) // 8 * 8
         self.max_batch = int(max_batch)
         self.timeout_s = float(timeout_s)
         self._pool = self.lib.comic_jpeg_pool_create(self.threads)
         if not self._pool:
             raise RuntimeError('comic_jpeg_pool_create(%d) failed' % self.threads)
 
-    def submit(self, paths, infos_ptr, status_ptr, coef_ptr):
+    def submit(self, paths, infos_ptr, status_ptr, coef_ptr, capacity):
         import ctypes as C
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, self.slot_elems)
+        h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, int(capacity))
         if not h:
             raise RuntimeError('comic_jpeg_pool_submit failed')
         return h
 
     def wait(self, handle, paths=()):
-        """-> bytes of the decoded images' RGB blob (their pixel_off assigned).  Bounded like DecodePool.geometry."""
+        """-> (coefficient elements in use, bytes of the decoded images' RGB blob -- their pixel_off assigned).  Bounded like
+        DecodePool.geometry."""
         import ctypes as C
-        total = C.c_int64(0)
-        rc = self.lib.comic_jpeg_pool_wait(self._pool, handle, self.timeout_s, C.byref(total))
+        used, total = C.c_int64(0), C.c_int64(0)
+        rc = self.lib.comic_jpeg_pool_wait(self._pool, handle, self.timeout_s, C.byref(used), C.byref(total))
         if rc != 0:
             raise RuntimeError('JPEG decode threads did not return within %.0f s for: %s'
                                % (self.timeout_s, ', '.join(str(p) for p in list(paths)[:4])))
-        return int(total.value)
+        return int(used.value), int(total.value)
 
     def close(self):
         if self._pool:
@@ -348,8 +352,9 @@ class DevicePreprocessor(object):
                             'offsets': [0, 8, 12, 16, 20, 24, 28, 32], 'itemsize': 40})
 
     def enable_split(self, jpool, slots):
-        """Consumer thread, once: the pinned staging slots the decode threads write coefficients into (the producer blocks
-        while all of them are in flight) and the device buffers of one batch."""
+        """Consumer thread, once: the pinned staging slots the decode threads write coefficients into (max_batch x slot_elems
+        elements each, the images of a batch back to back; the producer blocks while all of them are in flight) and the device
+        buffers of one batch."""
         torch = self.torch
         self._jpool = jpool
         self._free_coef = queue.Queue()
@@ -367,8 +372,12 @@ class DevicePreprocessor(object):
         jpool = self._jpool
         if len(paths) > jpool.max_batch:
             raise ValueError('batch of %d images exceeds the split decoder\'s staging slots (%d)' % (len(paths), jpool.max_batch))
-        slot = self._free_coef.get()
-        handle = jpool.submit(paths, slot['infos'].data_ptr(), slot['status'].ctypes.data, slot['coef'].data_ptr())
+        try:
+            slot = self._free_coef.get(timeout=jpool.timeout_s)
+        except queue.Empty:
+            raise RuntimeError('no coefficient staging slot came back within %.0f s (consumer stalled?)' % jpool.timeout_s)
+        handle = jpool.submit(paths, slot['infos'].data_ptr(), slot['status'].ctypes.data, slot['coef'].data_ptr(),
+                              slot['coef'].numel())
         return PackedImages(('split', jpool, handle, slot, list(paths), list(params)), None, None, len(paths), 0)
 
     def _finish_split(self, packed):
@@ -377,7 +386,7 @@ class DevicePreprocessor(object):
         _, jpool, handle, slot, paths, params = packed.slot
         n = packed.n
         try:
-            pixel_bytes = jpool.wait(handle, paths)
+            used, pixel_bytes = jpool.wait(handle, paths)
         except RuntimeError:
             # threads of this batch may still write into the slot: it is retired with the batch, a fresh one takes its place
             self.__dict__.setdefault('_retired_coef', []).append(slot)
@@ -385,12 +394,12 @@ class DevicePreprocessor(object):
                                      infos=torch.zeros_like(slot['infos']).pin_memory(), status=np.zeros_like(slot['status'])))
             raise
         try:
-            return self._launch_split(packed, pixel_bytes)
+            return self._launch_split(packed, used, pixel_bytes)
         except Exception:
             self._free_coef.put(slot)             # (the wait has returned: no thread writes into it any more)
             raise
 
-    def _launch_split(self, packed, pixel_bytes):
+    def _launch_split(self, packed, used, pixel_bytes):
         torch, L = self.torch, self.L
         _, jpool, handle, slot, paths, params = packed.slot
         n = packed.n
@@ -419,16 +428,13 @@ class DevicePreprocessor(object):
                 self._dev_blob = torch.empty(int(pixel_bytes * 1.3) + 4096, dtype=torch.uint8, device=self.device)
             st = L.stream_ptr()
             if ok.any():
-                used = int(infos['coef_count'][ok].max())
                 dev_infos = slot['infos'][:n * 512].to(self.device, non_blocking=True)
-                # only the used head of every fixed slot crosses the bus: one strided copy
-                L.check(self.lib.comic_copy_rows_h2d(self._dev_coef.data_ptr(), jpool.slot_elems * 2, slot['coef'].data_ptr(),
-                                                     jpool.slot_elems * 2, used * 2, n, st), 'copy_rows_h2d')
-                L.check(self.lib.comic_jpeg_pixels(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n, used // 64,
-                                                   int(w[ok].max()), int(h[ok].max()), self._dev_planes.data_ptr(),
-                                                   self._dev_blob.data_ptr(), st), 'jpeg_pixels')
+                self._dev_coef[:used].copy_(slot['coef'][:used], non_blocking=True)      # the batch's ONE coefficient copy
+                L.check(self.lib.comic_jpeg_pixels(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
+                                                   int(infos['coef_count'][ok].max()) // 64, int(w[ok].max()), int(h[ok].max()),
+                                                   self._dev_planes.data_ptr(), self._dev_blob.data_ptr(), st), 'jpeg_pixels')
             for o, im in late:
-                self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.ascontiguousarray(im).reshape(-1)))
+                self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.array(im, copy=True).reshape(-1)))
             dev_desc = torch.from_numpy(desc.view(np.uint8)).to(self.device)
             out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
             L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
@@ -487,6 +493,34 @@ class DevicePreprocessor(object):
             torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
 
     def finish(self, packed):
+        """Consumer half.  The copies and launches go to a stream of the loader's own: the host-to-device DMA of batch k+1
+        (60 MB for 64 images of 640 x 480) runs beside the kernels of step k that the consumer's stream still holds, instead
+        of queueing behind them and in front of step k+1; the consumer's stream waits for the loader's work only (the staging
+        and device buffers of the loader are touched by its own stream alone, the batch tensor is handed over with
+        record_stream)."""
+        torch = self.torch
+        if os.environ.get('COMIC_LOADER_STREAM', '1') != '1':
+            out = self._finish(packed)
+        else:
+            with torch.cuda.device(self.device):
+                main = torch.cuda.current_stream()
+                side = self.__dict__.get('_side')
+                if side is None:
+                    side = self._side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    out = self._finish(packed)
+                main.wait_stream(side)
+                out.record_stream(main)
+        # Back-pressure: at most two staging slots / blocks wait for the device.  Staging returns to the producer's free list
+        # only when the consumer polls its events (here), so a consumer that runs ahead of the device and then blocks on an
+        # empty prefetch queue would starve the producer of staging for good; with the cap, queue depth + the producer's
+        # one + two pending never exceed the depth + 4 slots there are.
+        while len(self._pending) > 2:
+            self._pending[0][1].synchronize()
+            self._reap()
+        return out
+
+    def _finish(self, packed):
         import ctypes as C
         torch, L = self.torch, self.L
         self._reap()
@@ -708,16 +742,16 @@ class InputManager(object):
         c = self.config
         if getattr(c, 'loader_split_jpeg', False) and getattr(self, '_jpeg_pool', None) is None:
             self._jpeg_pool = JpegSplitPool(int(getattr(c, 'loader_threads', 0)) or min(16, os.cpu_count() or 3),
-                                            slot_elems=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)),
+                                            slot_elems=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)) // 2,
                                             max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
                                                           getattr(c, 'batch_size_infer', 1)),
                                             timeout_s=float(getattr(c, 'loader_timeout_s', 120.0)))
-            self._devpre.enable_split(self._jpeg_pool, self._prefetch_depth + 2)
+            self._devpre.enable_split(self._jpeg_pool, self._prefetch_depth + 4)
             return
         nproc = int(getattr(self.config, 'loader_processes', 0) or 0)
         if nproc > 0 and getattr(self, '_decode_pool', None) is None:
             c = self.config
-            self._decode_pool = DecodePool(nproc, blocks=self._prefetch_depth + 2,
+            self._decode_pool = DecodePool(nproc, blocks=self._prefetch_depth + 4,
                                            slot_bytes=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)),
                                            max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
                                                          getattr(c, 'batch_size_infer', 1)),

@@ -191,16 +191,12 @@ int comic_image_preprocess(const uint8_t* blob, const void* desc, int n, float* 
  * jdcolor.c YCbCr -> RGB, in libjpeg's integer arithmetic -- the RGB bytes are the ones PIL gives for the same file
  * (oracle/jpeg_ref.py, tests/test_jpeg_split.py).
  * `coef`: the batch's quantised coefficients (device, int16, 16-byte aligned); `infos`: n comic_jpeg_info records (device)
- * with coef_base (multiple of 8 elements) and pixel_off filled, ncomp == 0 for an image to skip; `max_blocks`, `max_w`,
+ * with coef_base (multiple of 8 elements; comic_jpeg_pool lays the images out back to back) and pixel_off filled, ncomp == 0 for an image to skip; `max_blocks`, `max_w`,
  * `max_h`: the largest coef_count / 64, width and height among them; `planes`: scratch of as many BYTES as `coef` has
  * elements (the component planes); `pixels`: image i as height x width x 3 uint8 at pixel_off -- the blob
  * comic_image_preprocess reads. */
 int comic_jpeg_pixels(const int16_t* coef, const void* infos, int n, int max_blocks, int max_w, int max_h, uint8_t* planes,
                       uint8_t* pixels, void* stream);
-/* `rows` rows of `row_bytes` from pinned host memory (row i at src + i * src_pitch) to the device (dst + i * dst_pitch),
- * in stream order (one asynchronous copy per row): the used head of every fixed coefficient slot of a batch in one call. */
-int comic_copy_rows_h2d(void* dst, int64_t dst_pitch, const void* src, int64_t src_pitch, int64_t row_bytes, int rows,
-                        void* stream);
 
 /* ---- cnn_finetune: backward of the plan (train.py:241-249; model_base.py:76,834-849) ------
  * The CNN variables (conv weights, BN beta) become trainable; BN stays in inference mode, so a

@@ -57,18 +57,21 @@ int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coe
 /* ---- a batch at a time: a persistent pool of decode threads ------------------------------------------------------------
  * The loader's producer thread queues the files of a batch and goes on (several batches may be queued: the threads flow from
  * one into the next, no batch waits for the stragglers of the one before); no interpreter work per image.
- * Image i of a batch is decoded into the fixed slot coef + i * slot_elems (infos[i].coef_base = i * slot_elems), status[i]
- * gets its code; an image that is unsupported, corrupt, unreadable or larger than its slot takes the loader's PIL path. */
+ * Two passes: every file is read and its headers parsed, then the images are laid out BACK TO BACK in `coef` in path order
+ * (infos[i].coef_base, whole blocks: multiples of 64 elements) and their scans decoded -- one host-to-device copy of
+ * coef[0 .. coef_elems) moves the batch.  status[i] gets the image's code; an image that is unsupported, corrupt, unreadable
+ * or does not fit the rest of `capacity` (COMIC_JPEG_TOO_SMALL) takes no room and goes through the loader's PIL path. */
 typedef struct comic_jpeg_pool comic_jpeg_pool;
 comic_jpeg_pool* comic_jpeg_pool_create(int threads);
 void comic_jpeg_pool_destroy(comic_jpeg_pool* pool);          /* waits for queued work */
-/* Returns a batch handle (NULL: bad arguments / out of memory).  `paths` is copied; infos / status / coef must stay valid
- * until comic_jpeg_pool_wait has returned 0 for the handle. */
+/* Returns a batch handle (NULL: bad arguments / out of memory).  `paths` is copied; infos / status / coef (capacity int16
+ * elements) must stay valid until comic_jpeg_pool_wait has returned 0 for the handle. */
 void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, int n, comic_jpeg_info* infos, int32_t* status,
-                             int16_t* coef, int64_t slot_elems);
-/* 0: every image of the batch is done -- pixel_off of the decoded images assigned back to back (16-byte aligned, width *
- * height * 3 bytes each), their sum in *pixel_bytes, the handle released.  1: not done within timeout_s (handle still valid). */
-int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* pixel_bytes);
+                             int16_t* coef, int64_t capacity);
+/* 0: every image of the batch is done -- *coef_elems = elements of `coef` in use; pixel_off of the decoded images assigned
+ * back to back (16-byte aligned, width * height * 3 bytes each), their sum in *pixel_bytes; the handle is released.
+ * 1: not done within timeout_s (the handle stays valid). */
+int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* coef_elems, int64_t* pixel_bytes);
 
 #ifdef __cplusplus
 }

@@ -133,55 +133,65 @@ def test_files_the_split_decoder_does_not_take_are_reported():
     assert _split(bytes(bad))[0] in (L.JPEG_OK, L.JPEG_CORRUPT)
 
 
-def test_pool_decodes_queued_batches_into_fixed_slots(tmp_path):
+def test_pool_decodes_queued_batches_back_to_back(tmp_path):
     lib = L.load_jpeg()
     sizes = [(64, 48), (33, 70), (120, 90), (16, 16), (50, 50), (71, 29), (90, 120)]
-    paths, want = [], []
+    paths, want, counts = [], [], {}
     for i, (w, h) in enumerate(sizes):
         data = _encode(_photo(h, w, seed=i), quality=70 + 3 * i, subsampling=i % 3)
         p = str(tmp_path / ('%d.jpg' % i))
         open(p, 'wb').write(data)
         paths.append(p)
         want.append(_pil(data))
+        counts[p] = int(_split(data)[1].coef_count)
     prog = str(tmp_path / 'prog.jpg')
     open(prog, 'wb').write(_encode(_photo(40, 40), progressive=True))
     big = str(tmp_path / 'big.jpg')
     open(big, 'wb').write(_encode(_photo(200, 200), quality=90, subsampling=0))
     missing = str(tmp_path / 'missing.jpg')
     batch = paths + [prog, big, missing]
-    slot = 120 * 96 * 3                                     # the 200 x 200 4:4:4 file does not fit
+    capacity = sum(counts.values()) + 1000                  # every small file fits wherever the 200 x 200 one stands; it never does
     pool = lib.comic_jpeg_pool_create(3)
     assert pool
     runs = []
-    for rep in range(3):                                    # several batches queued before the first wait
+    for rep in range(4):                                    # several batches queued before the first wait
         order = batch[rep:] + batch[:rep]
         n = len(order)
         infos = np.zeros(n, L.JPEG_INFO_DTYPE)
         status = np.full(n, 99, np.int32)
-        coef = np.full(n * slot, 7, np.int16)
+        coef = np.full(capacity, 7, np.int16)
         arr = (C.c_char_p * n)(*[os.fsencode(p) for p in order])
-        h = lib.comic_jpeg_pool_submit(pool, arr, n, infos.ctypes.data, status.ctypes.data, coef.ctypes.data, slot)
+        h = lib.comic_jpeg_pool_submit(pool, arr, n, infos.ctypes.data, status.ctypes.data, coef.ctypes.data, capacity)
         assert h
         runs.append((order, infos, status, coef, h))
     for order, infos, status, coef, h in runs:
-        total = C.c_int64(-1)
-        assert lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(total)) == 0
-        off = 0
+        used, total = C.c_int64(-1), C.c_int64(-1)
+        assert lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(used), C.byref(total)) == 0
+        off = base = 0
         for i, p in enumerate(order):
             if p == prog:
                 assert status[i] == L.JPEG_UNSUPPORTED
             elif p == big:
-                assert status[i] == L.JPEG_TOO_SMALL and infos['coef_count'][i] > slot
+                assert status[i] == L.JPEG_TOO_SMALL and infos['coef_count'][i] > 1000
             elif p == missing:
                 assert status[i] == L.JPEG_IO
             else:
-                assert status[i] == 0 and infos['coef_base'][i] == i * slot and infos['pixel_off'][i] == off
+                assert status[i] == 0 and infos['coef_base'][i] == base and infos['pixel_off'][i] == off
                 info = infos[i]
-                img = jpeg_ref.pixels(info, coef[i * slot:i * slot + int(info['coef_count'])])
+                img = jpeg_ref.pixels(info, coef[base:base + counts[p]])
                 assert np.array_equal(img, want[paths.index(p)]), p
                 off += (img.size + 15) // 16 * 16
-        assert total.value == off
+                base += counts[p]
+        assert total.value == off and used.value == base == sum(counts.values())
     lib.comic_jpeg_pool_destroy(pool)
+    # destroy with work still queued: the pool finishes it first
+    pool = lib.comic_jpeg_pool_create(2)
+    n = len(paths)
+    infos, status, coef = np.zeros(n, L.JPEG_INFO_DTYPE), np.full(n, 99, np.int32), np.zeros(capacity, np.int16)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    assert lib.comic_jpeg_pool_submit(pool, arr, n, infos.ctypes.data, status.ctypes.data, coef.ctypes.data, capacity)
+    lib.comic_jpeg_pool_destroy(pool)
+    assert (status == 0).all()
 
 
 # ---- device half -----------------------------------------------------------------------------------------------------------
@@ -243,7 +253,8 @@ def test_device_pixels_are_pils_pixels(tmp_path):
 @pytest.mark.gpu
 def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     """The loader path end to end (pool -> pinned slot -> strided copy -> comic_jpeg_pixels -> comic_image_preprocess) against
-    PIL decode + the same device preprocessing; a progressive file and one larger than its slot take the PIL path inside."""
+    PIL decode + the same device preprocessing; a progressive file and the files the staging slot has no room for take the
+    PIL path inside."""
     import torch
     from comic_amd import inputs
     paths = _mixed_files(tmp_path, 10)
@@ -251,7 +262,7 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     open(prog, 'wb').write(_encode(_photo(300, 400), progressive=True, quality=85))
     paths.insert(3, prog)
     pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
-    jpool = inputs.JpegSplitPool(4, slot_elems=640 * 480 * 3, max_batch=16)       # the 640 x 640 4:4:4 file exceeds it
+    jpool = inputs.JpegSplitPool(4, slot_elems=200000, max_batch=16)       # room for about half of the files: the rest -> PIL
     pre.enable_split(jpool, 3)
     params = [(bool(i % 2), (i * 7) % 33, (i * 5) % 33) for i in range(len(paths))]
     ref = pre(list(map(inputs.decode_image, paths)), params).cpu()
@@ -282,12 +293,17 @@ def test_input_manager_with_split_decode_yields_the_batches_of_the_thread_decode
         a.enable_device_preprocess('cuda:0')
         b.enable_device_preprocess('cuda:0')
         assert a._jpeg_pool is not None and getattr(b, '_jpeg_pool', None) is None
+        on_device = 0
         for it_a, it_b in ((a.batch_train, b.batch_train), (a.batch_eval, b.batch_eval)):
-            for _ in range(5):
+            for _ in range(8):
                 (ia, ca), (ib, cb) = next(it_a), next(it_b)
-                assert ia.is_cuda and ia.dtype == torch.float32 and tuple(ia.shape[1:]) == (224, 224, 3)
-                assert torch.equal(ia, ib)
+                # (the batches the prefetch threads made before enable_device_preprocess are numpy arrays: same bits)
+                on_device += int(torch.is_tensor(ia) and ia.is_cuda)
+                ta, tb = torch.as_tensor(ia).cpu(), torch.as_tensor(ib).cpu()
+                assert ta.dtype == torch.float32 and tuple(ta.shape[1:]) == (224, 224, 3)
+                assert torch.equal(ta, tb)
                 np.testing.assert_array_equal(ca, cb)
+        assert on_device >= 4                          # the split decoder did serve batches
     finally:
         a.close()
         b.close()

@@ -98,7 +98,7 @@ for nt in [int(v) for v in os.environ.get('SPLIT_THREADS', '8,16').split(',') if
             if len(hs) == 4:
                 jpool.wait(hs.pop(0))
             infos, status, coef = bufs[(rep * 4 + k) % 4]
-            hs.append(jpool.submit(paths[b:b + 64], infos.ctypes.data, status.ctypes.data, coef.data_ptr()))
+            hs.append(jpool.submit(paths[b:b + 64], infos.ctypes.data, status.ctypes.data, coef.data_ptr(), coef.numel()))
     for h in hs:
         jpool.wait(h)
     print('split threads %2d host half alone : %6.0f images/s' % (nt, 24 * len(paths) / (time.time() - t0)))

@@ -1,0 +1,54 @@
+"""Training throughput FROM FILES (decoder mode, COMIC-256 defaults, batch 64): the whole chain -- JPEG files -> loader ->
+device preprocessing -> encoder -> decoder step -- with the three loaders: decode threads (default), decode processes
+(--loader_processes 16), split JPEG decode (--loader_split_jpeg, 16 C threads).  bench.py's headline uses synthetic images
+already resident in HBM; this is the same step fed by the input pipeline.  640x480 quality-90 4:2:0 re-encodes of two
+camera photographs (scikit-learn's sample images), 512 files."""
+import importlib.util, os, sys, tempfile, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from PIL import Image
+from tests import tiny_dataset
+from comic_amd import model as mdl, train_fn as train
+
+tmp = tempfile.mkdtemp()
+N = int(os.environ.get('FILES_N', '512'))
+ds = tiny_dataset.make(os.path.join(tmp, 'mscoco'), n_train=N, n_valid=64, n_test=4)
+import sklearn
+sd = os.path.join(os.path.dirname(sklearn.__file__), 'datasets', 'images')
+photos = [Image.open(os.path.join(sd, f)).convert('RGB') for f in ('china.jpg', 'flower.jpg')]
+for i in range(N):
+    im = photos[i % 2].crop((i % 40, i % 27, 600 + i % 40, 400 + i % 27)).resize((640, 480), Image.BICUBIC)
+    im.save(os.path.join(ds, 'images', 'COCO_train2014_%012d.jpg' % (i + 1)), quality=90, subsampling=2)
+spec = importlib.util.spec_from_file_location('cli_train_bench', os.path.join(ROOT, 'src', 'train.py'))
+cli = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(cli)
+STEPS, WARM = int(os.environ.get('STEPS', '120')), int(os.environ.get('WARM', '60'))
+modes = [m for m in os.environ.get('MODES', 'split,processes,threads').split(',') if m]
+for mode in modes:
+    extra = {'split': ['--loader_split_jpeg', '--loader_threads', '16'], 'processes': ['--loader_processes', '16'],
+             'threads': ['--loader_threads', '16']}[mode]
+    args = cli.create_parser().parse_args(['--dataset_dir', ds, '--log_root', os.path.join(tmp, 'exp_' + mode), '--train_mode',
+                                           'decoder', '--batch_size_train', '64', '--batch_size_eval', '64', '--max_epoch', '50'] + extra)
+    kwargs, _, overwrite = cli.build_kwargs(args)
+
+    def probe(config):
+        mdl.reset_default_graph()
+        man = train._manager(config)
+        try:
+            man.enable_device_preprocess('cuda:0')
+            m = mdl.CaptionModel(config, mode='train', batch_ops=man.batch_train, reuse=False, name='train', device='cuda:0')
+            steps = STEPS if mode != 'threads' else max(20, STEPS // 4)
+            for _ in range(WARM if mode != 'threads' else 25):
+                m.run_train_step()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(steps):
+                loss = m.run_train_step()
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            print('loader %-9s : %7.0f images/s  (%.2f ms per step of 64 images, loss %.4f)'
+                  % (mode, steps * 64 / dt, dt / steps * 1e3, float(loss)), flush=True)
+        finally:
+            man.close()
+    train.try_to_train(train_fn=probe, try_block=False, overwrite=overwrite, **kwargs)
