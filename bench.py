@@ -507,7 +507,63 @@ def extras(device, enc, cnn_params, plan):
     ms64 = e0.elapsed_time(e1) / 10
     out['cnn_frac_at_batch64'] = {'cnn_forward_ms': round(ms64, 4), 'images_per_forward': BATCH,
                                   'frac': round(FLOP_PER_IMAGE_CNN * BATCH / (ms64 * 1e-3) / PEAK_BF16_MFMA, 5)}
+    del enc64, imgs
+    torch.cuda.empty_cache()
+    try:
+        out['input_pipeline'] = input_pipeline_rate(device)
+    except Exception as e:                       # (e.g. no sample photographs on the box: the figure is optional)
+        out['input_pipeline'] = {'error': repr(e)}
     return out
+
+
+def input_pipeline_rate(device, n_files=128, threads=16):
+    """JPEG files -> network input with the split decoder: Huffman decoding on `threads` C threads
+    (libcomic_jpeg.so), inverse DCT / upsampling / colour conversion / resize / crop on the device; images/s of the loader
+    alone (tools/loader_bench.py FILES=photo is the longer version, tools/train_files_bench.py the training step fed by it)."""
+    import shutil
+    import tempfile
+    import torch
+    from PIL import Image
+    from comic_amd import inputs
+    import sklearn
+    sd = os.path.join(os.path.dirname(sklearn.__file__), 'datasets', 'images')
+    photos = [Image.open(os.path.join(sd, f)).convert('RGB') for f in ('china.jpg', 'flower.jpg')]
+    d = tempfile.mkdtemp()
+    try:
+        paths = []
+        for i in range(n_files):
+            im = photos[i % 2].crop((i % 40, i % 27, 600 + i % 40, 400 + i % 27)).resize((640, 480), Image.BICUBIC)
+            p = os.path.join(d, '%d.jpg' % i)
+            im.save(p, quality=90, subsampling=2)
+            paths.append(p)
+        kb = sum(os.path.getsize(p) for p in paths) / len(paths) / 1024
+        jpool = inputs.JpegSplitPool(threads, max_batch=BATCH)
+        pre = inputs.DevicePreprocessor(device, IMG, IMG)
+        pre.enable_split(jpool, 6)
+        params = [(False, 16, 16)] * BATCH
+        ref = pre(list(map(inputs.decode_image, paths[:BATCH])), params)
+        got = pre.finish(pre.pack_paths_split(paths[:BATCH], params))
+        same = bool(torch.equal(got, ref))            # against PIL decode + the same device preprocessing
+        n, inflight = 0, []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for rep in range(24):
+            for b in range(0, n_files, BATCH):
+                inflight.append(pre.pack_paths_split(paths[b:b + BATCH], params))
+                if len(inflight) > 3:
+                    pre.finish(inflight.pop(0))
+                n += BATCH
+        while inflight:
+            pre.finish(inflight.pop(0))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        jpool.close()
+        return {'images_per_sec': round(n / dt, 1), 'host_threads': threads, 'bit_identical_to_pil_path': same,
+                'files': '%d x 640x480 JPEG, quality 90, 4:2:0 (camera photographs re-encoded), %.0f KB on average' % (n_files, kb),
+                'path': 'libcomic_jpeg.so (Huffman decoding, C threads) -> comic_jpeg_pixels (IDCT / upsampling / colour) -> '
+                        'comic_image_preprocess (resize / crop / scale)'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def heaviest_conv_launch(enc, plan, reps=20):

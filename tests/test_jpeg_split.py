@@ -133,6 +133,31 @@ def test_files_the_split_decoder_does_not_take_are_reported():
     assert _split(bytes(bad))[0] in (L.JPEG_OK, L.JPEG_CORRUPT)
 
 
+def test_mutated_files_give_a_code_never_a_crash():
+    """Truncations, byte flips in headers and scan, runs of 0xFF: an error code or (garbage) coefficients, within the buffers.
+    (tools/fuzz_jpeg.c is the same loop for the address / undefined-behaviour sanitizers.)"""
+    rng = np.random.default_rng(11)
+    seeds = [_encode(_photo(61, 83, seed=1), quality=88, subsampling=2),
+             _encode(_photo(40, 57, seed=2), quality=70, subsampling=1, restart_marker_blocks=3),
+             _encode(_photo(33, 33, seed=3)[:, :, 0], quality=80)]
+    codes = set()
+    for data in seeds:
+        n = len(data)
+        for it in range(150):
+            d = bytearray(data)
+            kind = it % 4
+            if kind == 0:
+                d = d[:1 + int(rng.integers(n - 1))]
+            elif kind == 3:
+                at = int(rng.integers(n))
+                d[at:at + 40] = b'\xff' * len(d[at:at + 40])
+            else:
+                for _ in range(1 + int(rng.integers(8))):
+                    d[int(rng.integers(min(n, 600) if kind == 1 else n))] = int(rng.integers(256))
+            codes.add(_split(bytes(d))[0])
+    assert codes <= {L.JPEG_OK, L.JPEG_UNSUPPORTED, L.JPEG_CORRUPT} and L.JPEG_CORRUPT in codes
+
+
 def test_pool_decodes_queued_batches_back_to_back(tmp_path):
     lib = L.load_jpeg()
     sizes = [(64, 48), (33, 70), (120, 90), (16, 16), (50, 50), (71, 29), (90, 120)]
