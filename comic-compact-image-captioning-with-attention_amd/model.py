@@ -145,6 +145,7 @@ class ModelBase(object):
         ow.step(t.dw, lr, grad_scale=s1 * mult)
         ob.step(t.dbeta, lr, grad_scale=s1 * mult)
         enc.refresh_weights()
+        enc.clear_grads_async()
 
     # ---- optimiser / LR (model_base.py:775-883) -----------------------------------------
     def _create_optimiser(self):

@@ -808,6 +808,23 @@ class CnnEncoder:
                 t.filters_ev.record(t.aux)
             t.filters_ver = self.w_master.__dict__['_ver']
 
+    def clear_grads_async(self):
+        """After the optimiser has read the gradients of a step: clear the gradient buffers for the next backward on the aux
+        stream (beside the next forward / decoder step) instead of at the head of that backward (85 us of fills between the
+        decoder and the CNN backward).  The next backward() waits for the event."""
+        t = getattr(self, '_train', None)
+        if t is None:
+            return
+        torch = self.torch
+        t.aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(t.aux):
+            t.gflat.zero_()
+            t.dw.data.zero_()
+            t.dbeta.data.zero_()
+            ev = torch.cuda.Event()
+            ev.record(t.aux)
+        t.zero_ev = ev
+
     def _pack_x3(self):
         """The x3 plan copy of every conv filter from its fp32 master [Cout][Kpad]: per tap the channels
         [bf16(w) | bf16(w) | bf16(w - bf16(w))] against activations stored [hi | lo | hi] (COMIC_OP_X3).  Tensor glue at
@@ -1044,9 +1061,13 @@ class CnnEncoder:
         callback runs after each one -- the data-parallel step starts that bucket's all-reduce there, under the
         backward of the earlier blocks."""
         t = self.enable_training()
-        t.gflat.zero_()
-        t.dw.data.zero_()
-        t.dbeta.data.zero_()
+        if getattr(t, 'zero_ev', None) is not None:          # cleared on the aux stream behind the last optimiser step
+            self.torch.cuda.current_stream().wait_event(t.zero_ev)
+            t.zero_ev = None
+        else:
+            t.gflat.zero_()
+            t.dw.data.zero_()
+            t.dbeta.data.zero_()
         if d_fm is not None:
             g = t.gbufs[self.plan.fm if self.plan.fm is not None else self.plan.fm_src]
             g.view(-1).copy_(d_fm.reshape(-1))              # converts to the buffer's dtype

@@ -250,6 +250,7 @@ class CaptionTrainer:
         ow.step(t.dw, lr, grad_scale=scale * mult)
         ob.step(t.dbeta, lr, grad_scale=scale * mult)
         self.encoder.refresh_weights()
+        self.encoder.clear_grads_async()
         return res
 
     def enable_overlap(self, polite_lds_kb=84):
