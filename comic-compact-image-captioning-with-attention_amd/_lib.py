@@ -125,6 +125,7 @@ _SIGS = {
     'comic_gemm_group_workspace': (c_int64, [P, c_int]),
     'comic_gemm_group': (c_int, [P, c_int, P, c_int64, P]),
     'comic_debug_gemm_group_tuning': (c_int, [c_int, c_int]),
+    'comic_debug_cnn_backward_fusion': (c_int, [c_int]),
     'comic_embed_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_embed_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),

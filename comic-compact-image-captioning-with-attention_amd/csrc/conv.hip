@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kRowBytes = 80;  // 64 B of k + 16 B pad (spreads ds_read_b128 over the banks)
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool MASK = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr int BKE = 4 * EPC;  // k elements per tile (64 bytes per row)
@@ -204,6 +204,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         v3 = fmaxf(v3, 0.f);
       }
       const size_t off = (size_t)m * a.y_cs + a.y_co + n0;
+      if constexpr (MASK) {    // fused activation gradient of the producer conv (ConvArgs::mask_y); T is the plan dtype
+        const size_t yoff = (size_t)m * a.mask_cs + a.mask_co + n0;
+        float yv[4];
+        if (sizeof(T) == 4) {
+          const float4 t = *(const float4*)((const float*)a.mask_y + yoff);
+          yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w;
+        } else {
+          const uint2 t = *(const uint2*)((const bf16_t*)a.mask_y + yoff);
+          yv[0] = __uint_as_float(t.x << 16); yv[1] = __uint_as_float(t.x & 0xFFFF0000u);
+          yv[2] = __uint_as_float(t.y << 16); yv[3] = __uint_as_float(t.y & 0xFFFF0000u);
+        }
+        const float4 bs = *(const float4*)(a.mask_scale + n0);
+        const float g0 = yv[0] > 0.f ? v0 : 0.f, g1 = yv[1] > 0.f ? v1 : 0.f, g2 = yv[2] > 0.f ? v2 : 0.f, g3 = yv[3] > 0.f ? v3 : 0.f;
+        float* db = a.mask_dbeta + (size_t)(blockIdx.x & (kMaskCopies - 1)) * a.Cout + n0;
+        atomicAdd(db + 0, g0);
+        atomicAdd(db + 1, g1);
+        atomicAdd(db + 2, g2);
+        atomicAdd(db + 3, g3);
+        if (sizeof(T) == 4) *(float4*)((float*)a.y + off) = make_float4(g0 * bs.x, g1 * bs.y, g2 * bs.z, g3 * bs.w);
+        else *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(g0 * bs.x, g1 * bs.y), pack_bf16x2(g2 * bs.z, g3 * bs.w));
+        continue;
+      }
       if (sizeof(T) == 4 || a.out_f32) {
         float4* yp = (float4*)((float*)a.y + off);
         if (a.accum) {
@@ -983,7 +1005,7 @@ constexpr int kLoaderWaves = 20;
 constexpr int ring_stages(int nstage) { return nstage % 10; }
 constexpr int dma_threads(int wm, int wn, int nstage) { return (wm * wn + (nstage >= kLoaderWaves ? 4 : 0)) * 64; }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE_, bool ALIGNED>
+template <int BM, int BN, int WM, int WN, int NSTAGE_, bool ALIGNED, bool MASK = false>
 __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int block_m, const int block_n) {
   constexpr int BKE = 64;                       // bf16 elements per k-tile = 128 bytes per row
   constexpr int ROWS = BM + BN;
@@ -1227,7 +1249,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
     const int m = bm0 + wm * (BM / WM) + j * 16 + (lane & 15);
     mrow[j] = m < a.M ? m : -1;
   }
-  conv_store_tiles<TN, TM>(a, acc, bn0 + wn * (BN / WN), (lane >> 4) * 4, mrow);
+  conv_store_tiles<TN, TM, MASK>(a, acc, bn0 + wn * (BN / WN), (lane >> 4) * 4, mrow);
   STAMP(3);
 }
 
@@ -1619,9 +1641,62 @@ int launch_dma(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// Backward-data launches fused with the producer's activation gradient (ConvArgs::mask_y): the im2col kernel with the MASK
+// epilogue, the tile shapes the backward of small batches uses.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
+__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_mask_kernel(ConvArgs a) {
+  const int tiles_n = (a.Cout + BN - 1) / BN;
+  const int l = xcd_tile_index(a.tiles_m * tiles_n);
+  if (l < 0) return;
+  conv_igemm_dma_body<BM, BN, WM, WN, NSTAGE, ALIGNED, true>(a, l / tiles_n, l % tiles_n);
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
+int launch_dma_mask(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
+  const int lds = std::max(lds0, a.min_lds);
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_igemm_dma_mask_kernel<BM, BN, WM, WN, NSTAGE, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_igemm_dma_mask_kernel<BM, BN, WM, WN, NSTAGE, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      comic_set_error("conv: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.remap = 1;
+  b.tiles_m = cdiv(a.M, BM);
+  const long total = (long)b.tiles_m * cdiv(a.Cout, BN);
+  if (total >= (1L << 31) - 8) {
+    comic_set_error("conv: too many tiles");
+    return 1;
+  }
+  dim3 grid((unsigned)((total + 7) / 8 * 8));
+  if (a.Cin % 64 == 0)
+    hipLaunchKernelGGL((conv_igemm_dma_mask_kernel<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(dma_threads(WM, WN, NSTAGE)), lds, st, b);
+  else
+    hipLaunchKernelGGL((conv_igemm_dma_mask_kernel<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(dma_threads(WM, WN, NSTAGE)), lds, st, b);
+  return 0;
+}
+
+int dispatch_igemm_dma_mask(const ConvArgs& a, hipStream_t st) {
+  const long b128x128 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 128);
+  const long b128x64 = (long)cdiv(a.M, 128) * cdiv(a.Cout, 64);
+  const long b64x64 = (long)cdiv(a.M, 64) * cdiv(a.Cout, 64);
+  if (a.Cout <= 32) return launch_dma_mask<128, 32, 4, 1>(a, st);
+  if (a.Cout % 128 == 0 && b128x128 >= 512) return launch_dma_mask<128, 128, 2, 2>(a, st);
+  if (b128x64 >= 512) return launch_dma_mask<128, 64, 2, 2>(a, st);
+  if (b64x64 >= 384) return launch_dma_mask<64, 64, 2, 2>(a, st);
+  return launch_dma_mask<32, 64, 1, 4>(a, st);
+}
+
 // Image-resident kernel (conv_img.hip): n convs of ONE shape (same source geometry, Cin, Cout) as one launch.
 int img_config(const ConvArgs& a) {
-  if (!a.w_frag || a.accum || a.x_cs % 8 != 0 || a.x_co % 8 != 0) return -1;
+  if (!a.w_frag || a.accum || a.mask_y || a.x_cs % 8 != 0 || a.x_co % 8 != 0) return -1;
   return comic_img_config(a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.SH, a.SW, a.Ho, a.Wo);
 }
 bool img_same_shape(const ConvArgs& p, const ConvArgs& q) {
@@ -1938,6 +2013,12 @@ void launch_igemm(const ConvArgs& a, hipStream_t st) {
 }
 
 template <typename T>
+void launch_igemm_mask(const ConvArgs& a, hipStream_t st) {     // fused activation gradient (backward of the fp32 plan)
+  dim3 grid(cdiv(a.M, 64), cdiv(a.Cout, 64));
+  hipLaunchKernelGGL((conv_igemm_kernel<T, 64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
+}
+
+template <typename T>
 int dispatch_igemm(const ConvArgs& a, hipStream_t st) {
   // choose the largest tile that still gives >= ~2 workgroups per CU; small layers fall
   // back to 64x64 (XCD note: grid.x = pixel tiles, so workgroups b, b+8 share an L2 and a
@@ -1979,6 +2060,10 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   a.blk0 = 0;
   a.tiles_m = 0;
   a.accum = 0;
+  a.mask_y = nullptr;
+  a.mask_scale = nullptr;
+  a.mask_dbeta = nullptr;
+  a.mask_cs = a.mask_co = 0;
   a.member_kind = 0;
   a.w_frag = wt ? wt->w_frag : nullptr;
   a.min_lds = std::min(std::max(op->min_lds, 0), 160 * 1024);
@@ -1990,20 +2075,37 @@ int fill_args(ConvArgs& a, const comic_cnn_op* op, const void* x, int x_channels
   return 0;
 }
 
+// the activation gradient a backward-data launch applies to its result (ConvArgs::mask_*), and where that result goes
+struct ConvMask {
+  const void* y;            // forward output of the producer conv, rows of y_cs channels, slice from y_co
+  int y_cs, y_co;
+  const float* scale;       // its BatchNorm scale
+  float* dbeta;             // its d beta accumulator
+  void* dz;                 // its d-conv tensor [B][Ho][Wo][Cout] (stride 1: not dilated)
+};
+
 template <typename T>
 int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const comic_conv_weight* wt, int batch,
-           hipStream_t st, int accum = 0) {
+           hipStream_t st, int accum = 0, const ConvMask* mask = nullptr) {
   constexpr int EPC = Elem<T>::EPC;
   ConvArgs a;
   fill_args(a, op, x, xc, y, yc, wt, batch);
   a.accum = accum;
+  if (mask) {
+    COMIC_REQUIRE(op->kind == 0 && !accum && !op->out_f32 && !a.x3 && !a.scale, "conv: fused activation gradient on a plain backward-data launch only");
+    a.mask_y = mask->y;
+    a.mask_cs = mask->y_cs;
+    a.mask_co = mask->y_co;
+    a.mask_scale = mask->scale;
+    a.mask_dbeta = mask->dbeta;
+  }
   COMIC_REQUIRE(x && y, "cnn op %d: null buffer", op->kind);
   COMIC_REQUIRE((long)batch * op->H * op->W * xc < (1L << 31) && (long)a.M * yc < (1L << 31),
                 "cnn op: tensor exceeds 2^31 elements");
   COMIC_REQUIRE(op->src_coff + op->Cin <= xc, "cnn op: source channel slice out of range");
   switch (op->kind) {
     case 0: {
-      COMIC_REQUIRE(wt && wt->w && (accum || (op->flags & COMIC_OP_RAW) || (wt->scale && wt->shift)), "conv: missing weights");
+      COMIC_REQUIRE(wt && wt->w && (accum || mask || (op->flags & COMIC_OP_RAW) || (wt->scale && wt->shift)), "conv: missing weights");
       COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && xc % EPC == 0,
                     "conv: Cin/offset/stride must be multiples of %d", EPC);
       COMIC_REQUIRE(op->Cout % 16 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
@@ -2014,11 +2116,15 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
       if constexpr (sizeof(T) == 2) {
         COMIC_REQUIRE(a.zero, "conv: zero page symbol not resolvable");
         COMIC_REQUIRE((long)batch * op->H * op->W * xc * 2 < (1L << 31), "conv: activation tensor too large");
-        if (op->tile > 0) {
+        if (mask) {
+          if (int rc = dispatch_igemm_dma_mask(a, st)) return rc;
+        } else if (op->tile > 0) {
           if (int rc = launch_dma_tile(op->tile, a, st)) return rc;
         } else if (int rc = dispatch_igemm_dma(a, st)) {
           return rc;
         }
+      } else if (mask) {
+        launch_igemm_mask<T>(a, st);
       } else {
         dispatch_igemm<T>(a, st);
       }
@@ -2969,21 +3075,49 @@ size_t dz_bytes_of(const comic_cnn_op* op, int batch, size_t es) {
   const int Wd = (op->Wo - 1) * op->SW + 1;
   return ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
 }
+// (the scheduled backward keeps kMaskCopies partial d beta rows per conv behind the d-conv slices: fused activation gradients)
+size_t dbeta_partial_bytes(const comic_cnn_op* op) { return ((size_t)kMaskCopies * op->Cout * sizeof(float) + 255) & ~(size_t)255; }
 int64_t backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, size_t es, bool all) {
   size_t best = 0, sum = 0;
   for (int i = 0; i < n_ops; ++i) {
     if (ops[i].kind > 1) continue;
     const size_t dz = dz_bytes_of(ops + i, batch, es);
     best = std::max(best, dz);
-    sum += dz;
+    sum += dz + dbeta_partial_bytes(ops + i);
   }
   return (int64_t)(all ? sum : best);
+}
+
+// d beta[c] += the kMaskCopies partial sums of every conv whose activation gradient ran in a backward-data epilogue; one
+// workgroup per conv, the entries as kernel arguments
+constexpr int kFoldMax = 120;
+struct DbetaFoldTable {
+  struct {
+    const float* part;
+    float* dbeta;
+    int C, pad;
+  } e[kFoldMax];
+  int n;
+};
+static_assert(sizeof(DbetaFoldTable) <= 4096, "kernel argument block");
+__global__ __launch_bounds__(256) void dbeta_fold_kernel(const DbetaFoldTable tb) {
+  const auto& en = tb.e[blockIdx.x];
+  for (int c = threadIdx.x; c < en.C; c += blockDim.x) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < kMaskCopies; ++r) s += en.part[(size_t)r * en.C + c];
+    en.dbeta[c] += s;
+  }
 }
 
 template <typename T>
 int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
                   const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
-                  int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w) {
+                  int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w,
+                  bool dz_ready = false, const ConvMask* fuse = nullptr) {
+  // dz_ready: the backward-data launch of this conv's only reader has written dz and added d beta (its epilogue applied this
+  // conv's activation gradient); fuse: this conv's backward-data result is the gradient at the output of a conv with no
+  // other reader -- apply that conv's activation gradient in the epilogue and write its dz instead of accumulating into gx.
   constexpr int EPC = Elem<T>::EPC;
   const bool stem = op->kind == 1;
   COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
@@ -2998,10 +3132,11 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
   COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward: scratch too small (%zu needed)", dz_bytes);
   T* dz = (T*)scratch;
+  COMIC_REQUIRE(!dz_ready || dil == 1, "conv backward: a fused activation gradient writes an undilated d-conv tensor");
   if (dil > 1) {
     COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward: memset failed");
   }
-  {
+  if (!dz_ready) {
     ActGradArgs a{y, gy, yc, op->dst_coff, op->out_f32, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
     const long P = (long)batch * op->Ho * op->Wo;
     const long ppb = std::max<long>(64, cdiv64(P, 512));
@@ -3057,7 +3192,7 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
     }
   }
   COMIC_LAUNCH_CHECK("conv backward (weights)");
-  if (stem || !gx) return 0;
+  if (stem || (!gx && !fuse)) return 0;
   // backward-data: forward conv of dz with the flipped / transposed filter, accumulated into gx
   COMIC_REQUIRE(gr->w_bwd, "conv backward: missing backward-data filter buffer");
   const int K2 = op->KH * op->KW * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
@@ -3073,6 +3208,10 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   t.Ho = op->H; t.Wo = op->W;
   t.src_coff = 0; t.dst_coff = op->src_coff; t.relu = 0; t.out_f32 = 0; t.tile = gr->bwd_tile; t.group = 0; t.lane = 0;
   comic_conv_weight w2{gr->w_bwd, nullptr, nullptr};
+  if (fuse) {
+    t.dst_coff = 0;
+    return run_op<T>(&t, dz, op->Cout, fuse->dz, op->Cin, &w2, batch, st, /*accum=*/0, fuse);
+  }
   return run_op<T>(&t, dz, op->Cout, gx, xc, &w2, batch, st, /*accum=*/1);
 }
 
@@ -3242,6 +3381,8 @@ inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits f
   return ok;
 }
 
+bool g_no_act_fusion = false;      // comic_debug_cnn_backward_fusion(0): the unfused chain (A/B measurements, parity tests)
+
 template <typename T>
 int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched, void* const* buffers,
                             void* const* grad_buffers, void* const* grad_alt, const int32_t* buf_channels,
@@ -3251,12 +3392,49 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
   COMIC_REQUIRE(s1 && s1 != s0 && st_w && st_w != s0 && st_w != s1, "cnn_backward_sched: needs three distinct streams");
   COMIC_REQUIRE(backward_scratch_bytes(ops, n_ops, batch, sizeof(T), true) <= scratch_bytes,
                 "cnn_backward_sched: scratch too small (every conv needs its own d-conv slice)");
-  std::vector<size_t> dz_off((size_t)n_ops, 0);
+  std::vector<size_t> dz_off((size_t)n_ops, 0), part_off((size_t)n_ops, 0);
   size_t off = 0;
   for (int i = 0; i < n_ops; ++i)
     if (ops[i].kind <= 1) {
       dz_off[i] = off;
       off += dz_bytes_of(ops + i, batch, sizeof(T));
+    }
+  const size_t part0 = off;
+  for (int i = 0; i < n_ops; ++i)
+    if (ops[i].kind <= 1) {
+      part_off[i] = off;
+      off += dbeta_partial_bytes(ops + i);
+    }
+  COMIC_REQUIRE(hipMemsetAsync((char*)scratch + part0, 0, off - part0, s0) == hipSuccess, "cnn_backward_sched: memset failed");
+  // Activation-gradient fusion: conv p whose output slice is read by exactly one op, a conv i on the same lane, gets its d-conv
+  // tensor and d beta from the epilogue of i's backward-data launch (the inner convs of the Inception branches: one launch
+  // less per conv on the serial chain a block's longest branch is).  fused_by[p] = i, fuses[i] = p.
+  std::vector<int> lane_of((size_t)n_ops, -1), fused_by((size_t)n_ops, -1), fuses((size_t)n_ops, -1);
+  for (int k = 0; k < n_sched; ++k)
+    if (sched[4 * k] == 0 && sched[4 * k + 1] >= 0 && sched[4 * k + 1] < n_ops) lane_of[sched[4 * k + 1]] = sched[4 * k + 2];
+  if (!g_no_act_fusion)
+    for (int i = 0; i < n_ops; ++i) {
+      const comic_cnn_op& c = ops[i];
+      if (c.kind != 0 || c.out_f32 || (c.flags & COMIC_OP_X3)) continue;
+      int p = -1, readers = 0;
+      for (int j = 0; j < n_ops; ++j) {
+        const comic_cnn_op& o = ops[j];
+        // every op that touches this channel range of the buffer as a source (pools, concats, convs)
+        if (o.src == c.src && !(o.src_coff + o.Cin <= c.src_coff || c.src_coff + c.Cin <= o.src_coff)) ++readers;
+        if (o.kind == 0 && o.dst == c.src && o.dst_coff == c.src_coff && o.Cout == c.Cin) p = j;
+      }
+      if (p < 0 || readers != 1) continue;
+      const comic_cnn_op& q = ops[p];
+      if (q.SH != 1 || q.SW != 1 || q.out_f32 || (q.flags & (COMIC_OP_X3 | COMIC_OP_RAW)) || lane_of[p] != lane_of[i] || lane_of[i] < 0) continue;
+      // nothing else may write into that slice (a pool or a second conv) or read the gradient buffer's slice
+      bool only_writer = true;
+      for (int j = 0; j < n_ops; ++j)
+        if (j != p && ops[j].dst == c.src && ops[j].kind != 5 && ops[j].kind != 6 &&
+            !(ops[j].dst_coff + (ops[j].kind == 0 ? ops[j].Cout : ops[j].Cin) <= c.src_coff || c.src_coff + c.Cin <= ops[j].dst_coff))
+          only_writer = false;
+      if (!only_writer) continue;
+      fused_by[p] = i;
+      fuses[i] = p;
     }
   std::vector<char> seen((size_t)n_ops, 0);
   bool lane1_open = false;
@@ -3294,9 +3472,17 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
     const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
     if (op->kind <= 1) {
       void* dz = (char*)scratch + dz_off[r[1]];
+      ConvMask mk{};
+      const int p = fuses[r[1]];
+      if (p >= 0) {
+        COMIC_REQUIRE(!seen[p], "cnn_backward_sched: conv %d runs before its reader %d", p, r[1]);
+        mk = ConvMask{buffers[ops[p].dst], buf_channels[ops[p].dst], ops[p].dst_coff, weights[ops[p].weight].scale,
+                      (float*)((char*)scratch + part_off[p]), (char*)scratch + dz_off[p]};
+        COMIC_REQUIRE(mk.y && mk.scale && grads[ops[p].weight].dbeta, "cnn_backward_sched: conv %d has no forward output / scale / d beta", p);
+      }
       if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
                                     grads + op->weight, batch, dz, (int64_t)dz_bytes_of(op, batch, sizeof(T)), st,
-                                    filters_ready, st_w))
+                                    filters_ready, st_w, /*dz_ready=*/fused_by[r[1]] >= 0, p >= 0 ? &mk : nullptr))
         return rc;
     } else if (op->kind <= 4) {
       if (!gx) continue;
@@ -3308,6 +3494,29 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
   COMIC_REQUIRE(!lane1_open, "cnn_backward_sched: the schedule ends inside a fork / join region");
   for (int i = 0; i < n_ops; ++i)
     COMIC_REQUIRE(seen[i] || ops[i].kind == 5 || ops[i].kind == 6, "cnn_backward_sched: op %d is not in the schedule", i);
+  {
+    // the partial d beta rows of the fused convs -> d beta, on the weight-gradient lane (it waits for both chain lanes' launches
+    // so far; the optimiser waits for this lane)
+    DbetaFoldTable tb;
+    tb.n = 0;
+    auto flush = [&]() {
+      if (tb.n) hipLaunchKernelGGL(dbeta_fold_kernel, dim3(tb.n), dim3(256), 0, st_w, tb);
+      tb.n = 0;
+    };
+    bool any = false;
+    for (int p = 0; p < n_ops; ++p) any = any || fused_by[p] >= 0;
+    if (any) COMIC_REQUIRE(link_streams(s0, st_w), "cnn_backward_sched: fold of the fused d beta sums failed");
+    for (int p = 0; p < n_ops; ++p) {
+      if (fused_by[p] < 0) continue;
+      if (tb.n == kFoldMax) flush();
+      auto& en = tb.e[tb.n++];
+      en.part = (const float*)((char*)scratch + part_off[p]);
+      en.dbeta = grads[ops[p].weight].dbeta;
+      en.C = ops[p].Cout;
+      en.pad = 0;
+    }
+    flush();
+  }
   COMIC_REQUIRE(link_streams(st_w, s0), "cnn_backward_sched: join of the weight-gradient lane failed");
   COMIC_LAUNCH_CHECK("cnn_backward_sched");
   return 0;
@@ -3332,6 +3541,11 @@ extern "C" int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, cons
                                           (hipStream_t)stream1, (hipStream_t)wgrad_stream, filters_ready != 0);
   COMIC_REQUIRE(false, "unknown dtype %d", dtype);
   return 2;
+}
+
+extern "C" int comic_debug_cnn_backward_fusion(int on) {
+  g_no_act_fusion = !on;
+  return 0;
 }
 
 extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype, int lanes) {

@@ -28,9 +28,18 @@ struct ConvArgs {
   const void* w_frag; // host only: the weights in MFMA-fragment order (comic_conv_weight::w_frag), or null
   int x3;            // COMIC_OP_X3: channel stride between the [hi | lo | hi] regions of the bf16 destination (0: plain store)
   int x3_src;        // pools of a COMIC_OP_X3 plan: the same for the source buffer
+  // Backward-data launch fused with the activation gradient of the conv that PRODUCED its input (one reader only): the result
+  // g is the gradient at that conv's output y; the epilogue stores g * 1[y > 0] * mask_scale[c] (the gradient at its
+  // pre-BatchNorm output, what act_grad_kernel would write) and adds the column sums of g * 1[y > 0] to mask_dbeta.
+  const void* mask_y;       // forward output of the producer (plan dtype), rows of mask_cs channels, slice from mask_co; null: off
+  const float* mask_scale;
+  float* mask_dbeta;        // [kMaskCopies][Cout] partial sums (folded into d beta by dbeta_fold_kernel)
+  int mask_cs, mask_co;
 };
 
 namespace {
+
+constexpr int kMaskCopies = 32;   // accumulator copies per channel of a fused activation gradient (ConvArgs::mask_dbeta)
 
 template <typename T>
 struct Elem;
@@ -82,7 +91,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // front and the arithmetic is branch-free, so the only vector-memory wait in here is the one for those
 // loads: with the loads inside the per-tile branches the compiler has to drain vmcnt(0) at the top of
 // every tile, i.e. each store waited for the previous store's round trip.
-template <int TN, int TM>
+// MASK: the launch is a backward-data conv fused with its producer's activation gradient (ConvArgs::mask_y).  A template
+// parameter, not a runtime branch: the extra registers of that path pushed every forward kernel into spills otherwise.
+template <int TN, int TM, bool MASK = false>
 __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&acc)[TN][TM], const int nbase,
                                                  const int nq, const int (&mrow)[TM]) {
   float4 sc[TN], sh[TN];
@@ -96,6 +107,64 @@ __device__ __forceinline__ void conv_store_tiles(const ConvArgs& a, f32x4_t (&ac
   }
   const float lo = a.relu ? 0.f : -INFINITY;             // relu as one v_max per value
   const int esz = a.out_f32 ? 4 : 2;
+  if constexpr (MASK) {        // fused activation gradient of the producer conv (see ConvArgs::mask_y)
+    float4 bsc[TN], sum[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      bsc[i] = *(const float4*)(a.mask_scale + (nv[i] ? nbase + i * 16 + nq : 0));
+      sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const bool mok = mrow[j] >= 0;
+      const size_t m = (size_t)(mok ? mrow[j] : 0);
+      const unsigned char* yrow = (const unsigned char*)a.mask_y + (m * a.mask_cs + a.mask_co + nbase + nq) * esz;
+      unsigned char* drow = (unsigned char*)a.y + (m * a.y_cs + a.y_co + nbase + nq) * esz;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const bool ok = nv[i] & mok;
+        float yv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          if (a.out_f32) {
+            const float4 t = *(const float4*)(yrow + i * 64);
+            yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w;
+          } else {
+            const uint2 t = *(const uint2*)(yrow + i * 32);
+            yv[0] = __uint_as_float(t.x << 16); yv[1] = __uint_as_float(t.x & 0xFFFF0000u);
+            yv[2] = __uint_as_float(t.y << 16); yv[3] = __uint_as_float(t.y & 0xFFFF0000u);
+          }
+        }
+        const float g0 = yv[0] > 0.f ? acc[i][j][0] : 0.f, g1 = yv[1] > 0.f ? acc[i][j][1] : 0.f;
+        const float g2 = yv[2] > 0.f ? acc[i][j][2] : 0.f, g3 = yv[3] > 0.f ? acc[i][j][3] : 0.f;
+        sum[i].x += g0; sum[i].y += g1; sum[i].z += g2; sum[i].w += g3;
+        if (ok) {
+          if (a.out_f32) *(float4*)(drow + i * 64) = make_float4(g0 * bsc[i].x, g1 * bsc[i].y, g2 * bsc[i].z, g3 * bsc[i].w);
+          else *(uint2*)(drow + i * 32) = make_uint2(pack_bf16x2(g0 * bsc[i].x, g1 * bsc[i].y), pack_bf16x2(g2 * bsc[i].z, g3 * bsc[i].w));
+        }
+      }
+    }
+    // the 16 lanes of a row group hold the same four channels of 16 different pixels
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        sum[i].x += __shfl_xor(sum[i].x, d);
+        sum[i].y += __shfl_xor(sum[i].y, d);
+        sum[i].z += __shfl_xor(sum[i].z, d);
+        sum[i].w += __shfl_xor(sum[i].w, d);
+      }
+      if (nv[i] && (threadIdx.x & 15) == 0) {
+        // (kMaskCopies accumulators per channel, picked by the workgroup: every workgroup of a launch finishes at about the
+        // same time, and a thousand same-address atomics in a row cost 25 us per launch)
+        float* db = a.mask_dbeta + (size_t)(blockIdx.x & (kMaskCopies - 1)) * a.Cout + nbase + i * 16 + nq;
+        atomicAdd(db + 0, sum[i].x);
+        atomicAdd(db + 1, sum[i].y);
+        atomicAdd(db + 2, sum[i].z);
+        atomicAdd(db + 3, sum[i].w);
+      }
+    }
+    return;
+  }
   if (a.x3 && !a.out_f32) {    // COMIC_OP_X3: v -> hi = bf16(v), lo = bf16(v - hi), stored as regions [hi | lo | hi]
 #pragma unroll
     for (int j = 0; j < TM; ++j) {

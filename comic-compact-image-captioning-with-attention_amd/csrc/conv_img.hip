@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   ConvArgs ca;
   ca.scale = m.scale; ca.shift = m.shift; ca.y = m.y; ca.y_cs = m.y_cs; ca.y_co = m.y_co; ca.Cout = a.Cout;
   ca.relu = m.relu; ca.out_f32 = m.out_f32; ca.accum = 0; ca.x3 = 0; ca.x3_src = 0;   // (x3 plans carry no fragment-order weights: never here)
+  ca.mask_y = nullptr;     // (no fused activation gradient: a forward kernel)
   conv_store_tiles<TN, TM>(ca, acc, wn * TN * 16, fg * 4, mrow);
 }
 

@@ -306,6 +306,11 @@ int64_t comic_gemm_group_workspace(const comic_gemm_prob* probs, int n);
 int comic_gemm_group(const comic_gemm_prob* probs, int n, void* workspace, int64_t workspace_bytes, void* stream);
 /* measurement knobs of the grouped launch (work items per launch, XCD-contiguous item order); results do not change */
 int comic_debug_gemm_group_tuning(int target_items, int xcd_remap);
+/* comic_cnn_backward_sched fuses the activation gradient of a conv whose output has exactly one reader (a conv on the same
+ * lane: the inner convs of the Inception branches) into the epilogue of that reader's backward-data launch -- one launch less
+ * per conv on the serial chain of a block's longest branch.  on = 0 runs the unfused chain (A/B timing, parity tests);
+ * process-wide, default on. */
+int comic_debug_cnn_backward_fusion(int on);
 
 /* Skinny product for the decode steps: out[R][N] = x[R][Kin] W[Kin][N] + bias for 33 ... 256 rows (batch x beam), Kin a
  * multiple of 8, any N -- the [TF-1.9] dense layers inside rnn_decoder_beam_search's step (BasicLSTMCell's gate product

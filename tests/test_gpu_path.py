@@ -450,6 +450,37 @@ def test_inception_v3_backward_224_bf16_sanity():
     assert all(np.isfinite(v).all() for v in got.values())
 
 
+@pytest.mark.parametrize('dtype,tol', [('f32', 2e-5), ('bf16', 2e-2)])
+def test_backward_with_fused_activation_gradients_matches_the_unfused_chain(dtype, tol):
+    """comic_cnn_backward_sched hands the activation gradient of a conv with ONE reader (the inner convs of the Inception
+    branches) to the epilogue of that reader's backward-data launch.  Same gradients as the chain with the separate
+    act_grad launches (comic_debug_cnn_backward_fusion(0)): fp32 plan to rounding of the atomics' order, bf16 plan to the one
+    bf16 rounding of the intermediate gradient the fused form skips."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 25, 2048)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), params, B, dtype, DEV)
+    lib = L.load()
+    out = {}
+    try:
+        for fused in (0, 1):
+            lib.comic_debug_cnn_backward_fusion(fused)
+            enc.forward(dev(x))
+            t = enc.backward(dev(d_fm), dev(d_net))
+            sync()
+            assert t.sched is not None                   # the scheduled (three-lane) backward is the one that fuses
+            out[fused] = _cnn_grads_device(enc, t)
+    finally:
+        lib.comic_debug_cnn_backward_fusion(1)
+    errs = sorted((rel_err(out[1][k], out[0][k]), k) for k in out[0])
+    assert errs[-1][0] < tol, errs[-3:]
+    moved = sum(1 for k in out[0] if not np.array_equal(out[0][k], out[1][k]))
+    if dtype == 'bf16':
+        assert moved > 20                                # the fused form did run (it skips a bf16 rounding)
+
+
 # ----------------------------------------------------------------------------- decoder ----
 def _spec_and_cfg(**kw):
     base = dict(D=128, E=64, V=258, C=192, Cg=192, H=8, M=25)
