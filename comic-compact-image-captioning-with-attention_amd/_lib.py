@@ -134,6 +134,7 @@ _SIGS = {
     'comic_dropout_masks4_dev': (c_int, [P, P, P, P, P]),
     'comic_image_preprocess': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     'comic_jpeg_pixels': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    'comic_jpeg_preprocess': (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),

@@ -185,7 +185,111 @@ __global__ __launch_bounds__(64) void jpeg_colour_kernel(const comic_jpeg_info* 
   else colour_row<2, 2>(in, planes, pixels, y, x0);
 }
 
+// ---- component planes -> network input in one launch (the loader's path) ---------------------------------------------------
+// comic_image_preprocess (csrc/preprocess.hip: uint8 -> [0,1] -> TF-1 bilinear resize -> flip -> crop -> [-1,1], same float32
+// roundings, contraction off) whose four taps per output pixel are converted from the planes on the fly: the RGB image is
+// never written (59 MB per 64 images of 640 x 480, and the 88 us of jpeg_colour_kernel).  Images of the PIL path (ncomp == 0)
+// are read from the RGB blob as before.
+struct ImgDesc {                  // comic_image_desc
+  int64_t offset;
+  int32_t in_h, in_w;
+  int32_t flip, oy, ox;
+  float sy, sx;
+};
+
+__device__ __forceinline__ float lerp_rn(float a, float b, float w) {
+#pragma clang fp contract(off)
+  const float d = b - a;
+  const float m = d * w;
+  return a + m;
+}
+
+template <int HS, int VS>
+__device__ __forceinline__ void tap_rgb(const comic_jpeg_info* in, const uint8_t* __restrict__ planes, int y, int x, int (&rgb)[3]) {
+  const uint8_t* base = planes + in->coef_base;
+  const int yy = base[in->coef_off[0] + (long)y * (in->blocks_w[0] * 8) + x];
+  const int cs = in->blocks_w[1] * 8, cw = in->comp_w[1], ch = in->comp_h[1];
+  const int cb = chroma_at<HS, VS>(base + in->coef_off[1], cs, cw, ch, y, x);
+  const int cr = chroma_at<HS, VS>(base + in->coef_off[2], cs, cw, ch, y, x);
+  const int xb = cb - 128, xr = cr - 128;
+  rgb[0] = (int)clamp_u8(yy + ((kFix140200 * xr + kHalf) >> 16));
+  rgb[1] = (int)clamp_u8(yy + ((-kFix034414 * xb + kHalf - kFix071414 * xr) >> 16));
+  rgb[2] = (int)clamp_u8(yy + ((kFix177200 * xb + kHalf) >> 16));
+}
+
+__device__ __forceinline__ void tap(const comic_jpeg_info* in, const uint8_t* __restrict__ planes, const uint8_t* __restrict__ rgb_src,
+                                    int in_w, int y, int x, int (&rgb)[3]) {
+  if (in->ncomp == 0) {                                  // decoded by PIL: RGB bytes in the blob
+    const uint8_t* p = rgb_src + ((size_t)y * in_w + x) * 3;
+    rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
+  } else if (in->ncomp == 1) {
+    rgb[0] = rgb[1] = rgb[2] = planes[in->coef_base + (long)y * (in->blocks_w[0] * 8) + x];
+  } else if (in->hmax == 1) {
+    tap_rgb<1, 1>(in, planes, y, x, rgb);
+  } else if (in->vmax == 1) {
+    tap_rgb<2, 1>(in, planes, y, x, rgb);
+  } else {
+    tap_rgb<2, 2>(in, planes, y, x, rgb);
+  }
+}
+
+__global__ __launch_bounds__(256) void jpeg_preprocess_kernel(const comic_jpeg_info* __restrict__ infos,
+                                                              const uint8_t* __restrict__ planes, const uint8_t* __restrict__ blob,
+                                                              const ImgDesc* __restrict__ desc, float* __restrict__ dst, int out_h,
+                                                              int out_w, int resize) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= out_h * out_w) return;
+  const comic_jpeg_info* in = infos + i;
+  const ImgDesc d = desc[i];
+  const int y = p / out_w, x = p % out_w;
+  const int Y = d.oy + y;
+  const int X = d.flip ? resize - 1 - (d.ox + x) : d.ox + x;
+  const float ys = (float)Y * d.sy, xs = (float)X * d.sx;
+  const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
+  const int y1 = min((int)ceilf(ys), d.in_h - 1), x1 = min((int)ceilf(xs), d.in_w - 1);
+  const float wy = ys - (float)y0, wx = xs - (float)x0;
+  const float inv255 = (float)(1.0 / 255);
+  const uint8_t* src = blob + d.offset;
+  int t00[3], t01[3], t10[3], t11[3];
+  tap(in, planes, src, d.in_w, y0, x0, t00);
+  tap(in, planes, src, d.in_w, y0, x1, t01);
+  tap(in, planes, src, d.in_w, y1, x0, t10);
+  tap(in, planes, src, d.in_w, y1, x1, t11);
+  float* o = dst + ((size_t)i * out_h * out_w + p) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float p00 = (float)t00[c] * inv255, p01 = (float)t01[c] * inv255;
+    const float p10 = (float)t10[c] * inv255, p11 = (float)t11[c] * inv255;
+    const float top = lerp_rn(p00, p01, wx), bot = lerp_rn(p10, p11, wx);
+    const float v = lerp_rn(top, bot, wy);
+    const float centred = v - 0.5f;
+    o[c] = centred * 2.0f;
+  }
+}
+
 }  // namespace
+
+extern "C" int comic_jpeg_preprocess(const int16_t* coef, const void* infos, int n, int max_blocks, uint8_t* planes,
+                                     const uint8_t* blob, const void* desc, float* dst, int out_h, int out_w, int resize,
+                                     void* stream) {
+  COMIC_REQUIRE(coef && infos && planes && desc && dst, "jpeg_preprocess: null pointer");
+  COMIC_REQUIRE(n > 0 && n <= 65535 && max_blocks >= 0 && out_h > 0 && out_w > 0 && resize >= out_h && resize >= out_w,
+                "jpeg_preprocess: bad sizes");
+  COMIC_REQUIRE(((uintptr_t)coef & 15) == 0 && ((uintptr_t)planes & 7) == 0, "jpeg_preprocess: coefficient / plane blob alignment");
+  static_assert(sizeof(ImgDesc) == 40, "comic_image_desc layout");
+  hipStream_t st = (hipStream_t)stream;
+  if (max_blocks > 0) {
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3(cdiv(max_blocks, 256), n), dim3(256), 0, st, coef, (const comic_jpeg_info*)infos,
+                       planes);
+    COMIC_LAUNCH_CHECK("jpeg_idct");
+  }
+  hipLaunchKernelGGL(jpeg_preprocess_kernel, dim3(cdiv(out_h * out_w, 256), n), dim3(256), 0, st, (const comic_jpeg_info*)infos,
+                     planes, blob, (const ImgDesc*)desc, dst, out_h, out_w, resize);
+  COMIC_LAUNCH_CHECK("jpeg_preprocess");
+  return 0;
+}
 
 extern "C" int comic_jpeg_pixels(const int16_t* coef, const void* infos, int n, int max_blocks, int max_w, int max_h,
                                  uint8_t* planes, uint8_t* pixels, void* stream) {

@@ -408,8 +408,10 @@ class DevicePreprocessor(object):
         ok = status == L.JPEG_OK
         h, w = infos['height'].astype(np.int64), infos['width'].astype(np.int64)
         off = infos['pixel_off'].astype(np.int64)
-        # files the split decoder does not take: PIL, appended behind the device-decoded images of the blob
+        # files the split decoder does not take: PIL; their RGB bytes go to the blob the preprocessing kernel reads for images
+        # with ncomp == 0 (the images decoded on the device are never written as RGB)
         late = []
+        pixel_bytes = 0
         for i in np.nonzero(~ok)[0]:
             im = decode_image(paths[i])
             infos['ncomp'][i] = 0
@@ -424,21 +426,22 @@ class DevicePreprocessor(object):
         desc['sy'] = (h / self.resize).astype(np.float32)
         desc['sx'] = (w / self.resize).astype(np.float32)
         with torch.cuda.device(self.device):
-            if self._dev_blob is None or self._dev_blob.numel() < pixel_bytes:
+            if late and (self._dev_blob is None or self._dev_blob.numel() < pixel_bytes):
                 self._dev_blob = torch.empty(int(pixel_bytes * 1.3) + 4096, dtype=torch.uint8, device=self.device)
             st = L.stream_ptr()
-            if ok.any():
-                dev_infos = slot['infos'][:n * 512].to(self.device, non_blocking=True)
+            dev_infos = slot['infos'][:n * 512].to(self.device, non_blocking=True)
+            if used > 0:
                 self._dev_coef[:used].copy_(slot['coef'][:used], non_blocking=True)      # the batch's ONE coefficient copy
-                L.check(self.lib.comic_jpeg_pixels(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
-                                                   int(infos['coef_count'][ok].max()) // 64, int(w[ok].max()), int(h[ok].max()),
-                                                   self._dev_planes.data_ptr(), self._dev_blob.data_ptr(), st), 'jpeg_pixels')
             for o, im in late:
                 self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.array(im, copy=True).reshape(-1)))
             dev_desc = torch.from_numpy(desc.view(np.uint8)).to(self.device)
             out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
-            L.check(self.lib.comic_image_preprocess(self._dev_blob.data_ptr(), dev_desc.data_ptr(), n, out.data_ptr(),
-                                                    self.h, self.w, self.resize, st), 'image_preprocess')
+            # inverse DCT, then resize / flip / crop / scale with the taps converted from the component planes on the fly
+            L.check(self.lib.comic_jpeg_preprocess(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
+                                                   int(infos['coef_count'][ok].max()) // 64 if ok.any() else 0,
+                                                   self._dev_planes.data_ptr(), self._dev_blob.data_ptr() if late else None,
+                                                   dev_desc.data_ptr(),
+                                                   out.data_ptr(), self.h, self.w, self.resize, st), 'jpeg_preprocess')
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
         self._pending.append((('coef', slot), ev))

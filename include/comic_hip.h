@@ -197,6 +197,14 @@ int comic_image_preprocess(const uint8_t* blob, const void* desc, int n, float* 
  * comic_image_preprocess reads. */
 int comic_jpeg_pixels(const int16_t* coef, const void* infos, int n, int max_blocks, int max_w, int max_h, uint8_t* planes,
                       uint8_t* pixels, void* stream);
+/* The loader's form: inverse DCT into the component planes, then comic_image_preprocess with its four taps per output
+ * pixel converted from the planes on the fly (same integer upsampling / colour arithmetic, same float32 roundings: the
+ * values of comic_jpeg_pixels + comic_image_preprocess, bit for bit) -- the RGB image is never written.  `desc`: n
+ * comic_image_desc records (in_h / in_w / flip / crop / scales; `offset` is used for images with ncomp == 0 only, which are
+ * read as RGB bytes from `blob`: the files the loader's PIL path decoded; `blob` may be NULL when there are none);
+ * max_blocks 0: no image needs the inverse DCT. */
+int comic_jpeg_preprocess(const int16_t* coef, const void* infos, int n, int max_blocks, uint8_t* planes, const uint8_t* blob,
+                          const void* desc, float* dst /* [n,out_h,out_w,3] */, int out_h, int out_w, int resize, void* stream);
 
 /* ---- cnn_finetune: backward of the plan (train.py:241-249; model_base.py:76,834-849) ------
  * The CNN variables (conv weights, BN beta) become trainable; BN stays in inference mode, so a
