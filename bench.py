@@ -560,8 +560,8 @@ def input_pipeline_rate(device, n_files=128, threads=16):
         jpool.close()
         return {'images_per_sec': round(n / dt, 1), 'host_threads': threads, 'bit_identical_to_pil_path': same,
                 'files': '%d x 640x480 JPEG, quality 90, 4:2:0 (camera photographs re-encoded), %.0f KB on average' % (n_files, kb),
-                'path': 'libcomic_jpeg.so (Huffman decoding, C threads) -> comic_jpeg_pixels (IDCT / upsampling / colour) -> '
-                        'comic_image_preprocess (resize / crop / scale)'}
+                'path': 'libcomic_jpeg.so (Huffman decoding, C threads) -> comic_jpeg_preprocess (inverse DCT, then resize / crop / '
+                        'scale with the taps upsampled and colour-converted from the component planes)'}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
