@@ -120,6 +120,23 @@ def test_train_infer_cli_default_backbone(tmp_path):
                                                  '--get_metric_score', ''])
     caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
     assert caps and len(json.load(open(caps[0]))) == 4
+    # --loader_split_jpeg (Huffman decoding on C threads, the pixels on the device): the same captions, and a training run
+    os.rename(caps[0], caps[0] + '.pil')
+    _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
+                                                 '--infer_set', 'test', '--batch_size_infer', '4',
+                                                 '--get_metric_score', '', '--loader_split_jpeg', '--loader_threads', '3'])
+    assert json.load(open(caps[0])) == json.load(open(caps[0] + '.pil'))
+    logs2 = str(tmp_path / 'experiments_split')
+    _run(os.path.join(ROOT, 'src', 'train.py'), ['--dataset_dir', ds, '--log_root', logs2, '--batch_size_eval', '4',
+                                                 '--rnn_size', '128', '--rnn_word_size', '64', '--train_mode', 'decoder',
+                                                 '--batch_size_train', '4', '--max_epoch', '1', '--loader_split_jpeg'])
+    errs = glob.glob(os.path.join(logs2, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    ck2 = sorted(glob.glob(os.path.join(logs2, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01', 'model_compact-*.npz')))
+    assert ck2
+    z2 = np.load(ck2[-1])
+    # same files, same seed, bit-identical input tensors: the run with the split decoder ends at the same weights
+    np.testing.assert_array_equal(z2['Model/decoder/rnn_decoder/memory_layer/kernel'], z['Model/decoder/rnn_decoder/memory_layer/kernel'])
 
 
 def test_train_infer_cli_bf16x3_plan(tmp_path):
