@@ -48,7 +48,8 @@ def test_two_ranks_through_train_fn_end_with_equal_parameters(tmp_path):
     _launch([os.path.join(ROOT, 'tests', 'dp_worker.py'), 'cli', out, '--dataset_dir', ds, '--log_root', logs,
              '--cnn_name', 'inception_v3', '--cnn_fm_attention', 'Mixed_7c', '--cnn_input_size', '139,139',
              '--batch_size_eval', '4', '--rnn_size', '128', '--rnn_word_size', '64', '--train_mode', 'decoder',
-             '--batch_size_train', '4', '--max_epoch', '1'])
+             '--batch_size_train', '4', '--max_epoch', '1',
+             '--loader_split_jpeg', '--loader_threads', '2'])       # every rank with its own pool of decode threads
     assert not glob.glob(os.path.join(logs, 'mscoco', 'error__*')), open(glob.glob(os.path.join(logs, 'mscoco', 'error__*'))[0]).read()
     p0, p1 = (np.load(os.path.join(out, 'params_rank%d.npy' % r)) for r in (0, 1))
     s0, s1 = (int(np.load(os.path.join(out, 'step_rank%d.npy' % r))[0]) for r in (0, 1))
