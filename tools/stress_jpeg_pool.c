@@ -1,0 +1,37 @@
+// Stress of the JPEG decode pool (comic_jpeg_pool_*) for the CPU sanitizers: twelve batches queued at once over six threads,
+// a third of them with a staging buffer too small for all their images, waits polled in reverse order, files that are
+// missing / truncated / progressive among the arguments; forty rounds.
+//   gcc -O1 -g -fsanitize=address,undefined -pthread -o /tmp/stress_jpeg_pool tools/stress_jpeg_pool.c \
+//       comic-compact-image-captioning-with-attention_amd/csrc/jpeg_entropy.c && /tmp/stress_jpeg_pool a.jpg b.jpg missing.jpg ...
+// Round 4: clean under ASan + UBSan (ThreadSanitizer does not start in this container).
+#include "../include/comic_jpeg.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+int main(int argc, char** argv) {
+  // argv[1..]: files (some may be missing / corrupt)
+  const int n = argc - 1;
+  comic_jpeg_pool* pool = comic_jpeg_pool_create(6);
+  enum { B = 12 };
+  comic_jpeg_info* infos[B]; int32_t* status[B]; int16_t* coef[B]; void* h[B];
+  const int64_t cap = 4000000;
+  long ok = 0, bad = 0;
+  for (int round = 0; round < 40; ++round) {
+    for (int b = 0; b < B; ++b) {
+      infos[b] = calloc(n, sizeof(comic_jpeg_info)); status[b] = calloc(n, sizeof(int32_t)); coef[b] = malloc(cap * 2);
+      const char* paths[64];
+      for (int i = 0; i < n; ++i) paths[i] = argv[1 + (i + b + round) % n];
+      h[b] = comic_jpeg_pool_submit(pool, paths, n, infos[b], status[b], coef[b], (b % 3 == 2) ? 200000 : cap);
+      if (!h[b]) { printf("submit failed\n"); return 1; }
+    }
+    for (int b = B - 1; b >= 0; --b) {        // waits in reverse order
+      int64_t used = -1, px = -1;
+      while (comic_jpeg_pool_wait(pool, h[b], 0.001, &used, &px) == 1) {}
+      for (int i = 0; i < n; ++i) { if (status[b][i] == 0) ++ok; else ++bad; }
+      free(infos[b]); free(status[b]); free(coef[b]);
+    }
+  }
+  comic_jpeg_pool_destroy(pool);
+  printf("images ok %ld other %ld\n", ok, bad);
+  return 0;
+}
