@@ -247,11 +247,15 @@ class JpegSplitPool(object):
         self._pool = self.lib.comic_jpeg_pool_create(self.threads)
         if not self._pool:
             raise RuntimeError('comic_jpeg_pool_create(%d) failed' % self.threads)
+        self._lock = threading.Lock()              # submit() of a loader thread against close() of the main thread
 
     def submit(self, paths, infos_ptr, status_ptr, coef_ptr, capacity):
         import ctypes as C
         arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
-        h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, int(capacity))
+        with self._lock:
+            if not self._pool:
+                raise RuntimeError('the JPEG decode pool is closed')
+            h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, int(capacity))
         if not h:
             raise RuntimeError('comic_jpeg_pool_submit failed')
         return h
@@ -267,10 +271,15 @@ class JpegSplitPool(object):
                                % (self.timeout_s, ', '.join(str(p) for p in list(paths)[:4])))
         return int(used.value), int(total.value)
 
+    @property
+    def closed(self):
+        return not self._pool
+
     def close(self):
-        if self._pool:
-            self.lib.comic_jpeg_pool_destroy(self._pool)          # waits for queued work
-            self._pool = None
+        with self._lock:
+            pool, self._pool = self._pool, None
+        if pool:
+            self.lib.comic_jpeg_pool_destroy(pool)                # waits for queued work
 
 
 class PackedImages(object):
@@ -372,10 +381,17 @@ class DevicePreprocessor(object):
         jpool = self._jpool
         if len(paths) > jpool.max_batch:
             raise ValueError('batch of %d images exceeds the split decoder\'s staging slots (%d)' % (len(paths), jpool.max_batch))
-        try:
-            slot = self._free_coef.get(timeout=jpool.timeout_s)
-        except queue.Empty:
-            raise RuntimeError('no coefficient staging slot came back within %.0f s (consumer stalled?)' % jpool.timeout_s)
+        import time
+        t_end = time.monotonic() + jpool.timeout_s
+        while True:                  # (short polls: a loader thread parked here must notice the end of its stage)
+            try:
+                slot = self._free_coef.get(timeout=0.05)
+                break
+            except queue.Empty:
+                if jpool.closed:
+                    raise RuntimeError('the JPEG decode pool is closed')
+                if time.monotonic() > t_end:
+                    raise RuntimeError('no coefficient staging slot came back within %.0f s (consumer stalled?)' % jpool.timeout_s)
         handle = jpool.submit(paths, slot['infos'].data_ptr(), slot['status'].ctypes.data, slot['coef'].data_ptr(),
                               slot['coef'].numel())
         return PackedImages(('split', jpool, handle, slot, list(paths), list(params)), None, None, len(paths), 0)
