@@ -241,6 +241,8 @@ _JPEG_SIGS = {
     'comic_jpeg_pool_destroy': (None, [P]),
     'comic_jpeg_pool_submit': (P, [P, P, c_int, P, P, P, C.c_int64]),
     'comic_jpeg_pool_wait': (c_int, [P, P, C.c_double, P, P]),
+    'comic_jpeg_pool_enable_cache': (c_int, [P, C.c_int64]),
+    'comic_jpeg_pool_cache_stats': (c_int, [P, P, P, P]),
 }
 JPEG_EXPORTED_SYMBOLS = tuple(_JPEG_SIGS)
 _jpeg_lib = None

@@ -436,10 +436,12 @@ int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coe
 #include <pthread.h>
 #include <time.h>
 
+struct CacheEntry;
 typedef struct {
   uint8_t* data;                   // the file, kept from pass 1 to pass 2
   int64_t n;
   Parsed* ps;                      // its tables
+  const struct CacheEntry* hit;    // the image's coefficients are in the pool's cache: no file read, no Huffman decoding
 } Item;
 
 typedef struct Batch {
@@ -450,8 +452,125 @@ typedef struct Batch {
   int32_t* status;
   int16_t* coef;
   int64_t capacity, used;
+  struct comic_jpeg_pool* pool;
   struct Batch* link;
 } Batch;
+
+// ---- coefficient cache (comic_jpeg_pool_enable_cache): epochs after the first skip the entropy decoding ------------------------
+// An image is kept as its non-zero coefficients -- per 8x8 block a count and (position, value) pairs: about the size of
+// the JPEG file itself, 6-7x smaller than the dense int16 blocks -- under its path; entries are never evicted (insertion stops at
+// the byte limit), so a hit's pointer stays valid until the pool is destroyed.  Readers and the inserting thread meet under a
+// read-write lock.
+typedef struct CacheEntry {
+  char* path;
+  uint64_t hash;
+  comic_jpeg_info info;
+  uint8_t* packed;                 // per block: n, then n x (index, value lo, value hi)
+  int64_t packed_bytes;
+  struct CacheEntry* next;
+} CacheEntry;
+
+typedef struct {
+  pthread_rwlock_t lock;
+  CacheEntry** buckets;
+  int64_t n_buckets, max_bytes, bytes, entries, hits;
+} CoefCache;
+
+static uint64_t path_hash(const char* s) {
+  uint64_t h = 1469598103934665603ull;                  // FNV-1a
+  for (; *s; ++s) h = (h ^ (uint8_t)*s) * 1099511628211ull;
+  return h;
+}
+
+static const CacheEntry* cache_lookup(CoefCache* c, const char* path) {
+  if (!c || !c->buckets) return NULL;
+  const uint64_t h = path_hash(path);
+  pthread_rwlock_rdlock(&c->lock);
+  const CacheEntry* e = c->buckets[h % (uint64_t)c->n_buckets];
+  while (e && !(e->hash == h && !strcmp(e->path, path))) e = e->next;
+  pthread_rwlock_unlock(&c->lock);
+  if (e) __atomic_fetch_add(&c->hits, 1, __ATOMIC_RELAXED);
+  return e;
+}
+
+static int64_t pack_coefficients(const int16_t* coef, int64_t blocks, uint8_t* out) {   // out == NULL: size only
+  int64_t o = 0;
+  for (int64_t b = 0; b < blocks; ++b) {
+    const int16_t* blk = coef + b * 64;
+    const int64_t at = o++;
+    int n = 0;
+    for (int k = 0; k < 64; ++k)
+      if (blk[k]) {
+        if (out) {
+          out[o] = (uint8_t)k;
+          out[o + 1] = (uint8_t)(blk[k] & 0xff);
+          out[o + 2] = (uint8_t)((uint16_t)blk[k] >> 8);
+        }
+        o += 3;
+        ++n;
+      }
+    if (out) out[at] = (uint8_t)n;
+  }
+  return o;
+}
+
+static void unpack_coefficients(const uint8_t* in, int64_t blocks, int16_t* coef) {
+  memset(coef, 0, (size_t)blocks * 64 * sizeof(int16_t));
+  for (int64_t b = 0; b < blocks; ++b) {
+    int16_t* blk = coef + b * 64;
+    const int n = *in++;
+    for (int j = 0; j < n; ++j, in += 3) blk[in[0] & 63] = (int16_t)(in[1] | (in[2] << 8));
+  }
+}
+
+static void cache_insert(CoefCache* c, const char* path, const comic_jpeg_info* info, const int16_t* coef) {
+  if (!c || !c->buckets || c->bytes >= c->max_bytes) return;
+  const int64_t blocks = info->coef_count / 64;
+  const int64_t nb = pack_coefficients(coef, blocks, NULL);
+  const int64_t cost = nb + (int64_t)sizeof(CacheEntry) + (int64_t)strlen(path) + 1;
+  CacheEntry* e = (CacheEntry*)calloc(1, sizeof(CacheEntry));
+  uint8_t* packed = (uint8_t*)malloc((size_t)nb);
+  char* p = strdup(path);
+  if (!e || !packed || !p) {
+    free(e); free(packed); free(p);
+    return;
+  }
+  pack_coefficients(coef, blocks, packed);
+  e->path = p;
+  e->hash = path_hash(path);
+  e->info = *info;
+  e->info.coef_base = e->info.pixel_off = 0;
+  e->packed = packed;
+  e->packed_bytes = nb;
+  pthread_rwlock_wrlock(&c->lock);
+  CacheEntry** slot = &c->buckets[e->hash % (uint64_t)c->n_buckets];
+  const CacheEntry* dup = *slot;
+  while (dup && !(dup->hash == e->hash && !strcmp(dup->path, path))) dup = dup->next;
+  const int take = !dup && c->bytes + cost <= c->max_bytes;
+  if (take) {
+    e->next = *slot;
+    *slot = e;
+    c->bytes += cost;
+    c->entries += 1;
+  }
+  pthread_rwlock_unlock(&c->lock);
+  if (!take) {
+    free(e->path); free(e->packed); free(e);
+  }
+}
+
+static void cache_free(CoefCache* c) {
+  if (!c->buckets) return;
+  for (int64_t i = 0; i < c->n_buckets; ++i)
+    for (CacheEntry* e = c->buckets[i]; e;) {
+      CacheEntry* nx = e->next;
+      free(e->path); free(e->packed); free(e);
+      e = nx;
+    }
+  free(c->buckets);
+  c->buckets = NULL;
+  pthread_rwlock_destroy(&c->lock);
+}
 
 struct comic_jpeg_pool {
   pthread_mutex_t mu;
@@ -459,6 +578,7 @@ struct comic_jpeg_pool {
   Batch* head;                     // batches with passes left, in submission order
   int stop, nthreads;
   pthread_t* threads;
+  CoefCache cache;
 };
 
 static int read_file(const char* path, uint8_t** out, int64_t* out_n) {
@@ -503,6 +623,12 @@ static void pass1(Batch* b, int i) {
   Item* it = &b->items[i];
   comic_jpeg_info* in = &b->infos[i];
   memset(in, 0, sizeof(*in));
+  it->hit = cache_lookup(&b->pool->cache, b->paths[i]);
+  if (it->hit) {
+    *in = it->hit->info;
+    b->status[i] = COMIC_JPEG_OK;
+    return;
+  }
   int rc = read_file(b->paths[i], &it->data, &it->n);
   if (rc == COMIC_JPEG_OK) {
     it->ps = (Parsed*)malloc(sizeof(Parsed));
@@ -533,9 +659,15 @@ static void lay_out(Batch* b) {
 static void pass2(Batch* b, int i) {
   if (b->status[i] != COMIC_JPEG_OK) return;
   Item* it = &b->items[i];
+  int16_t* dst = b->coef + b->infos[i].coef_base;
+  if (it->hit) {
+    unpack_coefficients(it->hit->packed, it->hit->info.coef_count / 64, dst);
+    return;
+  }
   it->ps->info.coef_base = b->infos[i].coef_base;
-  const int rc = decode_scan(it->data, it->n, it->ps, b->coef + b->infos[i].coef_base);
+  const int rc = decode_scan(it->data, it->n, it->ps, dst);
   b->status[i] = rc;
+  if (rc == COMIC_JPEG_OK) cache_insert(&b->pool->cache, b->paths[i], &b->infos[i], dst);
   item_free(it);
 }
 
@@ -617,8 +749,36 @@ void comic_jpeg_pool_destroy(comic_jpeg_pool* pool) {
   pthread_mutex_destroy(&pool->mu);
   pthread_cond_destroy(&pool->work);
   pthread_cond_destroy(&pool->done);
+  cache_free(&pool->cache);
   free(pool->threads);
   free(pool);
+}
+
+int comic_jpeg_pool_enable_cache(comic_jpeg_pool* pool, int64_t max_bytes) {
+  if (!pool || max_bytes < 0) return COMIC_JPEG_CORRUPT;
+  CoefCache* c = &pool->cache;
+  if (c->buckets) {                                      // already on: only the limit moves
+    pthread_rwlock_wrlock(&c->lock);
+    c->max_bytes = max_bytes;
+    pthread_rwlock_unlock(&c->lock);
+    return COMIC_JPEG_OK;
+  }
+  if (max_bytes == 0) return COMIC_JPEG_OK;
+  c->n_buckets = 1 << 18;
+  c->buckets = (CacheEntry**)calloc((size_t)c->n_buckets, sizeof(CacheEntry*));
+  if (!c->buckets) return COMIC_JPEG_IO;
+  pthread_rwlock_init(&c->lock, NULL);
+  c->max_bytes = max_bytes;
+  return COMIC_JPEG_OK;
+}
+
+int comic_jpeg_pool_cache_stats(comic_jpeg_pool* pool, int64_t* bytes, int64_t* entries, int64_t* hits) {
+  if (!pool) return COMIC_JPEG_CORRUPT;
+  CoefCache* c = &pool->cache;
+  if (bytes) *bytes = c->buckets ? c->bytes : 0;
+  if (entries) *entries = c->buckets ? c->entries : 0;
+  if (hits) *hits = c->buckets ? __atomic_load_n(&c->hits, __ATOMIC_RELAXED) : 0;
+  return COMIC_JPEG_OK;
 }
 
 static void batch_free(Batch* b) {
@@ -655,6 +815,7 @@ void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, in
   b->status = status;
   b->coef = coef;
   b->capacity = capacity;
+  b->pool = pool;
   pthread_mutex_lock(&pool->mu);
   Batch** at = &pool->head;
   while (*at) at = &(*at)->link;

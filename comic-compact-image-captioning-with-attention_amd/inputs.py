@@ -235,7 +235,7 @@ class JpegSplitPool(object):
     (common/inputs/manager_image_caption.py:163-175).  Files the split decoder does not take (progressive, CMYK, ...) are
     decoded by PIL when their batch is finished."""
 
-    def __init__(self, threads, slot_elems=640 * 640 * 3 // 2, max_batch=64, timeout_s=120.0):
+    def __init__(self, threads, slot_elems=640 * 640 * 3 // 2, max_batch=64, timeout_s=120.0, cache_gb=0.0):
         from . import _lib as L
         self.L, self.lib = L, L.load_jpeg()
         self.threads = int(threads)
@@ -248,6 +248,10 @@ class JpegSplitPool(object):
         if not self._pool:
             raise RuntimeError('comic_jpeg_pool_create(%d) failed' % self.threads)
         self._lock = threading.Lock()              # submit() of a loader thread against close() of the main thread
+        # config.loader_cache_gb: the decoded coefficients of every image stay in host memory (as their non-zeros: about the
+        # size of the file) up to this many GB -- the epochs after the first skip file reads and Huffman decoding
+        if cache_gb and cache_gb > 0:
+            L.check(self.lib.comic_jpeg_pool_enable_cache(self._pool, int(float(cache_gb) * (1 << 30))), 'jpeg_pool_enable_cache')
 
     def submit(self, paths, infos_ptr, status_ptr, coef_ptr, capacity):
         import ctypes as C
@@ -274,6 +278,15 @@ class JpegSplitPool(object):
     @property
     def closed(self):
         return not self._pool
+
+    def cache_stats(self):
+        """-> (bytes in use, images cached, hits so far) of the coefficient cache."""
+        import ctypes as C
+        b, e, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        with self._lock:
+            if self._pool:
+                self.lib.comic_jpeg_pool_cache_stats(self._pool, C.byref(b), C.byref(e), C.byref(h))
+        return int(b.value), int(e.value), int(h.value)
 
     def close(self):
         with self._lock:
@@ -764,7 +777,8 @@ class InputManager(object):
                                             slot_elems=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)) // 2,
                                             max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),
                                                           getattr(c, 'batch_size_infer', 1)),
-                                            timeout_s=float(getattr(c, 'loader_timeout_s', 120.0)))
+                                            timeout_s=float(getattr(c, 'loader_timeout_s', 120.0)),
+                                            cache_gb=float(getattr(c, 'loader_cache_gb', 0.0) or 0.0))
             self._devpre.enable_split(self._jpeg_pool, self._prefetch_depth + 4)
             return
         nproc = int(getattr(self.config, 'loader_processes', 0) or 0)

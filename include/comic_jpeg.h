@@ -73,6 +73,14 @@ void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, in
  * 1: not done within timeout_s (the handle stays valid). */
 int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* coef_elems, int64_t* pixel_bytes);
 
+/* Coefficient cache of a pool (off by default): every image a batch has decoded is kept -- as its non-zero coefficients, about
+ * the size of the JPEG file -- under its path until `max_bytes` are in use (nothing is evicted; call before the first submit, or
+ * again to move the limit).  A later batch that names the path again gets the coefficients from memory: no file read, no Huffman
+ * decoding -- the epochs after the first run at the speed of a memory copy.  The files are assumed not to change while cached.
+ * Augmentation (flip, crop) happens on the device, behind the decode, so cached training batches are the bits of uncached ones. */
+int comic_jpeg_pool_enable_cache(comic_jpeg_pool* pool, int64_t max_bytes);
+int comic_jpeg_pool_cache_stats(comic_jpeg_pool* pool, int64_t* bytes, int64_t* entries, int64_t* hits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ def create_parser():
     a('--loader_split_jpeg', action='store_true', default=None,
       help='Split JPEG decode: C threads undo the entropy coding, the device does the pixels (bit-identical to PIL).')
     a('--loader_threads', type=int, default=None, help='Decode threads of the loader.')
+    a('--loader_cache_gb', type=float, default=None, help='Coefficient cache of the split JPEG decoder, GB.')
     return p
 
 

@@ -84,6 +84,9 @@ def create_parser():
       help='Split JPEG decode: `loader_threads` C threads undo the entropy coding, the device does inverse DCT / upsampling / '
            'colour conversion (bit-identical to PIL); files it does not take (progressive, CMYK) go through PIL.')
     a('--loader_threads', type=int, default=0, help='Decode threads of the loader (0 = min(16, cores)).')
+    a('--loader_cache_gb', type=float, default=0.0,
+      help='With --loader_split_jpeg: keep the decoded DCT coefficients of the images in host memory (as their non-zeros: about the '
+           'size of the JPEG files) up to this many GB; the epochs after the first skip file reads and Huffman decoding.')
     return p
 
 

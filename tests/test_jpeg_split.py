@@ -219,6 +219,59 @@ def test_pool_decodes_queued_batches_back_to_back(tmp_path):
     assert (status == 0).all()
 
 
+def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
+    """comic_jpeg_pool_enable_cache: the batches of a second pass over the files come from the cache (hits counted, files may
+    even be gone) with the coefficients of the first pass, bit for bit; the byte limit stops insertion, nothing is evicted."""
+    lib = L.load_jpeg()
+    paths = []
+    for i in range(9):
+        p = str(tmp_path / ('c%d.jpg' % i))
+        open(p, 'wb').write(_encode(_photo(40 + 7 * i, 60 + 5 * i, seed=i), quality=60 + 4 * i, subsampling=i % 3))
+        paths.append(p)
+    cap = 2_000_000
+
+    def run(pool, order):
+        n = len(order)
+        infos, status, coef = np.zeros(n, L.JPEG_INFO_DTYPE), np.full(n, 99, np.int32), np.full(cap, 7, np.int16)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in order])
+        h = lib.comic_jpeg_pool_submit(pool, arr, n, infos.ctypes.data, status.ctypes.data, coef.ctypes.data, cap)
+        used, total = C.c_int64(), C.c_int64()
+        assert lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(used), C.byref(total)) == 0
+        return infos, status, coef[:used.value].copy()
+
+    def stats(pool):
+        b, e, h = C.c_int64(), C.c_int64(), C.c_int64()
+        assert lib.comic_jpeg_pool_cache_stats(pool, C.byref(b), C.byref(e), C.byref(h)) == 0
+        return b.value, e.value, h.value
+    pool = lib.comic_jpeg_pool_create(3)
+    assert lib.comic_jpeg_pool_enable_cache(pool, 64 << 20) == 0
+    i1, s1, c1 = run(pool, paths)
+    b, e, h = stats(pool)
+    assert (s1 == 0).all() and e == 9 and h == 0 and 0 < b < c1.size * 2          # packed: smaller than the dense blocks
+    for p in paths[:4]:
+        os.remove(p)                                                               # the cache does not need the files
+    i2, s2, c2 = run(pool, paths)
+    assert (s2 == 0).all() and stats(pool)[2] == 9 and np.array_equal(c1, c2)
+    for f in ('width', 'height', 'coef_count', 'coef_base', 'pixel_off', 'quant', 'comp_w', 'blocks_w'):
+        assert np.array_equal(i1[f], i2[f]), f
+    i3, s3, c3 = run(pool, paths[::-1])                                            # another order: other bases, same images
+    assert (s3 == 0).all()
+    for k, p in enumerate(paths[::-1]):
+        j = paths.index(p)
+        a = c3[int(i3['coef_base'][k]):int(i3['coef_base'][k]) + int(i3['coef_count'][k])]
+        assert np.array_equal(a, c1[int(i1['coef_base'][j]):int(i1['coef_base'][j]) + int(i1['coef_count'][j])]), p
+    lib.comic_jpeg_pool_destroy(pool)
+    # a limit that holds about two images: insertion stops there
+    pool = lib.comic_jpeg_pool_create(2)
+    assert lib.comic_jpeg_pool_enable_cache(pool, 40_000) == 0
+    run(pool, paths[4:])
+    b, e, _ = stats(pool)
+    assert 0 < e < 5 and b <= 40_000
+    run(pool, paths[4:])
+    assert stats(pool)[1] == e and stats(pool)[2] == e
+    lib.comic_jpeg_pool_destroy(pool)
+
+
 # ---- device half -----------------------------------------------------------------------------------------------------------
 def _mixed_files(tmp_path, count=12):
     import sklearn

@@ -12,6 +12,7 @@ int main(int argc, char** argv) {
   // argv[1..]: files (some may be missing / corrupt)
   const int n = argc - 1;
   comic_jpeg_pool* pool = comic_jpeg_pool_create(6);
+  if (getenv("CACHE")) comic_jpeg_pool_enable_cache(pool, 3 << 20);      // (fills up half way through: hits, inserts and refusals mix)
   enum { B = 12 };
   comic_jpeg_info* infos[B]; int32_t* status[B]; int16_t* coef[B]; void* h[B];
   const int64_t cap = 4000000;

@@ -1,6 +1,7 @@
 """Training throughput FROM FILES (decoder mode, COMIC-256 defaults, batch 64): the whole chain -- JPEG files -> loader ->
-device preprocessing -> encoder -> decoder step -- with the three loaders: decode threads (default), decode processes
-(--loader_processes 16), split JPEG decode (--loader_split_jpeg, 16 C threads).  bench.py's headline uses synthetic images
+device preprocessing -> encoder -> decoder step -- with the loaders: decode threads (default), decode processes
+(--loader_processes 16), split JPEG decode (--loader_split_jpeg, 16 C threads), the same with its coefficient cache
+(MODES=cache: --loader_cache_gb 4; the timed steps come after the first epoch, i.e. from the cache).  bench.py's headline uses synthetic images
 already resident in HBM; this is the same step fed by the input pipeline.  640x480 quality-90 4:2:0 re-encodes of two
 camera photographs (scikit-learn's sample images), 512 files."""
 import importlib.util, os, sys, tempfile, time
@@ -27,6 +28,7 @@ STEPS, WARM = int(os.environ.get('STEPS', '120')), int(os.environ.get('WARM', '6
 modes = [m for m in os.environ.get('MODES', 'split,processes,threads').split(',') if m]
 for mode in modes:
     extra = {'split': ['--loader_split_jpeg', '--loader_threads', '16'], 'processes': ['--loader_processes', '16'],
+             'cache': ['--loader_split_jpeg', '--loader_threads', '16', '--loader_cache_gb', '4'],
              'threads': ['--loader_threads', '16']}[mode]
     args = cli.create_parser().parse_args(['--dataset_dir', ds, '--log_root', os.path.join(tmp, 'exp_' + mode), '--train_mode',
                                            'decoder', '--batch_size_train', '64', '--batch_size_eval', '64', '--max_epoch', '50'] + extra)
