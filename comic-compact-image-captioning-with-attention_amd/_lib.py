@@ -135,6 +135,7 @@ _SIGS = {
     'comic_image_preprocess': (c_int, [P, P, c_int, P, c_int, c_int, c_int, P]),
     'comic_jpeg_pixels': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     'comic_jpeg_preprocess': (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    'comic_jpeg_preprocess_packed': (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     'comic_weighted_sum_tb': (c_int, [P, P, c_int, c_int, P, P]),
     'comic_lstm_gates_fwd': (c_int, [P, P, P, P, P, P, P, P, c_float, P, c_int, P, P, c_int, c_int, P]),
     'comic_lstm_gates_bwd': (c_int, [P, P, P, P, P, c_float, P, c_int, P, P, P, c_int, c_int, P]),
@@ -240,6 +241,7 @@ _JPEG_SIGS = {
     'comic_jpeg_pool_create': (P, [c_int]),
     'comic_jpeg_pool_destroy': (None, [P]),
     'comic_jpeg_pool_submit': (P, [P, P, c_int, P, P, P, C.c_int64]),
+    'comic_jpeg_pool_submit_packed': (P, [P, P, c_int, P, P, P, C.c_int64]),
     'comic_jpeg_pool_wait': (c_int, [P, P, C.c_double, P, P]),
     'comic_jpeg_pool_enable_cache': (c_int, [P, C.c_int64]),
     'comic_jpeg_pool_cache_stats': (c_int, [P, P, P, P]),

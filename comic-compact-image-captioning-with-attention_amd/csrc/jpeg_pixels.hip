@@ -61,6 +61,35 @@ __device__ __forceinline__ void idct8(const int (&v)[8], int (&o)[8]) {
 
 __device__ __forceinline__ unsigned clamp_u8(int v) { return (unsigned)min(max(v, 0), 255); }
 
+// dequantisation + both passes + range limit of ONE block (64 int16 in raw, row-major) -> 8 rows of 8 bytes at dst
+__device__ __forceinline__ void idct_block(const uint4 (&raw)[8], const int* __restrict__ q, uint8_t* __restrict__ dst, const int stride) {
+  int ws[8][8];                                          // [row][column] after pass 1
+  // pass 1: columns of the dequantised block
+#pragma unroll
+  for (int col = 0; col < 8; ++col) {
+    int v[8], o[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const unsigned w = (&raw[r].x)[col >> 1];
+      const int cf = (int)(int16_t)(col & 1 ? (w >> 16) : (w & 0xffffu));
+      v[r] = cf * q[r * 8 + col];
+    }
+    idct8<kConstBits - kPass1Bits>(v, o);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ws[r][col] = o[r];
+  }
+  // pass 2: rows; + 128 and the range limit (0..255; the vector code of libjpeg-turbo saturates the same way)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    int o[8];
+    idct8<kConstBits + kPass1Bits + 3>(ws[r], o);
+    uint2 pk;
+    pk.x = clamp_u8(o[0] + 128) | (clamp_u8(o[1] + 128) << 8) | (clamp_u8(o[2] + 128) << 16) | (clamp_u8(o[3] + 128) << 24);
+    pk.y = clamp_u8(o[4] + 128) | (clamp_u8(o[5] + 128) << 8) | (clamp_u8(o[6] + 128) << 16) | (clamp_u8(o[7] + 128) << 24);
+    *(uint2*)(dst + (long)r * stride) = pk;
+  }
+}
+
 // grid (ceil(max blocks of an image / 256), n images)
 __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restrict__ coef, const comic_jpeg_info* __restrict__ infos,
                                                         uint8_t* __restrict__ planes) {
@@ -79,37 +108,59 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(const int16_t* __restric
   const int bw = in->blocks_w[c];
   const int by = (int)(gb / bw), bx = (int)(gb - (long)by * bw);
   const int16_t* src = coef + in->coef_base + (g << 6);
-  int ws[8][8];                                          // [row][column] after pass 1
   uint4 raw[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) raw[r] = *(const uint4*)(src + r * 8);
-  const int* q = quant[c];
-  // pass 1: columns of the dequantised block
+  idct_block(raw, quant[c], planes + in->coef_base + in->coef_off[c] + ((long)by * 8) * (bw * 8) + bx * 8, bw * 8);
+}
+
+// The same from the PACKED form of the loader's batches (comic_jpeg.h, comic_jpeg_pool_submit_packed): a thread expands its
+// block in LDS (32 words + 1 of padding per thread: the stride keeps the lanes of a wave on different banks), then runs the
+// transform above.  packed: 16-bit units; image i at infos[i].pixel_off, its planes at infos[i].coef_base.
+__global__ __launch_bounds__(256) void jpeg_idct_packed_kernel(const uint16_t* __restrict__ packed, const comic_jpeg_info* __restrict__ infos,
+                                                               uint8_t* __restrict__ planes) {
+  const comic_jpeg_info* in = infos + blockIdx.y;
+  __shared__ int quant[3][64];
+  __shared__ uint32_t blk[256][33];
+  if (in->ncomp == 0) return;
+  const int nc = in->ncomp;
+  if (threadIdx.x < 64 * nc) quant[threadIdx.x >> 6][threadIdx.x & 63] = in->quant[threadIdx.x >> 6][threadIdx.x & 63];
+  __syncthreads();
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = in->coef_count >> 6;
+  if (g >= total) return;
+  int c = 0;
+  if (nc == 3) c = g >= (in->coef_off[2] >> 6) ? 2 : (g >= (in->coef_off[1] >> 6) ? 1 : 0);
+  const long gb = g - (in->coef_off[c] >> 6);
+  const int bw = in->blocks_w[c];
+  const int by = (int)(gb / bw), bx = (int)(gb - (long)by * bw);
+  const uint16_t* img = packed + in->pixel_off;
+  const uint32_t d = ((const uint32_t*)img)[g];
+  const uint16_t* ent = img + 3 * total + (d >> 7);
+  const int n = (int)(d & 127);
+  uint32_t* mine = blk[threadIdx.x];
+  // (one access type for the LDS block: 16-bit stores through a second pointer type let the compiler move the 32-bit reads
+  // below across them)
+  auto put = [&](unsigned pos, unsigned v16) {
+    const unsigned sh = (pos & 1u) * 16u;
+    mine[pos >> 1] = (mine[pos >> 1] & ~(0xffffu << sh)) | ((v16 & 0xffffu) << sh);
+  };
 #pragma unroll
-  for (int col = 0; col < 8; ++col) {
-    int v[8], o[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const unsigned w = (&raw[r].x)[col >> 1];
-      const int cf = (int)(int16_t)(col & 1 ? (w >> 16) : (w & 0xffffu));
-      v[r] = cf * q[r * 8 + col];
+  for (int k = 0; k < 32; ++k) mine[k] = 0;
+  put(0, img[2 * total + g]);                            // DC
+  for (int j = 0; j < n; ++j) {
+    const unsigned e = ent[j];
+    const unsigned pos = e >> 10;
+    if (pos) put(pos, (unsigned)((int)(int16_t)(e << 6) >> 6));       // 10-bit value, sign-extended
+    else {
+      put(e & 63u, ent[j + 1]);
+      ++j;
     }
-    idct8<kConstBits - kPass1Bits>(v, o);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ws[r][col] = o[r];
   }
-  // pass 2: rows; + 128 and the range limit (0..255; the vector code of libjpeg-turbo saturates the same way)
-  const int stride = bw * 8;
-  uint8_t* dst = planes + in->coef_base + in->coef_off[c] + ((long)by * 8) * stride + bx * 8;
+  uint4 raw[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    int o[8];
-    idct8<kConstBits + kPass1Bits + 3>(ws[r], o);
-    uint2 pk;
-    pk.x = clamp_u8(o[0] + 128) | (clamp_u8(o[1] + 128) << 8) | (clamp_u8(o[2] + 128) << 16) | (clamp_u8(o[3] + 128) << 24);
-    pk.y = clamp_u8(o[4] + 128) | (clamp_u8(o[5] + 128) << 8) | (clamp_u8(o[6] + 128) << 16) | (clamp_u8(o[7] + 128) << 24);
-    *(uint2*)(dst + (long)r * stride) = pk;
-  }
+  for (int r = 0; r < 8; ++r) raw[r] = make_uint4(mine[4 * r], mine[4 * r + 1], mine[4 * r + 2], mine[4 * r + 3]);
+  idct_block(raw, quant[c], planes + in->coef_base + in->coef_off[c] + ((long)by * 8) * (bw * 8) + bx * 8, bw * 8);
 }
 
 // jdcolor.c build_ycc_rgb_table as arithmetic: FIX(x) = (int)(x * 65536 + 0.5)
@@ -284,6 +335,25 @@ extern "C" int comic_jpeg_preprocess(const int16_t* coef, const void* infos, int
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(cdiv(max_blocks, 256), n), dim3(256), 0, st, coef, (const comic_jpeg_info*)infos,
                        planes);
     COMIC_LAUNCH_CHECK("jpeg_idct");
+  }
+  hipLaunchKernelGGL(jpeg_preprocess_kernel, dim3(cdiv(out_h * out_w, 256), n), dim3(256), 0, st, (const comic_jpeg_info*)infos,
+                     planes, blob, (const ImgDesc*)desc, dst, out_h, out_w, resize);
+  COMIC_LAUNCH_CHECK("jpeg_preprocess");
+  return 0;
+}
+
+extern "C" int comic_jpeg_preprocess_packed(const uint16_t* packed, const void* infos, int n, int max_blocks, uint8_t* planes,
+                                            const uint8_t* blob, const void* desc, float* dst, int out_h, int out_w, int resize,
+                                            void* stream) {
+  COMIC_REQUIRE(packed && infos && planes && desc && dst, "jpeg_preprocess_packed: null pointer");
+  COMIC_REQUIRE(n > 0 && n <= 65535 && max_blocks >= 0 && out_h > 0 && out_w > 0 && resize >= out_h && resize >= out_w,
+                "jpeg_preprocess_packed: bad sizes");
+  COMIC_REQUIRE(((uintptr_t)packed & 3) == 0 && ((uintptr_t)planes & 7) == 0, "jpeg_preprocess_packed: blob alignment");
+  hipStream_t st = (hipStream_t)stream;
+  if (max_blocks > 0) {
+    hipLaunchKernelGGL(jpeg_idct_packed_kernel, dim3(cdiv(max_blocks, 256), n), dim3(256), 0, st, packed,
+                       (const comic_jpeg_info*)infos, planes);
+    COMIC_LAUNCH_CHECK("jpeg_idct_packed");
   }
   hipLaunchKernelGGL(jpeg_preprocess_kernel, dim3(cdiv(out_h * out_w, 256), n), dim3(256), 0, st, (const comic_jpeg_info*)infos,
                      planes, blob, (const ImgDesc*)desc, dst, out_h, out_w, resize);

@@ -228,8 +228,9 @@ class JpegSplitPool(object):
     """Split JPEG decode (config.loader_split_jpeg): host threads undo the entropy coding only, the device does the rest.
 
     A persistent pool of C threads (libcomic_jpeg.so, include/comic_jpeg.h: no interpreter work per image, no GPU runtime)
-    turns the files of a batch into quantised DCT coefficients, written back to back into a pinned staging slot (one
-    host-to-device copy per batch); inverse DCT,
+    turns the files of a batch into quantised DCT coefficients in PACKED form (a descriptor and the DC value per block, a
+    16-bit entry per non-zero AC coefficient: 3-4x fewer bytes than the dense blocks), written into a pinned staging slot
+    (one host-to-device copy per batch); inverse DCT,
     chroma upsampling and colour conversion run on the device in libjpeg's integer arithmetic (comic_jpeg_pixels), so the
     RGB bytes are PIL's.  Stands where the reference's tf.data map decodes on host cores
     (common/inputs/manager_image_caption.py:163-175).  Files the split decoder does not take (progressive, CMYK, ...) are
@@ -259,14 +260,14 @@ class JpegSplitPool(object):
         with self._lock:
             if not self._pool:
                 raise RuntimeError('the JPEG decode pool is closed')
-            h = self.lib.comic_jpeg_pool_submit(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, int(capacity))
+            h = self.lib.comic_jpeg_pool_submit_packed(self._pool, arr, len(paths), infos_ptr, status_ptr, coef_ptr, int(capacity))
         if not h:
             raise RuntimeError('comic_jpeg_pool_submit failed')
         return h
 
     def wait(self, handle, paths=()):
-        """-> (coefficient elements in use, bytes of the decoded images' RGB blob -- their pixel_off assigned).  Bounded like
-        DecodePool.geometry."""
+        """-> (16-bit units of the packed blob in use, bytes of the images' component planes back to back -- coef_base of the
+        images assigned).  Bounded like DecodePool.geometry."""
         import ctypes as C
         used, total = C.c_int64(0), C.c_int64(0)
         rc = self.lib.comic_jpeg_pool_wait(self._pool, handle, self.timeout_s, C.byref(used), C.byref(total))
@@ -440,7 +441,7 @@ class DevicePreprocessor(object):
         # files the split decoder does not take: PIL; their RGB bytes go to the blob the preprocessing kernel reads for images
         # with ncomp == 0 (the images decoded on the device are never written as RGB)
         late = []
-        pixel_bytes = 0
+        pixel_planes, pixel_bytes = pixel_bytes, 0           # (the wait's second figure: bytes of the component planes)
         for i in np.nonzero(~ok)[0]:
             im = decode_image(paths[i])
             infos['ncomp'][i] = 0
@@ -460,17 +461,19 @@ class DevicePreprocessor(object):
             st = L.stream_ptr()
             dev_infos = slot['infos'][:n * 512].to(self.device, non_blocking=True)
             if used > 0:
-                self._dev_coef[:used].copy_(slot['coef'][:used], non_blocking=True)      # the batch's ONE coefficient copy
+                self._dev_coef[:used].copy_(slot['coef'][:used], non_blocking=True)      # the batch's ONE (packed) coefficient copy
+            if pixel_planes > self._dev_planes.numel():
+                self._dev_planes = torch.empty(int(pixel_planes * 1.2), dtype=torch.uint8, device=self.device)
             for o, im in late:
                 self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.array(im, copy=True).reshape(-1)))
             dev_desc = torch.from_numpy(desc.view(np.uint8)).to(self.device)
             out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
-            # inverse DCT, then resize / flip / crop / scale with the taps converted from the component planes on the fly
-            L.check(self.lib.comic_jpeg_preprocess(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
-                                                   int(infos['coef_count'][ok].max()) // 64 if ok.any() else 0,
-                                                   self._dev_planes.data_ptr(), self._dev_blob.data_ptr() if late else None,
-                                                   dev_desc.data_ptr(),
-                                                   out.data_ptr(), self.h, self.w, self.resize, st), 'jpeg_preprocess')
+            # packed blocks -> inverse DCT, then resize / flip / crop / scale with the taps converted from the component planes
+            L.check(self.lib.comic_jpeg_preprocess_packed(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
+                                                          int(infos['coef_count'][ok].max()) // 64 if ok.any() else 0,
+                                                          self._dev_planes.data_ptr(), self._dev_blob.data_ptr() if late else None,
+                                                          dev_desc.data_ptr(), out.data_ptr(), self.h, self.w, self.resize, st),
+                    'jpeg_preprocess_packed')
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
         self._pending.append((('coef', slot), ev))

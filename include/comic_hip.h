@@ -205,6 +205,14 @@ int comic_jpeg_pixels(const int16_t* coef, const void* infos, int n, int max_blo
  * max_blocks 0: no image needs the inverse DCT. */
 int comic_jpeg_preprocess(const int16_t* coef, const void* infos, int n, int max_blocks, uint8_t* planes, const uint8_t* blob,
                           const void* desc, float* dst /* [n,out_h,out_w,3] */, int out_h, int out_w, int resize, void* stream);
+/* The same from the PACKED form of a batch (comic_jpeg.h, comic_jpeg_pool_submit_packed: per block a descriptor and the DC value,
+ * per non-zero AC coefficient a 16-bit entry -- 3-4x fewer bytes across the bus than the dense blocks): a thread expands its block
+ * in LDS in front of the inverse DCT.  `packed`: the batch's blob (device, 4-byte aligned, 16-bit units); image i at
+ * infos[i].pixel_off, its component planes at infos[i].coef_base of `planes` (as many bytes as the images' coef_count sum).
+ * Same results as comic_jpeg_preprocess on the dense coefficients, bit for bit. */
+int comic_jpeg_preprocess_packed(const uint16_t* packed, const void* infos, int n, int max_blocks, uint8_t* planes,
+                                 const uint8_t* blob, const void* desc, float* dst /* [n,out_h,out_w,3] */, int out_h, int out_w,
+                                 int resize, void* stream);
 
 /* ---- cnn_finetune: backward of the plan (train.py:241-249; model_base.py:76,834-849) ------
  * The CNN variables (conv weights, BN beta) become trainable; BN stays in inference mode, so a

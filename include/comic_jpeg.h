@@ -73,6 +73,20 @@ void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, in
  * 1: not done within timeout_s (the handle stays valid). */
 int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* coef_elems, int64_t* pixel_bytes);
 
+/* The loader's form: PACKED batches.  Image i is decoded to 16-bit units [desc: one uint32 per block][dc: one int16 per block]
+ * [entries]: desc[g] = (first entry << 7) | number of entries of block g (blocks in plane order: coef_off[c] / 64 + row *
+ * blocks_w[c] + column; first-entry indices count from the image's first entry), dc[g] = the block's DC coefficient, an entry =
+ * (natural position 1..63 << 10) | (value & 1023) for a non-zero AC coefficient within -512 .. 511, or the pair (position,
+ * value as int16) for a larger one.  3-4x fewer bytes than the dense blocks for the host's memory and the bus (0.28 instead of
+ * 0.92 MB for a detailed 640 x 480 image at quality 90), no clearing and no scattered stores on the host; the device entry point
+ * of comic_hip.h expands a block in LDS in front of its inverse DCT.  One pass per image; the images lie in `packed` (4-byte
+ * aligned) in the order their decodes end: infos[i].pixel_off = offset of image i (16-bit units, even), and after the wait
+ * infos[i].coef_base = offset of its component planes (samples) when the planes of the batch's images lie back to back.
+ * comic_jpeg_pool_wait returns the 16-bit units in use in *coef_elems and the samples of all planes in *pixel_bytes.  Images of
+ * more than 266 000 blocks are COMIC_JPEG_UNSUPPORTED. */
+void* comic_jpeg_pool_submit_packed(comic_jpeg_pool* pool, const char* const* paths, int n, comic_jpeg_info* infos,
+                                    int32_t* status, uint16_t* packed, int64_t capacity_u16);
+
 /* Coefficient cache of a pool (off by default): every image a batch has decoded is kept -- as its non-zero coefficients, about
  * the size of the JPEG file -- under its path until `max_bytes` are in use (nothing is evicted; call before the first submit, or
  * again to move the limit).  A later batch that names the path again gets the coefficients from memory: no file read, no Huffman

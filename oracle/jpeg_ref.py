@@ -117,6 +117,32 @@ def ycc_to_rgb(y, cb, cr):
     return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
 
 
+def unpack(packed, blocks):
+    """The packed form of a loader batch image (comic_jpeg_pool_submit_packed; 16-bit units: desc[blocks] as uint32 = (first entry
+    << 7) | count, dc[blocks] int16, then the entries: (position << 10) | (value & 1023), or the pair (position, int16 value))
+    -> dense int16 [blocks * 64] in natural order."""
+    pk = np.ascontiguousarray(packed, np.uint16)
+    desc = pk[:2 * blocks].view(np.uint32)
+    dcs = pk[2 * blocks:3 * blocks].view(np.int16)
+    ent = pk[3 * blocks:]
+    out = np.zeros(blocks * 64, np.int16)
+    out[0::64] = dcs
+    for b in range(blocks):
+        beg, n = int(desc[b] >> 7), int(desc[b] & 127)
+        j = 0
+        while j < n:
+            e = int(ent[beg + j])
+            pos = e >> 10
+            if pos:
+                v = e & 1023
+                out[b * 64 + pos] = v - 1024 if v >= 512 else v
+            else:
+                out[b * 64 + (e & 63)] = int(ent[beg + j + 1:beg + j + 2].view(np.int16)[0])
+                j += 1
+            j += 1
+    return out
+
+
 def pixels(info, coef):
     """comic_jpeg_info (any object with its fields) + the image's coefficients (int16, info.coef_count) -> uint8 [H, W, 3]."""
     if isinstance(info, np.void):                        # a record of a JPEG_INFO_DTYPE array

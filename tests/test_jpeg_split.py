@@ -219,6 +219,80 @@ def test_pool_decodes_queued_batches_back_to_back(tmp_path):
     assert (status == 0).all()
 
 
+def test_packed_batches_hold_the_coefficients_of_the_dense_decode(tmp_path):
+    """comic_jpeg_pool_submit_packed (the loader's form: a descriptor and the DC value per block, a 16-bit entry per non-zero AC coefficient) against the
+    dense decode of the same files; with the cache on, a second pass returns the same words."""
+    lib = L.load_jpeg()
+    paths, dense = [], {}
+    for i in range(8):
+        p = str(tmp_path / ('p%d.jpg' % i))
+        kw = dict(quality=55 + 6 * i, subsampling=i % 3)
+        if i == 5:
+            kw['restart_marker_blocks'] = 4
+        data = _encode(_photo(33 + 9 * i, 70 + 3 * i, seed=i) if i != 6 else _photo(50, 50, seed=6)[:, :, 0], **kw)
+        open(p, 'wb').write(data)
+        paths.append(p)
+        dense[p] = _split(data)
+    noisy = str(tmp_path / 'noisy.jpg')                    # full-swing stripes at quality 100: AC coefficients beyond +-511 (two-word entries)
+    stripes = np.zeros((40, 64), np.uint8)
+    stripes[:, 0::2] = 255
+    stripes[::3, :] = 255 - stripes[::3, :]
+    data = _encode(stripes, quality=100)
+    open(noisy, 'wb').write(data)
+    paths.append(noisy)
+    dense[noisy] = _split(data)
+    assert np.abs(dense[noisy][2].reshape(-1, 64)[:, 1:]).max() > 511
+    prog = str(tmp_path / 'prog.jpg')
+    open(prog, 'wb').write(_encode(_photo(40, 40), progressive=True))
+    order = paths[:3] + [prog, str(tmp_path / 'missing.jpg')] + paths[3:]
+    pool = lib.comic_jpeg_pool_create(3)
+    assert lib.comic_jpeg_pool_enable_cache(pool, 32 << 20) == 0
+    cap = 800_000
+    for rep in range(2):
+        n = len(order)
+        infos, status, blob = np.zeros(n, L.JPEG_INFO_DTYPE), np.full(n, 99, np.int32), np.full(cap, 0xdead, np.uint16)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in order])
+        h = lib.comic_jpeg_pool_submit_packed(pool, arr, n, infos.ctypes.data, status.ctypes.data, blob.ctypes.data, cap)
+        used, planes = C.c_int64(), C.c_int64()
+        assert h and lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(used), C.byref(planes)) == 0
+        spans, base = [], 0
+        for i, p in enumerate(order):
+            if p == prog:
+                assert status[i] == L.JPEG_UNSUPPORTED
+                continue
+            if p.endswith('missing.jpg'):
+                assert status[i] == L.JPEG_IO
+                continue
+            rc, dinfo, dcoef = dense[p]
+            assert status[i] == 0 and infos['coef_count'][i] == dinfo.coef_count and infos['coef_base'][i] == base
+            base += int(dinfo.coef_count)
+            blocks = int(dinfo.coef_count) // 64
+            off = int(infos['pixel_off'][i])
+            ac = dcoef.reshape(-1, 64)[:, 1:]
+            n16 = 3 * blocks + int(np.count_nonzero(ac)) + int(np.count_nonzero((ac < -512) | (ac > 511)))
+            n16 += n16 & 1
+            assert off % 2 == 0
+            img = blob[off:off + n16]
+            assert np.array_equal(jpeg_ref.unpack(img, blocks), dcoef), p
+            spans.append((off, off + n16))
+        spans.sort()
+        assert spans[0][0] == 0 and all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == used.value
+        assert planes.value == base
+    b, e, hits = C.c_int64(), C.c_int64(), C.c_int64()
+    lib.comic_jpeg_pool_cache_stats(pool, C.byref(b), C.byref(e), C.byref(hits))
+    assert e.value == 9 and hits.value == 9
+    # a blob with room for some of the images only: the others are reported, nothing is written past the end
+    n = len(paths)
+    small = 6000
+    infos, status, blob = np.zeros(n, L.JPEG_INFO_DTYPE), np.full(n, 99, np.int32), np.full(small + 64, 0xdead, np.uint16)
+    arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    h = lib.comic_jpeg_pool_submit_packed(pool, arr, n, infos.ctypes.data, status.ctypes.data, blob.ctypes.data, small)
+    used, planes = C.c_int64(), C.c_int64()
+    assert lib.comic_jpeg_pool_wait(pool, h, 60.0, C.byref(used), C.byref(planes)) == 0
+    assert set(status.tolist()) == {0, L.JPEG_TOO_SMALL} and used.value <= small and (blob[small:] == 0xdead).all()
+    lib.comic_jpeg_pool_destroy(pool)
+
+
 def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
     """comic_jpeg_pool_enable_cache: the batches of a second pass over the files come from the cache (hits counted, files may
     even be gone) with the coefficients of the first pass, bit for bit; the byte limit stops insertion, nothing is evicted."""

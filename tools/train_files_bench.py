@@ -44,11 +44,23 @@ for mode in modes:
             for _ in range(WARM if mode != 'threads' else 25):
                 m.run_train_step()
             torch.cuda.synchronize()
+            acc = {'finish': 0.0, 'n': 0}
+            if os.environ.get('PROFILE') == '1':          # host time of the loader's consumer half, per batch
+                inner = man._devpre.finish
+
+                def timed(packed):
+                    a = time.perf_counter(); r = inner(packed); acc['finish'] += time.perf_counter() - a; acc['n'] += 1
+                    return r
+                man._devpre.finish = timed
             t0 = time.time()
             for _ in range(steps):
                 loss = m.run_train_step()
+            t_issue = time.time() - t0
             torch.cuda.synchronize()
             dt = time.time() - t0
+            if acc['n']:
+                print('  host: %.3f ms per step to issue (of which %.3f ms in DevicePreprocessor.finish), %.3f ms per step in all'
+                      % (t_issue / steps * 1e3, acc['finish'] / max(acc['n'], 1) * 1e3, dt / steps * 1e3), flush=True)
             print('loader %-9s : %7.0f images/s  (%.2f ms per step of 64 images, loss %.4f)'
                   % (mode, steps * 64 / dt, dt / steps * 1e3, float(loss)), flush=True)
         finally:
