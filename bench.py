@@ -560,8 +560,9 @@ def input_pipeline_rate(device, n_files=128, threads=16):
         jpool.close()
         return {'images_per_sec': round(n / dt, 1), 'host_threads': threads, 'bit_identical_to_pil_path': same,
                 'files': '%d x 640x480 JPEG, quality 90, 4:2:0 (camera photographs re-encoded), %.0f KB on average' % (n_files, kb),
-                'path': 'libcomic_jpeg.so (Huffman decoding, C threads) -> comic_jpeg_preprocess (inverse DCT, then resize / crop / '
-                        'scale with the taps upsampled and colour-converted from the component planes)'}
+                'path': 'libcomic_jpeg.so (Huffman decoding on C threads into packed non-zero coefficients) -> '
+                        'comic_jpeg_preprocess_packed (blocks expanded in LDS, inverse DCT, then resize / crop / scale with the '
+                        'taps upsampled and colour-converted from the component planes)'}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
