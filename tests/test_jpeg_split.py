@@ -400,6 +400,22 @@ def test_device_pixels_are_pils_pixels(tmp_path):
         assert np.array_equal(img, want), (p, np.argwhere(img != want)[:4])
         # and the oracle agrees with both
         assert np.array_equal(jpeg_ref.pixels(infos[i], coef.numpy()[i * slot:i * slot + int(infos['coef_count'][i])]), want)
+    # comic_jpeg_preprocess (dense blocks -> network input, the RGB image never written) == comic_image_preprocess on the RGB blob
+    from comic_amd import inputs
+    desc = np.zeros(n, inputs.DevicePreprocessor._DESC_DTYPE)
+    desc['offset'], desc['in_h'], desc['in_w'] = infos['pixel_off'], infos['height'], infos['width']
+    desc['flip'], desc['oy'], desc['ox'] = np.arange(n) % 2, (np.arange(n) * 7) % 33, (np.arange(n) * 5) % 33
+    desc['sy'] = (infos['height'] / 256).astype(np.float32)
+    desc['sx'] = (infos['width'] / 256).astype(np.float32)
+    dev_desc = torch.from_numpy(desc.view(np.uint8)).cuda()
+    a = torch.empty((n, 224, 224, 3), dtype=torch.float32, device='cuda')
+    b = torch.empty_like(a)
+    L.check(lib.comic_image_preprocess(pixels.data_ptr(), dev_desc.data_ptr(), n, a.data_ptr(), 224, 224, 256, L.stream_ptr()), 'pre')
+    planes.zero_()
+    L.check(lib.comic_jpeg_preprocess(dev_coef.data_ptr(), dev_infos.data_ptr(), n, int(infos['coef_count'].max()) // 64,
+                                      planes.data_ptr(), None, dev_desc.data_ptr(), b.data_ptr(), 224, 224, 256, L.stream_ptr()),
+            'jpeg_preprocess')
+    assert torch.equal(a, b)
 
 
 @pytest.mark.gpu
