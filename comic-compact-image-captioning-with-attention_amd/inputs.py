@@ -385,6 +385,7 @@ class DevicePreprocessor(object):
         for _ in range(int(slots)):
             self._free_coef.put(dict(coef=torch.empty(n * jpool.slot_elems, dtype=torch.int16).pin_memory(),
                                      infos=torch.zeros(n * 512, dtype=torch.uint8).pin_memory(),
+                                     desc=torch.zeros(n * 40, dtype=torch.uint8).pin_memory(),
                                      status=np.zeros(n, np.int32)))
         with torch.cuda.device(self.device):
             self._dev_coef = torch.empty(n * jpool.slot_elems, dtype=torch.int16, device=self.device)
@@ -421,7 +422,8 @@ class DevicePreprocessor(object):
             # threads of this batch may still write into the slot: it is retired with the batch, a fresh one takes its place
             self.__dict__.setdefault('_retired_coef', []).append(slot)
             self._free_coef.put(dict(coef=torch.empty_like(slot['coef']).pin_memory(),
-                                     infos=torch.zeros_like(slot['infos']).pin_memory(), status=np.zeros_like(slot['status'])))
+                                     infos=torch.zeros_like(slot['infos']).pin_memory(),
+                                     desc=torch.zeros_like(slot['desc']).pin_memory(), status=np.zeros_like(slot['status'])))
             raise
         try:
             return self._launch_split(packed, used, pixel_bytes)
@@ -448,7 +450,7 @@ class DevicePreprocessor(object):
             h[i], w[i], off[i] = im.shape[0], im.shape[1], pixel_bytes
             late.append((int(pixel_bytes), im))
             pixel_bytes += (im.size + 15) // 16 * 16
-        desc = np.zeros(n, self._DESC_DTYPE)
+        desc = slot['desc'].numpy()[:n * 40].view(self._DESC_DTYPE)      # pinned: every copy of the batch is asynchronous
         desc['offset'], desc['in_h'], desc['in_w'] = off, h, w
         desc['flip'] = [int(bool(p[0])) for p in params]
         desc['oy'] = [int(p[1]) for p in params]
@@ -466,7 +468,7 @@ class DevicePreprocessor(object):
                 self._dev_planes = torch.empty(int(pixel_planes * 1.2), dtype=torch.uint8, device=self.device)
             for o, im in late:
                 self._dev_blob[o:o + im.size].copy_(torch.from_numpy(np.array(im, copy=True).reshape(-1)))
-            dev_desc = torch.from_numpy(desc.view(np.uint8)).to(self.device)
+            dev_desc = slot['desc'][:n * 40].to(self.device, non_blocking=True)
             out = torch.empty((n, self.h, self.w, 3), dtype=torch.float32, device=self.device)
             # packed blocks -> inverse DCT, then resize / flip / crop / scale with the taps converted from the component planes
             L.check(self.lib.comic_jpeg_preprocess_packed(self._dev_coef.data_ptr(), dev_infos.data_ptr(), n,
