@@ -429,6 +429,10 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     prog = str(tmp_path / 'prog.jpg')
     open(prog, 'wb').write(_encode(_photo(300, 400), progressive=True, quality=85))
     paths.insert(3, prog)
+    from PIL import Image
+    png = str(tmp_path / 'lossless.png')                   # not a JPEG at all: PIL path too
+    Image.fromarray(_photo(120, 90, seed=9)).save(png)
+    paths.append(png)
     pre = inputs.DevicePreprocessor('cuda:0', 224, 224)
     jpool = inputs.JpegSplitPool(4, slot_elems=200000, max_batch=16)       # room for about half of the files: the rest -> PIL
     pre.enable_split(jpool, 3)
@@ -441,7 +445,13 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     torch.cuda.synchronize()
     pre._reap()
     assert pre._free_coef.qsize() == 3                     # every staging slot came back
+    # a file that does not exist: the error of the PIL path reaches the consumer, the slot comes back
+    with pytest.raises(FileNotFoundError):
+        pre.finish(pre.pack_paths_split(paths[:2] + [str(tmp_path / 'missing.jpg')], params[:3]))
+    assert pre._free_coef.qsize() == 3
     jpool.close()
+    with pytest.raises(RuntimeError, match='closed'):
+        pre.pack_paths_split(paths[:2], params[:2])
 
 
 @pytest.mark.gpu
