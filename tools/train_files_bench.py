@@ -52,10 +52,19 @@ for mode in modes:
                     a = time.perf_counter(); r = inner(packed); acc['finish'] += time.perf_counter() - a; acc['n'] += 1
                     return r
                 man._devpre.finish = timed
+            prof = None
+            if os.environ.get('CPROFILE') == '1':
+                import cProfile
+                prof = cProfile.Profile()
+                prof.enable()
             t0 = time.time()
             for _ in range(steps):
                 loss = m.run_train_step()
             t_issue = time.time() - t0
+            if prof is not None:
+                import pstats
+                prof.disable()
+                pstats.Stats(prof).sort_stats('tottime').print_stats(22)
             torch.cuda.synchronize()
             dt = time.time() - t0
             if acc['n']:
