@@ -21,6 +21,20 @@ photos = [Image.open(os.path.join(sd, f)).convert('RGB') for f in ('china.jpg', 
 for i in range(N):
     im = photos[i % 2].crop((i % 40, i % 27, 600 + i % 40, 400 + i % 27)).resize((640, 480), Image.BICUBIC)
     im.save(os.path.join(ds, 'images', 'COCO_train2014_%012d.jpg' % (i + 1)), quality=90, subsampling=2)
+# captions of MS-COCO length (8 .. 14 words: 18 .. 30 radix tokens, the synthetic bench's distribution) instead of the tiny data
+# set's 4 .. 8 words: the decoder step costs what it costs in bench.py
+if os.environ.get('CAPTIONS', 'coco') == 'coco':
+    rng = np.random.default_rng(1)
+    words = ['a', 'man', 'dog', 'cat', 'on', 'the', 'table', 'sitting', 'red', 'bench', 'with', 'frisbee', 'park', 'two', 'people',
+             'standing', 'near', 'train', 'street', 'sign']
+    fp = os.path.join(ds, 'captions', 'mscoco_{}_w5_s20_include_restval'.format('train') + '.txt')
+    lines = []
+    for i in range(N):
+        rel = os.path.join('images', 'COCO_train2014_%012d.jpg' % (i + 1))
+        for _ in range(5):
+            lines.append('%s,<GO> %s <EOS>' % (rel, ' '.join(rng.choice(words, int(rng.integers(8, 15))))))
+    with open(fp, 'w', newline='') as f:
+        f.write('\r\n'.join(lines))
 spec = importlib.util.spec_from_file_location('cli_train_bench', os.path.join(ROOT, 'src', 'train.py'))
 cli = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(cli)
