@@ -37,8 +37,11 @@ typedef struct comic_jpeg_info {
   int32_t comp_w[3], comp_h[3];       /* libjpeg's downsampled_width / _height: the real samples of each component */
   int64_t coef_off[3];          /* first coefficient of each component plane, in int16 elements from the image's base */
   int64_t coef_count;           /* int16 elements of the image: sum of blocks_w * blocks_h * 64 */
-  int64_t coef_base;            /* filled by the caller: element offset of this image in the batch's coefficient blob */
-  int64_t pixel_off;            /* filled by the caller: byte offset of the RGB image in the batch's pixel blob */
+  int64_t coef_base;            /* offset of this image in the batch: of its dense coefficients (int16 elements) == of its
+                                 * component planes (samples); dense batches: filled by the pool / the caller; packed batches:
+                                 * filled by comic_jpeg_pool_wait */
+  int64_t pixel_off;            /* dense batches: byte offset of the image's RGB pixels in the batch's pixel blob (comic_jpeg_pixels);
+                                 * packed batches: offset of the image's packed coefficients in the blob (16-bit units) */
   uint16_t quant[3][64];        /* quantisation table of each component, natural (row-major) order */
 } comic_jpeg_info;
 
