@@ -559,6 +559,33 @@ def test_cli_accepts_every_option_of_the_reference(tmp_path):
     assert kw['legacy'] and kw['cnn_name'] == 'inception_v1' and kw['adam_epsilon'] == 1e-6
 
 
+def test_loader_flags_and_descriptor_layout(tmp_path):
+    """The loader's additions to the CLIs reach the config, and the numpy view of comic_image_desc that the split JPEG loader
+    fills vectorised has the ctypes structure's layout."""
+    import ctypes as C
+    import importlib.util
+    from comic_amd import inputs
+    spec = importlib.util.spec_from_file_location('train_cli3', os.path.join(ROOT, 'src', 'train.py'))
+    train = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(train)
+    kw, _, _ = train.build_kwargs(train.create_parser().parse_args(
+        ['--log_root', str(tmp_path), '--loader_split_jpeg', '--loader_threads', '4', '--loader_cache_gb', '2.5']))
+    assert kw['loader_split_jpeg'] is True and kw['loader_threads'] == 4 and kw['loader_cache_gb'] == 2.5
+    kw, _, _ = train.build_kwargs(train.create_parser().parse_args(['--log_root', str(tmp_path)]))
+    assert kw['loader_split_jpeg'] is False and kw['loader_cache_gb'] == 0.0
+    spec = importlib.util.spec_from_file_location('infer_cli3', os.path.join(ROOT, 'src', 'infer.py'))
+    infer = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(infer)
+    a = infer.create_parser().parse_args(['--loader_split_jpeg', '--loader_threads', '3'])
+    assert a.loader_split_jpeg is True and a.loader_threads == 3 and a.loader_cache_gb is None
+    assert infer.create_parser().parse_args([]).loader_split_jpeg is None          # the training run's choice applies
+    dt = inputs.DevicePreprocessor._DESC_DTYPE
+    assert dt.itemsize == C.sizeof(L.ImageDesc) == 40
+    for name, _ in L.ImageDesc._fields_:
+        assert dt.fields[name][1] == getattr(L.ImageDesc, name).offset, name
+        assert dt.fields[name][0].itemsize == getattr(L.ImageDesc, name).size, name
+
+
 def test_data_parallel_shards_are_disjoint_and_cover_the_epoch(tmp_path):
     """Input managers under data parallelism: a common shuffle, rank r takes items r, r+W, ..; max_step counts global
     batches; same rand_seed (= same parameter initialisation) on every rank."""
