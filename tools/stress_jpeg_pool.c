@@ -22,7 +22,9 @@ int main(int argc, char** argv) {
       infos[b] = calloc(n, sizeof(comic_jpeg_info)); status[b] = calloc(n, sizeof(int32_t)); coef[b] = malloc(cap * 2);
       const char* paths[64];
       for (int i = 0; i < n; ++i) paths[i] = argv[1 + (i + b + round) % n];
-      h[b] = comic_jpeg_pool_submit(pool, paths, n, infos[b], status[b], coef[b], (b % 3 == 2) ? 200000 : cap);
+      // even batches dense, odd ones packed (the loader's form); every third one too small for all of its images
+      h[b] = (b & 1) ? comic_jpeg_pool_submit_packed(pool, paths, n, infos[b], status[b], (uint16_t*)coef[b], (b % 3 == 2) ? 60000 : cap)
+                     : comic_jpeg_pool_submit(pool, paths, n, infos[b], status[b], coef[b], (b % 3 == 2) ? 200000 : cap);
       if (!h[b]) { printf("submit failed\n"); return 1; }
     }
     for (int b = B - 1; b >= 0; --b) {        // waits in reverse order
