@@ -249,6 +249,7 @@ class JpegSplitPool(object):
         if not self._pool:
             raise RuntimeError('comic_jpeg_pool_create(%d) failed' % self.threads)
         self._lock = threading.Lock()              # submit() of a loader thread against close() of the main thread
+        self.closing = False                       # set at the start of a stage's shutdown: loader threads parked on staging leave
         # config.loader_cache_gb: the decoded coefficients of every image stay in host memory (as their non-zeros: about the
         # size of the file) up to this many GB -- the epochs after the first skip file reads and Huffman decoding
         if cache_gb and cache_gb > 0:
@@ -406,7 +407,7 @@ class DevicePreprocessor(object):
                 slot = self._free_coef.get(timeout=0.05)
                 break
             except queue.Empty:
-                if jpool.closed:
+                if jpool.closed or jpool.closing:
                     raise RuntimeError('the JPEG decode pool is closed')
                 if time.monotonic() > t_end:
                     raise RuntimeError('no coefficient staging slot came back within %.0f s (consumer stalled?)' % jpool.timeout_s)
@@ -647,6 +648,8 @@ class InputManager(object):
 
     def close(self):
         """End of a train / eval / inference stage: stop the prefetch threads and the decode pool."""
+        if getattr(self, '_jpeg_pool', None) is not None:
+            self._jpeg_pool.closing = True            # (a producer waiting for a staging slot would sit out the join below)
         for name in ('batch_train', 'batch_eval', 'batch_infer'):
             it = getattr(self, name, None)
             if isinstance(it, Prefetch):
@@ -777,12 +780,15 @@ class InputManager(object):
     def enable_device_preprocess(self, device='cuda:0'):
         """From the next batch on: the host only decodes (thread pool), resize / flip / crop / scale run on `device`
         and the batches carry device tensors (bit-identical values; `CaptionModel` takes either)."""
-        if not str(device).startswith('cuda'):
-            return
+        if not str(device).startswith('cuda') or getattr(self, '_devpre', None) is not None:
+            return                                   # (a second call: the loader of this manager is set up)
         h, w = self.config.cnn_input_size
         self._devpre = DevicePreprocessor(device, h, w)
         c = self.config
-        if getattr(c, 'loader_split_jpeg', False) and getattr(self, '_jpeg_pool', None) is None:
+        # the split JPEG decoder is the default loader; --loader_processes N (an explicit request) or --no-loader_split_jpeg
+        # select the PIL loaders
+        if (getattr(c, 'loader_split_jpeg', True) and not int(getattr(c, 'loader_processes', 0) or 0)
+                and getattr(self, '_jpeg_pool', None) is None):
             self._jpeg_pool = JpegSplitPool(int(getattr(c, 'loader_threads', 0)) or min(16, os.cpu_count() or 3),
                                             slot_elems=int(getattr(c, 'loader_slot_bytes', 640 * 640 * 3)) // 2,
                                             max_batch=max(c.batch_size_train, getattr(c, 'batch_size_eval', 1),

@@ -32,7 +32,7 @@ def create_parser():
     a('--infer_max_length', type=int, default=30, help='The maximum caption length allowed during inference.')
     a('--batch_size_infer', type=int, default=25, help='The batch size.')
     # additions of this framework (the training run's choices apply when left out)
-    a('--loader_split_jpeg', action='store_true', default=None,
+    a('--loader_split_jpeg', action=argparse.BooleanOptionalAction, default=None,
       help='Split JPEG decode: C threads undo the entropy coding, the device does the pixels (bit-identical to PIL).')
     a('--loader_threads', type=int, default=None, help='Decode threads of the loader.')
     a('--loader_cache_gb', type=float, default=None, help='Coefficient cache of the split JPEG decoder, GB.')

@@ -80,9 +80,10 @@ def create_parser():
            'second stream under the decoder steps). 0 = auto (about 1280 images per forward), 1 = one forward per step.')
     a('--loader_processes', type=int, default=0,
       help='JPEG decode in this many worker processes (shared-memory staging); 0 = decode threads in this process.')
-    a('--loader_split_jpeg', action='store_true',
-      help='Split JPEG decode: `loader_threads` C threads undo the entropy coding, the device does inverse DCT / upsampling / '
-           'colour conversion (bit-identical to PIL); files it does not take (progressive, CMYK) go through PIL.')
+    a('--loader_split_jpeg', action=argparse.BooleanOptionalAction, default=True,
+      help='Split JPEG decode (default): `loader_threads` C threads undo the entropy coding, the device does inverse DCT / '
+           'upsampling / colour conversion (bit-identical to PIL); files it does not take (progressive, CMYK, PNG) go through PIL.  '
+           '--no-loader_split_jpeg: PIL decode on threads / --loader_processes.')
     a('--loader_threads', type=int, default=0, help='Decode threads of the loader (0 = min(16, cores)).')
     a('--loader_cache_gb', type=float, default=0.0,
       help='With --loader_split_jpeg: keep the decoded DCT coefficients of the images in host memory (as their non-zeros: about the '

@@ -104,7 +104,7 @@ def test_train_infer_cli_default_backbone(tmp_path):
     logs = str(tmp_path / 'experiments')
     _run(os.path.join(ROOT, 'src', 'train.py'), ['--dataset_dir', ds, '--log_root', logs, '--batch_size_eval', '4',
                                                  '--rnn_size', '128', '--rnn_word_size', '64', '--train_mode', 'decoder',
-                                                 '--batch_size_train', '4', '--max_epoch', '1'])
+                                                 '--batch_size_train', '4', '--max_epoch', '1', '--no-loader_split_jpeg'])
     errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
     assert not errs, open(errs[0]).read()
     run_dir = os.path.join(logs, 'mscoco', 'radix_b256_add_LN_softmax_h8_tie_lstm_run_01')
@@ -117,7 +117,7 @@ def test_train_infer_cli_default_backbone(tmp_path):
     assert z['Model/decoder/rnn_decoder/memory_layer/kernel'].shape[0] == 832     # attention over Mixed_4f
     _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
                                                  '--infer_set', 'test', '--batch_size_infer', '4',
-                                                 '--get_metric_score', ''])
+                                                 '--get_metric_score', '', '--no-loader_split_jpeg'])
     caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
     assert caps and len(json.load(open(caps[0]))) == 4
     # --loader_split_jpeg (Huffman decoding on C threads, the pixels on the device): the same captions, and a training run

@@ -572,7 +572,9 @@ def test_loader_flags_and_descriptor_layout(tmp_path):
         ['--log_root', str(tmp_path), '--loader_split_jpeg', '--loader_threads', '4', '--loader_cache_gb', '2.5']))
     assert kw['loader_split_jpeg'] is True and kw['loader_threads'] == 4 and kw['loader_cache_gb'] == 2.5
     kw, _, _ = train.build_kwargs(train.create_parser().parse_args(['--log_root', str(tmp_path)]))
-    assert kw['loader_split_jpeg'] is False and kw['loader_cache_gb'] == 0.0
+    assert kw['loader_split_jpeg'] is True and kw['loader_cache_gb'] == 0.0           # the split decoder is the default loader
+    kw, _, _ = train.build_kwargs(train.create_parser().parse_args(['--log_root', str(tmp_path), '--no-loader_split_jpeg']))
+    assert kw['loader_split_jpeg'] is False
     spec = importlib.util.spec_from_file_location('infer_cli3', os.path.join(ROOT, 'src', 'infer.py'))
     infer = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(infer)

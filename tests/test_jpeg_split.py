@@ -457,7 +457,7 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
 @pytest.mark.gpu
 def test_input_manager_with_split_decode_yields_the_batches_of_the_thread_decode(tmp_path):
     """config.loader_split_jpeg (train.py / infer.py --loader_split_jpeg): the managers' batches -- images on the device,
-    captions -- are the ones of the default loader (PIL decode threads + device preprocessing), bit for bit."""
+    captions -- are the ones of the PIL loader (decode threads + device preprocessing, --no-loader_split_jpeg), bit for bit."""
     import torch
     from tests import tiny_dataset
     from comic_amd import inputs, configuration as conf
@@ -466,7 +466,7 @@ def test_input_manager_with_split_decode_yields_the_batches_of_the_thread_decode
               cnn_input_size=[224, 224], cnn_input_augment=True, batch_size_train=8, batch_size_eval=2, max_epoch=3,
               rand_seed=7, token_type='radix', radix_base=256, loader_threads=4)
     a = inputs.InputManager_Radix(conf.Config(loader_split_jpeg=True, **kw))
-    b = inputs.InputManager_Radix(conf.Config(**kw))
+    b = inputs.InputManager_Radix(conf.Config(loader_split_jpeg=False, **kw))
     try:
         a.enable_device_preprocess('cuda:0')
         b.enable_device_preprocess('cuda:0')

@@ -41,9 +41,9 @@ spec.loader.exec_module(cli)
 STEPS, WARM = int(os.environ.get('STEPS', '120')), int(os.environ.get('WARM', '60'))
 modes = [m for m in os.environ.get('MODES', 'split,processes,threads').split(',') if m]
 for mode in modes:
-    extra = {'split': ['--loader_split_jpeg', '--loader_threads', '16'], 'processes': ['--loader_processes', '16'],
+    extra = {'split': ['--loader_split_jpeg', '--loader_threads', '16'], 'processes': ['--no-loader_split_jpeg', '--loader_processes', '16'],
              'cache': ['--loader_split_jpeg', '--loader_threads', '16', '--loader_cache_gb', '4'],
-             'threads': ['--loader_threads', '16']}[mode]
+             'threads': ['--no-loader_split_jpeg', '--loader_threads', '16']}[mode]
     args = cli.create_parser().parse_args(['--dataset_dir', ds, '--log_root', os.path.join(tmp, 'exp_' + mode), '--train_mode',
                                            'decoder', '--batch_size_train', '64', '--batch_size_eval', '64', '--max_epoch', '50'] + extra)
     kwargs, _, overwrite = cli.build_kwargs(args)
