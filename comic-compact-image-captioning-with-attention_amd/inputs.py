@@ -413,12 +413,22 @@ class DevicePreprocessor(object):
                     raise RuntimeError('no coefficient staging slot came back within %.0f s (consumer stalled?)' % jpool.timeout_s)
         handle = jpool.submit(paths, slot['infos'].data_ptr(), slot['status'].ctypes.data, slot['coef'].data_ptr(),
                               slot['coef'].numel())
-        return PackedImages(('split', jpool, handle, slot, list(paths), list(params)), None, None, len(paths), 0)
+        # files known (from an earlier batch) to need the PIL path start decoding now, on a few threads of their own, so that
+        # the consumer finds their pixels ready instead of decoding them inside its step
+        known = self.__dict__.setdefault('_pil_known', set())
+        early = {i: self._pil_threads().submit(decode_image, p) for i, p in enumerate(paths) if p in known} if known else {}
+        return PackedImages(('split', jpool, handle, slot, list(paths), list(params), early), None, None, len(paths), 0)
+
+    def _pil_threads(self):
+        pool = self.__dict__.get('_pil_pool')
+        if pool is None:
+            pool = self._pil_pool = ThreadPoolExecutor(max_workers=4)
+        return pool
 
     def _finish_split(self, packed):
         import ctypes as C
         torch, L = self.torch, self.L
-        _, jpool, handle, slot, paths, params = packed.slot
+        _, jpool, handle, slot, paths, params = packed.slot[:6]
         n = packed.n
         try:
             used, pixel_bytes = jpool.wait(handle, paths)
@@ -437,7 +447,8 @@ class DevicePreprocessor(object):
 
     def _launch_split(self, packed, used, pixel_bytes):
         torch, L = self.torch, self.L
-        _, jpool, handle, slot, paths, params = packed.slot
+        _, jpool, handle, slot, paths, params = packed.slot[:6]
+        early = packed.slot[6] if len(packed.slot) > 6 else {}
         n = packed.n
         status = slot['status'][:n]
         infos = slot['infos'].numpy()[:n * 512].view(L.JPEG_INFO_DTYPE)
@@ -448,8 +459,14 @@ class DevicePreprocessor(object):
         # with ncomp == 0 (the images decoded on the device are never written as RGB)
         late = []
         pixel_planes, pixel_bytes = pixel_bytes, 0           # (the wait's second figure: bytes of the component planes)
-        for i in np.nonzero(~ok)[0]:
-            im = decode_image(paths[i])
+        bad = [int(i) for i in np.nonzero(~ok)[0]]
+        known = self.__dict__.setdefault('_pil_known', set())
+        fresh = [i for i in bad if i not in early]
+        if fresh:                                # first sight of these files: decode them side by side, remember the paths
+            decoded = dict(zip(fresh, self._pil_threads().map(decode_image, [paths[i] for i in fresh])))
+            known.update(paths[i] for i in fresh if isinstance(paths[i], str) and len(known) < 1_000_000)
+        for i in bad:
+            im = early[i].result() if i in early else decoded[i]
             infos['ncomp'][i] = 0
             h[i], w[i], off[i] = im.shape[0], im.shape[1], pixel_bytes
             late.append((int(pixel_bytes), im))
@@ -663,6 +680,9 @@ class InputManager(object):
         if getattr(self, '_jpeg_pool', None) is not None:
             self._jpeg_pool.close()
             self._jpeg_pool = None
+        pil = getattr(getattr(self, '_devpre', None), '_pil_pool', None)
+        if pil is not None:
+            pil.shutdown(wait=False)
 
     def _setup(self, config, is_inference):
         config.split_sizes = {}

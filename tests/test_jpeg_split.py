@@ -445,6 +445,13 @@ def test_split_loader_batches_are_bit_identical_to_the_thread_decode(tmp_path):
     torch.cuda.synchronize()
     pre._reap()
     assert pre._free_coef.qsize() == 3                     # every staging slot came back
+    # files of the PIL path are remembered: later batches start their decode at pack time (same tensors)
+    assert prog in pre._pil_known and png in pre._pil_known
+    packed = pre.pack_paths_split(paths, params)
+    assert sorted(packed.slot[6]) == sorted(paths.index(p) for p in pre._pil_known if p in paths)
+    assert torch.equal(pre.finish(packed).cpu(), ref)
+    torch.cuda.synchronize()
+    pre._reap()
     # a file that does not exist: the error of the PIL path reaches the consumer, the slot comes back
     with pytest.raises(FileNotFoundError):
         pre.finish(pre.pack_paths_split(paths[:2] + [str(tmp_path / 'missing.jpg')], params[:3]))
