@@ -658,6 +658,22 @@ def pick_encoder_group(steps):
     return 1 if steps <= 1 else DEFAULT_ENC_GROUP
 
 
+def launch_ranks(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>` as a child process; returns its exit code.  The port is one the kernel has just handed out."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -667,14 +683,18 @@ def main():
     ap.add_argument('--no-extras', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (no torch import,
+        # no HIP call), starts one rank per GPU as a CHILD process group (never an exec) and leaves with the child's code;
+        # rank 0's JSON line goes straight to the inherited stdout.
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     # COMIC_DIST_BACKEND=gloo: rehearsal of the N > 1 path on fewer GPUs than ranks (gloo moves CUDA tensors through the
     # host; ranks share the visible devices round-robin).  The driver's scaling runs use the default: nccl = RCCL.
     backend = os.environ.get('COMIC_DIST_BACKEND', 'nccl')
@@ -955,6 +975,22 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         else:
             out['cpu_baseline'] = None
+        # compact digest of the secondary configurations as the LAST key, so that a reader who only keeps the tail of the
+        # line (the driver's record does) still sees them
+        ex = out.get('extras') or {}
+        def _g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        out['summary'] = {'images_per_sec': out['value'], 'ms_per_step': out['ms_per_step'], 'cnn_frac': out['roofline']['frac'],
+                          'frac_at_batch64': out['roofline'].get('frac_at_batch64'), 'decoder_ms': out['decoder_roofline']['ms_per_step'],
+                          'beam3': ex.get('beam3_captions_per_sec'), 'beam3_frac': _g(ex, 'beam3_roofline', 'frac'),
+                          'scst': ex.get('scst_images_per_sec'), 'cnn_finetune': ex.get('cnn_finetune_images_per_sec'),
+                          'cnn_finetune_frac': ex.get('cnn_finetune_conv_mfma_frac'),
+                          'xe_x3': _g(ex, 'xe_x3', 'images_per_sec'), 'xe_f32': _g(ex, 'xe_f32', 'images_per_sec'),
+                          'xe_299': _g(ex, 'xe_299', 'images_per_sec'), 'xe_v1': _g(ex, 'xe_v1', 'images_per_sec'),
+                          'input_pipeline': _g(ex, 'input_pipeline', 'images_per_sec'),
+                          'cpu_images_per_sec': _g(out, 'cpu_baseline', 'value'), 'voided_steps': voided}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -711,6 +711,7 @@ struct comic_jpeg_pool {
   pthread_mutex_t mu;
   pthread_cond_t work, done;
   Batch* head;                     // batches with passes left, in submission order
+  Batch* fin;                      // finished batches whose waiter has not come yet (freed by the waiter, or by destroy)
   int stop, nthreads;
   pthread_t* threads;
   CoefCache cache;
@@ -908,6 +909,8 @@ static void* pool_worker(void* arg) {
         Batch** at = &pool->head;
         while (*at && *at != b) at = &(*at)->link;
         if (*at) *at = b->link;
+        b->link = pool->fin;
+        pool->fin = b;
         pthread_cond_broadcast(&pool->done);
         if (pool->stop) pthread_cond_broadcast(&pool->work);
       }
@@ -917,9 +920,11 @@ static void* pool_worker(void* arg) {
         pthread_cond_broadcast(&pool->work);                 // pass 2 of this batch is open
       }
     } else if (++b->done2 == b->n) {
-      Batch** at = &pool->head;                              // out of the list; the waiter frees it
+      Batch** at = &pool->head;                              // out of the work list; the waiter (or destroy) frees it
       while (*at && *at != b) at = &(*at)->link;
       if (*at) *at = b->link;
+      b->link = pool->fin;
+      pool->fin = b;
       pthread_cond_broadcast(&pool->done);
       if (pool->stop) pthread_cond_broadcast(&pool->work);
     }
@@ -957,6 +962,8 @@ comic_jpeg_pool* comic_jpeg_pool_create(int threads) {
   return pool;
 }
 
+static void batch_free(Batch* b);
+
 void comic_jpeg_pool_destroy(comic_jpeg_pool* pool) {
   if (!pool) return;
   pthread_mutex_lock(&pool->mu);
@@ -964,6 +971,13 @@ void comic_jpeg_pool_destroy(comic_jpeg_pool* pool) {
   pthread_cond_broadcast(&pool->work);
   pthread_mutex_unlock(&pool->mu);
   for (int i = 0; i < pool->nthreads; ++i) pthread_join(pool->threads[i], NULL);
+  // the workers drained the queue before they left: what is still listed are finished batches nobody waited for (a stage
+  // closed with batches in flight, or a wait that timed out)
+  while (pool->fin) {
+    Batch* b = pool->fin;
+    pool->fin = b->link;
+    batch_free(b);
+  }
   pthread_mutex_destroy(&pool->mu);
   pthread_cond_destroy(&pool->work);
   pthread_cond_destroy(&pool->done);
@@ -982,6 +996,10 @@ int comic_jpeg_pool_enable_cache(comic_jpeg_pool* pool, int64_t max_bytes) {
     return COMIC_JPEG_OK;
   }
   if (max_bytes == 0) return COMIC_JPEG_OK;
+  pthread_mutex_lock(&pool->mu);
+  const int busy = pool->head != NULL;       // workers read c->buckets unlocked: the table must exist before the first submit
+  pthread_mutex_unlock(&pool->mu);
+  if (busy) return COMIC_JPEG_UNSUPPORTED;
   c->n_buckets = 1 << 18;
   c->buckets = (CacheEntry**)calloc((size_t)c->n_buckets, sizeof(CacheEntry*));
   if (!c->buckets) return COMIC_JPEG_IO;
@@ -1074,8 +1092,13 @@ int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, i
   while (b->done2 < b->n)
     if (pthread_cond_timedwait(&pool->done, &pool->mu, &until)) break;
   const int finished = b->done2 == b->n;
+  if (finished) {
+    Batch** at = &pool->fin;
+    while (*at && *at != b) at = &(*at)->link;
+    if (*at) *at = b->link;
+  }
   pthread_mutex_unlock(&pool->mu);
-  if (!finished) return 1;
+  if (!finished) return 1;                                         // stays listed: comic_jpeg_pool_destroy frees it
   int64_t off = 0;
   if (b->packed) {
     // the component planes of the images back to back (coef_base, in samples = bytes); pixel_off stays the packed offset

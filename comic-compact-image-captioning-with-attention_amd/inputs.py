@@ -272,6 +272,8 @@ class JpegSplitPool(object):
         import ctypes as C
         used, total = C.c_int64(0), C.c_int64(0)
         rc = self.lib.comic_jpeg_pool_wait(self._pool, handle, self.timeout_s, C.byref(used), C.byref(total))
+        if rc < 0:
+            raise ValueError('comic_jpeg_pool_wait: bad arguments (pool closed or not a batch handle)')
         if rc != 0:
             raise RuntimeError('JPEG decode threads did not return within %.0f s for: %s'
                                % (self.timeout_s, ', '.join(str(p) for p in list(paths)[:4])))
@@ -382,12 +384,19 @@ class DevicePreprocessor(object):
         torch = self.torch
         self._jpool = jpool
         self._free_coef = queue.Queue()
+        # every staging slot stays referenced HERE for the life of the preprocessor: the decode threads write into a slot until
+        # comic_jpeg_pool_wait / _destroy has returned (include/comic_jpeg.h), which a batch dropped at a stage's shutdown
+        # (Prefetch.close drains its queue) never waits for -- the slot's memory must not go back to an allocator before the
+        # pool is gone
+        self._all_coef = []
         n = jpool.max_batch
         for _ in range(int(slots)):
-            self._free_coef.put(dict(coef=torch.empty(n * jpool.slot_elems, dtype=torch.int16).pin_memory(),
-                                     infos=torch.zeros(n * 512, dtype=torch.uint8).pin_memory(),
-                                     desc=torch.zeros(n * 40, dtype=torch.uint8).pin_memory(),
-                                     status=np.zeros(n, np.int32)))
+            slot = dict(coef=torch.empty(n * jpool.slot_elems, dtype=torch.int16).pin_memory(),
+                        infos=torch.zeros(n * 512, dtype=torch.uint8).pin_memory(),
+                        desc=torch.zeros(n * 40, dtype=torch.uint8).pin_memory(),
+                        status=np.zeros(n, np.int32))
+            self._all_coef.append(slot)
+            self._free_coef.put(slot)
         with torch.cuda.device(self.device):
             self._dev_coef = torch.empty(n * jpool.slot_elems, dtype=torch.int16, device=self.device)
             self._dev_planes = torch.empty(n * jpool.slot_elems, dtype=torch.uint8, device=self.device)
@@ -434,10 +443,10 @@ class DevicePreprocessor(object):
             used, pixel_bytes = jpool.wait(handle, paths)
         except RuntimeError:
             # threads of this batch may still write into the slot: it is retired with the batch, a fresh one takes its place
-            self.__dict__.setdefault('_retired_coef', []).append(slot)
-            self._free_coef.put(dict(coef=torch.empty_like(slot['coef']).pin_memory(),
-                                     infos=torch.zeros_like(slot['infos']).pin_memory(),
-                                     desc=torch.zeros_like(slot['desc']).pin_memory(), status=np.zeros_like(slot['status'])))
+            fresh = dict(coef=torch.empty_like(slot['coef']).pin_memory(), infos=torch.zeros_like(slot['infos']).pin_memory(),
+                         desc=torch.zeros_like(slot['desc']).pin_memory(), status=np.zeros_like(slot['status']))
+            self._all_coef.append(fresh)             # (the retired slot stays in the list too)
+            self._free_coef.put(fresh)
             raise
         try:
             return self._launch_split(packed, used, pixel_bytes)
@@ -464,7 +473,10 @@ class DevicePreprocessor(object):
         fresh = [i for i in bad if i not in early]
         if fresh:                                # first sight of these files: decode them side by side, remember the paths
             decoded = dict(zip(fresh, self._pil_threads().map(decode_image, [paths[i] for i in fresh])))
-            known.update(paths[i] for i in fresh if isinstance(paths[i], str) and len(known) < 1_000_000)
+            # only files the split decoder can NEVER take; a slot that ran full (TOO_SMALL) or a read error says nothing about the
+            # file's next visit
+            known.update(paths[i] for i in fresh if isinstance(paths[i], str) and len(known) < 1_000_000
+                         and int(status[i]) in (L.JPEG_UNSUPPORTED, L.JPEG_CORRUPT))
         for i in bad:
             im = early[i].result() if i in early else decoded[i]
             infos['ncomp'][i] = 0

@@ -66,14 +66,14 @@ int comic_jpeg_decode_file(const char* path, comic_jpeg_info* info, int16_t* coe
  * or does not fit the rest of `capacity` (COMIC_JPEG_TOO_SMALL) takes no room and goes through the loader's PIL path. */
 typedef struct comic_jpeg_pool comic_jpeg_pool;
 comic_jpeg_pool* comic_jpeg_pool_create(int threads);
-void comic_jpeg_pool_destroy(comic_jpeg_pool* pool);          /* waits for queued work */
+void comic_jpeg_pool_destroy(comic_jpeg_pool* pool);          /* waits for queued work; releases the handles nobody waited for */
 /* Returns a batch handle (NULL: bad arguments / out of memory).  `paths` is copied; infos / status / coef (capacity int16
- * elements) must stay valid until comic_jpeg_pool_wait has returned 0 for the handle. */
+ * elements) must stay valid until comic_jpeg_pool_wait has returned 0 for the handle, or comic_jpeg_pool_destroy has returned. */
 void* comic_jpeg_pool_submit(comic_jpeg_pool* pool, const char* const* paths, int n, comic_jpeg_info* infos, int32_t* status,
                              int16_t* coef, int64_t capacity);
 /* 0: every image of the batch is done -- *coef_elems = elements of `coef` in use; pixel_off of the decoded images assigned
  * back to back (16-byte aligned, width * height * 3 bytes each), their sum in *pixel_bytes; the handle is released.
- * 1: not done within timeout_s (the handle stays valid). */
+ * 1: not done within timeout_s (the handle stays valid).  < 0: bad arguments. */
 int comic_jpeg_pool_wait(comic_jpeg_pool* pool, void* batch, double timeout_s, int64_t* coef_elems, int64_t* pixel_bytes);
 
 /* The loader's form: PACKED batches.  Image i is decoded to 16-bit units [desc: one uint32 per block][dc: one int16 per block]
@@ -91,8 +91,8 @@ void* comic_jpeg_pool_submit_packed(comic_jpeg_pool* pool, const char* const* pa
                                     int32_t* status, uint16_t* packed, int64_t capacity_u16);
 
 /* Coefficient cache of a pool (off by default): every image a batch has decoded is kept -- as its non-zero coefficients, about
- * the size of the JPEG file -- under its path until `max_bytes` are in use (nothing is evicted; call before the first submit, or
- * again to move the limit).  A later batch that names the path again gets the coefficients from memory: no file read, no Huffman
+ * the size of the JPEG file -- under its path until `max_bytes` are in use (nothing is evicted; call before the first submit -- switching it ON while batches are
+ * queued is refused with COMIC_JPEG_UNSUPPORTED -- or again to move the limit).  A later batch that names the path again gets the coefficients from memory: no file read, no Huffman
  * decoding -- the epochs after the first run at the speed of a memory copy.  The files are assumed not to change while cached.
  * Augmentation (flip, crop) happens on the device, behind the decode, so cached training batches are the bits of uncached ones. */
 int comic_jpeg_pool_enable_cache(comic_jpeg_pool* pool, int64_t max_bytes);

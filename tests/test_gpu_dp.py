@@ -93,3 +93,22 @@ def test_bench_world_two_branch_runs(tmp_path):
     assert j['n_gpus'] == 2 and j['config']['global_batch'] == 128 and j['scaling'] == 'weak'
     assert j['value'] > 0 and abs(j['value'] - 128 * 4 / (j['ms_per_step'] * 4e-3)) < 1e-3 * j['value']
     assert np.isfinite(j['final_loss'])
+
+
+def test_bench_gpus_two_launches_itself(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the environment: bench.py starts its own
+    torch.distributed.run child before anything touches the GPU, relays rank 0's single JSON line on stdout and leaves
+    with the child's exit code (the shape of the driver's 1-GPU command with another N)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(COMIC_DIST_BACKEND='gloo', COMIC_AUTOTUNE='0', COMIC_PERSIST='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+                        '--no-extras', '--no-cpu-baseline'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100)
+    if r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-12000:])
+    assert r.returncode == 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['config']['global_batch'] == 128 and j['value'] > 0 and np.isfinite(j['final_loss'])
+    assert list(j)[-1] == 'summary' and j['summary']['voided_steps'] == 0

@@ -34,7 +34,20 @@ int main(int argc, char** argv) {
       free(infos[b]); free(status[b]); free(coef[b]);
     }
   }
+  // a stage that closes with batches in flight: two batches queued, one waited for with a timeout too short to matter, none
+  // released -- destroy finishes the work and frees both handles (LeakSanitizer checks that), the buffers go afterwards
+  {
+    const char* paths[64];
+    for (int i = 0; i < n; ++i) paths[i] = argv[1 + i];
+    for (int b = 0; b < 2; ++b) {
+      infos[b] = calloc(n, sizeof(comic_jpeg_info)); status[b] = calloc(n, sizeof(int32_t)); coef[b] = malloc(cap * 2);
+      h[b] = comic_jpeg_pool_submit_packed(pool, paths, n, infos[b], status[b], (uint16_t*)coef[b], cap);
+    }
+    int64_t used = 0, px = 0;
+    (void)comic_jpeg_pool_wait(pool, h[1], 0.0, &used, &px);
+  }
   comic_jpeg_pool_destroy(pool);
+  for (int b = 0; b < 2; ++b) { free(infos[b]); free(status[b]); free(coef[b]); }
   printf("images ok %ld other %ld\n", ok, bad);
   return 0;
 }
