@@ -751,8 +751,6 @@ def main():
 
     # XE is normalised by the GLOBAL token count: every step all-reduces its token count as a device
     # scalar on the stream (Decoder.train_step(dp=...)); the host never waits for it
-    if os.environ.get('COMIC_GG_TARGET'):          # measurement knobs of the grouped GEMM launches (tools/, A/B runs)
-        tr.decoder.lib.comic_debug_gemm_group_tuning(int(os.environ['COMIC_GG_TARGET']), int(os.environ.get('COMIC_GG_FLAGS', '5')))
     tr.use_graph = GRAPH_CNN and GRAPH_DEC
     if overlap:
         tr.enable_overlap(int(os.environ.get('COMIC_POLITE_LDS_KB', '84')))

@@ -52,6 +52,8 @@ CELLS = {'LSTM': 0, 'LN_LSTM': 1, 'GRU': 2}          # include/comic_hip.h COMIC
 DEC_PHASE_FWD, DEC_PHASE_BWD = 512, 1024       # comic_decoder_train_step in two calls (Decoder.train_step(phase=...))
 DEC_NO_GROUP_GEMM = 2048
 DEC_BWD_OWN_ROWS = 4096
+DEC_INJECT_TIMEOUT = 8192       # per-call fault injection (tests)
+CNN_BWD_NO_ACT_FUSION = 2       # comic_cnn_backward_sched: bit 1 of filters_ready
 _DEC_ENV = (('COMIC_PERSIST', '0', DEC_NO_PERSIST), ('COMIC_PERSIST_BWD', '0', DEC_NO_PERSIST_BWD),
             ('COMIC_FUSED_STEP', '0', DEC_NO_FUSED_STEP), ('COMIC_SPLIT_ATTN_BWD', '0', DEC_NO_SPLIT_ATTN_BWD),
             ('COMIC_GRAD_LANES', '0', DEC_ONE_LANE), ('COMIC_SPLIT3', '0', DEC_EXACT_GEMM),
@@ -124,8 +126,6 @@ _SIGS = {
                                       c_float, P, c_int64, P]),
     'comic_gemm_group_workspace': (c_int64, [P, c_int]),
     'comic_gemm_group': (c_int, [P, c_int, P, c_int64, P]),
-    'comic_debug_gemm_group_tuning': (c_int, [c_int, c_int]),
-    'comic_debug_cnn_backward_fusion': (c_int, [c_int]),
     'comic_embed_fwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_embed_bwd': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'comic_dropout_apply': (c_int, [P, P, c_float, P, c_int64, P]),
@@ -157,7 +157,6 @@ _SIGS = {
     'comic_axpy': (c_int, [P, P, c_float, c_int64, P]),
     'comic_decoder_train_workspace': (c_int64, [P, c_int, c_int]),
     'comic_decoder_train_path': (c_int, []),
-    'comic_debug_inject_persist_timeout': (c_int, []),
     'comic_decoder_greedy_path': (c_int, []),
     'comic_decoder_beam_path': (c_int, []),
     'comic_beam_step_dense_workspace': (c_int64, [c_int, c_int, c_int, c_int]),

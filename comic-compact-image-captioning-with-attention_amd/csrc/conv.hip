@@ -3381,13 +3381,13 @@ inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits f
   return ok;
 }
 
-bool g_no_act_fusion = false;      // comic_debug_cnn_backward_fusion(0): the unfused chain (A/B measurements, parity tests)
 
 template <typename T>
 int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched, void* const* buffers,
                             void* const* grad_buffers, void* const* grad_alt, const int32_t* buf_channels,
                             const comic_conv_weight* weights, const comic_conv_grad* grads, int batch, void* scratch,
-                            int64_t scratch_bytes, hipStream_t s0, hipStream_t s1, hipStream_t st_w, bool filters_ready) {
+                            int64_t scratch_bytes, hipStream_t s0, hipStream_t s1, hipStream_t st_w, bool filters_ready,
+                            bool no_act_fusion) {
   constexpr int EPC = Elem<T>::EPC;
   COMIC_REQUIRE(s1 && s1 != s0 && st_w && st_w != s0 && st_w != s1, "cnn_backward_sched: needs three distinct streams");
   COMIC_REQUIRE(backward_scratch_bytes(ops, n_ops, batch, sizeof(T), true) <= scratch_bytes,
@@ -3412,7 +3412,7 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
   std::vector<int> lane_of((size_t)n_ops, -1), fused_by((size_t)n_ops, -1), fuses((size_t)n_ops, -1);
   for (int k = 0; k < n_sched; ++k)
     if (sched[4 * k] == 0 && sched[4 * k + 1] >= 0 && sched[4 * k + 1] < n_ops) lane_of[sched[4 * k + 1]] = sched[4 * k + 2];
-  if (!g_no_act_fusion)
+  if (!no_act_fusion)
     for (int i = 0; i < n_ops; ++i) {
       const comic_cnn_op& c = ops[i];
       if (c.kind != 0 || c.out_f32 || (c.flags & COMIC_OP_X3)) continue;
@@ -3534,19 +3534,17 @@ extern "C" int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, cons
   if (dtype == COMIC_BF16)
     return cnn_backward_sched_impl<bf16_t>(ops, n_ops, sched, n_sched, buffers, grad_buffers, grad_buffers_alt, buf_channels,
                                            weights, grads, batch, scratch, scratch_bytes, (hipStream_t)stream0,
-                                           (hipStream_t)stream1, (hipStream_t)wgrad_stream, filters_ready != 0);
+                                           (hipStream_t)stream1, (hipStream_t)wgrad_stream, (filters_ready & 1) != 0,
+                                          (filters_ready & COMIC_CNN_BWD_NO_ACT_FUSION) != 0);
   if (dtype == COMIC_F32)
     return cnn_backward_sched_impl<float>(ops, n_ops, sched, n_sched, buffers, grad_buffers, grad_buffers_alt, buf_channels,
                                           weights, grads, batch, scratch, scratch_bytes, (hipStream_t)stream0,
-                                          (hipStream_t)stream1, (hipStream_t)wgrad_stream, filters_ready != 0);
+                                          (hipStream_t)stream1, (hipStream_t)wgrad_stream, (filters_ready & 1) != 0,
+                                          (filters_ready & COMIC_CNN_BWD_NO_ACT_FUSION) != 0);
   COMIC_REQUIRE(false, "unknown dtype %d", dtype);
   return 2;
 }
 
-extern "C" int comic_debug_cnn_backward_fusion(int on) {
-  g_no_act_fusion = !on;
-  return 0;
-}
 
 extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype, int lanes) {
   if (!ops) return -1;

@@ -24,51 +24,130 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t*
   out[i] = (id >= 0 && id < V) ? table[(size_t)id * E + e] : 0.f;
 }
 
-// one block per vocabulary row: deterministic sum over the rows that reference it
-template <bool SET>
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ ids,
-                                                        const float* __restrict__ dout,
-                                                        float* __restrict__ dtable, int rows, int E) {
-  // ordered (ascending row) compaction of the rows that hold this vocabulary id, then a
-  // sequential sum over that list: deterministic, and the id scan is parallel
-  __shared__ int list[2048];
-  __shared__ int wcnt[4];
-  __shared__ int total;
-  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) total = 0;
-  __syncthreads();
-  for (int base = 0; base < rows; base += 256) {
+// d table[v, :] (+)= sum over the rows r with ids[r] == v of dout[r, :], deterministic and without atomics.
+// One workgroup per (vocabulary row v, slice of EW table columns).  The id scan is parallel (ballot + ordered compaction
+// into an LDS list); the SUM is parallel too: the list is cut into NS contiguous shares, row stream s (LPR lanes, VEC columns
+// each, NC column steps) adds the rows of its share in ascending order with four loads in flight, and the NS partial sums are
+// combined in stream order.  The shares depend only on (ids, rows), so two runs give the same bits.
+// Why: radix vocabularies are frequency-sorted (datasets/preprocessing/prepro_base.py:186) -- the high digit 0 sits on most
+// tokens -- and the one-sum-per-thread form this replaces walked such a row's 4 800 hits of a 224-hypothesis SCST step as ONE
+// dependent chain per column: 905 us per call (profiles/r04_scst_kernel_stats.csv).
+// A list that runs full is flushed into the streams' running sums and refilled: any number of hits per id, no special case.
+template <bool SET, int NT, int LPR, int VEC, int NC>
+__global__ __launch_bounds__(NT) void embed_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dout,
+                                                       float* __restrict__ dtable, int rows, int E) {
+  constexpr int NS = NT / LPR;            // row streams of the workgroup
+  constexpr int EW = LPR * VEC * NC;      // table columns of the workgroup
+  constexpr int CAP = 4096;               // >= NT: the hits of one scan pass always fit an empty list
+  static_assert(CAP >= NT && NT % 64 == 0 && NT % LPR == 0, "embed_bwd geometry");
+  __shared__ int list[CAP];
+  __shared__ int wcnt[NT / 64];
+  __shared__ float part[NS][EW];
+  const int v = blockIdx.x, e0 = blockIdx.y * EW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stream = tid / LPR, sl = tid % LPR;
+  float acc[NC][VEC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[c][k] = 0.f;
+
+  auto add_row = [&](int r) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = e0 + (c * LPR + sl) * VEC;
+      if (col < E) {
+        const float* src = dout + (size_t)r * E + col;
+        if constexpr (VEC == 4) {
+          const float4 x = *(const float4*)src;
+          acc[c][0] += x.x; acc[c][1] += x.y; acc[c][2] += x.z; acc[c][3] += x.w;
+        } else {
+          acc[c][0] += src[0];
+        }
+      }
+    }
+  };
+  auto flush = [&](int n) {               // stream s: entries [s*n/NS, (s+1)*n/NS) of the list, in order
+    const int lo = (int)((long)stream * n / NS), hi = (int)((long)(stream + 1) * n / NS);
+    int i = lo;
+    for (; i + 4 <= hi; i += 4) {
+      const int r0 = list[i], r1 = list[i + 1], r2 = list[i + 2], r3 = list[i + 3];
+      if constexpr (VEC == 4 && NC == 1) {          // four rows in flight, added in list order
+        const int col = e0 + sl * 4;
+        float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, x2 = x0, x3 = x0;
+        if (col < E) {
+          x0 = *(const float4*)(dout + (size_t)r0 * E + col);
+          x1 = *(const float4*)(dout + (size_t)r1 * E + col);
+          x2 = *(const float4*)(dout + (size_t)r2 * E + col);
+          x3 = *(const float4*)(dout + (size_t)r3 * E + col);
+        }
+        acc[0][0] = (((acc[0][0] + x0.x) + x1.x) + x2.x) + x3.x;
+        acc[0][1] = (((acc[0][1] + x0.y) + x1.y) + x2.y) + x3.y;
+        acc[0][2] = (((acc[0][2] + x0.z) + x1.z) + x2.z) + x3.z;
+        acc[0][3] = (((acc[0][3] + x0.w) + x1.w) + x2.w) + x3.w;
+      } else {
+        add_row(r0); add_row(r1); add_row(r2); add_row(r3);
+      }
+    }
+    for (; i < hi; ++i) add_row(list[i]);
+  };
+
+  int fill = 0, n_total = 0;              // uniform: every thread derives them from the same LDS counts
+  for (int base = 0; base < rows; base += NT) {
     const int r = base + tid;
     const bool hit = r < rows && ids[r] == v;
     const unsigned long long bal = __ballot(hit);
     if (lane == 0) wcnt[wave] = __popcll(bal);
     __syncthreads();
-    int off = total;
-    for (int w = 0; w < wave; ++w) off += wcnt[w];
-    if (hit) {
-      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
-      if (pos < 2048) list[pos] = r;
+    int before = 0, pass = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+      const int c = wcnt[w];
+      before += w < wave ? c : 0;
+      pass += c;
     }
-    __syncthreads();
-    if (tid == 0) total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (fill + pass > CAP) {              // (uniform) the list cannot take this pass: fold it into the running sums first
+      flush(fill);
+      fill = 0;
+      __syncthreads();
+    }
+    if (hit) list[fill + before + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+    fill += pass;
+    n_total += pass;
     __syncthreads();
   }
-  const int n = min(total, 2048);
-  if (n == 0) {                      // SET: the table row is written, not accumulated into (no zero fill before the launch)
+  if (n_total == 0) {                     // SET: the table row is written, not accumulated into (no zero fill before the launch)
     if (SET)
-      for (int e = tid; e < E; e += 256) dtable[(size_t)v * E + e] = 0.f;
+      for (int e = tid; e < EW && e0 + e < E; e += NT) dtable[(size_t)v * E + e0 + e] = 0.f;
     return;
   }
-  for (int e = tid; e < E; e += 256) {
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc += dout[(size_t)list[i] * E + e];
-    // rows beyond the LDS list (a token repeated > 2048 times in one batch): direct scan
-    if (total > 2048)
-      for (int r = list[2047] + 1; r < rows; ++r)
-        if (ids[r] == v) acc += dout[(size_t)r * E + e];
-    if (SET) dtable[(size_t)v * E + e] = acc;
-    else dtable[(size_t)v * E + e] += acc;
+  flush(fill);
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) part[stream][(c * LPR + sl) * VEC + k] = acc[c][k];
+  __syncthreads();
+  for (int e = tid; e < EW && e0 + e < E; e += NT) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int st = 0; st < NS; ++st) sum += part[st][e];
+    if (SET) dtable[(size_t)v * E + e0 + e] = sum;
+    else dtable[(size_t)v * E + e0 + e] += sum;
   }
+}
+
+// small vocabularies (radix / char tokens): 64 row streams of 16 lanes x float4 per 64-column slice, 1024 threads;
+// otherwise (word vocabularies: tens of thousands of mostly empty rows) 4 streams of a wave each over 256 columns
+template <bool SET>
+int embed_bwd_launch(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V, hipStream_t st) {
+  const bool vec = E % 4 == 0 && ((uintptr_t)dout & 15) == 0;
+  const int slices = (E + 63) / 64;
+  if (vec && (long)V * slices <= 4096)
+    hipLaunchKernelGGL((embed_bwd_kernel<SET, 1024, 16, 4, 1>), dim3(V, slices), dim3(1024), 0, st, ids, dout, dtable, rows, E);
+  else
+    hipLaunchKernelGGL((embed_bwd_kernel<SET, 256, 64, 1, 4>), dim3(V, (E + 255) / 256), dim3(256), 0, st, ids, dout, dtable,
+                       rows, E);
+  return 0;
 }
 
 // ------------------------------------------------------------------ dropout -----------
@@ -1233,13 +1312,13 @@ extern "C" int comic_embed_fwd(const float* table, const int32_t* ids, float* ou
 
 extern "C" int comic_embed_bwd(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V,
                                void* stream) {
-  hipLaunchKernelGGL(embed_bwd_kernel<false>, dim3(V), dim3(256), 0, (hipStream_t)stream, ids, dout, dtable, rows, E);
+  embed_bwd_launch<false>(ids, dout, dtable, rows, E, V, (hipStream_t)stream);
   COMIC_LAUNCH_CHECK("embed_bwd");
   return 0;
 }
 // dtable = (not +=) the scattered sums: every table row is written, so no zero fill precedes it
 int comic_embed_bwd_set(const int32_t* ids, const float* dout, float* dtable, int rows, int E, int V, hipStream_t st) {
-  hipLaunchKernelGGL(embed_bwd_kernel<true>, dim3(V), dim3(256), 0, st, ids, dout, dtable, rows, E);
+  embed_bwd_launch<true>(ids, dout, dtable, rows, E, V, st);
   COMIC_LAUNCH_CHECK("embed_bwd_set");
   return 0;
 }

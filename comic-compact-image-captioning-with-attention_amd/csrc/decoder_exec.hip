@@ -630,7 +630,7 @@ struct GemmGroupRun {
   }
   int run(void* slab, int64_t slab_cap, unsigned* tickets, hipStream_t st) {
     if (g.n == 0) return 0;
-    int target = comic_gemm_group_debug_target(640);
+    int target = kGemmGroupTargetItems;
     for (;;) {
       int64_t need = 0;
       int nt = 0;
@@ -840,8 +840,6 @@ thread_local int g_train_path = 0;
 extern "C" int comic_decoder_train_path(void) { return g_train_path; }
 // fault injection for the tests of the end-of-step gate: the next comic_decoder_train_step that runs a persistent loop
 // behaves as if one of its bounded waits had expired (one shot)
-static std::atomic<int> g_inject_timeout{0};
-extern "C" int comic_debug_inject_persist_timeout(void) { g_inject_timeout.store(1); return 0; }
 thread_local int g_greedy_path = 0;
 extern "C" int comic_decoder_greedy_path(void) { return g_greedy_path; }
 thread_local int g_beam_path = 0;
@@ -1481,7 +1479,7 @@ extern "C" int comic_decoder_train_step(const comic_decoder_desc* d, const comic
     if (d->context_layer) add(gr->W_a, (long)Cv * D);
     add(gr->W_o, (long)D * V); add(gr->b_o, V); add(gr->emb, (long)V * E);
     add(dfm, (long)B * M * d->C); add(dim_embed, (long)B * d->Cg);
-    if (g_inject_timeout.exchange(0) != 0)       // comic_debug_inject_persist_timeout: raise the error word by hand
+    if (d->flags & COMIC_DEC_INJECT_TIMEOUT)     // fault injection of THIS call: raise the loops' error word by hand
       COMIC_REQUIRE(hipMemsetAsync(persist_sync, 0xFF, sizeof(unsigned), st) == hipSuccess, "train_step: memset");
     RC(comic_persist_gate(persist_sync, loss_rows, map_loss, gr_, gr->status, p->status, st));
   }

@@ -38,5 +38,5 @@ struct ComicGemmGroup {
 // slab and tickets.  Returns the workgroups of the launch (< 0: error); *slab_bytes / *n_tickets receive what the
 // launch needs.
 int comic_gemm_group_plan(ComicGemmGroup& g, int target_items, int64_t* slab_bytes, int* n_tickets);
-int comic_gemm_group_debug_target(int dflt);
+constexpr int kGemmGroupTargetItems = 640;   // work items a grouped launch aims at (split-K degree follows from it)
 int comic_gemm_group_launch(const ComicGemmGroup& g, int n_wg, hipStream_t st);

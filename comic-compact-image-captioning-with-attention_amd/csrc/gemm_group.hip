@@ -237,23 +237,14 @@ int comic_gemm_group_plan(ComicGemmGroup& g, int target_items, int64_t* slab_byt
   return wg;
 }
 
-static int g_dbg_target = 0, g_dbg_xcd = 1, g_dbg_pc = 2;
-extern "C" int comic_debug_gemm_group_tuning(int target_items, int xcd_remap) {
-  g_dbg_target = target_items;
-  g_dbg_xcd = xcd_remap & 1;
-  g_dbg_pc = (xcd_remap & 2) ? 0 : (xcd_remap & 4) ? 2 : 1;        // bit 1: the four-wave kernel, bit 2: by launch size (default)
-  return 0;
-}
-int comic_gemm_group_debug_target(int dflt) { return g_dbg_target > 0 ? g_dbg_target : dflt; }
-
 int comic_gemm_group_launch(const ComicGemmGroup& g_in, int n_wg, hipStream_t st) {
   ComicGemmGroup g = g_in;
-  g.xcd_chunk = g_dbg_xcd ? n_wg / 8 : 0;
+  g.xcd_chunk = n_wg / 8;          // work items of one XCD are neighbours in the item order
   COMIC_REQUIRE(n_wg > 0, "gemm_group: empty launch");
   // producer / consumer kernel (one 8-wave workgroup per CU) when every product can be loaded 16 bytes at a time and the
   // launch fits the chip in one round; beyond that the four-wave kernel (two workgroups per CU) measured faster (the
   // weight-gradient group of the decoder step: 98 against 118 us; its single-round launches 19-23 against 23-29 us)
-  bool pc = g_dbg_pc == 1 || (g_dbg_pc == 2 && n_wg <= 256);
+  bool pc = n_wg <= 256;
   for (int i = 0; i < g.n && pc; ++i) {
     const ComicGemmProb& p = g.p[i];
     if (p.ones_a) continue;
@@ -290,7 +281,7 @@ int gg_from_public(const comic_gemm_prob* probs, int n, ComicGemmGroup& g) {
   }
   return 0;
 }
-#define kPublicTarget comic_gemm_group_debug_target(640)
+#define kPublicTarget kGemmGroupTargetItems
 }  // namespace
 
 extern "C" int64_t comic_gemm_group_workspace(const comic_gemm_prob* probs, int n) {

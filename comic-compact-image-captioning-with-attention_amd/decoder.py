@@ -408,7 +408,8 @@ class Decoder:
         BT = B * T
         i32, f32 = ctx.i32, ctx.f32
         ptab, gtab = self.params.table(), self.grads.table()
-        ctx.desc.flags = L.decoder_flags_from_env() | {None: 0, 'fwd': L.DEC_PHASE_FWD, 'bwd': L.DEC_PHASE_BWD}[phase]
+        ctx.desc.flags = (L.decoder_flags_from_env() | {None: 0, 'fwd': L.DEC_PHASE_FWD, 'bwd': L.DEC_PHASE_BWD}[phase]
+                          | (L.DEC_INJECT_TIMEOUT if ctx.__dict__.pop('inject_timeout', False) else 0))
         L.check(self.lib.comic_decoder_train_step(
             C.byref(ctx.desc), C.byref(ptab), C.byref(gtab), ctx.fm_in.data_ptr(), ctx.im_in.data_ptr(),
             i32.data_ptr(), i32.data_ptr() + 4 * BT, f32.data_ptr(), f32.data_ptr() + 4 * BT,
@@ -425,7 +426,7 @@ class Decoder:
 
     def train_step(self, fm, im_embed, captions, masks=None, rewards=None, training=True, seed=None,
                    want_input_grads=False, xe_denom=None, use_graph=False, on_inputs_consumed=None, dp=None,
-                   copy_inputs=True, phase=None):
+                   copy_inputs=True, phase=None, inject_timeout=False):
         """One teacher-forced forward + backward.  `captions` [B,L] int (PAD = -1).
         phase: None = the whole step.  'fwd' = everything no loss coefficient enters (forward to the logits; `rewards` is
         ignored) and 'bwd' = the rest, with the SAME captions and now the rewards: the SCST step enqueues 'fwd' as soon as
@@ -516,6 +517,9 @@ class Decoder:
                 on_inputs_consumed()
             ctx.calls += 1
             return None
+        if inject_timeout:          # fault injection of THIS call (COMIC_DEC_INJECT_TIMEOUT, tests): eager launches only
+            assert not use_graph and phase is None
+            ctx.inject_timeout = True
         if use_graph and ctx.graph is None and ctx.calls >= 1:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):

@@ -142,8 +142,11 @@ class ModelBase(object):
             t = enc.backward(res['dfm'], res['dim_embed'])
             s1 = 1.0
         ow.t = ob.t = self.opt.t            # one global step for every variable
-        ow.step(t.dw, lr, grad_scale=s1 * mult)
-        ob.step(t.dbeta, lr, grad_scale=s1 * mult)
+        # a step the decoder voided on the device (status word of its gradient buffer, all-reduced with it under data
+        # parallelism) is a no-op for the CNN variables as well
+        void = getattr(self.decoder.grads, 'status', None)
+        ow.step(t.dw, lr, grad_scale=s1 * mult, skip=void)
+        ob.step(t.dbeta, lr, grad_scale=s1 * mult, skip=void)
         enc.refresh_weights()
         enc.clear_grads_async()
 
@@ -417,7 +420,12 @@ class CaptionModel(ModelBase):
             import collections
             group = int(getattr(self._config, 'encoder_group', 1) or 0)
             if group <= 0:                 # --encoder_group 0: auto
-                group = auto_encoder_group(self._batch_size)
+                # a bf16x3 plan holds three channel regions per bf16 buffer: a third of the images reaches the same buffer sizes
+                # (and keeps the largest one, 109x109x192x3 at 224, under the kernels' 2^31-element limit)
+                x3 = str(getattr(self._config, 'cnn_dtype', 'bf16')) == 'bf16x3'
+                side = max(getattr(self._config, 'cnn_input_size', None) or [224, 224])
+                per_fwd = (1280 // 3 if x3 else 1280) * 224 * 224 // max(224 * 224, side * side)
+                group = auto_encoder_group(self._batch_size, images_per_forward=max(per_fwd, self._batch_size))
                 group = max(1, min(group, int(getattr(self._config, 'max_step', group)) - int(self.global_step)))
             enc = self._encoder_for(self._batch_size * group)
             enc.polite_lds_kb = int(getattr(self._config, 'encoder_polite_lds_kb', 84))   # see CaptionTrainer.enable_overlap

@@ -1054,12 +1054,13 @@ class CnnEncoder:
         return plan_grad_buckets(self.plan, self.w_master, self.beta, n)
 
 
-    def backward(self, d_fm, d_im_embed, buckets=None, on_bucket=None):
+    def backward(self, d_fm, d_im_embed, buckets=None, on_bucket=None, act_fusion=True):
         """d_fm [B, M, C] / d_im_embed [B, C_g] fp32 (the gradients of `forward`'s two outputs; either
         may be None) -> fills the weight / beta gradients of `enable_training()`'s state.
         buckets (from grad_buckets) + on_bucket(train_state, bucket): the backward is issued bucket by bucket and the
         callback runs after each one -- the data-parallel step starts that bucket's all-reduce there, under the
-        backward of the earlier blocks."""
+        backward of the earlier blocks.  act_fusion=False: THIS call of the scheduled backward runs the unfused chain
+        (COMIC_CNN_BWD_NO_ACT_FUSION; A/B timing, parity tests)."""
         t = self.enable_training()
         if getattr(t, 'zero_ev', None) is not None:          # cleared on the aux stream behind the last optimiser step
             self.torch.cuda.current_stream().wait_event(t.zero_ev)
@@ -1079,7 +1080,8 @@ class CnnEncoder:
         if buckets is None and on_bucket is None and t.sched is not None:
             L.check(self.lib.comic_cnn_backward_sched(self._ops, len(self.plan.ops), t.sched.ctypes.data, len(t.sched),
                                                       self._last_bufptr or self._bufptr, t.gptr, t.gptr_alt, self._bufch,
-                                                      self._wt, t.grads, self.batch, self.dcode, int(ready),
+                                                      self._wt, t.grads, self.batch, self.dcode,
+                                                      int(ready) | (0 if act_fusion else L.CNN_BWD_NO_ACT_FUSION),
                                                       t.scratch.data_ptr(), t.scratch_bytes, L.stream_ptr(),
                                                       t.lane1.cuda_stream, t.wlane.cuda_stream), 'cnn_backward_sched')
             return t

@@ -49,8 +49,8 @@ class GradClip:
         self.chunks = torch.from_numpy(np.asarray(rows, np.int64).reshape(-1, 5)).to(params.device)
         self.partial = torch.zeros(max(1, self.n_chunks), dtype=torch.float32, device=params.device)
 
-    def apply(self, params, grads, l2, grad_scale):
-        st = getattr(grads, 'status', None)
+    def apply(self, params, grads, l2, grad_scale, skip=None):
+        st = skip if skip is not None else getattr(grads, 'status', None)
         L.check(self.lib.comic_clip_by_norm(grads.data.data_ptr(), params.data.data_ptr(), self.chunks.data_ptr(),
                                             self.n_chunks, l2, grad_scale, self.clip_norm, self.partial.data_ptr(),
                                             st.data_ptr() if st is not None else None, L.stream_ptr()), 'clip_by_norm')
@@ -66,16 +66,18 @@ class AdamTF:
         self.t = 0                      # number of applied updates (== global_step)
         self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
-    def step(self, grads, lr, grad_scale=1.0):
+    def step(self, grads, lr, grad_scale=1.0, skip=None):
+        """skip: the status word of ANOTHER gradient buffer that gates this update too (the CNN optimisers of cnn_finetune
+        follow the decoder's verdict on the step: model.py)."""
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
         # a gradient buffer with a status word (decoder.FlatParams(status_tail=True)): the update is skipped on the device
         # when comic_decoder_train_step voided the step (on any rank: the word is part of the all-reduced buffer).  The
         # host-side step count `t` advances regardless -- one bias-correction step of drift per voided step, and the run
         # stops at the next log point anyway (train_fn._check_loss reads the sticky count).
-        st = getattr(grads, 'status', None)
+        st = skip if skip is not None else getattr(grads, 'status', None)
         if self.clip is not None:
-            self.clip.apply(self.params, grads, self.l2, grad_scale)
+            self.clip.apply(self.params, grads, self.l2, grad_scale, skip=st)
         L.check(self.lib.comic_adam_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
                                              self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
                                              self.eps, self.l2, grad_scale, st.data_ptr() if st is not None else None,
@@ -105,11 +107,11 @@ class MomentumTF:
         self.t = 0
         self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
-    def step(self, grads, lr, grad_scale=1.0):
+    def step(self, grads, lr, grad_scale=1.0, skip=None):
         self.t += 1
-        st = getattr(grads, 'status', None)
+        st = skip if skip is not None else getattr(grads, 'status', None)
         if self.clip is not None:
-            self.clip.apply(self.params, grads, self.l2, grad_scale)
+            self.clip.apply(self.params, grads, self.l2, grad_scale, skip=st)
         L.check(self.lib.comic_momentum_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
                                                  self.params.numel, lr, self.momentum, self.l2, grad_scale,
                                                  st.data_ptr() if st is not None else None, L.stream_ptr()), 'momentum_tf')

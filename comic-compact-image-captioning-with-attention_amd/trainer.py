@@ -247,8 +247,9 @@ class CaptionTrainer:
             scale = 1.0
         self.opt.step(self.decoder.grads, lr, grad_scale=scale)
         ow.t = ob.t = self.opt.t - 1
-        ow.step(t.dw, lr, grad_scale=scale * mult)
-        ob.step(t.dbeta, lr, grad_scale=scale * mult)
+        void = getattr(self.decoder.grads, 'status', None)     # a step voided on the device skips the CNN update too
+        ow.step(t.dw, lr, grad_scale=scale * mult, skip=void)
+        ob.step(t.dbeta, lr, grad_scale=scale * mult, skip=void)
         self.encoder.refresh_weights()
         self.encoder.clear_grads_async()
         return res

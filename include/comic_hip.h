@@ -257,7 +257,12 @@ int comic_cnn_backward(const comic_cnn_op* ops, int n_ops, void* const* buffers,
  *   2 JOIN_ADD  stream0 waits for stream1; index >= 0: grad_buffers[index] += grad_buffers_alt[index], the alternate buffer is
  *               cleared (alternate buffers are zero between calls)
  * Every op (kinds 5 / 6 excepted) appears exactly once, consumers before producers inside a lane; the scratch is the
- * lanes = 2 size; weight gradients go to wgrad_stream as in comic_cnn_backward.  All lanes are joined into stream0. */
+ * lanes = 2 size; weight gradients go to wgrad_stream as in comic_cnn_backward.  All lanes are joined into stream0.
+ * The pass fuses the activation gradient of a conv whose output has exactly one reader (a conv on the same lane: the inner
+ * convs of the Inception branches) into the epilogue of that reader's backward-data launch -- one launch less per conv on the
+ * serial chain of a block's longest branch.  filters_ready carries two bits here: bit 0 as in comic_cnn_backward, bit 1
+ * (COMIC_CNN_BWD_NO_ACT_FUSION) runs THIS call with the unfused chain (A/B timing, parity tests). */
+#define COMIC_CNN_BWD_NO_ACT_FUSION 2
 int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, const int32_t* sched, int n_sched, void* const* buffers,
                              void* const* grad_buffers, void* const* grad_buffers_alt, const int32_t* buf_channels,
                              const comic_conv_weight* weights, const comic_conv_grad* grads, int batch, int dtype,
@@ -320,13 +325,6 @@ typedef struct comic_gemm_prob {
 } comic_gemm_prob;
 int64_t comic_gemm_group_workspace(const comic_gemm_prob* probs, int n);
 int comic_gemm_group(const comic_gemm_prob* probs, int n, void* workspace, int64_t workspace_bytes, void* stream);
-/* measurement knobs of the grouped launch (work items per launch, XCD-contiguous item order); results do not change */
-int comic_debug_gemm_group_tuning(int target_items, int xcd_remap);
-/* comic_cnn_backward_sched fuses the activation gradient of a conv whose output has exactly one reader (a conv on the same
- * lane: the inner convs of the Inception branches) into the epilogue of that reader's backward-data launch -- one launch less
- * per conv on the serial chain of a block's longest branch.  on = 0 runs the unfused chain (A/B timing, parity tests);
- * process-wide, default on. */
-int comic_debug_cnn_backward_fusion(int on);
 
 /* Skinny product for the decode steps: out[R][N] = x[R][Kin] W[Kin][N] + bias for 33 ... 256 rows (batch x beam), Kin a
  * multiple of 8, any N -- the [TF-1.9] dense layers inside rnn_decoder_beam_search's step (BasicLSTMCell's gate product
@@ -528,6 +526,8 @@ typedef struct comic_decoder_desc {
 #define COMIC_DEC_PHASE_BWD 1024u       /* ... only the rest (loss, backward), over the SAME workspace and arguments as the forward call */
 #define COMIC_DEC_NO_GROUP_GEMM 2048u    /* comic_decoder_train_step: the products outside the time loops as separate launches on two lanes
                                            instead of grouped launches (comic_gemm_group) */
+#define COMIC_DEC_INJECT_TIMEOUT 8192u  /* fault injection (tests): THIS comic_decoder_train_step call, if it runs a persistent loop, reports a loop
+                                           timeout (NaN loss_rows[0] / map_loss, zero gradients, status words raised) although its kernels completed */
 #define COMIC_DEC_BWD_OWN_ROWS 4096u    /* persistent backward loop in its own-rows form (the form of memories of more than 64 rows) whatever M is */
 #define COMIC_DEC_NO_LSTM_STREAM 256u   /* decode steps at > 32 rows with the per-row-tile fused LSTM kernel instead of the streaming one */
 #define COMIC_DEC_NO_BEAM_LOGITS 128u   /* beam step as GEMM + statistics + chunk top-k + merge (large V) / comic_beam_step's kernel (small V)
@@ -580,9 +580,6 @@ int comic_decoder_train_step(const comic_decoder_desc* d, const comic_decoder_pa
  * (csrc/decoder_persist_bwd.hip); 0 = per-step launches.  The choice depends on the shape (D = 512, B <= 64, ...), the
  * device (one workgroup per CU must be resident) and the COMIC_PERSIST / COMIC_PERSIST_BWD switches. */
 int comic_decoder_train_path(void);
-/* Test hook (fault injection): the next comic_decoder_train_step that runs a persistent loop reports a loop timeout
- * (NaN loss_rows[0] / map_loss, zero gradients) although its kernels completed.  One shot. */
-int comic_debug_inject_persist_timeout(void);
 /* 1 when the LAST comic_decoder_greedy of this thread ran its loop as one persistent launch (D = 512, B <= 64,
  * V <= 512, no context layer, a device with enough CUs, COMIC_PERSIST != 0), 0 for per-step launches. */
 int comic_decoder_greedy_path(void);

@@ -518,6 +518,36 @@ def test_embed_fwd_bwd():
     assert_close(dt.cpu().numpy(), ref, 1e-6, 'embed_bwd')
 
 
+@pytest.mark.parametrize('V,E,rows,hot', [(258, 256, 6048, 4800),      # a 224-hypothesis SCST step of long captions: radix digit 0 on 80 %
+                                          (258, 256, 9000, 9000),      # one id on every row: the LDS list (4096 entries) runs full twice
+                                          (40, 100, 5000, 4500),       # E % 64 != 0: a partly used column slice
+                                          (3000, 64, 2000, 1500),      # many vocabulary rows: still the 1024-thread form (V * slices <= 4096)
+                                          (25599, 256, 1280, 300),     # word vocabulary: the one-wave-per-stream form
+                                          (300, 30, 5000, 4700)])      # E % 4 != 0: scalar columns
+def test_embed_bwd_skewed_ids_and_list_overflow(V, E, rows, hot):
+    """comic_embed_bwd on frequency-skewed ids (the reference vocabulary is frequency-sorted, prepro_base.py:186: one radix digit
+    sits on most tokens): `hot` rows carry id 1 -- more than the kernel's LDS list holds in two of the cases, so the
+    flush-and-refill path runs -- the rest are uniform with PAD (-1) among them.  Accumulating form (+=) against a float64
+    scatter-add; two runs give the same bits."""
+    rng = np.random.default_rng(V + rows)
+    ids = rng.integers(-1, V, rows).astype(np.int32)
+    ids[rng.permutation(rows)[:hot]] = 1
+    dout = rng.standard_normal((rows, E)).astype(np.float32)
+    base = rng.standard_normal((V, E)).astype(np.float32)
+    d_ids, d_dout = dev(ids), dev(dout)
+    runs = []
+    for _ in range(2):
+        dt = dev(base)
+        L.check(lib().comic_embed_bwd(d_ids.data_ptr(), d_dout.data_ptr(), dt.data_ptr(), rows, E, V, stream()))
+        runs.append(dt.cpu().numpy())
+    ref = base.astype(np.float64)
+    np.add.at(ref, ids[ids >= 0], dout[ids >= 0].astype(np.float64))
+    assert_close(runs[0], ref, 2e-6, 'embed_bwd skewed')
+    np.testing.assert_array_equal(runs[0], runs[1])
+    untouched = np.setdiff1d(np.arange(V), ids[ids >= 0])
+    np.testing.assert_array_equal(runs[0][untouched], base[untouched])
+
+
 def test_dropout_mask_and_apply():
     n = 1 << 20
     m = torch.empty(n, device=DEV)

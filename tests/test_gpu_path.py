@@ -454,7 +454,7 @@ def test_inception_v3_backward_224_bf16_sanity():
 def test_backward_with_fused_activation_gradients_matches_the_unfused_chain(dtype, tol):
     """comic_cnn_backward_sched hands the activation gradient of a conv with ONE reader (the inner convs of the Inception
     branches) to the epilogue of that reader's backward-data launch.  Same gradients as the chain with the separate
-    act_grad launches (comic_debug_cnn_backward_fusion(0)): fp32 plan to rounding of the atomics' order, bf16 plan to the one
+    act_grad launches (backward(act_fusion=False) = COMIC_CNN_BWD_NO_ACT_FUSION of that call): fp32 plan to rounding of the atomics' order, bf16 plan to the one
     bf16 rounding of the intermediate gradient the fused form skips."""
     B = 2
     params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
@@ -464,16 +464,12 @@ def test_backward_with_fused_activation_gradients_matches_the_unfused_chain(dtyp
     enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224)), params, B, dtype, DEV)
     lib = L.load()
     out = {}
-    try:
-        for fused in (0, 1):
-            lib.comic_debug_cnn_backward_fusion(fused)
-            enc.forward(dev(x))
-            t = enc.backward(dev(d_fm), dev(d_net))
-            sync()
-            assert t.sched is not None                   # the scheduled (three-lane) backward is the one that fuses
-            out[fused] = _cnn_grads_device(enc, t)
-    finally:
-        lib.comic_debug_cnn_backward_fusion(1)
+    for fused in (0, 1):
+        enc.forward(dev(x))
+        t = enc.backward(dev(d_fm), dev(d_net), act_fusion=bool(fused))
+        sync()
+        assert t.sched is not None                   # the scheduled (three-lane) backward is the one that fuses
+        out[fused] = _cnn_grads_device(enc, t)
     errs = sorted((rel_err(out[1][k], out[0][k]), k) for k in out[0])
     assert errs[-1][0] < tol, errs[-3:]
     moved = sum(1 for k in out[0] if not np.array_equal(out[0][k], out[1][k]))
@@ -707,7 +703,7 @@ def test_persistent_loop_timeout_voids_the_step():
     """A bounded wait of a persistent loop that expires must not train on garbage: the executor's last
     launch turns the step's losses into NaN and every gradient into zeros (comic_persist_gate), so the fused Adam that
     follows without a host check applies no gradient, and the host sees NaN at its next look at the loss.  The timeout
-    is injected (comic_debug_inject_persist_timeout); the step before and the step after are healthy."""
+    is injected into ONE call (COMIC_DEC_INJECT_TIMEOUT in that call's descriptor); the step before and the step after are healthy."""
     spec, cfg = _spec_and_cfg(D=512, E=256, C=2048, Cg=2048)
     B, Lc = 32, 12
     dec = cdec.Decoder(spec, _rand_params(cfg, 6), DEV)
@@ -719,8 +715,7 @@ def test_persistent_loop_timeout_voids_the_step():
     assert dec.lib.comic_decoder_train_path() == 3
     want = (float(good['loss']), dec.grads.data.clone(), good['dfm'].clone())
     assert np.isfinite(want[0]) and float(want[1].abs().max()) > 0
-    assert dec.lib.comic_debug_inject_persist_timeout() == 0
-    bad = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)
+    bad = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True, inject_timeout=True)
     sync()
     assert np.isnan(float(bad['loss'])) and np.isnan(float(bad['map_loss']))
     assert float(dec.grads.flat.abs().max()) == 0.0
@@ -735,7 +730,7 @@ def test_persistent_loop_timeout_voids_the_step():
         opt.step(dec.grads, 1e-2)
         sync()
         assert torch.equal(dec.params.data, before[0]) and torch.equal(opt.m.data, before[1]) and torch.equal(opt.v.data, before[2])
-    again = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)   # one shot
+    again = dec.train_step(dev(fm), dev(im), caps, masks=masks, training=True, want_input_grads=True)   # the flag was that call's alone
     sync()
     assert float(again['loss']) == want[0] and torch.equal(dec.grads.flat, want[1][:dec.grads.numel]) and torch.equal(again['dfm'], want[2])
     assert float(dec.grads.status) == 0.0 and dec.voided_steps() == 1      # healthy again; the count stays

@@ -3,14 +3,11 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
 from comic_amd import decoder as cdec, optim
 M, C, CG, B = (int(os.environ.get(k, d)) for k, d in (('M', '196'), ('C', '832'), ('CG', '1024'), ('B', '64')))
 dev = 'cuda:0'
-if os.environ.get('GG_TARGET'):
-    import comic_amd._lib as _L
-    _L.load().comic_debug_gemm_group_tuning(int(os.environ['GG_TARGET']), int(os.environ.get('GG_FLAGS', '5')))
+
 spec = cdec.DecoderSpec(M=M, C=C, Cg=CG)
 dec = cdec.Decoder(spec, None, dev, seed=1)
 opt = optim.AdamTF(dec.params)
