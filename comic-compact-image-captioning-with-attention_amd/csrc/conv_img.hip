@@ -31,8 +31,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t img_rsrc(const void* p, uint32
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
 
-template <int TM, int TN, int WM, int WN, int CS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgArgs a) {
+// PD: k-steps the weight fragments are requested ahead of their use.  Measured (round 5, 1280 images): PD 4 / 6 and a second
+// pixel-fragment set read one step ahead are no faster where they fit the registers and slower where they spill; with ALL
+// weight loads or ALL pixel reads removed the kernel gains 4-10 %: the k loop was never the problem.  What was: one
+// workgroup of two images per CU (the LDS a pair needs) leaves the patch fill and the epilogue stores of every workgroup
+// exposed -- 27 us per workgroup for 11 us of MFMA work at 12x12 128 -> 192.  WM = 1 with ONE image per workgroup (four
+// waves, half the LDS) puts two workgroups on a CU: one's fill and stores run under the other's MFMAs, +15-25 %.
+// 160 output channels run on the 192-channel geometry (the tiles beyond Cout load zeros -- the buffer descriptor ends at Cout --
+// and are not stored): 17 % of the MFMAs wasted, still +16 % over 10 waves x 2 images; skipping the dead tiles' loads and
+// MFMAs with wave-uniform branches measured 15 % SLOWER than issuing them.
+// zeros behind the pixels: a masked lane reads at (its live address mod 256) + the channel step's immediate offset
+constexpr int img_zero_bytes(int cs) { return (256 + cs * 64 + 1023) / 1024 * 1024; }
+
+template <int TM, int TN, int WM, int WN, int CS, int PD = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 : 1)) void conv_img_kernel(const ComicImgArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int CPP = CS * 4;            // 16-byte chunks per pixel (Cin = 32 * CS)
   constexpr int PMAX = TM * WM * 16;     // pixel slots of the workgroup
@@ -46,7 +58,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   const int img0 = grp * a.G;
   const int P = min(a.G, a.B - img0) * HW;            // resident pixels of this workgroup
   const int PXBp = a.PXBp;
-  const uint32_t zoff = PMAX * PXBp;                  // 1 KiB of zeros behind the pixels
+  const uint32_t zoff = (PMAX * PXBp + 255) & ~255;    // zeros behind the pixels, 256-byte aligned
 
   // ---- patch fill: the G images are consecutive pixels of the NHWC source; every load of a thread is in flight before
   // its first LDS write (one memory latency for the whole patch, not one per pass) ----------------------------------------
@@ -69,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
-    if (tid < 64) *(uint4*)(smem + zoff + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int z = tid; z < img_zero_bytes(CS) / 16; z += NT) *(uint4*)(smem + zoff + z * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
 
   // ---- per-lane pixel state ------------------------------------------------------------------------------------------
@@ -112,31 +124,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
   const int tile_stride = a.KS32 * 1024;
   const int wbase = wn * TN * tile_stride;
   const int nsteps = taps * CS;
-  // software pipeline of depth 2: w0 = this step's fragments, w1 = the next step's, w2 = the loads issued now for the
-  // step after that.  The sched_barrier pins the loads at the top of the step (left alone, the scheduler sinks them
-  // behind the last MFMA that reads the register they overwrite and their latency is exposed).
-  img_u32x4 w0[TN], w1[TN], w2[TN];
+  // software pipeline of depth PD: wq[0] = this step's fragments, wq[d] = those of step s + d, wq[PD] = the loads issued now.
+  // The sched_barrier pins the loads at the top of the step (left alone, the scheduler sinks them behind the last MFMA
+  // that reads the register they overwrite and their latency is exposed).
+  img_u32x4 wq[PD + 1][TN];
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    w0[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + i * tile_stride, 0);
-    w1[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + min(1, nsteps - 1) * 1024 + i * tile_stride, 0);
-  }
+  for (int d = 0; d < PD; ++d)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      wq[d][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + min(d, nsteps - 1) * 1024 + i * tile_stride, 0);
 
   __syncthreads();                       // the patch is complete (the only barrier of the kernel)
 
-  int kh = 0, kw = 0, s = 0;
-  for (int t = 0; t < taps; ++t) {
+  auto tap_addrs = [&](int t, int kh, int kw, uint32_t (&ad)[TM]) {
     const int tapoff = ((kh - PT) * W + (kw - PL)) * PXBp;
-    uint32_t addr[TM];
 #pragma unroll
-    for (int j = 0; j < TM; ++j) addr[j] = ((mask[j] >> t) & 1u) ? pixaddr[j] + (uint32_t)tapoff : zoff + (uint32_t)(fg * 16);
+    for (int j = 0; j < TM; ++j) {
+      // a tap outside the image reads zeros AT THE BANKS ITS PIXEL WOULD HAVE USED (the zero page is a multiple of 256 bytes
+      // from the base): the lane groups of a ds_read_b128 stay conflict-free whatever the mix of inside / outside lanes.
+      // (One fixed zero address per quarter wave collided with a live lane's bank in most groups of the 1x7 / 7x1 edge taps:
+      // SQ_LDS_BANK_CONFLICT 27-39 % of the LDS cycles in profiles/r04_cnn_mfma_counters_1280.json.)
+      const uint32_t live = pixaddr[j] + (uint32_t)tapoff;
+      ad[j] = ((mask[j] >> t) & 1u) ? live : zoff + (live & 255u);
+    }
+  };
+  int kh = 0, kw = 0, s = 0;
+  uint32_t addr[TM];
+  uint4 xf[TM];
+  tap_addrs(0, 0, 0, addr);
+  for (int t = 0; t < taps; ++t) {
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) {
-      const int so = wbase + min(s + 2, nsteps - 1) * 1024;      // the last prefetches re-read the last step
+      const int so = wbase + min(s + PD, nsteps - 1) * 1024;      // the last prefetches re-read the last step
       ++s;
 #pragma unroll
-      for (int i = 0; i < TN; ++i) w2[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + i * tile_stride, 0);
-      uint4 xf[TM];
+      for (int i = 0; i < TN; ++i)
+        wq[PD][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, so + i * tile_stride, 0);
 #pragma unroll
       for (int j = 0; j < TM; ++j) xf[j] = *(const uint4*)(smem + addr[j] + cs * 64);
       __builtin_amdgcn_sched_barrier(0);
@@ -144,18 +167,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_img_kernel(const ComicImgAr
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w0[i]),
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wq[0][i]),
                                                               __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        w0[i] = w1[i];
-        w1[i] = w2[i];
-      }
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wq[d][i] = wq[d + 1][i];
     }
     if (++kw == KW) {
       kw = 0;
       ++kh;
     }
+    if (t + 1 < taps) tap_addrs(t + 1, kh, kw, addr);
   }
 
   // ---- epilogue: BatchNorm + ReLU + store, shared with the other bf16 conv kernels ----------------------------------
@@ -192,17 +215,17 @@ __global__ void pack_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restr
 struct ImgCfg { int HW, Cin, Cout, G; };
 // instantiations: (TM, TN, WM, WN, CS)
 constexpr ImgCfg kCfg[] = {
-    {144, 128, 192, 2}, {144, 160, 192, 2}, {144, 192, 192, 2},      // 0-2: 9,3,2,4,{4,5,6}
-    {144, 128, 128, 2},                                                // 3:   9,2,2,4,4
-    {144, 160, 160, 2},                                                // 4:   9,2,2,5,5
+    {144, 128, 192, 1}, {144, 160, 192, 1}, {144, 192, 192, 1},      // 0-2: 9,3,1,4,{4,5,6}
+    {144, 128, 128, 1},                                                // 3:   9,2,1,4,4
+    {144, 160, 160, 1},                                                // 4:   9,3,1,4,5 on the 192-channel geometry (ragged)
     {625, 64, 96, 1},  {625, 96, 96, 1},                               // 5-6: 10,3,4,2,{2,3}
     {25, 384, 384, 6}, {25, 448, 384, 6},                              // 7-8: 5,6,2,4,{12,14}
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int TM, int TN, int WM, int WN, int CS>
+template <int TM, int TN, int WM, int WN, int CS, int PD = 2>
 int launch_img(const ComicImgArgs& a, hipStream_t st) {
-  const int lds = TM * WM * 16 * a.PXBp + 1024;
+  const int lds = ((TM * WM * 16 * a.PXBp + 255) & ~255) + img_zero_bytes(CS);
   if (lds > 160 * 1024) {
     comic_set_error("conv_img: %d bytes of LDS", lds);
     return 2;
@@ -210,14 +233,14 @@ int launch_img(const ComicImgArgs& a, hipStream_t st) {
   static PerDeviceOnce attr_once__;
   bool& attr_set = attr_once__.slot();   // hipFuncSetAttribute holds per device
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_img_kernel<TM, TN, WM, WN, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_img_kernel<TM, TN, WM, WN, CS, PD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess) {
       comic_set_error("conv_img: cannot reserve %d bytes of LDS", lds);
       return 1;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_img_kernel<TM, TN, WM, WN, CS>), dim3(a.groups * a.n_members), dim3(64 * WM * WN), lds, st, a);
+  hipLaunchKernelGGL((conv_img_kernel<TM, TN, WM, WN, CS, PD>), dim3(a.groups * a.n_members), dim3(64 * WM * WN), lds, st, a);
   return 0;
 }
 
@@ -230,15 +253,19 @@ int comic_img_config(int H, int W, int Cin, int Cout, int KH, int KW, int SH, in
   return -1;
 }
 
-int comic_img_images_per_group(int cfg) { return (cfg >= 0 && cfg < kNumCfg) ? kCfg[cfg].G : 0; }
+int comic_img_images_per_group(int cfg) {
+  if (cfg < 0 || cfg >= kNumCfg) return 0;
+  return kCfg[cfg].G;
+}
+
 
 int comic_img_launch(int cfg, const ComicImgArgs& a, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_img<9, 3, 2, 4, 4>(a, st);
-    case 1: return launch_img<9, 3, 2, 4, 5>(a, st);
-    case 2: return launch_img<9, 3, 2, 4, 6>(a, st);
-    case 3: return launch_img<9, 2, 2, 4, 4>(a, st);
-    case 4: return launch_img<9, 2, 2, 5, 5>(a, st);
+    case 0: return launch_img<9, 3, 1, 4, 4>(a, st);
+    case 1: return launch_img<9, 3, 1, 4, 5>(a, st);
+    case 2: return launch_img<9, 3, 1, 4, 6>(a, st);
+    case 3: return launch_img<9, 2, 1, 4, 4>(a, st);
+    case 4: return launch_img<9, 3, 1, 4, 5>(a, st);      // 160 channels on the 192-channel geometry
     case 5: return launch_img<10, 3, 4, 2, 2>(a, st);
     case 6: return launch_img<10, 3, 4, 2, 3>(a, st);
     case 7: return launch_img<5, 6, 2, 4, 12>(a, st);
