@@ -11,7 +11,7 @@ struct ComicStemArgs {
   const float *sc1, *sh1, *sc2, *sh2;
   bf16_t* y;              // pooled output [B][Hp][Wp][y_cs], channels [y_co, y_co + 64)
   int y_cs, y_co, Hp, Wp;
-  int n_tasks;            // 2 * B: (image, half of the pooled rows)
+  int n_tasks, parts;     // set by comic_stem_stream_launch: tasks = (image, band of the pooled rows), bands per image
   // op kind 9 (Conv2d_1a_3x3 inside the pass): the fp32 image instead of x; null = kind 8
   const float* img;       // [B][Hi][Wi][3]
   int Hi, Wi;

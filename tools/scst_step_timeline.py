@@ -30,6 +30,7 @@ imgs = torch.from_numpy(rng.uniform(-1, 1, (Bs, IMG, IMG, 3)).astype(np.float32)
 iters = 29
 len_rng = np.random.default_rng(11)
 ahead = {}
+GRAPH = os.environ.get('GRAPH', '1') == '1'       # GRAPH=0: eager launches (visible to rocprofv3's kernel trace)
 
 def cut(ids2d):
     ids2d = np.array(ids2d, copy=True)
@@ -43,18 +44,18 @@ def step(T):
     if 'f' in ahead:
         im, fm = ahead.pop('f')
     else:
-        im, fm = enc.forward(imgs, use_graph=True); im, fm = im.clone(), fm.clone()
-    fb = dec.beam_search_ids(fm, im, W, iters); fg = dec.greedy(fm, im, iters, defer=True); mark()      # 1 enqueue rollouts
+        im, fm = enc.forward(imgs, use_graph=GRAPH); im, fm = im.clone(), fm.clone()
+    fb = dec.beam_search_ids(fm, im, W, iters, use_graph=GRAPH); fg = dec.greedy(fm, im, iters, defer=True, use_graph=GRAPH); mark()      # 1 enqueue rollouts
     beam = fb().transpose(2, 1, 0); mark()                                                                  # 2 wait beam
     cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]; mark()              # 3 beam text
     ids = captions_to_batched_ids(cap_beam, cfg, table); mark()                                             # 4 ids
     g = fg()[0]; mark()                                                                                     # 5 wait greedy
     cap_greedy = [[c] for c in id_to_caption(cut(g), cfg)]; mark()                                          # 6 greedy text
     imt, fmt = im.repeat(W, 1), fm.repeat(W, 1, 1)
-    dec.train_step(fmt, imt, ids, training=True, use_graph=True, phase='fwd'); mark()                       # 7 enqueue fwd
-    a, b = enc.forward(imgs, use_graph=True); ahead['f'] = (a.clone(), b.clone()); mark()                   # 8 enqueue encoder
+    dec.train_step(fmt, imt, ids, training=True, use_graph=GRAPH, phase='fwd'); mark()                       # 7 enqueue fwd
+    a, b = enc.forward(imgs, use_graph=GRAPH); ahead['f'] = (a.clone(), b.clone()); mark()                   # 8 enqueue encoder
     hyp, ss, sg = scorer.get_hypo_scores(refs, cap_beam, cap_greedy); mark()                                # 9 score
-    res = dec.train_step(None, None, ids, rewards=(ss - sg).astype(np.float32), training=True, use_graph=True, phase='bwd')
+    res = dec.train_step(None, None, ids, rewards=(ss - sg).astype(np.float32), training=True, use_graph=GRAPH, phase='bwd')
     opt.step(dec.grads, 1e-3); mark()                                                                       # 10 enqueue bwd
     torch.cuda.synchronize(); mark()                                                                        # 11 drain
     T.append(np.diff(t) * 1e3)
