@@ -584,6 +584,7 @@ typedef struct CacheEntry {
   comic_jpeg_info info;
   uint16_t* packed;                // the packed form of decode_scan_packed
   int64_t n_u16;
+  int64_t file_size, mtime_ns;     // of the file when it was decoded: a file that changed since is decoded again
   struct CacheEntry* next;
 } CacheEntry;
 
@@ -599,6 +600,14 @@ static uint64_t path_hash(const char* s) {
   return h;
 }
 
+static int file_stamp(const char* path, int64_t* size, int64_t* mtime_ns) {
+  struct stat st;
+  if (stat(path, &st)) return -1;
+  *size = (int64_t)st.st_size;
+  *mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+  return 0;
+}
+
 static const CacheEntry* cache_lookup(CoefCache* c, const char* path) {
   if (!c || !c->buckets) return NULL;
   const uint64_t h = path_hash(path);
@@ -606,7 +615,11 @@ static const CacheEntry* cache_lookup(CoefCache* c, const char* path) {
   const CacheEntry* e = c->buckets[h % (uint64_t)c->n_buckets];
   while (e && !(e->hash == h && !strcmp(e->path, path))) e = e->next;
   pthread_rwlock_unlock(&c->lock);
-  if (e) __atomic_fetch_add(&c->hits, 1, __ATOMIC_RELAXED);
+  if (e) {                         // served only while the file is the one that was decoded (size and modification time)
+    int64_t size = 0, mt = 0;
+    if (file_stamp(path, &size, &mt) || size != e->file_size || mt != e->mtime_ns) return NULL;
+    __atomic_fetch_add(&c->hits, 1, __ATOMIC_RELAXED);
+  }
   return e;
 }
 
@@ -677,6 +690,10 @@ static void cache_insert(CoefCache* c, const char* path, const comic_jpeg_info* 
   e->info.coef_base = e->info.pixel_off = 0;
   e->packed = packed;
   e->n_u16 = n_u16;
+  if (file_stamp(path, &e->file_size, &e->mtime_ns)) {      // (gone since it was read: nothing to key the entry by)
+    free(e->path); free(e->packed); free(e);
+    return;
+  }
   pthread_rwlock_wrlock(&c->lock);
   CacheEntry** slot = &c->buckets[e->hash % (uint64_t)c->n_buckets];
   const CacheEntry* dup = *slot;

@@ -93,7 +93,9 @@ void* comic_jpeg_pool_submit_packed(comic_jpeg_pool* pool, const char* const* pa
 /* Coefficient cache of a pool (off by default): every image a batch has decoded is kept -- as its non-zero coefficients, about
  * the size of the JPEG file -- under its path until `max_bytes` are in use (nothing is evicted; call before the first submit -- switching it ON while batches are
  * queued is refused with COMIC_JPEG_UNSUPPORTED -- or again to move the limit).  A later batch that names the path again gets the coefficients from memory: no file read, no Huffman
- * decoding -- the epochs after the first run at the speed of a memory copy.  The files are assumed not to change while cached.
+ * decoding -- the epochs after the first run at the speed of a memory copy.  An entry is served only while the file's size and
+ * modification time are those of the decode that made it (one stat per hit); a file rewritten since is decoded from disk
+ * (its old entry stays: nothing is evicted).
  * Augmentation (flip, crop) happens on the device, behind the decode, so cached training batches are the bits of uncached ones. */
 int comic_jpeg_pool_enable_cache(comic_jpeg_pool* pool, int64_t max_bytes);
 int comic_jpeg_pool_cache_stats(comic_jpeg_pool* pool, int64_t* bytes, int64_t* entries, int64_t* hits);

@@ -294,8 +294,9 @@ def test_packed_batches_hold_the_coefficients_of_the_dense_decode(tmp_path):
 
 
 def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
-    """comic_jpeg_pool_enable_cache: the batches of a second pass over the files come from the cache (hits counted, files may
-    even be gone) with the coefficients of the first pass, bit for bit; the byte limit stops insertion, nothing is evicted."""
+    """comic_jpeg_pool_enable_cache: the batches of a second pass over the files come from the cache (hits counted) with the
+    coefficients of the first pass, bit for bit; a file REWRITTEN since (other size / modification time) is decoded from disk
+    again, not served stale; the byte limit stops insertion, nothing is evicted."""
     lib = L.load_jpeg()
     paths = []
     for i in range(9):
@@ -322,8 +323,6 @@ def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
     i1, s1, c1 = run(pool, paths)
     b, e, h = stats(pool)
     assert (s1 == 0).all() and e == 9 and h == 0 and 0 < b < c1.size * 2          # packed: smaller than the dense blocks
-    for p in paths[:4]:
-        os.remove(p)                                                               # the cache does not need the files
     i2, s2, c2 = run(pool, paths)
     assert (s2 == 0).all() and stats(pool)[2] == 9 and np.array_equal(c1, c2)
     for f in ('width', 'height', 'coef_count', 'coef_base', 'pixel_off', 'quant', 'comp_w', 'blocks_w'):
@@ -334,6 +333,14 @@ def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
         j = paths.index(p)
         a = c3[int(i3['coef_base'][k]):int(i3['coef_base'][k]) + int(i3['coef_count'][k])]
         assert np.array_equal(a, c1[int(i1['coef_base'][j]):int(i1['coef_base'][j]) + int(i1['coef_count'][j])]), p
+    # a file rewritten under the same path: its entry is not served any more, the eight others are
+    hits0 = stats(pool)[2]
+    open(paths[0], 'wb').write(_encode(_photo(33, 47, seed=77), quality=80, subsampling=0))
+    i4, s4, c4 = run(pool, paths)
+    assert (s4 == 0).all() and stats(pool)[2] == hits0 + 8
+    assert (int(i4['width'][0]), int(i4['height'][0])) == (47, 33) and (int(i1['width'][0]), int(i1['height'][0])) == (60, 40)
+    for f in ('width', 'height', 'coef_count'):
+        assert np.array_equal(i1[f][1:], i4[f][1:]), f
     lib.comic_jpeg_pool_destroy(pool)
     # a limit that holds about two images: insertion stops there
     pool = lib.comic_jpeg_pool_create(2)
