@@ -1296,6 +1296,8 @@ class CnnEncoder:
                 cands.append((timed(reps), tile))
             # the minimum over ~50 noisy measurements favours lucky ones: the three fastest are timed again, longer
             cands.sort()
+            if verbose and os.environ.get('COMIC_TUNE_DUMP') == '1':      # every candidate of the launch, fastest first
+                print('   candidates op %3d: %s' % (i, ' '.join('%d:%.0f' % (t, us * 1e3) for us, t in cands[:14])))
             finals = []
             for _, tile in cands[:3]:
                 op.tile = tile
