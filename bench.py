@@ -954,7 +954,7 @@ def main():
             'frac': round(dec_bytes / (dec_ms * 1e-3) / 8e12, 5), 'loops_persistent': dec_path,
             'note': 'the chain is latency-bound, not bandwidth-bound: 2 x T\' dependent phases of three to four '
                     'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
-        for tname in ('r04_cnn_hbm_traffic.json', 'r03_cnn_hbm_traffic.json'):   # committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+        for tname in ('r05_cnn_hbm_traffic.json', 'r04_cnn_hbm_traffic.json', 'r03_cnn_hbm_traffic.json'):   # committed PMC passes (FETCH_SIZE / WRITE_SIZE,
             tfile = os.path.join(ROOT, 'profiles', tname)                         # corrected per the microarch guide), newest first
             tj = (json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH)) if os.path.isfile(tfile) else None)
             if tj:

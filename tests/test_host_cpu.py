@@ -5,6 +5,7 @@ import json
 import os
 import pickle
 import re
+import sys
 import types
 
 import numpy as np
@@ -707,3 +708,32 @@ def test_gradient_clip_chunk_table():
         assert rows[:, 2].sum() == n and (rows[:, 2] <= 8192).all()
         assert (rows[:, 3] == np.flatnonzero(t[:, 0] == seg)[0]).all() and (rows[:, 4] == len(rows)).all()
         assert rows[0, 1] == p.offsets[k] and (np.diff(rows[:, 1]) == 8192).all()
+
+
+def test_bench_gpus_n_builds_the_launcher_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE): bench.launch_ranks starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same
+    arguments>` as a CHILD process (never an exec) and hands back its exit code; main() takes that branch before torch is
+    imported (the launcher process must not touch the GPU)."""
+    import importlib
+    import subprocess
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '20', '--warmup', '5'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 0 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
