@@ -3064,6 +3064,119 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
   store_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
 }
 
+
+// MaxPoolGrad of the 3x3 / stride-2 pools (MaxPool_3a / 5a and the pool branches of Mixed_6a / 7a; VALID or padded), tiled
+// through the LDS.  The gather kernel above re-derives a window's arg-max once per input pixel it covers: up to four
+// windows x nine 16-byte loads per thread -- 136 us per pool at 32 images (profiles/r05_finetune_lanes.txt: 6.5 % of the
+// step's chain lane for two element-wise ops).  Here a workgroup owns a 16 x 16 tile of INPUT pixels and CG channel chunks:
+//   1. the <= 19 x 19 input pixels its <= 9 x 9 windows read go to the LDS once (taps outside the image: -inf);
+//   2. one thread per (window, chunk) finds the arg-max per channel -- FIRST maximum in (kh, kw) scan order, strict >, as
+//      the gather kernel and TF's MaxPoolGrad -- and keeps (tap index per channel, the window's dy chunk) in the LDS;
+//   3. one thread per (input pixel, chunk) adds the dy of its <= 4 windows whose arg-max it is, in (ho, wo) order, into dx.
+// Same comparisons, same sums in the same order as pool_grad_kernel<T, 0>: identical bits.
+constexpr int kMpgTile = 16, kMpgWin = kMpgTile / 2 + 1, kMpgX = 2 * kMpgWin + 1, kMpgCG = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_grad_s2_kernel(PoolGradArgs a, int tiles_y, int tiles_x, int cgroups) {
+  constexpr int EPC = Elem<T>::EPC;
+  __shared__ uint4 xs[kMpgCG][kMpgX * kMpgX];                           // raw 16-byte chunks of the input pixels
+  __shared__ __attribute__((aligned(16))) float dys[kMpgCG][kMpgWin * kMpgWin][EPC];
+  __shared__ __attribute__((aligned(8))) unsigned char args[kMpgCG][kMpgWin * kMpgWin][8];
+  int bid = blockIdx.x;
+  const int cgi = bid % cgroups; bid /= cgroups;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int tid = threadIdx.x;
+  const int cvecs = a.C / EPC;
+  const int cv0 = cgi * kMpgCG, ncv = min(kMpgCG, cvecs - cv0);
+  const int y0 = ty * kMpgTile, x0 = tx * kMpgTile;
+  // windows that touch the tile: ho * 2 - PT <= y <= ho * 2 - PT + 2 for some y in [y0, y0 + 16)
+  const int ho_lo = max(0, (y0 + a.PT - 1) >> 1), ho_hi = min(a.Ho - 1, (min(a.H, y0 + kMpgTile) - 1 + a.PT) >> 1);
+  const int wo_lo = max(0, (x0 + a.PL - 1) >> 1), wo_hi = min(a.Wo - 1, (min(a.W, x0 + kMpgTile) - 1 + a.PL) >> 1);
+  const int nho = ho_hi - ho_lo + 1, nwo = wo_hi - wo_lo + 1;        // <= kMpgWin each (may be <= 0 at a ragged edge)
+  const int xr0 = 2 * ho_lo - a.PT, xc0 = 2 * wo_lo - a.PL;          // input pixel of LDS position (0, 0)
+  const int nxr = 2 * nho + 1, nxc = 2 * nwo + 1;
+  const bool any = nho > 0 && nwo > 0;
+  const uint32_t ninf = sizeof(T) == 2 ? 0xFF80FF80u : 0xFF800000u;  // -inf in every element of a chunk
+  if (any) {
+    for (int i = tid; i < nxr * nxc * ncv; i += 256) {
+      const int c = i % ncv, px = i / ncv;
+      const int r = px / nxc, q = px - r * nxc;
+      const int h = xr0 + r, w = xc0 + q;
+      uint4 v = make_uint4(ninf, ninf, ninf, ninf);
+      if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = *(const uint4*)((const T*)a.x + ((size_t)(b * a.H + h) * a.W + w) * a.xcs + a.xco + (cv0 + c) * EPC);
+      xs[c][r * kMpgX + q] = v;
+    }
+  }
+  __syncthreads();
+  if (any) {
+    for (int i = tid; i < nho * nwo * ncv; i += 256) {
+      const int c = i % ncv, wdx = i / ncv;
+      const int wr = wdx / nwo, wq = wdx - wr * nwo;
+      float best[EPC];
+      uint32_t arg[EPC];
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) { best[j] = -INFINITY; arg[j] = 255u; }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float v[EPC];
+          load_vec<T>((const T*)&xs[c][(2 * wr + kh) * kMpgX + 2 * wq + kw], v);
+#pragma unroll
+          for (int j = 0; j < EPC; ++j)
+            if (v[j] > best[j]) { best[j] = v[j]; arg[j] = kh * 3 + kw; }
+        }
+      float dyv[EPC];
+      load_chunk_f<T>(a.dy, ((size_t)(b * a.Ho + ho_lo + wr) * a.Wo + wo_lo + wq) * a.ycs + a.yco + (cv0 + c) * EPC, a.dy_f32 != 0, dyv);
+      const int slot = wr * kMpgWin + wq;
+#pragma unroll
+      for (int j = 0; j < EPC; j += 4) *(float4*)&dys[c][slot][j] = make_float4(dyv[j], dyv[j + 1], dyv[j + 2], dyv[j + 3]);
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        if (j < 4) lo |= arg[j] << (8 * j); else hi |= arg[j] << (8 * (j - 4));
+      }
+      *(uint2*)args[c][slot] = make_uint2(lo, hi);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kMpgTile * kMpgTile * ncv; i += 256) {
+    const int c = i % ncv, px = i / ncv;
+    const int hi = y0 + px / kMpgTile, wi = x0 + px % kMpgTile;
+    if (hi >= a.H || wi >= a.W) continue;
+    float g[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) g[j] = 0.f;
+    const int h_lo = max(0, (hi + a.PT - 1) >> 1), h_hi = min(a.Ho - 1, (hi + a.PT) >> 1);
+    const int w_lo = max(0, (wi + a.PL - 1) >> 1), w_hi = min(a.Wo - 1, (wi + a.PL) >> 1);
+    for (int ho = h_lo; ho <= h_hi; ++ho)
+      for (int wo = w_lo; wo <= w_hi; ++wo) {
+        const uint32_t mine = (uint32_t)((hi - (2 * ho - a.PT)) * 3 + (wi - (2 * wo - a.PL)));
+        const int slot = (ho - ho_lo) * kMpgWin + (wo - wo_lo);
+        const uint2 ab = *(const uint2*)args[c][slot];
+        float dv[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; j += 4) {
+          const float4 t = *(const float4*)&dys[c][slot][j];
+          dv[j] = t.x; dv[j + 1] = t.y; dv[j + 2] = t.z; dv[j + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const uint32_t aj = j < 4 ? (ab.x >> (8 * j)) & 255u : (ab.y >> (8 * (j - 4))) & 255u;
+          if (aj == mine) g[j] += dv[j];
+        }
+      }
+    const size_t off = ((size_t)(b * a.H + hi) * a.W + wi) * a.xcs + a.xco + (cv0 + c) * EPC;
+    float old[EPC];
+    load_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) old[j] += g[j];
+    store_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
+  }
+}
+
 // workgroups per backward-weight launch that the pixel split aims for (every split adds one fp32
 // atomic pass over the filter; fewer splits measured slower)
 int wgrad_blocks_target() { return 1024; }
@@ -3226,7 +3339,13 @@ int pool_backward(const comic_cnn_op* op, const void* x, int xc, const void* gy,
                  batch, op->H, op->W, op->Cin, op->KH, op->KW, op->SH, op->SW, op->PT, op->PL, op->Ho, op->Wo};
   const long total = (long)batch * op->H * op->W * (op->Cin / EPC);
   dim3 grid((unsigned)cdiv64(total, 256));
-  if (op->kind == 2)
+  if (op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 2 && op->SW == 2 && op->PT >= 0 && op->PT <= 1 && op->PL >= 0 &&
+      op->PL <= 1) {
+    const int tiles_y = cdiv(op->H, kMpgTile), tiles_x = cdiv(op->W, kMpgTile), cgroups = cdiv(op->Cin / EPC, kMpgCG);
+    const long wgs = (long)batch * tiles_y * tiles_x * cgroups;
+    COMIC_REQUIRE(wgs < (1L << 31), "pool backward: too many tiles");
+    hipLaunchKernelGGL((maxpool_grad_s2_kernel<T>), dim3((unsigned)wgs), dim3(256), 0, st, a, tiles_y, tiles_x, cgroups);
+  } else if (op->kind == 2)
     hipLaunchKernelGGL((pool_grad_kernel<T, 0>), grid, dim3(256), 0, st, a);
   else if (op->kind == 3)
     hipLaunchKernelGGL((pool_grad_kernel<T, 1>), grid, dim3(256), 0, st, a);
