@@ -566,14 +566,17 @@ def backward_schedule(plan):
                 ln = 0 if load[0] <= load[1] else 1
                 lanes[b] = ln
                 load[ln] += weight[b]
-        forked = False
+        # the fork goes in FRONT of the block's first op: lane 1's branches only need what precedes the block (the join of the
+        # block behind it).  The ops of a block are walked deepest first, so a fork at the first lane-1 op came after the
+        # deepest two or three convs of lane 0's branch -- lane 1 then sat out half of lane 0's chain and the lanes ran one
+        # after the other (profiles/r05_finetune_lanes.txt: one kernel in flight for 3.6 of 5.9 ms)
+        forked = any(ln == 1 for ln in lanes.values())
+        if forked:
+            rows.append((SCHED_FORK, 0, 0, 0))
         blk_in = None
         for i in idx:
             o = plan.ops[i]
             ln = lanes.get(o.get('branch'), 0)
-            if ln == 1 and not forked:
-                rows.append((SCHED_FORK, 0, 0, 0))
-                forked = True
             alt = 0
             if ln == 1 and o.get('block_in') is not None and o['src'] == o['block_in'] and o['src'] != plan.input:
                 alt, blk_in = 1, o['src']
