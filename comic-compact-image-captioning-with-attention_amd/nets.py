@@ -561,7 +561,9 @@ def backward_schedule(plan):
         lanes = {}
         if len(br) >= 2:
             load = [0, 0]
-            weight = {b: sum(1 + (plan.ops[i]['kind'] <= 1) for i in idx if plan.ops[i].get('branch') == b) for b in br}
+            # launches of a branch's chain: one per op (the activation gradients of its inner convs ride in the backward-data
+            # epilogue of their reader) + the activation gradient of the conv that writes the block's output slice
+            weight = {b: 1 + sum(1 for i in idx if plan.ops[i].get('branch') == b) for b in br}
             for b in sorted(br, key=lambda b: -weight[b]):
                 ln = 0 if load[0] <= load[1] else 1
                 lanes[b] = ln
