@@ -54,7 +54,7 @@ def extras(device, enc, cnn_params, plan):
     step, batch 32).  Synthetic inputs; single GPU."""
     import torch
     from comic_amd import decoder as cdec, nets, optim
-    from comic_amd.ops import id_to_caption, captions_to_batched_ids, build_radix_wtoi
+    from comic_amd.ops import id_to_caption, radix_ids_to_captions_and_ids, build_radix_wtoi
     from comic_amd.scst.scorers import captionScorer
     from comic_amd.scst import prepro_ngrams
     import types
@@ -173,8 +173,8 @@ def extras(device, enc, cnn_params, plan):
         fetch_beam = dec.beam_search_ids(fm, im, W, iters)
         fetch_greedy = dec.greedy(fm, im, iters, defer=True)
         beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
-        cap_beam = [[c] for c in id_to_caption(beam.reshape(-1, beam.shape[-1]), cfg)]
-        ids = captions_to_batched_ids(cap_beam, cfg, table)
+        caps, ids = radix_ids_to_captions_and_ids(beam.reshape(-1, beam.shape[-1]), cfg, table)     # (as train_fn's SCST loop)
+        cap_beam = [[c] for c in caps]
         cap_greedy = [[c] for c in id_to_caption(fetch_greedy()[0], cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)     # = encoder(imgs tiled W times): frozen CNN, run once
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
@@ -242,8 +242,8 @@ def extras(device, enc, cnn_params, plan):
         fetch_beam = dec.beam_search_ids(fm, im, W, real_iters)
         fetch_greedy = dec.greedy(fm, im, real_iters, defer=True)
         beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
-        cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]
-        ids = captions_to_batched_ids(cap_beam, cfg, table)
+        caps, ids = radix_ids_to_captions_and_ids(cut(beam.reshape(-1, beam.shape[-1])), cfg, table)
+        cap_beam = [[c] for c in caps]
         cap_greedy = [[c] for c in id_to_caption(cut(fetch_greedy()[0]), cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')

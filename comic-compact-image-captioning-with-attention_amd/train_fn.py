@@ -13,7 +13,7 @@ import numpy as np
 
 from . import configuration as conf
 from . import inputs, model as mdl
-from .ops import id_to_caption
+from .ops import id_to_caption, radix_ids_to_captions_and_ids
 from .scst.scorers import captionScorer
 
 pjoin = os.path.join
@@ -162,12 +162,18 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
         # (the greedy rollout runs on the device while the host turns the beam rollouts into text and ids)
         cap_beam, fetch_greedy = m_sample.sample(imgs, defer_greedy=True)
         cap_beam = np.reshape(cap_beam, [-1, cap_beam.shape[-1]])
-        cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
         # every sampled hypothesis is trained on (get_hypo_scores returns `sample` itself), so the update's forward pass --
         # which no reward enters -- is enqueued BEFORE the host scores the rollouts and runs on the device meanwhile.
         # The reference feeds the images tiled by the beam size (train_fn.py:251-253); the CNN is frozen and
         # deterministic, so the encoder runs once and its two outputs are tiled instead
-        hypos_idx = inputs_man.captions_to_batched_ids(cap_beam)
+        if c.token_type == 'radix' and getattr(inputs_man, 'radix_wtoi', None) is not None:
+            # ids -> text -> target ids in one pass (equal to the two calls; the host work between the rollouts and the
+            # update's forward pass is what the device waits for)
+            caps, hypos_idx = radix_ids_to_captions_and_ids(cap_beam, c, inputs_man.radix_wtoi)
+            cap_beam = [[s] for s in caps]
+        else:
+            cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
+            hypos_idx = inputs_man.captions_to_batched_ids(cap_beam)
         cap_greedy = [[s] for s in id_to_caption(fetch_greedy(), c)]
         m_train.begin_train_scst(imgs, hypos_idx, tile=c.scst_beam_size)
         # the next batch's encoder forward joins the update's forward pass on the device while the host scores

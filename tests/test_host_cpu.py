@@ -737,3 +737,50 @@ def test_bench_gpus_n_builds_the_launcher_command(monkeypatch):
     i = cmd.index(os.path.join(ROOT, 'bench.py'))
     assert cmd[i + 1:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_radix_round_trip_equals_the_two_conversions():
+    """ops.radix_ids_to_captions_and_ids (the SCST loop's ids -> text -> target ids in one pass) == id_to_caption followed by
+    captions_to_batched_ids, on random rollouts: invalid digits, <GO> / <EOS> in the middle, odd digit counts, empty captions,
+    word ids that decode to the special tokens or beyond the vocabulary (a KeyError in both), one- and two-digit words."""
+    def mk(nw, base):
+        wtoi = {'<PAD>': -1}
+        for i in range(nw):
+            wtoi['w%d' % i] = i
+        for tok in ('<UNK>', '<GO>', '<EOS>'):
+            wtoi[tok] = len(wtoi) - 1
+        cfg = types.SimpleNamespace(token_type='radix', radix_base=base, wtoi=wtoi, itow={str(v): k for k, v in wtoi.items()})
+        return cfg, ops.build_radix_wtoi(wtoi, base)
+    rng = np.random.default_rng(5)
+    for nw, base in ((10000, 256), (200, 256), (60000, 256), (100, 16), (9, 16)):
+        cfg, table = mk(nw, base)
+        for trial in range(25):
+            N, T = int(rng.integers(1, 30)), int(rng.integers(1, 41))
+            ids = rng.integers(-1, base + 2, (N, T))
+            if trial % 3 == 0:
+                ids[:, T // 2:] = base + 1
+            if trial % 5 == 0:
+                ids[0] = base + 1
+            if trial % 7 == 0:
+                ids = np.clip(ids, 0, 3)
+            try:
+                caps, err = ops.id_to_caption(ids, cfg), None
+                want = ops.captions_to_batched_ids([[c] for c in caps], cfg, table)
+            except KeyError as e:
+                err = str(e)
+            try:
+                caps2, got = ops.radix_ids_to_captions_and_ids(ids, cfg, table)
+                err2 = None
+            except KeyError as e:
+                err2 = str(e)
+            assert err == err2
+            if err is None:
+                assert caps == caps2 and want.shape == got.shape and (want == got).all()
+    # a vocabulary where join + split is not the identity takes the two calls
+    cfg, table = mk(50, 16)
+    cfg.itow['3'] = 'two words'
+    cfg.wtoi['two words'] = 3
+    table = ops.build_radix_wtoi(cfg.wtoi, 16)
+    ids = np.array([[0, 3, 0, 5, 17, -1]])
+    caps, got = ops.radix_ids_to_captions_and_ids(ids, cfg, table)
+    assert caps == ops.id_to_caption(ids, cfg) and (got == ops.captions_to_batched_ids([[c] for c in caps], cfg, table)).all()

@@ -4,7 +4,7 @@ import os, sys, time, types
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 from comic_amd import decoder as cdec, nets, optim
-from comic_amd.ops import id_to_caption, captions_to_batched_ids, build_radix_wtoi
+from comic_amd.ops import id_to_caption, radix_ids_to_captions_and_ids, build_radix_wtoi
 from comic_amd.scst.scorers import captionScorer
 from comic_amd.scst import prepro_ngrams
 device = 'cuda:0'
@@ -47,8 +47,8 @@ def step(T):
         im, fm = enc.forward(imgs, use_graph=GRAPH); im, fm = im.clone(), fm.clone()
     fb = dec.beam_search_ids(fm, im, W, iters, use_graph=GRAPH); fg = dec.greedy(fm, im, iters, defer=True, use_graph=GRAPH); mark()      # 1 enqueue rollouts
     beam = fb().transpose(2, 1, 0); mark()                                                                  # 2 wait beam
-    cap_beam = [[c] for c in id_to_caption(cut(beam.reshape(-1, beam.shape[-1])), cfg)]; mark()              # 3 beam text
-    ids = captions_to_batched_ids(cap_beam, cfg, table); mark()                                             # 4 ids
+    caps, ids = radix_ids_to_captions_and_ids(cut(beam.reshape(-1, beam.shape[-1])), cfg, table); mark()     # 3 beam text + ids
+    cap_beam = [[c] for c in caps]; mark()                                                                  # 4 (lists)
     g = fg()[0]; mark()                                                                                     # 5 wait greedy
     cap_greedy = [[c] for c in id_to_caption(cut(g), cfg)]; mark()                                          # 6 greedy text
     imt, fmt = im.repeat(W, 1), fm.repeat(W, 1, 1)
