@@ -175,9 +175,9 @@ def extras(device, enc, cnn_params, plan):
         beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
         caps, ids = radix_ids_to_captions_and_ids(beam.reshape(-1, beam.shape[-1]), cfg, table)     # (as train_fn's SCST loop)
         cap_beam = [[c] for c in caps]
-        cap_greedy = [[c] for c in id_to_caption(fetch_greedy()[0], cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)     # = encoder(imgs tiled W times): frozen CNN, run once
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        cap_greedy = [[c] for c in id_to_caption(fetch_greedy()[0], cfg)]
         encode_ahead()
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)
         res = dec.train_step(None, None, ids, rewards=(sc_s - sc_g).astype(np.float32), training=True, use_graph=True, phase='bwd')
@@ -244,9 +244,9 @@ def extras(device, enc, cnn_params, plan):
         beam = fetch_beam().transpose(2, 1, 0)             # (W,B,T)
         caps, ids = radix_ids_to_captions_and_ids(cut(beam.reshape(-1, beam.shape[-1])), cfg, table)
         cap_beam = [[c] for c in caps]
-        cap_greedy = [[c] for c in id_to_caption(cut(fetch_greedy()[0]), cfg)]
         im, fm = im.repeat(W, 1), fm.repeat(W, 1, 1)
         dec.train_step(fm, im, ids, training=True, use_graph=True, phase='fwd')
+        cap_greedy = [[c] for c in id_to_caption(cut(fetch_greedy()[0]), cfg)]
         if not feats:
             encode_group()
         hypos, sc_s, sc_g = scorer.get_hypo_scores(refs, cap_beam, cap_greedy)

@@ -619,7 +619,7 @@ class Decoder:
         attn_maps [B,H,T_exec,M] (device), logits [B,T_exec,V] or None.
         defer: only enqueue the loop and return a function that fetches the result (the SCST step converts the beam
         rollouts to text on the host while this loop runs)."""
-        s = self.spec
+        torch, s = self.torch, self.spec
         B = fm.shape[0]
         ctx = self._infer_ctx('greedy', B, 1, max_steps, want_logits, fm, im_embed)
 
@@ -630,13 +630,31 @@ class Decoder:
                                                   L.ptr(ctx.logits), ctx.hist.data_ptr(), ctx.first_eos.data_ptr(),
                                                   ctx.ws.data_ptr(), ctx.nbytes, L.stream_ptr()), 'decoder_greedy')
         self._run_infer(ctx, launch, use_graph)
+        if defer:
+            # the ids leave through pinned memory behind an event of their own (as beam_search_ids): the fetch then waits for
+            # the rollout, not for whatever the caller has enqueued behind it in the meantime (the SCST step enqueues the
+            # update's forward pass before it looks at the greedy captions)
+            if getattr(ctx, 'ids_host', None) is None:
+                ctx.ids_host = torch.empty((max_steps, B), dtype=torch.int32).pin_memory()
+                ctx.eos_host = torch.empty(B, dtype=torch.int32).pin_memory()
+                ctx.fetched = torch.cuda.Event()
+            ctx.ids_host.copy_(ctx.ids, non_blocking=True)
+            ctx.eos_host.copy_(ctx.first_eos, non_blocking=True)
+            ctx.fetched.record(torch.cuda.current_stream())
 
         def fetch():
-            fe = ctx.first_eos.cpu().numpy()
+            if defer:
+                ctx.fetched.synchronize()
+                fe = ctx.eos_host.numpy()
+            else:
+                fe = ctx.first_eos.cpu().numpy()
             if fe.min() < 0:                              # comic_persist_check_greedy: a bounded wait of the loop expired
                 raise L.ComicHipError('greedy: the persistent decode loop did not complete (a wait on another workgroup timed out)')
             t_exec = int(min(max_steps, fe.max() + 1))   # loop ends when every row has emitted EOS
-            out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
+            if defer:
+                out_ids = np.ascontiguousarray(ctx.ids_host[:t_exec].numpy().T)
+            else:
+                out_ids = ctx.ids[:t_exec].t().contiguous().cpu().numpy()
             hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
             return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
         return fetch if defer else fetch()

@@ -174,8 +174,10 @@ def _scst_loop(inputs_man, idx_ngram, device, dp):
         else:
             cap_beam = [[s] for s in id_to_caption(cap_beam, c)]
             hypos_idx = inputs_man.captions_to_batched_ids(cap_beam)
-        cap_greedy = [[s] for s in id_to_caption(fetch_greedy(), c)]
+        # the update's forward pass goes to the device BEFORE the host looks at the greedy rollout (which is still running:
+        # its ids come back through an event of their own), so the device runs rollouts and update back to back
         m_train.begin_train_scst(imgs, hypos_idx, tile=c.scst_beam_size)
+        cap_greedy = [[s] for s in id_to_caption(fetch_greedy(), c)]
         # the next batch's encoder forward joins the update's forward pass on the device while the host scores
         if group > 1:
             if not queue and step + 1 < c.max_step:

@@ -49,10 +49,10 @@ def step(T):
     beam = fb().transpose(2, 1, 0); mark()                                                                  # 2 wait beam
     caps, ids = radix_ids_to_captions_and_ids(cut(beam.reshape(-1, beam.shape[-1])), cfg, table); mark()     # 3 beam text + ids
     cap_beam = [[c] for c in caps]; mark()                                                                  # 4 (lists)
-    g = fg()[0]; mark()                                                                                     # 5 wait greedy
-    cap_greedy = [[c] for c in id_to_caption(cut(g), cfg)]; mark()                                          # 6 greedy text
     imt, fmt = im.repeat(W, 1), fm.repeat(W, 1, 1)
-    dec.train_step(fmt, imt, ids, training=True, use_graph=GRAPH, phase='fwd'); mark()                       # 7 enqueue fwd
+    dec.train_step(fmt, imt, ids, training=True, use_graph=GRAPH, phase='fwd'); mark()                       # 5 enqueue fwd
+    g = fg()[0]; mark()                                                                                     # 6 wait greedy
+    cap_greedy = [[c] for c in id_to_caption(cut(g), cfg)]; mark()                                          # 7 greedy text
     a, b = enc.forward(imgs, use_graph=GRAPH); ahead['f'] = (a.clone(), b.clone()); mark()                   # 8 enqueue encoder
     hyp, ss, sg = scorer.get_hypo_scores(refs, cap_beam, cap_greedy); mark()                                # 9 score
     res = dec.train_step(None, None, ids, rewards=(ss - sg).astype(np.float32), training=True, use_graph=GRAPH, phase='bwd')
@@ -66,7 +66,7 @@ for _ in range(4):
 torch.cuda.synchronize()
 for _ in range(8):
     step(T)
-names = ['enqueue rollouts', 'wait beam', 'beam text', 'ids', 'wait greedy', 'greedy text', 'enqueue fwd', 'enqueue encoder',
+names = ['enqueue rollouts', 'wait beam', 'beam text + ids', 'lists', 'enqueue fwd', 'wait greedy', 'greedy text', 'enqueue encoder',
          'score', 'enqueue bwd+opt', 'drain']
 m = np.mean(T, axis=0)
 print('  '.join('%s %.2f' % (n, v) for n, v in zip(names, m)), '| step %.2f ms' % m.sum())
