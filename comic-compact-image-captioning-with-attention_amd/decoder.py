@@ -561,13 +561,13 @@ class Decoder:
             it *= 5
         return it
 
-    def _infer_ctx(self, kind, B, W, max_steps, want_logits, fm, im_embed):
+    def _infer_ctx(self, kind, B, W, max_steps, want_logits, fm, im_embed, slot=0):
         """Persistent buffers (+ a hipGraph of the whole decode loop, captured on the second call
         with the same shape) of greedy / beam decoding: the executors run all `max_steps` steps on
         the device without host synchronisation, so one graph launch replaces ~8 kernel launches
         per step of host work."""
         torch, s = self.torch, self.spec
-        key = (kind, B, W, max_steps, bool(want_logits))
+        key = (kind, B, W, max_steps, bool(want_logits), int(slot))      # slot: independent buffer sets (decodes in flight on several streams)
         ctxs = self.__dict__.setdefault('_infer_ctxs', {})
         ctx = ctxs.get(key)
         if ctx is None:
@@ -685,7 +685,7 @@ class Decoder:
         hist = ctx.hist[:t_exec].reshape(t_exec, B, s.H, s.M).permute(1, 2, 0, 3).clone()
         return out_ids, hist, (ctx.logits[:t_exec].permute(1, 0, 2).clone() if want_logits else None)
 
-    def beam_search_ids(self, fm, im_embed, beam, max_steps, use_graph=True):
+    def beam_search_ids(self, fm, im_embed, beam, max_steps, use_graph=True, slot=0):
         """Beam search for its predicted ids alone, fetched WITHOUT draining the stream: the loop, gather_tree over all
         max_steps rows (rows past the executed steps come out as end_id) and the copies to pinned memory are enqueued, an
         event marks their end, and the returned function waits for that event only -- work enqueued behind it (the greedy
@@ -693,7 +693,7 @@ class Decoder:
         the same values as beam_search()['predicted_ids']."""
         torch, s = self.torch, self.spec
         B, W = fm.shape[0], beam
-        ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed)
+        ctx = self._infer_ctx('beam', B, W, max_steps, False, fm, im_embed, slot=slot)
         ctx.desc.length_penalty_weight = 0.0
 
         def launch():

@@ -51,8 +51,10 @@ def _inference_loop(inputs_man, curr_ckpt_path, ckpt_dir, ckpt_file, ckpt_num, d
     print('INFO: Graph constructed. Starting inference.')
     start_time = time.time()
     captions = []
+    # captions alone (no --save_attention_maps): the decode loops of two batches are in flight (CaptionModel.infer_pipelined)
+    batches = m_infer.infer_pipelined(want_attention=bool(getattr(c, 'save_attention_maps', False)))
     for step in range(num_batches):
-        word_ids, attn_maps = m_infer.infer()
+        word_ids, attn_maps = next(batches)
         captions = id_to_caption(word_ids, c)
         for i, f in enumerate(filenames[step * batch_size:(step + 1) * batch_size]):
             image_id = f.replace('.jpg', '')
@@ -65,7 +67,7 @@ def _inference_loop(inputs_man, curr_ckpt_path, ckpt_dir, ckpt_file, ckpt_num, d
                 else:
                     raise ValueError('Expected `image_id` to be list or string, saw `{}`'.format(type(found)))
             raw_outputs['captions'][f] = captions[i]
-            raw_outputs['attention'][f] = attn_maps[i]
+            raw_outputs['attention'][f] = attn_maps[i] if attn_maps is not None else None
             raw_outputs['image_ids'][f] = image_id
             coco_json.append(dict(image_id=image_id, caption=str(captions[i])))
     print('\nExample captions:\n{}\n'.format('\n'.join(captions[:3])))

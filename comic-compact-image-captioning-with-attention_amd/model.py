@@ -114,6 +114,12 @@ class ModelBase(object):
         im_embed, fm = enc.forward(images, use_graph=True)
         return self._embed(im_embed), fm
 
+    def _encode_copy(self, images):
+        """_encode, the two outputs as copies of their own (the encoder's output buffers belong to its next forward; a decode
+        that is still in flight on another stream must not read them)."""
+        im_embed, fm = self._encode(images)
+        return im_embed.clone(), fm.clone()
+
     def _embed(self, net):
         """`self.im_embed` of ModelBase._encoder: the squeezed pooled output, or its legacy LN_tanh + linear head."""
         return net if self.head is None else self.head.forward(net.contiguous())
@@ -496,14 +502,69 @@ class CaptionModel(ModelBase):
         config.pipeline_encoder, default on; config.pipeline_encoder_group batches per forward, 0 = auto).  Same
         arithmetic per image; a forward over more images may pick other conv tiles, i.e. another fp32 summation order."""
         c = self._config
-        if batch is not None or not (getattr(c, 'pipeline_encoder', True) and str(self.device).startswith('cuda')
-                                     and os.environ.get('COMIC_PIPELINE_INFER', '1') == '1'):
-            images = batch[0] if isinstance(batch, (tuple, list)) else (batch if batch is not None else next(self.batch_ops)[0])
-            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True,
-                                     length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
-            self.infer_output = [ids, attn]
-            return self.infer_output
-        torch = self.torch
+        if batch is not None:
+            images = batch[0] if isinstance(batch, (tuple, list)) else batch
+            im_embed, fm = self._encode(images)
+        else:
+            feats = self._next_infer_features()
+            if feats is None:
+                raise StopIteration('infer(): the input pipeline is exhausted')
+            im_embed, fm = feats
+        ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True,
+                                          length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
+        self.infer_output = [ids, attn]
+        return self.infer_output
+
+    def infer_pipelined(self, want_attention=True):
+        """Generator over the batches of the input pipeline -> [dec_preds (B,T), attention_maps or None] in input order, with
+        the decode loops of TWO batches in flight (two streams, two buffer sets of the decoder: Decoder.beam_search_ids(slot=)).
+        A beam-search step is five dependent launches of 50-230 workgroups that leave most of the chip idle between them; the
+        kernels of a second, independent batch fill those holes: 2.29 -> 1.64 ms per batch of 50 at beam 3 on the word
+        baseline (tools/beam_time.py TWO=1), the same ids.  Only the captions-only beam search runs this way (no attention
+        maps, no length penalty: what `infer.py` writes unless --save_attention_maps); everything else yields infer()."""
+        c, torch = self._config, self.torch
+        lp = getattr(c, 'infer_length_penalty_weight', 0.0)
+        two = (not want_attention and not lp and c.infer_beam_size > 1 and str(self.device).startswith('cuda')
+               and os.environ.get('COMIC_INFER_IN_FLIGHT', '2') != '1')
+        if not two:
+            while True:
+                feats = self._next_infer_features()
+                if feats is None:
+                    return
+                ids, attn = self._decode_features(feats[0], feats[1], c.infer_beam_size, c.infer_max_length, top_beam=True,
+                                                  want_attention=want_attention, length_penalty_weight=lp)
+                yield [ids, attn]
+        iters = self.decoder.max_iterations(c.infer_max_length, len(c.wtoi))
+        lanes = self.__dict__.setdefault('_infer_lanes', [torch.cuda.Stream(device=self.device) for _ in range(2)])
+        pending = [None, None]
+        n = 0
+        while True:
+            feats = self._next_infer_features()
+            k = n % 2
+            if pending[k] is not None:            # the batch decoded on this lane two batches ago: next in input order
+                yield [pending[k]()[:, :, 0].T.copy(), None]
+                pending[k] = None
+            if feats is None:
+                break
+            im_embed, fm = feats
+            lanes[k].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(lanes[k]):
+                pending[k] = self.decoder.beam_search_ids(fm, im_embed, c.infer_beam_size, iters, slot=k)
+            im_embed.record_stream(lanes[k])
+            fm.record_stream(lanes[k])
+            n += 1
+        k = n % 2                                 # the other lane still holds the last batch
+        if pending[k] is not None:
+            yield [pending[k]()[:, :, 0].T.copy(), None]
+        if pending[1 - k] is not None:
+            yield [pending[1 - k]()[:, :, 0].T.copy(), None]
+
+    def _next_infer_features(self):
+        """(im_embed, fm) of the next batch of the input pipeline, None at its end.  ONE encoder forward covers the next G
+        batches (config.pipeline_encoder_group, 0 = auto: about 200 images -- the forward at 200 images runs at 1.6x the MFMA
+        rate of 50) and runs on a second stream under the decode steps of the group in flight; batches that do not fill a
+        group (the end of the input, a ragged last batch) are encoded one by one, in input order."""
+        c, torch = self._config, self.torch
 
         def next_images():
             try:
@@ -512,6 +573,11 @@ class CaptionModel(ModelBase):
                 return None
             im = b[0] if isinstance(b, (tuple, list)) else b
             return im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im, np.float32)).to(self.device)
+
+        if not (getattr(c, 'pipeline_encoder', True) and str(self.device).startswith('cuda')
+                and os.environ.get('COMIC_PIPELINE_INFER', '1') == '1'):
+            images = next_images()
+            return None if images is None else self._encode_copy(images)
 
         def next_group(G, B):
             """up to G batches of B images in input order; stops at the end of the input or behind a ragged batch"""
@@ -525,24 +591,15 @@ class CaptionModel(ModelBase):
                     break
             return out
 
-        def serial(images):
-            ids, attn = self._decode(images, c.infer_beam_size, c.infer_max_length, top_beam=True,
-                                     length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
-            self.infer_output = [ids, attn]
-            return self.infer_output
-
-        # ONE encoder forward covers the next G batches (config.pipeline_encoder_group, 0 = auto: about 200 images -- the
-        # forward at 200 images runs at 1.6x the MFMA rate of 50); batches that do not fill a group (the end of the input,
-        # a ragged last batch) are decoded serially, in input order
         tail = self.__dict__.setdefault('_infer_tail', [])
         pipe = getattr(self, '_ipipe', None)
         if pipe is None or pipe.steps_ready == 0:
             if tail:
-                return serial(tail.pop(0))
+                return self._encode_copy(tail.pop(0))
             first = next_images() if pipe is None else None
             if pipe is None:
                 if first is None:
-                    raise StopIteration('infer(): the input pipeline is exhausted')
+                    return None
                 B = int(first.shape[0])
                 G = int(getattr(c, 'pipeline_encoder_group', 0)) or max(1, min(8, 200 // max(1, B)))
                 grp = [first] + next_group(G - 1, B)
@@ -550,10 +607,10 @@ class CaptionModel(ModelBase):
                 B, G = pipe.batch, pipe.group
                 grp = next_group(G, B)
             if not grp:
-                raise StopIteration('infer(): the input pipeline is exhausted')
+                return None
             if len(grp) < G or any(int(g.shape[0]) != B for g in grp):
                 tail.extend(grp)
-                return serial(tail.pop(0))
+                return self._encode_copy(tail.pop(0))
             if pipe is None:
                 from .trainer import EncoderPipeline
                 pipe = self._ipipe = EncoderPipeline(self._encoder_for(G * B), B, G, self.device)
@@ -566,10 +623,7 @@ class CaptionModel(ModelBase):
                 pipe.submit(torch.cat(grp, 0) if pipe.group > 1 else grp[0])
             else:
                 tail.extend(grp)                                      # served once the group in flight is consumed
-        ids, attn = self._decode_features(im_embed, fm, c.infer_beam_size, c.infer_max_length, top_beam=True,
-                                          length_penalty_weight=getattr(c, 'infer_length_penalty_weight', 0.0))
-        self.infer_output = [ids, attn]
-        return self.infer_output
+        return im_embed, fm
 
 
 def auto_encoder_group(batch_size, images_per_forward=1280, cap=64):

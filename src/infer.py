@@ -5,6 +5,8 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see comic_amd/__init__.py
+
 CURR_DIR = os.path.dirname(os.path.realpath(__file__))
 BASE_DIR = os.path.dirname(CURR_DIR)
 sys.path.insert(0, BASE_DIR)

@@ -11,6 +11,8 @@ import argparse
 import os
 import sys
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see comic_amd/__init__.py
+
 CURR_DIR = os.path.dirname(os.path.realpath(__file__))
 sys.path.insert(0, os.path.dirname(CURR_DIR))
 pjoin = os.path.join

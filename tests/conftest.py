@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # the product's setting (comic_amd/__init__.py), before any GPU call
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

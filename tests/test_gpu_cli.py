@@ -54,15 +54,19 @@ def test_train_infer_scst_cli(tmp_path):
     scores = open(os.path.join(out_dir, 'metric_scores.txt')).read()
     assert all(m in scores for m in ('Bleu_1', 'Bleu_4', 'ROUGE_L', 'CIDEr')) and 'METEOR' not in scores
     assert len(open(os.path.join(out_dir, 'metric_scores.csv')).read().strip().split(',')) == 7
-    # the inference loop runs the encoder of batch i + 1 under the decode of batch i: the serial loop writes the same captions
+    # the inference loop runs the encoder of batch i + 1 under the decode of batch i and keeps the decode loops of two batches
+    # in flight (CaptionModel.infer_pipelined): the serial loop -- one batch at a time, encoder then decode -- writes the same
+    # captions
     os.rename(caps[0], caps[0] + '.pipelined')
     os.environ['COMIC_PIPELINE_INFER'] = '0'
+    os.environ['COMIC_INFER_IN_FLIGHT'] = '1'
     try:
         _run(os.path.join(ROOT, 'src', 'infer.py'), ['--infer_checkpoints_dir', run_dir, '--dataset_dir', ds,
                                                      '--infer_set', 'test', '--batch_size_infer', '2',
                                                      '--get_metric_score', ''])
     finally:
         del os.environ['COMIC_PIPELINE_INFER']
+        del os.environ['COMIC_INFER_IN_FLIGHT']
     assert json.load(open(caps[0])) == json.load(open(caps[0] + '.pipelined'))
     # ---- CNN fine-tune: restores the decoder run, trains CNN + decoder, saves both ----
     _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '8',

@@ -1347,3 +1347,32 @@ def test_sampled_decode_matches_oracle_on_the_same_noise(kw):
 
 
 
+
+
+def test_two_beam_searches_in_flight_give_the_ids_of_one_at_a_time():
+    """Decoder.beam_search_ids(slot=): two buffer sets let the decode loops of two batches run on two streams at once
+    (CaptionModel.infer_pipelined); ids, batch by batch, equal the one-at-a-time loop -- word vocabulary (streaming logits)
+    and radix vocabulary, several rounds so both slots replay their captured graphs."""
+    for spec, B, W in ((cdec.DecoderSpec(V=25599, H=1, fm_projection=None, token_type='word', start_id=25597, end_id=25598), 6, 3),
+                       (cdec.DecoderSpec(), 5, 3)):
+        dec = cdec.Decoder(spec, None, DEV, seed=12)
+        rng = np.random.default_rng(3)
+        feats = [(dev(rng.standard_normal((B, spec.M, spec.C)).astype(np.float32)),
+                  dev(rng.standard_normal((B, spec.Cg)).astype(np.float32))) for _ in range(6)]
+        want = [dec.beam_search_ids(fm, im, W, 12)() for fm, im in feats]
+        lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+        pend, got = [None, None], []
+        for i, (fm, im) in enumerate(feats):
+            k = i % 2
+            if pend[k] is not None:
+                got.append(pend[k]())
+            lanes[k].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(lanes[k]):
+                pend[k] = dec.beam_search_ids(fm, im, W, 12, slot=k)
+        n = len(feats)
+        got.append(pend[n % 2]())
+        got.append(pend[1 - n % 2]())
+        sync()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
