@@ -2680,6 +2680,98 @@ __global__ __launch_bounds__(256) void act_grad_kernel(ActGradArgs a, float* __r
   }
 }
 
+// The same for COMIC_OP_X3 plans (bf16x3 backward): y is hi + lo of two channel regions (or fp32), dy an fp32 gradient
+// buffer of the LOGICAL channels, and dz leaves as the three regions [hi | lo | hi] of C channels each -- the operand
+// layout of the x3 convolutions, so that the backward-data conv of dz against [Wt_hi | Wt_hi | Wt_lo] is the split product
+// hi*hi + lo*hi + hi*lo with fp32 accumulation.
+struct ActGradX3Args {
+  const void* y;    // forward output: bf16 regions (hi at yco, lo y_lo channels behind) of rows of ycs channels, or fp32 (y_lo = 0)
+  const float* dy;  // its gradient: fp32 rows of gcs channels, slice from yco
+  int ycs, yco, y_lo, gcs;
+  const float* scale;
+  bf16_t* dz;       // [B][Hd][Wd][3 C]
+  int B, Ho, Wo, C, Hd, Wd, dil;
+};
+__global__ __launch_bounds__(256) void act_grad_x3_kernel(ActGradX3Args a, float* __restrict__ dbeta, long px_per_block) {
+  constexpr int EPC = 8, CPB = 64 / EPC, PL = 256 / CPB;
+  __shared__ float red[PL][64 + 1];
+  const int tid = threadIdx.x;
+  const int cc = tid % CPB, pl = tid / CPB;
+  const int c0 = blockIdx.y * 64 + cc * EPC;
+  const bool cok = c0 < a.C;           // C % 8 == 0
+  const long P = (long)a.B * a.Ho * a.Wo;
+  const long p0 = (long)blockIdx.x * px_per_block, p1 = min(P, p0 + px_per_block);
+  float sc[EPC], sum[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    sc[i] = cok ? a.scale[c0 + i] : 0.f;
+    sum[i] = 0.f;
+  }
+  if (cok) {
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const int wo = (int)(p % a.Wo);
+      const long q = p / a.Wo;
+      const int ho = (int)(q % a.Ho), b = (int)(q / a.Ho);
+      float yv[EPC], gv[EPC];
+      const size_t src = (size_t)p * a.ycs + a.yco + c0;
+      if (a.y_lo) {
+        float yl[EPC];
+        load_vec<bf16_t>((const bf16_t*)a.y + src, yv);
+        load_vec<bf16_t>((const bf16_t*)a.y + src + a.y_lo, yl);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) yv[i] += yl[i];
+      } else {
+        load_chunk_f<bf16_t>(a.y, src, true, yv);
+      }
+      load_chunk_f<bf16_t>(a.dy, (size_t)p * a.gcs + a.yco + c0, true, gv);
+      float hi[EPC], lo[EPC];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) {
+        const float g = yv[i] > 0.f ? gv[i] : 0.f;
+        sum[i] += g;
+        const float z = g * sc[i];
+        hi[i] = bf16_to_f32(f32_to_bf16(z));
+        lo[i] = z - hi[i];
+      }
+      bf16_t* dst = a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * 3 * a.C + c0;
+      store_vec<bf16_t>(dst, hi);
+      store_vec<bf16_t>(dst + a.C, lo);
+      store_vec<bf16_t>(dst + 2 * a.C, hi);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) red[pl][cc * EPC + i] = sum[i];
+  __syncthreads();
+  if (tid < 64) {
+    const int c = blockIdx.y * 64 + tid;
+    if (c < a.C) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < PL; ++r) s += red[r][tid];
+      atomicAdd(dbeta + c, s);
+    }
+  }
+}
+
+// master [Cout][Kpad] (fp32, k = (kh*KW + kw)*Cin + ci) -> x3 backward-data filter [Cin][Kpad2], k2 = tap2 * 3 Cout + region * Cout +
+// co with the flipped taps of pack_bwd_weights_kernel and the regions [W_hi | W_hi | W_lo]
+__device__ __forceinline__ bf16_t pack_bwd_x3_value(const float* __restrict__ master, int k2, int ci, int KH, int KW, int Cin,
+                                                    int Cout, int Kpad) {
+  if (k2 >= KH * KW * 3 * Cout) return f32_to_bf16(0.f);
+  const int tap2 = k2 / (3 * Cout), rr = k2 - tap2 * 3 * Cout;
+  const int region = rr / Cout, co = rr - region * Cout;
+  const int kh = KH - 1 - tap2 / KW, kw = KW - 1 - tap2 % KW;
+  const float v = master[(size_t)co * Kpad + (kh * KW + kw) * Cin + ci];
+  const bf16_t hi = f32_to_bf16(v);
+  return region < 2 ? hi : f32_to_bf16(v - bf16_to_f32(hi));
+}
+__global__ void pack_bwd_weights_x3_kernel(const float* __restrict__ master, bf16_t* __restrict__ out, int KH, int KW, int Cin,
+                                           int Cout, int Kpad, int Kpad2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cin * Kpad2) return;
+  out[idx] = pack_bwd_x3_value(master, (int)(idx % Kpad2), (int)(idx / Kpad2), KH, KW, Cin, Cout, Kpad);
+}
+
 // master [Cout][Kpad] (k = (kh*KW + kw)*Cin + ci) -> backward-data filter [Cin][Kpad2],
 // k2 = ((KH-1-kh)*KW + (KW-1-kw))*Cout + co
 template <typename T>
@@ -2701,8 +2793,9 @@ __global__ void pack_bwd_weights_kernel(const float* __restrict__ master, T* __r
 }
 
 struct WgradArgs {
-  const void* dz;   // [B][Hd][Wd][Cout] plan dtype
-  int Hd, Wd, dil;
+  const void* dz;   // [B][Hd][Wd][dz_cs] plan dtype, channels [dz_co, dz_co + Cout) (plain plans: dz_cs = Cout, dz_co = 0)
+  int Hd, Wd, dil, dz_cs, dz_co;
+  int x_part;       // STEM, bf16: 0 the image rounded to bf16, 1 its rounding residue (the lo half of an x3 backward)
   const void* x;    // forward input (plan dtype; STEM: fp32 image)
   int x_cs, x_co;
   float* dw;        // [Cout][Kpad] fp32 (STEM: [K][Cout]), accumulated with atomics
@@ -2749,7 +2842,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int rem = (int)(p - (long)b * hw);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     if (co_ok)
-      zreg = *(const uint4*)((const T*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.Cout + co_c);
+      zreg = *(const uint4*)((const T*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.dz_cs + a.dz_co + co_c);
     if (STEM) {
       float v[EPC];
 #pragma unroll
@@ -2766,6 +2859,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       if (sizeof(T) == 4) {
         xreg = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
       } else {
+        if (a.x_part) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] -= bf16_to_f32(f32_to_bf16(v[e]));
+        }
         xreg = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4 % EPC], v[5 % EPC]),
                           pack_bf16x2(v[6 % EPC], v[7 % EPC]));
       }
@@ -2913,7 +3010,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs a) {
     const int b = (int)(p / hw);
     const int rem = (int)(p - (long)b * hw);
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-    const bf16_t* zp = (const bf16_t*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.Cout;
+    const bf16_t* zp = (const bf16_t*)a.dz + (((size_t)b * a.Hd + ho * a.dil) * a.Wd + wo * a.dil) * a.dz_cs + a.dz_co;
 #pragma unroll
     for (int i = 0; i < ZCH; ++i)
       if (co_ok[i]) zreg[i] = *(const uint4*)(zp + co_c[i]);
@@ -2997,6 +3094,8 @@ struct PoolGradArgs {
   void* dx;         // gradient of the pool input, slice [xco, xco + C) of xcs  (accumulated)
   int xcs, xco, ycs, yco, dy_f32, dx_f32;
   int B, H, W, C, KH, KW, SH, SW, PT, PL, Ho, Wo;
+  int dxcs, dxco;   // channel stride / offset of dx (plain plans: xcs, xco)
+  int x_lo;         // x3 plans: x is hi + lo, the lo region x_lo channels behind the hi region (0: plain)
 };
 
 // MODE 0 max (first maximum in window scan order), 1 avg over valid taps, 2 plain mean over the
@@ -3035,7 +3134,14 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
             const int w2 = wo * a.SW - a.PL + kw;
             if ((unsigned)w2 >= (unsigned)a.W) continue;
             float v[EPC];
-            load_vec<T>((const T*)a.x + ((size_t)(b * a.H + h2) * a.W + w2) * a.xcs + a.xco + cv * EPC, v);
+            const T* xp = (const T*)a.x + ((size_t)(b * a.H + h2) * a.W + w2) * a.xcs + a.xco + cv * EPC;
+            load_vec<T>(xp, v);
+            if (a.x_lo) {                          // (hi + lo is exact in fp32: the order pool_x3_kernel's pairs have)
+              float vl[EPC];
+              load_vec<T>(xp + a.x_lo, vl);
+#pragma unroll
+              for (int j = 0; j < EPC; ++j) v[j] += vl[j];
+            }
 #pragma unroll
             for (int j = 0; j < EPC; ++j)
               if (v[j] > best[j]) { best[j] = v[j]; arg[j] = h2 * a.W + w2; }
@@ -3056,7 +3162,7 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
         for (int j = 0; j < EPC; ++j) g[j] += dyv[j] * inv;
       }
     }
-  const size_t off = (size_t)p * a.xcs + a.xco + cv * EPC;
+  const size_t off = (size_t)p * a.dxcs + a.dxco + cv * EPC;
   float old[EPC];
   load_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
 #pragma unroll
@@ -3186,7 +3292,8 @@ int wgrad_blocks_target() { return 1024; }
 size_t dz_bytes_of(const comic_cnn_op* op, int batch, size_t es) {
   const int Hd = (op->Ho - 1) * op->SH + 1;
   const int Wd = (op->Wo - 1) * op->SW + 1;
-  return ((size_t)batch * Hd * Wd * op->Cout * es + 255) & ~(size_t)255;
+  const int regions = (op->flags & COMIC_OP_X3) ? 3 : 1;      // x3 plans: d conv as [hi | lo | hi]
+  return ((size_t)batch * Hd * Wd * op->Cout * regions * es + 255) & ~(size_t)255;
 }
 // (the scheduled backward keeps kMaskCopies partial d beta rows per conv behind the d-conv slices: fused activation gradients)
 size_t dbeta_partial_bytes(const comic_cnn_op* op) { return ((size_t)kMaskCopies * op->Cout * sizeof(float) + 255) & ~(size_t)255; }
@@ -3268,6 +3375,7 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
     hipStream_t st = st_w;      // the launches of this scope go to the weight-gradient lane
     (void)st_chain;
     WgradArgs a{};
+    a.dz_cs = op->Cout; a.dz_co = 0; a.x_part = 0;
     a.dz = dz; a.Hd = Hd; a.Wd = Wd; a.dil = dil; a.x = x; a.x_cs = xc; a.x_co = op->src_coff; a.dw = gr->dw;
     a.B = batch; a.H = op->H; a.W = op->W; a.Cin = op->Cin; a.Cout = op->Cout; a.KH = op->KH; a.KW = op->KW;
     a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL; a.Ho = op->Ho; a.Wo = op->Wo; a.K = K; a.Kpad = Kpad;
@@ -3328,18 +3436,118 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
   return run_op<T>(&t, dz, op->Cout, gx, xc, &w2, batch, st, /*accum=*/1);
 }
 
+inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits for everything issued on `from` so far
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+  const bool ok = hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
+  (void)hipEventDestroy(ev);
+  return ok;
+}
+
+// A conv of a COMIC_OP_X3 plan ("bf16x3": cnn_finetune at fp32-class accuracy on the bf16 matrix cores).  Activations are
+// the three bf16 regions [hi | lo | hi] (xc, yc: physical channels = 3 x logical; fp32 outputs as they are), gradient
+// buffers fp32 of the LOGICAL channels (gxc, gyc), masters and weight gradients the logical [Cout][Kpad] of the bf16 plan.
+//   dz  = 1[y > 0] dy scale as [hi | lo | hi]                                              (act_grad_x3_kernel)
+//   dw += x_hi^T dz_hi + x_lo^T dz_hi + x_hi^T dz_lo      three launches of the bf16 backward-weight kernel over channel
+//                                                         slices of the regions, fp32 atomics into the one dw
+//   gx += conv(dz, [Wt_hi | Wt_hi | Wt_lo])               the bf16 forward kernels over 3 Cout channels, fp32 accumulate
+int conv_backward_x3(const comic_cnn_op* op, const void* x, int xc, const void* y, const float* gy, int yc, int gyc, float* gx,
+                     int gxc, const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
+                     int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w) {
+  const bool stem = op->kind == 1;
+  COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward (x3): missing weight / gradient record");
+  COMIC_REQUIRE(op->SH == op->SW && (op->SH == 1 || op->SH == 2), "conv backward (x3): stride must be 1 or 2");
+  COMIC_REQUIRE(op->Cout % 8 == 0 && op->dst_coff % 8 == 0 && (stem || (op->Cin % 3 == 0 && xc % 3 == 0)) &&
+                    (op->out_f32 || yc % 3 == 0), "conv backward (x3): channel regions do not fit the buffers");
+  const int cin = stem ? op->Cin : op->Cin / 3, x_lo = stem ? 0 : xc / 3, y_lo = op->out_f32 ? 0 : yc / 3;
+  const int K = op->KH * op->KW * cin, Kpad = (K + 63) / 64 * 64;
+  const int dil = op->SH;
+  const int Hd = (op->Ho - 1) * dil + 1, Wd = (op->Wo - 1) * dil + 1;
+  const size_t dz_bytes = dz_bytes_of(op, batch, 2);
+  COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward (x3): scratch too small (%zu needed)", dz_bytes);
+  bf16_t* dz = (bf16_t*)scratch;
+  if (dil > 1) COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward (x3): memset failed");
+  {
+    ActGradX3Args a{y, gy, yc, op->dst_coff, y_lo, gyc, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
+    const long P = (long)batch * op->Ho * op->Wo;
+    const long ppb = std::max<long>(64, cdiv64(P, 512));
+    hipLaunchKernelGGL(act_grad_x3_kernel, dim3((unsigned)cdiv64(P, ppb), cdiv(op->Cout, 64)), dim3(256), 0, st, a, gr->dbeta, ppb);
+  }
+  if (st_w != st) COMIC_REQUIRE(link_streams(st, st_w), "conv backward (x3): fork of the weight-gradient lane failed");
+  {
+    WgradArgs a{};
+    a.dz = dz; a.Hd = Hd; a.Wd = Wd; a.dil = dil; a.dz_cs = 3 * op->Cout; a.x = x; a.x_cs = xc; a.dw = gr->dw;
+    a.B = batch; a.H = op->H; a.W = op->W; a.Cin = cin; a.Cout = op->Cout; a.KH = op->KH; a.KW = op->KW;
+    a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL; a.Ho = op->Ho; a.Wo = op->Wo; a.K = K; a.Kpad = Kpad;
+    a.P = (long)batch * op->Ho * op->Wo;
+    for (int part = 0; part < 3; ++part) {                // (x, dz) halves: hi hi, lo hi, hi lo
+      const bool xl = part == 1, zl = part == 2;
+      a.dz_co = zl ? op->Cout : 0;
+      a.x_co = op->src_coff + (xl ? x_lo : 0);
+      a.x_part = xl ? 1 : 0;
+      if (stem) {
+        COMIC_REQUIRE(op->Cin <= 4, "stem conv backward: needs Cin <= 4");
+        const int tiles = cdiv(K, 64) * cdiv(op->Cout, 64);
+        long S = std::max<long>(1, std::min<long>(2048 / tiles, cdiv64(a.P, 32L * 8)));
+        a.p_per_split = cdiv64(cdiv64(a.P, S), 32) * 32;
+        S = cdiv64(a.P, a.p_per_split);
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), dim3(cdiv(K, 64), cdiv(op->Cout, 64), (unsigned)S), dim3(256), 0,
+                           st_w, a);
+      } else {
+        COMIC_REQUIRE(cin % 8 == 0 && op->src_coff % 8 == 0 && x_lo % 8 == 0, "conv backward (x3): misaligned input slice");
+        const bool big_m = op->Cout % 128 == 0, big_n = Kpad % 128 == 0 && K >= 256;
+        const int bm = big_m ? 128 : 64, bn = big_n ? 128 : 64;
+        const int tiles2 = cdiv(K, bn) * cdiv(op->Cout, bm);
+        long S2 = std::max<long>(1, std::min<long>(wgrad_blocks_target() / tiles2, cdiv64(a.P, 32L * 8)));
+        a.p_per_split = cdiv64(cdiv64(a.P, S2), 32) * 32;
+        S2 = cdiv64(a.P, a.p_per_split);
+        dim3 g2(cdiv(K, bn), cdiv(op->Cout, bm), (unsigned)S2);
+        if (big_m && big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), g2, dim3(256), 0, st_w, a);
+        else if (big_m) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), g2, dim3(256), 0, st_w, a);
+        else if (big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), g2, dim3(256), 0, st_w, a);
+        else hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), g2, dim3(256), 0, st_w, a);
+      }
+    }
+  }
+  COMIC_LAUNCH_CHECK("conv backward (x3, weights)");
+  if (stem || !gx) return 0;
+  COMIC_REQUIRE(gr->w_bwd, "conv backward (x3): missing backward-data filter buffer");
+  const int K2 = op->KH * op->KW * 3 * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
+  if (!filters_ready) {
+    const long n = (long)cin * Kpad2;
+    hipLaunchKernelGGL(pack_bwd_weights_x3_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, gr->w_master,
+                       (bf16_t*)gr->w_bwd, op->KH, op->KW, cin, op->Cout, Kpad, Kpad2);
+  }
+  comic_cnn_op t = *op;
+  t.kind = 0;
+  t.flags = COMIC_OP_RAW;
+  t.H = Hd; t.W = Wd; t.Cin = 3 * op->Cout; t.Cout = cin; t.SH = t.SW = 1;
+  t.PT = op->KH - 1 - op->PT; t.PL = op->KW - 1 - op->PL;
+  t.Ho = op->H; t.Wo = op->W;
+  t.src_coff = 0; t.dst_coff = op->src_coff; t.relu = 0; t.out_f32 = 1; t.tile = 0; t.group = 0; t.lane = 0;
+  comic_conv_weight w2{gr->w_bwd, nullptr, nullptr};
+  return run_op<bf16_t>(&t, dz, 3 * op->Cout, gx, gxc, &w2, batch, st, /*accum=*/1);
+}
+
+// x3: the pool of a COMIC_OP_X3 plan -- x the bf16 regions (hi + lo), gy / gx fp32 buffers of the logical channels
 template <typename T>
 int pool_backward(const comic_cnn_op* op, const void* x, int xc, const void* gy, int yc, void* gx, int batch,
-                  hipStream_t st) {
+                  hipStream_t st, bool x3 = false) {
   constexpr int EPC = Elem<T>::EPC;
   COMIC_REQUIRE(op->Cin % EPC == 0 && op->src_coff % EPC == 0 && op->dst_coff % EPC == 0 && xc % EPC == 0 &&
                     yc % EPC == 0, "pool backward: misaligned channel slices");
   PoolGradArgs a{x, gy, gx, xc, op->src_coff, yc, op->dst_coff, op->kind == 4 ? 1 : 0,
                  (op->kind == 4 && op->src_f32) ? 1 : 0,
                  batch, op->H, op->W, op->Cin, op->KH, op->KW, op->SH, op->SW, op->PT, op->PL, op->Ho, op->Wo};
+  a.dxcs = a.xcs; a.dxco = a.xco; a.x_lo = 0;
+  if (x3) {
+    COMIC_REQUIRE(sizeof(T) == 2 && xc % 3 == 0 && yc % 3 == 0 && (xc / 3) % EPC == 0 && (yc / 3) % EPC == 0,
+                  "pool backward (x3): channel regions do not fit the buffers");
+    a.x_lo = xc / 3; a.dxcs = xc / 3; a.ycs = yc / 3; a.dy_f32 = 1; a.dx_f32 = 1;
+  }
   const long total = (long)batch * op->H * op->W * (op->Cin / EPC);
   dim3 grid((unsigned)cdiv64(total, 256));
-  if (op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 2 && op->SW == 2 && op->PT >= 0 && op->PT <= 1 && op->PL >= 0 &&
+  if (!x3 && op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 2 && op->SW == 2 && op->PT >= 0 && op->PT <= 1 && op->PL >= 0 &&
       op->PL <= 1) {
     const int tiles_y = cdiv(op->H, kMpgTile), tiles_x = cdiv(op->W, kMpgTile), cgroups = cdiv(op->Cin / EPC, kMpgCG);
     const long wgs = (long)batch * tiles_y * tiles_x * cgroups;
@@ -3364,7 +3572,8 @@ struct PackBwdEntry {
   uint32_t first_block;            // of this entry in the launch (entries ascending)
   uint16_t Cin, Cout;
   uint8_t KH, KW;
-  uint8_t pad[6];
+  uint8_t x3;                      // 1: [W_hi | W_hi | W_lo] regions per tap (Cin = channels of ONE source region)
+  uint8_t pad[5];
 };
 struct PackBwdTable {
   PackBwdEntry e[kPackTableMax];
@@ -3382,9 +3591,14 @@ __global__ __launch_bounds__(256) void pack_bwd_weights_table_kernel(const PackB
   }
   const PackBwdEntry& en = tb.e[lo];
   const int KH = en.KH, KW = en.KW, Cin = en.Cin, Cout = en.Cout;
-  const int Kpad = (KH * KW * Cin + 63) / 64 * 64, Kpad2 = (KH * KW * Cout + 63) / 64 * 64;
+  const int Kpad = (KH * KW * Cin + 63) / 64 * 64, Kpad2 = (KH * KW * Cout * (en.x3 ? 3 : 1) + 63) / 64 * 64;
   const long idx = (long)(blockIdx.x - en.first_block) * blockDim.x + threadIdx.x;
   if (idx >= (long)Cin * Kpad2) return;
+  if (en.x3) {
+    if constexpr (sizeof(T) == 2)
+      ((bf16_t*)en.out)[idx] = pack_bwd_x3_value(en.master, (int)(idx % Kpad2), (int)(idx / Kpad2), KH, KW, Cin, Cout, Kpad);
+    return;
+  }
   const int k2 = (int)(idx % Kpad2), ci = (int)(idx / Kpad2);
   float v = 0.f;
   if (k2 < KH * KW * Cout) {
@@ -3414,14 +3628,18 @@ int pack_bwd_filters_impl(const comic_cnn_op* ops, int n_ops, const comic_conv_g
     const comic_conv_grad* gr = grads + op->weight;
     COMIC_REQUIRE(gr->w_master && gr->w_bwd, "pack_bwd_filters: missing buffers for conv %d", i);
     COMIC_REQUIRE(op->KH <= 255 && op->KW <= 255 && op->Cin <= 65535 && op->Cout <= 65535, "pack_bwd_filters: conv %d too large", i);
-    const int K2 = op->KH * op->KW * op->Cout, Kpad2 = (K2 + 63) / 64 * 64;
-    const long n = (long)op->Cin * Kpad2;
+    const bool x3 = (op->flags & COMIC_OP_X3) != 0;
+    COMIC_REQUIRE(!x3 || (sizeof(T) == 2 && op->Cin % 3 == 0), "pack_bwd_filters: COMIC_OP_X3 is a bf16-plan layout");
+    const int cin = x3 ? op->Cin / 3 : op->Cin;
+    const int K2 = op->KH * op->KW * op->Cout * (x3 ? 3 : 1), Kpad2 = (K2 + 63) / 64 * 64;
+    const long n = (long)cin * Kpad2;
     if (tb.n == kPackTableMax) flush();
     PackBwdEntry& en = tb.e[tb.n++];
     en.master = gr->w_master;
     en.out = gr->w_bwd;
     en.first_block = blocks;
-    en.Cin = (uint16_t)op->Cin;
+    en.x3 = x3 ? 1 : 0;
+    en.Cin = (uint16_t)cin;
     en.Cout = (uint16_t)op->Cout;
     en.KH = (uint8_t)op->KH;
     en.KW = (uint8_t)op->KW;
@@ -3449,7 +3667,20 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
     COMIC_REQUIRE(gy, "cnn_backward: op %d has no output gradient buffer", i);
     void* gx = grad_buffers[op->src];
     const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
-    if (op->kind <= 1) {
+    const bool x3 = (op->flags & COMIC_OP_X3) != 0;
+    if (x3 && op->kind <= 1) {
+      if constexpr (sizeof(T) == 2) {
+        const size_t dzb = dz_bytes_of(op, batch, sizeof(T));
+        void* dz = st_w != st ? (void*)((char*)scratch + dz_off) : scratch;
+        if (int rc = conv_backward_x3(op, buffers[op->src], xc, buffers[op->dst], (const float*)gy, yc, op->out_f32 ? yc : yc / 3,
+                                      (float*)gx, op->kind == 1 ? 0 : xc / 3, weights + op->weight, grads + op->weight, batch, dz,
+                                      st_w != st ? (int64_t)dzb : scratch_bytes, st, filters_ready, st_w))
+          return rc;
+        dz_off += dzb;
+      } else {
+        COMIC_REQUIRE(false, "cnn_backward: COMIC_OP_X3 is a bf16-plan layout");
+      }
+    } else if (op->kind <= 1) {
       const size_t dzb = dz_bytes_of(op, batch, sizeof(T));
       void* dz = st_w != st ? (void*)((char*)scratch + dz_off) : scratch;
       if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
@@ -3459,7 +3690,7 @@ int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, 
       dz_off += dzb;
     } else if (op->kind <= 4) {
       if (!gx) continue;
-      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st)) return rc;
+      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st, x3 && op->kind <= 3)) return rc;
     } else {
       COMIC_REQUIRE(false, "cnn_backward: unknown op kind %d", op->kind);
     }
@@ -3492,13 +3723,6 @@ __global__ void add_clear_kernel(T* __restrict__ y, T* __restrict__ x, long n_ch
   store_vec<T>(x + i * EPC, b);
 }
 
-inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits for everything issued on `from` so far
-  hipEvent_t ev;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
-  const bool ok = hipEventRecord(ev, from) == hipSuccess && hipStreamWaitEvent(to, ev, 0) == hipSuccess;
-  (void)hipEventDestroy(ev);
-  return ok;
-}
 
 
 template <typename T>

@@ -916,13 +916,19 @@ class CnnEncoder:
         if self._train is not None:
             return self._train
         torch, plan = self.torch, self.plan
-        if plan.pool_after_projection or getattr(plan, 'x3', False):
-            raise ValueError('cnn_finetune needs a plan built with pool_after_projection=False and x3=False (forward-only layouts)')
+        if plan.pool_after_projection:
+            raise ValueError('cnn_finetune needs a plan built with pool_after_projection=False (a forward-only layout)')
+        x3 = bool(getattr(plan, 'x3', False))
         t = type('CnnTrainState', (), {})()
         t.dw, t.dbeta = self.w_master.like(), self.beta.like()
-        sizes, total = [], 0
+        # gradient buffers: the plan dtype and geometry of the activation buffers; x3 plans ("bf16x3"): fp32 buffers of the
+        # LOGICAL channels (an activation buffer holds three bf16 regions of them: csrc/conv.hip conv_backward_x3)
+        geo, sizes, total = [], [], 0
         for bi, (H, W, Cc, f32) in enumerate(plan.buffers):
-            nbytes = 0 if bi == plan.input else self.batch * H * W * Cc * (4 if (f32 or self.dcode == 0) else 2)
+            g32 = f32 or self.dcode == 0 or x3
+            Cg = Cc // 3 if (x3 and not f32) else Cc
+            geo.append((Cg, g32))
+            nbytes = 0 if bi == plan.input else self.batch * H * W * Cg * (4 if g32 else 2)
             sizes.append((total, nbytes))
             total += (nbytes + 255) // 256 * 256
         t.gflat = torch.zeros(total, dtype=torch.uint8, device=self.device)
@@ -932,15 +938,16 @@ class CnnEncoder:
             if nbytes == 0:
                 t.gbufs.append(None)
                 continue
-            dt = torch.float32 if (f32 or self.dcode == 0) else self._tdt
-            t.gbufs.append(t.gflat[off:off + nbytes].view(dt).view(self.batch, H, W, Cc))
+            Cg, g32 = geo[bi]
+            dt = torch.float32 if g32 else self._tdt
+            t.gbufs.append(t.gflat[off:off + nbytes].view(dt).view(self.batch, H, W, Cg))
         t.gptr = (C.c_void_p * len(t.gbufs))(*[g.data_ptr() if g is not None else None for g in t.gbufs])
         esz = 4 if self.dcode == 0 else 2
         wb_off, n = [], 0
         for (prefix, kh, kw, cin, cout, stem), (cin, cout) in zip(plan.weights, plan.wphys):
             wb_off.append(n)
-            if not stem:
-                n += (cin * ((kh * kw * cout + 63) // 64 * 64) * esz + 255) // 256 * 256
+            if not stem:      # backward-data filter [Cin][roundup64(taps * Cout)]; x3: three regions per tap
+                n += (cin * ((kh * kw * cout * (3 if x3 else 1) + 63) // 64 * 64) * esz + 255) // 256 * 256
         t.w_bwd = torch.zeros(max(n, 256), dtype=torch.uint8, device=self.device)
         t.grads = (L.ConvGrad * len(plan.weights))()
         for i, (prefix, kh, kw, cin, cout, stem) in enumerate(plan.weights):
@@ -957,7 +964,7 @@ class CnnEncoder:
         # branch lanes of the backward (backward_schedule): a second chain stream and alternate gradient buffers of the
         # blocks' shared inputs (zero between steps: the join adds them in and clears them)
         t.sched, t.lane1 = None, None
-        if self.backward_lanes and self.backward_branch_lanes and plan.name == 'inception_v3':
+        if self.backward_lanes and self.backward_branch_lanes and plan.name == 'inception_v3' and not x3:
             sched, alt_bufs = backward_schedule(plan)
             if alt_bufs:
                 t.sched = np.ascontiguousarray(sched)
@@ -976,7 +983,7 @@ class CnnEncoder:
         d-conv tensor with the flipped / transposed filter; comic_conv_grad.bwd_tile) by timing the candidates on the real
         buffers, as autotune() does for the forward -- the heuristic picks 32x64 / 64x64 tiles for most of them at batch
         32.  Every variant gives the same bits.  -> {weight index: (ms, tile)}."""
-        if self.dcode != 1:
+        if self.dcode != 1 or getattr(self.plan, 'x3', False):      # (x3: the backward-data convs run on the heuristic tiles)
             return {}
         t = self.enable_training()
         torch, plan = self.torch, self.plan

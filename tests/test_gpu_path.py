@@ -323,7 +323,12 @@ def _device_activation_hook(enc, layer_tol, worst):
     def hook(wn, y):
         o = by_name[wn]
         cout = plan.weights[o['weight']][4]
-        act = enc.bufs[o['dst']][..., o['dst_coff']:o['dst_coff'] + cout].float().cpu().numpy()
+        b = enc.bufs[o['dst']]
+        act = b[..., o['dst_coff']:o['dst_coff'] + cout].float()
+        if getattr(plan, 'x3', False) and b.dtype != torch.float32:     # [hi | lo | hi] regions: the value is hi + lo
+            C3 = b.shape[-1] // 3
+            act = act + b[..., C3 + o['dst_coff']:C3 + o['dst_coff'] + cout].float()
+        act = act.cpu().numpy()
         e = rel_err(act, y)
         worst[0] = max(worst[0], e)
         assert e <= layer_tol, '%s: forward rel err %.3e > %.1e' % (wn, e, layer_tol)
@@ -379,13 +384,47 @@ def test_inception_v3_backward_224_f32():
         assert torch.equal(b1.view('b%d' % i), tr_.dbeta.view('b%d' % i)), i
 
 
+def test_inception_v3_backward_224_bf16x3_meets_the_fp32_bar():
+    """cnn_finetune on the bf16x3 plan (csrc/conv.hip conv_backward_x3: d conv as [hi | lo | hi] regions, the weight
+    gradient as three bf16 products x_hi dz_hi + x_lo dz_hi + x_hi dz_lo, backward-data as the x3 conv of d conv against
+    [Wt_hi | Wt_hi | Wt_lo] into fp32 gradient buffers, pools through hi + lo): d weights / d beta of all 94 convs at the bar
+    of the exact-fp32 plan, 1e-3 per variable (test_inception_v3_backward_224_f32), where the plain bf16 plan is at 4e-2.
+    The oracle differentiates through the device's activations (each within 1e-4 of its own layer output)."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 25, 2048)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224), x3=True), params, B, 'bf16x3', DEV)
+    enc.forward(dev(x))
+    t = enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    assert all(g is None or g.dtype == torch.float32 for g in t.gbufs)
+    got = _cnn_grads_device(enc, t)
+    worst = [0.0]
+    want, _, _ = cnn_ref.inception_v3_grads(params, x, d_net, d_fm, override=_device_activation_hook(enc, 1e-4, worst))
+    assert set(got) == set(want) and len(want) == 188
+    errs = sorted((rel_err(got[k], want[k]), k) for k in want)
+    print('bf16x3 backward: worst variable %.2e (%s), median %.2e, worst layer output %.2e' % (
+        errs[-1][0], errs[-1][1], errs[len(errs) // 2][0], worst[0]))
+    assert errs[-1][0] < F32_RTOL, errs[-1]
+    assert errs[len(errs) // 2][0] < 1e-4, errs[len(errs) // 2]
+    # a second step over the same buffers (gradient buffers cleared, filters packed ahead by the table launch): same gradients
+    enc.forward(dev(x))
+    enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    again = _cnn_grads_device(enc, t)
+    for k in want:
+        assert rel_err(again[k], got[k]) < 1e-5, k
+
+
 _CHAIN = [('c', 'c1', 32, (3, 3), 2, 'VALID'), ('c', 'c2', 64, (3, 3), 1, 'SAME'), ('max',),
           ('c', 'c3', 96, (1, 7), 1, 'SAME'), ('avg',), ('c', 'c4', 64, (3, 3), 2, 'VALID'),
           ('c', 'c5', 48, (5, 5), 1, 'SAME')]
 
 
-def _chain_oracle(params, x, d_net, d_fm, act_dtype):
-    n = cnn_ref._Net(params, None, act_dtype=act_dtype, run=True, tape=True)
+def _chain_oracle(params, x, d_net, d_fm, act_dtype, override=None):
+    n = cnn_ref._Net(params, None, act_dtype=act_dtype, run=True, tape=True, override=override)
     n.scope.append('Chain')
     h = np.asarray(x, np.float32)
     for op in _CHAIN:
@@ -400,7 +439,7 @@ def _chain_oracle(params, x, d_net, d_fm, act_dtype):
     return h, pooled, g
 
 
-@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 4e-2)])
+@pytest.mark.parametrize('dtype,tol', [('f32', 1e-3), ('bf16', 4e-2), ('bf16x3', 1e-3)])
 @pytest.mark.parametrize('B,size', [(3, 63), (2, 70)])
 def test_cnn_backward_chain(dtype, tol, B, size):
     """Every backward kernel on a shallow stack (stem conv, 3x3 SAME, max pool, 1x7, avg pool,
@@ -408,7 +447,7 @@ def test_cnn_backward_chain(dtype, tol, B, size):
     plan dtypes, ragged batch: d weights / d beta against the oracle's reverse pass over a
     forward that emulates the plan's storage type."""
     rng = np.random.default_rng(5 + B)
-    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN)
+    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN, x3=dtype == 'bf16x3')
     params = cnn_ref.randomize_bn(plan.init_params(seed=3), seed=4)
     x = rng.uniform(-1, 1, (B, size, size, 3)).astype(np.float32)
     Hf, Wf, Cf, _ = plan.buffers[plan.fm]
@@ -417,7 +456,11 @@ def test_cnn_backward_chain(dtype, tol, B, size):
     im, fm = enc.forward(dev(x))
     t = enc.backward(dev(d_fm), dev(d_net))
     sync()
-    h, pooled, want = _chain_oracle(params, x, d_net, d_fm, dtype)
+    # (bf16x3: fp32-class activations, 5e-6 from the oracle's -- enough to flip a ReLU mask or a max-pool arg-max here and
+    # there, each worth 1e-3 ... 1e-2 of a small layer's gradient: the oracle differentiates through the device's
+    # activations, as in the whole-network tests)
+    hook = _device_activation_hook(enc, 1e-4, [0.0]) if dtype == 'bf16x3' else None
+    h, pooled, want = _chain_oracle(params, x, d_net, d_fm, 'f32' if dtype == 'bf16x3' else dtype, hook)
     assert_close(fm.cpu().numpy().reshape(h.shape), h, tol, 'chain fm ' + dtype)
     assert_close(im.cpu().numpy(), pooled.reshape(B, -1), tol, 'chain pooled ' + dtype)
     got = _cnn_grads_device(enc, t)
