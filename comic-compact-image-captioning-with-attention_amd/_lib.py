@@ -114,6 +114,7 @@ _SIGS = {
     'comic_cnn_backward': (c_int, [P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
     'comic_cnn_backward_sched': (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
     'comic_cnn_pack_bwd_filters': (c_int, [P, c_int, P, c_int, P]),
+    'comic_cnn_pack_x3_weights': (c_int, [P, P, P, P, P, c_int, P]),
     'comic_cnn_refresh_weights': (c_int, [P, P, c_int64, P, P, P, P, c_int64, P]),
     'comic_cnn_pack_frag_weights': (c_int, [P, P, P, c_int, c_int64, P]),
     'comic_crc32c': (C.c_uint32, [P, C.c_size_t, C.c_uint32]),

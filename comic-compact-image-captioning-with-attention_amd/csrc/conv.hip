@@ -3650,6 +3650,41 @@ int pack_bwd_filters_impl(const comic_cnn_op* ops, int n_ops, const comic_conv_g
   return 0;
 }
 
+// forward filters of a COMIC_OP_X3 plan from the masters, every conv in one launch (comic_cnn_pack_x3_weights)
+struct PackX3Entry {
+  const float* master;
+  bf16_t* out;
+  uint32_t first_block;
+  uint16_t cout, cin, taps, pad;
+};
+struct PackX3Table {
+  PackX3Entry e[kPackTableMax];
+  int n;
+};
+static_assert(sizeof(PackX3Table) <= 4096, "kernel argument block");
+__global__ __launch_bounds__(256) void pack_x3_table_kernel(const PackX3Table tb) {
+  int lo = 0, hi = tb.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb.e[mid].first_block <= blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackX3Entry& en = tb.e[lo];
+  const int cin = en.cin, K = en.taps * cin, kpad = (K + 63) / 64 * 64, kpad3 = (3 * K + 63) / 64 * 64;
+  const long idx = (long)(blockIdx.x - en.first_block) * blockDim.x + threadIdx.x;
+  if (idx >= (long)en.cout * kpad3) return;
+  const int k3 = (int)(idx % kpad3), row = (int)(idx / kpad3);
+  bf16_t o = f32_to_bf16(0.f);
+  if (k3 < 3 * K) {
+    const int tap = k3 / (3 * cin), rr = k3 - tap * 3 * cin;
+    const int region = rr / cin, ci = rr - region * cin;
+    const float v = en.master[(size_t)row * kpad + tap * cin + ci];
+    const bf16_t h = f32_to_bf16(v);
+    o = region < 2 ? h : f32_to_bf16(v - bf16_to_f32(h));
+  }
+  en.out[idx] = o;
+}
+
 template <typename T>
 int cnn_backward_impl(const comic_cnn_op* ops, int n_ops, void* const* buffers, void* const* grad_buffers,
                       const int32_t* buf_channels, const comic_conv_weight* weights, const comic_conv_grad* grads,
@@ -3892,6 +3927,35 @@ extern "C" int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, cons
 extern "C" int64_t comic_cnn_backward_scratch_bytes(const comic_cnn_op* ops, int n_ops, int batch, int dtype, int lanes) {
   if (!ops) return -1;
   return backward_scratch_bytes(ops, n_ops, batch, dtype == COMIC_BF16 ? 2 : 4, lanes > 1);
+}
+
+extern "C" int comic_cnn_pack_x3_weights(const float* const* masters, void* const* outs, const int32_t* cout,
+                                         const int32_t* taps, const int32_t* cin, int n, void* stream) {
+  COMIC_REQUIRE(masters && outs && cout && taps && cin && n >= 0, "comic_cnn_pack_x3_weights: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  PackX3Table tb;
+  tb.n = 0;
+  uint32_t blocks = 0;
+  auto flush = [&]() {
+    if (tb.n) hipLaunchKernelGGL(pack_x3_table_kernel, dim3(blocks), dim3(256), 0, st, tb);
+    tb.n = 0;
+    blocks = 0;
+  };
+  for (int i = 0; i < n; ++i) {
+    COMIC_REQUIRE(masters[i] && outs[i] && cout[i] > 0 && cout[i] <= 65535 && cin[i] > 0 && cin[i] <= 65535 && taps[i] > 0 &&
+                      taps[i] <= 65535, "comic_cnn_pack_x3_weights: bad entry %d", i);
+    if (tb.n == kPackTableMax) flush();
+    PackX3Entry& en = tb.e[tb.n++];
+    en.master = masters[i];
+    en.out = (bf16_t*)outs[i];
+    en.first_block = blocks;
+    en.cout = (uint16_t)cout[i]; en.cin = (uint16_t)cin[i]; en.taps = (uint16_t)taps[i]; en.pad = 0;
+    const long K3 = 3L * taps[i] * cin[i];
+    blocks += (uint32_t)cdiv64((long)cout[i] * ((K3 + 63) / 64 * 64), 256);
+  }
+  flush();
+  COMIC_LAUNCH_CHECK("pack_x3_weights");
+  return 0;
 }
 
 extern "C" int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads, int dtype,

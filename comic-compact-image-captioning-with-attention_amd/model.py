@@ -52,10 +52,8 @@ class ModelBase(object):
             # frozen CNN (every mode but cnn_finetune): forward-only plan with the pool branches rewritten
             frozen = bool(getattr(c, 'freeze_scopes', 'Model/encoder/cnn'))
             # --cnn_dtype bf16x3: hi / lo split activations and filters on the bf16 kernels (nets.CnnPlan(x3=True)),
-            # the fast plan at the fp32 parity bar; frozen-CNN modes only (no backward over the split layout)
+            # the fast plan at the fp32 parity bar, every train mode (cnn_finetune: csrc/conv.hip conv_backward_x3)
             x3 = getattr(c, 'cnn_dtype', 'bf16') == 'bf16x3'
-            if x3 and not frozen:
-                raise ValueError('cnn_dtype bf16x3 is a forward-only plan: use bf16 or f32 for train_mode cnn_finetune')
             plan = nets.get_network_fn(c.cnn_name, num_classes=None, is_training=False)(
                 tuple(c.cnn_input_size), c.cnn_fm_attention, pool_after_projection=frozen, fuse_pools=frozen, x3=x3)
             share['plan'] = plan

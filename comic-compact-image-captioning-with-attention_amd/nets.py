@@ -832,20 +832,20 @@ class CnnEncoder:
 
     def _pack_x3(self):
         """The x3 plan copy of every conv filter from its fp32 master [Cout][Kpad]: per tap the channels
-        [bf16(w) | bf16(w) | bf16(w - bf16(w))] against activations stored [hi | lo | hi] (COMIC_OP_X3).  Tensor glue at
-        load / after an optimiser step of a frozen-CNN plan (torch ops, 94 small tensors)."""
-        torch = self.torch
-        for i, (prefix, kh, kw, cin, cout, stem) in enumerate(self.plan.weights):
-            if stem:
-                continue
-            cin_p, cout_p = self.plan.wphys[i]
-            K = kh * kw * cin_p
-            kpad, kpad3 = (K + 63) // 64 * 64, (3 * K + 63) // 64 * 64
-            m = self.w_master.view('w%d' % i).view(cout_p, kpad)[:, :K].reshape(cout_p, kh * kw, cin_p)
-            hi = m.to(torch.bfloat16)
-            lo = (m - hi.to(torch.float32)).to(torch.bfloat16)
-            dst = self.w_plan[self._x3_off[i]:self._x3_off[i] + cout_p * kpad3].view(cout_p, kpad3)
-            dst[:, :3 * K] = torch.cat([hi, hi, lo], dim=2).reshape(cout_p, 3 * K)
+        [bf16(w) | bf16(w) | bf16(w - bf16(w))] against activations stored [hi | lo | hi] (COMIC_OP_X3); at load and after
+        every optimiser step of cnn_finetune, one launch (comic_cnn_pack_x3_weights)."""
+        tb = self.__dict__.get('_x3_table')
+        if tb is None:          # pointer / shape tables of comic_cnn_pack_x3_weights (one launch for all convs)
+            idx = [i for i, w in enumerate(self.plan.weights) if not w[5]]
+            esz = self.w_plan.element_size()
+            tb = self._x3_table = (
+                (C.c_void_p * len(idx))(*[self.w_master.view('w%d' % i).data_ptr() for i in idx]),
+                (C.c_void_p * len(idx))(*[self.w_plan.data_ptr() + esz * self._x3_off[i] for i in idx]),
+                (C.c_int32 * len(idx))(*[self.plan.wphys[i][1] for i in idx]),
+                (C.c_int32 * len(idx))(*[self.plan.weights[i][1] * self.plan.weights[i][2] for i in idx]),
+                (C.c_int32 * len(idx))(*[self.plan.wphys[i][0] for i in idx]), len(idx))
+        L.check(self.lib.comic_cnn_pack_x3_weights(tb[0], tb[1], tb[2], tb[3], tb[4], tb[5], L.stream_ptr()),
+                'cnn_pack_x3_weights')
 
     def _unpack(self, i, flat_w, flat_b):
         """Packed master-layout buffers of weight i -> (HWIO array, per-channel vector) of the variable's shape."""

@@ -227,7 +227,15 @@ int comic_jpeg_preprocess_packed(const uint16_t* packed, const void* infos, int 
  *   w_bwd     plan-dtype scratch of Cin * roundup64(KH*KW*Cout) elements for the flipped /
  *             transposed filter of the backward-data pass (NULL for the stem conv)
  * comic_cnn_refresh_weights re-derives the plan-dtype weight copy (flat bf16 conversion of all
- * masters) and shift = beta - mean*scale after an optimiser step. */
+ * masters) and shift = beta - mean*scale after an optimiser step.
+ * COMIC_OP_X3 plans ("bf16x3": the same training step at fp32-class accuracy on the bf16 matrix cores): activation buffers
+ * hold the three bf16 regions, grad_buffers[i] is an fp32 buffer of the LOGICAL channels (a third of buffers[i]'s; fp32
+ * activation buffers as they are), masters / dw / dbeta keep the logical layout of the bf16 plan, and w_bwd holds
+ * (Cin / 3) * roundup64(KH*KW*3*Cout) bf16 -- [Wt_hi | Wt_hi | Wt_lo] per tap.  Per conv: d conv as [hi | lo | hi] regions,
+ * dw += x_hi dz_hi + x_lo dz_hi + x_hi dz_lo (three launches of the bf16 backward-weight kernel), backward-data as the bf16
+ * conv of d conv over 3 Cout channels accumulated in fp32; pools compare / sum hi + lo.  comic_cnn_backward only (the
+ * scheduled form below takes bf16 / fp32 plans); the forward's [W_hi | W_hi | W_lo] copy follows the masters with
+ * comic_cnn_pack_x3_weights. */
 typedef struct comic_conv_grad {
   const float* w_master;
   float* dw;
@@ -271,6 +279,11 @@ int comic_cnn_backward_sched(const comic_cnn_op* ops, int n_ops, const int32_t* 
 /* Packs the backward-data filters of every conv from the masters (what comic_cnn_backward does per
  * conv when filters_ready == 0).  They only change with the optimiser step, so the caller can do
  * this once per step off the critical path (e.g. on a second stream during the next forward). */
+/* COMIC_OP_X3 plans: the forward filter copy of n convs from their fp32 masters in one launch -- masters[i] [cout[i]][roundup64(taps[i]
+ * cin[i])] (k = tap cin + ci) -> outs[i] bf16 [cout[i]][roundup64(3 taps[i] cin[i])], per tap [bf16(w) | bf16(w) | bf16(w - bf16(w))]
+ * (cin = channels of ONE activation region; padding columns zero).  After an optimiser step of cnn_finetune on a bf16x3 plan. */
+int comic_cnn_pack_x3_weights(const float* const* masters, void* const* outs, const int32_t* cout, const int32_t* taps,
+                              const int32_t* cin, int n, void* stream);
 int comic_cnn_pack_bwd_filters(const comic_cnn_op* ops, int n_ops, const comic_conv_grad* grads,
                                int dtype, void* stream);
 int comic_cnn_refresh_weights(const float* master, void* plan_copy, int64_t n, const float* beta,

@@ -145,8 +145,8 @@ def test_train_infer_cli_default_backbone(tmp_path):
 
 def test_train_infer_cli_bf16x3_plan(tmp_path):
     """--cnn_dtype bf16x3 (the bf16 matrix cores at fp32-class accuracy: nets.CnnPlan(x3=True)): one decoder-mode epoch on
-    InceptionV3 and beam-3 inference from the run directory (the plan follows config.pkl); cnn_finetune refuses the
-    forward-only layout at build time."""
+    InceptionV3, one cnn_finetune epoch on top of it (the x3 backward: fp32 gradient buffers, three-product weight
+    gradients) and beam-3 inference from the run directory (the plan follows config.pkl)."""
     from tests import tiny_dataset
     from comic_amd import configuration as conf
     ds = tiny_dataset.make(str(tmp_path / 'mscoco'), n_train=8, n_valid=4, n_test=4)
@@ -166,10 +166,18 @@ def test_train_infer_cli_bf16x3_plan(tmp_path):
                                                  '--get_metric_score', ''])
     caps = glob.glob(os.path.join(run_dir, 'infer_test_beam_3_lpen_0.0', 'captions___*.json'))
     assert caps and len(json.load(open(caps[0]))) == 4
-    from comic_amd import nets
-    with pytest.raises(ValueError):
-        px = nets.CnnPlan('inception_v3', (139, 139), x3=True)
-        nets.CnnEncoder(px, px.init_params(0), 2, 'bf16x3', 'cuda:0').enable_training()
+    # cnn_finetune on top of the decoder run, same plan: the CNN variables move
+    z0 = np.load(sorted(glob.glob(os.path.join(run_dir, 'model_compact-*.npz')))[-1])
+    _run(os.path.join(ROOT, 'src', 'train.py'), common + ['--train_mode', 'cnn_finetune', '--batch_size_train', '4',
+                                                          '--max_epoch', '1'])
+    errs = glob.glob(os.path.join(logs, 'mscoco', 'error__*'))
+    assert not errs, open(errs[0]).read()
+    ft_dir = run_dir.replace('_run_01', '_cnnFT_run_01')
+    ck = sorted(glob.glob(os.path.join(ft_dir, 'model_compact-*.npz')))
+    assert ck, os.listdir(os.path.join(logs, 'mscoco'))
+    z1 = np.load(ck[-1])
+    k = 'Model/encoder/cnn/InceptionV3/Mixed_7c/Branch_0/Conv2d_0a_1x1/weights'
+    assert np.isfinite(z1[k]).all() and not np.array_equal(z1[k], z0[k]), 'CNN variables were not trained'
 
 
 @pytest.mark.parametrize('rnn,var', [('LN_LSTM', 'layer_norm_basic_lstm_cell/state/gamma'), ('GRU', 'gru_cell/candidate/kernel')])

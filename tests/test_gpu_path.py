@@ -46,6 +46,18 @@ def test_inception_v3_forward_224_bf16x3_meets_the_fp32_bar(cnn_params):
     plan = nets.CnnPlan('inception_v3', (224, 224), x3=True)
     assert all(o['flags'] & L.OP_X3 for o in plan.ops if o['kind'] in (0, 1, 2, 3))
     enc = nets.CnnEncoder(plan, cnn_params, B, 'bf16', DEV)
+    # the filter copy (comic_cnn_pack_x3_weights, one launch): per tap [bf16(w) | bf16(w) | bf16(w - bf16(w))], zero padding
+    for i in (1, 5, 40, 93):
+        prefix, kh, kw, cin, cout, stem = plan.weights[i]
+        cin_p, cout_p = plan.wphys[i]
+        K = kh * kw * cin_p
+        kpad, kpad3 = (K + 63) // 64 * 64, (3 * K + 63) // 64 * 64
+        m = enc.w_master.view('w%d' % i).view(cout_p, kpad)[:, :K].reshape(cout_p, kh * kw, cin_p)
+        hi = m.to(torch.bfloat16)
+        lo = (m - hi.float()).to(torch.bfloat16)
+        got = enc.w_plan[enc._x3_off[i]:enc._x3_off[i] + cout_p * kpad3].view(cout_p, kpad3)
+        assert torch.equal(got[:, :3 * K], torch.cat([hi, hi, lo], dim=2).reshape(cout_p, 3 * K)), prefix
+        assert not got[:, 3 * K:].any()
     im, fm = (t.clone() for t in enc.forward(dev(x)))
     sync()
     net_ref, ep = cnn_ref.inception_v3(cnn_params, x, act_dtype='f32')
@@ -927,14 +939,16 @@ def test_pipelined_xe_steps_equal_serial_steps(group):
     np.testing.assert_array_equal(tr.decoder.params.data.cpu().numpy(), ser.decoder.params.data.cpu().numpy())
 
 
-def test_cnn_finetune_step_end_to_end():
+@pytest.mark.parametrize('dtype', ['f32', 'bf16x3'])
+def test_cnn_finetune_step_end_to_end(dtype):
     """train_mode cnn_finetune on a shallow stack: CNN forward -> decoder XE step -> CNN backward
     -> TF-Adam on decoder AND CNN variables, against the oracle chain (cnn_ref reverse pass fed by
     decoder_ref's input gradients, then adam_tf_update); two steps, so the second one runs on the
-    refreshed weights.  fp32 plan."""
+    refreshed weights (bf16x3: the [W_hi | W_hi | W_lo] forward copy and the backward-data filters repacked from the
+    masters).  fp32 plan and the bf16x3 plan, both at the fp32 bar."""
     from comic_amd import trainer
     B, size, Lc = 3, 63, 9
-    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN)
+    plan = nets.CnnPlan('chain', (size, size), layers=_CHAIN, x3=dtype == 'bf16x3')
     cnn_p = cnn_ref.randomize_bn(plan.init_params(seed=3), seed=4)
     Hf, Wf, Cf, _ = plan.buffers[plan.fm]
     spec, cfg = _spec_and_cfg(C=Cf, Cg=Cf, M=Hf * Wf, l2_decay=0.0)
@@ -944,7 +958,7 @@ def test_cnn_finetune_step_end_to_end():
     x = rng.uniform(-1, 1, (B, size, size, 3)).astype(np.float32)
     _, _, caps = _batch(spec, B, Lc, 7)
     lr, eps = 1e-2, 1e-2
-    tr = trainer.CaptionTrainer(cnn_p, spec, p, B, (size, size), 'f32', DEV, lr_start=lr, lr_end=lr, max_step=10,
+    tr = trainer.CaptionTrainer(cnn_p, spec, p, B, (size, size), dtype, DEV, lr_start=lr, lr_end=lr, max_step=10,
                                 adam_epsilon=eps, plan=plan)
     tr.use_graph = False
     tr.enable_cnn_finetune()
