@@ -309,6 +309,29 @@ def extras(device, enc, cnn_params, plan):
     out['cnn_finetune_conv_mfma_frac'] = round(out['cnn_finetune_images_per_sec'] * 3 * FLOP_PER_IMAGE_CNN / PEAK_BF16_MFMA, 5)
     del tr
     torch.cuda.empty_cache()
+    # the same step on the bf16x3 plan: the trainable CNN at the fp32 parity bar (gradients 1.3e-5 from the fp32 oracle where
+    # the bf16 plan is at 4e-2; tests/test_gpu_path.py test_inception_v3_backward_224_bf16x3_meets_the_fp32_bar)
+    try:
+        plan_x3 = nets.CnnPlan('inception_v3', (IMG, IMG), x3=True)
+        tr = trainer.CaptionTrainer(cnn_params, cdec.DecoderSpec(), None, Bf, (IMG, IMG), 'bf16x3', device, seed=5, plan=plan_x3)
+        tr.enable_cnn_finetune()
+        if tune:
+            tr.encoder.autotune()
+        for _ in range(3):
+            tr.finetune_step(imgs, caps)
+        torch.cuda.synchronize()
+        n, t0 = 10, time.perf_counter()
+        for _ in range(n):
+            res = tr.finetune_step(imgs, caps)
+        torch.cuda.synchronize()
+        out['cnn_finetune_x3'] = {'images_per_sec': round(Bf * n / (time.perf_counter() - t0), 1), 'cnn_dtype': 'bf16x3',
+                                  'loss': round(float(res['loss']), 4),
+                                  'note': 'cnn_finetune at the fp32 parity bar on the bf16 matrix cores: activations / d conv as '
+                                          'hi-lo regions, 3 bf16 products per conv each way, fp32 gradient buffers'}
+        del tr
+    except Exception as e:
+        out['cnn_finetune_x3'] = {'error': repr(e)}
+    torch.cuda.empty_cache()
     # ---- decoder-mode XE at 299 x 299: the north star's 8x8x2048 map (M = 64), batch 64, serial steps ----------------
     plan299 = nets.CnnPlan('inception_v3', (299, 299), pool_after_projection=True, fuse_pools=True)
     # frozen CNN: ONE forward covers the batches of the next G_299 steps, as in the headline (serial here: forward, then its steps)
@@ -1001,6 +1024,7 @@ def main():
                           'beam3': ex.get('beam3_captions_per_sec'), 'beam3_frac': _g(ex, 'beam3_roofline', 'frac'),
                           'scst': ex.get('scst_images_per_sec'), 'cnn_finetune': ex.get('cnn_finetune_images_per_sec'),
                           'cnn_finetune_frac': ex.get('cnn_finetune_conv_mfma_frac'),
+                          'cnn_finetune_x3': _g(ex, 'cnn_finetune_x3', 'images_per_sec'),
                           'xe_x3': _g(ex, 'xe_x3', 'images_per_sec'), 'xe_f32': _g(ex, 'xe_f32', 'images_per_sec'),
                           'xe_299': _g(ex, 'xe_299', 'images_per_sec'), 'xe_v1': _g(ex, 'xe_v1', 'images_per_sec'),
                           'input_pipeline': _g(ex, 'input_pipeline', 'images_per_sec'),

@@ -2796,6 +2796,9 @@ struct WgradArgs {
   const void* dz;   // [B][Hd][Wd][dz_cs] plan dtype, channels [dz_co, dz_co + Cout) (plain plans: dz_cs = Cout, dz_co = 0)
   int Hd, Wd, dil, dz_cs, dz_co;
   int x_part;       // STEM, bf16: 0 the image rounded to bf16, 1 its rounding residue (the lo half of an x3 backward)
+  int parts;        // 3: the x3 backward's three products in ONE launch -- blockIdx.z = split * 3 + part, part 0 (x hi, dz hi),
+                    // 1 (x lo: x_lo_off channels further / the stem's residue, dz hi), 2 (x hi, dz lo: z_lo_off channels further)
+  int x_lo_off, z_lo_off;
   const void* x;    // forward input (plan dtype; STEM: fp32 image)
   int x_cs, x_co;
   float* dw;        // [Cout][Kpad] fp32 (STEM: [K][Cout]), accumulated with atomics
@@ -2815,7 +2818,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int kk0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
-  const long p_begin = (long)blockIdx.z * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
+  int bz = blockIdx.z;
+  if (a.parts == 3) {
+    const int part = bz % 3;
+    bz /= 3;
+    a.x_co += part == 1 ? a.x_lo_off : 0;
+    a.x_part = part == 1;
+    a.dz_co += part == 2 ? a.z_lo_off : 0;
+  }
+  const long p_begin = (long)bz * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
   const int px_l = tid / CPP, cg = tid % CPP;
   // this thread's fixed channel chunk of each tile
   const int co_c = co0 + cg * EPC;
@@ -2976,7 +2987,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int kk0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
-  const long p_begin = (long)blockIdx.z * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
+  int bz = blockIdx.z;
+  if (a.parts == 3) {
+    const int part = bz % 3;
+    bz /= 3;
+    a.x_co += part == 1 ? a.x_lo_off : 0;
+    a.dz_co += part == 2 ? a.z_lo_off : 0;
+  }
+  const long p_begin = (long)bz * a.p_per_split, p_end = min(a.P, p_begin + a.p_per_split);
   const int px_l = tid >> 3, cg = tid & 7;     // pixel of the step, 8-channel chunk inside 64 channels
   // fixed channel chunks of this thread
   int co_c[ZCH];
@@ -3448,8 +3466,9 @@ inline bool link_streams(hipStream_t from, hipStream_t to) {     // `to` waits f
 // the three bf16 regions [hi | lo | hi] (xc, yc: physical channels = 3 x logical; fp32 outputs as they are), gradient
 // buffers fp32 of the LOGICAL channels (gxc, gyc), masters and weight gradients the logical [Cout][Kpad] of the bf16 plan.
 //   dz  = 1[y > 0] dy scale as [hi | lo | hi]                                              (act_grad_x3_kernel)
-//   dw += x_hi^T dz_hi + x_lo^T dz_hi + x_hi^T dz_lo      three launches of the bf16 backward-weight kernel over channel
-//                                                         slices of the regions, fp32 atomics into the one dw
+//   dw += x_hi^T dz_hi + x_lo^T dz_hi + x_hi^T dz_lo      one launch of the bf16 backward-weight kernel, three work items per
+//                                                         (tile, pixel split) over channel slices of the regions, fp32
+//                                                         atomics into the one dw
 //   gx += conv(dz, [Wt_hi | Wt_hi | Wt_lo])               the bf16 forward kernels over 3 Cout channels, fp32 accumulate
 int conv_backward_x3(const comic_cnn_op* op, const void* x, int xc, const void* y, const float* gy, int yc, int gyc, float* gx,
                      int gxc, const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
@@ -3480,33 +3499,29 @@ int conv_backward_x3(const comic_cnn_op* op, const void* x, int xc, const void* 
     a.B = batch; a.H = op->H; a.W = op->W; a.Cin = cin; a.Cout = op->Cout; a.KH = op->KH; a.KW = op->KW;
     a.SH = op->SH; a.SW = op->SW; a.PT = op->PT; a.PL = op->PL; a.Ho = op->Ho; a.Wo = op->Wo; a.K = K; a.Kpad = Kpad;
     a.P = (long)batch * op->Ho * op->Wo;
-    for (int part = 0; part < 3; ++part) {                // (x, dz) halves: hi hi, lo hi, hi lo
-      const bool xl = part == 1, zl = part == 2;
-      a.dz_co = zl ? op->Cout : 0;
-      a.x_co = op->src_coff + (xl ? x_lo : 0);
-      a.x_part = xl ? 1 : 0;
-      if (stem) {
-        COMIC_REQUIRE(op->Cin <= 4, "stem conv backward: needs Cin <= 4");
-        const int tiles = cdiv(K, 64) * cdiv(op->Cout, 64);
-        long S = std::max<long>(1, std::min<long>(2048 / tiles, cdiv64(a.P, 32L * 8)));
-        a.p_per_split = cdiv64(cdiv64(a.P, S), 32) * 32;
-        S = cdiv64(a.P, a.p_per_split);
-        hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), dim3(cdiv(K, 64), cdiv(op->Cout, 64), (unsigned)S), dim3(256), 0,
-                           st_w, a);
-      } else {
-        COMIC_REQUIRE(cin % 8 == 0 && op->src_coff % 8 == 0 && x_lo % 8 == 0, "conv backward (x3): misaligned input slice");
-        const bool big_m = op->Cout % 128 == 0, big_n = Kpad % 128 == 0 && K >= 256;
-        const int bm = big_m ? 128 : 64, bn = big_n ? 128 : 64;
-        const int tiles2 = cdiv(K, bn) * cdiv(op->Cout, bm);
-        long S2 = std::max<long>(1, std::min<long>(wgrad_blocks_target() / tiles2, cdiv64(a.P, 32L * 8)));
-        a.p_per_split = cdiv64(cdiv64(a.P, S2), 32) * 32;
-        S2 = cdiv64(a.P, a.p_per_split);
-        dim3 g2(cdiv(K, bn), cdiv(op->Cout, bm), (unsigned)S2);
-        if (big_m && big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), g2, dim3(256), 0, st_w, a);
-        else if (big_m) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), g2, dim3(256), 0, st_w, a);
-        else if (big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), g2, dim3(256), 0, st_w, a);
-        else hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), g2, dim3(256), 0, st_w, a);
-      }
+    // the three products (x hi, dz hi), (x lo, dz hi), (x hi, dz lo) in one launch: blockIdx.z = split * 3 + part
+    a.parts = 3; a.dz_co = 0; a.x_co = op->src_coff; a.x_part = 0; a.x_lo_off = x_lo; a.z_lo_off = op->Cout;
+    if (stem) {
+      COMIC_REQUIRE(op->Cin <= 4, "stem conv backward: needs Cin <= 4");
+      const int tiles = cdiv(K, 64) * cdiv(op->Cout, 64) * 3;
+      long S = std::max<long>(1, std::min<long>(2048 / tiles, cdiv64(a.P, 32L * 8)));
+      a.p_per_split = cdiv64(cdiv64(a.P, S), 32) * 32;
+      S = cdiv64(a.P, a.p_per_split);
+      hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), dim3(cdiv(K, 64), cdiv(op->Cout, 64), (unsigned)(3 * S)), dim3(256), 0,
+                         st_w, a);
+    } else {
+      COMIC_REQUIRE(cin % 8 == 0 && op->src_coff % 8 == 0 && x_lo % 8 == 0, "conv backward (x3): misaligned input slice");
+      const bool big_m = op->Cout % 128 == 0, big_n = Kpad % 128 == 0 && K >= 256;
+      const int bm = big_m ? 128 : 64, bn = big_n ? 128 : 64;
+      const int tiles2 = cdiv(K, bn) * cdiv(op->Cout, bm) * 3;
+      long S2 = std::max<long>(1, std::min<long>(wgrad_blocks_target() / tiles2, cdiv64(a.P, 32L * 8)));
+      a.p_per_split = cdiv64(cdiv64(a.P, S2), 32) * 32;
+      S2 = cdiv64(a.P, a.p_per_split);
+      dim3 g2(cdiv(K, bn), cdiv(op->Cout, bm), (unsigned)(3 * S2));
+      if (big_m && big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 128>), g2, dim3(256), 0, st_w, a);
+      else if (big_m) hipLaunchKernelGGL((conv_wgrad_tr_kernel<128, 64>), g2, dim3(256), 0, st_w, a);
+      else if (big_n) hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 128>), g2, dim3(256), 0, st_w, a);
+      else hipLaunchKernelGGL((conv_wgrad_tr_kernel<64, 64>), g2, dim3(256), 0, st_w, a);
     }
   }
   COMIC_LAUNCH_CHECK("conv backward (x3, weights)");

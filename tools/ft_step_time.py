@@ -6,8 +6,9 @@ import bench
 from comic_amd import decoder as cdec, nets, trainer
 dev = 'cuda:0'
 Bf = int(os.environ.get('B', '32'))
-plan = nets.CnnPlan('inception_v3', (224, 224))
-tr = trainer.CaptionTrainer(plan.init_params(0), cdec.DecoderSpec(), None, Bf, (224, 224), 'bf16', dev, seed=5, plan=plan)
+X3 = os.environ.get('X3', '0') == '1'            # the bf16x3 plan (cnn_finetune at the fp32 parity bar)
+plan = nets.CnnPlan('inception_v3', (224, 224), x3=X3)
+tr = trainer.CaptionTrainer(plan.init_params(0), cdec.DecoderSpec(), None, Bf, (224, 224), 'bf16x3' if X3 else 'bf16', dev, seed=5, plan=plan)
 tr.enable_cnn_finetune(autotune_backward=os.environ.get('COMIC_AUTOTUNE_BWD', '0') == '1', tune_cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     tr.encoder.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
