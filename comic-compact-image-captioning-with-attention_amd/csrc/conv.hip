@@ -3199,10 +3199,12 @@ __global__ __launch_bounds__(256) void pool_grad_kernel(PoolGradArgs a) {
 //   3. one thread per (input pixel, chunk) adds the dy of its <= 4 windows whose arg-max it is, in (ho, wo) order, into dx.
 // Same comparisons, same sums in the same order as pool_grad_kernel<T, 0>: identical bits.
 constexpr int kMpgTile = 16, kMpgWin = kMpgTile / 2 + 1, kMpgX = 2 * kMpgWin + 1, kMpgCG = 4;
-template <typename T>
+// X3 (COMIC_OP_X3 plans): x is hi + lo of two bf16 regions (a.x_lo apart), dy / dx fp32 buffers with their own strides.
+template <typename T, bool X3 = false>
 __global__ __launch_bounds__(256) void maxpool_grad_s2_kernel(PoolGradArgs a, int tiles_y, int tiles_x, int cgroups) {
   constexpr int EPC = Elem<T>::EPC;
   __shared__ uint4 xs[kMpgCG][kMpgX * kMpgX];                           // raw 16-byte chunks of the input pixels
+  __shared__ uint4 xs_lo[X3 ? kMpgCG : 1][X3 ? kMpgX * kMpgX : 1];      // ... of their lo region
   __shared__ __attribute__((aligned(16))) float dys[kMpgCG][kMpgWin * kMpgWin][EPC];
   __shared__ __attribute__((aligned(8))) unsigned char args[kMpgCG][kMpgWin * kMpgWin][8];
   int bid = blockIdx.x;
@@ -3227,10 +3229,14 @@ __global__ __launch_bounds__(256) void maxpool_grad_s2_kernel(PoolGradArgs a, in
       const int c = i % ncv, px = i / ncv;
       const int r = px / nxc, q = px - r * nxc;
       const int h = xr0 + r, w = xc0 + q;
-      uint4 v = make_uint4(ninf, ninf, ninf, ninf);
-      if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = *(const uint4*)((const T*)a.x + ((size_t)(b * a.H + h) * a.W + w) * a.xcs + a.xco + (cv0 + c) * EPC);
+      uint4 v = make_uint4(ninf, ninf, ninf, ninf), vl = make_uint4(0, 0, 0, 0);
+      if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) {
+        const T* xp = (const T*)a.x + ((size_t)(b * a.H + h) * a.W + w) * a.xcs + a.xco + (cv0 + c) * EPC;
+        v = *(const uint4*)xp;
+        if constexpr (X3) vl = *(const uint4*)(xp + a.x_lo);
+      }
       xs[c][r * kMpgX + q] = v;
+      if constexpr (X3) xs_lo[c][r * kMpgX + q] = vl;
     }
   }
   __syncthreads();
@@ -3248,6 +3254,12 @@ __global__ __launch_bounds__(256) void maxpool_grad_s2_kernel(PoolGradArgs a, in
         for (int kw = 0; kw < 3; ++kw) {
           float v[EPC];
           load_vec<T>((const T*)&xs[c][(2 * wr + kh) * kMpgX + 2 * wq + kw], v);
+          if constexpr (X3) {
+            float vl[EPC];
+            load_vec<T>((const T*)&xs_lo[c][(2 * wr + kh) * kMpgX + 2 * wq + kw], vl);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) v[j] += vl[j];
+          }
 #pragma unroll
           for (int j = 0; j < EPC; ++j)
             if (v[j] > best[j]) { best[j] = v[j]; arg[j] = kh * 3 + kw; }
@@ -3292,7 +3304,7 @@ __global__ __launch_bounds__(256) void maxpool_grad_s2_kernel(PoolGradArgs a, in
           if (aj == mine) g[j] += dv[j];
         }
       }
-    const size_t off = ((size_t)(b * a.H + hi) * a.W + wi) * a.xcs + a.xco + (cv0 + c) * EPC;
+    const size_t off = ((size_t)(b * a.H + hi) * a.W + wi) * a.dxcs + a.dxco + (cv0 + c) * EPC;
     float old[EPC];
     load_chunk_f<T>(a.dx, off, a.dx_f32 != 0, old);
 #pragma unroll
@@ -3562,12 +3574,17 @@ int pool_backward(const comic_cnn_op* op, const void* x, int xc, const void* gy,
   }
   const long total = (long)batch * op->H * op->W * (op->Cin / EPC);
   dim3 grid((unsigned)cdiv64(total, 256));
-  if (!x3 && op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 2 && op->SW == 2 && op->PT >= 0 && op->PT <= 1 && op->PL >= 0 &&
+  if (op->kind == 2 && op->KH == 3 && op->KW == 3 && op->SH == 2 && op->SW == 2 && op->PT >= 0 && op->PT <= 1 && op->PL >= 0 &&
       op->PL <= 1) {
     const int tiles_y = cdiv(op->H, kMpgTile), tiles_x = cdiv(op->W, kMpgTile), cgroups = cdiv(op->Cin / EPC, kMpgCG);
     const long wgs = (long)batch * tiles_y * tiles_x * cgroups;
     COMIC_REQUIRE(wgs < (1L << 31), "pool backward: too many tiles");
-    hipLaunchKernelGGL((maxpool_grad_s2_kernel<T>), dim3((unsigned)wgs), dim3(256), 0, st, a, tiles_y, tiles_x, cgroups);
+    if constexpr (sizeof(T) == 2) {
+      if (x3) hipLaunchKernelGGL((maxpool_grad_s2_kernel<T, true>), dim3((unsigned)wgs), dim3(256), 0, st, a, tiles_y, tiles_x, cgroups);
+      else hipLaunchKernelGGL((maxpool_grad_s2_kernel<T>), dim3((unsigned)wgs), dim3(256), 0, st, a, tiles_y, tiles_x, cgroups);
+    } else {
+      hipLaunchKernelGGL((maxpool_grad_s2_kernel<T>), dim3((unsigned)wgs), dim3(256), 0, st, a, tiles_y, tiles_x, cgroups);
+    }
   } else if (op->kind == 2)
     hipLaunchKernelGGL((pool_grad_kernel<T, 0>), grid, dim3(256), 0, st, a);
   else if (op->kind == 3)
@@ -3848,6 +3865,11 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
         COMIC_REQUIRE(any && grad_buffers[r[1]] && grad_alt && grad_alt[r[1]], "cnn_backward_sched: no alternate buffer %d", r[1]);
         const long n = (long)batch * any->H * any->W * buf_channels[r[1]];
         COMIC_REQUIRE(n % EPC == 0, "cnn_backward_sched: buffer %d is not a whole number of 16-byte chunks", r[1]);
+        if ((any->flags & COMIC_OP_X3) && any->kind <= 3 && any->kind != 1) {      // x3 plans: fp32 gradients of the logical channels
+          COMIC_REQUIRE(n % 12 == 0, "cnn_backward_sched: buffer %d is not three regions of whole chunks", r[1]);
+          hipLaunchKernelGGL((add_clear_kernel<float>), dim3((unsigned)cdiv64(n / 12, 256)), dim3(256), 0, s0,
+                             (float*)grad_buffers[r[1]], (float*)grad_alt[r[1]], n / 12);
+        } else
         hipLaunchKernelGGL((add_clear_kernel<T>), dim3((unsigned)cdiv64(n / EPC, 256)), dim3(256), 0, s0,
                            (T*)grad_buffers[r[1]], (T*)grad_alt[r[1]], n / EPC);
       }
@@ -3863,7 +3885,17 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
     void* gx = r[3] ? (grad_alt ? grad_alt[op->src] : nullptr) : grad_buffers[op->src];
     COMIC_REQUIRE(!r[3] || gx, "cnn_backward_sched: op %d has no alternate input-gradient buffer", r[1]);
     const int xc = buf_channels[op->src], yc = buf_channels[op->dst];
-    if (op->kind <= 1) {
+    const bool x3 = (op->flags & COMIC_OP_X3) != 0;
+    if (x3 && op->kind <= 1) {
+      if constexpr (sizeof(T) == 2) {
+        if (int rc = conv_backward_x3(op, buffers[op->src], xc, buffers[op->dst], (const float*)gy, yc, op->out_f32 ? yc : yc / 3,
+                                      (float*)gx, op->kind == 1 ? 0 : xc / 3, weights + op->weight, grads + op->weight, batch,
+                                      (char*)scratch + dz_off[r[1]], (int64_t)dz_bytes_of(op, batch, sizeof(T)), st, filters_ready, st_w))
+          return rc;
+      } else {
+        COMIC_REQUIRE(false, "cnn_backward_sched: COMIC_OP_X3 is a bf16-plan layout");
+      }
+    } else if (op->kind <= 1) {
       void* dz = (char*)scratch + dz_off[r[1]];
       ConvMask mk{};
       const int p = fuses[r[1]];
@@ -3879,7 +3911,7 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
         return rc;
     } else if (op->kind <= 4) {
       if (!gx) continue;
-      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st)) return rc;
+      if (int rc = pool_backward<T>(op, buffers[op->src], xc, gy, yc, gx, batch, st, x3 && op->kind <= 3)) return rc;
     } else {
       COMIC_REQUIRE(false, "cnn_backward_sched: unknown op kind %d", op->kind);
     }

@@ -964,7 +964,7 @@ class CnnEncoder:
         # branch lanes of the backward (backward_schedule): a second chain stream and alternate gradient buffers of the
         # blocks' shared inputs (zero between steps: the join adds them in and clears them)
         t.sched, t.lane1 = None, None
-        if self.backward_lanes and self.backward_branch_lanes and plan.name == 'inception_v3' and not x3:
+        if self.backward_lanes and self.backward_branch_lanes and plan.name == 'inception_v3':
             sched, alt_bufs = backward_schedule(plan)
             if alt_bufs:
                 t.sched = np.ascontiguousarray(sched)

@@ -233,8 +233,8 @@ int comic_jpeg_preprocess_packed(const uint16_t* packed, const void* infos, int 
  * activation buffers as they are), masters / dw / dbeta keep the logical layout of the bf16 plan, and w_bwd holds
  * (Cin / 3) * roundup64(KH*KW*3*Cout) bf16 -- [Wt_hi | Wt_hi | Wt_lo] per tap.  Per conv: d conv as [hi | lo | hi] regions,
  * dw += x_hi dz_hi + x_lo dz_hi + x_hi dz_lo (one launch of the bf16 backward-weight kernel, three work items per tile), backward-data as the bf16
- * conv of d conv over 3 Cout channels accumulated in fp32; pools compare / sum hi + lo.  comic_cnn_backward only (the
- * scheduled form below takes bf16 / fp32 plans); the forward's [W_hi | W_hi | W_lo] copy follows the masters with
+ * conv of d conv over 3 Cout channels accumulated in fp32; pools compare / sum hi + lo.  Both passes below take them (the
+ * scheduled one without the fused activation gradients); the forward's [W_hi | W_hi | W_lo] copy follows the masters with
  * comic_cnn_pack_x3_weights. */
 typedef struct comic_conv_grad {
   const float* w_master;

@@ -8,9 +8,10 @@ dev = 'cuda:0'
 Bf = int(os.environ.get('B', '32'))
 X3 = os.environ.get('X3', '0') == '1'            # the bf16x3 plan (cnn_finetune at the fp32 parity bar)
 plan = nets.CnnPlan('inception_v3', (224, 224), x3=X3)
-tr = trainer.CaptionTrainer(plan.init_params(0), cdec.DecoderSpec(), None, Bf, (224, 224), 'bf16x3' if X3 else 'bf16', dev, seed=5, plan=plan)
+DTYPE = 'bf16x3' if X3 else os.environ.get('DTYPE', 'bf16')       # DTYPE=f32: the exact-fp32 plan
+tr = trainer.CaptionTrainer(plan.init_params(0), cdec.DecoderSpec(), None, Bf, (224, 224), DTYPE, dev, seed=5, plan=plan)
 tr.enable_cnn_finetune(autotune_backward=os.environ.get('COMIC_AUTOTUNE_BWD', '0') == '1', tune_cache=os.environ.get('COMIC_TUNE_CACHE') or None)
-if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
+if os.environ.get('COMIC_AUTOTUNE', '1') == '1' and DTYPE != 'f32':
     tr.encoder.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 rng = np.random.default_rng(0)
 imgs = torch.from_numpy(rng.uniform(-1, 1, (Bf, 224, 224, 3)).astype(np.float32)).to(dev)
