@@ -54,7 +54,7 @@ def extras(device, enc, cnn_params, plan):
     and SCST images/sec (configs[3]: greedy + beam-7 rollouts, C++ CIDEr-D/BLEU reward, reward-weighted
     step, batch 32).  Synthetic inputs; single GPU."""
     import torch
-    from comic_amd import decoder as cdec, nets, optim
+    from comic_amd import decoder as cdec, nets, optim, streams
     from comic_amd.ops import id_to_caption, radix_ids_to_captions_and_ids, build_radix_wtoi
     from comic_amd.scst.scorers import captionScorer
     from comic_amd.scst import prepro_ngrams
@@ -89,7 +89,7 @@ def extras(device, enc, cnn_params, plan):
     pipe.submit(imgsG)
     # as `infer.py` runs it (CaptionModel.infer_pipelined): the decode loops of TWO batches in flight on two streams (a beam step
     # is five dependent launches of 50-230 workgroups; the kernels of the second, independent batch fill the holes)
-    lanes = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    lanes = [streams.lane(torch, device, 'infer0'), streams.lane(torch, device, 'infer1')]
     pend = [None, None]
 
     def decode_batches(nb):

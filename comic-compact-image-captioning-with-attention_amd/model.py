@@ -24,7 +24,7 @@ import numpy as np
 
 from . import checkpoint as ckpt
 from . import decoder as cdec
-from . import encoder_head, nets, optim
+from . import encoder_head, nets, optim, streams
 from .trainer import DataParallel
 
 _SHARED = {}          # variable store of the current "graph" (tf.variable_scope('Model', AUTO_REUSE))
@@ -533,7 +533,7 @@ class CaptionModel(ModelBase):
                                                   want_attention=want_attention, length_penalty_weight=lp)
                 yield [ids, attn]
         iters = self.decoder.max_iterations(c.infer_max_length, len(c.wtoi))
-        lanes = self.__dict__.setdefault('_infer_lanes', [torch.cuda.Stream(device=self.device) for _ in range(2)])
+        lanes = self.__dict__.setdefault('_infer_lanes', [streams.lane(torch, self.device, 'infer%d' % k) for k in range(2)])
         pending = [None, None]
         n = 0
         while True:

@@ -21,6 +21,7 @@ import os
 import numpy as np
 
 from . import _lib as L
+from . import streams
 
 BN_EPS = 1e-3            # inception_utils.py:36
 
@@ -960,7 +961,7 @@ class CnnEncoder:
         t.scratch_bytes = int(self.lib.comic_cnn_backward_scratch_bytes(self._ops, len(plan.ops), self.batch,
                                                                          self.dcode, 2 if self.backward_lanes else 1))
         t.scratch = torch.empty(t.scratch_bytes, dtype=torch.uint8, device=self.device)
-        t.wlane = torch.cuda.Stream(device=self.device) if self.backward_lanes else None
+        t.wlane = streams.lane(torch, self.device, 'wgrad') if self.backward_lanes else None
         # branch lanes of the backward (backward_schedule): a second chain stream and alternate gradient buffers of the
         # blocks' shared inputs (zero between steps: the join adds them in and clears them)
         t.sched, t.lane1 = None, None
@@ -968,11 +969,11 @@ class CnnEncoder:
             sched, alt_bufs = backward_schedule(plan)
             if alt_bufs:
                 t.sched = np.ascontiguousarray(sched)
-                t.lane1 = torch.cuda.Stream(device=self.device)
+                t.lane1 = streams.lane(torch, self.device, 'chain1')
                 t.galt = {b: torch.zeros_like(t.gbufs[b]) for b in alt_bufs}
                 t.gptr_alt = (C.c_void_p * len(t.gbufs))(*[t.galt[b].data_ptr() if b in t.galt else None
                                                            for b in range(len(t.gbufs))])
-        t.aux = torch.cuda.Stream(device=self.device)
+        t.aux = streams.lane(torch, self.device, 'aux')
         t.filters_ev = torch.cuda.Event()
         t.filters_ver = -1
         self._train = t

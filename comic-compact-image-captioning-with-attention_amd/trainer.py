@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import decoder as cdec, nets, optim
+from . import decoder as cdec, nets, optim, streams
 
 
 class DataParallel:
@@ -68,7 +68,7 @@ class DataParallel:
             return
         import torch
         if getattr(self, '_comm', None) is None:
-            self._comm = torch.cuda.Stream(device=flat_slice.device)
+            self._comm = streams.lane(torch, flat_slice.device, 'comm')
             self._pending = []
         self._comm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._comm):
@@ -95,7 +95,7 @@ def side_stream(torch, device):
     """The stream the frozen encoder's forward runs on beside the decoder.  Priorities on this runtime are 0 (default,
     lowest) and -1; raising either stream above the other measured slower (COMIC_SIDE_PRIORITY to experiment)."""
     import os
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get('COMIC_SIDE_PRIORITY', '0')))
+    return streams.lane(torch, device, 'encoder', priority=int(os.environ.get('COMIC_SIDE_PRIORITY', '0')))
 
 
 class EncoderPipeline:
