@@ -87,10 +87,11 @@ def extras(device, enc, cnn_params, plan):
     imgsG = imgs.repeat(G, 1, 1, 1).contiguous()
     pipe = _tr.EncoderPipeline(encG, B, G, device)
     pipe.submit(imgsG)
-    # as `infer.py` runs it (CaptionModel.infer_pipelined): the decode loops of TWO batches in flight on two streams (a beam step
-    # is five dependent launches of 50-230 workgroups; the kernels of the second, independent batch fill the holes)
-    lanes = [streams.lane(torch, device, 'infer0'), streams.lane(torch, device, 'infer1')]
-    pend = [None, None]
+    # as `infer.py` runs it (CaptionModel.infer_pipelined): the decode loops of THREE batches in flight on three streams (a beam
+    # step is five dependent launches of 50-230 workgroups; the kernels of the other, independent batches fill the holes)
+    NL = int(os.environ.get('COMIC_INFER_IN_FLIGHT', '3'))
+    lanes = [streams.lane(torch, device, 'infer%d' % k) for k in range(NL)]
+    pend = [None] * NL
 
     def decode_batches(nb):
         r = None
@@ -99,19 +100,19 @@ def extras(device, enc, cnn_params, plan):
             im, fm = im_s.clone(), fm_s.clone()
             if rel():
                 pipe.submit(imgsG)
-            k = i % 2
+            k = i % NL
             if pend[k] is not None:
                 r = pend[k]()
             lanes[k].wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(lanes[k]):
                 pend[k] = dec.beam_search_ids(fm, im, 3, max_steps, slot=k)
             im.record_stream(lanes[k]); fm.record_stream(lanes[k])
-        for k in range(2):
+        for k in range(NL):
             if pend[k] is not None:
                 r = pend[k]()
                 pend[k] = None
         return r
-    decode_batches(2 * G)                  # untimed: captures the group encoder's graph and both decode graphs
+    decode_batches(3 * G)                  # untimed: captures the group encoder's graph and both decode graphs
     torch.cuda.synchronize()
     n, t0 = 4 * G, time.perf_counter()
     r = {'predicted_ids': decode_batches(n)}
@@ -119,9 +120,11 @@ def extras(device, enc, cnn_params, plan):
     dt = (time.perf_counter() - t0) / n
     out['beam3_captions_per_sec'] = round(B / dt, 1)
     out['beam3_config'] = ('word tokens V=25599, 1 head, fm_projection none, batch 50, max 30 steps, %d steps executed; one encoder '
-                           'forward per 4 batches on a side stream and the decode loops of two batches in flight '
+                           'forward per 4 batches on a side stream and the decode loops of three batches in flight '
                            '(CaptionModel.infer_pipelined)' % r['predicted_ids'].shape[0])
     del pipe, encG
+    if os.environ.get('COMIC_EXTRAS_ONLY') == 'beam':
+        return out
     t0 = time.perf_counter()
     for _ in range(3):
         im, fm = enc50.forward(imgs, use_graph=True)

@@ -515,16 +515,19 @@ class CaptionModel(ModelBase):
 
     def infer_pipelined(self, want_attention=True):
         """Generator over the batches of the input pipeline -> [dec_preds (B,T), attention_maps or None] in input order, with
-        the decode loops of TWO batches in flight (two streams, two buffer sets of the decoder: Decoder.beam_search_ids(slot=)).
+        the decode loops of THREE batches in flight (COMIC_INFER_IN_FLIGHT; one stream and one buffer set of the decoder each:
+        Decoder.beam_search_ids(slot=)).
         A beam-search step is five dependent launches of 50-230 workgroups that leave most of the chip idle between them; the
         kernels of a second, independent batch fill those holes: 2.29 -> 1.64 ms per batch of 50 at beam 3 on the word
-        baseline (tools/beam_time.py TWO=1), the same ids.  Only the captions-only beam search runs this way (no attention
+        baseline (tools/beam_time.py TWO=1), the same ids; three in flight +6 % over two (24.5k against 23.1k captions/s on one
+        box; four and five lose: 23.9k, 19.3k -- each loop streams the 52 MB vocabulary projection per step).  Only the captions-only beam search runs this way (no attention
         maps, no length penalty: what `infer.py` writes unless --save_attention_maps); everything else yields infer()."""
         c, torch = self._config, self.torch
         lp = getattr(c, 'infer_length_penalty_weight', 0.0)
-        two = (not want_attention and not lp and c.infer_beam_size > 1 and str(self.device).startswith('cuda')
-               and os.environ.get('COMIC_INFER_IN_FLIGHT', '2') != '1')
-        if not two:
+        NL = max(1, min(5, int(os.environ.get('COMIC_INFER_IN_FLIGHT', '3'))))      # decode loops in flight (3: measured best of 1-5)
+        if want_attention or lp or c.infer_beam_size <= 1 or not str(self.device).startswith('cuda'):
+            NL = 1
+        if NL == 1:
             while True:
                 feats = self._next_infer_features()
                 if feats is None:
@@ -533,13 +536,13 @@ class CaptionModel(ModelBase):
                                                   want_attention=want_attention, length_penalty_weight=lp)
                 yield [ids, attn]
         iters = self.decoder.max_iterations(c.infer_max_length, len(c.wtoi))
-        lanes = self.__dict__.setdefault('_infer_lanes', [streams.lane(torch, self.device, 'infer%d' % k) for k in range(2)])
-        pending = [None, None]
+        lanes = [streams.lane(torch, self.device, 'infer%d' % k) for k in range(NL)]
+        pending = [None] * NL
         n = 0
         while True:
             feats = self._next_infer_features()
-            k = n % 2
-            if pending[k] is not None:            # the batch decoded on this lane two batches ago: next in input order
+            k = n % NL
+            if pending[k] is not None:            # the batch decoded on this lane NL batches ago: next in input order
                 yield [pending[k]()[:, :, 0].T.copy(), None]
                 pending[k] = None
             if feats is None:
@@ -551,11 +554,11 @@ class CaptionModel(ModelBase):
             im_embed.record_stream(lanes[k])
             fm.record_stream(lanes[k])
             n += 1
-        k = n % 2                                 # the other lane still holds the last batch
-        if pending[k] is not None:
-            yield [pending[k]()[:, :, 0].T.copy(), None]
-        if pending[1 - k] is not None:
-            yield [pending[1 - k]()[:, :, 0].T.copy(), None]
+        for j in range(NL):                       # the lanes still hold the last batches, oldest first
+            k = (n + j) % NL
+            if pending[k] is not None:
+                yield [pending[k]()[:, :, 0].T.copy(), None]
+                pending[k] = None
 
     def _next_infer_features(self):
         """(im_embed, fm) of the next batch of the input pipeline, None at its end.  ONE encoder forward covers the next G

@@ -9,7 +9,7 @@ therefore takes its lanes from this table: a role is ONE stream per device for t
 in a fixed order, and there are no more of them than hardware queues beside the default stream.  Sharing a stream between
 components only adds ordering; the roles that run at the same time inside one step are distinct."""
 
-ROLES = ('encoder', 'wgrad', 'chain1', 'aux', 'infer0', 'infer1', 'comm')
+ROLES = ('encoder', 'wgrad', 'chain1', 'aux', 'infer0', 'infer1', 'comm', 'infer2', 'infer3', 'infer4')
 _LANES = {}
 
 
