@@ -786,6 +786,19 @@ __global__ __launch_bounds__(256) void maxpool3_rows_kernel(ConvArgs a) {
   }
 }
 
+// bf16 store of four channels of a kind-7 output; a.x3 (COMIC_OP_X3): as the three regions [hi | lo | hi]
+__device__ __forceinline__ void pbr_store_bf16(const ConvArgs& a, size_t off, float v0, float v1, float v2, float v3) {
+  bf16_t* yp = (bf16_t*)a.y + off;
+  const uint32_t h01 = pack_bf16x2(v0, v1), h23 = pack_bf16x2(v2, v3);
+  *(uint2*)yp = make_uint2(h01, h23);
+  if (a.x3) {
+    const uint32_t l01 = pack_bf16x2(v0 - __uint_as_float(h01 << 16), v1 - __uint_as_float(h01 & 0xFFFF0000u));
+    const uint32_t l23 = pack_bf16x2(v2 - __uint_as_float(h23 << 16), v3 - __uint_as_float(h23 & 0xFFFF0000u));
+    *(uint2*)(yp + a.x3) = make_uint2(l01, l23);
+    *(uint2*)(yp + 2 * a.x3) = make_uint2(h01, h23);
+  }
+}
+
 // kind 7: 3x3 s1 SAME average (divisor = taps inside the image) of an fp32 map, then the folded
 // BatchNorm + ReLU of the projection that produced it.  One thread per (pixel, 4 channels).
 __device__ __forceinline__ void pool_bn_relu_item(const ConvArgs& a, const long idx, const int cvecs) {
@@ -832,7 +845,7 @@ __device__ __forceinline__ void pool_bn_relu_item(const ConvArgs& a, const long 
   if (a.out_f32)
     *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
   else
-    *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    pbr_store_bf16(a, off, v0, v1, v2, v3);
 }
 
 __global__ __launch_bounds__(256) void pool_bn_relu_kernel(ConvArgs a) {
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(256) void pool_bn_relu_rows_kernel(ConvArgs a) {
       if (a.out_f32)
         *(float4*)((float*)a.y + off) = make_float4(v0, v1, v2, v3);
       else
-        *(uint2*)((bf16_t*)a.y + off) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        pbr_store_bf16(a, off, v0, v1, v2, v3);
       c0 = c1;
       c1 = c2;
     }
@@ -2217,7 +2230,7 @@ int run_op(const comic_cnn_op* op, const void* x, int xc, void* y, int yc, const
                     "pool+bn: 3x3 stride-1 SAME only");
       COMIC_REQUIRE(op->Cin % 4 == 0 && op->src_coff % 4 == 0 && xc % 4 == 0 && op->dst_coff % 4 == 0 && yc % 4 == 0,
                     "pool+bn: channel counts/offsets must be multiples of 4");
-      COMIC_REQUIRE(op->dst_coff + op->Cin <= yc, "pool+bn: destination channel slice out of range");
+      COMIC_REQUIRE(op->dst_coff + op->Cin <= (a.x3 ? a.x3 : yc), "pool+bn: destination channel slice out of range");
       const long total = (long)a.M * (op->Cin / 4);
       a.out_f32 = (op->out_f32 || sizeof(T) == 4) ? 1 : 0;
       // row-walking form when there are enough rows to occupy the chip (op->tile: 1 forces it, 2 forces the per-pixel form)

@@ -178,12 +178,12 @@ class CnnPlan:
         # packed [W_hi | W_hi | W_lo] per tap (CnnEncoder), i.e. hi*W_hi + lo*W_hi + hi*W_lo with fp32 accumulation.
         self.x3 = bool(x3)
         if self.x3:
-            if pool_after_projection or fuse_pools or self._logical or name == 'inception_v1':
-                raise ValueError('x3 plans: plain InceptionV3 / chain layouts only (no pool rewrites, no padded channels)')
+            if fuse_pools or self._logical or name == 'inception_v1':
+                raise ValueError('x3 plans: InceptionV3 / chain layouts only (no folded max-pools, no padded channels)')
             for o in self.ops:
                 if o['kind'] == 0:
                     o['Cin'] *= 3
-                if o['kind'] in (0, 1, 2, 3):
+                if o['kind'] in (0, 1, 2, 3, 7):       # (7: the pool-after-projection branches store the three regions too)
                     o['flags'] = o.get('flags', 0) | L.OP_X3
             self.buffers = [(H, W, Cc if f32 else 3 * Cc, f32) for (H, W, Cc, f32) in self.buffers]
 
@@ -1352,8 +1352,8 @@ def get_network_fn(name, num_classes=None, weight_decay=0.0, is_training=False):
         raise NotImplementedError('the reference always builds the CNN with is_training=False (model_base.py:76)')
 
     def network_fn(image_size=(224, 224), final_endpoint=None, pool_after_projection=False, fuse_pools=False, x3=False):
-        par = pool_after_projection and name == 'inception_v3' and not x3
+        par = pool_after_projection and name == 'inception_v3'
         return CnnPlan(name, image_size, final_endpoint or ('Mixed_4f' if name == 'inception_v1' else 'Mixed_7c'),
-                       pool_after_projection=par, fuse_pools=fuse_pools and par, x3=x3)
+                       pool_after_projection=par, fuse_pools=fuse_pools and par and not x3, x3=x3)
     network_fn.default_image_size = 224 if name == 'inception_v1' else 299
     return network_fn

@@ -127,7 +127,8 @@ typedef struct comic_cnn_op {
                                    product, fp32 accumulation) on the unchanged conv kernels.  With the bit set a conv /
                                    stem conv stores its bf16 output as the three regions (region stride = a third of the
                                    destination buffer's channels; Cout, dst_coff count channels of ONE region) and a pool
-                                   reads hi + lo and writes the three regions (Cin = channels of one region).  fp32
+                                   reads hi + lo and writes the three regions (Cin = channels of one region); kind 7 (3x3
+                                   average + BN + ReLU of an fp32 map) stores the three regions likewise.  fp32
                                    outputs (out_f32) are stored once, as always. */
 
 typedef struct comic_conv_weight {

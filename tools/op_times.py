@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import numpy as np, torch
 from comic_amd import nets, _lib as L
 B = int(os.environ.get('B', '64'))
+X3 = os.environ.get('X3', '0') == '1'           # the bf16x3 plan (no rewrites)
 plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (int(os.environ.get('IMG', '224')),) * 2,
                     pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1',
-                    fuse_pools=os.environ.get('FUSE', '1') == '1')
+                    fuse_pools=os.environ.get('FUSE', '1') == '1' and not X3, x3=X3)
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE'))
