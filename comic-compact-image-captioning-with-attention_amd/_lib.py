@@ -70,7 +70,7 @@ def decoder_flags_from_env():
     return f
 
 
-CONV_TILES = 58          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants, 56..58 walk forms
+CONV_TILES = 61          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants, 56..61 walk forms
 WS_TILE = 54             # weight-stationary 1x1 groups (csrc/conv_ws.hip)
 IMG_TILE = 55            # image-resident stride-1 convs on 25x25 / 12x12 / 5x5 maps (csrc/conv_img.hip)
 OP_RAW, OP_POOLED_SRC, OP_X3 = 1, 2, 4      # COMIC_OP_X3: [hi | lo | hi] channel regions of a bf16x3 plan

@@ -1278,7 +1278,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvArgs& a, const int
 // k-tiles of the next tile land under the epilogue of this one), and after the first tile the pixel rows come from the
 // L2 this workgroup has just filled.  Same operands in the same order per accumulator as conv_igemm_dma_body: identical bits.
 template <int BM, int BN, int WM, int WN, int NSTAGE_, bool ALIGNED>
-__device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restrict__ args, const int n_members, const int block_m) {
+__device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restrict__ args, const int n_members, const int block_m,
+                                                         const int r_begin, const int r_end) {   // out-channel tiles [r_begin, r_end) of the walk
   constexpr int BKE = 64;
   constexpr int ROWS = BM + BN;
   constexpr int STAGE_BYTES = ROWS * 128;
@@ -1302,9 +1303,8 @@ __device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restr
   const int wave = loader ? wave_id - NWC : wave_id;
   const int wm = wave / WN, wn = wave % WN;
   const int bm0 = block_m * BM;
-  const int R = a.grp_nt;                        // out-channel tiles of all members
   const int nk = a.Kpad / BKE;
-  const int total = R * nk;                      // k-tiles of the whole walk
+  const int total = (r_end - r_begin) * nk;      // k-tiles of the whole walk
   const int slot = lane & 7, rsub = lane >> 3;
 
   if (loader) {
@@ -1358,7 +1358,7 @@ __device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restr
         wsrc[i] = wg + (size_t)(nok[i] ? nn : 0) * a.Kpad + chunk * 8;
       }
     };
-    int gi = 0, gi_kt = 0, gi_r = 0;             // issue pointer: stream index, its k-tile and out-channel tile
+    int gi = 0, gi_kt = 0, gi_r = r_begin;       // issue pointer: stream index, its k-tile and out-channel tile
     auto issue = [&]() {
       if (gi_kt == 0) {
         set_tile(gi_r);
@@ -1455,7 +1455,7 @@ __device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restr
     mrow[j] = m < a.M ? m : -1;
   }
   int g = 0;
-  for (int r = 0; r < R; ++r) {
+  for (int r = r_begin; r < r_end; ++r) {
     f32x4_t acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -1496,13 +1496,21 @@ __device__ __forceinline__ void conv_igemm_dma_walk_body(const ConvArgs* __restr
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_walk_kernel(const ConvArgs* __restrict__ args, int n, int total) {
-  const int bm = xcd_tile_index(total);
-  if (bm < 0) return;
+__global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_walk_kernel(const ConvArgs* __restrict__ args, int n, int total,
+                                                                                         int split) {
+  // split 2 ("paired walk"): the walk of a pixel tile is shared by two workgroups with consecutive logical ids -- they start
+  // together on ONE XCD, stream the pixel rows at the same time (one fetch from the memory side for both) and re-read them
+  // from an L2 that holds 16 pixel tiles per XCD instead of 32 (K = 768: 196 KB each)
+  const int l = xcd_tile_index(total);
+  if (l < 0) return;
+  const int bm = l / split, part = l - bm * split;
+  const int R = args[0].grp_nt;                  // out-channel tiles of all members
+  const int r0 = R * part / split, r1 = R * (part + 1) / split;
+  if (r0 >= r1) return;
   if (args[0].Cin % 64 == 0)
-    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, true>(args, n, bm);
+    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, true>(args, n, bm, r0, r1);
   else
-    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, false>(args, n, bm);
+    conv_igemm_dma_walk_body<BM, BN, WM, WN, NSTAGE, false>(args, n, bm, r0, r1);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool ALIGNED>
@@ -1614,7 +1622,7 @@ int launch_dma_grouped(const ConvArgs* args_dev, int n, int total_blocks, int mi
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_dma_walk(const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st) {
+int launch_dma_walk(const ConvArgs* args_dev, int n, int total_blocks, int min_lds, hipStream_t st, int split = 1) {
   constexpr int lds0 = ring_stages(NSTAGE) * (BM + BN) * 128;
   const int lds = std::max(lds0, min_lds);
   static PerDeviceOnce attr_once__;
@@ -1628,7 +1636,7 @@ int launch_dma_walk(const ConvArgs* args_dev, int n, int total_blocks, int min_l
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_dma_walk_kernel<BM, BN, WM, WN, NSTAGE>), dim3((total_blocks + 7) / 8 * 8),
-                     dim3(dma_threads(WM, WN, NSTAGE)), lds, st, args_dev, n, total_blocks);
+                     dim3(dma_threads(WM, WN, NSTAGE)), lds, st, args_dev, n, total_blocks, split);
   return 0;
 }
 
@@ -1762,7 +1770,8 @@ constexpr int kNumConvTiles = 12;
 // 47 %, 128x192 56 %; with two stages (instead of three) two such workgroups still share a CU.
 constexpr int kWideTile0 = 26, kNumWideTiles = 22;      // 35..47: four MFMA waves + four loader waves      // 29..31: 8 waves, one workgroup per CU (fill bound 62 / 80 / 94 %)
 // 56..58: "walk" forms of 44 / 38 / 35 for launches whose members share their im2col matrix (conv_igemm_dma_walk_body)
-constexpr int kWalkTile0 = 56, kNumWalkTiles = 3;
+constexpr int kWalkTile0 = 56, kNumWalkTiles = 6;      // 56..58: one workgroup per pixel tile; 59..61: two (paired walk)
+inline int walk_split(int t) { return t >= kWalkTile0 + 3 ? 2 : 1; }
 inline bool is_walk_tile(int t) { return t >= kWalkTile0 && t < kWalkTile0 + kNumWalkTiles; }
 inline bool is_im2col_tile(int t) { return t <= kNumConvTiles || (t >= kWideTile0 && t < kWideTile0 + kNumWideTiles) || is_walk_tile(t); }
 int launch_dma_tile(int tile, const ConvArgs& a, hipStream_t st) {
@@ -1835,7 +1844,7 @@ constexpr int kTileBM[kNumConvTiles + 1] = {0, 128, 128, 64, 32, 128, 64, 256, 1
 constexpr int kTileBN[kNumConvTiles + 1] = {0, 128, 64, 64, 64, 32, 128, 64, 64, 64, 64, 128, 32};
 constexpr int kWideBM[kNumWideTiles] = {128, 128, 192, 256, 256, 256, 128, 256, 192, 128, 128, 128, 192, 128, 192, 128, 160, 192, 192, 64, 128, 64};
 constexpr int kWideBN[kNumWideTiles] = {128, 192, 128, 128, 192, 256, 160, 64, 96, 192, 128, 256, 128, 160, 192, 192, 192, 160, 192, 128, 64, 64};
-constexpr int kWalkBase[kNumWalkTiles] = {44, 38, 35};
+constexpr int kWalkBase[kNumWalkTiles] = {44, 38, 35, 44, 38, 35};
 inline int im2col_tile_threads(int t) { return (t >= 29 && t <= 31) || t >= 35 ? 512 : 256; }
 inline int tile_bm(int t) { return is_walk_tile(t) ? kWideBM[kWalkBase[t - kWalkTile0] - kWideTile0] : t >= kWideTile0 ? kWideBM[t - kWideTile0] : kTileBM[t]; }
 inline int tile_bn(int t) { return is_walk_tile(t) ? kWideBN[kWalkBase[t - kWalkTile0] - kWideTile0] : t >= kWideTile0 ? kWideBN[t - kWideTile0] : kTileBN[t]; }
@@ -1867,6 +1876,9 @@ int launch_dma_grouped_tile(int tile, const ConvArgs* args_dev, int n, int total
     case 56: return launch_dma_walk<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
     case 57: return launch_dma_walk<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
     case 58: return launch_dma_walk<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st);
+    case 59: return launch_dma_walk<192, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st, 2);
+    case 60: return launch_dma_walk<192, 128, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st, 2);
+    case 61: return launch_dma_walk<128, 192, 2, 2, kLoaderWaves + 3>(args_dev, n, total_blocks, min_lds, st, 2);
     case 1: return launch_dma_grouped<128, 128, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
     case 2: return launch_dma_grouped<128, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
     case 3: return launch_dma_grouped<64, 64, 2, 2, 3>(args_dev, n, total_blocks, min_lds, st);
@@ -2497,7 +2509,7 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
         lds_max = std::max(lds_max, lds);
       }
       COMIC_REQUIRE(blocks > 0 && blocks < (1L << 31), "grouped launch: bad workgroup count");
-      if (is_walk_tile(tile)) blocks = cdiv(batch * op->Ho * op->Wo, tile_bm(tile));   // one workgroup per pixel tile
+      if (is_walk_tile(tile)) blocks = (long)cdiv(batch * op->Ho * op->Wo, tile_bm(tile)) * walk_split(tile);   // one (or two) workgroups per pixel tile
       if (!is_im2col_tile(tile)) {
         if (int rc = launch_patch_grouped_tile(tile, gargs, n, (int)blocks, std::max(lds_max, op->min_lds), main_st)) return rc;
       } else if (int rc = launch_dma_grouped_tile(tile, gargs, n, (int)blocks, op->min_lds, main_st)) {

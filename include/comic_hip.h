@@ -32,7 +32,7 @@ extern "C" {
 #define COMIC_F32 0
 #define COMIC_BF16 1
 #define COMIC_ABI_VERSION 1
-#define COMIC_CONV_TILES 58
+#define COMIC_CONV_TILES 61
 #define COMIC_WS_TILE 54     /* weight-stationary 1x1 group kernel (csrc/conv_ws.hip) */
 #define COMIC_IMG_TILE 55    /* image-resident kernel for stride-1 SAME convs on small maps (csrc/conv_img.hip) */
 
@@ -96,7 +96,8 @@ typedef struct comic_cnn_op {
                         loader waves.  Id 54 (COMIC_WS_TILE): weight-stationary kernel for 1x1 convs / groups of 1x1 convs
                         over one source with Cin <= 288 and <= 256 output channels in total (all weights in registers,
                         persistent workgroups, activation tiles streamed once).  An ineligible layer returns an error
-                        for ids 13..25 and 48..58.  Ids 56..58: "walk" forms of 44 / 38 / 35 for grouped launches whose
+                        for ids 13..25 and 48..61.  Ids 56..58 (59..61: the same with the walk of a pixel tile shared by two
+                        workgroups that start together on one XCD): "walk" forms of 44 / 38 / 35 for grouped launches whose
                         members share their im2col matrix (the 1x1 convs at the head of an Inception block): one workgroup per
                         pixel tile walks over the out-channel tiles of all members -- the loader waves' k-tile stream runs on
                         across the tiles (no pipeline fill after the first) and the pixel rows are re-read from the L2 the

@@ -145,7 +145,7 @@ def test_stem_stream_with_conv2d_1a_is_bit_identical(cnn_params, B):
 
 @pytest.mark.parametrize('B', [3, 40])
 def test_walk_tiles_give_the_bits_of_the_one_tile_launch(cnn_params, B):
-    """Tile ids 56..58 (conv_igemm_dma_walk_body: one workgroup per pixel tile walks over the out-channel tiles of all members of a
+    """Tile ids 56..61 (conv_igemm_dma_walk_body: one workgroup per pixel tile walks over the out-channel tiles of all members of a
     shared-input group) against the same groups on tile 44: the whole forward bit for bit, with the 1x1 groups at the head
     of every Inception block on each walk form; a launch whose members do not share their input refuses the ids."""
     x = np.random.default_rng(7 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
@@ -163,7 +163,7 @@ def test_walk_tiles_give_the_bits_of_the_one_tile_launch(cnn_params, B):
         sync()
         return im.clone(), fm.clone()
     im0, fm0 = forward_with(44)
-    for tile in (56, 57, 58):
+    for tile in (56, 57, 58, 59, 60, 61):        # 59..61: the walk of a pixel tile shared by two workgroups (paired walk)
         im1, fm1 = forward_with(tile)
         assert torch.equal(fm1, fm0) and torch.equal(im1, im0), 'walk tile %d differs' % tile
     # a group over different inputs (depth 1: 1x7 | 7x1 of two branches) is not eligible
