@@ -79,7 +79,7 @@ def test_conv_variant_ids_match_header():
     patch = [t for t in range(1, L.CONV_TILES + 1) if not L.is_im2col_tile(t)]
     assert im2col == list(range(1, 13)) + list(range(26, 48))
     # may-refuse ids (incl. the weight-stationary and image-resident kernels and the walk forms 56..58 of shared-input groups)
-    assert patch == list(range(13, 26)) + list(range(48, 54)) + [L.WS_TILE, L.IMG_TILE] + [56, 57, 58]
+    assert patch == list(range(13, 26)) + list(range(48, 54)) + [L.WS_TILE, L.IMG_TILE] + [56, 57, 58, 59, 60, 61]
     assert int(re.search(r'#define COMIC_WS_TILE (\d+)', header).group(1)) == L.WS_TILE
     assert int(re.search(r'#define COMIC_IMG_TILE (\d+)', header).group(1)) == L.IMG_TILE
     assert int(re.search(r'#define COMIC_OP_POOLED_SRC (\d+)', header).group(1)) == L.OP_POOLED_SRC
