@@ -14,5 +14,6 @@ echo "== bench eager trace"; COMIC_GRAPH_CNN=0 COMIC_GRAPH_DEC=0 COMIC_OVERLAP=0
 t=$(ls $out/kt_bench_steps20_eager/*/*kernel_trace.csv | head -1); python3 tools/step_timeline.py $t > $out/decoder_step_timeline.txt; tail -1 $out/decoder_step_timeline.txt
 echo "== beam-3"; GRAPH=0 prof beam3 python3 tools/beam_time.py
 echo "== cnn_finetune"; prof finetune python3 tools/ft_step_prof.py && { t=$(ls $out/kt_finetune/*/*kernel_trace.csv | head -1); python3 tools/ft_lanes.py $t > $out/finetune_lanes.txt; head -3 $out/finetune_lanes.txt; }
+echo "== cnn_finetune, bf16x3 plan"; X3=1 N=4 prof finetune_x3 python3 tools/ft_step_time.py
 echo "== scst"; GRAPH=0 prof scst python3 tools/scst_step_timeline.py
 python3 tools/scst_step_timeline.py 2>&1 | tail -1 > $out/scst_step_timeline.txt; cat $out/scst_step_timeline.txt
