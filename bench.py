@@ -430,7 +430,7 @@ def extras(device, enc, cnn_params, plan):
     # ---- the fast plan AT the parity bar: bf16x3 (hi / lo split activations and filters on the bf16 matrix cores, nets.CnnPlan(x3=
     # True), COMIC_OP_X3): its deviation from the fp32 plan on the same step, and its throughput with one forward per G_X3 steps --
     G_X3 = 5                                    # 320 images per forward (a bf16x3 buffer of 109x109x192 stays below 2^31 bytes)
-    plan_x3 = nets.CnnPlan('inception_v3', (IMG, IMG), x3=True)
+    plan_x3 = nets.CnnPlan('inception_v3', (IMG, IMG), x3=True, pool_after_projection=True)     # the frozen-CNN form, as CaptionModel builds it
     trx1 = trainer.CaptionTrainer(cnn_params, spec0, p_same, BATCH, (IMG, IMG), 'bf16x3', device, seed=8, plan=plan_x3)
     im_e, fm_e = trx1.encoder.forward(imgs, use_graph=False)
     r = trx1.decoder.train_step(fm_e, im_e, caps, training=False)
@@ -472,7 +472,7 @@ def extras(device, enc, cnn_params, plan):
     out['xe_x3'] = {'images_per_sec': round(BATCH / dt, 1), 'ms_per_step': round(dt * 1e3, 3),
                     'config': 'the same step with the bf16x3 CNN plan: activations stored as [hi | lo | hi] bf16 channel regions, filters '
                               '[W_hi | W_hi | W_lo], v_mfma_f32_16x16x32_bf16 over 3x the input channels (hi*W_hi + lo*W_hi + hi*W_lo, fp32 '
-                              'accumulation), plain op order; batch 64, one forward per %d steps, not overlapped' % G_X3,
+                              'accumulation), the pool branches behind their projections (the frozen-CNN rewrite); batch 64, one forward per %d steps, not overlapped' % G_X3,
                     'cnn_forward_ms_per_step': round(x3_ms, 3),
                     'cnn_mfma_frac_useful': round(FLOP_PER_IMAGE_CNN * BATCH / (x3_ms * 1e-3) / PEAK_BF16_MFMA, 5),
                     'cnn_mfma_frac_issued': round(3 * FLOP_PER_IMAGE_CNN * BATCH / (x3_ms * 1e-3) / PEAK_BF16_MFMA, 5),
