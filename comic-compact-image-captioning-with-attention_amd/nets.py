@@ -573,13 +573,21 @@ def backward_schedule(plan):
         # block behind it).  The ops of a block are walked deepest first, so a fork at the first lane-1 op came after the
         # deepest two or three convs of lane 0's branch -- lane 1 then sat out half of lane 0's chain and the lanes ran one
         # after the other (profiles/r05_finetune_lanes.txt: one kernel in flight for 3.6 of 5.9 ms)
-        forked = any(ln == 1 for ln in lanes.values())
-        if forked:
-            rows.append((SCHED_FORK, 0, 0, 0))
-        blk_in = None
+        # ... of its BRANCHES: an op of the range that belongs to no branch (the head's global pool in the last range: it adds
+        # into the gradient of the block's output, which lane 1's first ops read) runs on lane 0 outside the fork / join
+        # region -- with the fork in front of it the two raced (run-to-run differences of 1e-4 in the weight gradients)
+        two = any(ln == 1 for ln in lanes.values())
+        forked, blk_in = False, None
         for i in idx:
             o = plan.ops[i]
-            ln = lanes.get(o.get('branch'), 0)
+            in_branch = o.get('branch') is not None
+            if two and in_branch and not forked:
+                rows.append((SCHED_FORK, 0, 0, 0))
+                forked, blk_in = True, None
+            elif forked and not in_branch:
+                rows.append((SCHED_JOIN_ADD, blk_in if blk_in is not None else -1, 0, 0))
+                forked = False
+            ln = lanes.get(o.get('branch'), 0) if forked else 0
             alt = 0
             if ln == 1 and o.get('block_in') is not None and o['src'] == o['block_in'] and o['src'] != plan.input:
                 alt, blk_in = 1, o['src']

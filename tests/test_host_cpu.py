@@ -691,6 +691,30 @@ def test_backward_schedule_of_the_branch_lanes():
                         assert pos[j] < k, (j, int(r[1]))
         assert not open_
         assert len(alt) == 11 and plan.input not in alt
+        # Inside a fork / join region the lanes run concurrently: a gradient buffer one lane READS (its op's dst) or accumulates
+        # into (its op's src; 'alt' copies apart) must not be accumulated into by the other lane.  (The head's global pool adds
+        # d im_embed into the gradient of the last block's OUTPUT, which every branch of that block reads: it has to run before
+        # the fork -- with the fork in front of it lane 1 raced it, 1e-4 run-to-run differences in the CNN gradients.)
+        region, regions = None, []
+        for r in sched:
+            if r[0] == nets.SCHED_FORK:
+                region = []
+            elif r[0] == nets.SCHED_JOIN_ADD:
+                regions.append(region)
+                region = None
+            elif region is not None:
+                region.append((int(r[2]), plan.ops[int(r[1])], int(r[3])))
+        assert len(regions) == 11
+        for reg in regions:
+            assert all(o.get('branch') is not None for _, o, _ in reg)
+            for lane in (0, 1):
+                writes = {('alt' if a else 'main', o['src']) for ln, o, a in reg if ln == lane and o['kind'] <= 4 and o['src'] != plan.input}
+                other_reads = {('main', o['dst']) for ln, o, a in reg if ln != lane}
+                other_writes = {('alt' if a else 'main', o['src']) for ln, o, a in reg if ln != lane and o['src'] != plan.input}
+                assert not (writes & other_reads) and not (writes & other_writes), (lane, writes & (other_reads | other_writes))
+        gap = [k for k, r in enumerate(sched) if r[0] == nets.SCHED_RUN and plan.ops[int(r[1])]['kind'] == 4]
+        first_fork = min(k for k, r in enumerate(sched) if r[0] == nets.SCHED_FORK)
+        assert gap and gap[0] < first_fork
 
 
 def test_gradient_clip_chunk_table():
