@@ -542,6 +542,35 @@ def test_backward_with_fused_activation_gradients_matches_the_unfused_chain(dtyp
         assert moved > 20                                # the fused form did run (it skips a bf16 rounding)
 
 
+@pytest.mark.parametrize('dtype,tol', [('bf16', 2e-2), ('bf16x3', 2e-5)])
+def test_bucketed_backward_matches_the_scheduled_backward(dtype, tol):
+    """The data-parallel form of the cnn_finetune backward (comic_cnn_backward bucket by bucket, the callback after each one:
+    nets.CnnEncoder.backward(buckets=, on_bucket=)) against the scheduled three-lane pass of the single-GPU step, on the bf16
+    plan and on the bf16x3 plan (fp32 gradient buffers): the same gradients up to the summation order of the atomics and --
+    bf16 -- the rounding of the intermediate gradients the fused activation gradients skip; every bucket's callback sees its
+    ranges complete."""
+    B = 2
+    params = cnn_ref.randomize_bn(cnn_ref.init_params(0, 224), seed=1)
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    d_net, d_fm = _seeds(rng, B, 25, 2048)
+    enc = nets.CnnEncoder(nets.CnnPlan('inception_v3', (224, 224), x3=dtype == 'bf16x3'), params, B, dtype, DEV)
+    enc.forward(dev(x))
+    t = enc.backward(dev(d_fm), dev(d_net))
+    sync()
+    assert t.sched is not None
+    want = _cnn_grads_device(enc, t)
+    seen = []
+    enc.forward(dev(x))
+    buckets = enc.grad_buckets(4)
+    t = enc.backward(dev(d_fm), dev(d_net), buckets, lambda ts, bk: seen.append(bk))
+    sync()
+    got = _cnn_grads_device(enc, t)
+    assert seen == list(buckets) and len(buckets) >= 3
+    errs = sorted((rel_err(got[k], want[k]), k) for k in want)
+    assert errs[-1][0] < tol, errs[-3:]
+
+
 # ----------------------------------------------------------------------------- decoder ----
 def _spec_and_cfg(**kw):
     base = dict(D=128, E=64, V=258, C=192, Cg=192, H=8, M=25)
