@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-5 profile set, part B: eager kernel stats of the bench command, decoder step timeline, beam-3 / SCST / cnn_finetune stats.
-out=gpurun_out/r5prof; mkdir -p $out
+# profile set, part B: eager kernel stats of the bench command, decoder step timeline, beam-3 / SCST / cnn_finetune stats.
+out=${OUT:-gpurun_out/prof}; mkdir -p $out
 export TMPDIR=/tmp
 export COMIC_TUNE_CACHE=$out/tiles_bench.json
 prof() {   # name, then the program
