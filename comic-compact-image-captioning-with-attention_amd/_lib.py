@@ -73,7 +73,9 @@ def decoder_flags_from_env():
 CONV_TILES = 61          # 1..12 im2col LDS-DMA variants, 13..25 patch-resident variants, 26..47 wide two-stage im2col variants, 56..61 walk forms
 WS_TILE = 54             # weight-stationary 1x1 groups (csrc/conv_ws.hip)
 IMG_TILE = 55            # image-resident stride-1 convs on 25x25 / 12x12 / 5x5 maps (csrc/conv_img.hip)
+CHAIN_TILE = 62          # a group of one or two CHAINS of image-resident convs (OP_CHAIN_LINK), one launch (conv_img_chain_kernel)
 OP_RAW, OP_POOLED_SRC, OP_X3 = 1, 2, 4      # COMIC_OP_X3: [hi | lo | hi] channel regions of a bf16x3 plan
+OP_CHAIN_LINK = 8        # the conv's output goes to the next op of the table through the LDS (its dst buffer is not written)
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
 

@@ -1763,6 +1763,64 @@ int launch_img_convs(const ConvArgs* a, int n, hipStream_t st) {
   return comic_img_launch(cfg, ia, st);
 }
 
+int validate_grouped_conv(const comic_cnn_op* op, int xc, int yc, const comic_conv_weight* wt, int batch);
+// Chains of image-resident convs (COMIC_CHAIN_TILE, conv_img.hip conv_img_chain_kernel): the n ops of the group are one or
+// two chains, chain after chain; an op with COMIC_OP_CHAIN_LINK hands its output to the NEXT op of the table through the LDS
+// (its dst buffer is not written), an op without it ends its chain and stores to its dst slice.
+int launch_img_chains(const comic_cnn_op* op, int n, void* const* buffers, const int32_t* buf_channels,
+                      const comic_conv_weight* weights, int batch, hipStream_t st) {
+  ComicChainArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.B = batch; ca.H = op[0].H; ca.W = op[0].W; ca.Cin = op[0].Cin;
+  const int pxb = ca.Cin * 2;
+  ca.PXBp = pxb + ((pxb % 64 == 0) ? 32 : 0);
+  COMIC_REQUIRE(comic_img_chain_supported(ca.H, ca.W, ca.Cin), "conv chain: %dx%d maps of %d channels are not supported", ca.H,
+                ca.W, ca.Cin);
+  int nm = 0;
+  for (int j = 0; j < n;) {
+    COMIC_REQUIRE(nm < kChainMaxMembers, "conv chain: more than %d chains in one launch", kChainMaxMembers);
+    ComicChainMember& m = ca.m[nm];
+    int len = 0;
+    for (;; ++len) {
+      COMIC_REQUIRE(j + len < n && len < kChainMaxConvs, "conv chain: a chain of more than %d convs, or a link flag on the last op",
+                    kChainMaxConvs);
+      const comic_cnn_op* o = op + j + len;
+      const comic_conv_weight* wt = weights + o->weight;
+      const bool link = (o->flags & COMIC_OP_CHAIN_LINK) != 0;
+      if (int rc = validate_grouped_conv(o, buf_channels[o->src], buf_channels[o->dst], wt, batch)) return rc;
+      COMIC_REQUIRE(o->SH == 1 && o->SW == 1 && o->Ho == o->H && o->Wo == o->W && o->H == ca.H && o->W == ca.W &&
+                        o->Cin == ca.Cin && o->KH * o->KW >= 2 && o->KH * o->KW <= 32 && !(o->flags & (COMIC_OP_RAW | COMIC_OP_X3)),
+                    "conv chain: every conv must be a stride-1 SAME conv with BatchNorm over the chain's %dx%dx%d input", ca.H, ca.W,
+                    ca.Cin);
+      COMIC_REQUIRE(wt->w_frag, "conv chain: no fragment-order weights");
+      COMIC_REQUIRE(o->Cout == (link ? ca.Cin : 192), "conv chain: inner convs keep the channel count, the last one has 192 outputs");
+      COMIC_REQUIRE(!link || (!o->out_f32 && o->dst == o[1].src && o->dst_coff == 0 && o[1].src_coff == 0 &&
+                              buf_channels[o->dst] == ca.Cin),
+                    "conv chain: a linked conv must feed the next op of the table");
+      ComicChainConv& c = m.c[len];
+      c.wf = (const bf16_t*)wt->w_frag; c.scale = wt->scale; c.shift = wt->shift;
+      c.KH = o->KH; c.KW = o->KW; c.PT = o->PT; c.PL = o->PL; c.Cout = o->Cout; c.relu = o->relu;
+      c.KS32 = ((o->KH * o->KW * o->Cin + 63) / 64 * 64) / 32;
+      if (len == 0) {
+        COMIC_REQUIRE(buf_channels[o->src] % 8 == 0 && o->src_coff % 8 == 0 && buffers[o->src], "conv chain: bad source slice");
+        m.x = (const bf16_t*)buffers[o->src]; m.x_cs = buf_channels[o->src]; m.x_co = o->src_coff;
+      }
+      if (!link) {
+        COMIC_REQUIRE(buffers[o->dst], "conv chain: null destination");
+        m.y = buffers[o->dst]; m.y_cs = buf_channels[o->dst]; m.y_co = o->dst_coff; m.out_f32 = o->out_f32;
+        ++len;
+        break;
+      }
+    }
+    m.n_convs = len;
+    j += len;
+    ++nm;
+  }
+  if (nm == 2 && ca.m[1].n_convs > ca.m[0].n_convs) std::swap(ca.m[0], ca.m[1]);     // the longer chain's workgroups first
+  ca.n_members = nm;
+  return comic_img_chain_launch(ca, st);
+}
+
 // explicit tile selection (comic_cnn_op.tile, filled by the host-side autotuner)
 constexpr int kNumConvTiles = 12;
 // ids 26..28: two-stage wide im2col tiles.  The L2 -> LDS fill (about 30 B/clk/CU) bounds the im2col kernel: a k-tile
@@ -1974,7 +2032,7 @@ bool ws_group_selected(const comic_cnn_op* ops, int n, int batch) {
 }
 
 int group_tile(const comic_cnn_op* ops, int n, int batch) {
-  if (ops[0].tile == COMIC_IMG_TILE) return COMIC_IMG_TILE;
+  if (ops[0].tile == COMIC_IMG_TILE || ops[0].tile == COMIC_CHAIN_TILE) return ops[0].tile;
   if (ops[0].tile > 0 && ops[0].tile < COMIC_WS_TILE) return ops[0].tile;
   if (is_walk_tile(ops[0].tile)) return ops[0].tile;
   bool all128 = true;
@@ -2335,7 +2393,7 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
     }
     COMIC_REQUIRE(ops[i].tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
     const int tile = group_tile(ops + i, n, batch);
-    if (tile == COMIC_IMG_TILE) {                       // conv_img.hip takes its arguments by value, too
+    if (tile == COMIC_IMG_TILE || tile == COMIC_CHAIN_TILE) {      // conv_img.hip takes its arguments by value, too
       memset(out, 0, sizeof(ConvArgs) * n);
       out += n;
       i += n;
@@ -2468,6 +2526,13 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       }
       COMIC_REQUIRE(op->tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
       const int tile = group_tile(op, n, batch);
+      if (tile == COMIC_CHAIN_TILE) {
+        if (int rc = launch_img_chains(op, n, buffers, buf_channels, weights, batch, main_st)) return rc;
+        COMIC_LAUNCH_CHECK("image-resident conv chains");
+        gargs += n;
+        i += n - 1;
+        continue;
+      }
       if (tile == COMIC_IMG_TILE) {
         // members of one shape share a launch; a member of another shape (7x1 128 -> 192 beside 1x7 128 -> 128) gets its own
         COMIC_REQUIRE(n <= kImgMaxMembers, "grouped launch: too many members for the image-resident kernel");

@@ -26,3 +26,25 @@ struct ComicImgArgs {
 int comic_img_config(int H, int W, int Cin, int Cout, int KH, int KW, int SH, int SW, int Ho, int Wo);
 int comic_img_images_per_group(int cfg);
 int comic_img_launch(int cfg, const ComicImgArgs& a, hipStream_t st);
+
+// ---- chains of image-resident convs (conv_img_chain_kernel): the 1x7 / 7x1 convs of a Mixed_6 branch as one launch --------
+constexpr int kChainMaxConvs = 4, kChainMaxMembers = 2;
+struct ComicChainConv {
+  const bf16_t* wf;      // fragment-order weights
+  const float* scale;
+  const float* shift;
+  int KH, KW, PT, PL, KS32, Cout, relu, pad_;
+};
+struct ComicChainMember {
+  const bf16_t* x;       // input of the first conv
+  void* y;               // output of the last conv
+  int x_cs, x_co, y_cs, y_co, out_f32, n_convs;
+  ComicChainConv c[kChainMaxConvs];
+};
+struct ComicChainArgs {
+  ComicChainMember m[kChainMaxMembers];     // member 0: the longer chain
+  int n_members;
+  int B, H, W, Cin, PXBp;   // Cin = input channels of every conv = output channels of every conv but a chain's last (192)
+};
+int comic_img_chain_supported(int H, int W, int Cin);
+int comic_img_chain_launch(const ComicChainArgs& a, hipStream_t st);

@@ -43,85 +43,51 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t img_rsrc(const void* p, uint32
 // zeros behind the pixels: a masked lane reads at (its live address mod 256) + the channel step's immediate offset
 constexpr int img_zero_bytes(int cs) { return (256 + cs * 64 + 1023) / 1024 * 1024; }
 
-template <int TM, int TN, int WM, int WN, int CS, int PD = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 : 1)) void conv_img_kernel(const ComicImgArgs a) {
-  constexpr int NT = 64 * WM * WN;
-  constexpr int CPP = CS * 4;            // 16-byte chunks per pixel (Cin = 32 * CS)
-  constexpr int PMAX = TM * WM * 16;     // pixel slots of the workgroup
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int mi = blockIdx.x % a.n_members, grp = blockIdx.x / a.n_members;
-  const ComicImgMember& m = a.m[mi];
-  const int HW = a.H * a.W, W = a.W, H = a.H;
-  const int img0 = grp * a.G;
-  const int P = min(a.G, a.B - img0) * HW;            // resident pixels of this workgroup
-  const int PXBp = a.PXBp;
-  const uint32_t zoff = (PMAX * PXBp + 255) & ~255;    // zeros behind the pixels, 256-byte aligned
-
-  // ---- patch fill: the G images are consecutive pixels of the NHWC source; every load of a thread is in flight before
-  // its first LDS write (one memory latency for the whole patch, not one per pass) ----------------------------------------
-  {
-    constexpr int U = (PMAX * CPP + NT - 1) / NT;
-    const bf16_t* __restrict__ xg = m.x + (size_t)img0 * HW * m.x_cs + m.x_co;
-    const int x_cs = m.x_cs;
-    const int total = P * CPP;
-    uint4 v[U];
-    int dst[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int idx = u * NT + tid;
-      const bool ok = idx < total;
-      const int p = ok ? idx / CPP : 0;
-      const int c = ok ? idx - p * CPP : 0;
-      dst[u] = ok ? p * PXBp + c * 16 : -1;
-      v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
-    for (int z = tid; z < img_zero_bytes(CS) / 16; z += NT) *(uint4*)(smem + zoff + z * 16) = make_uint4(0u, 0u, 0u, 0u);
-  }
-
-  // ---- per-lane pixel state ------------------------------------------------------------------------------------------
+// Per-lane state of a wave's TM pixel tiles under one filter shape: LDS address of the lane's pixel (+ its 16-byte k group),
+// the taps (kh, kw) that stay inside the image as a bit mask (bit kh*KW + kw), and the pixel's row in the NHWC destination.
+template <int TM>
+__device__ __forceinline__ void img_pixel_state(int lane, int wm, int P, int H, int W, int PXBp, int KH, int KW, int PT, int PL,
+                                                int img0, uint32_t (&pixaddr)[TM], uint32_t (&mask)[TM], int (&mrow)[TM]) {
   const int fr = lane & 15, fg = lane >> 4;
-  const int KH = m.KH, KW = m.KW, PT = m.PT, PL = m.PL;
-  const int taps = KH * KW;
-  uint32_t pixaddr[TM], mask[TM];
-  int mrow[TM];
-  {
-    const float rHW = 1.0f / (float)HW, rW = 1.0f / (float)W;
+  const int HW = H * W;
+  const float rHW = 1.0f / (float)HW, rW = 1.0f / (float)W;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int p = (wm * TM + j) * 16 + fr;
-      const bool pv = p < P;
-      const int pp = pv ? p : 0;
-      const int img = (int)(((float)pp + 0.5f) * rHW);        // exact for these sizes (pp < 2^16)
-      const int r = pp - img * HW;
-      const int h = (int)(((float)r + 0.5f) * rW), w = r - h * W;
-      pixaddr[j] = (uint32_t)(pp * PXBp + fg * 16);
-      // taps (kh, kw) inside the image: kh in [klo, khi], kw in [wlo, whi]; bit kh*KW + kw
-      const int klo = max(0, PT - h), khi = min(KH - 1, H - 1 - h + PT);
-      const int wlo = max(0, PL - w), whi = min(KW - 1, W - 1 - w + PL);
-      const uint32_t rowbits = ((2u << whi) - 1u) & ~((1u << wlo) - 1u);
-      uint32_t mk = 0;
-      for (int kh = klo; kh <= khi; ++kh) mk |= rowbits << (kh * KW);
-      mask[j] = pv ? mk : 0u;
-      mrow[j] = pv ? img0 * HW + pp : -1;
-    }
+  for (int j = 0; j < TM; ++j) {
+    const int p = (wm * TM + j) * 16 + fr;
+    const bool pv = p < P;
+    const int pp = pv ? p : 0;
+    const int img = (int)(((float)pp + 0.5f) * rHW);        // exact for these sizes (pp < 2^16)
+    const int r = pp - img * HW;
+    const int h = (int)(((float)r + 0.5f) * rW), w = r - h * W;
+    pixaddr[j] = (uint32_t)(pp * PXBp + fg * 16);
+    // taps (kh, kw) inside the image: kh in [klo, khi], kw in [wlo, whi]; bit kh*KW + kw
+    const int klo = max(0, PT - h), khi = min(KH - 1, H - 1 - h + PT);
+    const int wlo = max(0, PL - w), whi = min(KW - 1, W - 1 - w + PL);
+    const uint32_t rowbits = ((2u << whi) - 1u) & ~((1u << wlo) - 1u);
+    uint32_t mk = 0;
+    for (int kh = klo; kh <= khi; ++kh) mk |= rowbits << (kh * KW);
+    mask[j] = pv ? mk : 0u;
+    mrow[j] = pv ? img0 * HW + pp : -1;
   }
+}
 
-  f32x4_t acc[TN][TM];
+// The k loop of one convolution over the resident pixels: acc[i][j] = sum over (tap, channel step) of W-fragment x pixel
+// fragment, k order (kh, kw, c) as in conv_igemm_dma_body.  SYNC: a workgroup barrier between the first weight requests and
+// the first LDS read (the patch fill of conv_img_kernel ends there).
+template <int TM, int TN, int CS, int PD, bool SYNC>
+__device__ __forceinline__ void img_kloop(const unsigned char* smem, uint32_t zoff, const uint32_t (&pixaddr)[TM],
+                                          const uint32_t (&mask)[TM], const bf16_t* wf, int Cout, int KS32, int KH, int KW,
+                                          int PT, int PL, int W, int PXBp, int wn, int lane, f32x4_t (&acc)[TN][TM]) {
+  const int taps = KH * KW;
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   // ---- weight stream: tile (wn*TN + i), step s at byte ((tile * KS32 + s) * 64 + lane) * 16 ---------------------------
-  const __amdgpu_buffer_rsrc_t wr = img_rsrc(m.wf, (uint32_t)(a.Cout / 16) * (uint32_t)a.KS32 * 1024u);
+  const __amdgpu_buffer_rsrc_t wr = img_rsrc(wf, (uint32_t)(Cout / 16) * (uint32_t)KS32 * 1024u);
   const int wv = lane * 16;
-  const int tile_stride = a.KS32 * 1024;
+  const int tile_stride = KS32 * 1024;
   const int wbase = wn * TN * tile_stride;
   const int nsteps = taps * CS;
   // software pipeline of depth PD: wq[0] = this step's fragments, wq[d] = those of step s + d, wq[PD] = the loads issued now.
@@ -134,7 +100,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 
     for (int i = 0; i < TN; ++i)
       wq[d][i] = __builtin_amdgcn_raw_buffer_load_b128(wr, wv, wbase + min(d, nsteps - 1) * 1024 + i * tile_stride, 0);
 
-  __syncthreads();                       // the patch is complete (the only barrier of the kernel)
+  if constexpr (SYNC) __syncthreads();   // the patch is complete (the only barrier of conv_img_kernel)
 
   auto tap_addrs = [&](int t, int kh, int kw, uint32_t (&ad)[TM]) {
     const int tapoff = ((kh - PT) * W + (kw - PL)) * PXBp;
@@ -180,6 +146,56 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 
     }
     if (t + 1 < taps) tap_addrs(t + 1, kh, kw, addr);
   }
+}
+
+template <int TM, int TN, int WM, int WN, int CS, int PD = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 : 1)) void conv_img_kernel(const ComicImgArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CPP = CS * 4;            // 16-byte chunks per pixel (Cin = 32 * CS)
+  constexpr int PMAX = TM * WM * 16;     // pixel slots of the workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int mi = blockIdx.x % a.n_members, grp = blockIdx.x / a.n_members;
+  const ComicImgMember& m = a.m[mi];
+  const int HW = a.H * a.W, W = a.W, H = a.H;
+  const int img0 = grp * a.G;
+  const int P = min(a.G, a.B - img0) * HW;            // resident pixels of this workgroup
+  const int PXBp = a.PXBp;
+  const uint32_t zoff = (PMAX * PXBp + 255) & ~255;    // zeros behind the pixels, 256-byte aligned
+
+  // ---- patch fill: the G images are consecutive pixels of the NHWC source; every load of a thread is in flight before
+  // its first LDS write (one memory latency for the whole patch, not one per pass) ----------------------------------------
+  {
+    constexpr int U = (PMAX * CPP + NT - 1) / NT;
+    const bf16_t* __restrict__ xg = m.x + (size_t)img0 * HW * m.x_cs + m.x_co;
+    const int x_cs = m.x_cs;
+    const int total = P * CPP;
+    uint4 v[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * NT + tid;
+      const bool ok = idx < total;
+      const int p = ok ? idx / CPP : 0;
+      const int c = ok ? idx - p * CPP : 0;
+      dst[u] = ok ? p * PXBp + c * 16 : -1;
+      v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
+    for (int z = tid; z < img_zero_bytes(CS) / 16; z += NT) *(uint4*)(smem + zoff + z * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  // ---- per-lane pixel state, k loop (img_pixel_state / img_kloop: shared with conv_img_chain_kernel) --------------------
+  const int fg = lane >> 4;
+  uint32_t pixaddr[TM], mask[TM];
+  int mrow[TM];
+  img_pixel_state<TM>(lane, wm, P, a.H, a.W, PXBp, m.KH, m.KW, m.PT, m.PL, img0, pixaddr, mask, mrow);
+  f32x4_t acc[TN][TM];
+  img_kloop<TM, TN, CS, PD, true>(smem, zoff, pixaddr, mask, m.wf, a.Cout, a.KS32, m.KH, m.KW, m.PT, m.PL, a.W, PXBp, wn, lane, acc);
 
   // ---- epilogue: BatchNorm + ReLU + store, shared with the other bf16 conv kernels ----------------------------------
   ConvArgs ca;
@@ -187,6 +203,111 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : WM * WN <= 5 ? 3 
   ca.relu = m.relu; ca.out_f32 = m.out_f32; ca.accum = 0; ca.x3 = 0; ca.x3_src = 0;   // (x3 plans carry no fragment-order weights: never here)
   ca.mask_y = nullptr;     // (no fused activation gradient: a forward kernel)
   conv_store_tiles<TN, TM>(ca, acc, wn * TN * 16, fg * 4, mrow);
+}
+
+// ---- Branch chains of Mixed_6b-e (common/nets/inception_v3.py:262-345): 1x7 -> 7x1 and 7x1 -> 1x7 -> 7x1 -> 1x7 ------------
+// conv_img_kernel spends 11 of a workgroup's 27 us in MFMAs at 12x12 128 -> 192; the rest is the patch fill in front of
+// the loop and the epilogue stores behind it, and between two convs of a branch those are a write of the 12x12xC map to
+// HBM and a read of the same map.  Here ONE workgroup (one image, four waves) runs every 7-tap conv of a branch: after a
+// conv's k loop the complete output map sits in the accumulators of the four waves (wave wn: channels [wn*TN*16, +TN*16) of
+// all 144 pixels), so BatchNorm + ReLU + the bf16 rounding of the unfused store are applied in registers and the map is
+// written IN PLACE over the patch it was computed from (barrier - write - barrier): one patch, 41-61 KB, still two
+// workgroups per CU.  Only the first conv's input is filled from HBM and only the last conv's output is stored; weights
+// stream global -> VGPR as before.  Same operands, same k order, same epilogue arithmetic per value: bit-identical to the
+// chain of single launches.
+// TNI: 16-channel tiles per wave of the INNER convs (Cout = Cin: 2 at 128 channels, 3 at 160 -- ragged, as cfg 4 -- and
+// 192); the last conv of a chain has 192 output channels (three tiles per wave).
+template <int TM, int TNI, int CS, int PD = 2>
+__global__ __launch_bounds__(256, 2) void conv_img_chain_kernel(const ComicChainArgs a) {
+  constexpr int NT = 256, WN = 4;
+  constexpr int CPP = CS * 4;
+  constexpr int PMAX = TM * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // member 0 holds the longer chain: all of its workgroups are dispatched first
+  const int mi = (int)blockIdx.x >= a.B ? 1 : 0;
+  const int img0 = (int)blockIdx.x - mi * a.B;
+  const ComicChainMember& m = a.m[mi];
+  const int HW = a.H * a.W;
+  const int P = HW;
+  const int PXBp = a.PXBp;
+  const uint32_t zoff = (PMAX * PXBp + 255) & ~255;
+
+  {
+    constexpr int U = (PMAX * CPP + NT - 1) / NT;
+    const bf16_t* __restrict__ xg = m.x + (size_t)img0 * HW * m.x_cs + m.x_co;
+    const int x_cs = m.x_cs;
+    const int total = P * CPP;
+    uint4 v[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = u * NT + tid;
+      const bool ok = idx < total;
+      const int p = ok ? idx / CPP : 0;
+      const int c = ok ? idx - p * CPP : 0;
+      dst[u] = ok ? p * PXBp + c * 16 : -1;
+      v[u] = *(const uint4*)(xg + (size_t)p * x_cs + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) *(uint4*)(smem + dst[u]) = v[u];
+    for (int z = tid; z < img_zero_bytes(CS) / 16; z += NT) *(uint4*)(smem + zoff + z * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  uint32_t pixaddr[TM], mask[TM];
+  int mrow[TM];
+  const int nc = m.n_convs;
+  for (int ci = 0; ci + 1 < nc; ++ci) {
+    const ComicChainConv& c = m.c[ci];
+    img_pixel_state<TM>(lane, 0, P, a.H, a.W, PXBp, c.KH, c.KW, c.PT, c.PL, img0, pixaddr, mask, mrow);
+    f32x4_t acc[TNI][TM];
+    img_kloop<TM, TNI, CS, PD, false>(smem, zoff, pixaddr, mask, c.wf, a.Cin, c.KS32, c.KH, c.KW, c.PT, c.PL, a.W, PXBp, wn, lane, acc);
+    // BatchNorm + ReLU + bf16 as conv_store_tiles computes them, written over the patch: lane (fr, fg) holds channels
+    // [n0 + 4 fg, + 4) of pixel 16 j + fr
+    float4 sc[TNI], sh[TNI];
+    bool nv[TNI];
+#pragma unroll
+    for (int i = 0; i < TNI; ++i) {
+      nv[i] = (wn * TNI + i) * 16 < a.Cin;                    // wave-uniform
+      const int n0 = nv[i] ? (wn * TNI + i) * 16 + fg * 4 : 0;
+      sc[i] = *(const float4*)(c.scale + n0);
+      sh[i] = *(const float4*)(c.shift + n0);
+    }
+    const float lo = c.relu ? 0.f : -INFINITY;
+    __syncthreads();                    // every wave has read its last pixel fragment of this conv
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      unsigned char* prow = smem + (j * 16 + fr) * PXBp + (wn * TNI * 16 + fg * 4) * 2;
+#pragma unroll
+      for (int i = 0; i < TNI; ++i) {
+        float v0 = fmaf(acc[i][j][0], sc[i].x, sh[i].x);
+        float v1 = fmaf(acc[i][j][1], sc[i].y, sh[i].y);
+        float v2 = fmaf(acc[i][j][2], sc[i].z, sh[i].z);
+        float v3 = fmaf(acc[i][j][3], sc[i].w, sh[i].w);
+        asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v0), "s"(lo));
+        asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
+        asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
+        asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
+        if (nv[i]) *(uint2*)(prow + i * 32) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    }
+    __syncthreads();                    // the next conv's input is complete
+  }
+  {
+    const ComicChainConv& c = m.c[nc - 1];
+    img_pixel_state<TM>(lane, 0, P, a.H, a.W, PXBp, c.KH, c.KW, c.PT, c.PL, img0, pixaddr, mask, mrow);
+    f32x4_t acc[3][TM];
+    img_kloop<TM, 3, CS, PD, false>(smem, zoff, pixaddr, mask, c.wf, c.Cout, c.KS32, c.KH, c.KW, c.PT, c.PL, a.W, PXBp, wn, lane, acc);
+    ConvArgs ca;
+    ca.scale = c.scale; ca.shift = c.shift; ca.y = m.y; ca.y_cs = m.y_cs; ca.y_co = m.y_co; ca.Cout = c.Cout;
+    ca.relu = c.relu; ca.out_f32 = m.out_f32; ca.accum = 0; ca.x3 = 0; ca.x3_src = 0;
+    ca.mask_y = nullptr;
+    conv_store_tiles<3, TM>(ca, acc, wn * 3 * 16, fg * 4, mrow);
+  }
 }
 
 // [Cout][Kpad] bf16 -> fragment order, for every conv weight of a flat plan buffer in one launch.  table: per weight
@@ -244,6 +365,24 @@ int launch_img(const ComicImgArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int TNI, int CS>
+int launch_chain(const ComicChainArgs& a, hipStream_t st) {
+  constexpr int TM = 9;
+  const int lds = ((TM * 16 * a.PXBp + 255) & ~255) + img_zero_bytes(CS);
+  static PerDeviceOnce attr_once__;
+  bool& attr_set = attr_once__.slot();
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_img_chain_kernel<TM, TNI, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      comic_set_error("conv_img_chain: cannot reserve %d bytes of LDS", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_img_chain_kernel<TM, TNI, CS>), dim3(a.B * a.n_members), dim3(256), lds, st, a);
+  return 0;
+}
+
 }  // namespace
 
 int comic_img_config(int H, int W, int Cin, int Cout, int KH, int KW, int SH, int SW, int Ho, int Wo) {
@@ -273,6 +412,24 @@ int comic_img_launch(int cfg, const ComicImgArgs& a, hipStream_t st) {
     default:
       comic_set_error("conv_img: unknown configuration %d", cfg);
       return 2;
+  }
+}
+
+// Chains of stride-1 SAME 7-tap convs over 12x12 maps with Cin = every inner Cout in {128, 160, 192} and 192 channels out of
+// the last conv (the branches of Mixed_6b-e): 1 where conv_img_chain_kernel serves the shape.
+int comic_img_chain_supported(int H, int W, int Cin) {
+  return H * W == 144 && (Cin == 128 || Cin == 160 || Cin == 192);
+}
+
+int comic_img_chain_launch(const ComicChainArgs& a, hipStream_t st) {
+  if (!comic_img_chain_supported(a.H, a.W, a.Cin) || a.n_members < 1 || a.n_members > kChainMaxMembers) {
+    comic_set_error("conv_img_chain: unsupported shape (%dx%d, Cin %d, %d members)", a.H, a.W, a.Cin, a.n_members);
+    return 2;
+  }
+  switch (a.Cin) {
+    case 128: return launch_chain<2, 4>(a, st);
+    case 160: return launch_chain<3, 5>(a, st);
+    default: return launch_chain<3, 6>(a, st);
   }
 }
 

@@ -126,7 +126,7 @@ class CnnPlan:
 
     def __init__(self, name='inception_v3', image_size=(224, 224), final_endpoint='Mixed_7c', branch_streams=False,
                  group_branches=True, layers=None, pool_after_projection=False, ride_pools=False, side_pools=None,
-                 fuse_pools=False, x3=False, fuse_stem_1a=True):
+                 fuse_pools=False, x3=False, fuse_stem_1a=True, fuse_chains=None):
         if name not in ('inception_v3', 'inception_v1', 'chain'):
             raise NotImplementedError('only inception_v3 / inception_v1 are on the MI355X hot path (got %r)' % name)
         self.name = name
@@ -162,6 +162,12 @@ class CnnPlan:
         # their loads (COMIC_OP_POOLED_SRC, csrc/conv_ws.hip): the pooled map is never written or re-read.
         self.fuse_pools = bool(fuse_pools)
         self.fuse_stem_1a = bool(fuse_stem_1a)   # with fuse_pools: Conv2d_1a inside the streaming stem op (kind 9)
+        # third forward-only rewrite (bf16 plans; default: on with fuse_pools): the 1x7 / 7x1 convs of a Mixed_6b-e branch run as
+        # ONE launch per block (tile CHAIN_TILE, csrc/conv_img.hip conv_img_chain_kernel: a workgroup per image and branch,
+        # the 12x12 intermediate maps stay in the LDS).  The intermediate buffers of the plan are then never written.
+        self.fuse_chains = self.fuse_pools if fuse_chains is None else bool(fuse_chains)
+        if self.fuse_chains and (x3 or not self.group_branches):
+            raise ValueError('fuse_chains needs a grouped bf16 plan')
         if self.fuse_pools and not (pool_after_projection and name == 'inception_v3'):
             raise ValueError('fuse_pools needs an inception_v3 plan with pool_after_projection=True')
         self._pooled_src = None  # (buffer id, pooled H, pooled W) while a folded max-pool waits for its consumers
@@ -282,7 +288,18 @@ class CnnPlan:
         block = self.ops[first_op:]
         del self.ops[first_op:]
         forked = False
-        for d in sorted({o['depth'] for o in block}):
+        chains = self._find_chains(block) if self.fuse_chains else []
+        chained = [o for ch in chains for o in ch]
+        for ch in chains:        # what follows a chain in its branch moves up to the chain's depth (the chain launch precedes that level)
+            rest = sorted((o for o in block if o.get('branch') == ch[0].get('branch') and o['depth'] > ch[-1]['depth']),
+                          key=lambda o: o['depth'])
+            for k, o in enumerate(rest):
+                o['depth'] = ch[0]['depth'] + k
+        block = [o for o in block if not any(o is c for c in chained)]
+        for di, d in enumerate(sorted({o['depth'] for o in block})):
+            if di == 1 and chains:
+                self._emit_chains(chains)
+                chains = []
             level = [o for o in block if o['depth'] == d]
             # pool + BN + ReLU ops (kind 7) ride in the conv launch of their depth as extra members (last, so the
             # group's tile id stays on its first conv): elementwise work under the MFMA tiles instead of a launch
@@ -304,8 +321,51 @@ class CnnPlan:
                     o['group'] = self._next_group
                 self._next_group += 1
             self.ops += members
+        if chains:
+            self._emit_chains(chains)
         if forked:
             self.ops.append(self._sync_op(6))
+
+    CHAIN_CHANNELS = (128, 160, 192)          # comic_img_chain_supported (csrc/conv_img.hip)
+
+    def _find_chains(self, block):
+        """Runs of >= 2 consecutive convs of one branch, from depth 1 on, that are stride-1 SAME 7-tap convs over 12x12 maps
+        and keep the channel count until a last conv with 192 outputs (the branches of Mixed_6b-e and Branch_1 of Mixed_7a,
+        inception_v3.py:262-366): at most two per block, all over one channel count.  -> [[op, ...], ...]"""
+        def seven(o, cin):
+            return (o['kind'] == 0 and o['H'] * o['W'] == 144 and (o['Ho'], o['Wo']) == (o['H'], o['W']) and
+                    o['SH'] == o['SW'] == 1 and o['KH'] * o['KW'] == 7 and o['Cin'] == cin and not o.get('flags', 0))
+        out = []
+        for b in sorted({o.get('branch') for o in block if o.get('branch') is not None}):
+            ops = sorted((o for o in block if o.get('branch') == b), key=lambda o: o['depth'])
+            if len(ops) < 3 or ops[0]['kind'] != 0:
+                continue
+            cin = ops[1]['Cin']
+            run = []
+            for o in ops[1:]:
+                if not (cin in self.CHAIN_CHANNELS and seven(o, cin) and len(run) < 4):
+                    break
+                if run and not (run[-1]['Cout'] == cin and not run[-1]['out_f32'] and run[-1]['dst'] == o['src']
+                                and run[-1]['dst_coff'] == 0 and sum(1 for q in block if q['src'] == run[-1]['dst']) == 1):
+                    break                               # (an intermediate map must have no other reader)
+                run.append(o)
+            while run and run[-1]['Cout'] != 192:
+                run.pop()
+            if len(run) >= 2:
+                out.append(run)
+        if len(out) > 2 or len({ch[0]['Cin'] for ch in out}) > 1:
+            return []
+        return out
+
+    def _emit_chains(self, chains):
+        for ch in chains:
+            for o in ch[:-1]:
+                o['flags'] = o.get('flags', 0) | L.OP_CHAIN_LINK
+            for o in ch:
+                o['group'] = self._next_group
+                o['tile'] = L.CHAIN_TILE
+                self.ops.append(o)
+        self._next_group += 1
 
     @staticmethod
     def _sync_op(kind):
@@ -1218,6 +1278,7 @@ class CnnEncoder:
         H, W = p.buffers[p.input][:2]
         return '%s:%dx%d:B%d:%s%s:%dops:polite%d' % (p.name, H, W, self.batch, 'par' if p.pool_after_projection else 'plain',
                                                     ('+fp' if getattr(p, 'fuse_pools', False) else '') +
+                                                    ('+ch' if getattr(p, 'fuse_chains', False) else '') +
                                                     ('+x3' if getattr(p, 'x3', False) else ''),
                                                   len(p.ops), self.polite_lds_kb)
 
@@ -1264,7 +1325,7 @@ class CnnEncoder:
                 i += 1
                 continue
             op = self._ops[i]
-            if o.get('flags', 0) & L.OP_POOLED_SRC:   # one kernel serves these (conv_ws.hip): nothing to choose
+            if o.get('flags', 0) & L.OP_POOLED_SRC or o.get('tile') == L.CHAIN_TILE:   # one kernel serves these (conv_ws.hip / the chain kernel): nothing to choose
                 n = 1
                 while i + n < n_ops and op.group > 0 and self._ops[i + n].group == op.group:
                     n += 1

@@ -35,6 +35,7 @@ extern "C" {
 #define COMIC_CONV_TILES 61
 #define COMIC_WS_TILE 54     /* weight-stationary 1x1 group kernel (csrc/conv_ws.hip) */
 #define COMIC_IMG_TILE 55    /* image-resident kernel for stride-1 SAME convs on small maps (csrc/conv_img.hip) */
+#define COMIC_CHAIN_TILE 62  /* the grouped ops are one or two CHAINS of image-resident convs (COMIC_OP_CHAIN_LINK): one launch */
 
 const char* comic_last_error(void);
 int comic_abi_version(void);
@@ -131,6 +132,14 @@ typedef struct comic_cnn_op {
                                    reads hi + lo and writes the three regions (Cin = channels of one region); kind 7 (3x3
                                    average + BN + ReLU of an fp32 map) stores the three regions likewise.  fp32
                                    outputs (out_f32) are stored once, as always. */
+#define COMIC_OP_CHAIN_LINK 8    /* bit 3, convs of a COMIC_CHAIN_TILE group (forward-only bf16 plans): this conv's output is the
+                                   input of the NEXT op of the table and travels through the LDS of the workgroup that computes
+                                   both (csrc/conv_img.hip, conv_img_chain_kernel: the 1x7 / 7x1 convs of a Mixed_6b-e branch,
+                                   inception_v3.py:262-345) -- its dst buffer is NOT written.  The group holds one or two chains,
+                                   chain after chain; an op without the bit ends its chain and stores to its dst slice.
+                                   Every conv: stride 1, SAME, 12x12 maps, Cin in {128, 160, 192}; linked convs keep the
+                                   channel count, a chain's last conv has 192 output channels.  Bit-identical to the same ops
+                                   run one launch each. */
 
 typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */

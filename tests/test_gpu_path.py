@@ -218,6 +218,67 @@ def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
         nets.CnnPlan('inception_v3', (224, 224), fuse_pools=True)
 
 
+@pytest.mark.parametrize('B', [3, 70])
+def test_fused_branch_chains_are_bit_identical(cnn_params, B):
+    """Third forward-only rewrite (`CnnPlan(fuse_chains=True)`, tile CHAIN_TILE, csrc/conv_img.hip conv_img_chain_kernel): the
+    1x7 / 7x1 convs of a Mixed_6b-e branch (inception_v3.py:262-345) as ONE launch per block, a workgroup per (image, branch),
+    the intermediate 12x12 maps rewritten in place in the LDS.  Against the same plan with one launch per conv depth: every
+    block output from Mixed_6b on, the feature map and the pooled embedding bit for bit (same operands, k order and epilogue
+    arithmetic per value), eagerly and replayed from a graph; against the oracle at the bf16 tolerance."""
+    x = np.random.default_rng(31 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    sep = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_chains=False)
+    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    assert fus.fuse_chains and not sep.fuse_chains and len(fus.ops) == len(sep.ops)
+    ch = [o for o in fus.ops if o.get('tile') == nets.L.CHAIN_TILE]
+    assert len(ch) == 26 and sum(1 for o in ch if o.get('flags', 0) & nets.L.OP_CHAIN_LINK) == 17       # (Mixed_7a: 1x7 -> 7x1)
+    assert len({o['group'] for o in ch}) == 5 and {o['Cin'] for o in ch} == {128, 160, 192}
+    assert not any(o.get('tile') == nets.L.CHAIN_TILE for o in sep.ops)
+    assert fus.macs == sep.macs and fus.weights == sep.weights
+    e0 = nets.CnnEncoder(sep, cnn_params, B, 'bf16', DEV)
+    e1 = nets.CnnEncoder(fus, cnn_params, B, 'bf16', DEV, weights_from=e0)
+    im0, fm0 = (t.clone() for t in e0.forward(dev(x)))
+    im1, fm1 = (t.clone() for t in e1.forward(dev(x)))
+    sync()
+    for name in ('Mixed_6a', 'Mixed_6b', 'Mixed_6c', 'Mixed_6d', 'Mixed_6e', 'Mixed_7a'):
+        assert torch.equal(e1.end_point(name).view(torch.int16), e0.end_point(name).view(torch.int16)), name
+    assert torch.equal(fm1, fm0) and torch.equal(im1, im0)
+    for _ in range(2):
+        im2, fm2 = e1.forward(dev(x), use_graph=True)
+    assert torch.equal(fm2, fm0) and torch.equal(im2, im0)
+    net_ref, ep = cnn_ref.inception_v3(cnn_params, x[:2], act_dtype='bf16')
+    for name in ('Mixed_6b', 'Mixed_6e'):
+        assert_close(e1.end_point(name)[:2].float().cpu().numpy(), ep[name], 3e-2, name + ' (fused chains)')
+    # the autotuner leaves the chain launches alone and keeps the result
+    e1.autotune(reps=1)
+    assert all(e1._ops[i].tile == nets.L.CHAIN_TILE for i, o in enumerate(fus.ops) if o.get('tile') == nets.L.CHAIN_TILE)
+    im3, fm3 = e1.forward(dev(x))
+    sync()
+    assert torch.equal(fm3, fm0) and torch.equal(im3, im0)
+
+
+def test_chain_launch_refuses_what_the_kernel_does_not_cover(cnn_params):
+    """A COMIC_CHAIN_TILE group whose ops are not a chain (a link flag on the last op, a linked conv that does not feed the next
+    op, another map size) is an error of the call, not a wrong answer."""
+    B = 2
+    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    e1 = nets.CnnEncoder(fus, cnn_params, B, 'bf16', DEV)
+    ch = [i for i, o in enumerate(fus.ops) if o.get('tile') == nets.L.CHAIN_TILE]
+    last = [i for i in ch if not fus.ops[i].get('flags', 0) & nets.L.OP_CHAIN_LINK][-1]
+    x = dev(np.zeros((B, 224, 224, 3), np.float32))
+    e1._ops[last].flags |= nets.L.OP_CHAIN_LINK
+    with pytest.raises(L.ComicHipError):
+        e1.forward(x)
+    e1._ops[last].flags &= ~nets.L.OP_CHAIN_LINK
+    first = ch[0]
+    keep = e1._ops[first].dst
+    e1._ops[first].dst = e1._ops[first].src
+    with pytest.raises(L.ComicHipError):
+        e1.forward(x)
+    e1._ops[first].dst = keep
+    e1.forward(x)
+    sync()
+
+
 def test_inception_v3_forward_299_f32():
     """The north-star's 8x8x2048 feature map needs 299x299 inputs."""
     params = cnn_ref.randomize_bn(cnn_ref.init_params(3, 299), seed=4)
