@@ -885,8 +885,7 @@ def main():
                     n_fwd[0] += 1
                 im_embed, fm = feats[0][j * BATCH:(j + 1) * BATCH], feats[1][j * BATCH:(j + 1) * BATCH]
                 res = tr.decoder.train_step(fm, im_embed, cap, training=True, dp=dp, use_graph=GRAPH_DEC)
-            scale = dp.average_(tr.decoder.grads.data)
-            tr.opt.step(tr.decoder.grads, tr.lr(), grad_scale=scale)
+            dp.exchange_and_step(tr.opt, tr.decoder.grads, tr.lr())
             if STEP_TIMES is not None:
                 e = torch.cuda.Event(enable_timing=True); e.record(); STEP_TIMES.append((e, time.perf_counter()))
         return res

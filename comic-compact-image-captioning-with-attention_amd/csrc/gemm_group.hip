@@ -20,6 +20,8 @@
 namespace {
 
 constexpr int GB = 128;                 // tile edge
+constexpr int kGemmGroupSlots = 512;    // workgroups of the four-wave kernel resident together: two per CU (80 KiB of LDS each)
+constexpr int kItemOverhead = 6;        // k-tiles a work item costs beside its k loop (prologue, partial-tile store, its share of the combine)
 constexpr int kSc1 = 16;                // cache-policy bit of raw buffer accesses: sc1
 typedef __attribute__((ext_vector_type(4))) unsigned gg_u32x4_t;
 
@@ -214,12 +216,38 @@ int comic_gemm_group_plan(ComicGemmGroup& g, int target_items, int64_t* slab_byt
     p.tiles_n = cdiv(p.N, GB);
     cost += (long)cdiv(p.M, GB) * p.tiles_n * cdiv(p.K, 32);
   }
-  const long klen = std::max<long>(8, cost / std::max(1, target_items));   // k-tiles (of 32) per work item
+  // k-tiles (of 32) per work item.  A launch runs in ROUNDS of the workgroups that are resident together (kGemmGroupSlots:
+  // two four-wave workgroups per CU), so what counts is rounds x the longest item, not the item count: the weight-gradient
+  // group of a decoder step split into 580 items of 26-30 k-tiles ran two rounds for 1.13 rounds of work (112 us,
+  // profiles/r05_decoder_step_timeline.txt).  Every item length from the old rule's up to the unsplit one is priced as
+  // rounds x (longest item + kItemOverhead k-tiles of prologue, slab store and combine) and the cheapest taken; a smaller
+  // `target_items` (the caller's retry when the slab is too small) raises the shortest length that is tried.
+  auto split_of = [](int kt, long klen) { return (int)std::min<long>(16, std::max<long>(1, (kt + klen / 2) / klen)); };
+  long klen = std::max<long>(8, cost / std::max(1, target_items));
+  {
+    long best = -1, best_klen = klen, kt_max = 8;
+    for (int i = 0; i < g.n; ++i) kt_max = std::max<long>(kt_max, cdiv(g.p[i].K, 32));
+    for (long kl = klen; kl <= kt_max; ++kl) {
+      long items = 0, longest = 0;
+      for (int i = 0; i < g.n; ++i) {
+        const ComicGemmProb& p = g.p[i];
+        const int kt = cdiv(p.K, 32), S = split_of(kt, kl);
+        items += (long)p.tiles_m * p.tiles_n * S;
+        if (!p.ones_a) longest = std::max<long>(longest, cdiv(kt, S));
+      }
+      const long est = cdiv64(items, kGemmGroupSlots) * (longest + kItemOverhead);
+      if (best < 0 || est < best) {
+        best = est;
+        best_klen = kl;
+      }
+    }
+    klen = best_klen;
+  }
   int wg = 0, tickets = 0, slab_tiles = 0;
   for (int i = 0; i < g.n; ++i) {
     ComicGemmProb& p = g.p[i];
     const int nt = cdiv(p.M, GB) * p.tiles_n, kt = cdiv(p.K, 32);
-    int S = (int)std::min<long>(16, std::max<long>(1, (kt + klen / 2) / klen));
+    int S = split_of(kt, klen);
     p.k_per_slice = cdiv(kt, S) * 32;
     S = cdiv(p.K, p.k_per_slice);
     p.S = S;

@@ -473,6 +473,11 @@ class CaptionModel(ModelBase):
         self._dec_reduced = False
         if ft:
             self._cnn_update(res, lr)
+        if not ft and self.head is None:   # decoder mode: the flat gradient in chunks, each updated behind its own all-reduce
+            self.dp.exchange_and_step(self.opt, self.decoder.grads, lr)
+            self.dec_log_ppl = res['loss']
+            self.last = res
+            return res['loss']
         scale = 1.0 / self.dp.world if self._dec_reduced else self.dp.average_(self.decoder.grads.data)
         if self.head is not None:          # legacy head: its variables train with the decoder (model_base.py:834-849)
             hg = self.head.backward(res['dim_embed'])
@@ -727,8 +732,7 @@ class CaptionModel_SCST(ModelBase):
         lr = self.lr
         res = self.decoder.train_step(fm, im_embed, np.asarray(captions), rewards=np.asarray(rewards, np.float32),
                                       training=True, use_graph=True)
-        scale = self.dp.average_(self.decoder.grads.data)
-        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        self.dp.exchange_and_step(self.opt, self.decoder.grads, lr)
         return res['loss']
 
     def begin_train_scst(self, imgs, captions, tile=1):
@@ -742,6 +746,5 @@ class CaptionModel_SCST(ModelBase):
         lr = self.lr
         res = self.decoder.train_step(None, None, captions, rewards=np.asarray(rewards, np.float32), training=True,
                                       use_graph=True, phase='bwd')
-        scale = self.dp.average_(self.decoder.grads.data)
-        self.opt.step(self.decoder.grads, lr, grad_scale=scale)
+        self.dp.exchange_and_step(self.opt, self.decoder.grads, lr)
         return res['loss']

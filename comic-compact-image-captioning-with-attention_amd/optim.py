@@ -66,9 +66,13 @@ class AdamTF:
         self.t = 0                      # number of applied updates (== global_step)
         self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
-    def step(self, grads, lr, grad_scale=1.0, skip=None):
+    def step(self, grads, lr, grad_scale=1.0, skip=None, ranges=None, before_range=None):
         """skip: the status word of ANOTHER gradient buffer that gates this update too (the CNN optimisers of cnn_finetune
-        follow the decoder's verdict on the step: model.py)."""
+        follow the decoder's verdict on the step: model.py).
+        ranges: [(lo, hi), ...] element ranges of the flat buffer (together: all of it) updated one launch each, in that
+        order, `before_range(i)` called in front of launch i -- the chunked gradient exchange (trainer.DataParallel.
+        exchange_and_step) orders the stream behind chunk i's all-reduce there, so the update of a chunk runs beside the
+        exchange of the next.  The update is element-wise: any partition gives the bits of the one-launch update."""
         self.t += 1
         lr_t = lr * math.sqrt(1.0 - self.beta2 ** self.t) / (1.0 - self.beta1 ** self.t)
         # a gradient buffer with a status word (decoder.FlatParams(status_tail=True)): the update is skipped on the device
@@ -77,11 +81,15 @@ class AdamTF:
         # stops at the next log point anyway (train_fn._check_loss reads the sticky count).
         st = skip if skip is not None else getattr(grads, 'status', None)
         if self.clip is not None:
+            assert ranges is None, 'per-variable clipping reads whole variables: one launch over the flat buffer'
             self.clip.apply(self.params, grads, self.l2, grad_scale, skip=st)
-        L.check(self.lib.comic_adam_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
-                                             self.v.data.data_ptr(), self.params.numel, lr_t, self.beta1, self.beta2,
-                                             self.eps, self.l2, grad_scale, st.data_ptr() if st is not None else None,
-                                             L.stream_ptr()), 'adam_tf')
+        for i, (lo, hi) in enumerate(ranges or [(0, self.params.numel)]):
+            if before_range is not None:
+                before_range(i)
+            L.check(self.lib.comic_adam_tf_gated(self.params.data.data_ptr() + 4 * lo, grads.data.data_ptr() + 4 * lo,
+                                                 self.m.data.data_ptr() + 4 * lo, self.v.data.data_ptr() + 4 * lo, hi - lo,
+                                                 lr_t, self.beta1, self.beta2, self.eps, self.l2, grad_scale,
+                                                 st.data_ptr() if st is not None else None, L.stream_ptr()), 'adam_tf')
 
     def state_dict(self):
         return dict(t=self.t, m=self.m.data.clone(), v=self.v.data.clone())
@@ -107,14 +115,20 @@ class MomentumTF:
         self.t = 0
         self.clip = GradClip(params, clip_norm) if clip_norm and clip_norm > 0 else None
 
-    def step(self, grads, lr, grad_scale=1.0, skip=None):
+    def step(self, grads, lr, grad_scale=1.0, skip=None, ranges=None, before_range=None):
+        """ranges / before_range: as AdamTF.step."""
         self.t += 1
         st = skip if skip is not None else getattr(grads, 'status', None)
         if self.clip is not None:
+            assert ranges is None, 'per-variable clipping reads whole variables: one launch over the flat buffer'
             self.clip.apply(self.params, grads, self.l2, grad_scale, skip=st)
-        L.check(self.lib.comic_momentum_tf_gated(self.params.data.data_ptr(), grads.data.data_ptr(), self.m.data.data_ptr(),
-                                                 self.params.numel, lr, self.momentum, self.l2, grad_scale,
-                                                 st.data_ptr() if st is not None else None, L.stream_ptr()), 'momentum_tf')
+        for i, (lo, hi) in enumerate(ranges or [(0, self.params.numel)]):
+            if before_range is not None:
+                before_range(i)
+            L.check(self.lib.comic_momentum_tf_gated(self.params.data.data_ptr() + 4 * lo, grads.data.data_ptr() + 4 * lo,
+                                                     self.m.data.data_ptr() + 4 * lo, hi - lo, lr, self.momentum, self.l2,
+                                                     grad_scale, st.data_ptr() if st is not None else None, L.stream_ptr()),
+                    'momentum_tf')
 
     state_dict = AdamTF.state_dict
     load_state_dict = AdamTF.load_state_dict

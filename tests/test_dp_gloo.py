@@ -95,6 +95,50 @@ def _bucket_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _chunk_worker(rank, world, port, ret):
+    """The decoder's chunked gradient exchange (DataParallel.chunk_bounds: ranges on variable boundaries, the last range --
+    with the status word behind the variables -- first) against ONE flat all-reduce of the same buffer, on CPU tensors over
+    gloo; and the optimiser's range-by-range update order (`before_range` called once per range, in exchange order)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from comic_amd.decoder import FlatParams, DecoderSpec
+    from comic_amd.trainer import DataParallel
+    dp = DataParallel(dist)
+    G = FlatParams(DecoderSpec(M=25, C=2048, Cg=2048).param_shapes(), 'cpu', status_tail=True)
+    g = torch.Generator().manual_seed(300 + rank)
+    G.data.copy_(torch.randn(G.data.numel(), generator=g))
+    G.data[G.numel] = float(rank)                      # the status word: rank 1 voids the step
+    flat = G.data.clone()
+    dp.average_(flat)
+    bounds = dp.chunk_bounds(G, 4)
+    tail = G.data.numel() - G.numel
+    for j, (lo, hi) in enumerate(bounds[::-1]):
+        dp.reduce_async(G.data[lo:hi + (tail if j == 0 else 0)])
+    dp.wait_all()
+    if rank == 0:
+        ret['equal'] = bool(torch.equal(G.data, flat))
+        ret['status'] = float(G.data[G.numel])
+        ret['bounds'] = [tuple(b) for b in bounds]
+        ret['numel'] = G.numel
+        ret['cuts'] = sorted(G.offsets.values())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_chunked_decoder_exchange_equals_flat_all_reduce():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_chunk_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret['equal'] and ret['status'] == 1.0
+    b = ret['bounds']
+    assert 2 <= len(b) <= 4 and b[0][0] == 0 and b[-1][1] == ret['numel']
+    assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1)) and all(lo in ret['cuts'] for lo, _ in b)
+    sizes = [hi - lo for lo, hi in b]
+    assert max(sizes) < 0.6 * ret['numel']              # no chunk carries most of the buffer (K alone is 46 %)
+
+
 @pytest.mark.timeout(300)
 def test_bucketed_exchange_equals_flat_all_reduce():
     world, port = 2, _free_port()

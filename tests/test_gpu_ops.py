@@ -862,6 +862,48 @@ def test_adam_tf_matches_oracle():
     assert_close(dv.cpu().numpy(), v, 1e-5, 'adam v')
 
 
+@pytest.mark.parametrize('opt_name', ['adam', 'sgd'])
+def test_optimiser_update_by_ranges_equals_one_launch(opt_name):
+    """The chunked gradient exchange (trainer.DataParallel.exchange_and_step) updates the flat buffer range by range, each
+    range behind its own all-reduce, the status word's range first: the same bits as the one-launch update, `before_range`
+    called once per range in order, and a voided step (status word set) skips every range."""
+    from comic_amd import decoder as cdec, optim
+    from comic_amd.trainer import DataParallel
+    spec = cdec.DecoderSpec(M=25, C=2048, Cg=2048)
+    outs = []
+    for mode in ('flat', 'ranges', 'ranges_void'):
+        g = torch.Generator(device='cpu').manual_seed(3)
+        PP = cdec.FlatParams(spec.param_shapes(), DEV, status_tail=True)
+        GG = cdec.FlatParams(spec.param_shapes(), DEV, status_tail=True)
+        PP.data[:PP.numel].copy_(torch.randn(PP.numel, generator=g))
+        GG.data[:GG.numel].copy_(torch.randn(GG.numel, generator=g))
+        opt = optim.make_optimiser(opt_name, PP)
+        seen = []
+        for step in range(2):
+            if mode == 'flat':
+                opt.step(GG, 1e-2, grad_scale=0.5)
+            else:
+                if mode == 'ranges_void' and step == 1:
+                    GG.data[GG.numel] = 1.0
+                rng_ = DataParallel.chunk_bounds(GG, 4)[::-1]
+                opt.step(GG, 1e-2, grad_scale=0.5, ranges=rng_, before_range=seen.append)
+        sync()
+        assert mode == 'flat' or seen == [0, 1, 2, 3] * 2
+        outs.append((PP.data.clone(), opt.m.data.clone(), opt.v.data.clone(), opt.t))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][:3], outs[1][:3])) and outs[0][3] == outs[1][3] == 2
+    opt1 = outs[2]
+    assert not torch.equal(opt1[0], outs[0][0])        # the voided second step left the parameters of step 1 ...
+    PP = cdec.FlatParams(spec.param_shapes(), DEV, status_tail=True)
+    GG = cdec.FlatParams(spec.param_shapes(), DEV, status_tail=True)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    PP.data[:PP.numel].copy_(torch.randn(PP.numel, generator=g))
+    GG.data[:GG.numel].copy_(torch.randn(GG.numel, generator=g))
+    o1 = optim.make_optimiser(opt_name, PP)
+    o1.step(GG, 1e-2, grad_scale=0.5)
+    sync()
+    assert torch.equal(opt1[0][:PP.numel], PP.data[:PP.numel])      # ... in every range
+
+
 def test_gradient_clipping_matches_oracle():
     """clip_gradient_norm (model_base.py:394-401): tf.clip_by_norm per variable on g*gscale + l2*w, then the TF-Adam update;
     variables of one element, of less than a chunk and of several chunks, norms above and below the threshold, and the
