@@ -76,6 +76,7 @@ IMG_TILE = 55            # image-resident stride-1 convs on 25x25 / 12x12 / 5x5 
 CHAIN_TILE = 62          # a group of one or two CHAINS of image-resident convs (OP_CHAIN_LINK), one launch (conv_img_chain_kernel)
 OP_RAW, OP_POOLED_SRC, OP_X3 = 1, 2, 4      # COMIC_OP_X3: [hi | lo | hi] channel regions of a bf16x3 plan
 OP_CHAIN_LINK = 8        # the conv's output goes to the next op of the table through the LDS (its dst buffer is not written)
+OP_CHAIN_KEEP = 16       # ... and to its dst buffer as well (trainable plans: the backward reads it)
 IM2COL_CONV_TILES = 12   # 13..25 are the patch-resident variants (stride-1 layers whose input window fits the LDS)
 
 

@@ -1801,6 +1801,11 @@ int launch_img_chains(const comic_cnn_op* op, int n, void* const* buffers, const
       c.wf = (const bf16_t*)wt->w_frag; c.scale = wt->scale; c.shift = wt->shift;
       c.KH = o->KH; c.KW = o->KW; c.PT = o->PT; c.PL = o->PL; c.Cout = o->Cout; c.relu = o->relu;
       c.KS32 = ((o->KH * o->KW * o->Cin + 63) / 64 * 64) / 32;
+      c.keep = nullptr;
+      if (link && (o->flags & COMIC_OP_CHAIN_KEEP)) {
+        COMIC_REQUIRE(buffers[o->dst] && buf_channels[o->dst] % 4 == 0, "conv chain: a kept intermediate map needs its buffer");
+        c.keep = buffers[o->dst]; c.keep_cs = buf_channels[o->dst]; c.keep_co = o->dst_coff;
+      }
       if (len == 0) {
         COMIC_REQUIRE(buf_channels[o->src] % 8 == 0 && o->src_coff % 8 == 0 && buffers[o->src], "conv chain: bad source slice");
         m.x = (const bf16_t*)buffers[o->src]; m.x_cs = buf_channels[o->src]; m.x_co = o->src_coff;
@@ -3461,50 +3466,22 @@ __global__ __launch_bounds__(256) void dbeta_fold_kernel(const DbetaFoldTable tb
   }
 }
 
+// One conv's weight gradient dw += x^T dz (the d-conv tensor dz as act_grad_kernel / a fused backward-data epilogue wrote it).
+struct PendingWgrad {
+  const comic_cnn_op* op;
+  const void* x;
+  int xc;
+  const void* dz;
+  const comic_conv_grad* gr;
+};
 template <typename T>
-int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
-                  const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
-                  int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w,
-                  bool dz_ready = false, const ConvMask* fuse = nullptr) {
-  // dz_ready: the backward-data launch of this conv's only reader has written dz and added d beta (its epilogue applied this
-  // conv's activation gradient); fuse: this conv's backward-data result is the gradient at the output of a conv with no
-  // other reader -- apply that conv's activation gradient in the epilogue and write its dz instead of accumulating into gx.
+int launch_wgrad(const comic_cnn_op* op, const void* x, int xc, const void* dz, const comic_conv_grad* gr, int batch, hipStream_t st) {
   constexpr int EPC = Elem<T>::EPC;
   const bool stem = op->kind == 1;
-  COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
-  COMIC_REQUIRE(op->Cout % EPC == 0 && op->dst_coff % EPC == 0 && yc % EPC == 0, "conv backward: misaligned output slice");
-  COMIC_REQUIRE(op->SH == op->SW && (op->SH == 1 || op->SH == 2), "conv backward: stride must be 1 or 2");
   const int K = op->KH * op->KW * op->Cin, Kpad = (K + 63) / 64 * 64;
   const int dil = op->SH;
-  // zero-dilated d conv geometry: output pixel (ho, wo) sits at (ho*dil, wo*dil); the backward-data
-  // conv pads PT' = KH - 1 - PT rows on top and reads zeros below the buffer (bounds checks)
-  const int Hd = (op->Ho - 1) * dil + 1;
-  const int Wd = (op->Wo - 1) * dil + 1;
-  const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
-  COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward: scratch too small (%zu needed)", dz_bytes);
-  T* dz = (T*)scratch;
-  COMIC_REQUIRE(!dz_ready || dil == 1, "conv backward: a fused activation gradient writes an undilated d-conv tensor");
-  if (dil > 1) {
-    COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward: memset failed");
-  }
-  if (!dz_ready) {
-    ActGradArgs a{y, gy, yc, op->dst_coff, op->out_f32, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
-    const long P = (long)batch * op->Ho * op->Wo;
-    const long ppb = std::max<long>(64, cdiv64(P, 512));
-    hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(P, ppb), cdiv(op->Cout, 64)), dim3(256), 0, st, a,
-                       gr->dbeta, ppb);
-  }
-  if (st_w != st) {     // the weight gradient runs on its own lane, beside the backward-data chain (dz is this conv's own)
-    hipEvent_t ev;
-    COMIC_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "conv backward: event");
-    const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(st_w, ev, 0) == hipSuccess;
-    (void)hipEventDestroy(ev);   // released once it has completed
-    COMIC_REQUIRE(ok, "conv backward: fork of the weight-gradient lane failed");
-  }
+  const int Hd = (op->Ho - 1) * dil + 1, Wd = (op->Wo - 1) * dil + 1;
   {
-    hipStream_t st_chain = st;
-    hipStream_t st = st_w;      // the launches of this scope go to the weight-gradient lane
-    (void)st_chain;
     WgradArgs a{};
     a.dz_cs = op->Cout; a.dz_co = 0; a.x_part = 0;
     a.dz = dz; a.Hd = Hd; a.Wd = Wd; a.dil = dil; a.x = x; a.x_cs = xc; a.x_co = op->src_coff; a.dw = gr->dw;
@@ -3513,7 +3490,9 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
     a.P = (long)batch * op->Ho * op->Wo;
     constexpr int BKE = 4 * EPC;
     const int tiles = cdiv(K, 64) * cdiv(op->Cout, 64);
-    long S = std::max<long>(1, std::min<long>(2048 / tiles, cdiv64(a.P, (long)BKE * 8)));
+    // (stem: K = 27 taps x 32 channels = 864 sums that EVERY workgroup adds into -- 2048 pixel slices queue up at those
+    // addresses: Conv2d_1a's weight gradient, the last launch of the backward, 178 -> ~100 us with a quarter of the slices)
+    long S = std::max<long>(1, std::min<long>((stem ? 512 : 2048) / tiles, cdiv64(a.P, (long)BKE * 8)));
     a.p_per_split = cdiv64(cdiv64(a.P, S), BKE) * BKE;
     S = cdiv64(a.P, a.p_per_split);
     dim3 grid(cdiv(K, 64), cdiv(op->Cout, 64), (unsigned)S);
@@ -3542,6 +3521,54 @@ int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, 
         hipLaunchKernelGGL((conv_wgrad_kernel<T, false>), grid, dim3(256), 0, st, a);
       }
     }
+  }
+  return 0;
+}
+
+template <typename T>
+int conv_backward(const comic_cnn_op* op, const void* x, int xc, const void* y, const void* gy, int yc, void* gx,
+                  const comic_conv_weight* wt, const comic_conv_grad* gr, int batch, void* scratch,
+                  int64_t scratch_bytes, hipStream_t st, bool filters_ready, hipStream_t st_w,
+                  bool dz_ready = false, const ConvMask* fuse = nullptr, std::vector<PendingWgrad>* defer = nullptr) {
+  // dz_ready: the backward-data launch of this conv's only reader has written dz and added d beta (its epilogue applied this
+  // conv's activation gradient); fuse: this conv's backward-data result is the gradient at the output of a conv with no
+  // other reader -- apply that conv's activation gradient in the epilogue and write its dz instead of accumulating into gx.
+  constexpr int EPC = Elem<T>::EPC;
+  const bool stem = op->kind == 1;
+  COMIC_REQUIRE(wt && wt->scale && gr && gr->w_master && gr->dw && gr->dbeta, "conv backward: missing weight / gradient record");
+  COMIC_REQUIRE(op->Cout % EPC == 0 && op->dst_coff % EPC == 0 && yc % EPC == 0, "conv backward: misaligned output slice");
+  COMIC_REQUIRE(op->SH == op->SW && (op->SH == 1 || op->SH == 2), "conv backward: stride must be 1 or 2");
+  const int K = op->KH * op->KW * op->Cin, Kpad = (K + 63) / 64 * 64;
+  const int dil = op->SH;
+  // zero-dilated d conv geometry: output pixel (ho, wo) sits at (ho*dil, wo*dil); the backward-data
+  // conv pads PT' = KH - 1 - PT rows on top and reads zeros below the buffer (bounds checks)
+  const int Hd = (op->Ho - 1) * dil + 1;
+  const int Wd = (op->Wo - 1) * dil + 1;
+  const size_t dz_bytes = ((size_t)batch * Hd * Wd * op->Cout * sizeof(T) + 255) & ~(size_t)255;
+  COMIC_REQUIRE((int64_t)dz_bytes <= scratch_bytes, "conv backward: scratch too small (%zu needed)", dz_bytes);
+  T* dz = (T*)scratch;
+  COMIC_REQUIRE(!dz_ready || dil == 1, "conv backward: a fused activation gradient writes an undilated d-conv tensor");
+  if (dil > 1) {
+    COMIC_REQUIRE(hipMemsetAsync(dz, 0, dz_bytes, st) == hipSuccess, "conv backward: memset failed");
+  }
+  if (!dz_ready) {
+    ActGradArgs a{y, gy, yc, op->dst_coff, op->out_f32, wt->scale, dz, batch, op->Ho, op->Wo, op->Cout, Hd, Wd, dil};
+    const long P = (long)batch * op->Ho * op->Wo;
+    const long ppb = std::max<long>(64, cdiv64(P, 512));
+    hipLaunchKernelGGL((act_grad_kernel<T>), dim3((unsigned)cdiv64(P, ppb), cdiv(op->Cout, 64)), dim3(256), 0, st, a,
+                       gr->dbeta, ppb);
+  }
+  if (defer) {            // the caller launches the weight gradient later (launch_wgrad), behind one fork for several convs
+    defer->push_back(PendingWgrad{op, x, xc, (const void*)dz, gr});
+  } else {
+    if (st_w != st) {     // the weight gradient runs on its own lane, beside the backward-data chain (dz is this conv's own)
+      hipEvent_t ev;
+      COMIC_REQUIRE(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "conv backward: event");
+      const bool ok = hipEventRecord(ev, st) == hipSuccess && hipStreamWaitEvent(st_w, ev, 0) == hipSuccess;
+      (void)hipEventDestroy(ev);   // released once it has completed
+      COMIC_REQUIRE(ok, "conv backward: fork of the weight-gradient lane failed");
+    }
+    if (int rc = launch_wgrad<T>(op, x, xc, dz, gr, batch, st_w)) return rc;
   }
   COMIC_LAUNCH_CHECK("conv backward (weights)");
   if (stem || (!gx && !fuse)) return 0;
@@ -3949,6 +3976,22 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
     }
   std::vector<char> seen((size_t)n_ops, 0);
   bool lane1_open = false;
+  // Weight gradients of the convs inside a fork / join region (the branches of an Inception block) are launched at the
+  // region's join, behind ONE fork of the weight-gradient lane, instead of one fork per conv between two launches of a
+  // chain lane: an event record in front of every backward-data launch kept the chain lanes idle for longer than their
+  // kernels ran (10-28 us between dependent launches of 6-25 us, profiles/r05_finetune_lanes.txt).  Every conv owns its
+  // d-conv slice of the scratch, so a later launch reads the same bytes.  Outside the regions (the stem's serial chain of
+  // large convs) a weight gradient still starts as soon as its d-conv tensor exists.
+  std::vector<PendingWgrad> pend;
+  auto flush_wgrads = [&]() -> int {
+    if (pend.empty()) return 0;
+    COMIC_REQUIRE(link_streams(s0, st_w), "cnn_backward_sched: fork of the weight-gradient lane failed");
+    for (const PendingWgrad& w : pend)
+      if (int rc = launch_wgrad<T>(w.op, w.x, w.xc, w.dz, w.gr, batch, st_w)) return rc;
+    pend.clear();
+    COMIC_LAUNCH_CHECK("cnn_backward_sched (weight gradients of a block)");
+    return 0;
+  };
   for (int k = 0; k < n_sched; ++k) {
     const int32_t* r = sched + 4 * k;
     if (r[0] == 1) {                       // FORK
@@ -3959,6 +4002,7 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
     if (r[0] == 2) {                       // JOIN_ADD
       COMIC_REQUIRE(link_streams(s1, s0), "cnn_backward_sched: join failed");
       lane1_open = false;
+      if (int rc = flush_wgrads()) return rc;
       if (r[1] >= 0) {
         const comic_cnn_op* any = nullptr;
         for (int i = 0; i < n_ops && !any; ++i)
@@ -4008,7 +4052,8 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
       }
       if (int rc = conv_backward<T>(op, buffers[op->src], xc, buffers[op->dst], gy, yc, gx, weights + op->weight,
                                     grads + op->weight, batch, dz, (int64_t)dz_bytes_of(op, batch, sizeof(T)), st,
-                                    filters_ready, st_w, /*dz_ready=*/fused_by[r[1]] >= 0, p >= 0 ? &mk : nullptr))
+                                    filters_ready, st_w, /*dz_ready=*/fused_by[r[1]] >= 0, p >= 0 ? &mk : nullptr,
+                                    lane1_open ? &pend : nullptr))
         return rc;
     } else if (op->kind <= 4) {
       if (!gx) continue;
@@ -4018,6 +4063,7 @@ int cnn_backward_sched_impl(const comic_cnn_op* ops, int n_ops, const int32_t* s
     }
   }
   COMIC_REQUIRE(!lane1_open, "cnn_backward_sched: the schedule ends inside a fork / join region");
+  if (int rc = flush_wgrads()) return rc;
   for (int i = 0; i < n_ops; ++i)
     COMIC_REQUIRE(seen[i] || ops[i].kind == 5 || ops[i].kind == 6, "cnn_backward_sched: op %d is not in the schedule", i);
   {

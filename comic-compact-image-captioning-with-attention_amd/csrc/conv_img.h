@@ -33,7 +33,9 @@ struct ComicChainConv {
   const bf16_t* wf;      // fragment-order weights
   const float* scale;
   const float* shift;
-  int KH, KW, PT, PL, KS32, Cout, relu, pad_;
+  int KH, KW, PT, PL, KS32, Cout, relu, keep_cs;
+  void* keep;            // linked convs of a trainable plan (COMIC_OP_CHAIN_KEEP): the conv's destination buffer, written as well
+  int keep_co, pad_;
 };
 struct ComicChainMember {
   const bf16_t* x;       // input of the first conv

@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256, 2) void conv_img_chain_kernel(const ComicChain
         asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v1), "s"(lo));
         asm("v_max_f32 %0, %1, %2" : "=v"(v2) : "v"(v2), "s"(lo));
         asm("v_max_f32 %0, %1, %2" : "=v"(v3) : "v"(v3), "s"(lo));
-        if (nv[i]) *(uint2*)(prow + i * 32) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        if (nv[i]) *(uint2*)(prow + i * 32) = pk;
+        // COMIC_OP_CHAIN_KEEP (trainable plans: the backward reads every conv's output): the same bits go to the conv's own
+        // destination as well -- a store that nothing of this launch waits for
+        if (c.keep && nv[i])
+          *(uint2*)((unsigned char*)c.keep + ((size_t)(img0 * HW + j * 16 + fr) * c.keep_cs + c.keep_co + (wn * TNI + i) * 16 + fg * 4) * 2) = pk;
       }
     }
     __syncthreads();                    // the next conv's input is complete

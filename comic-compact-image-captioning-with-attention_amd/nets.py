@@ -165,7 +165,11 @@ class CnnPlan:
         # third forward-only rewrite (bf16 plans; default: on with fuse_pools): the 1x7 / 7x1 convs of a Mixed_6b-e branch run as
         # ONE launch per block (tile CHAIN_TILE, csrc/conv_img.hip conv_img_chain_kernel: a workgroup per image and branch,
         # the 12x12 intermediate maps stay in the LDS).  The intermediate buffers of the plan are then never written.
-        self.fuse_chains = self.fuse_pools if fuse_chains is None else bool(fuse_chains)
+        # Plans without the forward-only rewrites (cnn_finetune) fuse the chains too and KEEP the intermediate maps
+        # (OP_CHAIN_KEEP: each linked conv also stores its output, which the backward reads): 26 launches become 5.
+        bf16_grouped = not x3 and self.group_branches and name == 'inception_v3'
+        self.fuse_chains = bf16_grouped if fuse_chains is None else bool(fuse_chains)
+        self.keep_chain_maps = not self.pool_after_projection
         if self.fuse_chains and (x3 or not self.group_branches):
             raise ValueError('fuse_chains needs a grouped bf16 plan')
         if self.fuse_pools and not (pool_after_projection and name == 'inception_v3'):
@@ -360,7 +364,7 @@ class CnnPlan:
     def _emit_chains(self, chains):
         for ch in chains:
             for o in ch[:-1]:
-                o['flags'] = o.get('flags', 0) | L.OP_CHAIN_LINK
+                o['flags'] = o.get('flags', 0) | L.OP_CHAIN_LINK | (L.OP_CHAIN_KEEP if self.keep_chain_maps else 0)
             for o in ch:
                 o['group'] = self._next_group
                 o['tile'] = L.CHAIN_TILE
@@ -792,6 +796,9 @@ class CnnEncoder:
                     setattr(ops[i], k, v)
             if self.dcode != 1:
                 ops[i].group = 0               # the fp32 parity path launches every conv on its own
+                if o.get('tile') == L.CHAIN_TILE:
+                    ops[i].tile = 0
+                    ops[i].flags &= ~(L.OP_CHAIN_LINK | L.OP_CHAIN_KEEP)
         self._ops = ops
         self._group_args = None
         self._build_group_args()

@@ -140,6 +140,8 @@ typedef struct comic_cnn_op {
                                    Every conv: stride 1, SAME, 12x12 maps, Cin in {128, 160, 192}; linked convs keep the
                                    channel count, a chain's last conv has 192 output channels.  Bit-identical to the same ops
                                    run one launch each. */
+#define COMIC_OP_CHAIN_KEEP 16   /* bit 4, with COMIC_OP_CHAIN_LINK (trainable plans, whose backward reads every conv's output):
+                                   the conv's output is ALSO stored to its dst slice, the same bits the unfused op writes. */
 
 typedef struct comic_conv_weight {
   const void* w;       /* packed [Cout][Kpad], plan dtype (stem conv: fp32 [K][Cout]) */

@@ -256,6 +256,35 @@ def test_fused_branch_chains_are_bit_identical(cnn_params, B):
     assert torch.equal(fm3, fm0) and torch.equal(im3, im0)
 
 
+def test_fused_chains_of_a_trainable_plan_keep_every_intermediate_map(cnn_params):
+    """Plans without the forward-only rewrites (cnn_finetune: the backward reads every conv's output) run the fused chain
+    launches with COMIC_OP_CHAIN_KEEP: each linked conv also stores its map.  EVERY buffer of the plan -- the 17 intermediate
+    12x12 maps among them -- bit for bit the buffer of the same plan with one launch per conv depth; an fp32 encoder over
+    the same plan runs its convs one by one (no chain launch on the exact-fp32 path)."""
+    B = 5
+    x = np.random.default_rng(77).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
+    sep = nets.CnnPlan('inception_v3', (224, 224), fuse_chains=False)
+    fus = nets.CnnPlan('inception_v3', (224, 224))
+    ch = [o for o in fus.ops if o.get('tile') == nets.L.CHAIN_TILE]
+    keep = nets.L.OP_CHAIN_LINK | nets.L.OP_CHAIN_KEEP
+    assert fus.fuse_chains and fus.keep_chain_maps and len(ch) == 26 and sum(1 for o in ch if o.get('flags', 0) == keep) == 17
+    assert fus.buffers == sep.buffers and fus.weights == sep.weights
+    e0 = nets.CnnEncoder(sep, cnn_params, B, 'bf16', DEV)
+    e1 = nets.CnnEncoder(fus, cnn_params, B, 'bf16', DEV, weights_from=e0)
+    for b in e1.bufs:
+        b.view(torch.uint8).fill_(0x5A)            # a kept map that is NOT written would keep this pattern
+    e0.forward(dev(x)); e1.forward(dev(x))
+    sync()
+    for bi, (b0, b1) in enumerate(zip(e0.bufs, e1.bufs)):
+        if bi != fus.input:
+            assert torch.equal(b0.view(torch.uint8), b1.view(torch.uint8)), 'buffer %d %s' % (bi, fus.buffers[bi])
+    e32 = nets.CnnEncoder(fus, cnn_params, 2, 'f32', DEV)
+    im32, fm32 = e32.forward(dev(x[:2]))
+    sync()
+    net_ref, ep = cnn_ref.inception_v3(cnn_params, x[:2])
+    assert_close(fm32.cpu().numpy().reshape(ep['Mixed_7c'].shape), ep['Mixed_7c'], 1e-3, 'fp32 encoder over a chain plan')
+
+
 def test_chain_launch_refuses_what_the_kernel_does_not_cover(cnn_params):
     """A COMIC_CHAIN_TILE group whose ops are not a chain (a link flag on the last op, a linked conv that does not feed the next
     op, another map size) is an error of the call, not a wrong answer."""
