@@ -2398,6 +2398,9 @@ extern "C" int comic_cnn_build_group_args(const comic_cnn_op* ops, int n_ops, vo
     }
     COMIC_REQUIRE(ops[i].tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
     const int tile = group_tile(ops + i, n, batch);
+    for (int j = 0; j < n; ++j)
+      COMIC_REQUIRE(tile == COMIC_CHAIN_TILE || !(ops[i + j].flags & COMIC_OP_CHAIN_LINK),
+                    "conv: COMIC_OP_CHAIN_LINK ops depend on each other -- their group runs on COMIC_CHAIN_TILE only (got tile %d)", tile);
     if (tile == COMIC_IMG_TILE || tile == COMIC_CHAIN_TILE) {      // conv_img.hip takes its arguments by value, too
       memset(out, 0, sizeof(ConvArgs) * n);
       out += n;
@@ -2531,6 +2534,9 @@ static int cnn_forward_impl(const comic_cnn_op* ops, int n_ops, void* const* buf
       }
       COMIC_REQUIRE(op->tile != COMIC_WS_TILE, "conv: group is not eligible for the weight-stationary 1x1 kernel");
       const int tile = group_tile(op, n, batch);
+      for (int j = 0; j < n; ++j)
+        COMIC_REQUIRE(tile == COMIC_CHAIN_TILE || !(op[j].flags & COMIC_OP_CHAIN_LINK),
+                      "conv: COMIC_OP_CHAIN_LINK ops depend on each other -- their group runs on COMIC_CHAIN_TILE only (got tile %d)", tile);
       if (tile == COMIC_CHAIN_TILE) {
         if (int rc = launch_img_chains(op, n, buffers, buf_channels, weights, batch, main_st)) return rc;
         COMIC_LAUNCH_CHECK("image-resident conv chains");

@@ -167,7 +167,8 @@ class CnnPlan:
         # the 12x12 intermediate maps stay in the LDS).  The intermediate buffers of the plan are then never written.
         # Plans without the forward-only rewrites (cnn_finetune) fuse the chains too and KEEP the intermediate maps
         # (OP_CHAIN_KEEP: each linked conv also stores its output, which the backward reads): 26 launches become 5.
-        bf16_grouped = not x3 and self.group_branches and name == 'inception_v3'
+        # (ride_pools plans keep one launch per conv depth: their pool ops ride in the depth's conv launch)
+        bf16_grouped = not x3 and self.group_branches and name == 'inception_v3' and not self.ride_pools
         self.fuse_chains = bf16_grouped if fuse_chains is None else bool(fuse_chains)
         self.keep_chain_maps = not self.pool_after_projection
         if self.fuse_chains and (x3 or not self.group_branches):

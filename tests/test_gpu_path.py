@@ -149,7 +149,7 @@ def test_walk_tiles_give_the_bits_of_the_one_tile_launch(cnn_params, B):
     shared-input group) against the same groups on tile 44: the whole forward bit for bit, with the 1x1 groups at the head
     of every Inception block on each walk form; a launch whose members do not share their input refuses the ids."""
     x = np.random.default_rng(7 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
-    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_chains=False)
     enc = nets.CnnEncoder(plan, cnn_params, B, 'bf16', DEV)
     heads = [i for i, o in enumerate(plan.ops) if o['kind'] == 0 and o.get('group', 0) and o['KH'] == 1 and o['KW'] == 1 and o['depth'] == 0
              and (i == 0 or plan.ops[i - 1].get('group', 0) != o['group'])]
@@ -184,7 +184,7 @@ def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
     every layer is partial."""
     B = 3
     x = np.random.default_rng(12).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
-    pa = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True)
+    pa = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_chains=False)
     pb = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
     assert sum(1 for o in pb.ops if o['kind'] == 2) == sum(1 for o in pa.ops if o['kind'] == 2) - 2
     # MaxPool_5a folded into the four 1x1 convs of Mixed_5b; Conv2d_1a -> 2a -> 2b -> MaxPool_3a is one streaming op (kind 9)
@@ -202,6 +202,11 @@ def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
         for i, o in enumerate(plan.ops):
             if o['kind'] == 7:
                 e._ops[i].tile = 1
+    ci = [i for i, o in enumerate(pb.ops) if o.get('tile') == nets.L.CHAIN_TILE][0]
+    eb._ops[ci].tile = 3                           # linked convs on another tile id are refused, not run side by side
+    with pytest.raises(L.ComicHipError):
+        eb._build_group_args()
+    eb._ops[ci].tile = nets.L.CHAIN_TILE
     ea._build_group_args()
     eb._build_group_args()
     ima, fma = (t.clone() for t in ea.forward(dev(x)))
