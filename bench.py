@@ -89,7 +89,7 @@ def extras(device, enc, cnn_params, plan):
     pipe.submit(imgsG)
     # as `infer.py` runs it (CaptionModel.infer_pipelined): the decode loops of THREE batches in flight on three streams (a beam
     # step is five dependent launches of 50-230 workgroups; the kernels of the other, independent batches fill the holes)
-    NL = int(os.environ.get('COMIC_INFER_IN_FLIGHT', '3'))
+    NL = max(1, min(5, int(os.environ.get('COMIC_INFER_IN_FLIGHT', '3'))))     # (as CaptionModel.infer_pipelined clamps it)
     lanes = [streams.lane(torch, device, 'infer%d' % k) for k in range(NL)]
     pend = [None] * NL
 

@@ -1578,6 +1578,9 @@ __global__ __launch_bounds__(dma_threads(WM, WN, NSTAGE)) void conv_igemm_dma_gr
     // the out-channel tiles of a pixel tile 8 workgroups apart: consecutive workgroup ids go round the 8 XCDs, so b and
     // b + 8 start together on ONE XCD and the second reads the im2col rows the first has just pulled into that L2
     // (3x3 / 2 288 -> 384 of Mixed_6a at 1280 images: 2.5 GB of reads per launch, every tap of either tile from the memory side)
+    // The pairing is between `local` and `local + 8`, i.e. hardware ids bid and bid + 8 (this branch runs without the
+    // xcd_tile_index remap: bid == blockIdx.x), which share an XCD whatever a.blk0 is -- a member need not start on a
+    // multiple of 8; only WHICH XCD a pair lands on moves with blk0.
     const int tiles_n = (a.Cout + BN - 1) / BN;
     const int full = a.tiles_m & ~7;
     if (local < full * tiles_n) {

@@ -698,7 +698,12 @@ static void cache_insert(CoefCache* c, const char* path, const comic_jpeg_info* 
   CacheEntry** slot = &c->buckets[e->hash % (uint64_t)c->n_buckets];
   const CacheEntry* dup = *slot;
   while (dup && !(dup->hash == e->hash && !strcmp(dup->path, path))) dup = dup->next;
-  const int take = !dup && c->bytes + cost <= c->max_bytes;
+  // An entry of this path with ANOTHER stamp is the decode of a file that has been rewritten since: cache_lookup refuses it
+  // from now on, so the fresh decode goes in FRONT of it (a lookup stops at the first entry of a path) instead of being
+  // dropped as a duplicate -- otherwise a file rewritten once was decoded again in every later epoch.  The stale entry stays
+  // allocated and counted: entries are never freed while the pool lives (a reader may still be copying from one).
+  const int stale = dup && (dup->file_size != e->file_size || dup->mtime_ns != e->mtime_ns);
+  const int take = (!dup || stale) && c->bytes + cost <= c->max_bytes;
   if (take) {
     e->next = *slot;
     *slot = e;

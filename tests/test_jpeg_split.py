@@ -341,6 +341,12 @@ def test_coefficient_cache_serves_the_second_pass_from_memory(tmp_path):
     assert (int(i4['width'][0]), int(i4['height'][0])) == (47, 33) and (int(i1['width'][0]), int(i1['height'][0])) == (60, 40)
     for f in ('width', 'height', 'coef_count'):
         assert np.array_equal(i1[f][1:], i4[f][1:]), f
+    # ... and the fresh decode took its place in the cache (it used to be dropped as a duplicate of the stale entry, so the file
+    # was decoded again in every later pass): the next pass is nine hits, with the rewritten image
+    assert stats(pool)[1] == 10
+    i5, s5, c5 = run(pool, paths)
+    assert (s5 == 0).all() and stats(pool)[2] == hits0 + 8 + 9 and np.array_equal(c5, c4)
+    assert (int(i5['width'][0]), int(i5['height'][0])) == (47, 33)
     lib.comic_jpeg_pool_destroy(pool)
     # a limit that holds about two images: insertion stops there
     pool = lib.comic_jpeg_pool_create(2)
