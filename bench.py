@@ -616,6 +616,7 @@ def heaviest_conv_launch(enc, plan, reps=20):
     import torch
     from comic_amd import _lib as L
     best, bi = 0, None
+    plan = enc.plan           # (the encoder's own op table: small batches run the sibling plan without fused chains)
     for i, o in enumerate(plan.ops):
         if o['kind'] == 0 and not o.get('group'):
             fl = 2 * enc.batch * o['Ho'] * o['Wo'] * o['KH'] * o['KW'] * o['Cin'] * o['Cout']

@@ -171,6 +171,16 @@ class CnnPlan:
         bf16_grouped = not x3 and self.group_branches and name == 'inception_v3' and not self.ride_pools
         self.fuse_chains = bf16_grouped if fuse_chains is None else bool(fuse_chains)
         self.keep_chain_maps = not self.pool_after_projection
+        # fuse_chains=None (default): a SIBLING plan with one launch per conv depth serves small batches.  A fused chain is one
+        # workgroup per (image, branch) whose convs run one after the other at the matrix rate of ONE CU (~12 us per conv
+        # whatever the batch): 2 B workgroups leave most of the chip idle below ~100 images, where the depth-major launches
+        # spread every conv over all CUs (forward of 32 images 0.69 ms against 0.78 fused, 64: equal, 200: 1.98 against 1.84,
+        # 1280: 9.7-9.85 against 9.47-9.55 ms).  CnnEncoder takes the sibling when its batch is below CHAIN_MIN_BATCH.
+        self.small_batch_plan = None
+        if fuse_chains is None and self.fuse_chains:
+            self.small_batch_plan = CnnPlan(name, image_size, final_endpoint, branch_streams, group_branches, layers,
+                                            pool_after_projection, ride_pools, side_pools, fuse_pools, x3, fuse_stem_1a,
+                                            fuse_chains=False)
         if self.fuse_chains and (x3 or not self.group_branches):
             raise ValueError('fuse_chains needs a grouped bf16 plan')
         if self.fuse_pools and not (pool_after_projection and name == 'inception_v3'):
@@ -332,6 +342,7 @@ class CnnPlan:
             self.ops.append(self._sync_op(6))
 
     CHAIN_CHANNELS = (128, 160, 192)          # comic_img_chain_supported (csrc/conv_img.hip)
+    CHAIN_MIN_BATCH = 96                      # images per forward from which the fused chains pay (see small_batch_plan)
 
     def _find_chains(self, block):
         """Runs of >= 2 consecutive convs of one branch, from depth 1 on, that are stride-1 SAME 7-tap convs over 12x12 maps
@@ -717,6 +728,9 @@ class CnnEncoder:
             assert getattr(plan, 'x3', False), "dtype 'bf16x3' needs a plan built with x3=True"
             dtype = 'bf16'
         assert dtype in ('bf16', 'f32') and (dtype == 'bf16' or not getattr(plan, 'x3', False))
+        small = getattr(plan, 'small_batch_plan', None)
+        if small is not None and (batch < plan.CHAIN_MIN_BATCH or dtype != 'bf16'):
+            plan = small          # same buffers, weights and end points; one launch per conv depth instead of fused chains
         self.plan, self.batch, self.dtype, self.device = plan, batch, dtype, device
         self.dcode = 1 if dtype == 'bf16' else 0
         if getattr(plan, 'fuse_pools', False) and dtype != 'bf16':

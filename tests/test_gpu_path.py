@@ -185,7 +185,7 @@ def test_inception_v3_fused_pools_weight_stationary_1x1(cnn_params):
     B = 3
     x = np.random.default_rng(12).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
     pa = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_chains=False)
-    pb = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    pb = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_chains=True)
     assert sum(1 for o in pb.ops if o['kind'] == 2) == sum(1 for o in pa.ops if o['kind'] == 2) - 2
     # MaxPool_5a folded into the four 1x1 convs of Mixed_5b; Conv2d_1a -> 2a -> 2b -> MaxPool_3a is one streaming op (kind 9)
     assert sum(1 for o in pb.ops if o.get('flags', 0) & 2) == 4 and sum(1 for o in pb.ops if o['kind'] == 9) == 1
@@ -232,7 +232,7 @@ def test_fused_branch_chains_are_bit_identical(cnn_params, B):
     arithmetic per value), eagerly and replayed from a graph; against the oracle at the bf16 tolerance."""
     x = np.random.default_rng(31 + B).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
     sep = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_chains=False)
-    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_chains=True)
     assert fus.fuse_chains and not sep.fuse_chains and len(fus.ops) == len(sep.ops)
     ch = [o for o in fus.ops if o.get('tile') == nets.L.CHAIN_TILE]
     assert len(ch) == 26 and sum(1 for o in ch if o.get('flags', 0) & nets.L.OP_CHAIN_LINK) == 17       # (Mixed_7a: 1x7 -> 7x1)
@@ -269,7 +269,7 @@ def test_fused_chains_of_a_trainable_plan_keep_every_intermediate_map(cnn_params
     B = 5
     x = np.random.default_rng(77).uniform(-1, 1, (B, 224, 224, 3)).astype(np.float32)
     sep = nets.CnnPlan('inception_v3', (224, 224), fuse_chains=False)
-    fus = nets.CnnPlan('inception_v3', (224, 224))
+    fus = nets.CnnPlan('inception_v3', (224, 224), fuse_chains=True)
     ch = [o for o in fus.ops if o.get('tile') == nets.L.CHAIN_TILE]
     keep = nets.L.OP_CHAIN_LINK | nets.L.OP_CHAIN_KEEP
     assert fus.fuse_chains and fus.keep_chain_maps and len(ch) == 26 and sum(1 for o in ch if o.get('flags', 0) == keep) == 17
@@ -294,7 +294,7 @@ def test_chain_launch_refuses_what_the_kernel_does_not_cover(cnn_params):
     """A COMIC_CHAIN_TILE group whose ops are not a chain (a link flag on the last op, a linked conv that does not feed the next
     op, another map size) is an error of the call, not a wrong answer."""
     B = 2
-    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
+    fus = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True, fuse_chains=True)
     e1 = nets.CnnEncoder(fus, cnn_params, B, 'bf16', DEV)
     ch = [i for i, o in enumerate(fus.ops) if o.get('tile') == nets.L.CHAIN_TILE]
     last = [i for i in ch if not fus.ops[i].get('flags', 0) & nets.L.OP_CHAIN_LINK][-1]

@@ -8,6 +8,7 @@ B = int(os.environ.get('B', '1280')); OP = int(os.environ.get('OP', '43')); N = 
 tiles = [int(t) for t in os.environ.get('TILES', '44,58,59').split(',')]
 plan = nets.CnnPlan('inception_v3', (224, 224), pool_after_projection=True, fuse_pools=True)
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
+plan = enc.plan            # (small batches: the sibling plan without fused chains, CnnPlan.small_batch_plan)
 x = torch.rand(B, 224, 224, 3, device='cuda:0') * 2 - 1
 enc.forward(x)
 torch.cuda.synchronize()

@@ -9,6 +9,7 @@ plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (int(os.environ.get('
                     pool_after_projection=os.environ.get('COMIC_POOL_REWRITE', '1') == '1',
                     fuse_pools=os.environ.get('FUSE', '1') == '1' and not X3, x3=X3)
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
+plan = enc.plan            # (small batches: the sibling plan without fused chains, CnnPlan.small_batch_plan)
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE'))
 IMG = int(os.environ.get('IMG', '224'))

@@ -9,6 +9,7 @@ plan = nets.CnnPlan(os.environ.get('NET', 'inception_v3'), (224, 224), group_bra
                     fuse_pools=os.environ.get('COMIC_POOL_REWRITE', '1') == '1' and os.environ.get('COMIC_FUSE_POOLS', '1') == '1',
                     x3=os.environ.get('X3', '0') == '1', fuse_stem_1a=os.environ.get('COMIC_FUSE_1A', '1') == '1')
 enc = nets.CnnEncoder(plan, plan.init_params(0), B, 'bf16', 'cuda:0')
+plan = enc.plan            # (small batches: the sibling plan without fused chains, CnnPlan.small_batch_plan)
 if os.environ.get('COMIC_AUTOTUNE', '1') == '1':
     enc.autotune(cache=os.environ.get('COMIC_TUNE_CACHE') or None)
 x = torch.rand(B, 224, 224, 3, device='cuda:0') * 2 - 1
