@@ -945,8 +945,9 @@ def main():
     top = heaviest_conv_launch(tr.encoder, plan) if rank == 0 else None
 
     if rank == 0:
-        n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1))
-        n_launch = sum(1 for o in plan.ops if o['kind'] in (0, 1) and not o.get('group')) + len({o['group'] for o in plan.ops if o.get('group')})
+        plan = tr.encoder.plan          # (the encoder's own op table)
+        n_conv = sum(1 for o in plan.ops if o['kind'] in (0, 1, 8, 9)) + sum(1 for o in plan.ops if o['kind'] == 8) + 2 * sum(1 for o in plan.ops if o['kind'] == 9)
+        n_launch = sum(1 for o in plan.ops if o['kind'] in (0, 1, 8, 9) and not o.get('group')) + len({o['group'] for o in plan.ops if o.get('group')})
         # Kernel quality is judged on the forward ALONE on the GPU (HIP events in this process, same graph /
         # launches, right after the timed loop); inside the timed region the same forward is deliberately
         # run at one workgroup per CU underneath the decoder step, so its wall time there says how well
@@ -965,7 +966,7 @@ def main():
                        'encoder_group': GROUP, 'encoder_forwards_in_timed_region': n_fwd[0],
                        'inputs': 'pinned host memory, H2D copy per group inside the timed region' if h2d else
                                  'resident in HBM, %d distinct image groups in rotation' % N_IMG_SETS},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma / conv_patch (+ _grouped) kernels <bf16> (%d convs in %d '
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_dma / conv_patch (+ _grouped) / conv_img_chain kernels <bf16> (%d convs in %d '
                                                     'launches per forward of %d images, whole InceptionV3 forward timed with HIP events)' % (n_conv, n_launch, ENC_BATCH),
                          'achieved': round(achieved / 1e12, 3), 'peak': PEAK_BF16_MFMA / 1e12, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_BF16_MFMA, 5), 'traffic': None,
@@ -996,7 +997,7 @@ def main():
             'frac': round(dec_bytes / (dec_ms * 1e-3) / 8e12, 5), 'loops_persistent': dec_path,
             'note': 'the chain is latency-bound, not bandwidth-bound: 2 x T\' dependent phases of three to four '
                     'cross-workgroup hand-offs each (DESIGN.md section 4, Persistent time loops)'}
-        for tname in ('r05_cnn_hbm_traffic.json', 'r04_cnn_hbm_traffic.json', 'r03_cnn_hbm_traffic.json'):   # committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+        for tname in ('r06_cnn_hbm_traffic.json', 'r05_cnn_hbm_traffic.json', 'r04_cnn_hbm_traffic.json'):   # committed PMC passes (FETCH_SIZE / WRITE_SIZE,
             tfile = os.path.join(ROOT, 'profiles', tname)                         # corrected per the microarch guide), newest first
             tj = (json.load(open(tfile)).get('by_images_per_forward', {}).get(str(ENC_BATCH)) if os.path.isfile(tfile) else None)
             if tj:
