@@ -83,6 +83,9 @@ def test_conv_variant_ids_match_header():
     assert int(re.search(r'#define COMIC_WS_TILE (\d+)', header).group(1)) == L.WS_TILE
     assert int(re.search(r'#define COMIC_IMG_TILE (\d+)', header).group(1)) == L.IMG_TILE
     assert int(re.search(r'#define COMIC_OP_POOLED_SRC (\d+)', header).group(1)) == L.OP_POOLED_SRC
+    assert int(re.search(r'#define COMIC_CHAIN_TILE (\d+)', header).group(1)) == L.CHAIN_TILE > L.CONV_TILES   # never an autotune candidate
+    assert int(re.search(r'#define COMIC_OP_CHAIN_LINK (\d+)', header).group(1)) == L.OP_CHAIN_LINK
+    assert int(re.search(r'#define COMIC_OP_CHAIN_KEEP (\d+)', header).group(1)) == L.OP_CHAIN_KEEP
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -715,6 +718,55 @@ def test_backward_schedule_of_the_branch_lanes():
         gap = [k for k, r in enumerate(sched) if r[0] == nets.SCHED_RUN and plan.ops[int(r[1])]['kind'] == 4]
         first_fork = min(k for k, r in enumerate(sched) if r[0] == nets.SCHED_FORK)
         assert gap and gap[0] < first_fork
+
+
+def test_fused_chain_plans_are_well_formed():
+    """CnnPlan(fuse_chains=...) (csrc/conv_img.hip conv_img_chain_kernel; inception_v3.py:262-366): the chain groups hold one or two
+    chains, chain after chain, every conv but a chain's last linked to the NEXT op of the table; every op still runs after
+    the producer of its source; frozen plans do not keep the intermediate maps, trainable plans do; the default builds the
+    depth-major sibling that encoders take for small batches; other map sizes (299 px: 17x17) and backbones have no chains."""
+    from comic_amd import nets
+    for kw, keep in ((dict(pool_after_projection=True, fuse_pools=True), 0), (dict(), L.OP_CHAIN_KEEP)):
+        plan = nets.CnnPlan('inception_v3', (224, 224), **kw)
+        sib = plan.small_batch_plan
+        assert plan.fuse_chains and sib is not None and not sib.fuse_chains and sib.small_batch_plan is None
+        assert sib.buffers == plan.buffers and sib.weights == plan.weights and sib.end_points == plan.end_points and sib.macs == plan.macs
+        assert not any(o.get('tile') == L.CHAIN_TILE or o.get('flags', 0) & L.OP_CHAIN_LINK for o in sib.ops)
+        assert sorted((o['kind'], o['src'], o['dst'], o.get('weight', -1)) for o in sib.ops) == \
+            sorted((o['kind'], o['src'], o['dst'], o.get('weight', -1)) for o in plan.ops)
+        groups = {}
+        for i, o in enumerate(plan.ops):
+            if o.get('tile') == L.CHAIN_TILE:
+                groups.setdefault(o['group'], []).append(i)
+        assert len(groups) == 5 and sorted(len(g) for g in groups.values()) == [2, 6, 6, 6, 6]
+        for g in groups.values():
+            assert g == list(range(g[0], g[0] + len(g)))                      # adjacent in the table
+            ops = [plan.ops[i] for i in g]
+            assert len({o['Cin'] for o in ops}) == 1 and ops[0]['Cin'] in nets.CnnPlan.CHAIN_CHANNELS
+            n_chains = 0
+            for a, b in zip(ops, ops[1:] + [None]):
+                link = a.get('flags', 0) & L.OP_CHAIN_LINK
+                assert (a.get('flags', 0) & L.OP_CHAIN_KEEP) == (keep if link else 0)
+                if link:
+                    assert b is not None and a['dst'] == b['src'] and a['Cout'] == a['Cin'] and a['dst_coff'] == 0
+                    assert sum(1 for q in plan.ops if q['src'] == a['dst']) == 1   # nobody else reads the map that stays in the LDS
+                else:
+                    assert a['Cout'] == 192
+                    n_chains += 1
+            assert 1 <= n_chains <= 2
+        written = {plan.input}
+        for o in plan.ops:                                                   # table order == a valid execution order
+            if o['kind'] in (5, 6):
+                continue
+            assert o['src'] in written, o
+            written.add(o['dst'])
+    assert not any(o.get('tile') == L.CHAIN_TILE for o in nets.CnnPlan('inception_v3', (299, 299), pool_after_projection=True, fuse_pools=True).ops)
+    assert nets.CnnPlan('inception_v3', (224, 224), x3=True).small_batch_plan is None
+    assert not nets.CnnPlan('inception_v3', (224, 224), x3=True).fuse_chains and not nets.CnnPlan('inception_v1', (224, 224)).fuse_chains
+    forced = nets.CnnPlan('inception_v3', (224, 224), fuse_chains=True)
+    assert forced.fuse_chains and forced.small_batch_plan is None
+    with pytest.raises(ValueError):
+        nets.CnnPlan('inception_v3', (224, 224), x3=True, fuse_chains=True)
 
 
 def test_gradient_clip_chunk_table():
